@@ -1,0 +1,482 @@
+"""Generate the golden fixtures under tests/golden/ by importing the REAL reference.
+
+Runs only in the build container (needs /root/reference); the fixtures it writes are plain
+data (inputs + the reference's outputs) and are committed.  Nothing here travels as code the
+tests execute: tests read the .npz files only.
+
+    python tests/golden/make_golden.py            # regenerate everything
+
+Shims: torchvision is not installed -> stub modules whose `ops.RoIAlign` is the
+oracle's published-algorithm restatement (parity for RoIAlign is therefore pinned by KATs, not by
+this script) and whose `models.resnet18/34` are structurally identical random-init ResNets; HF
+weights cannot be downloaded -> a local `bert-base-uncased/` directory with a small BertConfig
+(hidden 768, 2 layers) and a dummy vocab.  Weights everywhere are the deterministic
+`oracle.vbg_oracle.synth_state_dict` values derived from the state_dict key names, so the
+tests can rebuild them without storing 100 MB of parameters.
+"""
+import json
+import os
+import random
+import sys
+import tempfile
+import types
+
+import numpy as np
+import torch
+
+HERE = os.path.dirname(os.path.abspath(__file__))
+ROOT = os.path.dirname(os.path.dirname(HERE))
+sys.path.insert(0, os.path.join(ROOT, "oracle"))
+import vbg_oracle as O  # noqa: E402
+
+import transformers  # noqa: E402  (import BEFORE stubbing torchvision: its availability probe must see it absent)
+from transformers import BertConfig, BertModel, BertTokenizer  # noqa: E402
+
+REF = "/root/reference"
+
+
+# ---------------------------------------------------------------------------------------------
+# shims
+# ---------------------------------------------------------------------------------------------
+def install_torchvision_stub():
+    import importlib.machinery
+    import torch.nn as nn
+
+    def mod(name):
+        m = types.ModuleType(name)
+        m.__spec__ = importlib.machinery.ModuleSpec(name, None)
+        sys.modules[name] = m
+        return m
+
+    tv = mod("torchvision")
+    ops = mod("torchvision.ops")
+    models = mod("torchvision.models")
+    tfm = mod("torchvision.transforms")
+    tv.ops, tv.models, tv.transforms = ops, models, tfm
+
+    class RoIAlign(nn.Module):
+        def __init__(self, output_size, spatial_scale, sampling_ratio, aligned=False):
+            super().__init__()
+            assert sampling_ratio <= 0 and not aligned
+            self.output_size, self.spatial_scale = output_size, spatial_scale
+
+        def forward(self, x, boxes):
+            return O.roi_align(x, boxes, self.output_size, self.spatial_scale)
+
+    ops.RoIAlign = RoIAlign
+
+    class _Block(nn.Module):
+        def __init__(self, cin, cout, stride):
+            super().__init__()
+            self.conv1 = nn.Conv2d(cin, cout, 3, stride, 1, bias=False)
+            self.bn1 = nn.BatchNorm2d(cout)
+            self.relu = nn.ReLU(inplace=True)
+            self.conv2 = nn.Conv2d(cout, cout, 3, 1, 1, bias=False)
+            self.bn2 = nn.BatchNorm2d(cout)
+            self.downsample = None
+            if stride != 1 or cin != cout:
+                self.downsample = nn.Sequential(nn.Conv2d(cin, cout, 1, stride, bias=False), nn.BatchNorm2d(cout))
+
+        def forward(self, x):
+            idt = x if self.downsample is None else self.downsample(x)
+            out = self.relu(self.bn1(self.conv1(x)))
+            out = self.bn2(self.conv2(out))
+            return self.relu(out + idt)
+
+    class _ResNet(nn.Module):
+        def __init__(self, sizes):
+            super().__init__()
+            self.conv1 = nn.Conv2d(3, 64, 7, 2, 3, bias=False)
+            self.bn1 = nn.BatchNorm2d(64)
+            self.relu = nn.ReLU(inplace=True)
+            self.maxpool = nn.MaxPool2d(3, 2, 1)
+            cin = 64
+            for li, (c, n) in enumerate(zip((64, 128, 256, 512), sizes), 1):
+                blocks = []
+                for i in range(n):
+                    blocks.append(_Block(cin, c, 2 if (i == 0 and li > 1) else 1))
+                    cin = c
+                setattr(self, f"layer{li}", nn.Sequential(*blocks))
+            self.avgpool = nn.AdaptiveAvgPool2d((1, 1))
+            self.fc = nn.Linear(512, 1000)
+
+    models.resnet18 = lambda pretrained=False, **k: _ResNet([2, 2, 2, 2])
+    models.resnet34 = lambda pretrained=False, **k: _ResNet([3, 4, 6, 3])
+
+
+def make_bert_dir(top, name, layers, vocab):
+    d = os.path.join(top, name)
+    os.makedirs(d, exist_ok=True)
+    cfg = BertConfig(vocab_size=vocab, num_hidden_layers=layers, hidden_dropout_prob=0.0,
+                     attention_probs_dropout_prob=0.0)
+    cfg.save_pretrained(d)
+    toks = ["[PAD]"] + [f"[unused{i}]" for i in range(1, 100)] + ["[UNK]", "[CLS]", "[SEP]", "[MASK]"]
+    toks += [f"tok{i}" for i in range(len(toks), vocab)]
+    with open(os.path.join(d, "vocab.txt"), "w") as f:
+        f.write("\n".join(toks) + "\n")
+    return d
+
+
+def shapes_of(module):
+    return {k: tuple(v.shape) for k, v in module.state_dict().items()}
+
+
+def load_synth(module):
+    sd = O.synth_state_dict(shapes_of(module))
+    missing, unexpected = module.load_state_dict(sd, strict=False)
+    assert not unexpected, unexpected
+    for k in missing:
+        assert k.endswith("num_batches_tracked") or k.endswith("position_ids") or k.endswith("token_type_ids"), k
+    return sd
+
+
+def npz(name, **arrs):
+    out = {}
+    for k, v in arrs.items():
+        if isinstance(v, torch.Tensor):
+            v = v.detach().cpu().numpy()
+        out[k] = np.asarray(v)
+    np.savez_compressed(os.path.join(HERE, name), **out)
+    print("wrote", name, {k: v.shape for k, v in out.items()})
+
+
+# ---------------------------------------------------------------------------------------------
+def gen_transform(T):
+    tr = T.GeneralizedViBERTgridTransform([0.9248, 0.9224, 0.9215], [0.1532, 0.1545, 0.1536], [48, 64], 56, 80)
+    g = torch.Generator().manual_seed(1)
+    imgs = (torch.rand(3, 61, 47, generator=g), torch.rand(3, 50, 90, generator=g), torch.rand(3, 64, 64, generator=g))
+    coors = (torch.tensor([[3, 5, 40, 20], [0, 0, 47, 61], [10, 30, 11, 31], [46, 60, 47, 61]]),
+             torch.tensor([[1, 2, 88, 49], [30, 10, 60, 40]]),
+             torch.tensor([[0, 0, 64, 64], [7, 9, 23, 33], [63, 1, 64, 2]]))
+    out = {}
+    for i in range(3):
+        out[f"img{i}"] = imgs[i]
+        out[f"coor{i}"] = coors[i]
+    # eval mode: test_min_size 56
+    tr.eval()
+    il, oc = tr(imgs, coors)
+    out["eval_batch"] = il.tensors
+    out["eval_sizes"] = np.array(il.image_sizes)
+    for i in range(3):
+        out[f"eval_coor{i}"] = oc[i]
+    # train mode with a pinned torch RNG; record which sizes got drawn via the output sizes
+    tr.train()
+    torch.manual_seed(123)
+    il, oc = tr(imgs, coors)
+    out["train_batch"] = il.tensors
+    out["train_sizes"] = np.array(il.image_sizes)
+    for i in range(3):
+        out[f"train_coor{i}"] = oc[i]
+    # identity case
+    tr2 = T.GeneralizedViBERTgridTransform([0.9248, 0.9224, 0.9215], [0.1532, 0.1545, 0.1536], [64], 64, 64)
+    tr2.eval()
+    il, oc = tr2((imgs[2],), (coors[2],))
+    out["ident_batch"] = il.tensors
+    out["ident_coor"] = oc[0]
+    npz("transform.npz", **out)
+
+
+def gen_windows(G):
+    class Fake(torch.nn.Module):
+        def __init__(self):
+            super().__init__()
+            self.calls = []
+
+        def forward(self, input_ids=None, attention_mask=None):
+            self.calls.append((input_ids.clone(), attention_mask.clone()))
+            h = torch.stack([input_ids.float(), attention_mask.float(),
+                             torch.arange(input_ids.shape[1]).float()[None].expand_as(input_ids)], -1)
+            return types.SimpleNamespace(last_hidden_state=h)
+
+    out = {}
+    for T_ in (5, 509, 510, 511, 512, 1020, 1021):
+        fake = Fake()
+        gen = G.BERTgridGenerator(bert_model=fake, grid_mode="mean", stride=8)
+        g = torch.Generator().manual_seed(T_)
+        lens = [T_, max(1, T_ - 3)]
+        corpus = torch.zeros((2, T_), dtype=torch.long)
+        for b, L in enumerate(lens):
+            corpus[b, :L] = torch.randint(1000, 30000, (L,), generator=g)
+        mask = (corpus != 0).int()
+        segs = tuple(torch.arange(L, dtype=torch.int32) // 2 for L in lens)
+        embs = gen.BERT_embedding(corpus, mask, segs)
+        out[f"T{T_}_corpus"] = corpus
+        out[f"T{T_}_nwin"] = len(fake.calls)
+        for w, (ids, am) in enumerate(fake.calls):
+            out[f"T{T_}_ids{w}"] = ids
+            out[f"T{T_}_am{w}"] = am
+        for b in range(2):
+            out[f"T{T_}_emb{b}"] = embs[b]
+    npz("windows.npz", **out)
+
+
+def gen_aggregate(G):
+    out = {}
+    g = torch.Generator().manual_seed(5)
+    for mode in ("mean", "first"):
+        class Fake(torch.nn.Module):
+            def forward(self, input_ids=None, attention_mask=None):
+                gg = torch.Generator().manual_seed(int(input_ids.sum()) % 100000)
+                return types.SimpleNamespace(last_hidden_state=torch.randn(*input_ids.shape, 16, generator=gg))
+        gen = G.BERTgridGenerator(bert_model=Fake(), grid_mode=mode, stride=8)
+        corpus = torch.zeros((2, 11), dtype=torch.long)
+        corpus[0, :11] = torch.randint(1000, 2000, (11,), generator=g)
+        corpus[1, :7] = torch.randint(1000, 2000, (7,), generator=g)
+        mask = (corpus != 0).int()
+        segs = (torch.tensor([0, 0, 0, 1, 2, 2, 5, 5, 5, 5, 6], dtype=torch.int32),
+                torch.tensor([3, 3, 4, 4, 4, 4, 9], dtype=torch.int32))
+        # capture token embeddings through the same fake
+        wins = O.bert_windows(corpus, mask)
+        tok = torch.cat([Fake()(ids, am).last_hidden_state[:, 1:1 + cur] for ids, am, cur in wins], 1)
+        embs = gen.BERT_embedding(corpus, mask, segs)
+        out[f"{mode}_tok"] = tok
+        out[f"{mode}_mask"] = mask
+        for b in range(2):
+            out[f"{mode}_seg{b}"] = segs[b]
+            out[f"{mode}_out{b}"] = embs[b]
+    npz("aggregate.npz", **out)
+
+
+def gen_scatter(G):
+    gen = G.BERTgridGenerator(bert_model=torch.nn.Identity(), grid_mode="mean", stride=8)
+    g = torch.Generator().manual_seed(9)
+    H, W = 64, 96
+    boxes = (torch.tensor([[0, 0, 40, 24], [16, 8, 64, 40], [17, 9, 23, 15], [90, 50, 200, 100], [30, 30, 10, 10],
+                           [-20, -9, 20, 9], [8, 56, 96, 64], [40, 16, 48, 24]], dtype=torch.int32),
+             torch.tensor([[0, 0, 96, 64], [8, 8, 88, 56], [16, 16, 80, 48]], dtype=torch.int32),
+             torch.zeros((0, 4), dtype=torch.int32))
+    embs = tuple(torch.randn(b.shape[0], 6, generator=g, requires_grad=True) for b in boxes)
+    grid = gen.BERTgrid_embedding((H, W), embs, boxes)
+    gout = torch.randn(grid.shape, generator=g)
+    grid.backward(gout)
+    out = dict(H=H, W=W, grid=grid, gout=gout)
+    for b in range(3):
+        out[f"box{b}"] = boxes[b]
+        out[f"emb{b}"] = embs[b]
+        out[f"gemb{b}"] = embs[b].grad if embs[b].grad is not None else torch.zeros_like(embs[b])
+    npz("scatter.npz", **out)
+
+
+def gen_losses(L):
+    out = {}
+    g = torch.Generator().manual_seed(11)
+    # random-sample CE on [B,3,H,W]
+    x = torch.randn(2, 3, 24, 24, generator=g, requires_grad=True)
+    t = torch.randint(0, 3, (2, 24, 24), generator=g)
+    t[0, :12] = 0
+    random.seed(77)
+    l = L.CrossEntropyLossRandomSample(sample_list=[256, 512, 256])(x, t)
+    l.backward()
+    out.update(rs_x=x, rs_t=t, rs_loss=l, rs_grad=x.grad)
+    # OHEM CE without random, 5 classes, no ties
+    x2 = torch.randn(400, 5, generator=g, requires_grad=True)
+    t2 = (torch.rand(400, generator=g) > 0.7).long() * torch.randint(1, 5, (400,), generator=g)
+    l2 = L.CrossEntropyLossOHEM(num_hard_positive=32, num_hard_negative=32)(x2, t2)
+    l2.backward()
+    out.update(oh_x=x2, oh_t=t2, oh_loss=l2, oh_grad=x2.grad)
+    # OHEM with random pre-sampling and class weights
+    x3 = torch.randn(300, 5, generator=g, requires_grad=True)
+    t3 = (torch.rand(300, generator=g) > 0.5).long() * torch.randint(1, 5, (300,), generator=g)
+    w = torch.tensor([0.5, 1.0, 2.0, 1.5, 1.0])
+    random.seed(5)
+    l3 = L.CrossEntropyLossOHEM(num_hard_positive=16, num_hard_negative=16, weight=w, random=True)(x3, t3)
+    l3.backward()
+    out.update(ohr_x=x3, ohr_t=t3, ohr_w=w, ohr_loss=l3, ohr_grad=x3.grad)
+    # OHEM with ties (replicated logits like the x4 nearest-upsampled seg head)
+    base = torch.randn(1, 5, 6, 6, generator=g)
+    x4 = torch.nn.functional.interpolate(base, scale_factor=4, mode="nearest").clone().requires_grad_(True)
+    t4 = torch.zeros(1, 24, 24, dtype=torch.long)
+    t4[0, 3:14, 2:17] = 2
+    t4[0, 10:20, 12:22] = 4
+    l4 = L.CrossEntropyLossOHEM(num_hard_positive=40, num_hard_negative=40)(x4, t4)
+    l4.backward()
+    out.update(tie_x=x4, tie_t=t4, tie_loss=l4, tie_grad=x4.grad)
+    # fewer elements than k
+    x5 = torch.randn(10, 2, generator=g, requires_grad=True)
+    t5 = torch.tensor([0, 1, 0, 0, 1, 0, 0, 0, 0, 0])
+    random.seed(1)
+    l5 = L.CrossEntropyLossOHEM(num_hard_positive=16, num_hard_negative=16, random=True)(x5, t5)
+    l5.backward()
+    out.update(few_x=x5, few_t=t5, few_loss=l5, few_grad=x5.grad)
+    npz("losses.npz", **out)
+
+
+def gen_labels(S):
+    head = S.SimplifiedSemanticSegmentationClassifier(p_fuse_channel=8, num_classes=5,
+                                                      loss_1_sample_list=[4, 4, 4], num_hard_positive=4,
+                                                      num_hard_negative=4)
+    rec = {}
+
+    class Grab(torch.nn.Module):
+        def __init__(self, name):
+            super().__init__()
+            self.name = name
+
+        def forward(self, x, t):
+            rec[self.name] = t.clone()
+            return torch.zeros(())
+
+    head.aux_loss_1 = Grab("pos_neg")
+    head.aux_loss_2 = Grab("cls")
+    coors = (torch.tensor([[0, 0, 20, 10], [5, 5, 30, 25], [6, 6, 8, 8], [60, 30, 90, 40], [10, 20, 10, 40]], dtype=torch.int32),
+             torch.tensor([[2, 2, 62, 30], [30, 0, 64, 32]], dtype=torch.int32))
+    classes = (torch.tensor([1, 0, 3, 2, 4], dtype=torch.int32), torch.tensor([0, 4], dtype=torch.int32))
+    head.eval()
+    head(torch.zeros(2, 8, 8, 16), classes, coors)
+    out = dict(pos_neg=rec["pos_neg"], cls=rec["cls"])
+    for b in range(2):
+        out[f"coor{b}"] = coors[b]
+        out[f"class{b}"] = classes[b]
+    npz("labels.npz", **out)
+
+
+def gen_bert(tmp):
+    cfg = BertConfig(vocab_size=1200, num_hidden_layers=2, hidden_dropout_prob=0.0, attention_probs_dropout_prob=0.0)
+    m = BertModel(cfg)
+    load_synth(m)
+    m.eval()
+    g = torch.Generator().manual_seed(3)
+    ids = torch.randint(104, 1200, (2, 24), generator=g)
+    am = torch.ones(2, 24, dtype=torch.long)
+    ids[1, 15:] = 0
+    am[1, 15:] = 0
+    ids[1, 20] = 102
+    am[1, 20] = 1
+    with torch.no_grad():
+        h = m(input_ids=ids, attention_mask=am).last_hidden_state
+    npz("bert.npz", ids=ids, am=am, hidden=h, layers=2, vocab=1200)
+
+
+def gen_backbone(R):
+    out = {}
+    g = torch.Generator().manual_seed(21)
+    x = torch.randn(2, 3, 64, 96, generator=g)
+    grid = torch.randn(2, 768, 8, 12, generator=g) * (torch.rand(2, 1, 8, 12, generator=g) > 0.5)
+    out.update(x=x, grid=grid)
+    for kind, fn, kw in (("resnet_18_fpn", R.resnet_18_fpn, {}), ("resnet_34_fpn_pretrained", R.resnet_34_fpn, dict(pretrained=True))):
+        net = fn(grid_channel=768, **kw)
+        load_synth(net)
+        net.eval()
+        with torch.no_grad():
+            out[kind + "_eval"] = net(x, grid)
+        net.train()
+        with torch.no_grad():
+            out[kind + "_train"] = net(x, grid)
+        # running stats after one train step of a representative BN
+        key = "conv_1.1.running_mean" if kind == "resnet_18_fpn" else "resnet.bn1.running_mean"
+        out[kind + "_rm"] = net.state_dict()[key]
+        out[kind + "_rv"] = net.state_dict()[key.replace("mean", "var")]
+    npz("backbone.npz", **out)
+
+
+def gen_e2e(V, tmp):
+    out = {}
+    tokenizer = BertTokenizer(os.path.join(tmp, "bert-base-uncased", "vocab.txt"))
+    for tag, backbone in (("r18", "resnet_18_fpn"), ("r34p", "resnet_34_fpn_pretrained")):
+        net = V.ViBERTgridNet(num_classes=5, image_mean=[0.9248, 0.9224, 0.9215], image_std=[0.1532, 0.1545, 0.1536],
+                              image_min_size=[96], image_max_size=128, test_image_min_size=96,
+                              bert_model="bert-base-uncased", tokenizer=tokenizer, backbone=backbone, grid_mode="mean",
+                              loss_weights=None, num_hard_positive_main_1=4, num_hard_negative_main_1=4,
+                              num_hard_positive_main_2=6, num_hard_negative_main_2=6,
+                              loss_aux_sample_list=[64, 128, 64], num_hard_positive_aux=64, num_hard_negative_aux=64,
+                              loss_control_lambda=1, add_pos_neg=True, classifier_mode="simp", ohem_random=True,
+                              layer_mode="single", work_mode="eval")
+        sd = load_synth(net)
+        B, T_, S = 2, 24, 8
+        g = torch.Generator().manual_seed(1234)
+        imgs = tuple(torch.rand(3, 96, 128, generator=g) for _ in range(B))
+        coors = []
+        for b in range(B):
+            x1 = torch.randint(0, 128 - 41, (S,), generator=g)
+            y1 = torch.randint(0, 96 - 25, (S,), generator=g)
+            w = torch.randint(8, 41, (S,), generator=g)
+            h = torch.randint(8, 25, (S,), generator=g)
+            coors.append(torch.stack([x1, y1, x1 + w, y1 + h], 1).long())
+        coors = tuple(coors)
+        segs = tuple(torch.arange(S, dtype=torch.int32).repeat_interleave(T_ // S) for _ in range(B))
+        classes = tuple(torch.randint(0, 5, (S,), generator=g).int() for _ in range(B))
+        corpus = torch.randint(1000, 1200, (B, T_), generator=g)
+        mask = torch.ones(B, T_, dtype=torch.int32)
+        # second doc shorter: 21 tokens, 7 segments
+        corpus[1, 21:] = 0
+        mask[1, 21:] = 0
+        segs = (segs[0], segs[1][:21])
+        coors = (coors[0], coors[1][:7])
+        classes = (classes[0], classes[1][:7])
+
+        net.eval()
+        random.seed(7)
+        with torch.no_grad():
+            loss, pm, ps, gt, pred = net(imgs, segs, classes, coors, corpus, mask)
+        out.update({f"{tag}_eval_loss": loss, f"{tag}_pred_mask": pm[:, :, ::4, ::4], f"{tag}_pred_ss": ps[:, :, ::4, ::4],
+                    f"{tag}_gt": gt, f"{tag}_pred": pred})
+        net.train()      # flips work_mode to "train" (model/ViBERTgrid_net.py:462-464)
+        random.seed(7)
+        loss = net(imgs, segs, classes, coors, corpus, mask)
+        loss.backward()
+        out[f"{tag}_train_loss"] = loss
+        gn = {}
+        for k, p in net.named_parameters():
+            if k.startswith("BERTgrid_generator."):
+                continue
+            gn[k] = 0.0 if p.grad is None else float(p.grad.double().norm())
+        out[f"{tag}_gradnorm_keys"] = np.array(sorted(gn.keys()))
+        out[f"{tag}_gradnorm_vals"] = np.array([gn[k] for k in sorted(gn.keys())])
+        pick = ["bert_model.encoder.layer.0.attention.self.query.weight", "late_fusion_net.fuse_embedding_net.linear.weight",
+                "field_type_classification_head.category_classification_net.linear_2.weight",
+                "bert_model.embeddings.word_embeddings.weight"]
+        named = dict(net.named_parameters())
+        for k in pick:
+            out[f"{tag}_grad::{k}"] = named[k].grad.flatten()[:: max(1, named[k].numel() // 4096)][:4096]
+        if tag == "r18":
+            for b in range(B):
+                out[f"img{b}"] = imgs[b]
+                out[f"coor{b}"] = coors[b]
+                out[f"seg{b}"] = segs[b]
+                out[f"class{b}"] = classes[b]
+            out["corpus"] = corpus
+            out["mask"] = mask
+            shapes = shapes_of(net)
+            out["r18_keys"] = np.array(list(shapes.keys()))
+        else:
+            out["r34p_keys"] = np.array(list(shapes_of(net).keys()))
+    npz("e2e.npz", **out)
+
+
+def main():
+    torch.set_num_threads(8)
+    install_torchvision_stub()
+    sys.path.insert(0, REF)
+    tmp = tempfile.mkdtemp(prefix="vbg_golden_")
+    make_bert_dir(tmp, "bert-base-uncased", layers=2, vocab=1200)
+    os.chdir(tmp)
+    import model.BERTgrid_generator as G
+    import model.ResNetFPN_ViBERTgrid as R
+    import model.semantic_segmentation_head as S
+    import model.ViBERTgrid_net as V
+    import pipeline.custom_loss as L
+    import pipeline.transform as T
+
+    which = sys.argv[1:] or ["transform", "windows", "aggregate", "scatter", "losses", "labels", "bert", "backbone", "e2e"]
+    if "transform" in which:
+        gen_transform(T)
+    if "windows" in which:
+        gen_windows(G)
+    if "aggregate" in which:
+        gen_aggregate(G)
+    if "scatter" in which:
+        gen_scatter(G)
+    if "losses" in which:
+        gen_losses(L)
+    if "labels" in which:
+        gen_labels(S)
+    if "bert" in which:
+        gen_bert(tmp)
+    if "backbone" in which:
+        gen_backbone(R)
+    if "e2e" in which:
+        gen_e2e(V, tmp)
+
+
+if __name__ == "__main__":
+    main()

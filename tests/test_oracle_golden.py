@@ -1,0 +1,209 @@
+"""Pin the CPU oracle (oracle/vbg_oracle.py) against vectors produced by the real reference
+(tests/golden/make_golden.py).  CPU only."""
+import random
+
+import numpy as np
+import pytest
+import torch
+
+import vbg_oracle as O
+
+T = torch.from_numpy
+
+
+def test_transform(golden):
+    g = golden("transform.npz")
+    imgs = [T(g[f"img{i}"]) for i in range(3)]
+    coors = [T(g[f"coor{i}"]) for i in range(3)]
+    cfg = O.NetCfg(image_min_size=(48, 64), image_max_size=80, test_image_min_size=56)
+    batch, oc, sizes = O.transform(imgs, coors, cfg, training=False)
+    assert np.array_equal(np.array(sizes), g["eval_sizes"])
+    assert torch.allclose(batch, T(g["eval_batch"]), rtol=1e-5, atol=1e-6)
+    for i in range(3):
+        assert np.array_equal(oc[i].numpy(), g[f"eval_coor{i}"]), i
+    # train mode draws the min side with torch's global CPU RNG exactly like the reference
+    torch.manual_seed(123)
+    batch, oc, sizes = O.transform(imgs, coors, cfg, training=True)
+    assert np.array_equal(np.array(sizes), g["train_sizes"])
+    assert torch.allclose(batch, T(g["train_batch"]), rtol=1e-5, atol=1e-6)
+    for i in range(3):
+        assert np.array_equal(oc[i].numpy(), g[f"train_coor{i}"]), i
+    cfg2 = O.NetCfg(image_min_size=(64,), image_max_size=64, test_image_min_size=64)
+    batch, oc, _ = O.transform(imgs[2:], coors[2:], cfg2, training=False)
+    assert torch.allclose(batch, T(g["ident_batch"]), rtol=1e-6, atol=1e-6)
+    assert np.array_equal(oc[0].numpy(), g["ident_coor"])
+
+
+@pytest.mark.parametrize("Tn", [5, 509, 510, 511, 512, 1020, 1021])
+def test_windows(golden, Tn):
+    g = golden("windows.npz")
+    corpus = T(g[f"T{Tn}_corpus"])
+    mask = (corpus != 0).int()
+    wins = O.bert_windows(corpus, mask)
+    assert len(wins) == int(g[f"T{Tn}_nwin"]) == Tn // 510 + 1
+    for w, (ids, am, cur) in enumerate(wins):
+        assert np.array_equal(ids.numpy(), g[f"T{Tn}_ids{w}"])
+        assert np.array_equal(am.numpy(), g[f"T{Tn}_am{w}"])
+    # kept slices + mean aggregation over pairs of tokens, through the same fake encoder
+    tok = torch.cat([torch.stack([ids.float(), am.float(), torch.arange(ids.shape[1]).float()[None].expand_as(ids)], -1)[:, 1:1 + cur]
+                     for ids, am, cur in wins], 1)
+    lens = [Tn, max(1, Tn - 3)]
+    for b in range(2):
+        seg = torch.arange(lens[b], dtype=torch.int32) // 2
+        out = O.seg_aggregate(tok[b], mask[b], seg, "mean")
+        assert np.array_equal(out.numpy(), g[f"T{Tn}_emb{b}"])
+
+
+@pytest.mark.parametrize("mode", ["mean", "first"])
+def test_aggregate(golden, mode):
+    g = golden("aggregate.npz")
+    tok, mask = T(g[f"{mode}_tok"]), T(g[f"{mode}_mask"])
+    for b in range(2):
+        out = O.seg_aggregate(tok[b], mask[b], T(g[f"{mode}_seg{b}"]), mode)
+        assert np.array_equal(out.numpy(), g[f"{mode}_out{b}"])      # bit exact, order-sensitive sum
+
+
+def test_scatter(golden):
+    g = golden("scatter.npz")
+    H, W = int(g["H"]), int(g["W"])
+    embs = [T(g[f"emb{b}"]).clone().requires_grad_(True) for b in range(3)]
+    boxes = [T(g[f"box{b}"]) for b in range(3)]
+    grid = O.grid_scatter(embs, boxes, H, W, 8)
+    assert np.array_equal(grid.detach().numpy(), g["grid"])          # bit exact
+    grid.backward(T(g["gout"]))
+    for b in range(3):
+        ge = embs[b].grad if embs[b].grad is not None else torch.zeros_like(embs[b])
+        assert torch.allclose(ge, T(g[f"gemb{b}"]), rtol=1e-5, atol=1e-6)
+
+
+def test_labels(golden):
+    g = golden("labels.npz")
+    coors = [T(g[f"coor{b}"]) for b in range(2)]
+    classes = [T(g[f"class{b}"]) for b in range(2)]
+    pn, cls = O.label_raster(classes, coors, 32, 64)
+    assert np.array_equal(pn.numpy(), g["pos_neg"])
+    assert np.array_equal(cls.numpy(), g["cls"])
+
+
+def test_losses(golden):
+    g = golden("losses.npz")
+    x = T(g["rs_x"]).clone().requires_grad_(True)
+    random.seed(77)
+    l = O.ce_random_sample(x, T(g["rs_t"]), [256, 512, 256])
+    assert l.dtype == torch.float64 and l.shape == (1,)
+    assert torch.allclose(l, T(g["rs_loss"]), rtol=1e-6)
+    l.backward()
+    assert torch.allclose(x.grad, T(g["rs_grad"]), rtol=1e-5, atol=1e-8)
+
+    x = T(g["oh_x"]).clone().requires_grad_(True)
+    l = O.ce_ohem(x, T(g["oh_t"]), 32, 32)
+    assert torch.allclose(l, T(g["oh_loss"]), rtol=1e-6)
+    l.backward()
+    assert torch.allclose(x.grad, T(g["oh_grad"]), rtol=1e-5, atol=1e-8)
+
+    x = T(g["ohr_x"]).clone().requires_grad_(True)
+    random.seed(5)
+    l = O.ce_ohem(x, T(g["ohr_t"]), 16, 16, T(g["ohr_w"]), rand=True)
+    assert torch.allclose(l, T(g["ohr_loss"]), rtol=1e-6)
+    l.backward()
+    assert torch.allclose(x.grad, T(g["ohr_grad"]), rtol=1e-5, atol=1e-8)
+
+    # heavy ties (replicated logits): the reference's CPU sort order must be reproduced
+    x = T(g["tie_x"]).clone().requires_grad_(True)
+    l = O.ce_ohem(x, T(g["tie_t"]), 40, 40)
+    assert torch.allclose(l, T(g["tie_loss"]), rtol=1e-6)
+    l.backward()
+    assert torch.allclose(x.grad, T(g["tie_grad"]), rtol=1e-5, atol=1e-8)
+
+    x = T(g["few_x"]).clone().requires_grad_(True)
+    random.seed(1)
+    l = O.ce_ohem(x, T(g["few_t"]), 16, 16, rand=True)
+    assert torch.allclose(l, T(g["few_loss"]), rtol=1e-6)
+    l.backward()
+    assert torch.allclose(x.grad, T(g["few_grad"]), rtol=1e-5, atol=1e-8)
+
+
+def test_bert(golden):
+    g = golden("bert.npz")
+    bc = O.BertCfg(layers=int(g["layers"]), dropout=0.0)
+    sd = O.synth_state_dict(O.bert_shapes("", bc, int(g["vocab"])))
+    h = O.bert_forward(sd, "", T(g["ids"]), T(g["am"]), bc)
+    ref = T(g["hidden"])
+    am = T(g["am"]).bool()
+    # only mask==1 positions are ever consumed downstream
+    assert torch.allclose(h[am], ref[am], rtol=1e-4, atol=2e-5)
+
+
+@pytest.mark.parametrize("kind", ["resnet_18_fpn", "resnet_34_fpn_pretrained"])
+def test_backbone(golden, kind):
+    g = golden("backbone.npz")
+    sd = O.synth_state_dict(O.backbone_shapes(kind, 768, prefix=""))
+    x, grid = T(g["x"]), T(g["grid"])
+    with torch.no_grad():
+        ev = O.backbone_forward(sd, x, grid, kind, False, prefix="")
+        assert torch.allclose(ev, T(g[kind + "_eval"]), rtol=1e-4, atol=1e-4)
+        tr = O.backbone_forward(sd, x, grid, kind, True, prefix="")
+        assert torch.allclose(tr, T(g[kind + "_train"]), rtol=1e-3, atol=1e-3)
+    key = "conv_1.1" if kind == "resnet_18_fpn" else "resnet.bn1"
+    assert torch.allclose(sd[key + ".running_mean"], T(g[kind + "_rm"]), rtol=1e-5, atol=1e-6)
+    assert torch.allclose(sd[key + ".running_var"], T(g[kind + "_rv"]), rtol=1e-5, atol=1e-6)
+
+
+def _e2e_inputs(g):
+    imgs = [T(g[f"img{b}"]) for b in range(2)]
+    coors = [T(g[f"coor{b}"]) for b in range(2)]
+    segs = [T(g[f"seg{b}"]) for b in range(2)]
+    classes = [T(g[f"class{b}"]) for b in range(2)]
+    return imgs, segs, classes, coors, T(g["corpus"]), T(g["mask"])
+
+
+def e2e_cfg(backbone):
+    return O.NetCfg(num_classes=5, image_min_size=(96,), image_max_size=128, test_image_min_size=96, backbone=backbone,
+                    num_hard_positive_main_1=4, num_hard_negative_main_1=4, num_hard_positive_main_2=6,
+                    num_hard_negative_main_2=6, loss_aux_sample_list=(64, 128, 64), num_hard_positive_aux=64,
+                    num_hard_negative_aux=64, ohem_random=True, bert=O.BertCfg(layers=2, dropout=0.0))
+
+
+@pytest.mark.parametrize("tag,backbone", [("r18", "resnet_18_fpn"), ("r34p", "resnet_34_fpn_pretrained")])
+def test_e2e(golden, tag, backbone):
+    g = golden("e2e.npz")
+    cfg = e2e_cfg(backbone)
+    shapes = O.state_shapes(cfg, vocab=1200)
+    # boundary: the state_dict key inventory equals the reference's
+    ref_keys = set(str(k) for k in g[f"{tag}_keys"])
+    mine = set(shapes.keys())
+    extra_ok = lambda k: k.endswith("position_ids") or k.endswith("token_type_ids")
+    assert {k for k in ref_keys - mine if not extra_ok(k)} == set()
+    assert mine - ref_keys == set()
+    sd = O.synth_state_dict(shapes)
+    imgs, segs, classes, coors, corpus, mask = _e2e_inputs(g)
+
+    random.seed(7)
+    with torch.no_grad():
+        loss, pm, ps, gt, pred = O.forward({k: v.clone() for k, v in sd.items()}, cfg, imgs, segs, classes, coors, corpus, mask, training=False)
+    assert np.array_equal(gt.numpy(), g[f"{tag}_gt"])
+    assert torch.allclose(pred, T(g[f"{tag}_pred"]), rtol=1e-4, atol=1e-5)
+    assert torch.allclose(pm[:, :, ::4, ::4], T(g[f"{tag}_pred_mask"]), rtol=1e-3, atol=1e-4)
+    assert torch.allclose(ps[:, :, ::4, ::4], T(g[f"{tag}_pred_ss"]), rtol=1e-3, atol=1e-4)
+    assert loss.dtype == torch.float64 and loss.shape == (1,)
+    assert torch.allclose(loss, T(g[f"{tag}_eval_loss"]), rtol=1e-4)
+
+    # train mode (batch-stat BN), loss + gradients
+    sdg = {k: (v.clone().requires_grad_(True) if v.is_floating_point() and "running" not in k else v.clone()) for k, v in sd.items()}
+    random.seed(7)
+    out = O.forward(sdg, cfg, imgs, segs, classes, coors, corpus, mask, training=True)
+    out[0].backward()
+    assert torch.allclose(out[0].detach(), T(g[f"{tag}_train_loss"]), rtol=1e-4)
+    keys = [str(k) for k in g[f"{tag}_gradnorm_keys"]]
+    vals = g[f"{tag}_gradnorm_vals"]
+    for k, v in zip(keys, vals):
+        gr = sdg[k].grad
+        n = 0.0 if gr is None else float(gr.double().norm())
+        assert abs(n - v) <= 2e-3 * max(abs(v), 1e-3), (k, n, v)
+    for name in g.files:
+        if name.startswith(f"{tag}_grad::"):
+            k = name.split("::")[1]
+            gr = sdg[k].grad
+            samp = gr.flatten()[:: max(1, gr.numel() // 4096)][:4096]
+            ref = T(g[name])
+            assert torch.allclose(samp, ref, rtol=2e-3, atol=2e-4 * float(ref.abs().max())), k
