@@ -1,0 +1,232 @@
+/* libvbg — C-ABI of the MI355X-native ViBERTgrid hot path (gfx950 only).
+ *
+ * The reference (ZeningLin/ViBERTgrid-PyTorch) is 100 % Python: it has no FFI, so there is no
+ * existing binding to mirror.  Each entry point below replaces the third-party library call the
+ * reference makes at the cited file:line (paths relative to the reference root); the Python side
+ * that binds them with ctypes is vibertgrid-pytorch_amd/vbg/lib.py, and INTEGRATION.md shows the
+ * stub a reference maintainer would add.
+ *
+ * Conventions
+ *   - plain pointers and sizes only; every pointer is a DEVICE pointer unless named `h_*`;
+ *   - activations are NHWC / row-major [rows, channels] fp32; index tensors are int32 unless noted;
+ *   - `stream` is a hipStream_t; nothing uses the default stream, nothing synchronises the device;
+ *   - the caller owns every buffer including workspaces; the library keeps no mutable global state;
+ *   - return value: 0 ok, negative = argument error (VBG_EARG = -1), positive = hipError_t;
+ *   - re-entrant: may be called concurrently from autograd worker threads on different streams.
+ */
+#ifndef VBG_H
+#define VBG_H
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+#define VBG_VERSION 100
+
+int vbg_version(void);
+
+/* ------------------------------------------------------------------------------------------
+ * GEMM / implicit-GEMM convolution (fp32 MFMA).  C[M,N] (+)= opA[M,K] * opB[K,N].
+ * Replaces: torch.nn.Linear / Conv2d forward+backward inside transformers.BertModel
+ * (model/BERTgrid_generator.py:134), model/ResNetFPN_ViBERTgrid.py:478-508 & 612-648,
+ * model/semantic_segmentation_head.py:66-78, model/field_type_classification_head.py:64-75,
+ * 181-188, 564-575, and torch.cat + conv1x1 / Linear fusions at ResNetFPN_ViBERTgrid.py:317-318,
+ * 505-506, field_type_classification_head.py:185-188 (K segments read in place: no concat).
+ * ------------------------------------------------------------------------------------------ */
+enum {
+    VBG_OP_DENSE_K = 0, /* elem(row,k) = p[row*ld + k]      (k contiguous; A may have K segments)  */
+    VBG_OP_DENSE_R = 1, /* elem(row,k) = p[k*ld + row]      (row contiguous)                        */
+    VBG_OP_CONV_K = 2,  /* A only: row = output pixel, k = (tap, channel) gathered from NHWC source */
+    VBG_OP_CONV_R = 3,  /* B only: k = output pixel, col = (tap, ci) gathered from NHWC source      */
+    VBG_OP_WT_R = 4     /* B only: conv weight [Cout][taps][Cin] read as k = (tap, co), col = ci    */
+};
+enum { VBG_EPI_NONE = 0, VBG_EPI_RELU = 1, VBG_EPI_GELU_DUAL = 2 /* C = x, C2 = gelu_erf(x) */ };
+
+typedef struct vbg_conv_geo {
+    int Hs, Ws, Cs;      /* gather-source tensor [*, Hs, Ws, Cs] (X for fwd/wgrad, dY for dgrad)   */
+    int Hr, Wr;          /* spatial dims of the row space (output pixels; dX pixels for dgrad)      */
+    int kh, kw, stride, pad;
+    int dgrad;           /* 0: src = row*stride - pad + tap;  1: src = (row + pad - tap) / stride   */
+} vbg_conv_geo;
+
+typedef struct vbg_gemm_desc {
+    int M, N, K;
+    const float* A; long long lda; int a_kind; int a_vec;   /* a_vec: 16-byte vector loads legal   */
+    /* DENSE_K A may be split along K into up to 4 segments, each its own tensor read in place;     */
+    /* shift>0: the segment lives at 1/2^shift resolution (nearest-upsampled on the fly), rows are  */
+    /* pixels of an [*, a_H, a_W] map.                                                               */
+    int a_nseg; const float* a_seg_ptr[4]; int a_seg_kend[4]; long long a_seg_ld[4]; int a_seg_shift[4];
+    int a_H, a_W;
+    int a_prologue; float a_scale;                          /* 1: a = max(a,0)*a_scale              */
+    const float* B; long long ldb; int b_kind; int b_vec;
+    vbg_conv_geo geo;
+    float* C; long long ldc; float* C2; const float* bias;  /* bias[N] or NULL                      */
+    int epi; float alpha; int accumulate;                   /* accumulate: atomic += into C         */
+    int splitk;                                             /* >1 requires accumulate               */
+    int tile;                                               /* 0 auto, 64 or 128                    */
+    /* grouped problems: grp[g*6 + {0..5}] = M, N, K, offA, offB, offC (elements); NULL = single   */
+    const long long* grp; int ngroups; int grp_maxM, grp_maxN;
+} vbg_gemm_desc;
+
+int vbg_gemm(const vbg_gemm_desc* desc, void* stream);
+
+/* column sums: out[n] (+)= sum_m x[m*ld + n]   (bias gradients) */
+int vbg_colsum(const float* x, long long ld, int M, int N, float* out, int accumulate, void* stream);
+
+/* stem im2col: NHWC [B,H,W,C] -> [B*Ho*Wo, Kpad] with k = (dy*kw+dx)*C + c, zero padded to Kpad */
+int vbg_im2col(const float* x, int B, int H, int W, int C, int kh, int kw, int stride, int pad, int Kpad,
+               float* out, void* stream);
+
+/* ------------------------------------------------------------------------------------------
+ * a1. input transform  (pipeline/transform.py:104-171, 225-271)
+ * ------------------------------------------------------------------------------------------ */
+/* one image CHW [3,h,w] -> normalised, bilinearly resized (align_corners=False, torch
+ * recompute_scale_factor semantics: src = (dst+0.5)*(in/out)-0.5) into batch slot b of an NHWC
+ * [B,H,W,3] buffer that the caller zero-filled (padding).  oh==h && ow==w is an exact copy. */
+int vbg_normalize_resize(const float* img, int h, int w, int oh, int ow, const float* h_mean3, const float* h_std3,
+                         float* batch_nhwc, int b, int H, int W, void* stream);
+/* boxes int64 [S,4] -> int32 [S,4]: cols 0,2 *= ratio_h, cols 1,3 *= ratio_w in fp32, truncate */
+int vbg_rescale_boxes(const long long* in, int S, float ratio_h, float ratio_w, int* out, void* stream);
+
+/* ------------------------------------------------------------------------------------------
+ * a3. BERT encoder pieces (transformers BertModel; model/BERTgrid_generator.py:134)
+ * ------------------------------------------------------------------------------------------ */
+/* out[t] = dropout(LN(word[ids[t]] + pos[pos_ids[t]] + type[0])) ; saves xhat/rstd for backward */
+int vbg_embed_ln_fwd(const int* ids, const int* pos_ids, int ntok, int hidden, const float* word, const float* pos,
+                     const float* type0, const float* gamma, const float* beta, float eps, float drop_p,
+                     unsigned long long seed, unsigned long long stream_id, float* out, float* xhat, float* rstd,
+                     void* stream);
+int vbg_embed_ln_bwd(const float* dout, const float* xhat, const float* rstd, const int* ids, const int* pos_ids,
+                     int ntok, int hidden, const float* gamma, float drop_p, unsigned long long seed,
+                     unsigned long long stream_id, float* dword, float* dpos, float* dtype0, float* dgamma,
+                     float* dbeta, void* stream);
+/* y = LN(dropout(x) + res) * gamma + beta ; x already holds the dense output + bias */
+int vbg_dropout_add_ln_fwd(const float* x, const float* res, int rows, int hidden, const float* gamma,
+                           const float* beta, float eps, float drop_p, unsigned long long seed,
+                           unsigned long long stream_id, float* y, float* xhat, float* rstd, void* stream);
+/* dx (to the dense output), dres (added into `dres_accum` if accumulate else written), dgamma/dbeta += */
+int vbg_dropout_add_ln_bwd(const float* dy, const float* xhat, const float* rstd, int rows, int hidden,
+                           const float* gamma, float drop_p, unsigned long long seed, unsigned long long stream_id,
+                           float* dx, float* dres, float* dgamma, float* dbeta, void* stream);
+/* attention probabilities, in place on the grouped score buffer: for group g (= seq*heads + head)
+ * rows L=len[g/heads], row stride ldp[g/heads], block offset off[g]; P = softmax(S*scale);
+ * dropped entries are stored NEGATED (sign bit = dropped), kept entries unscaled; pad columns = 0. */
+int vbg_softmax_fwd(float* s, const long long* off, const int* len, const int* ldp, int ngroups, int heads,
+                    int maxlen, float scale, float drop_p, unsigned long long seed, unsigned long long stream_id,
+                    void* stream);
+/* dS (in place on dp) from sign-encoded P and dP_drop: dS = scale * P * (keep*dP/(1-p) - sum_j P_drop*dP_drop) */
+int vbg_softmax_bwd(const float* p, float* dp, const long long* off, const int* len, const int* ldp, int ngroups,
+                    int heads, int maxlen, float scale, float drop_p, void* stream);
+int vbg_gelu_bwd(const float* h, float* dg_inout, long long n, void* stream);      /* dh = dg * gelu'(h) */
+int vbg_relu_bwd(const float* y, float* dy_inout, long long n, void* stream);      /* dx = dy * (y > 0)  */
+
+/* ------------------------------------------------------------------------------------------
+ * a4. token -> segment aggregation  (model/BERTgrid_generator.py:148-191)
+ * ------------------------------------------------------------------------------------------ */
+/* tok_row[i] = row of the i-th token (mask==1 order) in `tok`; runs: start[s], len[s] in token order.
+ * mode 0 mean = sequential sum in token order then / n (bit-exact vs the reference), 1 = first. */
+int vbg_seg_reduce_fwd(const float* tok, const int* tok_row, const int* run_start, const int* run_len, int nseg,
+                       int hidden, int mode, float* out, void* stream);
+int vbg_seg_reduce_bwd(const float* dout, const int* tok_row, const int* run_start, const int* run_len, int nseg,
+                       int hidden, int mode, float* dtok_accum, void* stream);
+
+/* ------------------------------------------------------------------------------------------
+ * a5 / a9. bbox -> owner map, grid scatter, label raster  (model/BERTgrid_generator.py:193-245,
+ *          model/semantic_segmentation_head.py:314-341).  Bit-exact.
+ * ------------------------------------------------------------------------------------------ */
+/* boxes int32 [nbox,4] (x1,y1,x2,y2) for all docs, doc b owns boxes [box_off[b], box_off[b+1]).
+ * owner[b,y,x] = GLOBAL index of the last box of doc b whose rectangle
+ * rows int(y1/stride):int(y2/stride), cols int(x1/stride):int(x2/stride) (python slice clipping,
+ * truncating division) covers the cell, else -1. */
+int vbg_owner_map(const int* boxes, const int* box_off, int B, int gh, int gw, int stride, int* owner, void* stream);
+/* grid[b,y,x,:] = emb[owner] or 0.  layout 0: NHWC [B,gh,gw,C]; 1: NCHW [B,C,gh,gw] (reference layout) */
+int vbg_grid_scatter_fwd(const float* emb, const int* owner, int B, int gh, int gw, int C, int layout, float* grid,
+                         void* stream);
+/* demb[s,:] (+)= sum over cells owned by s of dgrid (CopySlices semantics); dgrid NHWC */
+int vbg_grid_scatter_bwd(const float* dgrid, const int* owner, const int* boxes, const int* box_doc, int nbox, int gh,
+                         int gw, int stride, int C, float* demb_accum, void* stream);
+/* full-resolution labels from the stride-1 owner map: pos_neg (0 bg / 1 class>0 / 2 class==0), cls */
+int vbg_label_raster(const int* owner, const int* seg_class, long long ncell, int* pos_neg, int* cls, void* stream);
+
+/* ------------------------------------------------------------------------------------------
+ * a6-a9, a11. convolution trunk helpers (NHWC): BatchNorm (Sync-able), max-pool, FPN resampling
+ * ------------------------------------------------------------------------------------------ */
+/* per-channel sum / sum of squares over rows of x[M,C] (fp64 accumulators, all-reducible for SyncBN):
+ * stats[0..C) += sum, stats[C..2C) += sumsq */
+int vbg_bn_stats(const float* x, long long M, int C, double* stats_accum, void* stream);
+/* from (global) sums over `count` rows: mean, invstd; running <- (1-mom)*running + mom*{mean, unbiased var} */
+int vbg_bn_finalize(const double* stats, double count, int C, float eps, float momentum, float* mean, float* invstd,
+                    float* running_mean, float* running_var, void* stream);
+/* y = relu?( (x-mean)*invstd*gamma + beta (+ res) ) */
+int vbg_bn_apply(const float* x, const float* res, long long M, int C, const float* mean, const float* invstd,
+                 const float* gamma, const float* beta, int relu, float* y, void* stream);
+/* backward reductions: sums[0..C) += sum(g), sums[C..2C) += sum(g*xhat), g = dy*(y>0 if relu) */
+int vbg_bn_bwd_reduce(const float* dy, const float* y, const float* x, long long M, int C, const float* mean,
+                      const float* invstd, int relu, double* sums_accum, void* stream);
+/* dx = gamma*invstd*(g - sum_g/count - xhat*sum_gx/count); dres = g (optional); dgamma += sum_gx, dbeta += sum_g */
+int vbg_bn_bwd_apply(const float* dy, const float* y, const float* x, long long M, int C, const float* mean,
+                     const float* invstd, const float* gamma, const double* sums, double count, int relu, float* dx,
+                     float* dres, float* dgamma_accum, float* dbeta_accum, void* stream);
+int vbg_maxpool3x3s2_fwd(const float* x, int B, int H, int W, int C, float* y, int* argmax, void* stream);
+int vbg_maxpool3x3s2_bwd(const float* dy, const int* argmax, int B, int Ho, int Wo, int C, int H, int W,
+                         float* dx_zeroed, void* stream);
+/* y[b,y,x,:] = lo[b,y/2,x/2,:] + skip[b,y,x,:]   (nearest x2 upsample + add) */
+int vbg_upsample2_add(const float* lo, const float* skip, int B, int H, int W, int C, float* y, void* stream);
+/* lo[b,y,x,:] (+)= sum of the f x f block of hi   (backward of nearest upsampling by f) */
+int vbg_sumpool(const float* hi, int B, int H, int W, int C, int f, float* lo, int accumulate, void* stream);
+/* layout changes: [B,C,HW] <-> [B,HW,C] */
+int vbg_nchw_to_nhwc(const float* x, int B, int C, int HW, float* y, void* stream);
+int vbg_nhwc_to_nchw(const float* x, int B, int C, int HW, float* y, void* stream);
+/* nearest-upsample a [B,h,w,C] NHWC map by f into NCHW [B,C,h*f,w*f] (eval-mode seg logits) */
+int vbg_upsample_nhwc_to_nchw(const float* x, int B, int h, int w, int C, int f, float* y, void* stream);
+int vbg_add_inplace(float* a, const float* b, long long n, void* stream);
+
+/* ------------------------------------------------------------------------------------------
+ * a10. RoIAlign  (torchvision.ops.RoIAlign(7, 1/4, sampling_ratio=-1, aligned=False);
+ *      model/grid_roi_align.py:37-41, 81).  feat NHWC [B,H,W,C]; boxes int32 image coords.
+ * ------------------------------------------------------------------------------------------ */
+int vbg_roi_align_fwd(const float* feat, int B, int H, int W, int C, const int* boxes, const int* box_doc, int nroi,
+                      int out, float scale, float* y /* [nroi,out,out,C] */, void* stream);
+int vbg_roi_align_bwd(const float* dy, int B, int H, int W, int C, const int* boxes, const int* box_doc, int nroi,
+                      int out, float scale, float* dfeat_accum, void* stream);
+
+/* ------------------------------------------------------------------------------------------
+ * a13. losses  (pipeline/custom_loss.py:35-101, 127-201)
+ * ------------------------------------------------------------------------------------------ */
+/* per-element CE.  Element i of the list is pixel/row e = elem ? elem[i] : i; its label is labels[e];
+ * its logits row is e itself (H <= 0) or, for logits kept at 1/2^up_shift resolution of an
+ * [*, H, W] label map, the low-resolution pixel under e (nearest upsampling folded into the index).
+ * loss[i] = -w[t] * log_softmax(x)[t]. */
+int vbg_ce_fwd(const float* logits, long long ld, int ncls, const int* elem, const int* labels, long long n,
+               const float* weight, int up_shift, int H, int W, float* loss, void* stream);
+/* dlogits[row(e)] += g * w[t] * (softmax(x) - onehot(t)),  g = gmul * (gscale_dev ? *gscale_dev : 1) (atomic) */
+int vbg_ce_bwd(const float* logits, long long ld, int ncls, const int* elem, const int* labels, long long n,
+               const float* weight, const float* gscale_dev, float gmul, int up_shift, int H, int W,
+               float* dlogits_accum, void* stream);
+/* order-preserving compaction: out_idx = ascending i with (labels[i] == value) == eq; *out_count_dev = how many */
+long long vbg_compact_ws_bytes(long long n);
+int vbg_compact(const int* labels, long long n, int value, int eq, int* out_idx, int* out_count_dev, void* ws,
+                long long ws_bytes, void* stream);
+/* STABLE descending sort (LSD radix): keys_out sorted, idx_out[r] = original position of rank r */
+long long vbg_sort_ws_bytes(long long n);
+int vbg_sort_desc(const float* keys, long long n, float* keys_out, int* idx_out, void* ws, long long ws_bytes,
+                  void* stream);
+int vbg_gather_f32(const float* src, const int* idx, long long n, float* out, void* stream);
+int vbg_gather_i32(const int* src, const int* idx, long long n, int* out, void* stream);
+int vbg_sum_f32(const float* x, long long n, float* out_accum, void* stream);
+
+/* ------------------------------------------------------------------------------------------
+ * a15. optimizers on flat fp32 ranges  (torch.optim.SGD / AdamW; train_SROIE.py:223-235)
+ * ------------------------------------------------------------------------------------------ */
+int vbg_sgd_step(float* p, const float* g, float* mom, long long n, float lr, float momentum, float wd,
+                 int first_step, float grad_scale, void* stream);
+int vbg_adamw_step(float* p, const float* g, float* m, float* v, long long n, float lr, float b1, float b2,
+                   float eps, float wd, int step, float grad_scale, void* stream);
+/* out[0] += sum(g^2) */
+int vbg_sumsq(const float* g, long long n, float* out_accum, void* stream);
+int vbg_scale_inplace(float* x, long long n, float s, void* stream);
+
+#ifdef __cplusplus
+}
+#endif
+#endif /* VBG_H */

@@ -1,0 +1,444 @@
+// NHWC helpers around the implicit-GEMM convolutions of the ResNet-FPN trunk and heads
+// (model/ResNetFPN_ViBERTgrid.py:106-184, 478-508; model/semantic_segmentation_head.py:66-78;
+// model/field_type_classification_head.py:64-75): BatchNorm statistics / apply / backward
+// (Sync-able: statistics are plain sums the caller may all-reduce), 3x3/s2 max-pool, nearest
+// up/down-sampling of the FPN, layout changes, input normalisation + bilinear resize
+// (pipeline/transform.py:104-157), stem im2col.  All HBM-bound streaming kernels.
+#include "vbg_common.h"
+#include "../../include/vbg.h"
+
+namespace vbg {
+
+static inline int ew_grid(long long n, int block) {
+    long long g = (n + block - 1) / block;
+    if (g > 256 * 8) g = 256 * 8;
+    if (g < 1) g = 1;
+    return (int)g;
+}
+
+// ------------------------------------------------------------------------------------------
+// BatchNorm.  x is [M, C] (NHWC rows).  Block: 64 channels x 4 row lanes, BN_ROWS rows per block.
+// ------------------------------------------------------------------------------------------
+constexpr int BN_ROWS = 512;
+
+__global__ __launch_bounds__(256) void bn_stats_kernel(const float* __restrict__ x, long long M, int C, double* stats) {
+    __shared__ double sh[2][4][64];
+    const int cl = threadIdx.x & 63, rl = threadIdx.x >> 6;
+    const int c = blockIdx.x * 64 + cl;
+    const long long r0 = (long long)blockIdx.y * BN_ROWS;
+    const long long r1 = min(M, r0 + BN_ROWS);
+    float s = 0.f, q = 0.f;
+    if (c < C)
+        for (long long r = r0 + rl; r < r1; r += 4) { const float v = x[r * C + c]; s += v; q += v * v; }
+    sh[0][rl][cl] = (double)s;
+    sh[1][rl][cl] = (double)q;
+    __syncthreads();
+    if (rl == 0 && c < C) {
+        unsafeAtomicAdd(stats + c, sh[0][0][cl] + sh[0][1][cl] + sh[0][2][cl] + sh[0][3][cl]);
+        unsafeAtomicAdd(stats + C + c, sh[1][0][cl] + sh[1][1][cl] + sh[1][2][cl] + sh[1][3][cl]);
+    }
+}
+
+__global__ void bn_finalize_kernel(const double* __restrict__ stats, double count, int C, float eps, float momentum,
+                                   float* mean, float* invstd, float* running_mean, float* running_var) {
+    const int c = blockIdx.x * blockDim.x + threadIdx.x;
+    if (c >= C) return;
+    const double m = stats[c] / count;
+    double var = stats[C + c] / count - m * m;
+    if (var < 0.0) var = 0.0;
+    mean[c] = (float)m;
+    invstd[c] = (float)(1.0 / sqrt(var + (double)eps));
+    if (running_mean) {
+        const double unbiased = count > 1.0 ? var * count / (count - 1.0) : var;
+        running_mean[c] = (1.f - momentum) * running_mean[c] + momentum * (float)m;
+        running_var[c] = (1.f - momentum) * running_var[c] + momentum * (float)unbiased;
+    }
+}
+
+__global__ void bn_apply_kernel(const float* __restrict__ x, const float* __restrict__ res, long long M, int C4,
+                                const float* __restrict__ mean, const float* __restrict__ invstd,
+                                const float* __restrict__ gamma, const float* __restrict__ beta, int relu,
+                                float* __restrict__ y) {
+    const long long total = M * C4;
+    const long long stride = (long long)gridDim.x * blockDim.x;
+    for (long long i = (long long)blockIdx.x * blockDim.x + threadIdx.x; i < total; i += stride) {
+        const int c4 = (int)(i % C4);
+        const float4 xv = reinterpret_cast<const float4*>(x)[i];
+        const float4 mu = reinterpret_cast<const float4*>(mean)[c4];
+        const float4 is = reinterpret_cast<const float4*>(invstd)[c4];
+        const float4 ga = reinterpret_cast<const float4*>(gamma)[c4];
+        const float4 be = reinterpret_cast<const float4*>(beta)[c4];
+        float4 o;
+        o.x = (xv.x - mu.x) * is.x * ga.x + be.x; o.y = (xv.y - mu.y) * is.y * ga.y + be.y;
+        o.z = (xv.z - mu.z) * is.z * ga.z + be.z; o.w = (xv.w - mu.w) * is.w * ga.w + be.w;
+        if (res) {
+            const float4 rv = reinterpret_cast<const float4*>(res)[i];
+            o.x += rv.x; o.y += rv.y; o.z += rv.z; o.w += rv.w;
+        }
+        if (relu) { o.x = fmaxf(o.x, 0.f); o.y = fmaxf(o.y, 0.f); o.z = fmaxf(o.z, 0.f); o.w = fmaxf(o.w, 0.f); }
+        reinterpret_cast<float4*>(y)[i] = o;
+    }
+}
+
+__global__ __launch_bounds__(256) void bn_bwd_reduce_kernel(const float* __restrict__ dy, const float* __restrict__ y,
+                                                            const float* __restrict__ x, long long M, int C,
+                                                            const float* __restrict__ mean, const float* __restrict__ invstd,
+                                                            int relu, double* sums) {
+    __shared__ double sh[2][4][64];
+    const int cl = threadIdx.x & 63, rl = threadIdx.x >> 6;
+    const int c = blockIdx.x * 64 + cl;
+    const long long r0 = (long long)blockIdx.y * BN_ROWS;
+    const long long r1 = min(M, r0 + BN_ROWS);
+    float s = 0.f, q = 0.f;
+    if (c < C) {
+        const float mu = mean[c], is = invstd[c];
+        for (long long r = r0 + rl; r < r1; r += 4) {
+            float g = dy[r * C + c];
+            if (relu && !(y[r * C + c] > 0.f)) g = 0.f;
+            s += g;
+            q += g * ((x[r * C + c] - mu) * is);
+        }
+    }
+    sh[0][rl][cl] = (double)s;
+    sh[1][rl][cl] = (double)q;
+    __syncthreads();
+    if (rl == 0 && c < C) {
+        unsafeAtomicAdd(sums + c, sh[0][0][cl] + sh[0][1][cl] + sh[0][2][cl] + sh[0][3][cl]);
+        unsafeAtomicAdd(sums + C + c, sh[1][0][cl] + sh[1][1][cl] + sh[1][2][cl] + sh[1][3][cl]);
+    }
+}
+
+__global__ void bn_bwd_apply_kernel(const float* __restrict__ dy, const float* __restrict__ y, const float* __restrict__ x,
+                                    long long M, int C, const float* __restrict__ mean, const float* __restrict__ invstd,
+                                    const float* __restrict__ gamma, const double* __restrict__ sums, double count, int relu,
+                                    float* __restrict__ dx, float* __restrict__ dres) {
+    const long long total = M * C;
+    const long long stride = (long long)gridDim.x * blockDim.x;
+    for (long long i = (long long)blockIdx.x * blockDim.x + threadIdx.x; i < total; i += stride) {
+        const int c = (int)(i % C);
+        float g = dy[i];
+        if (relu && !(y[i] > 0.f)) g = 0.f;
+        const float is = invstd[c];
+        const float xh = (x[i] - mean[c]) * is;
+        const float mg = (float)(sums[c] / count), mgx = (float)(sums[C + c] / count);
+        dx[i] = gamma[c] * is * (g - mg - xh * mgx);
+        if (dres) dres[i] = g;
+    }
+}
+
+__global__ void bn_param_grad_kernel(const double* __restrict__ sums, int C, float* dgamma, float* dbeta) {
+    const int c = blockIdx.x * blockDim.x + threadIdx.x;
+    if (c >= C) return;
+    dbeta[c] += (float)sums[c];
+    dgamma[c] += (float)sums[C + c];
+}
+
+// ------------------------------------------------------------------------------------------
+__global__ void maxpool_fwd_kernel(const float* __restrict__ x, int B, int H, int W, int C, int Ho, int Wo,
+                                   float* __restrict__ y, int* __restrict__ argmax) {
+    const long long total = (long long)B * Ho * Wo * C;
+    const long long stride = (long long)gridDim.x * blockDim.x;
+    for (long long i = (long long)blockIdx.x * blockDim.x + threadIdx.x; i < total; i += stride) {
+        const int c = (int)(i % C);
+        long long t = i / C;
+        const int ox = (int)(t % Wo); t /= Wo;
+        const int oy = (int)(t % Ho);
+        const int b = (int)(t / Ho);
+        float best = -INFINITY;
+        int bi = -1;
+        for (int dy = 0; dy < 3; ++dy) {
+            const int iy = oy * 2 - 1 + dy;
+            if (iy < 0 || iy >= H) continue;
+            for (int dx = 0; dx < 3; ++dx) {
+                const int ix = ox * 2 - 1 + dx;
+                if (ix < 0 || ix >= W) continue;
+                const float v = x[(((long long)b * H + iy) * W + ix) * C + c];
+                if (v > best || bi < 0) { best = v; bi = iy * W + ix; }
+            }
+        }
+        y[i] = best;
+        argmax[i] = bi;
+    }
+}
+
+__global__ void maxpool_bwd_kernel(const float* __restrict__ dy, const int* __restrict__ argmax, int HoWo, int C, int HW,
+                                   long long total, float* dx) {
+    const long long stride = (long long)gridDim.x * blockDim.x;
+    for (long long i = (long long)blockIdx.x * blockDim.x + threadIdx.x; i < total; i += stride) {
+        const int c = (int)(i % C);
+        const long long b = i / ((long long)HoWo * C);
+        unsafeAtomicAdd(dx + (b * HW + argmax[i]) * C + c, dy[i]);
+    }
+}
+
+__global__ void upsample2_add_kernel(const float* __restrict__ lo, const float* __restrict__ skip, int B, int H, int W, int C4,
+                                     float* __restrict__ y) {
+    const long long total = (long long)B * H * W * C4;
+    const long long stride = (long long)gridDim.x * blockDim.x;
+    for (long long i = (long long)blockIdx.x * blockDim.x + threadIdx.x; i < total; i += stride) {
+        const int c4 = (int)(i % C4);
+        long long t = i / C4;
+        const int x = (int)(t % W); t /= W;
+        const int yy = (int)(t % H);
+        const int b = (int)(t / H);
+        const float4 a = reinterpret_cast<const float4*>(lo)[(((long long)b * (H / 2) + (yy >> 1)) * (W / 2) + (x >> 1)) * C4 + c4];
+        const float4 s = reinterpret_cast<const float4*>(skip)[i];
+        reinterpret_cast<float4*>(y)[i] = make_float4(a.x + s.x, a.y + s.y, a.z + s.z, a.w + s.w);
+    }
+}
+
+__global__ void sumpool_kernel(const float* __restrict__ hi, int B, int H, int W, int C4, int f, float* lo, int accumulate) {
+    const int Hl = H / f, Wl = W / f;
+    const long long total = (long long)B * Hl * Wl * C4;
+    const long long stride = (long long)gridDim.x * blockDim.x;
+    for (long long i = (long long)blockIdx.x * blockDim.x + threadIdx.x; i < total; i += stride) {
+        const int c4 = (int)(i % C4);
+        long long t = i / C4;
+        const int x = (int)(t % Wl); t /= Wl;
+        const int y = (int)(t % Hl);
+        const int b = (int)(t / Hl);
+        float4 acc = make_float4(0.f, 0.f, 0.f, 0.f);
+        for (int dy = 0; dy < f; ++dy)
+            for (int dx = 0; dx < f; ++dx) {
+                const float4 v = reinterpret_cast<const float4*>(hi)[(((long long)b * H + y * f + dy) * W + x * f + dx) * C4 + c4];
+                acc.x += v.x; acc.y += v.y; acc.z += v.z; acc.w += v.w;
+            }
+        if (accumulate) {
+            const float4 o = reinterpret_cast<float4*>(lo)[i];
+            acc.x += o.x; acc.y += o.y; acc.z += o.z; acc.w += o.w;
+        }
+        reinterpret_cast<float4*>(lo)[i] = acc;
+    }
+}
+
+// [B, R, Cc] -> [B, Cc, R] through a padded 32x32 LDS tile (both sides coalesced)
+__global__ __launch_bounds__(256) void transpose_kernel(const float* __restrict__ x, int R, int Cc, float* __restrict__ y) {
+    __shared__ float tile[32][33];
+    const int b = blockIdx.z;
+    const int r0 = blockIdx.y * 32, c0 = blockIdx.x * 32;
+    const int tx = threadIdx.x & 31, ty = threadIdx.x >> 5;
+    const float* xb = x + (long long)b * R * Cc;
+    float* yb = y + (long long)b * R * Cc;
+    for (int j = ty; j < 32; j += 8) {
+        const int r = r0 + j, c = c0 + tx;
+        tile[j][tx] = (r < R && c < Cc) ? xb[(long long)r * Cc + c] : 0.f;
+    }
+    __syncthreads();
+    for (int j = ty; j < 32; j += 8) {
+        const int c = c0 + j, r = r0 + tx;
+        if (r < R && c < Cc) yb[(long long)c * R + r] = tile[tx][j];
+    }
+}
+
+__global__ void upsample_nhwc_to_nchw_kernel(const float* __restrict__ x, int B, int h, int w, int C, int f, float* __restrict__ y) {
+    const int H = h * f, W = w * f;
+    const long long total = (long long)B * C * H * W;
+    const long long stride = (long long)gridDim.x * blockDim.x;
+    for (long long i = (long long)blockIdx.x * blockDim.x + threadIdx.x; i < total; i += stride) {
+        const int X = (int)(i % W);
+        long long t = i / W;
+        const int Y = (int)(t % H); t /= H;
+        const int c = (int)(t % C);
+        const int b = (int)(t / C);
+        y[i] = x[(((long long)b * h + Y / f) * w + X / f) * C + c];
+    }
+}
+
+// ------------------------------------------------------------------------------------------
+// input transform: (img - mean) / std, bilinear resize (align_corners=False, scale = in/out),
+// written NHWC into batch slot b.  One thread per output pixel (3 channels).
+// ------------------------------------------------------------------------------------------
+__global__ void normalize_resize_kernel(const float* __restrict__ img, int h, int w, int oh, int ow, float m0, float m1, float m2,
+                                        float s0, float s1, float s2, float* __restrict__ out, int W) {
+    const int i = blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= oh * ow) return;
+    const int oy = i / ow, ox = i - oy * ow;
+    const float mean[3] = {m0, m1, m2}, sd[3] = {s0, s1, s2};
+    float v[3];
+    if (oh == h && ow == w) {
+#pragma unroll
+        for (int c = 0; c < 3; ++c) v[c] = (img[((long long)c * h + oy) * w + ox] - mean[c]) / sd[c];
+    } else {
+        const float sy = (float)h / (float)oh, sx = (float)w / (float)ow;
+        float fy = ((float)oy + 0.5f) * sy - 0.5f; if (fy < 0.f) fy = 0.f;
+        float fx = ((float)ox + 0.5f) * sx - 0.5f; if (fx < 0.f) fx = 0.f;
+        const int y0 = (int)fy, x0 = (int)fx;
+        const int y1 = y0 + ((y0 < h - 1) ? 1 : 0), x1 = x0 + ((x0 < w - 1) ? 1 : 0);
+        const float ly = fy - (float)y0, lx = fx - (float)x0, hy = 1.f - ly, hx = 1.f - lx;
+#pragma unroll
+        for (int c = 0; c < 3; ++c) {
+            const float* p = img + (long long)c * h * w;
+            const float a = (p[(long long)y0 * w + x0] - mean[c]) / sd[c], b = (p[(long long)y0 * w + x1] - mean[c]) / sd[c];
+            const float d = (p[(long long)y1 * w + x0] - mean[c]) / sd[c], e = (p[(long long)y1 * w + x1] - mean[c]) / sd[c];
+            v[c] = hy * (hx * a + lx * b) + ly * (hx * d + lx * e);
+        }
+    }
+    float* o = out + ((long long)oy * W + ox) * 3;
+    o[0] = v[0]; o[1] = v[1]; o[2] = v[2];
+}
+
+__global__ void rescale_boxes_kernel(const long long* __restrict__ in, int n, float rh, float rw, int* __restrict__ out) {
+    const int i = blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= n) return;
+    const float r = ((i & 1) == 0) ? rh : rw;       // cols 0,2 <- height ratio; 1,3 <- width ratio (reference swap)
+    out[i] = (int)__fmul_rn((float)in[i], r);
+}
+
+__global__ void im2col_kernel(const float* __restrict__ x, int B, int H, int W, int C, int kh, int kw, int stride, int pad,
+                              int Ho, int Wo, int Kpad, float* __restrict__ out) {
+    const long long total = (long long)B * Ho * Wo * Kpad;
+    const long long gstride = (long long)gridDim.x * blockDim.x;
+    const int K = kh * kw * C;
+    for (long long i = (long long)blockIdx.x * blockDim.x + threadIdx.x; i < total; i += gstride) {
+        const int k = (int)(i % Kpad);
+        long long t = i / Kpad;
+        const int ox = (int)(t % Wo); t /= Wo;
+        const int oy = (int)(t % Ho);
+        const int b = (int)(t / Ho);
+        float v = 0.f;
+        if (k < K) {
+            const int c = k % C, tap = k / C;
+            const int dy = tap / kw, dx = tap - dy * kw;
+            const int iy = oy * stride - pad + dy, ix = ox * stride - pad + dx;
+            if (iy >= 0 && iy < H && ix >= 0 && ix < W) v = x[(((long long)b * H + iy) * W + ix) * C + c];
+        }
+        out[i] = v;
+    }
+}
+
+}  // namespace vbg
+
+using namespace vbg;
+#define S_ ((hipStream_t)stream)
+#define ALIGNED16(p) (((uintptr_t)(p)) % 16 == 0)
+
+extern "C" int vbg_bn_stats(const float* x, long long M, int C, double* stats_accum, void* stream) {
+    VBG_CHECK_ARG(x && stats_accum && M >= 0 && C > 0);
+    if (M == 0) return VBG_OK;
+    hipLaunchKernelGGL(bn_stats_kernel, dim3(cdiv(C, 64), cdiv(M, BN_ROWS)), dim3(256), 0, S_, x, M, C, stats_accum);
+    VBG_LAUNCH_RET();
+}
+
+extern "C" int vbg_bn_finalize(const double* stats, double count, int C, float eps, float momentum, float* mean, float* invstd,
+                               float* running_mean, float* running_var, void* stream) {
+    VBG_CHECK_ARG(stats && mean && invstd && C > 0 && count > 0 && ((running_mean == nullptr) == (running_var == nullptr)));
+    hipLaunchKernelGGL(bn_finalize_kernel, dim3(cdiv(C, 256)), dim3(256), 0, S_, stats, count, C, eps, momentum, mean, invstd,
+                       running_mean, running_var);
+    VBG_LAUNCH_RET();
+}
+
+extern "C" int vbg_bn_apply(const float* x, const float* res, long long M, int C, const float* mean, const float* invstd,
+                            const float* gamma, const float* beta, int relu, float* y, void* stream) {
+    VBG_CHECK_ARG(x && mean && invstd && gamma && beta && y && M >= 0 && C > 0 && C % 4 == 0);
+    VBG_CHECK_ARG(ALIGNED16(x) && ALIGNED16(y) && ALIGNED16(mean) && ALIGNED16(invstd) && ALIGNED16(gamma) && ALIGNED16(beta) &&
+                  (!res || ALIGNED16(res)));
+    if (M == 0) return VBG_OK;
+    hipLaunchKernelGGL(bn_apply_kernel, dim3(ew_grid(M * (C / 4), 256)), dim3(256), 0, S_, x, res, M, C / 4, mean, invstd, gamma,
+                       beta, relu, y);
+    VBG_LAUNCH_RET();
+}
+
+extern "C" int vbg_bn_bwd_reduce(const float* dy, const float* y, const float* x, long long M, int C, const float* mean,
+                                 const float* invstd, int relu, double* sums_accum, void* stream) {
+    VBG_CHECK_ARG(dy && x && mean && invstd && sums_accum && M >= 0 && C > 0 && (!relu || y));
+    if (M == 0) return VBG_OK;
+    hipLaunchKernelGGL(bn_bwd_reduce_kernel, dim3(cdiv(C, 64), cdiv(M, BN_ROWS)), dim3(256), 0, S_, dy, y, x, M, C, mean, invstd,
+                       relu, sums_accum);
+    VBG_LAUNCH_RET();
+}
+
+extern "C" int vbg_bn_bwd_apply(const float* dy, const float* y, const float* x, long long M, int C, const float* mean,
+                                const float* invstd, const float* gamma, const double* sums, double count, int relu, float* dx,
+                                float* dres, float* dgamma_accum, float* dbeta_accum, void* stream) {
+    VBG_CHECK_ARG(dy && x && mean && invstd && gamma && sums && dx && M >= 0 && C > 0 && count > 0 && (!relu || y));
+    if (M > 0) hipLaunchKernelGGL(bn_bwd_apply_kernel, dim3(ew_grid(M * C, 256)), dim3(256), 0, S_, dy, y, x, M, C, mean, invstd,
+                                  gamma, sums, count, relu, dx, dres);
+    if (dgamma_accum && dbeta_accum)
+        hipLaunchKernelGGL(bn_param_grad_kernel, dim3(cdiv(C, 256)), dim3(256), 0, S_, sums, C, dgamma_accum, dbeta_accum);
+    VBG_LAUNCH_RET();
+}
+
+extern "C" int vbg_maxpool3x3s2_fwd(const float* x, int B, int H, int W, int C, float* y, int* argmax, void* stream) {
+    VBG_CHECK_ARG(x && y && argmax && B >= 0 && H > 0 && W > 0 && C > 0);
+    const int Ho = (H + 2 - 3) / 2 + 1, Wo = (W + 2 - 3) / 2 + 1;
+    const long long total = (long long)B * Ho * Wo * C;
+    if (total == 0) return VBG_OK;
+    hipLaunchKernelGGL(maxpool_fwd_kernel, dim3(ew_grid(total, 256)), dim3(256), 0, S_, x, B, H, W, C, Ho, Wo, y, argmax);
+    VBG_LAUNCH_RET();
+}
+
+extern "C" int vbg_maxpool3x3s2_bwd(const float* dy, const int* argmax, int B, int Ho, int Wo, int C, int H, int W,
+                                    float* dx_zeroed, void* stream) {
+    VBG_CHECK_ARG(dy && argmax && dx_zeroed && B >= 0 && Ho > 0 && Wo > 0 && C > 0);
+    const long long total = (long long)B * Ho * Wo * C;
+    if (total == 0) return VBG_OK;
+    hipLaunchKernelGGL(maxpool_bwd_kernel, dim3(ew_grid(total, 256)), dim3(256), 0, S_, dy, argmax, Ho * Wo, C, H * W, total,
+                       dx_zeroed);
+    VBG_LAUNCH_RET();
+}
+
+extern "C" int vbg_upsample2_add(const float* lo, const float* skip, int B, int H, int W, int C, float* y, void* stream) {
+    VBG_CHECK_ARG(lo && skip && y && H % 2 == 0 && W % 2 == 0 && C % 4 == 0 && ALIGNED16(lo) && ALIGNED16(skip) && ALIGNED16(y));
+    const long long total = (long long)B * H * W * (C / 4);
+    if (total == 0) return VBG_OK;
+    hipLaunchKernelGGL(upsample2_add_kernel, dim3(ew_grid(total, 256)), dim3(256), 0, S_, lo, skip, B, H, W, C / 4, y);
+    VBG_LAUNCH_RET();
+}
+
+extern "C" int vbg_sumpool(const float* hi, int B, int H, int W, int C, int f, float* lo, int accumulate, void* stream) {
+    VBG_CHECK_ARG(hi && lo && f >= 1 && H % f == 0 && W % f == 0 && C % 4 == 0 && ALIGNED16(hi) && ALIGNED16(lo));
+    const long long total = (long long)B * (H / f) * (W / f) * (C / 4);
+    if (total == 0) return VBG_OK;
+    hipLaunchKernelGGL(sumpool_kernel, dim3(ew_grid(total, 256)), dim3(256), 0, S_, hi, B, H, W, C / 4, f, lo, accumulate);
+    VBG_LAUNCH_RET();
+}
+
+extern "C" int vbg_nchw_to_nhwc(const float* x, int B, int C, int HW, float* y, void* stream) {
+    VBG_CHECK_ARG(x && y && B >= 0 && C > 0 && HW > 0);
+    if (B == 0) return VBG_OK;
+    hipLaunchKernelGGL(transpose_kernel, dim3(cdiv(HW, 32), cdiv(C, 32), B), dim3(256), 0, S_, x, C, HW, y);
+    VBG_LAUNCH_RET();
+}
+
+extern "C" int vbg_nhwc_to_nchw(const float* x, int B, int C, int HW, float* y, void* stream) {
+    VBG_CHECK_ARG(x && y && B >= 0 && C > 0 && HW > 0);
+    if (B == 0) return VBG_OK;
+    hipLaunchKernelGGL(transpose_kernel, dim3(cdiv(C, 32), cdiv(HW, 32), B), dim3(256), 0, S_, x, HW, C, y);
+    VBG_LAUNCH_RET();
+}
+
+extern "C" int vbg_upsample_nhwc_to_nchw(const float* x, int B, int h, int w, int C, int f, float* y, void* stream) {
+    VBG_CHECK_ARG(x && y && f >= 1 && C > 0);
+    const long long total = (long long)B * C * h * f * w * f;
+    if (total == 0) return VBG_OK;
+    hipLaunchKernelGGL(upsample_nhwc_to_nchw_kernel, dim3(ew_grid(total, 256)), dim3(256), 0, S_, x, B, h, w, C, f, y);
+    VBG_LAUNCH_RET();
+}
+
+extern "C" int vbg_normalize_resize(const float* img, int h, int w, int oh, int ow, const float* h_mean3, const float* h_std3,
+                                    float* batch_nhwc, int b, int H, int W, void* stream) {
+    VBG_CHECK_ARG(img && h_mean3 && h_std3 && batch_nhwc && h > 0 && w > 0 && oh > 0 && ow > 0 && oh <= H && ow <= W && b >= 0);
+    float* out = batch_nhwc + (long long)b * H * W * 3;
+    hipLaunchKernelGGL(normalize_resize_kernel, dim3(cdiv((long)oh * ow, 256)), dim3(256), 0, S_, img, h, w, oh, ow, h_mean3[0],
+                       h_mean3[1], h_mean3[2], h_std3[0], h_std3[1], h_std3[2], out, W);
+    VBG_LAUNCH_RET();
+}
+
+extern "C" int vbg_rescale_boxes(const long long* in, int S, float ratio_h, float ratio_w, int* out, void* stream) {
+    VBG_CHECK_ARG(S >= 0);
+    if (S == 0) return VBG_OK;
+    VBG_CHECK_ARG(in && out);
+    hipLaunchKernelGGL(rescale_boxes_kernel, dim3(cdiv(S * 4, 256)), dim3(256), 0, S_, in, S * 4, ratio_h, ratio_w, out);
+    VBG_LAUNCH_RET();
+}
+
+extern "C" int vbg_im2col(const float* x, int B, int H, int W, int C, int kh, int kw, int stride, int pad, int Kpad, float* out,
+                          void* stream) {
+    VBG_CHECK_ARG(x && out && Kpad >= kh * kw * C && stride > 0);
+    const int Ho = (H + 2 * pad - kh) / stride + 1, Wo = (W + 2 * pad - kw) / stride + 1;
+    const long long total = (long long)B * Ho * Wo * Kpad;
+    if (total == 0) return VBG_OK;
+    hipLaunchKernelGGL(im2col_kernel, dim3(ew_grid(total, 256)), dim3(256), 0, S_, x, B, H, W, C, kh, kw, stride, pad, Ho, Wo, Kpad,
+                       out);
+    VBG_LAUNCH_RET();
+}

@@ -1,0 +1,466 @@
+// Row-wise kernels of the BERT encoder (transformers BertModel called at
+// model/BERTgrid_generator.py:134): embedding gather + LayerNorm, dropout + residual + LayerNorm,
+// attention softmax (+dropout), GELU / ReLU backward, bias-gradient column sums.
+// All HBM-bound: one pass over the rows, float4 where the layout allows, wave64 reductions.
+#include "vbg_common.h"
+#include "../../include/vbg.h"
+
+namespace vbg {
+
+constexpr int LN_THREADS = 256;
+constexpr int LN_MAXPER = 4;      // hidden <= 1024
+
+// ------------------------------------------------------------------------------------------
+// LayerNorm helpers: each thread owns columns tid, tid+256, ... (<= 4)
+// ------------------------------------------------------------------------------------------
+__device__ __forceinline__ void ln_forward_row(const float (&x)[LN_MAXPER], int hidden, float eps, float* sh,
+                                               float (&xhat)[LN_MAXPER], float& rstd) {
+    float s = 0.f;
+#pragma unroll
+    for (int j = 0; j < LN_MAXPER; ++j) if ((int)threadIdx.x + j * LN_THREADS < hidden) s += x[j];
+    const float mean = block_sum(s, sh) / (float)hidden;
+    float q = 0.f;
+#pragma unroll
+    for (int j = 0; j < LN_MAXPER; ++j) if ((int)threadIdx.x + j * LN_THREADS < hidden) { const float d = x[j] - mean; q += d * d; }
+    const float var = block_sum(q, sh) / (float)hidden;
+    rstd = 1.0f / sqrtf(var + eps);
+#pragma unroll
+    for (int j = 0; j < LN_MAXPER; ++j) xhat[j] = (x[j] - mean) * rstd;
+}
+
+__global__ __launch_bounds__(LN_THREADS) void embed_ln_fwd_kernel(
+    const int* __restrict__ ids, const int* __restrict__ pos_ids, int ntok, int hidden, const float* __restrict__ word,
+    const float* __restrict__ pos, const float* __restrict__ type0, const float* __restrict__ gamma,
+    const float* __restrict__ beta, float eps, uint32_t drop_thr, float keep_scale, uint64_t seed, uint64_t sid,
+    float* __restrict__ out, float* __restrict__ xhat_out, float* __restrict__ rstd_out) {
+    __shared__ float sh[16];
+    const int t = blockIdx.x;
+    if (t >= ntok) return;
+    const long long wid = ids[t], pid = pos_ids[t];
+    float x[LN_MAXPER], xh[LN_MAXPER];
+#pragma unroll
+    for (int j = 0; j < LN_MAXPER; ++j) {
+        const int c = threadIdx.x + j * LN_THREADS;
+        x[j] = (c < hidden) ? (word[wid * hidden + c] + type0[c]) + pos[pid * hidden + c] : 0.f;
+    }
+    float rstd;
+    ln_forward_row(x, hidden, eps, sh, xh, rstd);
+#pragma unroll
+    for (int j = 0; j < LN_MAXPER; ++j) {
+        const int c = threadIdx.x + j * LN_THREADS;
+        if (c < hidden) {
+            float y = xh[j] * gamma[c] + beta[c];
+            if (drop_thr) y = rng_keep(seed, sid, (uint64_t)t * hidden + c, drop_thr) ? y * keep_scale : 0.f;
+            out[(long long)t * hidden + c] = y;
+            xhat_out[(long long)t * hidden + c] = xh[j];
+        }
+    }
+    if (threadIdx.x == 0) rstd_out[t] = rstd;
+}
+
+// LN backward over a chunk of rows per block; returns dz for the row in `dz`
+__device__ __forceinline__ void ln_backward_row(const float (&g)[LN_MAXPER], const float (&xh)[LN_MAXPER],
+                                                const float (&gam)[LN_MAXPER], float rstd, int hidden, float* sh,
+                                                float (&dz)[LN_MAXPER]) {
+    float s1 = 0.f, s2 = 0.f;
+#pragma unroll
+    for (int j = 0; j < LN_MAXPER; ++j) {
+        if ((int)threadIdx.x + j * LN_THREADS < hidden) { const float d = g[j] * gam[j]; s1 += d; s2 += d * xh[j]; }
+    }
+    const float m1 = block_sum(s1, sh) / (float)hidden;
+    const float m2 = block_sum(s2, sh) / (float)hidden;
+#pragma unroll
+    for (int j = 0; j < LN_MAXPER; ++j) dz[j] = rstd * (g[j] * gam[j] - m1 - xh[j] * m2);
+}
+
+constexpr int LN_ROWS_PER_BLOCK = 16;
+
+__global__ __launch_bounds__(LN_THREADS) void embed_ln_bwd_kernel(
+    const float* __restrict__ dout, const float* __restrict__ xhat, const float* __restrict__ rstd,
+    const int* __restrict__ ids, const int* __restrict__ pos_ids, int ntok, int hidden, const float* __restrict__ gamma,
+    uint32_t drop_thr, float keep_scale, uint64_t seed, uint64_t sid, float* dword, float* dpos, float* dtype0,
+    float* dgamma, float* dbeta) {
+    __shared__ float sh[16];
+    float gam[LN_MAXPER], ag[LN_MAXPER], ab[LN_MAXPER], at[LN_MAXPER];
+#pragma unroll
+    for (int j = 0; j < LN_MAXPER; ++j) {
+        const int c = threadIdx.x + j * LN_THREADS;
+        gam[j] = (c < hidden) ? gamma[c] : 0.f;
+        ag[j] = ab[j] = at[j] = 0.f;
+    }
+    const int t0 = blockIdx.x * LN_ROWS_PER_BLOCK;
+    for (int t = t0; t < min(ntok, t0 + LN_ROWS_PER_BLOCK); ++t) {
+        float g[LN_MAXPER], xh[LN_MAXPER], dz[LN_MAXPER];
+#pragma unroll
+        for (int j = 0; j < LN_MAXPER; ++j) {
+            const int c = threadIdx.x + j * LN_THREADS;
+            g[j] = xh[j] = 0.f;
+            if (c < hidden) {
+                float v = dout[(long long)t * hidden + c];
+                if (drop_thr) v = rng_keep(seed, sid, (uint64_t)t * hidden + c, drop_thr) ? v * keep_scale : 0.f;
+                g[j] = v;
+                xh[j] = xhat[(long long)t * hidden + c];
+                ag[j] += v * xh[j];
+                ab[j] += v;
+            }
+        }
+        ln_backward_row(g, xh, gam, rstd[t], hidden, sh, dz);
+        const long long wid = ids[t], pid = pos_ids[t];
+#pragma unroll
+        for (int j = 0; j < LN_MAXPER; ++j) {
+            const int c = threadIdx.x + j * LN_THREADS;
+            if (c < hidden) {
+                unsafeAtomicAdd(dword + wid * hidden + c, dz[j]);
+                unsafeAtomicAdd(dpos + pid * hidden + c, dz[j]);
+                at[j] += dz[j];
+            }
+        }
+    }
+#pragma unroll
+    for (int j = 0; j < LN_MAXPER; ++j) {
+        const int c = threadIdx.x + j * LN_THREADS;
+        if (c < hidden) {
+            unsafeAtomicAdd(dgamma + c, ag[j]);
+            unsafeAtomicAdd(dbeta + c, ab[j]);
+            unsafeAtomicAdd(dtype0 + c, at[j]);
+        }
+    }
+}
+
+__global__ __launch_bounds__(LN_THREADS) void dropout_add_ln_fwd_kernel(
+    const float* __restrict__ x, const float* __restrict__ res, int rows, int hidden, const float* __restrict__ gamma,
+    const float* __restrict__ beta, float eps, uint32_t drop_thr, float keep_scale, uint64_t seed, uint64_t sid,
+    float* __restrict__ y, float* __restrict__ xhat_out, float* __restrict__ rstd_out) {
+    __shared__ float sh[16];
+    const int t = blockIdx.x;
+    if (t >= rows) return;
+    float z[LN_MAXPER], xh[LN_MAXPER];
+#pragma unroll
+    for (int j = 0; j < LN_MAXPER; ++j) {
+        const int c = threadIdx.x + j * LN_THREADS;
+        z[j] = 0.f;
+        if (c < hidden) {
+            float v = x[(long long)t * hidden + c];
+            if (drop_thr) v = rng_keep(seed, sid, (uint64_t)t * hidden + c, drop_thr) ? v * keep_scale : 0.f;
+            z[j] = v + res[(long long)t * hidden + c];
+        }
+    }
+    float rstd;
+    ln_forward_row(z, hidden, eps, sh, xh, rstd);
+#pragma unroll
+    for (int j = 0; j < LN_MAXPER; ++j) {
+        const int c = threadIdx.x + j * LN_THREADS;
+        if (c < hidden) {
+            y[(long long)t * hidden + c] = xh[j] * gamma[c] + beta[c];
+            xhat_out[(long long)t * hidden + c] = xh[j];
+        }
+    }
+    if (threadIdx.x == 0) rstd_out[t] = rstd;
+}
+
+__global__ __launch_bounds__(LN_THREADS) void dropout_add_ln_bwd_kernel(
+    const float* __restrict__ dy, const float* __restrict__ xhat, const float* __restrict__ rstd, int rows, int hidden,
+    const float* __restrict__ gamma, uint32_t drop_thr, float keep_scale, uint64_t seed, uint64_t sid,
+    float* __restrict__ dx, float* __restrict__ dres, float* dgamma, float* dbeta) {
+    __shared__ float sh[16];
+    float gam[LN_MAXPER], ag[LN_MAXPER], ab[LN_MAXPER];
+#pragma unroll
+    for (int j = 0; j < LN_MAXPER; ++j) {
+        const int c = threadIdx.x + j * LN_THREADS;
+        gam[j] = (c < hidden) ? gamma[c] : 0.f;
+        ag[j] = ab[j] = 0.f;
+    }
+    const int t0 = blockIdx.x * LN_ROWS_PER_BLOCK;
+    for (int t = t0; t < min(rows, t0 + LN_ROWS_PER_BLOCK); ++t) {
+        float g[LN_MAXPER], xh[LN_MAXPER], dz[LN_MAXPER];
+#pragma unroll
+        for (int j = 0; j < LN_MAXPER; ++j) {
+            const int c = threadIdx.x + j * LN_THREADS;
+            g[j] = xh[j] = 0.f;
+            if (c < hidden) {
+                g[j] = dy[(long long)t * hidden + c];
+                xh[j] = xhat[(long long)t * hidden + c];
+                ag[j] += g[j] * xh[j];
+                ab[j] += g[j];
+            }
+        }
+        ln_backward_row(g, xh, gam, rstd[t], hidden, sh, dz);
+#pragma unroll
+        for (int j = 0; j < LN_MAXPER; ++j) {
+            const int c = threadIdx.x + j * LN_THREADS;
+            if (c < hidden) {
+                const long long o = (long long)t * hidden + c;
+                dres[o] = dz[j];
+                float v = dz[j];
+                if (drop_thr) v = rng_keep(seed, sid, (uint64_t)t * hidden + c, drop_thr) ? v * keep_scale : 0.f;
+                dx[o] = v;
+            }
+        }
+    }
+#pragma unroll
+    for (int j = 0; j < LN_MAXPER; ++j) {
+        const int c = threadIdx.x + j * LN_THREADS;
+        if (c < hidden) {
+            unsafeAtomicAdd(dgamma + c, ag[j]);
+            unsafeAtomicAdd(dbeta + c, ab[j]);
+        }
+    }
+}
+
+// ------------------------------------------------------------------------------------------
+// attention softmax: one wave per (group, row); L <= 512 -> 8 elements per lane
+// ------------------------------------------------------------------------------------------
+constexpr int SM_PER = 8;
+
+__global__ __launch_bounds__(64) void softmax_fwd_kernel(float* s, const long long* __restrict__ off,
+                                                         const int* __restrict__ len, const int* __restrict__ ldp,
+                                                         int heads, int maxlen, float scale, uint32_t drop_thr,
+                                                         uint64_t seed, uint64_t sid) {
+    const int g = blockIdx.y, row = blockIdx.x, seq = g / heads;
+    const int L = len[seq];
+    if (row >= L) return;
+    const int ld = ldp[seq];
+    float* p = s + off[g] + (long long)row * ld;
+    const int lane = threadIdx.x;
+    float v[SM_PER];
+    float mx = -INFINITY;
+#pragma unroll
+    for (int j = 0; j < SM_PER; ++j) {
+        const int c = lane + j * 64;
+        v[j] = (c < L) ? p[c] * scale : -INFINITY;
+        mx = fmaxf(mx, v[j]);
+    }
+    mx = wave_max(mx);
+    float sum = 0.f;
+#pragma unroll
+    for (int j = 0; j < SM_PER; ++j) {
+        v[j] = (lane + j * 64 < L) ? __expf(v[j] - mx) : 0.f;
+        sum += v[j];
+    }
+    sum = wave_sum(sum);
+    const float inv = 1.0f / sum;
+    const uint64_t base = ((uint64_t)g * maxlen + row) * maxlen;
+#pragma unroll
+    for (int j = 0; j < SM_PER; ++j) {
+        const int c = lane + j * 64;
+        if (c < ld) {
+            float o = 0.f;
+            if (c < L) {
+                o = v[j] * inv;
+                if (drop_thr && !rng_keep(seed, sid, base + c, drop_thr)) o = -o;
+            }
+            p[c] = o;
+        }
+    }
+}
+
+__global__ __launch_bounds__(64) void softmax_bwd_kernel(const float* __restrict__ pbuf, float* dpbuf,
+                                                         const long long* __restrict__ off, const int* __restrict__ len,
+                                                         const int* __restrict__ ldp, int heads, float scale,
+                                                         float keep_scale) {
+    const int g = blockIdx.y, row = blockIdx.x, seq = g / heads;
+    const int L = len[seq];
+    if (row >= L) return;
+    const int ld = ldp[seq];
+    const float* p = pbuf + off[g] + (long long)row * ld;
+    float* dp = dpbuf + off[g] + (long long)row * ld;
+    const int lane = threadIdx.x;
+    float pv[SM_PER], dv[SM_PER];
+    float d = 0.f;
+#pragma unroll
+    for (int j = 0; j < SM_PER; ++j) {
+        const int c = lane + j * 64;
+        pv[j] = dv[j] = 0.f;
+        if (c < L) {
+            const float ps = p[c];
+            pv[j] = fabsf(ps);
+            // sign bit set (including -0.0) = dropped
+            dv[j] = (__float_as_uint(ps) >> 31) ? 0.f : dp[c] * keep_scale;
+            d += pv[j] * dv[j];
+        }
+    }
+    d = wave_sum(d);
+#pragma unroll
+    for (int j = 0; j < SM_PER; ++j) {
+        const int c = lane + j * 64;
+        if (c < ld) dp[c] = (c < L) ? scale * pv[j] * (dv[j] - d) : 0.f;
+    }
+}
+
+// ------------------------------------------------------------------------------------------
+__global__ void gelu_bwd_kernel(const float* __restrict__ h, float* dg, long long n4, long long n) {
+    const long long stride = (long long)gridDim.x * blockDim.x;
+    for (long long i = (long long)blockIdx.x * blockDim.x + threadIdx.x; i < n4; i += stride) {
+        const float4 hv = reinterpret_cast<const float4*>(h)[i];
+        float4 g = reinterpret_cast<float4*>(dg)[i];
+        g.x *= gelu_erf_grad(hv.x); g.y *= gelu_erf_grad(hv.y); g.z *= gelu_erf_grad(hv.z); g.w *= gelu_erf_grad(hv.w);
+        reinterpret_cast<float4*>(dg)[i] = g;
+    }
+    if (blockIdx.x == 0) for (long long i = n4 * 4 + threadIdx.x; i < n; i += blockDim.x) dg[i] *= gelu_erf_grad(h[i]);
+}
+
+__global__ void relu_bwd_kernel(const float* __restrict__ y, float* dy, long long n4, long long n) {
+    const long long stride = (long long)gridDim.x * blockDim.x;
+    for (long long i = (long long)blockIdx.x * blockDim.x + threadIdx.x; i < n4; i += stride) {
+        const float4 yv = reinterpret_cast<const float4*>(y)[i];
+        float4 g = reinterpret_cast<float4*>(dy)[i];
+        g.x = yv.x > 0.f ? g.x : 0.f; g.y = yv.y > 0.f ? g.y : 0.f; g.z = yv.z > 0.f ? g.z : 0.f; g.w = yv.w > 0.f ? g.w : 0.f;
+        reinterpret_cast<float4*>(dy)[i] = g;
+    }
+    if (blockIdx.x == 0) for (long long i = n4 * 4 + threadIdx.x; i < n; i += blockDim.x) dy[i] = y[i] > 0.f ? dy[i] : 0.f;
+}
+
+__global__ void add_inplace_kernel(float* a, const float* __restrict__ b, long long n4, long long n) {
+    const long long stride = (long long)gridDim.x * blockDim.x;
+    for (long long i = (long long)blockIdx.x * blockDim.x + threadIdx.x; i < n4; i += stride) {
+        float4 x = reinterpret_cast<float4*>(a)[i];
+        const float4 y = reinterpret_cast<const float4*>(b)[i];
+        x.x += y.x; x.y += y.y; x.z += y.z; x.w += y.w;
+        reinterpret_cast<float4*>(a)[i] = x;
+    }
+    if (blockIdx.x == 0) for (long long i = n4 * 4 + threadIdx.x; i < n; i += blockDim.x) a[i] += b[i];
+}
+
+__global__ void scale_inplace_kernel(float* a, long long n, float s) {
+    const long long stride = (long long)gridDim.x * blockDim.x;
+    for (long long i = (long long)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += stride) a[i] *= s;
+}
+
+// column sums: block = 64 columns x 4 row lanes, 256 rows per block
+__global__ __launch_bounds__(256) void colsum_kernel(const float* __restrict__ x, long long ld, int M, int N, float* out) {
+    __shared__ float sh[4][64];
+    const int c = blockIdx.x * 64 + (threadIdx.x & 63);
+    const int rl = threadIdx.x >> 6;
+    const int r0 = blockIdx.y * 256;
+    float s = 0.f;
+    if (c < N) {
+        for (int r = r0 + rl; r < min(M, r0 + 256); r += 4) s += x[(long long)r * ld + c];
+    }
+    sh[rl][threadIdx.x & 63] = s;
+    __syncthreads();
+    if (rl == 0 && c < N) unsafeAtomicAdd(out + c, sh[0][threadIdx.x] + sh[1][threadIdx.x] + sh[2][threadIdx.x] + sh[3][threadIdx.x]);
+}
+
+static inline int ew_grid(long long n, int block) {
+    long long g = (n + block - 1) / block;
+    if (g > 256 * 8) g = 256 * 8;
+    if (g < 1) g = 1;
+    return (int)g;
+}
+
+}  // namespace vbg
+
+using namespace vbg;
+
+extern "C" int vbg_embed_ln_fwd(const int* ids, const int* pos_ids, int ntok, int hidden, const float* word,
+                                const float* pos, const float* type0, const float* gamma, const float* beta, float eps,
+                                float drop_p, unsigned long long seed, unsigned long long sid, float* out, float* xhat,
+                                float* rstd, void* stream) {
+    VBG_CHECK_ARG(ids && pos_ids && word && pos && type0 && gamma && beta && out && xhat && rstd);
+    VBG_CHECK_ARG(hidden > 0 && hidden <= LN_THREADS * LN_MAXPER && drop_p >= 0.f && drop_p < 1.f);
+    if (ntok <= 0) return VBG_OK;
+    hipLaunchKernelGGL(embed_ln_fwd_kernel, dim3(ntok), dim3(LN_THREADS), 0, (hipStream_t)stream, ids, pos_ids, ntok, hidden,
+                       word, pos, type0, gamma, beta, eps, drop_threshold(drop_p), 1.0f / (1.0f - drop_p), seed, sid, out,
+                       xhat, rstd);
+    VBG_LAUNCH_RET();
+}
+
+extern "C" int vbg_embed_ln_bwd(const float* dout, const float* xhat, const float* rstd, const int* ids, const int* pos_ids,
+                                int ntok, int hidden, const float* gamma, float drop_p, unsigned long long seed,
+                                unsigned long long sid, float* dword, float* dpos, float* dtype0, float* dgamma,
+                                float* dbeta, void* stream) {
+    VBG_CHECK_ARG(dout && xhat && rstd && ids && pos_ids && gamma && dword && dpos && dtype0 && dgamma && dbeta);
+    VBG_CHECK_ARG(hidden > 0 && hidden <= LN_THREADS * LN_MAXPER && drop_p >= 0.f && drop_p < 1.f);
+    if (ntok <= 0) return VBG_OK;
+    hipLaunchKernelGGL(embed_ln_bwd_kernel, dim3(cdiv(ntok, LN_ROWS_PER_BLOCK)), dim3(LN_THREADS), 0, (hipStream_t)stream,
+                       dout, xhat, rstd, ids, pos_ids, ntok, hidden, gamma, drop_threshold(drop_p), 1.0f / (1.0f - drop_p),
+                       seed, sid, dword, dpos, dtype0, dgamma, dbeta);
+    VBG_LAUNCH_RET();
+}
+
+extern "C" int vbg_dropout_add_ln_fwd(const float* x, const float* res, int rows, int hidden, const float* gamma,
+                                      const float* beta, float eps, float drop_p, unsigned long long seed,
+                                      unsigned long long sid, float* y, float* xhat, float* rstd, void* stream) {
+    VBG_CHECK_ARG(x && res && gamma && beta && y && xhat && rstd);
+    VBG_CHECK_ARG(hidden > 0 && hidden <= LN_THREADS * LN_MAXPER && drop_p >= 0.f && drop_p < 1.f);
+    if (rows <= 0) return VBG_OK;
+    hipLaunchKernelGGL(dropout_add_ln_fwd_kernel, dim3(rows), dim3(LN_THREADS), 0, (hipStream_t)stream, x, res, rows, hidden,
+                       gamma, beta, eps, drop_threshold(drop_p), 1.0f / (1.0f - drop_p), seed, sid, y, xhat, rstd);
+    VBG_LAUNCH_RET();
+}
+
+extern "C" int vbg_dropout_add_ln_bwd(const float* dy, const float* xhat, const float* rstd, int rows, int hidden,
+                                      const float* gamma, float drop_p, unsigned long long seed, unsigned long long sid,
+                                      float* dx, float* dres, float* dgamma, float* dbeta, void* stream) {
+    VBG_CHECK_ARG(dy && xhat && rstd && gamma && dx && dres && dgamma && dbeta);
+    VBG_CHECK_ARG(hidden > 0 && hidden <= LN_THREADS * LN_MAXPER && drop_p >= 0.f && drop_p < 1.f);
+    if (rows <= 0) return VBG_OK;
+    hipLaunchKernelGGL(dropout_add_ln_bwd_kernel, dim3(cdiv(rows, LN_ROWS_PER_BLOCK)), dim3(LN_THREADS), 0,
+                       (hipStream_t)stream, dy, xhat, rstd, rows, hidden, gamma, drop_threshold(drop_p),
+                       1.0f / (1.0f - drop_p), seed, sid, dx, dres, dgamma, dbeta);
+    VBG_LAUNCH_RET();
+}
+
+extern "C" int vbg_softmax_fwd(float* s, const long long* off, const int* len, const int* ldp, int ngroups, int heads,
+                               int maxlen, float scale, float drop_p, unsigned long long seed, unsigned long long sid,
+                               void* stream) {
+    VBG_CHECK_ARG(s && off && len && ldp && heads > 0 && ngroups >= 0 && ngroups % heads == 0);
+    VBG_CHECK_ARG(maxlen >= 0 && maxlen <= 64 * SM_PER && drop_p >= 0.f && drop_p < 1.f);
+    if (ngroups == 0 || maxlen == 0) return VBG_OK;
+    hipLaunchKernelGGL(softmax_fwd_kernel, dim3(maxlen, ngroups), dim3(64), 0, (hipStream_t)stream, s, off, len, ldp, heads,
+                       maxlen, scale, drop_threshold(drop_p), seed, sid);
+    VBG_LAUNCH_RET();
+}
+
+extern "C" int vbg_softmax_bwd(const float* p, float* dp, const long long* off, const int* len, const int* ldp, int ngroups,
+                               int heads, int maxlen, float scale, float drop_p, void* stream) {
+    VBG_CHECK_ARG(p && dp && off && len && ldp && heads > 0 && ngroups >= 0 && ngroups % heads == 0);
+    VBG_CHECK_ARG(maxlen >= 0 && maxlen <= 64 * SM_PER && drop_p >= 0.f && drop_p < 1.f);
+    if (ngroups == 0 || maxlen == 0) return VBG_OK;
+    hipLaunchKernelGGL(softmax_bwd_kernel, dim3(maxlen, ngroups), dim3(64), 0, (hipStream_t)stream, p, dp, off, len, ldp,
+                       heads, scale, 1.0f / (1.0f - drop_p));
+    VBG_LAUNCH_RET();
+}
+
+extern "C" int vbg_gelu_bwd(const float* h, float* dg, long long n, void* stream) {
+    VBG_CHECK_ARG(h && dg && n >= 0);
+    if (n == 0) return VBG_OK;
+    hipLaunchKernelGGL(gelu_bwd_kernel, dim3(ew_grid(n / 4, 256)), dim3(256), 0, (hipStream_t)stream, h, dg, n / 4, n);
+    VBG_LAUNCH_RET();
+}
+
+extern "C" int vbg_relu_bwd(const float* y, float* dy, long long n, void* stream) {
+    VBG_CHECK_ARG(y && dy && n >= 0);
+    if (n == 0) return VBG_OK;
+    hipLaunchKernelGGL(relu_bwd_kernel, dim3(ew_grid(n / 4, 256)), dim3(256), 0, (hipStream_t)stream, y, dy, n / 4, n);
+    VBG_LAUNCH_RET();
+}
+
+extern "C" int vbg_add_inplace(float* a, const float* b, long long n, void* stream) {
+    VBG_CHECK_ARG(a && b && n >= 0);
+    if (n == 0) return VBG_OK;
+    hipLaunchKernelGGL(add_inplace_kernel, dim3(ew_grid(n / 4, 256)), dim3(256), 0, (hipStream_t)stream, a, b, n / 4, n);
+    VBG_LAUNCH_RET();
+}
+
+extern "C" int vbg_scale_inplace(float* x, long long n, float s, void* stream) {
+    VBG_CHECK_ARG(x && n >= 0);
+    if (n == 0) return VBG_OK;
+    hipLaunchKernelGGL(scale_inplace_kernel, dim3(ew_grid(n, 256)), dim3(256), 0, (hipStream_t)stream, x, n, s);
+    VBG_LAUNCH_RET();
+}
+
+extern "C" int vbg_colsum(const float* x, long long ld, int M, int N, float* out, int accumulate, void* stream) {
+    VBG_CHECK_ARG(x && out && M >= 0 && N >= 0);
+    if (N == 0) return VBG_OK;
+    hipStream_t s = (hipStream_t)stream;
+    if (!accumulate) {
+        hipError_t e = hipMemsetAsync(out, 0, sizeof(float) * (size_t)N, s);
+        if (e != hipSuccess) return (int)e;
+    }
+    if (M == 0) return VBG_OK;
+    hipLaunchKernelGGL(colsum_kernel, dim3(cdiv(N, 64), cdiv(M, 256)), dim3(256), 0, s, x, ld, M, N, out);
+    VBG_LAUNCH_RET();
+}
+
+extern "C" int vbg_version(void) { return VBG_VERSION; }

@@ -1,0 +1,80 @@
+// Shared device/host helpers for libvbg (gfx950 only).
+#pragma once
+#include <hip/hip_runtime.h>
+#include <stdint.h>
+
+#define VBG_OK 0
+#define VBG_EARG (-1)
+
+// every C-ABI entry point: 0 ok, negative = argument error, positive = hipError_t
+#define VBG_CHECK_ARG(cond) do { if (!(cond)) return VBG_EARG; } while (0)
+#define VBG_LAUNCH_RET() do { hipError_t e__ = hipGetLastError(); return e__ == hipSuccess ? VBG_OK : (int)e__; } while (0)
+
+typedef float f32x4 __attribute__((ext_vector_type(4)));
+typedef float f32x16 __attribute__((ext_vector_type(16)));
+
+namespace vbg {
+
+static inline int cdiv(long a, long b) { return (int)((a + b - 1) / b); }
+
+// ---- wave / block reductions (wave = 64 lanes) ------------------------------------------
+__device__ __forceinline__ float wave_sum(float v) {
+#pragma unroll
+    for (int o = 32; o > 0; o >>= 1) v += __shfl_xor(v, o, 64);
+    return v;
+}
+__device__ __forceinline__ float wave_max(float v) {
+#pragma unroll
+    for (int o = 32; o > 0; o >>= 1) v = fmaxf(v, __shfl_xor(v, o, 64));
+    return v;
+}
+// block reduce for blockDim.x <= 1024 (multiple of 64); `sh` has >= 16 floats; result broadcast
+__device__ __forceinline__ float block_sum(float v, float* sh) {
+    const int lane = threadIdx.x & 63, w = threadIdx.x >> 6, nw = (blockDim.x + 63) >> 6;
+    v = wave_sum(v);
+    __syncthreads();
+    if (lane == 0) sh[w] = v;
+    __syncthreads();
+    float r = 0.f;
+    for (int i = 0; i < nw; ++i) r += sh[i];
+    return r;
+}
+__device__ __forceinline__ float block_max(float v, float* sh) {
+    const int lane = threadIdx.x & 63, w = threadIdx.x >> 6, nw = (blockDim.x + 63) >> 6;
+    v = wave_max(v);
+    __syncthreads();
+    if (lane == 0) sh[w] = v;
+    __syncthreads();
+    float r = sh[0];
+    for (int i = 1; i < nw; ++i) r = fmaxf(r, sh[i]);
+    return r;
+}
+
+// ---- counter-based RNG for dropout: one 32-bit draw per (seed, stream, index) ----------
+// (splitmix64-style finaliser; deterministic, so backward regenerates the forward mask)
+__host__ __device__ __forceinline__ uint32_t rng_u32(uint64_t seed, uint64_t stream, uint64_t idx) {
+    uint64_t z = seed + 0x9E3779B97F4A7C15ull * (stream + 1) + idx * 0xBF58476D1CE4E5B9ull;
+    z ^= z >> 30; z *= 0xBF58476D1CE4E5B9ull;
+    z ^= z >> 27; z *= 0x94D049BB133111EBull;
+    z ^= z >> 31;
+    return (uint32_t)(z >> 16);
+}
+// keep with probability 1-p: threshold on a 32-bit draw
+__host__ __device__ __forceinline__ bool rng_keep(uint64_t seed, uint64_t stream, uint64_t idx, uint32_t drop_thresh) {
+    return rng_u32(seed, stream, idx) >= drop_thresh;
+}
+static inline uint32_t drop_threshold(float p) {
+    double t = (double)p * 4294967296.0;
+    if (t <= 0) return 0u;
+    if (t >= 4294967295.0) return 4294967295u;
+    return (uint32_t)t;
+}
+
+__device__ __forceinline__ float gelu_erf(float x) { return 0.5f * x * (1.0f + erff(x * 0.70710678118654752440f)); }
+__device__ __forceinline__ float gelu_erf_grad(float x) {
+    const float cdf = 0.5f * (1.0f + erff(x * 0.70710678118654752440f));
+    const float pdf = 0.39894228040143267794f * __expf(-0.5f * x * x);
+    return cdf + x * pdf;
+}
+
+}  // namespace vbg

@@ -1,0 +1,113 @@
+"""ctypes binding of libvbg.so (the C-ABI declared in include/vbg.h).
+
+The library is the product: there is NO fallback.  If `libvbg.so` is missing or a symbol is
+absent the import fails loudly (build it with `python -c "import __graft_entry__ as g; g.build()"`
+or `make -C vibertgrid-pytorch_amd/csrc`).
+"""
+import ctypes as C
+import os
+
+_HERE = os.path.dirname(os.path.abspath(__file__))
+LIB_PATH = os.path.join(os.path.dirname(_HERE), "libvbg.so")
+
+c_int, c_ll, c_f, c_d, c_vp, c_ull = C.c_int, C.c_longlong, C.c_float, C.c_double, C.c_void_p, C.c_ulonglong
+
+
+class ConvGeo(C.Structure):
+    _fields_ = [("Hs", c_int), ("Ws", c_int), ("Cs", c_int), ("Hr", c_int), ("Wr", c_int), ("kh", c_int), ("kw", c_int),
+                ("stride", c_int), ("pad", c_int), ("dgrad", c_int)]
+
+
+class GemmDesc(C.Structure):
+    _fields_ = [("M", c_int), ("N", c_int), ("K", c_int),
+                ("A", c_vp), ("lda", c_ll), ("a_kind", c_int), ("a_vec", c_int),
+                ("a_nseg", c_int), ("a_seg_ptr", c_vp * 4), ("a_seg_kend", c_int * 4), ("a_seg_ld", c_ll * 4),
+                ("a_seg_shift", c_int * 4), ("a_H", c_int), ("a_W", c_int),
+                ("a_prologue", c_int), ("a_scale", c_f),
+                ("B", c_vp), ("ldb", c_ll), ("b_kind", c_int), ("b_vec", c_int),
+                ("geo", ConvGeo),
+                ("C", c_vp), ("ldc", c_ll), ("C2", c_vp), ("bias", c_vp),
+                ("epi", c_int), ("alpha", c_f), ("accumulate", c_int), ("splitk", c_int), ("tile", c_int),
+                ("grp", c_vp), ("ngroups", c_int), ("grp_maxM", c_int), ("grp_maxN", c_int)]
+
+
+OP_DENSE_K, OP_DENSE_R, OP_CONV_K, OP_CONV_R, OP_WT_R = 0, 1, 2, 3, 4
+EPI_NONE, EPI_RELU, EPI_GELU_DUAL = 0, 1, 2
+
+# name -> (restype, argtypes); must list EVERY symbol include/vbg.h declares (tests check this)
+SIGNATURES = {
+    "vbg_version": (c_int, []),
+    "vbg_gemm": (c_int, [C.POINTER(GemmDesc), c_vp]),
+    "vbg_colsum": (c_int, [c_vp, c_ll, c_int, c_int, c_vp, c_int, c_vp]),
+    "vbg_im2col": (c_int, [c_vp, c_int, c_int, c_int, c_int, c_int, c_int, c_int, c_int, c_int, c_vp, c_vp]),
+    "vbg_normalize_resize": (c_int, [c_vp, c_int, c_int, c_int, c_int, C.POINTER(c_f), C.POINTER(c_f), c_vp, c_int, c_int, c_int, c_vp]),
+    "vbg_rescale_boxes": (c_int, [c_vp, c_int, c_f, c_f, c_vp, c_vp]),
+    "vbg_embed_ln_fwd": (c_int, [c_vp, c_vp, c_int, c_int, c_vp, c_vp, c_vp, c_vp, c_vp, c_f, c_f, c_ull, c_ull, c_vp, c_vp, c_vp, c_vp]),
+    "vbg_embed_ln_bwd": (c_int, [c_vp, c_vp, c_vp, c_vp, c_vp, c_int, c_int, c_vp, c_f, c_ull, c_ull, c_vp, c_vp, c_vp, c_vp, c_vp, c_vp]),
+    "vbg_dropout_add_ln_fwd": (c_int, [c_vp, c_vp, c_int, c_int, c_vp, c_vp, c_f, c_f, c_ull, c_ull, c_vp, c_vp, c_vp, c_vp]),
+    "vbg_dropout_add_ln_bwd": (c_int, [c_vp, c_vp, c_vp, c_int, c_int, c_vp, c_f, c_ull, c_ull, c_vp, c_vp, c_vp, c_vp, c_vp]),
+    "vbg_softmax_fwd": (c_int, [c_vp, c_vp, c_vp, c_vp, c_int, c_int, c_int, c_f, c_f, c_ull, c_ull, c_vp]),
+    "vbg_softmax_bwd": (c_int, [c_vp, c_vp, c_vp, c_vp, c_vp, c_int, c_int, c_int, c_f, c_f, c_vp]),
+    "vbg_gelu_bwd": (c_int, [c_vp, c_vp, c_ll, c_vp]),
+    "vbg_relu_bwd": (c_int, [c_vp, c_vp, c_ll, c_vp]),
+    "vbg_add_inplace": (c_int, [c_vp, c_vp, c_ll, c_vp]),
+    "vbg_scale_inplace": (c_int, [c_vp, c_ll, c_f, c_vp]),
+    "vbg_seg_reduce_fwd": (c_int, [c_vp, c_vp, c_vp, c_vp, c_int, c_int, c_int, c_vp, c_vp]),
+    "vbg_seg_reduce_bwd": (c_int, [c_vp, c_vp, c_vp, c_vp, c_int, c_int, c_int, c_vp, c_vp]),
+    "vbg_owner_map": (c_int, [c_vp, c_vp, c_int, c_int, c_int, c_int, c_vp, c_vp]),
+    "vbg_grid_scatter_fwd": (c_int, [c_vp, c_vp, c_int, c_int, c_int, c_int, c_int, c_vp, c_vp]),
+    "vbg_grid_scatter_bwd": (c_int, [c_vp, c_vp, c_vp, c_vp, c_int, c_int, c_int, c_int, c_int, c_vp, c_vp]),
+    "vbg_label_raster": (c_int, [c_vp, c_vp, c_ll, c_vp, c_vp, c_vp]),
+    "vbg_bn_stats": (c_int, [c_vp, c_ll, c_int, c_vp, c_vp]),
+    "vbg_bn_finalize": (c_int, [c_vp, c_d, c_int, c_f, c_f, c_vp, c_vp, c_vp, c_vp, c_vp]),
+    "vbg_bn_apply": (c_int, [c_vp, c_vp, c_ll, c_int, c_vp, c_vp, c_vp, c_vp, c_int, c_vp, c_vp]),
+    "vbg_bn_bwd_reduce": (c_int, [c_vp, c_vp, c_vp, c_ll, c_int, c_vp, c_vp, c_int, c_vp, c_vp]),
+    "vbg_bn_bwd_apply": (c_int, [c_vp, c_vp, c_vp, c_ll, c_int, c_vp, c_vp, c_vp, c_vp, c_d, c_int, c_vp, c_vp, c_vp, c_vp, c_vp]),
+    "vbg_maxpool3x3s2_fwd": (c_int, [c_vp, c_int, c_int, c_int, c_int, c_vp, c_vp, c_vp]),
+    "vbg_maxpool3x3s2_bwd": (c_int, [c_vp, c_vp, c_int, c_int, c_int, c_int, c_int, c_int, c_vp, c_vp]),
+    "vbg_upsample2_add": (c_int, [c_vp, c_vp, c_int, c_int, c_int, c_int, c_vp, c_vp]),
+    "vbg_sumpool": (c_int, [c_vp, c_int, c_int, c_int, c_int, c_int, c_vp, c_int, c_vp]),
+    "vbg_nchw_to_nhwc": (c_int, [c_vp, c_int, c_int, c_int, c_vp, c_vp]),
+    "vbg_nhwc_to_nchw": (c_int, [c_vp, c_int, c_int, c_int, c_vp, c_vp]),
+    "vbg_upsample_nhwc_to_nchw": (c_int, [c_vp, c_int, c_int, c_int, c_int, c_int, c_vp, c_vp]),
+    "vbg_roi_align_fwd": (c_int, [c_vp, c_int, c_int, c_int, c_int, c_vp, c_vp, c_int, c_int, c_f, c_vp, c_vp]),
+    "vbg_roi_align_bwd": (c_int, [c_vp, c_int, c_int, c_int, c_int, c_vp, c_vp, c_int, c_int, c_f, c_vp, c_vp]),
+    "vbg_ce_fwd": (c_int, [c_vp, c_ll, c_int, c_vp, c_vp, c_ll, c_vp, c_int, c_int, c_int, c_vp, c_vp]),
+    "vbg_ce_bwd": (c_int, [c_vp, c_ll, c_int, c_vp, c_vp, c_ll, c_vp, c_vp, c_f, c_int, c_int, c_int, c_vp, c_vp]),
+    "vbg_compact_ws_bytes": (c_ll, [c_ll]),
+    "vbg_compact": (c_int, [c_vp, c_ll, c_int, c_int, c_vp, c_vp, c_vp, c_ll, c_vp]),
+    "vbg_sort_ws_bytes": (c_ll, [c_ll]),
+    "vbg_sort_desc": (c_int, [c_vp, c_ll, c_vp, c_vp, c_vp, c_ll, c_vp]),
+    "vbg_gather_f32": (c_int, [c_vp, c_vp, c_ll, c_vp, c_vp]),
+    "vbg_gather_i32": (c_int, [c_vp, c_vp, c_ll, c_vp, c_vp]),
+    "vbg_sum_f32": (c_int, [c_vp, c_ll, c_vp, c_vp]),
+    "vbg_sumsq": (c_int, [c_vp, c_ll, c_vp, c_vp]),
+    "vbg_sgd_step": (c_int, [c_vp, c_vp, c_vp, c_ll, c_f, c_f, c_f, c_int, c_f, c_vp]),
+    "vbg_adamw_step": (c_int, [c_vp, c_vp, c_vp, c_vp, c_ll, c_f, c_f, c_f, c_f, c_f, c_int, c_f, c_vp]),
+}
+
+
+class VbgError(RuntimeError):
+    pass
+
+
+def _load():
+    if not os.path.exists(LIB_PATH):
+        raise ImportError(
+            f"{LIB_PATH} not found: the HIP library is the product and there is no fallback. "
+            "Build it with `make -C vibertgrid-pytorch_amd/csrc` (hipcc, gfx950).")
+    lib = C.CDLL(LIB_PATH)
+    for name, (res, args) in SIGNATURES.items():
+        fn = getattr(lib, name)           # AttributeError if the .so lacks a declared symbol
+        fn.restype = res
+        fn.argtypes = args
+    return lib
+
+
+lib = _load()
+
+
+def check(rc: int, what: str):
+    if rc != 0:
+        kind = "argument error" if rc < 0 else f"hipError {rc}"
+        raise VbgError(f"{what} failed: {kind}")

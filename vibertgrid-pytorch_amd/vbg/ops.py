@@ -1,0 +1,519 @@
+"""Thin torch-tensor -> raw-pointer shims over the C-ABI (vbg/lib.py).  PyTorch is used for device
+memory and streams only; every function below launches hand-written HIP kernels on the CURRENT
+stream and never synchronises.  No fallbacks: tensors must live on a GPU."""
+import ctypes as C
+
+import torch
+
+from .lib import (EPI_GELU_DUAL, EPI_NONE, EPI_RELU, OP_CONV_K, OP_CONV_R, OP_DENSE_K, OP_DENSE_R, OP_WT_R, ConvGeo,
+                  GemmDesc, check, lib)
+
+f32 = torch.float32
+i32 = torch.int32
+
+
+def _stream():
+    return C.c_void_p(torch.cuda.current_stream().cuda_stream)
+
+
+def P(t):
+    if t is None:
+        return None
+    assert t.is_cuda, "libvbg operates on device memory only"
+    return C.c_void_p(t.data_ptr())
+
+
+def _vec_ok(t_ptr: int, ld: int) -> int:
+    return int(t_ptr % 16 == 0 and ld % 4 == 0)
+
+
+def _chk_f32(*ts):
+    for t in ts:
+        if t is not None:
+            assert t.is_cuda and t.dtype == f32, (t.device, t.dtype)
+
+
+# ----------------------------------------------------------------------------------------------
+# GEMM family
+# ----------------------------------------------------------------------------------------------
+def gemm_raw(M, N, K, A, lda, a_kind, B, ldb, b_kind, Cout, ldc, *, bias=None, epi=EPI_NONE, C2=None, accumulate=False,
+             splitk=1, geo=None, segs=None, a_hw=(0, 0), a_relu_scale=None, grp=None, ngroups=0, grp_max=(0, 0), tile=0,
+             alpha=1.0, a_ptr_off=0, b_ptr_off=0, c_ptr_off=0):
+    """A, B, Cout: tensors (their data_ptr + element offsets are used)."""
+    d = GemmDesc()
+    d.M, d.N, d.K = int(M), int(N), int(K)
+    ap = A.data_ptr() + 4 * a_ptr_off
+    bp = B.data_ptr() + 4 * b_ptr_off
+    d.A, d.lda, d.a_kind = ap, int(lda), a_kind
+    d.B, d.ldb, d.b_kind = bp, int(ldb), b_kind
+    d.a_vec = _vec_ok(ap, lda)
+    d.b_vec = _vec_ok(bp, ldb)
+    if segs:
+        d.a_nseg = len(segs)
+        vec = 1
+        for i, (t, kend, ld, sh) in enumerate(segs):
+            d.a_seg_ptr[i] = t.data_ptr()
+            d.a_seg_kend[i] = int(kend)
+            d.a_seg_ld[i] = int(ld)
+            d.a_seg_shift[i] = int(sh)
+            vec &= _vec_ok(t.data_ptr(), ld)
+        d.a_vec = vec
+        d.a_H, d.a_W = int(a_hw[0]), int(a_hw[1])
+    if a_relu_scale is not None:
+        d.a_prologue, d.a_scale = 1, float(a_relu_scale)
+    if geo is not None:
+        d.geo = geo
+    d.C, d.ldc = Cout.data_ptr() + 4 * c_ptr_off, int(ldc)
+    d.C2 = None if C2 is None else C2.data_ptr() + 4 * c_ptr_off
+    d.bias = None if bias is None else bias.data_ptr()
+    d.epi, d.alpha, d.accumulate, d.splitk, d.tile = epi, float(alpha), int(bool(accumulate)), int(splitk), int(tile)
+    if grp is not None:
+        d.grp, d.ngroups = grp.data_ptr(), int(ngroups)
+        d.grp_maxM, d.grp_maxN = int(grp_max[0]), int(grp_max[1])
+    check(lib.vbg_gemm(C.byref(d), _stream()), "vbg_gemm")
+
+
+def _pick_splitk(M, N, Kred, bk=16):
+    """Split the reduction when the output has too few tiles to fill 256 CUs."""
+    tiles = ((M + 127) // 128) * ((N + 127) // 128)
+    if tiles >= 128:
+        return 1
+    tiles64 = ((M + 63) // 64) * ((N + 63) // 64)
+    nkt = (Kred + bk - 1) // bk
+    want = max(1, 512 // max(tiles64, 1))
+    return int(max(1, min(want, nkt // 8 if nkt >= 16 else 1, 64)))
+
+
+def linear_fwd(x, w, bias=None, epi=EPI_NONE, out=None, out2=None):
+    """y[M,N] = x[M,K] @ w[N,K]^T (+bias) ; rows of x may be strided (x.stride(0))."""
+    _chk_f32(x, w, bias)
+    M, K = x.shape
+    N = w.shape[0]
+    assert w.shape[1] == K and x.stride(1) == 1 and w.stride(1) == 1
+    if out is None:
+        out = torch.empty((M, N), device=x.device, dtype=f32)
+    if epi == EPI_GELU_DUAL and out2 is None:
+        out2 = torch.empty_like(out)
+    gemm_raw(M, N, K, x, x.stride(0), OP_DENSE_K, w, w.stride(0), OP_DENSE_K, out, out.stride(0), bias=bias, epi=epi, C2=out2)
+    return (out, out2) if epi == EPI_GELU_DUAL else out
+
+
+def linear_dgrad(dy, w, out=None, accumulate=False):
+    """dx[M,K] (+)= dy[M,N] @ w[N,K]"""
+    _chk_f32(dy, w)
+    M, N = dy.shape
+    K = w.shape[1]
+    assert w.shape[0] == N and dy.stride(1) == 1 and w.stride(1) == 1
+    if out is None:
+        assert not accumulate
+        out = torch.empty((M, K), device=dy.device, dtype=f32)
+    gemm_raw(M, K, N, dy, dy.stride(0), OP_DENSE_K, w, w.stride(0), OP_DENSE_R, out, out.stride(0), accumulate=accumulate)
+    return out
+
+
+def linear_wgrad(dy, x, out, accumulate=True):
+    """dw[N,K] (+)= dy[M,N]^T @ x[M,K]   (split over M with atomics when dw has few tiles)"""
+    _chk_f32(dy, x, out)
+    M, N = dy.shape
+    K = x.shape[1]
+    assert x.shape[0] == M and out.shape == (N, K) and dy.stride(1) == 1 and x.stride(1) == 1
+    sk = _pick_splitk(N, K, M)
+    if not accumulate and sk > 1:
+        out.zero_()
+    gemm_raw(N, K, M, dy, dy.stride(0), OP_DENSE_R, x, x.stride(0), OP_DENSE_R, out, out.stride(0),
+             accumulate=(accumulate or sk > 1), splitk=sk)
+    return out
+
+
+def colsum(x, out=None, accumulate=False):
+    _chk_f32(x)
+    M, N = x.shape
+    assert x.stride(1) == 1
+    if out is None:
+        out = torch.empty((N,), device=x.device, dtype=f32)
+        accumulate = False
+    check(lib.vbg_colsum(P(x), x.stride(0), M, N, P(out), int(accumulate), _stream()), "vbg_colsum")
+    return out
+
+
+def conv_geo(Hs, Ws, Cs, Hr, Wr, kh, kw, stride, pad, dgrad=0):
+    g = ConvGeo()
+    g.Hs, g.Ws, g.Cs, g.Hr, g.Wr, g.kh, g.kw, g.stride, g.pad, g.dgrad = Hs, Ws, Cs, Hr, Wr, kh, kw, stride, pad, dgrad
+    return g
+
+
+def conv_out_hw(H, W, k, stride, pad):
+    return (H + 2 * pad - k) // stride + 1, (W + 2 * pad - k) // stride + 1
+
+
+def conv2d_fwd(x, w_ohwi, stride, pad, bias=None, out=None):
+    """x NHWC [B,H,W,Cin] contiguous; w_ohwi [Cout,kh,kw,Cin] contiguous -> y NHWC [B,Ho,Wo,Cout]."""
+    _chk_f32(x, w_ohwi, bias)
+    B, H, W, Cin = x.shape
+    Cout, kh, kw, _ = w_ohwi.shape
+    assert x.is_contiguous() and w_ohwi.is_contiguous() and w_ohwi.shape[3] == Cin and Cin % 16 == 0
+    Ho, Wo = conv_out_hw(H, W, kh, stride, pad)
+    if out is None:
+        out = torch.empty((B, Ho, Wo, Cout), device=x.device, dtype=f32)
+    M, K = B * Ho * Wo, kh * kw * Cin
+    if kh == 1 and kw == 1 and stride == 1 and pad == 0:
+        gemm_raw(M, Cout, K, x, Cin, OP_DENSE_K, w_ohwi, K, OP_DENSE_K, out, Cout, bias=bias)
+    else:
+        gemm_raw(M, Cout, K, x, Cin, OP_CONV_K, w_ohwi, K, OP_DENSE_K, out, Cout, bias=bias,
+                 geo=conv_geo(H, W, Cin, Ho, Wo, kh, kw, stride, pad, 0))
+    return out
+
+
+def conv2d_dgrad(dy, w_ohwi, x_shape, stride, pad, out=None, accumulate=False):
+    """dx NHWC [B,H,W,Cin] (+)= conv_transpose(dy NHWC [B,Ho,Wo,Cout], w)."""
+    _chk_f32(dy, w_ohwi)
+    B, H, W, Cin = x_shape
+    Cout, kh, kw, _ = w_ohwi.shape
+    Bq, Ho, Wo, Cq = dy.shape
+    assert dy.is_contiguous() and w_ohwi.is_contiguous() and Cq == Cout and Bq == B
+    if out is None:
+        assert not accumulate
+        out = torch.empty(x_shape, device=dy.device, dtype=f32)
+    M = B * H * W
+    if kh == 1 and kw == 1 and stride == 1 and pad == 0:
+        gemm_raw(M, Cin, Cout, dy, Cout, OP_DENSE_K, w_ohwi, Cin, OP_DENSE_R, out, Cin, accumulate=accumulate)
+    else:
+        assert Cout % 16 == 0 and Cin % 4 == 0
+        gemm_raw(M, Cin, kh * kw * Cout, dy, Cout, OP_CONV_K, w_ohwi, Cin, OP_WT_R, out, Cin, accumulate=accumulate,
+                 geo=conv_geo(Ho, Wo, Cout, H, W, kh, kw, stride, pad, 1))
+    return out
+
+
+def conv2d_wgrad(dy, x, dw_ohwi, stride, pad, accumulate=True):
+    """dw [Cout,kh,kw,Cin] (+)= sum over pixels dy^T * im2col(x)."""
+    _chk_f32(dy, x, dw_ohwi)
+    B, H, W, Cin = x.shape
+    Cout, kh, kw, _ = dw_ohwi.shape
+    _, Ho, Wo, _ = dy.shape
+    assert dy.is_contiguous() and x.is_contiguous() and dw_ohwi.is_contiguous()
+    Mpix, Kc = B * Ho * Wo, kh * kw * Cin
+    sk = _pick_splitk(Cout, Kc, Mpix)
+    if not accumulate and sk > 1:
+        dw_ohwi.zero_()
+    acc = accumulate or sk > 1
+    if kh == 1 and kw == 1 and stride == 1 and pad == 0:
+        gemm_raw(Cout, Kc, Mpix, dy, Cout, OP_DENSE_R, x, Cin, OP_DENSE_R, dw_ohwi, Kc, accumulate=acc, splitk=sk)
+    else:
+        assert Cin % 16 == 0
+        gemm_raw(Cout, Kc, Mpix, dy, Cout, OP_DENSE_R, x, Cin, OP_CONV_R, dw_ohwi, Kc, accumulate=acc, splitk=sk,
+                 geo=conv_geo(H, W, Cin, Ho, Wo, kh, kw, stride, pad, 0))
+    return dw_ohwi
+
+
+def im2col(x, kh, kw, stride, pad, Kpad):
+    _chk_f32(x)
+    B, H, W, Cc = x.shape
+    Ho, Wo = conv_out_hw(H, W, kh, stride, pad)
+    out = torch.empty((B * Ho * Wo, Kpad), device=x.device, dtype=f32)
+    check(lib.vbg_im2col(P(x), B, H, W, Cc, kh, kw, stride, pad, Kpad, P(out), _stream()), "vbg_im2col")
+    return out
+
+
+# ----------------------------------------------------------------------------------------------
+# row kernels
+# ----------------------------------------------------------------------------------------------
+def embed_ln_fwd(ids, pos_ids, word, pos, type0, gamma, beta, eps, p, seed, sid):
+    ntok, hidden = ids.numel(), word.shape[1]
+    out = torch.empty((ntok, hidden), device=word.device, dtype=f32)
+    xhat = torch.empty_like(out)
+    rstd = torch.empty((ntok,), device=word.device, dtype=f32)
+    check(lib.vbg_embed_ln_fwd(P(ids), P(pos_ids), ntok, hidden, P(word), P(pos), P(type0), P(gamma), P(beta), eps, p, seed, sid,
+                               P(out), P(xhat), P(rstd), _stream()), "vbg_embed_ln_fwd")
+    return out, xhat, rstd
+
+
+def embed_ln_bwd(dout, xhat, rstd, ids, pos_ids, gamma, p, seed, sid, dword, dpos, dtype0, dgamma, dbeta):
+    ntok, hidden = xhat.shape
+    check(lib.vbg_embed_ln_bwd(P(dout), P(xhat), P(rstd), P(ids), P(pos_ids), ntok, hidden, P(gamma), p, seed, sid, P(dword),
+                               P(dpos), P(dtype0), P(dgamma), P(dbeta), _stream()), "vbg_embed_ln_bwd")
+
+
+def dropout_add_ln_fwd(x, res, gamma, beta, eps, p, seed, sid):
+    rows, hidden = x.shape
+    y = torch.empty_like(x)
+    xhat = torch.empty_like(x)
+    rstd = torch.empty((rows,), device=x.device, dtype=f32)
+    check(lib.vbg_dropout_add_ln_fwd(P(x), P(res), rows, hidden, P(gamma), P(beta), eps, p, seed, sid, P(y), P(xhat), P(rstd),
+                                     _stream()), "vbg_dropout_add_ln_fwd")
+    return y, xhat, rstd
+
+
+def dropout_add_ln_bwd(dy, xhat, rstd, gamma, p, seed, sid, dgamma, dbeta):
+    rows, hidden = xhat.shape
+    dx = torch.empty_like(xhat)
+    dres = torch.empty_like(xhat)
+    check(lib.vbg_dropout_add_ln_bwd(P(dy), P(xhat), P(rstd), rows, hidden, P(gamma), p, seed, sid, P(dx), P(dres), P(dgamma),
+                                     P(dbeta), _stream()), "vbg_dropout_add_ln_bwd")
+    return dx, dres
+
+
+def softmax_fwd(s, off, lens, ldp, ngroups, heads, maxlen, scale, p, seed, sid):
+    check(lib.vbg_softmax_fwd(P(s), P(off), P(lens), P(ldp), ngroups, heads, maxlen, scale, p, seed, sid, _stream()), "vbg_softmax_fwd")
+
+
+def softmax_bwd(pbuf, dp, off, lens, ldp, ngroups, heads, maxlen, scale, p):
+    check(lib.vbg_softmax_bwd(P(pbuf), P(dp), P(off), P(lens), P(ldp), ngroups, heads, maxlen, scale, p, _stream()), "vbg_softmax_bwd")
+
+
+def gelu_bwd_(h, dg):
+    check(lib.vbg_gelu_bwd(P(h), P(dg), dg.numel(), _stream()), "vbg_gelu_bwd")
+    return dg
+
+
+def relu_bwd_(y, dy):
+    check(lib.vbg_relu_bwd(P(y), P(dy), dy.numel(), _stream()), "vbg_relu_bwd")
+    return dy
+
+
+def add_(a, b):
+    assert a.numel() == b.numel() and a.is_contiguous() and b.is_contiguous()
+    check(lib.vbg_add_inplace(P(a), P(b), a.numel(), _stream()), "vbg_add_inplace")
+    return a
+
+
+def scale_(a, s):
+    check(lib.vbg_scale_inplace(P(a), a.numel(), float(s), _stream()), "vbg_scale_inplace")
+    return a
+
+
+# ----------------------------------------------------------------------------------------------
+# BERTgrid
+# ----------------------------------------------------------------------------------------------
+def seg_reduce_fwd(tok, tok_row, run_start, run_len, mode):
+    nseg, hidden = run_start.numel(), tok.shape[1]
+    out = torch.empty((nseg, hidden), device=tok.device, dtype=f32)
+    check(lib.vbg_seg_reduce_fwd(P(tok), P(tok_row), P(run_start), P(run_len), nseg, hidden, mode, P(out), _stream()), "vbg_seg_reduce_fwd")
+    return out
+
+
+def seg_reduce_bwd(dout, tok_row, run_start, run_len, mode, dtok):
+    nseg, hidden = dout.shape
+    check(lib.vbg_seg_reduce_bwd(P(dout), P(tok_row), P(run_start), P(run_len), nseg, hidden, mode, P(dtok), _stream()), "vbg_seg_reduce_bwd")
+
+
+def owner_map(boxes, box_off, B, gh, gw, stride):
+    own = torch.empty((B, gh, gw), device=box_off.device, dtype=i32)
+    check(lib.vbg_owner_map(P(boxes) if boxes.numel() else None, P(box_off), B, gh, gw, stride, P(own), _stream()), "vbg_owner_map")
+    return own
+
+
+def grid_scatter_fwd(emb, owner, C_, layout=0):
+    B, gh, gw = owner.shape
+    shape = (B, gh, gw, C_) if layout == 0 else (B, C_, gh, gw)
+    grid = torch.empty(shape, device=owner.device, dtype=f32)
+    check(lib.vbg_grid_scatter_fwd(P(emb) if emb.numel() else None, P(owner), B, gh, gw, C_, layout, P(grid), _stream()), "vbg_grid_scatter_fwd")
+    return grid
+
+
+def grid_scatter_bwd(dgrid, owner, boxes, box_doc, stride, demb):
+    B, gh, gw = owner.shape
+    nbox, C_ = demb.shape
+    check(lib.vbg_grid_scatter_bwd(P(dgrid), P(owner), P(boxes) if nbox else None, P(box_doc) if nbox else None, nbox, gh, gw, stride,
+                                   C_, P(demb), _stream()), "vbg_grid_scatter_bwd")
+
+
+def label_raster(owner, seg_class):
+    pn = torch.empty_like(owner)
+    cl = torch.empty_like(owner)
+    check(lib.vbg_label_raster(P(owner), P(seg_class) if seg_class.numel() else None, owner.numel(), P(pn), P(cl), _stream()), "vbg_label_raster")
+    return pn, cl
+
+
+# ----------------------------------------------------------------------------------------------
+# conv helpers
+# ----------------------------------------------------------------------------------------------
+def bn_stats(x2d, stats):
+    M, C_ = x2d.shape
+    check(lib.vbg_bn_stats(P(x2d), M, C_, P(stats), _stream()), "vbg_bn_stats")
+
+
+def bn_finalize(stats, count, eps, momentum, running_mean, running_var):
+    C_ = stats.numel() // 2
+    mean = torch.empty((C_,), device=stats.device, dtype=f32)
+    invstd = torch.empty_like(mean)
+    check(lib.vbg_bn_finalize(P(stats), float(count), C_, eps, momentum, P(mean), P(invstd), P(running_mean), P(running_var), _stream()), "vbg_bn_finalize")
+    return mean, invstd
+
+
+def bn_apply(x2d, res2d, mean, invstd, gamma, beta, relu, out=None):
+    M, C_ = x2d.shape
+    if out is None:
+        out = torch.empty_like(x2d)
+    check(lib.vbg_bn_apply(P(x2d), P(res2d), M, C_, P(mean), P(invstd), P(gamma), P(beta), int(relu), P(out), _stream()), "vbg_bn_apply")
+    return out
+
+
+def bn_bwd_reduce(dy, y, x, mean, invstd, relu, sums):
+    M, C_ = x.shape
+    check(lib.vbg_bn_bwd_reduce(P(dy), P(y), P(x), M, C_, P(mean), P(invstd), int(relu), P(sums), _stream()), "vbg_bn_bwd_reduce")
+
+
+def bn_bwd_apply(dy, y, x, mean, invstd, gamma, sums, count, relu, want_dres, dgamma, dbeta):
+    M, C_ = x.shape
+    dx = torch.empty_like(x)
+    dres = torch.empty_like(x) if want_dres else None
+    check(lib.vbg_bn_bwd_apply(P(dy), P(y), P(x), M, C_, P(mean), P(invstd), P(gamma), P(sums), float(count), int(relu), P(dx), P(dres),
+                               P(dgamma), P(dbeta), _stream()), "vbg_bn_bwd_apply")
+    return dx, dres
+
+
+def maxpool_fwd(x):
+    B, H, W, C_ = x.shape
+    Ho, Wo = conv_out_hw(H, W, 3, 2, 1)
+    y = torch.empty((B, Ho, Wo, C_), device=x.device, dtype=f32)
+    am = torch.empty((B, Ho, Wo, C_), device=x.device, dtype=i32)
+    check(lib.vbg_maxpool3x3s2_fwd(P(x), B, H, W, C_, P(y), P(am), _stream()), "vbg_maxpool_fwd")
+    return y, am
+
+
+def maxpool_bwd(dy, am, H, W):
+    B, Ho, Wo, C_ = dy.shape
+    dx = torch.zeros((B, H, W, C_), device=dy.device, dtype=f32)
+    check(lib.vbg_maxpool3x3s2_bwd(P(dy), P(am), B, Ho, Wo, C_, H, W, P(dx), _stream()), "vbg_maxpool_bwd")
+    return dx
+
+
+def upsample2_add(lo, skip):
+    B, H, W, C_ = skip.shape
+    y = torch.empty_like(skip)
+    check(lib.vbg_upsample2_add(P(lo), P(skip), B, H, W, C_, P(y), _stream()), "vbg_upsample2_add")
+    return y
+
+
+def sumpool(hi, f, out=None, accumulate=False):
+    B, H, W, C_ = hi.shape
+    if out is None:
+        out = torch.empty((B, H // f, W // f, C_), device=hi.device, dtype=f32)
+        accumulate = False
+    check(lib.vbg_sumpool(P(hi), B, H, W, C_, f, P(out), int(accumulate), _stream()), "vbg_sumpool")
+    return out
+
+
+def nchw_to_nhwc(x):
+    B, C_, H, W = x.shape
+    y = torch.empty((B, H, W, C_), device=x.device, dtype=f32)
+    check(lib.vbg_nchw_to_nhwc(P(x), B, C_, H * W, P(y), _stream()), "vbg_nchw_to_nhwc")
+    return y
+
+
+def nhwc_to_nchw(x):
+    B, H, W, C_ = x.shape
+    y = torch.empty((B, C_, H, W), device=x.device, dtype=f32)
+    check(lib.vbg_nhwc_to_nchw(P(x), B, C_, H * W, P(y), _stream()), "vbg_nhwc_to_nchw")
+    return y
+
+
+def upsample_nhwc_to_nchw(x, f):
+    B, h, w, C_ = x.shape
+    y = torch.empty((B, C_, h * f, w * f), device=x.device, dtype=f32)
+    check(lib.vbg_upsample_nhwc_to_nchw(P(x), B, h, w, C_, f, P(y), _stream()), "vbg_upsample_nhwc_to_nchw")
+    return y
+
+
+def normalize_resize(img, oh, ow, mean, std, batch, b):
+    _, h, w = img.shape
+    _, H, W, _ = batch.shape
+    m = (C.c_float * 3)(*[float(v) for v in mean])
+    s = (C.c_float * 3)(*[float(v) for v in std])
+    check(lib.vbg_normalize_resize(P(img), h, w, oh, ow, m, s, P(batch), b, H, W, _stream()), "vbg_normalize_resize")
+
+
+def rescale_boxes(coor_i64, rh, rw):
+    S = coor_i64.shape[0]
+    out = torch.empty((S, 4), device=coor_i64.device, dtype=i32)
+    check(lib.vbg_rescale_boxes(P(coor_i64) if S else None, S, float(rh), float(rw), P(out) if S else None, _stream()), "vbg_rescale_boxes")
+    return out
+
+
+# ----------------------------------------------------------------------------------------------
+# RoIAlign
+# ----------------------------------------------------------------------------------------------
+def roi_align_fwd(feat, boxes, box_doc, out_size, scale):
+    B, H, W, C_ = feat.shape
+    n = boxes.shape[0]
+    y = torch.empty((n, out_size, out_size, C_), device=feat.device, dtype=f32)
+    check(lib.vbg_roi_align_fwd(P(feat), B, H, W, C_, P(boxes) if n else None, P(box_doc) if n else None, n, out_size, scale, P(y), _stream()), "vbg_roi_align_fwd")
+    return y
+
+
+def roi_align_bwd(dy, feat_shape, boxes, box_doc, out_size, scale, dfeat):
+    B, H, W, C_ = feat_shape
+    n = boxes.shape[0]
+    check(lib.vbg_roi_align_bwd(P(dy), B, H, W, C_, P(boxes) if n else None, P(box_doc) if n else None, n, out_size, scale, P(dfeat), _stream()), "vbg_roi_align_bwd")
+
+
+# ----------------------------------------------------------------------------------------------
+# losses
+# ----------------------------------------------------------------------------------------------
+def ce_fwd(logits2d, elem, labels, n, weight=None, up_shift=0, H=0, W=0):
+    loss = torch.empty((n,), device=logits2d.device, dtype=f32)
+    check(lib.vbg_ce_fwd(P(logits2d), logits2d.stride(0), logits2d.shape[1], P(elem), P(labels), n, P(weight), up_shift, H, W, P(loss), _stream()), "vbg_ce_fwd")
+    return loss
+
+
+def ce_bwd(logits2d, elem, labels, n, weight, gscale_dev, gmul, up_shift, H, W, dlogits):
+    check(lib.vbg_ce_bwd(P(logits2d), logits2d.stride(0), logits2d.shape[1], P(elem), P(labels), n, P(weight), P(gscale_dev), float(gmul), up_shift,
+                         H, W, P(dlogits), _stream()), "vbg_ce_bwd")
+
+
+def compact(labels, value, eq):
+    """-> (idx int32[n] (first count valid), count int32[1] device)"""
+    n = labels.numel()
+    idx = torch.empty((max(n, 1),), device=labels.device, dtype=i32)
+    cnt = torch.empty((1,), device=labels.device, dtype=i32)
+    wsb = lib.vbg_compact_ws_bytes(n)
+    ws = torch.empty((wsb,), device=labels.device, dtype=torch.uint8)
+    check(lib.vbg_compact(P(labels), n, value, int(eq), P(idx), P(cnt), P(ws), wsb, _stream()), "vbg_compact")
+    return idx, cnt
+
+
+def sort_desc(keys):
+    n = keys.numel()
+    ko = torch.empty_like(keys)
+    io = torch.empty((n,), device=keys.device, dtype=i32)
+    if n == 0:
+        return ko, io
+    wsb = lib.vbg_sort_ws_bytes(n)
+    ws = torch.empty((wsb,), device=keys.device, dtype=torch.uint8)
+    check(lib.vbg_sort_desc(P(keys), n, P(ko), P(io), P(ws), wsb, _stream()), "vbg_sort_desc")
+    return ko, io
+
+
+def gather_f32(src, idx):
+    n = idx.numel()
+    out = torch.empty((n,), device=src.device, dtype=f32)
+    check(lib.vbg_gather_f32(P(src), P(idx), n, P(out), _stream()), "vbg_gather_f32")
+    return out
+
+
+def gather_i32(src, idx):
+    n = idx.numel()
+    out = torch.empty((n,), device=src.device, dtype=i32)
+    check(lib.vbg_gather_i32(P(src), P(idx), n, P(out), _stream()), "vbg_gather_i32")
+    return out
+
+
+def sum_f32(x, out):
+    check(lib.vbg_sum_f32(P(x), x.numel(), P(out), _stream()), "vbg_sum_f32")
+    return out
+
+
+def sumsq(x, out):
+    check(lib.vbg_sumsq(P(x), x.numel(), P(out), _stream()), "vbg_sumsq")
+    return out
+
+
+# ----------------------------------------------------------------------------------------------
+# optimizers
+# ----------------------------------------------------------------------------------------------
+def sgd_step(p, g, mom, lr, momentum, wd, first, grad_scale=1.0):
+    check(lib.vbg_sgd_step(P(p), P(g), P(mom), p.numel(), lr, momentum, wd, int(first), grad_scale, _stream()), "vbg_sgd_step")
+
+
+def adamw_step(p, g, m, v, lr, b1, b2, eps, wd, step, grad_scale=1.0):
+    check(lib.vbg_adamw_step(P(p), P(g), P(m), P(v), p.numel(), lr, b1, b2, eps, wd, step, grad_scale, _stream()), "vbg_adamw_step")
