@@ -61,10 +61,11 @@ typedef struct vbg_gemm_desc {
     const float* B; long long ldb; int b_kind; int b_vec;
     vbg_conv_geo geo;
     float* C; long long ldc; float* C2; const float* bias;  /* bias[N] or NULL                      */
-    int epi; float alpha; int accumulate;                   /* accumulate: atomic += into C         */
+    int epi; float alpha; int accumulate;                   /* C += result (atomic only if splitk>1)*/
     int splitk;                                             /* >1 requires accumulate               */
     int tile;                                               /* 0 auto, 64 or 128                    */
-    /* grouped problems: grp[g*6 + {0..5}] = M, N, K, offA, offB, offC (elements); NULL = single   */
+    /* grouped problems: grp[g*8 + {0..6}] = M, N, K, offA, offB, offC, offBias (elements; offsets */
+    /* are relative to A/B/C/bias and may be negative); NULL = single problem                       */
     const long long* grp; int ngroups; int grp_maxM, grp_maxN;
 } vbg_gemm_desc;
 
@@ -117,6 +118,8 @@ int vbg_softmax_fwd(float* s, const long long* off, const int* len, const int* l
 /* dS (in place on dp) from sign-encoded P and dP_drop: dS = scale * P * (keep*dP/(1-p) - sum_j P_drop*dP_drop) */
 int vbg_softmax_bwd(const float* p, float* dp, const long long* off, const int* len, const int* ldp, int ngroups,
                     int heads, int maxlen, float scale, float drop_p, void* stream);
+/* y[r,:] = softmax(x[r,:]) for the returned class probabilities (field_type_classification_head.py:587) */
+int vbg_row_softmax(const float* x, int rows, int cols, float* y, void* stream);
 int vbg_gelu_bwd(const float* h, float* dg_inout, long long n, void* stream);      /* dh = dg * gelu'(h) */
 int vbg_relu_bwd(const float* y, float* dy_inout, long long n, void* stream);      /* dx = dy * (y > 0)  */
 
@@ -154,8 +157,9 @@ int vbg_label_raster(const int* owner, const int* seg_class, long long ncell, in
 /* per-channel sum / sum of squares over rows of x[M,C] (fp64 accumulators, all-reducible for SyncBN):
  * stats[0..C) += sum, stats[C..2C) += sumsq */
 int vbg_bn_stats(const float* x, long long M, int C, double* stats_accum, void* stream);
-/* from (global) sums over `count` rows: mean, invstd; running <- (1-mom)*running + mom*{mean, unbiased var} */
-int vbg_bn_finalize(const double* stats, double count, int C, float eps, float momentum, float* mean, float* invstd,
+/* from (global) sums over `count` rows (count_dev, if non-NULL, is a device scalar that overrides `count`:
+ * the all-reduced row count under SyncBN): mean, invstd; running <- (1-mom)*running + mom*{mean, unbiased var} */
+int vbg_bn_finalize(const double* stats, double count, const double* count_dev, int C, float eps, float momentum, float* mean, float* invstd,
                     float* running_mean, float* running_var, void* stream);
 /* y = relu?( (x-mean)*invstd*gamma + beta (+ res) ) */
 int vbg_bn_apply(const float* x, const float* res, long long M, int C, const float* mean, const float* invstd,
@@ -165,7 +169,8 @@ int vbg_bn_bwd_reduce(const float* dy, const float* y, const float* x, long long
                       const float* invstd, int relu, double* sums_accum, void* stream);
 /* dx = gamma*invstd*(g - sum_g/count - xhat*sum_gx/count); dres = g (optional); dgamma += sum_gx, dbeta += sum_g */
 int vbg_bn_bwd_apply(const float* dy, const float* y, const float* x, long long M, int C, const float* mean,
-                     const float* invstd, const float* gamma, const double* sums, double count, int relu, float* dx,
+                     const float* invstd, const float* gamma, const double* sums, double count, const double* count_dev,
+                     int relu, float* dx,
                      float* dres, float* dgamma_accum, float* dbeta_accum, void* stream);
 int vbg_maxpool3x3s2_fwd(const float* x, int B, int H, int W, int C, float* y, int* argmax, void* stream);
 int vbg_maxpool3x3s2_bwd(const float* dy, const int* argmax, int B, int Ho, int Wo, int C, int H, int W,

@@ -123,7 +123,7 @@ def test_gemm_grouped(ops):
     for L in lens:
         ld = (L + 3) // 4 * 4
         for h in range(heads):
-            grp += [L, L, dh, rows * heads * dh + h * dh, rows * heads * dh + h * dh, total]
+            grp += [L, L, dh, rows * heads * dh + h * dh, rows * heads * dh + h * dh, total, 0, 0]
             s_off.append((total, L, ld))
             total += L * ld
         rows += L
@@ -133,7 +133,7 @@ def test_gemm_grouped(ops):
     # here every group has its own ld, so run groups with equal ld together
     for ldv in sorted(set(x[2] for x in s_off)):
         sel = [i for i, x in enumerate(s_off) if x[2] == ldv]
-        gg = torch.tensor([v for i in sel for v in grp[6 * i:6 * i + 6]], dtype=torch.int64, device=dev())
+        gg = torch.tensor([v for i in sel for v in grp[8 * i:8 * i + 8]], dtype=torch.int64, device=dev())
         Lm = max(s_off[i][1] for i in sel)
         ops.gemm_raw(0, 0, 0, q.to(dev()), heads * dh, OP_DENSE_K, k.to(dev()), heads * dh, OP_DENSE_K, S, ldv, grp=gg, ngroups=len(sel), grp_max=(Lm, Lm))
     r = 0

@@ -39,10 +39,12 @@ __global__ __launch_bounds__(256) void bn_stats_kernel(const float* __restrict__
     }
 }
 
-__global__ void bn_finalize_kernel(const double* __restrict__ stats, double count, int C, float eps, float momentum,
-                                   float* mean, float* invstd, float* running_mean, float* running_var) {
+__global__ void bn_finalize_kernel(const double* __restrict__ stats, double count, const double* __restrict__ count_dev, int C,
+                                   float eps, float momentum, float* mean, float* invstd, float* running_mean,
+                                   float* running_var) {
     const int c = blockIdx.x * blockDim.x + threadIdx.x;
     if (c >= C) return;
+    if (count_dev) count = count_dev[0];
     const double m = stats[c] / count;
     double var = stats[C + c] / count - m * m;
     if (var < 0.0) var = 0.0;
@@ -110,8 +112,10 @@ __global__ __launch_bounds__(256) void bn_bwd_reduce_kernel(const float* __restr
 
 __global__ void bn_bwd_apply_kernel(const float* __restrict__ dy, const float* __restrict__ y, const float* __restrict__ x,
                                     long long M, int C, const float* __restrict__ mean, const float* __restrict__ invstd,
-                                    const float* __restrict__ gamma, const double* __restrict__ sums, double count, int relu,
-                                    float* __restrict__ dx, float* __restrict__ dres) {
+                                    const float* __restrict__ gamma, const double* __restrict__ sums, double count,
+                                    const double* __restrict__ count_dev, int relu, float* __restrict__ dx,
+                                    float* __restrict__ dres) {
+    if (count_dev) count = count_dev[0];
     const long long total = M * C;
     const long long stride = (long long)gridDim.x * blockDim.x;
     for (long long i = (long long)blockIdx.x * blockDim.x + threadIdx.x; i < total; i += stride) {
@@ -319,11 +323,11 @@ extern "C" int vbg_bn_stats(const float* x, long long M, int C, double* stats_ac
     VBG_LAUNCH_RET();
 }
 
-extern "C" int vbg_bn_finalize(const double* stats, double count, int C, float eps, float momentum, float* mean, float* invstd,
-                               float* running_mean, float* running_var, void* stream) {
-    VBG_CHECK_ARG(stats && mean && invstd && C > 0 && count > 0 && ((running_mean == nullptr) == (running_var == nullptr)));
-    hipLaunchKernelGGL(bn_finalize_kernel, dim3(cdiv(C, 256)), dim3(256), 0, S_, stats, count, C, eps, momentum, mean, invstd,
-                       running_mean, running_var);
+extern "C" int vbg_bn_finalize(const double* stats, double count, const double* count_dev, int C, float eps, float momentum,
+                               float* mean, float* invstd, float* running_mean, float* running_var, void* stream) {
+    VBG_CHECK_ARG(stats && mean && invstd && C > 0 && (count > 0 || count_dev) && ((running_mean == nullptr) == (running_var == nullptr)));
+    hipLaunchKernelGGL(bn_finalize_kernel, dim3(cdiv(C, 256)), dim3(256), 0, S_, stats, count, count_dev, C, eps, momentum, mean,
+                       invstd, running_mean, running_var);
     VBG_LAUNCH_RET();
 }
 
@@ -348,11 +352,12 @@ extern "C" int vbg_bn_bwd_reduce(const float* dy, const float* y, const float* x
 }
 
 extern "C" int vbg_bn_bwd_apply(const float* dy, const float* y, const float* x, long long M, int C, const float* mean,
-                                const float* invstd, const float* gamma, const double* sums, double count, int relu, float* dx,
-                                float* dres, float* dgamma_accum, float* dbeta_accum, void* stream) {
-    VBG_CHECK_ARG(dy && x && mean && invstd && gamma && sums && dx && M >= 0 && C > 0 && count > 0 && (!relu || y));
+                                const float* invstd, const float* gamma, const double* sums, double count,
+                                const double* count_dev, int relu, float* dx, float* dres, float* dgamma_accum,
+                                float* dbeta_accum, void* stream) {
+    VBG_CHECK_ARG(dy && x && mean && invstd && gamma && sums && dx && M >= 0 && C > 0 && (count > 0 || count_dev) && (!relu || y));
     if (M > 0) hipLaunchKernelGGL(bn_bwd_apply_kernel, dim3(ew_grid(M * C, 256)), dim3(256), 0, S_, dy, y, x, M, C, mean, invstd,
-                                  gamma, sums, count, relu, dx, dres);
+                                  gamma, sums, count, count_dev, relu, dx, dres);
     if (dgamma_accum && dbeta_accum)
         hipLaunchKernelGGL(bn_param_grad_kernel, dim3(cdiv(C, 256)), dim3(256), 0, S_, sums, C, dgamma_accum, dbeta_accum);
     VBG_LAUNCH_RET();

@@ -41,11 +41,13 @@ __global__ __launch_bounds__(256) void gemm_kernel(const vbg_gemm_desc p) {
     const float* B = p.B;
     float* C = p.C;
     float* C2 = p.C2;
+    const float* bias = p.bias;
     if (p.grp) {
-        const long long* g = p.grp + 6 * (long long)grp;
+        const long long* g = p.grp + 8 * (long long)grp;
         M = (int)g[0]; N = (int)g[1]; K = (int)g[2];
         A += g[3]; B += g[4]; C += g[5];
         if (C2) C2 += g[5];
+        if (bias) bias += g[6];
     }
     const int m0 = blockIdx.x * BM, n0 = blockIdx.y * BN;
     if (m0 >= M || n0 >= N) return;
@@ -292,12 +294,13 @@ __global__ __launch_bounds__(256) void gemm_kernel(const vbg_gemm_desc p) {
     }
 
     // ---------------- epilogue ----------------------------------------------------------
-    const bool add_bias = (p.bias != nullptr) && (split == 0);
+    const bool add_bias = (bias != nullptr) && (split == 0);
+    const bool atomic = p.accumulate && p.splitk > 1;
 #pragma unroll
     for (int j = 0; j < TN; ++j) {
         const int n = n0 + wn * WN + j * 32 + lr;
         if (n >= N) continue;
-        const float bv = add_bias ? p.bias[n] : 0.f;
+        const float bv = add_bias ? bias[n] : 0.f;
 #pragma unroll
         for (int i = 0; i < TM; ++i) {
 #pragma unroll
@@ -306,8 +309,10 @@ __global__ __launch_bounds__(256) void gemm_kernel(const vbg_gemm_desc p) {
                 if (m >= M) continue;
                 float v = acc[i][j][r] * p.alpha + bv;
                 const long long o = (long long)m * p.ldc + n;
-                if (p.accumulate) {
+                if (atomic) {
                     unsafeAtomicAdd(C + o, v);
+                } else if (p.accumulate) {
+                    C[o] += v;                       // single owner per element: plain read-modify-write
                 } else if (p.epi == VBG_EPI_RELU) {
                     C[o] = fmaxf(v, 0.f);
                 } else if (p.epi == VBG_EPI_GELU_DUAL) {

@@ -341,6 +341,19 @@ __global__ __launch_bounds__(256) void colsum_kernel(const float* __restrict__ x
     if (rl == 0 && c < N) unsafeAtomicAdd(out + c, sh[0][threadIdx.x] + sh[1][threadIdx.x] + sh[2][threadIdx.x] + sh[3][threadIdx.x]);
 }
 
+// plain row softmax for the returned class probabilities ([rows, cols], cols small)
+__global__ void row_softmax_kernel(const float* __restrict__ x, int rows, int cols, float* __restrict__ y) {
+    const int r = blockIdx.x * blockDim.x + threadIdx.x;
+    if (r >= rows) return;
+    const float* p = x + (long long)r * cols;
+    float mx = p[0];
+    for (int c = 1; c < cols; ++c) mx = fmaxf(mx, p[c]);
+    float s = 0.f;
+    for (int c = 0; c < cols; ++c) s += expf(p[c] - mx);
+    const float inv = 1.f / s;
+    for (int c = 0; c < cols; ++c) y[(long long)r * cols + c] = expf(p[c] - mx) * inv;
+}
+
 static inline int ew_grid(long long n, int block) {
     long long g = (n + block - 1) / block;
     if (g > 256 * 8) g = 256 * 8;
@@ -460,6 +473,14 @@ extern "C" int vbg_colsum(const float* x, long long ld, int M, int N, float* out
     }
     if (M == 0) return VBG_OK;
     hipLaunchKernelGGL(colsum_kernel, dim3(cdiv(N, 64), cdiv(M, 256)), dim3(256), 0, s, x, ld, M, N, out);
+    VBG_LAUNCH_RET();
+}
+
+extern "C" int vbg_row_softmax(const float* x, int rows, int cols, float* y, void* stream) {
+    VBG_CHECK_ARG(rows >= 0 && cols > 0);
+    if (rows == 0) return VBG_OK;
+    VBG_CHECK_ARG(x && y);
+    hipLaunchKernelGGL(row_softmax_kernel, dim3(cdiv(rows, 256)), dim3(256), 0, (hipStream_t)stream, x, rows, cols, y);
     VBG_LAUNCH_RET();
 }
 

@@ -1,0 +1,217 @@
+"""ViBERTgridNet — the drop-in boundary (reference model/ViBERTgrid_net.py:37-544).
+
+Same constructor keywords / defaults / validation errors (:128-460), same `forward` (:501-544),
+`inference` (:470-499), `train()` / `eval()` work_mode flips (:462-468), same public attributes
+(`tokenizer`, `bert_model`, `backbone`, `transform`, `work_mode`, `bert_model_list`, `backbone_list`)
+and the same `state_dict()` key layout (BERT registered under `bert_model.` and again under
+`BERTgrid_generator.model.`).  Everything numeric below this class runs in libvbg (HIP, gfx950);
+importing this module without the built library raises ImportError — there is no fallback.
+
+What differs from the reference is only HOW the step is scheduled: label rasterisation, category
+compaction and the host random draws of all four losses are planned up-front with a single
+device->host copy, BERT runs on packed (un-padded) tokens, the grid / P_fuse / late-fusion concats
+are never materialised, and activations are NHWC.
+"""
+from typing import Any, Dict, List, Tuple
+
+import torch
+import torch.nn as nn
+from transformers import AutoConfig, BertModel, BertTokenizer, RobertaModel, RobertaTokenizer
+
+from model.BERTgrid_generator import BERTgridGenerator
+from model.field_type_classification_head import (CRFFieldTypeClassification, FieldTypeClassification, LateFusion,
+                                                   SimplifiedFieldTypeClassification)
+from model.grid_roi_align import GridROIAlign
+from model.ResNetFPN_ViBERTgrid import resnet_18_D_fpn, resnet_18_fpn, resnet_34_D_fpn, resnet_34_fpn
+from model.semantic_segmentation_head import SemanticSegmentationClassifier, SimplifiedSemanticSegmentationClassifier
+from pipeline.custom_loss import resolve_plans
+from pipeline.transform import GeneralizedViBERTgridTransform, ImageList  # noqa: F401  (ImageList re-exported like the reference)
+
+_BERT_HIDDEN = {
+    "private_bert-base-uncased": 768, "bert-base-uncased": 768, "bert-base-cased": 768, "roberta-base": 768,
+    "bert-base-chinese": 768, "hfl/chinese-bert-wwm-ext": 768, "hfl/chinese-bert-wwm": 768,
+}
+_BACKBONES = {
+    "resnet_18_fpn": lambda c: resnet_18_fpn(grid_channel=c),
+    "resnet_34_fpn": lambda c: resnet_34_fpn(grid_channel=c),
+    "resnet_18_fpn_pretrained": lambda c: resnet_18_fpn(grid_channel=c, pretrained=True),
+    "resnet_34_fpn_pretrained": lambda c: resnet_34_fpn(grid_channel=c, pretrained=True),
+    "resnet_18_D_fpn": lambda c: resnet_18_D_fpn(grid_channel=c),
+    "resnet_34_D_fpn": lambda c: resnet_34_D_fpn(grid_channel=c),
+}
+
+
+def _three(v, name):
+    assert isinstance(v, (float, List)), f"{name} must be float or list of float, {type(v)} given"
+    if isinstance(v, float):
+        return [v] * 3
+    if len(v) != 3:
+        raise ValueError(f"{name} must contain 3 three values, {len(v)} given")
+    return v
+
+
+class ViBERTgridNet(nn.Module):
+    def __init__(self, num_classes, image_mean: Any, image_std: Any, image_min_size: Any, image_max_size, test_image_min_size=512,
+                 bert_model: str = "bert-base-uncased", tokenizer: Any = None, backbone: str = "resnet_18_fpn", grid_mode: str = "mean",
+                 early_fusion_downsampling_ratio=8, roi_shape=7, p_fuse_downsampling_ratio=4, late_fusion_fuse_embedding_channel=1024,
+                 loss_weights: Any = None, num_hard_positive_main_1=-1, num_hard_negative_main_1=-1, num_hard_positive_main_2=-1,
+                 num_hard_negative_main_2=-1, loss_aux_sample_list: List = None, num_hard_positive_aux=-1, num_hard_negative_aux=-1,
+                 loss_control_lambda: float = 1, add_pos_neg: bool = True, classifier_mode: str = "full", tag_to_idx: Dict = None,
+                 ohem_random: bool = False, layer_mode: str = "single", work_mode: str = "train") -> None:
+        super().__init__()
+        assert work_mode in ["train", "eval", "inference"], f"mode must be 'train' 'eval' or 'inference', {work_mode} given"
+        self.work_mode = work_mode
+        self.num_classes = num_classes
+        self.num_tokens = len(tag_to_idx) if tag_to_idx is not None else num_classes
+
+        # ---- pre-processing -----------------------------------------------------------------
+        self.image_mean = _three(image_mean, "image_mean")
+        self.image_std = _three(image_std, "image_std")
+        self.test_image_min_size = test_image_min_size
+        assert isinstance(image_min_size, (int, Tuple, List)), f"image_min_size must be int, Tuple or List, {type(image_min_size)} given"
+        image_min_size = list(image_min_size)
+        assert isinstance(image_max_size, int), f"image_max_size must be int, {type(image_max_size)} given"
+        self.image_min_size, self.image_max_size = image_min_size, image_max_size
+        self.transform = GeneralizedViBERTgridTransform(image_mean=self.image_mean, image_std=self.image_std,
+                                                        train_min_size=self.image_min_size, test_min_size=self.test_image_min_size,
+                                                        max_size=self.image_max_size)
+
+        # ---- language model (parameter owner; arithmetic is libvbg) ----------------------------
+        self.bert_model_list = dict(_BERT_HIDDEN)
+        assert bert_model in self.bert_model_list.keys(), \
+            f"the given bert model {bert_model} does not exists, see attribute bert_model_list for all bert_models"
+        self.bert_hidden_size = self.bert_model_list[bert_model]
+        is_roberta = "roberta-" in bert_model
+        if not is_roberta and "bert-" not in bert_model:
+            raise ValueError("no tokenizer and bert model loaded")
+        tok_cls, model_cls, tok_name = ((RobertaTokenizer, RobertaModel, "RobertaTokenizer") if is_roberta
+                                        else (BertTokenizer, BertModel, "BertTokenizer"))
+        if tokenizer is None:
+            self.tokenizer = tok_cls.from_pretrained(bert_model)
+        elif isinstance(tokenizer, tok_cls):
+            self.tokenizer = tokenizer
+        else:
+            raise ValueError(f"invalid value of parameter tokenizer, must be None or callable {tok_name}")
+        if self.work_mode in ("train", "inference"):
+            print("loading pretrained")
+            self.bert_model = model_cls.from_pretrained(bert_model)
+        else:
+            print("in evaluation mode, no pretrained will be loaded")
+            self.bert_config = AutoConfig.from_pretrained(bert_model)
+            self.bert_model = model_cls(self.bert_config)
+
+        # ---- backbone ---------------------------------------------------------------------------
+        self.backbone_list = list(_BACKBONES.keys())
+        assert backbone in self.backbone_list, \
+            f"the given backbone {backbone} does not exists, see attribute backbone_list for all backbones"
+        self.backbone = _BACKBONES[backbone](self.bert_hidden_size)
+        self.p_fuse_channel = 256
+
+        assert grid_mode in ["mean", "first"], f"grid_mode should be 'mean' or 'first', {grid_mode} were given"
+        self.grid_mode = grid_mode
+        self.early_fusion_downsampling_ratio = early_fusion_downsampling_ratio
+        self.roi_shape = roi_shape
+        self.p_fuse_downsampling_ratio = p_fuse_downsampling_ratio
+        self.late_fusion_fuse_embedding_channel = late_fusion_fuse_embedding_channel
+
+        # ---- losses -----------------------------------------------------------------------------
+        self.loss_control_lambda = None if self.work_mode == "inference" else loss_control_lambda
+        if loss_weights is None or self.work_mode == "inference":
+            self.loss_weights = None
+        elif isinstance(loss_weights, List):
+            self.loss_weights = torch.tensor(loss_weights)
+        elif isinstance(loss_weights, torch.Tensor):
+            pass          # (sic) the reference leaves self.loss_weights unset for a Tensor argument (:344-345)
+        else:
+            raise TypeError(f"loss_weights must be None, List or torch.Tensor, {type(loss_weights)} given")
+        assert classifier_mode in ["full", "simp", "crf"], "invalid classifier mode, must be 'full', 'simp' or 'crf'"
+        self.classifier_mode = classifier_mode
+
+        self.BERTgrid_generator = BERTgridGenerator(bert_model=self.bert_model, grid_mode=self.grid_mode,
+                                                    stride=self.early_fusion_downsampling_ratio)
+        self.grid_roi_align_net = GridROIAlign(output_size=self.roi_shape, step=self.p_fuse_downsampling_ratio)
+        self.late_fusion_net = LateFusion(bert_hidden_size=self.bert_hidden_size, roi_channel=self.p_fuse_channel, roi_shape=self.roi_shape)
+
+        inference = self.work_mode == "inference"
+        if self.classifier_mode == "simp":
+            if inference:
+                self.field_type_classification_head = SimplifiedFieldTypeClassification(
+                    num_classes=self.num_tokens, fuse_embedding_channel=self.late_fusion_fuse_embedding_channel, layer_mode=layer_mode,
+                    work_mode=self.work_mode, add_pos_neg=add_pos_neg)
+                self.semantic_segmentation_head = None
+            else:
+                lw = getattr(self, "loss_weights", None)
+                lw = None if lw is None else lw.to(torch.float32)
+                # NOTE the reference does not forward add_pos_neg here (:417-428): the head default (True) applies
+                self.field_type_classification_head = SimplifiedFieldTypeClassification(
+                    num_classes=self.num_tokens, fuse_embedding_channel=self.late_fusion_fuse_embedding_channel, loss_weights=lw,
+                    num_hard_positive_1=num_hard_positive_main_1, num_hard_negative_1=num_hard_negative_main_1,
+                    num_hard_positive_2=num_hard_positive_main_2, num_hard_negative_2=num_hard_negative_main_2, random=ohem_random,
+                    layer_mode=layer_mode, work_mode=self.work_mode)
+                self.semantic_segmentation_head = SimplifiedSemanticSegmentationClassifier(
+                    p_fuse_channel=self.p_fuse_channel, num_classes=self.num_tokens, loss_weights=lw,
+                    loss_1_sample_list=loss_aux_sample_list, num_hard_positive=num_hard_positive_aux,
+                    num_hard_negative=num_hard_negative_aux)
+        elif self.classifier_mode == "full":
+            self.field_type_classification_head = FieldTypeClassification()
+            self.semantic_segmentation_head = None if inference else SemanticSegmentationClassifier()
+        else:
+            assert tag_to_idx is not None, "tag_to_idx cannot be None in crf mode"
+            self.field_type_classification_head = CRFFieldTypeClassification()
+            self.semantic_segmentation_head = None if inference else SemanticSegmentationClassifier()
+
+    # the reference flips work_mode on train()/eval() (:462-468), even for a model built in another mode
+    def train(self, mode: bool = True):
+        self.work_mode = "train"
+        return super().train(mode)
+
+    def eval(self):
+        self.work_mode = "eval"
+        return super().eval()
+
+    # ---------------------------------------------------------------------------------------------
+    def _trunk(self, image, seg_indices, coors, corpus, mask):
+        batch, icoors, _ = self.transform.forward_nhwc(image, coors)
+        B, H, W, _ = batch.shape
+        packed = BERTgridGenerator.pack_boxes(tuple(icoors))
+        return batch, icoors, packed, B, H, W
+
+    def _features(self, batch, packed, B, H, W, seg_indices, corpus, mask):
+        gen = self.BERTgrid_generator
+        emb_cat, counts = gen._segment_embeddings(corpus, mask, seg_indices)
+        boxes, box_off, box_doc = packed
+        assert emb_cat.shape[0] == boxes.shape[0], "number of segment embeddings and boxes mismatch"
+        grid = gen._scatter((H, W), emb_cat, boxes, box_off, box_doc, B, 0)
+        p_fuse = self.backbone(batch, grid)
+        return emb_cat, p_fuse
+
+    def inference(self, image: Tuple[torch.Tensor], seg_indices: Tuple[torch.Tensor], coors: torch.Tensor, corpus: torch.Tensor,
+                  mask: torch.Tensor):
+        batch, icoors, packed, B, H, W = self._trunk(image, seg_indices, coors, corpus, mask)
+        emb_cat, p_fuse = self._features(batch, packed, B, H, W, seg_indices, corpus, mask)
+        roi = self.grid_roi_align_net(p_fuse, icoors, None, packed=packed)
+        fuse = self.late_fusion_net(roi, emb_cat)
+        return self.field_type_classification_head.inference(fuse)
+
+    def forward(self, image: Tuple[torch.Tensor], seg_indices: Tuple[torch.Tensor], segment_classes: Tuple[torch.Tensor],
+                coors: torch.Tensor, corpus: torch.Tensor, mask: torch.Tensor):
+        batch, icoors, packed, B, H, W = self._trunk(image, seg_indices, coors, corpus, mask)
+        seg_head, cls_head = self.semantic_segmentation_head, self.field_type_classification_head
+        # label-only work of all four losses first: ONE device->host copy, host RNG draws in the reference's order
+        classes = torch.cat([c.reshape(-1) for c in segment_classes]).int()
+        pos_neg, cls_map = seg_head.make_labels(packed, classes, B, H, W)
+        label_class, label_pn = cls_head.make_labels(segment_classes)
+        plans = seg_head.plans(pos_neg, cls_map) + cls_head.plans(label_class, label_pn)
+        resolve_plans(plans)
+
+        emb_cat, p_fuse = self._features(batch, packed, B, H, W, seg_indices, corpus, mask)
+        train_only = self.work_mode == "train" and self.training
+        loss_aux, pred_mask, pred_ss = seg_head(p_fuse, segment_classes, icoors, prepared=(pos_neg, cls_map, plans[:2]),
+                                                materialize=not train_only)
+        roi = self.grid_roi_align_net(p_fuse, icoors, None, packed=packed)
+        fuse = self.late_fusion_net(roi, emb_cat)
+        loss_c, gt_label, pred_label = cls_head(fuse, segment_classes, prepared=(label_class, label_pn, plans[2:]))
+        total_loss = loss_c + self.loss_control_lambda * loss_aux
+        if train_only:
+            return total_loss
+        return total_loss, pred_mask, pred_ss, gt_label, pred_label

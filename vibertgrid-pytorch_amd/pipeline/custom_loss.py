@@ -1,0 +1,175 @@
+"""Sampled / OHEM cross-entropy losses, device-driven (reference: pipeline/custom_loss.py
+`CrossEntropyLossRandomSample` :9-101 and `CrossEntropyLossOHEM` :104-201).
+
+Semantics kept from the reference, quirks included:
+* categories are order-preserving compactions of the per-element losses (`ce_loss[mask]`);
+* the random subsets come from python's global `random.sample(range(n), k)` on the HOST, consumed in
+  the same order as the reference (so a pinned `random.seed` selects the same elements);
+* OHEM indexes the SORTED losses with the ORIGINAL positions of the top-k
+  (`sorted_loss[sorted_index[:k]]`, :175-176) — reproduced literally;
+* RandomSample returns float64 shape [1], OHEM a 0-dim float32.
+Differences: the sort is a stable descending radix sort on the GPU (the reference's `torch.sort` is
+unstable; with exactly tied losses its result depends on the tie order — DESIGN.md "OHEM ties");
+per-element CE is computed straight from low-resolution logits (`up_shift`), so the seg head never
+materialises the x4-upsampled activation; only the selected elements carry gradient, as in the
+reference.
+
+A "plan" holds everything that depends on LABELS only (category compactions, counts, host random
+draws).  Plans for several losses are resolved with ONE device->host copy (`resolve_plans`).
+"""
+import random
+from typing import List, Optional, Sequence
+
+import numpy as np
+import torch
+
+from vbg import functions as Fn
+from vbg import ops
+
+
+class _Cat:
+    __slots__ = ("idx", "cnt_dev", "n", "elem")
+
+
+class RandomSamplePlan:
+    """label-only part of CrossEntropyLossRandomSample."""
+
+    def __init__(self, labels_i32: torch.Tensor, ncls_logits: int, sample_list: Sequence[int]):
+        self.labels = labels_i32
+        self.sample_list = list(sample_list)
+        self.cats: List[_Cat] = []
+        ncat = len(sample_list)
+        if ncat == 2 and ncls_logits >= 2:
+            spec = [(0, True), (0, False)]
+        else:
+            assert ncat == ncls_logits, f"shape mismatch, number of elements in sample_list must be 2 or equals dimensions of input, {ncat} and {ncls_logits} given"
+            spec = [(c, True) for c in range(ncat)]
+        for value, eq in spec:
+            c = _Cat()
+            c.idx, c.cnt_dev = ops.compact(labels_i32, value, eq)
+            self.cats.append(c)
+
+    def count_tensors(self):
+        return [c.cnt_dev for c in self.cats]
+
+    def resolve(self, counts: Sequence[int]):
+        dev = self.labels.device
+        self.num_keep_total = 0
+        for c, n, k in zip(self.cats, counts, self.sample_list):
+            c.n = int(n)
+            keep = min(k, c.n)
+            self.num_keep_total += keep
+            if keep == k:
+                sel = torch.tensor(random.sample(range(c.n), keep), dtype=torch.int32).to(dev)
+                c.elem = ops.gather_i32(c.idx, sel)
+            else:
+                c.elem = c.idx[:c.n]
+
+
+class OhemPlan:
+    """label-only part of CrossEntropyLossOHEM (positives = label != 0)."""
+
+    def __init__(self, labels_i32: torch.Tensor, num_pos: int, num_neg: int, rand: bool):
+        self.labels, self.num_pos, self.num_neg, self.rand = labels_i32, num_pos, num_neg, rand
+        self.plain = (num_pos == -1 and num_neg == -1)
+        self.cats: List[_Cat] = []
+        if not self.plain:
+            for eq in (False, True):          # positives first, like the reference
+                c = _Cat()
+                c.idx, c.cnt_dev = ops.compact(labels_i32, 0, eq)
+                self.cats.append(c)
+
+    def count_tensors(self):
+        return [c.cnt_dev for c in self.cats]
+
+    def resolve(self, counts: Sequence[int]):
+        dev = self.labels.device
+        for c, n, k in zip(self.cats, counts, (self.num_pos, self.num_neg)):
+            c.n = int(n)
+            c.elem = c.idx[:c.n]
+            if self.rand and 2 * k < c.n:
+                sel = torch.tensor(random.sample(range(c.n), 2 * k), dtype=torch.int32).to(dev)
+                c.elem = ops.gather_i32(c.idx, sel)
+
+
+def resolve_plans(plans):
+    """One D2H copy for the category counts of all plans, then the host-side random draws in order."""
+    tens = [t for p in plans for t in p.count_tensors()]
+    counts = torch.cat(tens).cpu().tolist() if tens else []
+    o = 0
+    for p in plans:
+        k = len(p.count_tensors())
+        p.resolve(counts[o:o + k])
+        o += k
+
+
+class CrossEntropyLossRandomSample(torch.nn.Module):
+    def __init__(self, sample_list: Optional[List], weight: Optional[torch.Tensor] = None, reduction: str = "mean") -> None:
+        super().__init__()
+        assert reduction == "mean", "only the reduction the model uses is implemented"
+        self.sample_list = sample_list
+        if sample_list is not None:
+            assert len(sample_list) >= 2, f"sample list must contains at least two elements, {len(sample_list)} given"
+        self.register_buffer("weight", weight)
+
+    def plan(self, labels_i32, ncls_logits):
+        return RandomSamplePlan(labels_i32, ncls_logits, self.sample_list)
+
+    def forward(self, logits2d: torch.Tensor, labels_i32: torch.Tensor, plan: RandomSamplePlan = None, up_shift: int = 0,
+                H: int = 0, W: int = 0) -> torch.Tensor:
+        """logits2d [rows, C] fp32 (rows = low-res pixels when H > 0); labels int32 flat (full resolution)."""
+        assert self.sample_list is not None, "sample_list=None (plain CE) is not used by the model"
+        if plan is None:
+            plan = self.plan(labels_i32, logits2d.shape[1])
+            resolve_plans([plan])
+        total = torch.zeros((1,), dtype=torch.float64, device=logits2d.device)
+        for c in plan.cats:
+            if c.elem.numel():
+                total = total + Fn.SelectedCEFn.apply(logits2d, c.elem, labels_i32, self.weight, 1.0, up_shift, H, W).double()
+        return total / plan.num_keep_total
+
+
+class CrossEntropyLossOHEM(torch.nn.Module):
+    def __init__(self, num_hard_positive: int = -1, num_hard_negative: int = -1, weight: Optional[torch.Tensor] = None,
+                 reduction: str = "mean", random: bool = False) -> None:
+        super().__init__()
+        assert reduction == "mean", "only the reduction the model uses is implemented"
+        self.num_hard_positive, self.num_hard_negative, self.random = num_hard_positive, num_hard_negative, random
+        self.register_buffer("weight", weight)
+
+    def plan(self, labels_i32):
+        return OhemPlan(labels_i32, self.num_hard_positive, self.num_hard_negative, self.random)
+
+    def forward(self, logits2d: torch.Tensor, labels_i32: torch.Tensor, plan: OhemPlan = None, up_shift: int = 0, H: int = 0,
+                W: int = 0) -> torch.Tensor:
+        if plan is None:
+            plan = self.plan(labels_i32)
+            resolve_plans([plan])
+        n = labels_i32.numel()
+        if plan.plain:
+            if self.weight is not None:
+                raise NotImplementedError("weighted plain mean CE is not on the model's path")
+            elem = torch.arange(n, dtype=torch.int32, device=logits2d.device)
+            return Fn.SelectedCEFn.apply(logits2d, elem, labels_i32, None, 1.0 / n, up_shift, H, W)
+        ce_all = ops.ce_fwd(logits2d.detach(), None, labels_i32, n, self.weight, up_shift, H, W)
+        elems, keeps = [], []
+        for c, k in zip(plan.cats, (self.num_hard_positive, self.num_hard_negative)):
+            m = int(c.elem.numel())
+            keep = min(m, k)
+            keeps.append(keep)
+            if 0 < keep < m:
+                v = ops.gather_f32(ce_all, c.elem)
+                _, si = ops.sort_desc(v)                       # si[r] = position (in c.elem) of rank r
+                ranks = ops.gather_i32(si, si[:keep].contiguous())   # the reference's sorted_loss[sorted_index[:k]]
+                elems.append(ops.gather_i32(c.elem, ranks))
+            else:
+                elems.append(c.elem)
+        denom = keeps[0] + keeps[1]
+        total = None
+        for e in elems:
+            if e.numel():
+                t = Fn.SelectedCEFn.apply(logits2d, e.contiguous(), labels_i32, self.weight, 1.0 / denom, up_shift, H, W)
+                total = t if total is None else total + t
+        if total is None:
+            total = logits2d.sum() * 0.0
+        return total

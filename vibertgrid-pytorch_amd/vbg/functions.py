@@ -1,0 +1,462 @@
+"""autograd.Function wrappers: every forward AND backward below is a sequence of libvbg kernel launches
+(vbg/ops.py).  torch.autograd only sequences the nodes and accumulates parameter gradients.
+
+Layout conventions: activations NHWC fp32 contiguous; conv weights are the reference's OIHW parameters
+held in channels_last memory, i.e. physically [Cout, kh, kw, Cin] (`ohwi()` is a free view)."""
+import torch
+import torch.distributed as dist
+
+from . import ops
+from .lib import EPI_GELU_DUAL, EPI_NONE, EPI_RELU, OP_DENSE_K, OP_DENSE_R
+
+f32 = torch.float32
+
+
+def ohwi(w):
+    """OIHW parameter -> contiguous [Cout,kh,kw,Cin] tensor (a view when the parameter is channels_last)."""
+    v = w.permute(0, 2, 3, 1)
+    return v if v.is_contiguous() else v.contiguous()
+
+
+def oihw_grad_like(dw_ohwi):
+    return dw_ohwi.permute(0, 3, 1, 2)
+
+
+def _c(t):
+    return t if t.is_contiguous() else t.contiguous()
+
+
+class SyncCtx:
+    """Process group for SyncBatchNorm statistics (train_SROIE.py:202-203 `convert_sync_batchnorm`)."""
+    group = None
+
+    @classmethod
+    def active(cls):
+        return dist.is_available() and dist.is_initialized() and dist.get_world_size(cls.group) > 1
+
+
+# ----------------------------------------------------------------------------------------------
+class LinearFn(torch.autograd.Function):
+    """y = x @ w^T + b (optional fused ReLU)."""
+
+    @staticmethod
+    def forward(ctx, x, w, b, relu):
+        x = _c(x)
+        y = ops.linear_fwd(x, w, b, EPI_RELU if relu else EPI_NONE)
+        ctx.relu = relu
+        ctx.has_bias = b is not None
+        ctx.save_for_backward(x, w, y if relu else None)
+        return y
+
+    @staticmethod
+    def backward(ctx, dy):
+        x, w, y = ctx.saved_tensors
+        dy = _c(dy)
+        if ctx.relu:
+            dy = ops.relu_bwd_(y, dy.clone())
+        dx = ops.linear_dgrad(dy, w) if ctx.needs_input_grad[0] else None
+        dw = torch.empty_like(w)
+        ops.linear_wgrad(dy, x, dw, accumulate=False)
+        db = ops.colsum(dy) if ctx.has_bias else None
+        return dx, dw, db, None
+
+
+class SegLinearFn(torch.autograd.Function):
+    """y = cat(x_i upsampled by 2^shift_i, channel dim) @ w^T + b with the concat never materialised
+    (K segments read in place).  Covers early fusion (ResNetFPN_ViBERTgrid.py:317-318), P_fuse (:502-506)
+    and late fusion (field_type_classification_head.py:185-188)."""
+
+    @staticmethod
+    def forward(ctx, w2d, b, shifts, hw, *xs):
+        xs = [_c(x) for x in xs]
+        chans = [x.shape[-1] for x in xs]
+        K = sum(chans)
+        assert w2d.shape[1] == K and w2d.is_contiguous()
+        N = w2d.shape[0]
+        full = xs[shifts.index(0)]
+        M = full.numel() // full.shape[-1]
+        out = torch.empty((M, N), device=full.device, dtype=f32)
+        kend, segs = 0, []
+        for x, c, s in zip(xs, chans, shifts):
+            kend += c
+            segs.append((x, kend, c, s))
+        ops.gemm_raw(M, N, K, xs[0], chans[0], OP_DENSE_K, w2d, K, OP_DENSE_K, out, N, bias=b, segs=segs,
+                     a_hw=hw if any(shifts) else (0, 0))
+        ctx.shifts, ctx.hw, ctx.chans, ctx.has_bias = shifts, hw, chans, b is not None
+        ctx.full_shape = full.shape
+        ctx.save_for_backward(w2d, *xs)
+        return out.view(*full.shape[:-1], N)
+
+    @staticmethod
+    def backward(ctx, dy):
+        w2d, *xs = ctx.saved_tensors
+        N, K = w2d.shape
+        dy = _c(dy)
+        dy2 = dy.view(-1, N)
+        dw = torch.empty_like(w2d)
+        pooled = {0: dy}
+        dxs = []
+        koff = 0
+        for i, (x, c, s) in enumerate(zip(xs, ctx.chans, ctx.shifts)):
+            if s not in pooled:
+                B, H, W = ctx.full_shape[0], ctx.hw[0], ctx.hw[1]
+                pooled[s] = ops.sumpool(dy.view(B, H, W, N), 1 << s)
+            g2 = pooled[s].view(-1, N)
+            Ms = g2.shape[0]
+            dx = None
+            if ctx.needs_input_grad[4 + i]:
+                dx = torch.empty_like(x)
+                ops.gemm_raw(Ms, c, N, g2, N, OP_DENSE_K, w2d, K, OP_DENSE_R, dx, c, b_ptr_off=koff)
+            dxs.append(dx)
+            sk = ops._pick_splitk(N, c, Ms)
+            if sk > 1:
+                dw[:, koff:koff + c].zero_()
+            ops.gemm_raw(N, c, Ms, g2, N, OP_DENSE_R, x.view(-1, c), c, OP_DENSE_R, dw, K, c_ptr_off=koff, accumulate=sk > 1, splitk=sk)
+            koff += c
+        db = ops.colsum(dy2) if ctx.has_bias else None
+        return (dw, db, None, None, *dxs)
+
+
+# ----------------------------------------------------------------------------------------------
+def _conv_any(x, w4, stride, pad, bias=None):
+    """x NHWC; w4 = OHWI weight.  Cin=3 stem goes through im2col (K=147, row stride 148)."""
+    if x.shape[-1] % 16 != 0:
+        B, H, W, Cin = x.shape
+        Cout, kh, kw, _ = w4.shape
+        K = kh * kw * Cin
+        Kp = (K + 3) // 4 * 4
+        col = ops.im2col(x, kh, kw, stride, pad, Kp)
+        Ho, Wo = ops.conv_out_hw(H, W, kh, stride, pad)
+        out = torch.empty((B, Ho, Wo, Cout), device=x.device, dtype=f32)
+        ops.gemm_raw(B * Ho * Wo, Cout, K, col, Kp, OP_DENSE_K, w4, K, OP_DENSE_K, out, Cout, bias=bias)
+        return out, col
+    return ops.conv2d_fwd(x, w4, stride, pad, bias), None
+
+
+def _conv_wgrad_any(dy, x, col, w4_shape, stride, pad):
+    dw = torch.empty(w4_shape, device=dy.device, dtype=f32)
+    if col is not None:
+        Cout, kh, kw, Cin = w4_shape
+        K = kh * kw * Cin
+        Mpix = col.shape[0]
+        sk = ops._pick_splitk(Cout, K, Mpix)
+        if sk > 1:
+            dw.zero_()
+        ops.gemm_raw(Cout, K, Mpix, dy, Cout, OP_DENSE_R, col, col.shape[1], OP_DENSE_R, dw, K, accumulate=sk > 1, splitk=sk)
+    else:
+        ops.conv2d_wgrad(dy, x, dw, stride, pad, accumulate=False)
+    return dw
+
+
+class ConvFn(torch.autograd.Function):
+    """plain convolution (FPN lateral / merge / 1x1 heads), optional bias."""
+
+    @staticmethod
+    def forward(ctx, x, w, b, stride, pad):
+        x = _c(x)
+        w4 = ohwi(w)
+        y, col = _conv_any(x, w4, stride, pad, b)
+        ctx.stride, ctx.pad, ctx.has_bias = stride, pad, b is not None
+        ctx.save_for_backward(x, w4, col)
+        return y
+
+    @staticmethod
+    def backward(ctx, dy):
+        x, w4, col = ctx.saved_tensors
+        dy = _c(dy)
+        dx = ops.conv2d_dgrad(dy, w4, tuple(x.shape), ctx.stride, ctx.pad) if ctx.needs_input_grad[0] else None
+        dw = _conv_wgrad_any(dy, x, col, tuple(w4.shape), ctx.stride, ctx.pad)
+        db = ops.colsum(dy.view(-1, dy.shape[-1])) if ctx.has_bias else None
+        return dx, oihw_grad_like(dw), db, None, None
+
+
+class ConvBnFn(torch.autograd.Function):
+    """conv (bias-free) -> BatchNorm2d (batch statistics in training, SyncBN-able) -> (+ residual) -> ReLU."""
+
+    @staticmethod
+    def forward(ctx, x, w, gamma, beta, running_mean, running_var, res, stride, pad, relu, training, momentum, eps, sync):
+        x = _c(x)
+        sync = bool(sync) and SyncCtx.active()
+        w4 = ohwi(w)
+        z, col = _conv_any(x, w4, stride, pad)
+        C = z.shape[-1]
+        z2 = z.view(-1, C)
+        M = z2.shape[0]
+        if training:
+            stats = torch.zeros((2 * C + 1,), device=x.device, dtype=torch.float64)
+            ops.bn_stats(z2, stats)
+            count, count_dev = float(M), None
+            if sync:
+                stats[2 * C] = M
+                dist.all_reduce(stats, group=SyncCtx.group)
+                count_dev = stats[2 * C:]                  # global row count stays on the device (no sync)
+            mean, invstd = ops.bn_finalize(stats[:2 * C], count, eps, momentum, running_mean, running_var, count_dev)
+        else:
+            mean, invstd, count, count_dev = running_mean, torch.rsqrt(running_var + eps), float(M), None
+        r2 = None if res is None else _c(res).view(-1, C)
+        y = ops.bn_apply(z2, r2, mean, invstd, gamma, beta, relu).view(z.shape)
+        ctx.cfg = (stride, pad, relu, training, count, res is not None, sync)
+        ctx.save_for_backward(x, w4, col, z, y if relu else None, mean, invstd, gamma, count_dev)
+        return y
+
+    @staticmethod
+    def backward(ctx, dy):
+        x, w4, col, z, y, mean, invstd, gamma, count_dev = ctx.saved_tensors
+        stride, pad, relu, training, count, has_res, sync = ctx.cfg
+        assert training, "BatchNorm backward is implemented for training mode only"
+        C = z.shape[-1]
+        dy2 = _c(dy).view(-1, C)
+        z2 = z.view(-1, C)
+        y2 = None if y is None else y.view(-1, C)
+        sums = torch.zeros((2 * C,), device=dy.device, dtype=torch.float64)
+        ops.bn_bwd_reduce(dy2, y2, z2, mean, invstd, relu, sums)
+        dbeta = sums[:C].to(f32)
+        dgamma = sums[C:].to(f32)
+        if sync:
+            dist.all_reduce(sums, group=SyncCtx.group)
+        dz2, dres2 = ops.bn_bwd_apply(dy2, y2, z2, mean, invstd, gamma, sums, count, relu, has_res, None, None, count_dev)
+        dz = dz2.view(z.shape)
+        dx = ops.conv2d_dgrad(dz, w4, tuple(x.shape), stride, pad) if ctx.needs_input_grad[0] else None
+        dw = _conv_wgrad_any(dz, x, col, tuple(w4.shape), stride, pad)
+        dres = dres2.view(z.shape) if has_res else None
+        return dx, oihw_grad_like(dw), dgamma, dbeta, None, None, dres, None, None, None, None, None, None, None
+
+
+class MaxPoolFn(torch.autograd.Function):
+    @staticmethod
+    def forward(ctx, x):
+        x = _c(x)
+        y, am = ops.maxpool_fwd(x)
+        ctx.hw = (x.shape[1], x.shape[2])
+        ctx.save_for_backward(am)
+        return y
+
+    @staticmethod
+    def backward(ctx, dy):
+        (am,) = ctx.saved_tensors
+        return ops.maxpool_bwd(_c(dy), am, *ctx.hw)
+
+
+class UpAddFn(torch.autograd.Function):
+    """nearest x2 upsample of `lo` + `skip` (FPN top-down, ResNetFPN_ViBERTgrid.py:490-500)."""
+
+    @staticmethod
+    def forward(ctx, lo, skip):
+        return ops.upsample2_add(_c(lo), _c(skip))
+
+    @staticmethod
+    def backward(ctx, dy):
+        dy = _c(dy)
+        return ops.sumpool(dy, 2), dy
+
+
+class NhwcToNchwFlatFn(torch.autograd.Function):
+    """[N,h,w,C] -> [N, C*h*w] in the reference's NCHW flatten order (nn.Flatten at
+    field_type_classification_head.py:72) so `linear.weight` keeps its checkpoint layout."""
+
+    @staticmethod
+    def forward(ctx, x):
+        ctx.shape = x.shape
+        return ops.nhwc_to_nchw(_c(x)).view(x.shape[0], -1)
+
+    @staticmethod
+    def backward(ctx, dy):
+        N, h, w, C = ctx.shape
+        return ops.nchw_to_nhwc(_c(dy).view(N, C, h, w))
+
+
+class RoiAlignFn(torch.autograd.Function):
+    @staticmethod
+    def forward(ctx, feat, boxes, box_doc, out_size, scale):
+        feat = _c(feat)
+        ctx.cfg = (tuple(feat.shape), out_size, scale)
+        ctx.save_for_backward(boxes, box_doc)
+        return ops.roi_align_fwd(feat, boxes, box_doc, out_size, scale)
+
+    @staticmethod
+    def backward(ctx, dy):
+        boxes, box_doc = ctx.saved_tensors
+        shape, out_size, scale = ctx.cfg
+        dfeat = torch.zeros(shape, device=dy.device, dtype=f32)
+        ops.roi_align_bwd(_c(dy), shape, boxes, box_doc, out_size, scale, dfeat)
+        return dfeat, None, None, None, None
+
+
+class SegReduceFn(torch.autograd.Function):
+    @staticmethod
+    def forward(ctx, tok, tok_row, run_start, run_len, mode):
+        tok = _c(tok)
+        ctx.mode, ctx.shape = mode, tok.shape
+        ctx.save_for_backward(tok_row, run_start, run_len)
+        return ops.seg_reduce_fwd(tok, tok_row, run_start, run_len, mode)
+
+    @staticmethod
+    def backward(ctx, dy):
+        tok_row, run_start, run_len = ctx.saved_tensors
+        dtok = torch.zeros(ctx.shape, device=dy.device, dtype=f32)
+        ops.seg_reduce_bwd(_c(dy), tok_row, run_start, run_len, ctx.mode, dtok)
+        return dtok, None, None, None, None
+
+
+class GridScatterFn(torch.autograd.Function):
+    @staticmethod
+    def forward(ctx, emb, owner, boxes, box_doc, stride, layout):
+        emb = _c(emb)
+        ctx.cfg = (stride, layout, emb.shape)
+        ctx.save_for_backward(owner, boxes, box_doc)
+        return ops.grid_scatter_fwd(emb, owner, emb.shape[1], layout)
+
+    @staticmethod
+    def backward(ctx, dy):
+        owner, boxes, box_doc = ctx.saved_tensors
+        stride, layout, shape = ctx.cfg
+        dy = _c(dy)
+        if layout == 1:
+            dy = ops.nchw_to_nhwc(dy)
+        demb = torch.zeros(shape, device=dy.device, dtype=f32)
+        ops.grid_scatter_bwd(dy, owner, boxes, box_doc, stride, demb)
+        return demb, None, None, None, None, None
+
+
+# ----------------------------------------------------------------------------------------------
+# BERT
+# ----------------------------------------------------------------------------------------------
+class BertEmbedFn(torch.autograd.Function):
+    @staticmethod
+    def forward(ctx, word, pos, typ, gamma, beta, ids, pos_ids, eps, p, seed, sid):
+        type0 = typ[0].contiguous()
+        out, xhat, rstd = ops.embed_ln_fwd(ids, pos_ids, word, pos, type0, gamma, beta, eps, p, seed, sid)
+        ctx.cfg = (p, seed, sid, word.shape, pos.shape, typ.shape)
+        ctx.save_for_backward(xhat, rstd, ids, pos_ids, gamma)
+        return out
+
+    @staticmethod
+    def backward(ctx, dout):
+        xhat, rstd, ids, pos_ids, gamma = ctx.saved_tensors
+        p, seed, sid, wshape, pshape, tshape = ctx.cfg
+        dev = dout.device
+        dword = torch.zeros(wshape, device=dev, dtype=f32)
+        dpos = torch.zeros(pshape, device=dev, dtype=f32)
+        dtyp = torch.zeros(tshape, device=dev, dtype=f32)
+        dg = torch.zeros_like(gamma)
+        db = torch.zeros_like(gamma)
+        ops.embed_ln_bwd(_c(dout), xhat, rstd, ids, pos_ids, gamma, p, seed, sid, dword, dpos, dtyp[0], dg, db)
+        return dword, dpos, dtyp, dg, db, None, None, None, None, None, None
+
+
+class AttnMeta:
+    """Host-built description of the packed variable-length sequences of one batch (see
+    model/BERTgrid_generator.py in this package): device tables for the grouped attention GEMMs."""
+    __slots__ = ("ntok", "nseq", "heads", "dh", "maxlen", "ld", "s_elems", "soff", "lens", "ldp", "t_qk", "t_pv", "t_dp", "t_dv",
+                 "t_dq", "t_dk", "ngroups")
+
+
+class BertLayerFn(torch.autograd.Function):
+    """One transformer encoder layer over packed tokens [ntok, hidden] (HF BertLayer: self-attention,
+    out-proj + dropout + residual LN, FFN(GELU erf) + dropout + residual LN)."""
+
+    @staticmethod
+    def forward(ctx, x, wq, bq, wk, bk, wv, bv, wo, bo, g1, b1, wi, bi, wo2, bo2, g2, b2, meta, eps, p, seed, layer):
+        x = _c(x)
+        ntok, hid = x.shape
+        H, dh = meta.heads, meta.dh
+        dev = x.device
+        qkv = torch.empty((ntok, 3 * hid), device=dev, dtype=f32)
+        for j, (w, b) in enumerate(((wq, bq), (wk, bk), (wv, bv))):
+            ops.gemm_raw(ntok, hid, hid, x, hid, OP_DENSE_K, w, hid, OP_DENSE_K, qkv, 3 * hid, bias=b, c_ptr_off=j * hid)
+        # scores -> probabilities (in place), grouped over (sequence, head)
+        P = torch.empty((meta.s_elems,), device=dev, dtype=f32)
+        ops.gemm_raw(0, 0, 0, qkv, 3 * hid, OP_DENSE_K, qkv, 3 * hid, OP_DENSE_K, P, meta.ld, grp=meta.t_qk, ngroups=meta.ngroups,
+                     grp_max=(meta.maxlen, meta.maxlen), b_ptr_off=hid)
+        sid = layer * 8
+        ops.softmax_fwd(P, meta.soff, meta.lens, meta.ldp, meta.ngroups, H, meta.maxlen, 1.0 / (dh ** 0.5), p, seed, sid + 0)
+        ctxv = torch.empty((ntok, hid), device=dev, dtype=f32)
+        ops.gemm_raw(0, 0, 0, P, meta.ld, OP_DENSE_K, qkv, 3 * hid, OP_DENSE_R, ctxv, hid, grp=meta.t_pv, ngroups=meta.ngroups,
+                     grp_max=(meta.maxlen, dh), b_ptr_off=2 * hid, a_relu_scale=1.0 / (1.0 - p))
+        ao = ops.linear_fwd(ctxv, wo, bo)
+        x1, xh1, rs1 = ops.dropout_add_ln_fwd(ao, x, g1, b1, eps, p, seed, sid + 1)
+        h, g = ops.linear_fwd(x1, wi, bi, EPI_GELU_DUAL)
+        fo = ops.linear_fwd(g, wo2, bo2)
+        y, xh2, rs2 = ops.dropout_add_ln_fwd(fo, x1, g2, b2, eps, p, seed, sid + 2)
+        ctx.meta, ctx.cfg = meta, (eps, p, seed, sid)
+        ctx.save_for_backward(x, wq, wk, wv, wo, g1, wi, wo2, g2, qkv, P, ctxv, xh1, rs1, x1, h, g, xh2, rs2)
+        return y
+
+    @staticmethod
+    def backward(ctx, dy):
+        (x, wq, wk, wv, wo, g1, wi, wo2, g2, qkv, P, ctxv, xh1, rs1, x1, h, g, xh2, rs2) = ctx.saved_tensors
+        meta = ctx.meta
+        eps, p, seed, sid = ctx.cfg
+        ntok, hid = x.shape
+        H, dh = meta.heads, meta.dh
+        dev = x.device
+        z = lambda t: torch.zeros_like(t)
+        dg2, db2 = z(g2), z(g2)
+        dfo, dx1 = ops.dropout_add_ln_bwd(_c(dy), xh2, rs2, g2, p, seed, sid + 2, dg2, db2)
+        # FFN
+        dwo2 = torch.empty_like(wo2)
+        ops.linear_wgrad(dfo, g, dwo2, accumulate=False)
+        dbo2 = ops.colsum(dfo)
+        dh_ = ops.linear_dgrad(dfo, wo2)
+        ops.gelu_bwd_(h, dh_)
+        dwi = torch.empty_like(wi)
+        ops.linear_wgrad(dh_, x1, dwi, accumulate=False)
+        dbi = ops.colsum(dh_)
+        ops.linear_dgrad(dh_, wi, out=dx1, accumulate=True)
+        # LN1
+        dg1, db1 = z(g1), z(g1)
+        dao, dx = ops.dropout_add_ln_bwd(dx1, xh1, rs1, g1, p, seed, sid + 1, dg1, db1)
+        dwo = torch.empty_like(wo)
+        ops.linear_wgrad(dao, ctxv, dwo, accumulate=False)
+        dbo = ops.colsum(dao)
+        dctx = ops.linear_dgrad(dao, wo)
+        # attention backward (grouped GEMMs + row softmax backward)
+        dP = torch.empty_like(P)
+        ops.gemm_raw(0, 0, 0, dctx, hid, OP_DENSE_K, qkv, 3 * hid, OP_DENSE_K, dP, meta.ld, grp=meta.t_dp, ngroups=meta.ngroups,
+                     grp_max=(meta.maxlen, meta.maxlen), b_ptr_off=2 * hid)
+        dqkv = torch.empty_like(qkv)
+        ops.gemm_raw(0, 0, 0, P, meta.ld, OP_DENSE_R, dctx, hid, OP_DENSE_R, dqkv, 3 * hid, grp=meta.t_dv, ngroups=meta.ngroups,
+                     grp_max=(meta.maxlen, dh), c_ptr_off=2 * hid, a_relu_scale=1.0 / (1.0 - p))
+        ops.softmax_bwd(P, dP, meta.soff, meta.lens, meta.ldp, meta.ngroups, H, meta.maxlen, 1.0 / (dh ** 0.5), p)
+        ops.gemm_raw(0, 0, 0, dP, meta.ld, OP_DENSE_K, qkv, 3 * hid, OP_DENSE_R, dqkv, 3 * hid, grp=meta.t_dq, ngroups=meta.ngroups,
+                     grp_max=(meta.maxlen, dh), b_ptr_off=hid)
+        ops.gemm_raw(0, 0, 0, dP, meta.ld, OP_DENSE_R, qkv, 3 * hid, OP_DENSE_R, dqkv, 3 * hid, grp=meta.t_dk, ngroups=meta.ngroups,
+                     grp_max=(meta.maxlen, dh), c_ptr_off=hid)
+        # QKV projections
+        dws = []
+        for j, w in enumerate((wq, wk, wv)):
+            dj = dqkv[:, j * hid:(j + 1) * hid]
+            dw = torch.empty_like(w)
+            ops.linear_wgrad(dj, x, dw, accumulate=False)
+            dws.append(dw)
+            ops.linear_dgrad(dj, w, out=dx, accumulate=True)
+        dbqkv = ops.colsum(dqkv)
+        return (dx, dws[0], dbqkv[:hid], dws[1], dbqkv[hid:2 * hid], dws[2], dbqkv[2 * hid:], dwo, dbo, dg1, db1, dwi, dbi, dwo2, dbo2,
+                dg2, db2, None, None, None, None, None)
+
+
+# ----------------------------------------------------------------------------------------------
+# losses
+# ----------------------------------------------------------------------------------------------
+class SelectedCEFn(torch.autograd.Function):
+    """sum_i w[t_i] * CE(logits[row(e_i)], t_i) * scale over a selected element list `elem` (int32,
+    already chosen by the sampling / OHEM logic); returns a 0-dim fp32 tensor."""
+
+    @staticmethod
+    def forward(ctx, logits2d, elem, labels, weight, scale, up_shift, H, W):
+        n = int(elem.numel())
+        loss = ops.ce_fwd(logits2d, elem, labels, n, weight, up_shift, H, W)
+        out = torch.zeros((1,), device=logits2d.device, dtype=f32)
+        ops.sum_f32(loss, out)
+        ctx.cfg = (n, scale, up_shift, H, W)
+        ctx.save_for_backward(logits2d, elem, labels, weight)
+        return (out * scale).view(())
+
+    @staticmethod
+    def backward(ctx, dout):
+        logits2d, elem, labels, weight = ctx.saved_tensors
+        n, scale, up_shift, H, W = ctx.cfg
+        dl = torch.zeros_like(logits2d)
+        g = _c(dout).to(f32).view(1)
+        ops.ce_bwd(logits2d, elem, labels, n, weight, g, scale, up_shift, H, W, dl)
+        return dl, None, None, None, None, None, None, None

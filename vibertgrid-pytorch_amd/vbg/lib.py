@@ -48,6 +48,7 @@ SIGNATURES = {
     "vbg_dropout_add_ln_bwd": (c_int, [c_vp, c_vp, c_vp, c_int, c_int, c_vp, c_f, c_ull, c_ull, c_vp, c_vp, c_vp, c_vp, c_vp]),
     "vbg_softmax_fwd": (c_int, [c_vp, c_vp, c_vp, c_vp, c_int, c_int, c_int, c_f, c_f, c_ull, c_ull, c_vp]),
     "vbg_softmax_bwd": (c_int, [c_vp, c_vp, c_vp, c_vp, c_vp, c_int, c_int, c_int, c_f, c_f, c_vp]),
+    "vbg_row_softmax": (c_int, [c_vp, c_int, c_int, c_vp, c_vp]),
     "vbg_gelu_bwd": (c_int, [c_vp, c_vp, c_ll, c_vp]),
     "vbg_relu_bwd": (c_int, [c_vp, c_vp, c_ll, c_vp]),
     "vbg_add_inplace": (c_int, [c_vp, c_vp, c_ll, c_vp]),
@@ -59,10 +60,10 @@ SIGNATURES = {
     "vbg_grid_scatter_bwd": (c_int, [c_vp, c_vp, c_vp, c_vp, c_int, c_int, c_int, c_int, c_int, c_vp, c_vp]),
     "vbg_label_raster": (c_int, [c_vp, c_vp, c_ll, c_vp, c_vp, c_vp]),
     "vbg_bn_stats": (c_int, [c_vp, c_ll, c_int, c_vp, c_vp]),
-    "vbg_bn_finalize": (c_int, [c_vp, c_d, c_int, c_f, c_f, c_vp, c_vp, c_vp, c_vp, c_vp]),
+    "vbg_bn_finalize": (c_int, [c_vp, c_d, c_vp, c_int, c_f, c_f, c_vp, c_vp, c_vp, c_vp, c_vp]),
     "vbg_bn_apply": (c_int, [c_vp, c_vp, c_ll, c_int, c_vp, c_vp, c_vp, c_vp, c_int, c_vp, c_vp]),
     "vbg_bn_bwd_reduce": (c_int, [c_vp, c_vp, c_vp, c_ll, c_int, c_vp, c_vp, c_int, c_vp, c_vp]),
-    "vbg_bn_bwd_apply": (c_int, [c_vp, c_vp, c_vp, c_ll, c_int, c_vp, c_vp, c_vp, c_vp, c_d, c_int, c_vp, c_vp, c_vp, c_vp, c_vp]),
+    "vbg_bn_bwd_apply": (c_int, [c_vp, c_vp, c_vp, c_ll, c_int, c_vp, c_vp, c_vp, c_vp, c_d, c_vp, c_int, c_vp, c_vp, c_vp, c_vp, c_vp]),
     "vbg_maxpool3x3s2_fwd": (c_int, [c_vp, c_int, c_int, c_int, c_int, c_vp, c_vp, c_vp]),
     "vbg_maxpool3x3s2_bwd": (c_int, [c_vp, c_vp, c_int, c_int, c_int, c_int, c_int, c_int, c_vp, c_vp]),
     "vbg_upsample2_add": (c_int, [c_vp, c_vp, c_int, c_int, c_int, c_int, c_vp, c_vp]),

@@ -260,6 +260,13 @@ def softmax_bwd(pbuf, dp, off, lens, ldp, ngroups, heads, maxlen, scale, p):
     check(lib.vbg_softmax_bwd(P(pbuf), P(dp), P(off), P(lens), P(ldp), ngroups, heads, maxlen, scale, p, _stream()), "vbg_softmax_bwd")
 
 
+def row_softmax(x):
+    rows, cols = x.shape
+    y = torch.empty_like(x)
+    check(lib.vbg_row_softmax(P(x.contiguous()), rows, cols, P(y), _stream()), "vbg_row_softmax")
+    return y
+
+
 def gelu_bwd_(h, dg):
     check(lib.vbg_gelu_bwd(P(h), P(dg), dg.numel(), _stream()), "vbg_gelu_bwd")
     return dg
@@ -332,11 +339,11 @@ def bn_stats(x2d, stats):
     check(lib.vbg_bn_stats(P(x2d), M, C_, P(stats), _stream()), "vbg_bn_stats")
 
 
-def bn_finalize(stats, count, eps, momentum, running_mean, running_var):
+def bn_finalize(stats, count, eps, momentum, running_mean, running_var, count_dev=None):
     C_ = stats.numel() // 2
     mean = torch.empty((C_,), device=stats.device, dtype=f32)
     invstd = torch.empty_like(mean)
-    check(lib.vbg_bn_finalize(P(stats), float(count), C_, eps, momentum, P(mean), P(invstd), P(running_mean), P(running_var), _stream()), "vbg_bn_finalize")
+    check(lib.vbg_bn_finalize(P(stats), float(count), P(count_dev), C_, eps, momentum, P(mean), P(invstd), P(running_mean), P(running_var), _stream()), "vbg_bn_finalize")
     return mean, invstd
 
 
@@ -353,11 +360,11 @@ def bn_bwd_reduce(dy, y, x, mean, invstd, relu, sums):
     check(lib.vbg_bn_bwd_reduce(P(dy), P(y), P(x), M, C_, P(mean), P(invstd), int(relu), P(sums), _stream()), "vbg_bn_bwd_reduce")
 
 
-def bn_bwd_apply(dy, y, x, mean, invstd, gamma, sums, count, relu, want_dres, dgamma, dbeta):
+def bn_bwd_apply(dy, y, x, mean, invstd, gamma, sums, count, relu, want_dres, dgamma, dbeta, count_dev=None):
     M, C_ = x.shape
     dx = torch.empty_like(x)
     dres = torch.empty_like(x) if want_dres else None
-    check(lib.vbg_bn_bwd_apply(P(dy), P(y), P(x), M, C_, P(mean), P(invstd), P(gamma), P(sums), float(count), int(relu), P(dx), P(dres),
+    check(lib.vbg_bn_bwd_apply(P(dy), P(y), P(x), M, C_, P(mean), P(invstd), P(gamma), P(sums), float(count), P(count_dev), int(relu), P(dx), P(dres),
                                P(dgamma), P(dbeta), _stream()), "vbg_bn_bwd_apply")
     return dx, dres
 
