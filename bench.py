@@ -1,0 +1,223 @@
+#!/usr/bin/env python3
+"""Training-throughput bench of the MI355X-native ViBERTgrid step (BASELINE.json metric).
+
+    python bench.py --gpus 1 --steps K --warmup W
+    python -m torch.distributed.run --nnodes=1 --nproc-per-node N --master-addr 127.0.0.1 --master-port P \
+        bench.py --gpus N --steps K --warmup W
+
+One "step" = the body of the reference's train loop (pipeline/train_val_utils.py:248-287) on one synthetic
+batch that is already resident in HBM: forward (ViBERTgridNet, train mode, dropout on), loss .item(), zero_grad,
+backward (+ bucketed RCCL all-reduce when N > 1), conditional grad-norm clip, fused SGD + AdamW steps, barrier.
+Workload = BASELINE.json configs[1]: SROIE line-level, resnet_34_fpn_pretrained + bert-base-uncased (12 layers,
+vocab 30522, random init: no network for checkpoints), 512x512, seq_len 512, 128 segments, batch 8 per GPU.
+Prints ONE JSON line on rank 0.
+"""
+import argparse
+import json
+import os
+import random
+import sys
+import tempfile
+import time
+
+ROOT = os.path.dirname(os.path.abspath(__file__))
+sys.path.insert(0, os.path.join(ROOT, "vibertgrid-pytorch_amd"))
+
+import torch
+import torch.distributed as dist
+
+NCLS, VOCAB = 5, 30522
+F_STEP_GF = 690.1          # algorithmic GFLOP per document of one training step at cfg2 (PAD excluded)
+PEAK_F32_TF = 157.3        # MI355X fp32 MFMA peak (MI355X_MICROARCH.md)
+
+
+def make_bert_dir(top, layers=12, vocab=VOCAB, dropout=0.1):
+    from transformers import BertConfig
+    d = os.path.join(top, "bert-base-uncased")
+    os.makedirs(d, exist_ok=True)
+    BertConfig(vocab_size=vocab, num_hidden_layers=layers, hidden_dropout_prob=dropout, attention_probs_dropout_prob=dropout).save_pretrained(d)
+    toks = ["[PAD]"] + [f"[unused{i}]" for i in range(1, 100)] + ["[UNK]", "[CLS]", "[SEP]", "[MASK]"]
+    toks += [f"tok{i}" for i in range(len(toks), vocab)]
+    with open(os.path.join(d, "vocab.txt"), "w") as f:
+        f.write("\n".join(toks) + "\n")
+    return d
+
+
+def synthetic_batch(B, H, W, T, S, ncls, vocab, seed):
+    """SURVEY.md §8(d) synthetic documents (fixed across steps: data loading is off the clock)."""
+    g = torch.Generator().manual_seed(seed)
+    imgs = tuple(torch.rand(3, H, W, generator=g) for _ in range(B))
+    coors, segs, classes = [], [], []
+    for _ in range(B):
+        x1 = torch.randint(0, W - 72, (S,), generator=g)
+        y1 = torch.randint(0, H - 24, (S,), generator=g)
+        w = torch.randint(8, 73, (S,), generator=g)
+        h = torch.randint(8, 25, (S,), generator=g)
+        coors.append(torch.stack([x1, y1, x1 + w, y1 + h], 1).long())
+        segs.append(torch.arange(S, dtype=torch.int32).repeat_interleave(T // S))
+        classes.append(torch.randint(0, ncls, (S,), generator=g).int())
+    corpus = torch.randint(1000, vocab, (B, T), generator=g)
+    mask = torch.ones(B, T, dtype=torch.int32)
+    return imgs, tuple(segs), tuple(classes), tuple(coors), corpus, mask
+
+
+def build_model(tmp, backbone="resnet_34_fpn_pretrained", layers=12, vocab=VOCAB, dropout=0.1):
+    import warnings
+    from transformers import BertTokenizer
+    from model.ViBERTgrid_net import ViBERTgridNet
+    d = make_bert_dir(tmp, layers, vocab, dropout)
+    cwd = os.getcwd()
+    os.chdir(tmp)
+    try:
+        with warnings.catch_warnings():
+            warnings.simplefilter("ignore")
+            # work_mode="eval" builds BERT from its config (no checkpoint download); .train() flips work_mode to "train"
+            net = ViBERTgridNet(num_classes=NCLS, image_mean=[0.9248, 0.9224, 0.9215], image_std=[0.1532, 0.1545, 0.1536],
+                                image_min_size=[512], image_max_size=512, test_image_min_size=512, bert_model="bert-base-uncased",
+                                tokenizer=BertTokenizer(os.path.join(d, "vocab.txt")), backbone=backbone, grid_mode="mean",
+                                loss_weights=None, num_hard_positive_main_1=16, num_hard_negative_main_1=16,
+                                num_hard_positive_main_2=32, num_hard_negative_main_2=32, loss_aux_sample_list=[256, 512, 256],
+                                num_hard_positive_aux=256, num_hard_negative_aux=256, loss_control_lambda=1, add_pos_neg=True,
+                                classifier_mode="simp", ohem_random=True, layer_mode="single", work_mode="eval")
+    finally:
+        os.chdir(cwd)
+    return net
+
+
+def cpu_baseline(threads):
+    """The CPU oracle (oracle/vbg_oracle.py: the pinned restatement of the reference's step) timed on this box's
+    host cores on a bounded sample: ONE cfg2-shaped document (B=1), one forward+backward+optimizer step."""
+    sys.path.insert(0, os.path.join(ROOT, "oracle"))
+    import vbg_oracle as O
+    torch.set_num_threads(threads)
+    cfg = O.NetCfg(num_classes=NCLS, backbone="resnet_34_fpn_pretrained", bert=O.BertCfg(layers=12, dropout=0.1))
+    sd = O.synth_state_dict(O.state_shapes(cfg, vocab=VOCAB, dup_bert=False))
+    sd = {k: (v.requires_grad_(True) if v.is_floating_point() and "running" not in k else v) for k, v in sd.items()}
+    batch = synthetic_batch(1, 512, 512, 512, 128, NCLS, VOCAB, 4321)
+    random.seed(0)
+    t0 = time.time()
+    loss = O.forward(sd, cfg, *batch, training=True)[0]
+    loss.backward()
+    with torch.no_grad():
+        for k, v in sd.items():
+            if v.grad is None:
+                continue
+            if "bert_model" in k:
+                p, m, vv = O.adamw_step(v, v.grad, torch.zeros_like(v), torch.zeros_like(v), 1, 5e-5, 0.9, 0.999, 1e-8, 0.01)
+            else:
+                p, m = O.sgd_step(v, v.grad, None, 0.005, 0.9, 0.005)
+            v.copy_(p)
+    dt = time.time() - t0
+    return {"value": round(1.0 / dt, 5), "unit": "docs/sec", "cores": threads, "kind": "port",
+            "sample": f"1 document (cfg2 shape: 512x512, T=512, S=128, r34+bert-base), 1 step fwd+bwd+opt, {dt:.1f} s, torch CPU fp32"}
+
+
+def main():
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--gpus", type=int, default=1)
+    ap.add_argument("--steps", type=int, default=10)
+    ap.add_argument("--warmup", type=int, default=3)
+    ap.add_argument("--batch", type=int, default=8, help="documents per GPU (BASELINE config: 8)")
+    ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--no-syncbn", action="store_true")
+    args = ap.parse_args()
+
+    world = int(os.environ.get("WORLD_SIZE", "1"))
+    rank = int(os.environ.get("RANK", "0"))
+    local = int(os.environ.get("LOCAL_RANK", "0"))
+    if not torch.cuda.is_available():
+        raise SystemExit("bench.py needs a GPU: the HIP library is the product, there is no CPU fallback")
+    torch.cuda.set_device(local)
+    dev = torch.device("cuda", local)
+    if world > 1:
+        os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
+        dist.init_process_group("nccl", rank=rank, world_size=world)
+    assert world == args.gpus, f"--gpus {args.gpus} but WORLD_SIZE={world} (launch with torch.distributed.run)"
+
+    from vbg import ops
+    from vbg.lib import OP_DENSE_K
+    from vbg.optim import FlatReducer, FusedAdamW, FusedSGD, clip_grad_norm_, split_parameters
+
+    torch.manual_seed(42)
+    random.seed(42 + rank)
+    tmp = tempfile.mkdtemp(prefix="vbg_bench_")
+    net = build_model(tmp)
+    sync_bn = world > 1 and not args.no_syncbn
+    if sync_bn:
+        net = torch.nn.SyncBatchNorm.convert_sync_batchnorm(net)      # example_config.yaml syncBN: True
+    net = net.to(dev).train()
+    cnn, bert = split_parameters(net)
+    opt_cnn = FusedSGD(cnn, dev, lr=0.005, momentum=0.9, weight_decay=0.005)
+    opt_bert = FusedAdamW(bert, dev, lr=5e-5, betas=(0.9, 0.999), eps=1e-8, weight_decay=0.01)
+    opts = [opt_cnn, opt_bert]
+    reducer = FlatReducer(opts)
+
+    B = args.batch
+    batch = synthetic_batch(B, 512, 512, 512, 128, NCLS, VOCAB, 1234 + rank)
+    mv = lambda ts: tuple(t.to(dev) for t in ts)
+    dbatch = (mv(batch[0]), mv(batch[1]), mv(batch[2]), mv(batch[3]), batch[4].to(dev), batch[5].to(dev))
+
+    def step():
+        loss = net(*dbatch)
+        val = loss.item()
+        opt_cnn.zero_grad()
+        opt_bert.zero_grad()
+        loss.backward()
+        reducer.finish()
+        if val > 10:
+            clip_grad_norm_(opts, 2.0, 1.0 / world)
+        opt_cnn.step()
+        opt_bert.step()
+        if world > 1:
+            dist.barrier()
+        return val
+
+    for _ in range(args.warmup):
+        last = step()
+
+    prof = ops.GemmProfiler(OP_DENSE_K, OP_DENSE_K, False)       # the dense NT GEMM (BERT linears, 1x1 convs): dominant kernel
+    ops.set_gemm_profiler(prof)
+    if world > 1:
+        dist.barrier()
+    torch.cuda.synchronize()
+    t0 = time.perf_counter()
+    for _ in range(args.steps):
+        last = step()
+    if world > 1:
+        dist.barrier()
+    torch.cuda.synchronize()
+    dt = time.perf_counter() - t0
+    ops.set_gemm_profiler(None)
+    if world > 1:
+        t = torch.tensor([dt], device=dev, dtype=torch.float64)
+        dist.all_reduce(t, op=dist.ReduceOp.MAX)
+        dt = float(t.item())
+    launches, flops, ms = prof.summary()
+
+    if rank == 0:
+        docs = B * world * args.steps
+        value = docs / dt
+        ach = (flops / (ms * 1e-3)) / 1e12 if ms > 0 else 0.0
+        out = {
+            "metric": "training docs/sec, 512x512 img + seq_len 512, bert-base+resnet34; 1/2/4/8 GPU",
+            "value": round(value, 3), "unit": "docs/sec", "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
+            "ms_per_step": round(1e3 * dt / args.steps, 3), "higher_is_better": True, "scaling": "weak", "vs_baseline": None,
+            "dtype": "f32", "data": "synthetic",
+            "config": {"workload": "SROIE line-level cfg2: resnet_34_fpn_pretrained + bert-base-uncased (12L, vocab 30522, random init), "
+                                   "512x512, T=512 tokens, S=128 segments, batch 8/GPU, fwd+bwd+SGD/AdamW, dropout 0.1, simp classifier",
+                       "global_batch": B * world, "seq_len": 512, "parallelism": f"dp{world}" + ("+syncbn" if sync_bn else ""),
+                       "last_loss": round(float(last), 4)},
+            "step_mfma_frac": round(value / world * F_STEP_GF / 1e3 / PEAK_F32_TF, 4),
+            "roofline": {"bound": "mfma", "kernel": "vbg::gemm_kernel<128,128,DENSE_K,DENSE_K> (fp32 MFMA NT GEMM)",
+                         "achieved": round(ach, 2), "peak": PEAK_F32_TF, "unit": "TFLOP/s", "frac": round(ach / PEAK_F32_TF, 4),
+                         "traffic": None, "launches": launches, "avg_us": round(1e3 * ms / max(launches, 1), 2)},
+        }
+        if world == 1 and not args.no_cpu_baseline:
+            out["cpu_baseline"] = cpu_baseline(os.cpu_count() or 1)
+        print(json.dumps(out), flush=True)
+    if world > 1:
+        dist.destroy_process_group()
+
+
+if __name__ == "__main__":
+    main()

@@ -70,7 +70,43 @@ def gemm_raw(M, N, K, A, lda, a_kind, B, ldb, b_kind, Cout, ldc, *, bias=None, e
     if grp is not None:
         d.grp, d.ngroups = grp.data_ptr(), int(ngroups)
         d.grp_maxM, d.grp_maxN = int(grp_max[0]), int(grp_max[1])
+    prof = _GEMM_PROF
+    if prof is not None and prof.match(a_kind, b_kind, grp is not None):
+        e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+        e0.record()
+        check(lib.vbg_gemm(C.byref(d), _stream()), "vbg_gemm")
+        e1.record()
+        prof.add(2.0 * M * N * K, e0, e1)
+        return
     check(lib.vbg_gemm(C.byref(d), _stream()), "vbg_gemm")
+
+
+class GemmProfiler:
+    """Optional HIP-event timing of ONE GEMM variant (bench.py roofline): events are recorded on the stream the
+    kernel is launched on (torch's current stream), flops = 2*M*N*K of that launch."""
+
+    def __init__(self, a_kind, b_kind, grouped=False):
+        self.key = (a_kind, b_kind, grouped)
+        self.records = []
+
+    def match(self, a_kind, b_kind, grouped):
+        return (a_kind, b_kind, grouped) == self.key
+
+    def add(self, flops, e0, e1):
+        self.records.append((flops, e0, e1))
+
+    def summary(self):
+        """-> (launches, total_flops, total_ms)  (call after a device sync)"""
+        ms = sum(e0.elapsed_time(e1) for _, e0, e1 in self.records)
+        return len(self.records), sum(f for f, _, _ in self.records), ms
+
+
+_GEMM_PROF = None
+
+
+def set_gemm_profiler(p):
+    global _GEMM_PROF
+    _GEMM_PROF = p
 
 
 def _pick_splitk(M, N, Kred, bk=16):
