@@ -319,14 +319,14 @@ using namespace vbg;
 extern "C" int vbg_bn_stats(const float* x, long long M, int C, double* stats_accum, void* stream) {
     VBG_CHECK_ARG(x && stats_accum && M >= 0 && C > 0);
     if (M == 0) return VBG_OK;
-    hipLaunchKernelGGL(bn_stats_kernel, dim3(cdiv(C, 64), cdiv(M, BN_ROWS)), dim3(256), 0, S_, x, M, C, stats_accum);
+    VBG_LAUNCH(bn_stats_kernel, dim3(cdiv(C, 64), cdiv(M, BN_ROWS)), dim3(256), 0, S_, x, M, C, stats_accum);
     VBG_LAUNCH_RET();
 }
 
 extern "C" int vbg_bn_finalize(const double* stats, double count, const double* count_dev, int C, float eps, float momentum,
                                float* mean, float* invstd, float* running_mean, float* running_var, void* stream) {
     VBG_CHECK_ARG(stats && mean && invstd && C > 0 && (count > 0 || count_dev) && ((running_mean == nullptr) == (running_var == nullptr)));
-    hipLaunchKernelGGL(bn_finalize_kernel, dim3(cdiv(C, 256)), dim3(256), 0, S_, stats, count, count_dev, C, eps, momentum, mean,
+    VBG_LAUNCH(bn_finalize_kernel, dim3(cdiv(C, 256)), dim3(256), 0, S_, stats, count, count_dev, C, eps, momentum, mean,
                        invstd, running_mean, running_var);
     VBG_LAUNCH_RET();
 }
@@ -337,7 +337,7 @@ extern "C" int vbg_bn_apply(const float* x, const float* res, long long M, int C
     VBG_CHECK_ARG(ALIGNED16(x) && ALIGNED16(y) && ALIGNED16(mean) && ALIGNED16(invstd) && ALIGNED16(gamma) && ALIGNED16(beta) &&
                   (!res || ALIGNED16(res)));
     if (M == 0) return VBG_OK;
-    hipLaunchKernelGGL(bn_apply_kernel, dim3(ew_grid(M * (C / 4), 256)), dim3(256), 0, S_, x, res, M, C / 4, mean, invstd, gamma,
+    VBG_LAUNCH(bn_apply_kernel, dim3(ew_grid(M * (C / 4), 256)), dim3(256), 0, S_, x, res, M, C / 4, mean, invstd, gamma,
                        beta, relu, y);
     VBG_LAUNCH_RET();
 }
@@ -346,7 +346,7 @@ extern "C" int vbg_bn_bwd_reduce(const float* dy, const float* y, const float* x
                                  const float* invstd, int relu, double* sums_accum, void* stream) {
     VBG_CHECK_ARG(dy && x && mean && invstd && sums_accum && M >= 0 && C > 0 && (!relu || y));
     if (M == 0) return VBG_OK;
-    hipLaunchKernelGGL(bn_bwd_reduce_kernel, dim3(cdiv(C, 64), cdiv(M, BN_ROWS)), dim3(256), 0, S_, dy, y, x, M, C, mean, invstd,
+    VBG_LAUNCH(bn_bwd_reduce_kernel, dim3(cdiv(C, 64), cdiv(M, BN_ROWS)), dim3(256), 0, S_, dy, y, x, M, C, mean, invstd,
                        relu, sums_accum);
     VBG_LAUNCH_RET();
 }
@@ -356,10 +356,10 @@ extern "C" int vbg_bn_bwd_apply(const float* dy, const float* y, const float* x,
                                 const double* count_dev, int relu, float* dx, float* dres, float* dgamma_accum,
                                 float* dbeta_accum, void* stream) {
     VBG_CHECK_ARG(dy && x && mean && invstd && gamma && sums && dx && M >= 0 && C > 0 && (count > 0 || count_dev) && (!relu || y));
-    if (M > 0) hipLaunchKernelGGL(bn_bwd_apply_kernel, dim3(ew_grid(M * C, 256)), dim3(256), 0, S_, dy, y, x, M, C, mean, invstd,
+    if (M > 0) VBG_LAUNCH(bn_bwd_apply_kernel, dim3(ew_grid(M * C, 256)), dim3(256), 0, S_, dy, y, x, M, C, mean, invstd,
                                   gamma, sums, count, count_dev, relu, dx, dres);
     if (dgamma_accum && dbeta_accum)
-        hipLaunchKernelGGL(bn_param_grad_kernel, dim3(cdiv(C, 256)), dim3(256), 0, S_, sums, C, dgamma_accum, dbeta_accum);
+        VBG_LAUNCH(bn_param_grad_kernel, dim3(cdiv(C, 256)), dim3(256), 0, S_, sums, C, dgamma_accum, dbeta_accum);
     VBG_LAUNCH_RET();
 }
 
@@ -368,7 +368,7 @@ extern "C" int vbg_maxpool3x3s2_fwd(const float* x, int B, int H, int W, int C, 
     const int Ho = (H + 2 - 3) / 2 + 1, Wo = (W + 2 - 3) / 2 + 1;
     const long long total = (long long)B * Ho * Wo * C;
     if (total == 0) return VBG_OK;
-    hipLaunchKernelGGL(maxpool_fwd_kernel, dim3(ew_grid(total, 256)), dim3(256), 0, S_, x, B, H, W, C, Ho, Wo, y, argmax);
+    VBG_LAUNCH(maxpool_fwd_kernel, dim3(ew_grid(total, 256)), dim3(256), 0, S_, x, B, H, W, C, Ho, Wo, y, argmax);
     VBG_LAUNCH_RET();
 }
 
@@ -377,7 +377,7 @@ extern "C" int vbg_maxpool3x3s2_bwd(const float* dy, const int* argmax, int B, i
     VBG_CHECK_ARG(dy && argmax && dx_zeroed && B >= 0 && Ho > 0 && Wo > 0 && C > 0);
     const long long total = (long long)B * Ho * Wo * C;
     if (total == 0) return VBG_OK;
-    hipLaunchKernelGGL(maxpool_bwd_kernel, dim3(ew_grid(total, 256)), dim3(256), 0, S_, dy, argmax, Ho * Wo, C, H * W, total,
+    VBG_LAUNCH(maxpool_bwd_kernel, dim3(ew_grid(total, 256)), dim3(256), 0, S_, dy, argmax, Ho * Wo, C, H * W, total,
                        dx_zeroed);
     VBG_LAUNCH_RET();
 }
@@ -386,7 +386,7 @@ extern "C" int vbg_upsample2_add(const float* lo, const float* skip, int B, int 
     VBG_CHECK_ARG(lo && skip && y && H % 2 == 0 && W % 2 == 0 && C % 4 == 0 && ALIGNED16(lo) && ALIGNED16(skip) && ALIGNED16(y));
     const long long total = (long long)B * H * W * (C / 4);
     if (total == 0) return VBG_OK;
-    hipLaunchKernelGGL(upsample2_add_kernel, dim3(ew_grid(total, 256)), dim3(256), 0, S_, lo, skip, B, H, W, C / 4, y);
+    VBG_LAUNCH(upsample2_add_kernel, dim3(ew_grid(total, 256)), dim3(256), 0, S_, lo, skip, B, H, W, C / 4, y);
     VBG_LAUNCH_RET();
 }
 
@@ -394,21 +394,21 @@ extern "C" int vbg_sumpool(const float* hi, int B, int H, int W, int C, int f, f
     VBG_CHECK_ARG(hi && lo && f >= 1 && H % f == 0 && W % f == 0 && C % 4 == 0 && ALIGNED16(hi) && ALIGNED16(lo));
     const long long total = (long long)B * (H / f) * (W / f) * (C / 4);
     if (total == 0) return VBG_OK;
-    hipLaunchKernelGGL(sumpool_kernel, dim3(ew_grid(total, 256)), dim3(256), 0, S_, hi, B, H, W, C / 4, f, lo, accumulate);
+    VBG_LAUNCH(sumpool_kernel, dim3(ew_grid(total, 256)), dim3(256), 0, S_, hi, B, H, W, C / 4, f, lo, accumulate);
     VBG_LAUNCH_RET();
 }
 
 extern "C" int vbg_nchw_to_nhwc(const float* x, int B, int C, int HW, float* y, void* stream) {
     VBG_CHECK_ARG(x && y && B >= 0 && C > 0 && HW > 0);
     if (B == 0) return VBG_OK;
-    hipLaunchKernelGGL(transpose_kernel, dim3(cdiv(HW, 32), cdiv(C, 32), B), dim3(256), 0, S_, x, C, HW, y);
+    VBG_LAUNCH(transpose_kernel, dim3(cdiv(HW, 32), cdiv(C, 32), B), dim3(256), 0, S_, x, C, HW, y);
     VBG_LAUNCH_RET();
 }
 
 extern "C" int vbg_nhwc_to_nchw(const float* x, int B, int C, int HW, float* y, void* stream) {
     VBG_CHECK_ARG(x && y && B >= 0 && C > 0 && HW > 0);
     if (B == 0) return VBG_OK;
-    hipLaunchKernelGGL(transpose_kernel, dim3(cdiv(C, 32), cdiv(HW, 32), B), dim3(256), 0, S_, x, HW, C, y);
+    VBG_LAUNCH(transpose_kernel, dim3(cdiv(C, 32), cdiv(HW, 32), B), dim3(256), 0, S_, x, HW, C, y);
     VBG_LAUNCH_RET();
 }
 
@@ -416,7 +416,7 @@ extern "C" int vbg_upsample_nhwc_to_nchw(const float* x, int B, int h, int w, in
     VBG_CHECK_ARG(x && y && f >= 1 && C > 0);
     const long long total = (long long)B * C * h * f * w * f;
     if (total == 0) return VBG_OK;
-    hipLaunchKernelGGL(upsample_nhwc_to_nchw_kernel, dim3(ew_grid(total, 256)), dim3(256), 0, S_, x, B, h, w, C, f, y);
+    VBG_LAUNCH(upsample_nhwc_to_nchw_kernel, dim3(ew_grid(total, 256)), dim3(256), 0, S_, x, B, h, w, C, f, y);
     VBG_LAUNCH_RET();
 }
 
@@ -424,7 +424,7 @@ extern "C" int vbg_normalize_resize(const float* img, int h, int w, int oh, int 
                                     float* batch_nhwc, int b, int H, int W, void* stream) {
     VBG_CHECK_ARG(img && h_mean3 && h_std3 && batch_nhwc && h > 0 && w > 0 && oh > 0 && ow > 0 && oh <= H && ow <= W && b >= 0);
     float* out = batch_nhwc + (long long)b * H * W * 3;
-    hipLaunchKernelGGL(normalize_resize_kernel, dim3(cdiv((long)oh * ow, 256)), dim3(256), 0, S_, img, h, w, oh, ow, h_mean3[0],
+    VBG_LAUNCH(normalize_resize_kernel, dim3(cdiv((long)oh * ow, 256)), dim3(256), 0, S_, img, h, w, oh, ow, h_mean3[0],
                        h_mean3[1], h_mean3[2], h_std3[0], h_std3[1], h_std3[2], out, W);
     VBG_LAUNCH_RET();
 }
@@ -433,7 +433,7 @@ extern "C" int vbg_rescale_boxes(const long long* in, int S, float ratio_h, floa
     VBG_CHECK_ARG(S >= 0);
     if (S == 0) return VBG_OK;
     VBG_CHECK_ARG(in && out);
-    hipLaunchKernelGGL(rescale_boxes_kernel, dim3(cdiv(S * 4, 256)), dim3(256), 0, S_, in, S * 4, ratio_h, ratio_w, out);
+    VBG_LAUNCH(rescale_boxes_kernel, dim3(cdiv(S * 4, 256)), dim3(256), 0, S_, in, S * 4, ratio_h, ratio_w, out);
     VBG_LAUNCH_RET();
 }
 
@@ -443,7 +443,7 @@ extern "C" int vbg_im2col(const float* x, int B, int H, int W, int C, int kh, in
     const int Ho = (H + 2 * pad - kh) / stride + 1, Wo = (W + 2 * pad - kw) / stride + 1;
     const long long total = (long long)B * Ho * Wo * Kpad;
     if (total == 0) return VBG_OK;
-    hipLaunchKernelGGL(im2col_kernel, dim3(ew_grid(total, 256)), dim3(256), 0, S_, x, B, H, W, C, kh, kw, stride, pad, Ho, Wo, Kpad,
+    VBG_LAUNCH(im2col_kernel, dim3(ew_grid(total, 256)), dim3(256), 0, S_, x, B, H, W, C, kh, kw, stride, pad, Ho, Wo, Kpad,
                        out);
     VBG_LAUNCH_RET();
 }

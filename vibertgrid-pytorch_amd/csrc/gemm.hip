@@ -332,10 +332,10 @@ static int launch_pair(const vbg_gemm_desc& d, int groups, int maxM, int maxN, h
     const bool big = d.tile == 128 || (d.tile == 0 && tilesL >= 192);
     if (big) {
         dim3 g(cdiv(maxM, 128), cdiv(maxN, 128), groups * d.splitk);
-        hipLaunchKernelGGL((gemm_kernel<128, 128, AK, BKD>), g, dim3(256), 0, s, d);
+        VBG_LAUNCH((gemm_kernel<128, 128, AK, BKD>), g, dim3(256), 0, s, d);
     } else {
         dim3 g(cdiv(maxM, 64), cdiv(maxN, 64), groups * d.splitk);
-        hipLaunchKernelGGL((gemm_kernel<64, 64, AK, BKD>), g, dim3(256), 0, s, d);
+        VBG_LAUNCH((gemm_kernel<64, 64, AK, BKD>), g, dim3(256), 0, s, d);
     }
     VBG_LAUNCH_RET();
 }

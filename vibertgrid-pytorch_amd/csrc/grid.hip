@@ -166,7 +166,7 @@ extern "C" int vbg_seg_reduce_fwd(const float* tok, const int* tok_row, const in
                                   int hidden, int mode, float* out, void* stream) {
     VBG_CHECK_ARG(tok && tok_row && run_start && run_len && out && hidden > 0 && (mode == 0 || mode == 1) && nseg >= 0);
     if (nseg == 0) return VBG_OK;
-    hipLaunchKernelGGL(seg_reduce_fwd_kernel, dim3(nseg), dim3(256), 0, (hipStream_t)stream, tok, tok_row, run_start, run_len,
+    VBG_LAUNCH(seg_reduce_fwd_kernel, dim3(nseg), dim3(256), 0, (hipStream_t)stream, tok, tok_row, run_start, run_len,
                        hidden, mode, out);
     VBG_LAUNCH_RET();
 }
@@ -175,7 +175,7 @@ extern "C" int vbg_seg_reduce_bwd(const float* dout, const int* tok_row, const i
                                   int hidden, int mode, float* dtok_accum, void* stream) {
     VBG_CHECK_ARG(dout && tok_row && run_start && run_len && dtok_accum && hidden > 0 && (mode == 0 || mode == 1) && nseg >= 0);
     if (nseg == 0) return VBG_OK;
-    hipLaunchKernelGGL(seg_reduce_bwd_kernel, dim3(nseg), dim3(256), 0, (hipStream_t)stream, dout, tok_row, run_start, run_len,
+    VBG_LAUNCH(seg_reduce_bwd_kernel, dim3(nseg), dim3(256), 0, (hipStream_t)stream, dout, tok_row, run_start, run_len,
                        hidden, mode, dtok_accum);
     VBG_LAUNCH_RET();
 }
@@ -183,7 +183,7 @@ extern "C" int vbg_seg_reduce_bwd(const float* dout, const int* tok_row, const i
 extern "C" int vbg_owner_map(const int* boxes, const int* box_off, int B, int gh, int gw, int stride, int* owner, void* stream) {
     VBG_CHECK_ARG(box_off && owner && B >= 0 && gh >= 0 && gw >= 0 && stride > 0);
     if (B == 0 || gh == 0 || gw == 0) return VBG_OK;
-    hipLaunchKernelGGL(owner_map_kernel, dim3(cdiv((long)gh * gw, 256), B), dim3(256), 0, (hipStream_t)stream, boxes, box_off, gh,
+    VBG_LAUNCH(owner_map_kernel, dim3(cdiv((long)gh * gw, 256), B), dim3(256), 0, (hipStream_t)stream, boxes, box_off, gh,
                        gw, stride, owner);
     VBG_LAUNCH_RET();
 }
@@ -195,10 +195,10 @@ extern "C" int vbg_grid_scatter_fwd(const float* emb, const int* owner, int B, i
     if (ncell == 0) return VBG_OK;
     if (layout == 0) {
         VBG_CHECK_ARG(C % 4 == 0 && ((uintptr_t)emb % 16 == 0) && ((uintptr_t)grid % 16 == 0));
-        hipLaunchKernelGGL(grid_scatter_nhwc_kernel, dim3(ew_grid(ncell * (C / 4), 256)), dim3(256), 0, (hipStream_t)stream, emb,
+        VBG_LAUNCH(grid_scatter_nhwc_kernel, dim3(ew_grid(ncell * (C / 4), 256)), dim3(256), 0, (hipStream_t)stream, emb,
                            owner, ncell, C / 4, grid);
     } else {
-        hipLaunchKernelGGL(grid_scatter_nchw_kernel, dim3(ew_grid(ncell * C, 256)), dim3(256), 0, (hipStream_t)stream, emb, owner,
+        VBG_LAUNCH(grid_scatter_nchw_kernel, dim3(ew_grid(ncell * C, 256)), dim3(256), 0, (hipStream_t)stream, emb, owner,
                            B, C, gh * gw, grid);
     }
     VBG_LAUNCH_RET();
@@ -209,7 +209,7 @@ extern "C" int vbg_grid_scatter_bwd(const float* dgrid, const int* owner, const 
     VBG_CHECK_ARG(dgrid && owner && demb_accum && nbox >= 0 && gh > 0 && gw > 0 && stride > 0 && C > 0);
     if (nbox == 0) return VBG_OK;
     VBG_CHECK_ARG(boxes && box_doc);
-    hipLaunchKernelGGL(grid_scatter_bwd_kernel, dim3(nbox), dim3(256), 0, (hipStream_t)stream, dgrid, owner, boxes, box_doc, gh, gw,
+    VBG_LAUNCH(grid_scatter_bwd_kernel, dim3(nbox), dim3(256), 0, (hipStream_t)stream, dgrid, owner, boxes, box_doc, gh, gw,
                        stride, C, demb_accum);
     VBG_LAUNCH_RET();
 }
@@ -217,7 +217,7 @@ extern "C" int vbg_grid_scatter_bwd(const float* dgrid, const int* owner, const 
 extern "C" int vbg_label_raster(const int* owner, const int* seg_class, long long ncell, int* pos_neg, int* cls, void* stream) {
     VBG_CHECK_ARG(owner && pos_neg && cls && ncell >= 0);
     if (ncell == 0) return VBG_OK;
-    hipLaunchKernelGGL(label_raster_kernel, dim3(ew_grid(ncell, 256)), dim3(256), 0, (hipStream_t)stream, owner, seg_class, ncell,
+    VBG_LAUNCH(label_raster_kernel, dim3(ew_grid(ncell, 256)), dim3(256), 0, (hipStream_t)stream, owner, seg_class, ncell,
                        pos_neg, cls);
     VBG_LAUNCH_RET();
 }

@@ -114,7 +114,7 @@ extern "C" int vbg_ce_fwd(const float* logits, long long ld, int ncls, const int
     VBG_CHECK_ARG(n >= 0 && ncls > 0 && up_shift >= 0);
     if (n == 0) return VBG_OK;
     VBG_CHECK_ARG(logits && labels && loss);
-    hipLaunchKernelGGL(ce_fwd_kernel, dim3(ew_grid(n, 256)), dim3(256), 0, S_, logits, ld, ncls, elem, labels, n, weight, up_shift,
+    VBG_LAUNCH(ce_fwd_kernel, dim3(ew_grid(n, 256)), dim3(256), 0, S_, logits, ld, ncls, elem, labels, n, weight, up_shift,
                        H, W, loss);
     VBG_LAUNCH_RET();
 }
@@ -125,7 +125,7 @@ extern "C" int vbg_ce_bwd(const float* logits, long long ld, int ncls, const int
     VBG_CHECK_ARG(n >= 0 && ncls > 0 && up_shift >= 0);
     if (n == 0) return VBG_OK;
     VBG_CHECK_ARG(logits && labels && dlogits_accum);
-    hipLaunchKernelGGL(ce_bwd_kernel, dim3(ew_grid(n, 256)), dim3(256), 0, S_, logits, ld, ncls, elem, labels, n, weight,
+    VBG_LAUNCH(ce_bwd_kernel, dim3(ew_grid(n, 256)), dim3(256), 0, S_, logits, ld, ncls, elem, labels, n, weight,
                        gscale_dev, gmul, up_shift, H, W, dlogits_accum);
     VBG_LAUNCH_RET();
 }
@@ -167,7 +167,7 @@ extern "C" int vbg_sort_desc(const float* keys, long long n, float* keys_out, in
     const size_t iota_bytes = (((size_t)n * sizeof(int)) + 255) / 256 * 256;
     VBG_CHECK_ARG((size_t)ws_bytes > iota_bytes);
     int* iota = (int*)ws;
-    hipLaunchKernelGGL(iota_kernel, dim3(ew_grid(n, 256)), dim3(256), 0, S_, iota, n);
+    VBG_LAUNCH(iota_kernel, dim3(ew_grid(n, 256)), dim3(256), 0, S_, iota, n);
     size_t bytes = (size_t)ws_bytes - iota_bytes;
     hipError_t e = rocprim::radix_sort_pairs_desc((char*)ws + iota_bytes, bytes, keys, keys_out, (const int*)iota, idx_out,
                                                   (size_t)n, 0, 32, S_);
@@ -178,7 +178,7 @@ extern "C" int vbg_gather_f32(const float* src, const int* idx, long long n, flo
     VBG_CHECK_ARG(n >= 0);
     if (n == 0) return VBG_OK;
     VBG_CHECK_ARG(src && idx && out);
-    hipLaunchKernelGGL(gather_f32_kernel, dim3(ew_grid(n, 256)), dim3(256), 0, S_, src, idx, n, out);
+    VBG_LAUNCH(gather_f32_kernel, dim3(ew_grid(n, 256)), dim3(256), 0, S_, src, idx, n, out);
     VBG_LAUNCH_RET();
 }
 
@@ -186,7 +186,7 @@ extern "C" int vbg_gather_i32(const int* src, const int* idx, long long n, int* 
     VBG_CHECK_ARG(n >= 0);
     if (n == 0) return VBG_OK;
     VBG_CHECK_ARG(src && idx && out);
-    hipLaunchKernelGGL(gather_i32_kernel, dim3(ew_grid(n, 256)), dim3(256), 0, S_, src, idx, n, out);
+    VBG_LAUNCH(gather_i32_kernel, dim3(ew_grid(n, 256)), dim3(256), 0, S_, src, idx, n, out);
     VBG_LAUNCH_RET();
 }
 
@@ -194,7 +194,7 @@ extern "C" int vbg_sum_f32(const float* x, long long n, float* out_accum, void* 
     VBG_CHECK_ARG(n >= 0 && out_accum);
     if (n == 0) return VBG_OK;
     VBG_CHECK_ARG(x);
-    hipLaunchKernelGGL(sum_kernel, dim3(ew_grid(n, 1024)), dim3(256), 0, S_, x, n, out_accum);
+    VBG_LAUNCH(sum_kernel, dim3(ew_grid(n, 1024)), dim3(256), 0, S_, x, n, out_accum);
     VBG_LAUNCH_RET();
 }
 
@@ -202,6 +202,6 @@ extern "C" int vbg_sumsq(const float* g, long long n, float* out_accum, void* st
     VBG_CHECK_ARG(n >= 0 && out_accum);
     if (n == 0) return VBG_OK;
     VBG_CHECK_ARG(g);
-    hipLaunchKernelGGL(sumsq_kernel, dim3(ew_grid(n, 1024)), dim3(256), 0, S_, g, n, out_accum);
+    VBG_LAUNCH(sumsq_kernel, dim3(ew_grid(n, 1024)), dim3(256), 0, S_, g, n, out_accum);
     VBG_LAUNCH_RET();
 }

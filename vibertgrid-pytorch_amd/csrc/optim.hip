@@ -72,7 +72,7 @@ extern "C" int vbg_sgd_step(float* p, const float* g, float* mom, long long n, f
     if (n == 0) return VBG_OK;
     VBG_CHECK_ARG(p && g && mom);
     const long long n4 = (ALIGNED16(p) && ALIGNED16(g) && ALIGNED16(mom)) ? n / 4 : 0;
-    hipLaunchKernelGGL(sgd_kernel, dim3(ew_grid(n / 4 + 1, 256)), dim3(256), 0, (hipStream_t)stream, p, g, mom, n4, n, lr, momentum,
+    VBG_LAUNCH(sgd_kernel, dim3(ew_grid(n / 4 + 1, 256)), dim3(256), 0, (hipStream_t)stream, p, g, mom, n4, n, lr, momentum,
                        wd, first_step, grad_scale);
     VBG_LAUNCH_RET();
 }
@@ -84,7 +84,7 @@ extern "C" int vbg_adamw_step(float* p, const float* g, float* m, float* v, long
     VBG_CHECK_ARG(p && g && m && v);
     const long long n4 = (ALIGNED16(p) && ALIGNED16(g) && ALIGNED16(m) && ALIGNED16(v)) ? n / 4 : 0;
     const double bc1 = 1.0 - pow((double)b1, (double)step), bc2 = 1.0 - pow((double)b2, (double)step);
-    hipLaunchKernelGGL(adamw_kernel, dim3(ew_grid(n / 4 + 1, 256)), dim3(256), 0, (hipStream_t)stream, p, g, m, v, n4, n, lr, b1, b2,
+    VBG_LAUNCH(adamw_kernel, dim3(ew_grid(n / 4 + 1, 256)), dim3(256), 0, (hipStream_t)stream, p, g, m, v, n4, n, lr, b1, b2,
                        eps, wd, (float)bc1, (float)sqrt(bc2), grad_scale);
     VBG_LAUNCH_RET();
 }

@@ -104,7 +104,7 @@ extern "C" int vbg_roi_align_fwd(const float* feat, int B, int H, int W, int C, 
     VBG_CHECK_ARG(feat && y && B >= 0 && H > 0 && W > 0 && C > 0 && out > 0 && nroi >= 0);
     if (nroi == 0) return VBG_OK;
     VBG_CHECK_ARG(boxes && box_doc);
-    hipLaunchKernelGGL(roi_align_fwd_kernel, dim3(out * out, nroi), dim3(C >= 256 ? 256 : (C >= 128 ? 128 : 64)), 0,
+    VBG_LAUNCH(roi_align_fwd_kernel, dim3(out * out, nroi), dim3(C >= 256 ? 256 : (C >= 128 ? 128 : 64)), 0,
                        (hipStream_t)stream, feat, H, W, C, boxes, box_doc, out, scale, y);
     VBG_LAUNCH_RET();
 }
@@ -114,7 +114,7 @@ extern "C" int vbg_roi_align_bwd(const float* dy, int B, int H, int W, int C, co
     VBG_CHECK_ARG(dy && dfeat_accum && B >= 0 && H > 0 && W > 0 && C > 0 && out > 0 && nroi >= 0);
     if (nroi == 0) return VBG_OK;
     VBG_CHECK_ARG(boxes && box_doc);
-    hipLaunchKernelGGL(roi_align_bwd_kernel, dim3(out * out, nroi), dim3(C >= 256 ? 256 : (C >= 128 ? 128 : 64)), 0,
+    VBG_LAUNCH(roi_align_bwd_kernel, dim3(out * out, nroi), dim3(C >= 256 ? 256 : (C >= 128 ? 128 : 64)), 0,
                        (hipStream_t)stream, dy, H, W, C, boxes, box_doc, out, scale, dfeat_accum);
     VBG_LAUNCH_RET();
 }

@@ -372,7 +372,7 @@ extern "C" int vbg_embed_ln_fwd(const int* ids, const int* pos_ids, int ntok, in
     VBG_CHECK_ARG(ids && pos_ids && word && pos && type0 && gamma && beta && out && xhat && rstd);
     VBG_CHECK_ARG(hidden > 0 && hidden <= LN_THREADS * LN_MAXPER && drop_p >= 0.f && drop_p < 1.f);
     if (ntok <= 0) return VBG_OK;
-    hipLaunchKernelGGL(embed_ln_fwd_kernel, dim3(ntok), dim3(LN_THREADS), 0, (hipStream_t)stream, ids, pos_ids, ntok, hidden,
+    VBG_LAUNCH(embed_ln_fwd_kernel, dim3(ntok), dim3(LN_THREADS), 0, (hipStream_t)stream, ids, pos_ids, ntok, hidden,
                        word, pos, type0, gamma, beta, eps, drop_threshold(drop_p), 1.0f / (1.0f - drop_p), seed, sid, out,
                        xhat, rstd);
     VBG_LAUNCH_RET();
@@ -385,7 +385,7 @@ extern "C" int vbg_embed_ln_bwd(const float* dout, const float* xhat, const floa
     VBG_CHECK_ARG(dout && xhat && rstd && ids && pos_ids && gamma && dword && dpos && dtype0 && dgamma && dbeta);
     VBG_CHECK_ARG(hidden > 0 && hidden <= LN_THREADS * LN_MAXPER && drop_p >= 0.f && drop_p < 1.f);
     if (ntok <= 0) return VBG_OK;
-    hipLaunchKernelGGL(embed_ln_bwd_kernel, dim3(cdiv(ntok, LN_ROWS_PER_BLOCK)), dim3(LN_THREADS), 0, (hipStream_t)stream,
+    VBG_LAUNCH(embed_ln_bwd_kernel, dim3(cdiv(ntok, LN_ROWS_PER_BLOCK)), dim3(LN_THREADS), 0, (hipStream_t)stream,
                        dout, xhat, rstd, ids, pos_ids, ntok, hidden, gamma, drop_threshold(drop_p), 1.0f / (1.0f - drop_p),
                        seed, sid, dword, dpos, dtype0, dgamma, dbeta);
     VBG_LAUNCH_RET();
@@ -397,7 +397,7 @@ extern "C" int vbg_dropout_add_ln_fwd(const float* x, const float* res, int rows
     VBG_CHECK_ARG(x && res && gamma && beta && y && xhat && rstd);
     VBG_CHECK_ARG(hidden > 0 && hidden <= LN_THREADS * LN_MAXPER && drop_p >= 0.f && drop_p < 1.f);
     if (rows <= 0) return VBG_OK;
-    hipLaunchKernelGGL(dropout_add_ln_fwd_kernel, dim3(rows), dim3(LN_THREADS), 0, (hipStream_t)stream, x, res, rows, hidden,
+    VBG_LAUNCH(dropout_add_ln_fwd_kernel, dim3(rows), dim3(LN_THREADS), 0, (hipStream_t)stream, x, res, rows, hidden,
                        gamma, beta, eps, drop_threshold(drop_p), 1.0f / (1.0f - drop_p), seed, sid, y, xhat, rstd);
     VBG_LAUNCH_RET();
 }
@@ -408,7 +408,7 @@ extern "C" int vbg_dropout_add_ln_bwd(const float* dy, const float* xhat, const 
     VBG_CHECK_ARG(dy && xhat && rstd && gamma && dx && dres && dgamma && dbeta);
     VBG_CHECK_ARG(hidden > 0 && hidden <= LN_THREADS * LN_MAXPER && drop_p >= 0.f && drop_p < 1.f);
     if (rows <= 0) return VBG_OK;
-    hipLaunchKernelGGL(dropout_add_ln_bwd_kernel, dim3(cdiv(rows, LN_ROWS_PER_BLOCK)), dim3(LN_THREADS), 0,
+    VBG_LAUNCH(dropout_add_ln_bwd_kernel, dim3(cdiv(rows, LN_ROWS_PER_BLOCK)), dim3(LN_THREADS), 0,
                        (hipStream_t)stream, dy, xhat, rstd, rows, hidden, gamma, drop_threshold(drop_p),
                        1.0f / (1.0f - drop_p), seed, sid, dx, dres, dgamma, dbeta);
     VBG_LAUNCH_RET();
@@ -420,7 +420,7 @@ extern "C" int vbg_softmax_fwd(float* s, const long long* off, const int* len, c
     VBG_CHECK_ARG(s && off && len && ldp && heads > 0 && ngroups >= 0 && ngroups % heads == 0);
     VBG_CHECK_ARG(maxlen >= 0 && maxlen <= 64 * SM_PER && drop_p >= 0.f && drop_p < 1.f);
     if (ngroups == 0 || maxlen == 0) return VBG_OK;
-    hipLaunchKernelGGL(softmax_fwd_kernel, dim3(maxlen, ngroups), dim3(64), 0, (hipStream_t)stream, s, off, len, ldp, heads,
+    VBG_LAUNCH(softmax_fwd_kernel, dim3(maxlen, ngroups), dim3(64), 0, (hipStream_t)stream, s, off, len, ldp, heads,
                        maxlen, scale, drop_threshold(drop_p), seed, sid);
     VBG_LAUNCH_RET();
 }
@@ -430,7 +430,7 @@ extern "C" int vbg_softmax_bwd(const float* p, float* dp, const long long* off, 
     VBG_CHECK_ARG(p && dp && off && len && ldp && heads > 0 && ngroups >= 0 && ngroups % heads == 0);
     VBG_CHECK_ARG(maxlen >= 0 && maxlen <= 64 * SM_PER && drop_p >= 0.f && drop_p < 1.f);
     if (ngroups == 0 || maxlen == 0) return VBG_OK;
-    hipLaunchKernelGGL(softmax_bwd_kernel, dim3(maxlen, ngroups), dim3(64), 0, (hipStream_t)stream, p, dp, off, len, ldp,
+    VBG_LAUNCH(softmax_bwd_kernel, dim3(maxlen, ngroups), dim3(64), 0, (hipStream_t)stream, p, dp, off, len, ldp,
                        heads, scale, 1.0f / (1.0f - drop_p));
     VBG_LAUNCH_RET();
 }
@@ -438,28 +438,28 @@ extern "C" int vbg_softmax_bwd(const float* p, float* dp, const long long* off, 
 extern "C" int vbg_gelu_bwd(const float* h, float* dg, long long n, void* stream) {
     VBG_CHECK_ARG(h && dg && n >= 0);
     if (n == 0) return VBG_OK;
-    hipLaunchKernelGGL(gelu_bwd_kernel, dim3(ew_grid(n / 4, 256)), dim3(256), 0, (hipStream_t)stream, h, dg, n / 4, n);
+    VBG_LAUNCH(gelu_bwd_kernel, dim3(ew_grid(n / 4, 256)), dim3(256), 0, (hipStream_t)stream, h, dg, n / 4, n);
     VBG_LAUNCH_RET();
 }
 
 extern "C" int vbg_relu_bwd(const float* y, float* dy, long long n, void* stream) {
     VBG_CHECK_ARG(y && dy && n >= 0);
     if (n == 0) return VBG_OK;
-    hipLaunchKernelGGL(relu_bwd_kernel, dim3(ew_grid(n / 4, 256)), dim3(256), 0, (hipStream_t)stream, y, dy, n / 4, n);
+    VBG_LAUNCH(relu_bwd_kernel, dim3(ew_grid(n / 4, 256)), dim3(256), 0, (hipStream_t)stream, y, dy, n / 4, n);
     VBG_LAUNCH_RET();
 }
 
 extern "C" int vbg_add_inplace(float* a, const float* b, long long n, void* stream) {
     VBG_CHECK_ARG(a && b && n >= 0);
     if (n == 0) return VBG_OK;
-    hipLaunchKernelGGL(add_inplace_kernel, dim3(ew_grid(n / 4, 256)), dim3(256), 0, (hipStream_t)stream, a, b, n / 4, n);
+    VBG_LAUNCH(add_inplace_kernel, dim3(ew_grid(n / 4, 256)), dim3(256), 0, (hipStream_t)stream, a, b, n / 4, n);
     VBG_LAUNCH_RET();
 }
 
 extern "C" int vbg_scale_inplace(float* x, long long n, float s, void* stream) {
     VBG_CHECK_ARG(x && n >= 0);
     if (n == 0) return VBG_OK;
-    hipLaunchKernelGGL(scale_inplace_kernel, dim3(ew_grid(n, 256)), dim3(256), 0, (hipStream_t)stream, x, n, s);
+    VBG_LAUNCH(scale_inplace_kernel, dim3(ew_grid(n, 256)), dim3(256), 0, (hipStream_t)stream, x, n, s);
     VBG_LAUNCH_RET();
 }
 
@@ -472,7 +472,7 @@ extern "C" int vbg_colsum(const float* x, long long ld, int M, int N, float* out
         if (e != hipSuccess) return (int)e;
     }
     if (M == 0) return VBG_OK;
-    hipLaunchKernelGGL(colsum_kernel, dim3(cdiv(N, 64), cdiv(M, 256)), dim3(256), 0, s, x, ld, M, N, out);
+    VBG_LAUNCH(colsum_kernel, dim3(cdiv(N, 64), cdiv(M, 256)), dim3(256), 0, s, x, ld, M, N, out);
     VBG_LAUNCH_RET();
 }
 
@@ -480,7 +480,7 @@ extern "C" int vbg_row_softmax(const float* x, int rows, int cols, float* y, voi
     VBG_CHECK_ARG(rows >= 0 && cols > 0);
     if (rows == 0) return VBG_OK;
     VBG_CHECK_ARG(x && y);
-    hipLaunchKernelGGL(row_softmax_kernel, dim3(cdiv(rows, 256)), dim3(256), 0, (hipStream_t)stream, x, rows, cols, y);
+    VBG_LAUNCH(row_softmax_kernel, dim3(cdiv(rows, 256)), dim3(256), 0, (hipStream_t)stream, x, rows, cols, y);
     VBG_LAUNCH_RET();
 }
 

@@ -8,6 +8,8 @@
 
 // every C-ABI entry point: 0 ok, negative = argument error, positive = hipError_t
 #define VBG_CHECK_ARG(cond) do { if (!(cond)) return VBG_EARG; } while (0)
+// clear any stale sticky error left by unrelated runtime calls on this thread, then launch
+#define VBG_LAUNCH(...) do { (void)hipGetLastError(); hipLaunchKernelGGL(__VA_ARGS__); } while (0)
 #define VBG_LAUNCH_RET() do { hipError_t e__ = hipGetLastError(); return e__ == hipSuccess ? VBG_OK : (int)e__; } while (0)
 
 typedef float f32x4 __attribute__((ext_vector_type(4)));
