@@ -7,6 +7,9 @@ or `make -C vibertgrid-pytorch_amd/csrc`).
 import ctypes as C
 import os
 
+import torch  # noqa: F401  -- MUST be imported before libvbg.so is dlopen'ed: pointers and streams come from torch, so
+#                              both have to bind to the SAME libamdhip64 instance (torch ships its own copy)
+
 _HERE = os.path.dirname(os.path.abspath(__file__))
 LIB_PATH = os.path.join(os.path.dirname(_HERE), "libvbg.so")
 
