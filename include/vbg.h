@@ -63,10 +63,11 @@ typedef struct vbg_gemm_desc {
     float* C; long long ldc; float* C2; const float* bias;  /* bias[N] or NULL                      */
     int epi; float alpha; int accumulate;                   /* C += result (atomic only if splitk>1)*/
     int splitk;                                             /* >1 requires accumulate               */
-    int tile;                                               /* 0 auto, 64 or 128                    */
+    int tile;                                               /* 0 auto, BM*1000+BN: 128128/128064/64064 */
     /* grouped problems: grp[g*8 + {0..6}] = M, N, K, offA, offB, offC, offBias (elements; offsets */
     /* are relative to A/B/C/bias and may be negative); NULL = single problem                       */
     const long long* grp; int ngroups; int grp_maxM, grp_maxN;
+    int bk;                                                 /* k-tile depth: 0 auto, 16 or 32       */
 } vbg_gemm_desc;
 
 int vbg_gemm(const vbg_gemm_desc* desc, void* stream);

@@ -38,7 +38,7 @@ def _chk_f32(*ts):
 # ----------------------------------------------------------------------------------------------
 def gemm_raw(M, N, K, A, lda, a_kind, B, ldb, b_kind, Cout, ldc, *, bias=None, epi=EPI_NONE, C2=None, accumulate=False,
              splitk=1, geo=None, segs=None, a_hw=(0, 0), a_relu_scale=None, grp=None, ngroups=0, grp_max=(0, 0), tile=0,
-             alpha=1.0, a_ptr_off=0, b_ptr_off=0, c_ptr_off=0):
+             alpha=1.0, a_ptr_off=0, b_ptr_off=0, c_ptr_off=0, bk=0):
     """A, B, Cout: tensors (their data_ptr + element offsets are used)."""
     d = GemmDesc()
     d.M, d.N, d.K = int(M), int(N), int(K)
@@ -67,6 +67,7 @@ def gemm_raw(M, N, K, A, lda, a_kind, B, ldb, b_kind, Cout, ldc, *, bias=None, e
     d.C2 = None if C2 is None else C2.data_ptr() + 4 * c_ptr_off
     d.bias = None if bias is None else bias.data_ptr()
     d.epi, d.alpha, d.accumulate, d.splitk, d.tile = epi, float(alpha), int(bool(accumulate)), int(splitk), int(tile)
+    d.bk = int(bk)
     if grp is not None:
         d.grp, d.ngroups = grp.data_ptr(), int(ngroups)
         d.grp_maxM, d.grp_maxN = int(grp_max[0]), int(grp_max[1])
