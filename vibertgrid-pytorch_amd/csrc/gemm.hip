@@ -8,11 +8,17 @@
 // late / P_fuse fusions (K segments read from several tensors in place; :315-321, :502-506,
 // model/field_type_classification_head.py:181-188) and all their dgrad / wgrad products.
 //
-// Tiling: 256 threads = 4 waves (2x2), block tile BMxBN in {128x128, 64x64}, BK = 16, operands
-// staged through LDS as [k][row] so each MFMA operand read is a conflict-free ds_read_b32 over 32
-// consecutive rows; register prefetch of tile t+1 overlaps the MFMAs of tile t; LDS double
-// buffered (one barrier per k-tile).  fp32 MFMA issues one 32x32x2 every 64 cycles per SIMD, so
-// LDS bandwidth (16 B/clk/CU needed) is never the limiter; the loaders are kept simple.
+// Structure (256 threads = 4 waves in 2x2, block tile BMxBN, k-tile BK, LDS double buffered):
+//  * global -> registers: every load of the vector path is an UNCONDITIONAL float4 from a clamped
+//    (always legal) address; nothing consumes the registers until the LDS-store phase after the
+//    MFMAs of the current tile (zero-masking and the optional A prologue happen there), so the next
+//    tile's loads stay in flight behind the compute and the k-loop has no divergent branches;
+//  * registers -> LDS: one 16-byte ds_write per float4 for both layouts.  K-contiguous operands are
+//    stored row-major [row][BK+4]: the 144-/80-byte row stride puts 16 consecutive rows on 16
+//    different 16-byte slots, so the fragment read is ONE conflict-free ds_read_b128 per 32 rows per
+//    8 k (the MFMA k index is permuted identically for A and B: lanes 0-31 take k = 8g+j, lanes 32-63
+//    k = 8g+4+j at step j).  Row-contiguous operands are stored [k][rows+4] and read with ds_read_b32;
+//  * fragments of k-group g+1 are fetched while the MFMAs of group g issue (two register sets).
 #include "vbg_common.h"
 #include "../../include/vbg.h"
 
@@ -25,25 +31,35 @@ __device__ __forceinline__ float4 mask4(float4 v, int nvalid) {
     v.z = nvalid > 2 ? v.z : 0.f; v.w = nvalid > 3 ? v.w : 0.f;
     return v;
 }
+// general path: element-wise guarded loads (unaligned operands, tiny classifier layers)
+__device__ __forceinline__ float4 lds4(const float* ptr, int nvalid) {
+    float4 v = make_float4(0.f, 0.f, 0.f, 0.f);
+    if (nvalid > 0) v.x = ptr[0];
+    if (nvalid > 1) v.y = ptr[1];
+    if (nvalid > 2) v.z = ptr[2];
+    if (nvalid > 3) v.w = ptr[3];
+    return v;
+}
 
-// VEC = both operands 16-byte aligned with leading dimensions % 4 == 0: every global load is an unconditional
-// float4 from a CLAMPED (always legal) address, out-of-range elements are zeroed by selects -> the k-loop has no
-// divergent branches, so the next tile's loads stay in flight behind the MFMAs.  !VEC = general scalar path.
 template <int BM, int BN, int BK, int AK, int BKD, bool VEC>
 __global__ __launch_bounds__(256) void gemm_kernel(const vbg_gemm_desc p) {
     constexpr int KF = BK / 4;                 // float4 chunks per row of a K-contiguous tile
+    constexpr int NG = BK / 8;                 // k-groups (8 k = 4 MFMA steps) per tile
     constexpr bool A_KC = (AK == VBG_OP_DENSE_K || AK == VBG_OP_CONV_K);
     constexpr bool B_KC = (BKD == VBG_OP_DENSE_K);
-    constexpr int SA = A_KC ? BM + 1 : BM + 4;
-    constexpr int SB = B_KC ? BN + 1 : BN + 4;
+    constexpr int SKR = BK + 4;                // row stride of a row-major (K-contiguous) LDS tile
+    constexpr int SA = BM + 4, SB = BN + 4;    // k-row stride of a k-major (row-contiguous) LDS tile
+    constexpr int ASZ = A_KC ? BM * SKR : BK * SA;
+    constexpr int BSZ = B_KC ? BN * SKR : BK * SB;
     constexpr int NA = BM * KF / 256;
     constexpr int NB = BN * KF / 256;
     constexpr int WM = BM / 2, WN = BN / 2;
     constexpr int TM = WM / 32, TN = WN / 32;
-    __shared__ __attribute__((aligned(16))) float smem[2 * BK * (SA + SB)];
+    __shared__ __attribute__((aligned(16))) float smem[2 * (ASZ + BSZ)];
     float* const As = smem;
-    float* const Bs = smem + 2 * BK * SA;
+    float* const Bs = smem + 2 * ASZ;
 
+    const vbg_conv_geo geo = p.geo;            // uniform descriptor fields live in SGPRs for the whole kernel
     const int tid = threadIdx.x;
     const int z = blockIdx.z;
     const int grp = z / p.splitk, split = z - grp * p.splitk;
@@ -69,8 +85,8 @@ __global__ __launch_bounds__(256) void gemm_kernel(const vbg_gemm_desc p) {
     if (kt0 >= kt1) return;
 
     // ---------------- per-thread loader state -----------------------------------------
-    // A, K-contiguous kinds: float4 #i covers row (f>>2), k offset (f&3)*4
-    // A/B, row-contiguous kinds: float4 #i covers rows (f % (BR/4))*4.., k index f / (BR/4)
+    // K-contiguous kinds : float4 #i (f = tid + 256 i) covers row f / KF, k offset (f % KF) * 4
+    // row-contiguous kinds: float4 #i covers rows (f % (BR/4)) * 4 .. +3, k index f / (BR/4)
     int a_n[NA], a_y[NA], a_x[NA];          // row -> (image, y, x) for conv / shifted segments
     bool a_rv[NA];
     if constexpr (A_KC) {
@@ -81,9 +97,9 @@ __global__ __launch_bounds__(256) void gemm_kernel(const vbg_gemm_desc p) {
             a_rv[i] = gm < M;
             a_n[i] = a_y[i] = a_x[i] = 0;
             if (AK == VBG_OP_CONV_K || p.a_H > 0) {
-                const int Hr = (AK == VBG_OP_CONV_K) ? p.geo.Hr : p.a_H;
-                const int Wr = (AK == VBG_OP_CONV_K) ? p.geo.Wr : p.a_W;
-                const int g = a_rv[i] ? gm : 0;
+                const int Hr = (AK == VBG_OP_CONV_K) ? geo.Hr : p.a_H;
+                const int Wr = (AK == VBG_OP_CONV_K) ? geo.Wr : p.a_W;
+                const int g = a_rv[i] ? gm : M - 1;
                 a_x[i] = g % Wr;
                 const int t = g / Wr;
                 a_y[i] = t % Hr;
@@ -91,223 +107,129 @@ __global__ __launch_bounds__(256) void gemm_kernel(const vbg_gemm_desc p) {
             }
         }
     }
-    // B CONV_R: columns (tap, ci) fixed per thread
-    int b_dy[NB], b_dx[NB], b_ci[NB];
+    int b_dy[NB], b_dx[NB], b_ci[NB];       // B CONV_R: columns (tap, ci) are fixed per thread
     if constexpr (BKD == VBG_OP_CONV_R) {
 #pragma unroll
         for (int i = 0; i < NB; ++i) {
             const int f = tid + i * 256;
-            const int c = n0 + (f % (BN / 4)) * 4;
-            const int tap = c / p.geo.Cs;
-            b_ci[i] = c - tap * p.geo.Cs;
-            b_dy[i] = tap / p.geo.kw;
-            b_dx[i] = tap - b_dy[i] * p.geo.kw;
+            const int c = min(n0 + (f % (BN / 4)) * 4, N - 4);
+            const int tap = c / geo.Cs;
+            b_ci[i] = c - tap * geo.Cs;
+            b_dy[i] = tap / geo.kw;
+            b_dx[i] = tap - b_dy[i] * geo.kw;
         }
     }
 
     float4 ra[NA], rb[NB];
-    int ra_n[NA], rb_n[NB];        // VEC path: #valid elements of each float4; the zero-masking (and the A prologue) is
-                                   // applied when the registers are written to LDS, AFTER the MFMAs of the current tile,
-                                   // so nothing consumes the loads early and they stay in flight behind the compute
+    int ra_n[NA], rb_n[NB];        // #valid elements of each float4 (zero-masking is deferred to store_tiles)
 
-    auto ld4 = [](const float* ptr, bool vec, int nvalid) -> float4 {
-        // nvalid: how many of the 4 consecutive elements are in range (<=0: none)
-        float4 v = make_float4(0.f, 0.f, 0.f, 0.f);
-        if (nvalid >= 4 && vec) {
-            v = *reinterpret_cast<const float4*>(ptr);
-        } else if (nvalid > 0) {
-            v.x = ptr[0];
-            if (nvalid > 1) v.y = ptr[1];
-            if (nvalid > 2) v.z = ptr[2];
-            if (nvalid > 3) v.w = ptr[3];
+    // DENSE_K A: state of the CURRENT K segment stays in registers; the kernarg arrays are only read again when
+    // the k-loop crosses into the next segment (a dependent chain of scalar loads per k-tile was the top stall).
+    int seg = 0, seg_kbeg = 0, seg_kspan = 0, seg_klast = 0;
+    const float* seg_base = nullptr;
+    long long a_roff[NA];
+    auto enter_segment = [&](int sg) {
+        seg = sg;
+        seg_base = p.a_seg_ptr[sg] + (A - p.A);                         // + group offset
+        const long long ld = p.a_seg_ld[sg];
+        seg_kbeg = (sg == 0) ? 0 : p.a_seg_kend[sg - 1];
+        seg_kspan = ((p.a_nseg == 1) ? K : p.a_seg_kend[sg]) - seg_kbeg;
+        seg_klast = ((seg_kspan + 3) & ~3) - 4;
+        const int sh = p.a_seg_shift[sg];
+#pragma unroll
+        for (int i = 0; i < NA; ++i) {
+            const int f = tid + i * 256;
+            long long row = min(m0 + f / KF, M - 1);
+            if (sh > 0) row = ((long long)a_n[i] * (p.a_H >> sh) + (a_y[i] >> sh)) * (p.a_W >> sh) + (a_x[i] >> sh);
+            a_roff[i] = row * ld;
         }
-        return v;
     };
+    if constexpr (AK == VBG_OP_DENSE_K) {
+        enter_segment(0);
+        while (seg + 1 < p.a_nseg && kt0 * BK >= seg_kbeg + seg_kspan) enter_segment(seg + 1);
+    }
+    long long b_roff[NB];
+    if constexpr (BKD == VBG_OP_DENSE_K) {
+#pragma unroll
+        for (int i = 0; i < NB; ++i) b_roff[i] = (long long)min(n0 + (tid + i * 256) / KF, N - 1) * p.ldb;
+    }
+    const long long lda = p.lda, ldb = p.ldb;
 
     auto load_tiles = [&](int kt) {
         const int k0 = kt * BK;
-        if constexpr (VEC) {
-            // ------------------------------ A (vector, branch-free) ------------------------------
-            if constexpr (AK == VBG_OP_DENSE_K) {
-                int seg = 0;
-                while (seg + 1 < p.a_nseg && k0 >= p.a_seg_kend[seg]) ++seg;
-                const float* base = p.a_seg_ptr[seg] + (A - p.A);
-                const long long ld = p.a_seg_ld[seg];
-                const int kbeg = (seg == 0) ? 0 : p.a_seg_kend[seg - 1];
-                const int kspan = ((p.a_nseg == 1) ? K : p.a_seg_kend[seg]) - kbeg;
-                const int klast = ((kspan + 3) & ~3) - 4;
-                const int sh = p.a_seg_shift[seg];
-#pragma unroll
-                for (int i = 0; i < NA; ++i) {
-                    const int f = tid + i * 256;
-                    const int kk = k0 - kbeg + (f % KF) * 4;
-                    long long row = min(m0 + f / KF, M - 1);
-                    if (sh > 0) row = ((long long)a_n[i] * (p.a_H >> sh) + (a_y[i] >> sh)) * (p.a_W >> sh) + (a_x[i] >> sh);
-                    ra[i] = ldv4(base + row * ld + min(kk, klast)); ra_n[i] = kspan - kk;
-                }
-            } else if constexpr (AK == VBG_OP_CONV_K) {
-                const int Cs = p.geo.Cs;
-                const int tap = k0 / Cs;
-                const int c0 = k0 - tap * Cs;
-                const int dy = tap / p.geo.kw, dx = tap - dy * p.geo.kw;
-#pragma unroll
-                for (int i = 0; i < NA; ++i) {
-                    const int f = tid + i * 256;
-                    int sy, sx;
-                    bool ok = a_rv[i];
-                    if (!p.geo.dgrad) {
-                        sy = a_y[i] * p.geo.stride - p.geo.pad + dy;
-                        sx = a_x[i] * p.geo.stride - p.geo.pad + dx;
-                    } else {
-                        const int ty = a_y[i] + p.geo.pad - dy, tx = a_x[i] + p.geo.pad - dx;
-                        sy = ty / p.geo.stride; sx = tx / p.geo.stride;
-                        ok = ok && ty >= 0 && tx >= 0 && (sy * p.geo.stride == ty) && (sx * p.geo.stride == tx);
-                    }
-                    ok = ok && sy >= 0 && sy < p.geo.Hs && sx >= 0 && sx < p.geo.Ws;
-                    const long long off = (((long long)a_n[i] * p.geo.Hs + sy) * p.geo.Ws + sx) * Cs + c0 + (f % KF) * 4;
-                    ra[i] = ldv4(A + (ok ? off : 0)); ra_n[i] = ok ? 4 : 0;
-                }
-            } else {
-                const int rlast = ((M + 3) & ~3) - 4;
-#pragma unroll
-                for (int i = 0; i < NA; ++i) {
-                    const int f = tid + i * 256;
-                    const int r = m0 + (f % (BM / 4)) * 4;
-                    const int k = k0 + f / (BM / 4);
-                    ra[i] = ldv4(A + (long long)min(k, K - 1) * p.lda + min(r, rlast)); ra_n[i] = (k < K) ? (M - r) : 0;
-                }
-            }
-            // ------------------------------ B (vector, branch-free) ------------------------------
-            if constexpr (BKD == VBG_OP_DENSE_K) {
-                const int klast = ((K + 3) & ~3) - 4;
-#pragma unroll
-                for (int i = 0; i < NB; ++i) {
-                    const int f = tid + i * 256;
-                    const int kk = k0 + (f % KF) * 4;
-                    const int col = min(n0 + f / KF, N - 1);
-                    rb[i] = ldv4(B + (long long)col * p.ldb + min(kk, klast)); rb_n[i] = K - kk;
-                }
-            } else if constexpr (BKD == VBG_OP_DENSE_R) {
-                const int clast = ((N + 3) & ~3) - 4;
-#pragma unroll
-                for (int i = 0; i < NB; ++i) {
-                    const int f = tid + i * 256;
-                    const int c = n0 + (f % (BN / 4)) * 4;
-                    const int k = k0 + f / (BN / 4);
-                    rb[i] = ldv4(B + (long long)min(k, K - 1) * p.ldb + min(c, clast)); rb_n[i] = (k < K) ? (N - c) : 0;
-                }
-            } else if constexpr (BKD == VBG_OP_WT_R) {
-                const int Cout = p.geo.Cs;
-                const int taps = p.geo.kh * p.geo.kw;
-                const int tap = k0 / Cout;
-                const int co0 = k0 - tap * Cout;
-#pragma unroll
-                for (int i = 0; i < NB; ++i) {
-                    const int f = tid + i * 256;
-                    const int c = n0 + (f % (BN / 4)) * 4;
-                    const int co = co0 + f / (BN / 4);
-                    rb[i] = ldv4(B + ((long long)co * taps + tap) * N + min(c, N - 4)); rb_n[i] = N - c;
-                }
-            } else {
-#pragma unroll
-                for (int i = 0; i < NB; ++i) {
-                    const int f = tid + i * 256;
-                    const int c = n0 + (f % (BN / 4)) * 4;
-                    const int pix = k0 + f / (BN / 4);
-                    const int pc = min(pix, K - 1);
-                    const int px = pc % p.geo.Wr;
-                    const int t = pc / p.geo.Wr;
-                    const int py = t % p.geo.Hr;
-                    const int pn = t / p.geo.Hr;
-                    const int sy = py * p.geo.stride - p.geo.pad + b_dy[i];
-                    const int sx = px * p.geo.stride - p.geo.pad + b_dx[i];
-                    const bool ok = (pix < K) && (c < N) && sy >= 0 && sy < p.geo.Hs && sx >= 0 && sx < p.geo.Ws;
-                    const long long off = (((long long)pn * p.geo.Hs + sy) * p.geo.Ws + sx) * p.geo.Cs + b_ci[i];
-                    rb[i] = ldv4(B + (ok ? off : 0)); rb_n[i] = ok ? 4 : 0;
-                }
-            }
-            return;
-        }
         // ------------------------------ A ------------------------------
         if constexpr (AK == VBG_OP_DENSE_K) {
             // host normalises a_nseg >= 1 (segment 0 = {A, K, lda, 0} for the plain case)
-            int seg = 0;
-            while (seg + 1 < p.a_nseg && k0 >= p.a_seg_kend[seg]) ++seg;
-            const float* base = p.a_seg_ptr[seg] + (A - p.A);          // + group offset
-            const long long ld = p.a_seg_ld[seg];
-            const int kbeg = (seg == 0) ? 0 : p.a_seg_kend[seg - 1];
-            const int kend = (p.a_nseg == 1) ? K : p.a_seg_kend[seg];
-            const int sh = p.a_seg_shift[seg];
+            if (seg + 1 < p.a_nseg && k0 >= seg_kbeg + seg_kspan) enter_segment(seg + 1);     // rare, uniform
 #pragma unroll
             for (int i = 0; i < NA; ++i) {
                 const int f = tid + i * 256;
-                const int k = k0 + (f % KF) * 4;
-                long long row = m0 + f / KF;
-                if (sh > 0) row = ((long long)a_n[i] * (p.a_H >> sh) + (a_y[i] >> sh)) * (p.a_W >> sh) + (a_x[i] >> sh);
-                ra[i] = ld4(base + row * ld + (k - kbeg), p.a_vec, a_rv[i] ? (kend - k) : 0);
+                const int kk = k0 - seg_kbeg + (f % KF) * 4;
+                ra_n[i] = a_rv[i] ? (seg_kspan - kk) : 0;
+                if constexpr (VEC) ra[i] = ldv4(seg_base + a_roff[i] + min(kk, seg_klast));
+                else ra[i] = lds4(seg_base + a_roff[i] + kk, ra_n[i]);
             }
         } else if constexpr (AK == VBG_OP_CONV_K) {
-            const int Cs = p.geo.Cs;
+            const int Cs = geo.Cs;
             const int tap = k0 / Cs;
             const int c0 = k0 - tap * Cs;
-            const int dy = tap / p.geo.kw, dx = tap - dy * p.geo.kw;
+            const int dy = tap / geo.kw, dx = tap - dy * geo.kw;
 #pragma unroll
             for (int i = 0; i < NA; ++i) {
                 const int f = tid + i * 256;
                 int sy, sx;
                 bool ok = a_rv[i];
-                if (!p.geo.dgrad) {
-                    sy = a_y[i] * p.geo.stride - p.geo.pad + dy;
-                    sx = a_x[i] * p.geo.stride - p.geo.pad + dx;
+                if (!geo.dgrad) {
+                    sy = a_y[i] * geo.stride - geo.pad + dy;
+                    sx = a_x[i] * geo.stride - geo.pad + dx;
                 } else {
-                    const int ty = a_y[i] + p.geo.pad - dy, tx = a_x[i] + p.geo.pad - dx;
-                    ok = ok && ty >= 0 && tx >= 0;
-                    if (p.geo.stride == 1) { sy = ty; sx = tx; }
-                    else {
-                        sy = ty / p.geo.stride; sx = tx / p.geo.stride;
-                        ok = ok && (sy * p.geo.stride == ty) && (sx * p.geo.stride == tx);
-                    }
+                    const int ty = a_y[i] + geo.pad - dy, tx = a_x[i] + geo.pad - dx;
+                    sy = ty / geo.stride; sx = tx / geo.stride;
+                    ok = ok && ty >= 0 && tx >= 0 && (sy * geo.stride == ty) && (sx * geo.stride == tx);
                 }
-                ok = ok && sy >= 0 && sy < p.geo.Hs && sx >= 0 && sx < p.geo.Ws;
-                const long long off = (((long long)a_n[i] * p.geo.Hs + sy) * p.geo.Ws + sx) * Cs + c0 + (f % KF) * 4;
-                ra[i] = ld4(A + (ok ? off : 0), true, ok ? 4 : 0);
+                ok = ok && sy >= 0 && sy < geo.Hs && sx >= 0 && sx < geo.Ws;
+                const long long off = (((long long)a_n[i] * geo.Hs + sy) * geo.Ws + sx) * Cs + c0 + (f % KF) * 4;
+                ra_n[i] = ok ? 4 : 0;
+                ra[i] = ldv4(A + (ok ? off : 0));                      // conv operands are always 16-byte aligned
             }
         } else {  // VBG_OP_DENSE_R : elem(row, k) = A[k*lda + row]
+            const int rlast = ((M + 3) & ~3) - 4;
 #pragma unroll
             for (int i = 0; i < NA; ++i) {
                 const int f = tid + i * 256;
                 const int r = m0 + (f % (BM / 4)) * 4;
                 const int k = k0 + f / (BM / 4);
-                ra[i] = ld4(A + (long long)k * p.lda + r, p.a_vec, (k < K) ? (M - r) : 0);
-            }
-        }
-        if (p.a_prologue == 1) {
-#pragma unroll
-            for (int i = 0; i < NA; ++i) {
-                ra[i].x = fmaxf(ra[i].x, 0.f) * p.a_scale; ra[i].y = fmaxf(ra[i].y, 0.f) * p.a_scale;
-                ra[i].z = fmaxf(ra[i].z, 0.f) * p.a_scale; ra[i].w = fmaxf(ra[i].w, 0.f) * p.a_scale;
+                ra_n[i] = (k < K) ? (M - r) : 0;
+                if constexpr (VEC) ra[i] = ldv4(A + (long long)min(k, K - 1) * lda + min(r, rlast));
+                else ra[i] = lds4(A + (long long)k * lda + r, ra_n[i]);
             }
         }
         // ------------------------------ B ------------------------------
         if constexpr (BKD == VBG_OP_DENSE_K) {      // elem(col, k) = B[col*ldb + k]
+            const int klast = ((K + 3) & ~3) - 4;
 #pragma unroll
             for (int i = 0; i < NB; ++i) {
                 const int f = tid + i * 256;
-                const int k = k0 + (f % KF) * 4;
+                const int kk = k0 + (f % KF) * 4;
                 const int col = n0 + f / KF;
-                rb[i] = ld4(B + (long long)col * p.ldb + k, p.b_vec, (col < N) ? (K - k) : 0);
+                rb_n[i] = (col < N) ? (K - kk) : 0;
+                if constexpr (VEC) rb[i] = ldv4(B + b_roff[i] + min(kk, klast));
+                else rb[i] = lds4(B + b_roff[i] + kk, rb_n[i]);
             }
         } else if constexpr (BKD == VBG_OP_DENSE_R) {   // elem(col, k) = B[k*ldb + col]
+            const int clast = ((N + 3) & ~3) - 4;
 #pragma unroll
             for (int i = 0; i < NB; ++i) {
                 const int f = tid + i * 256;
                 const int c = n0 + (f % (BN / 4)) * 4;
                 const int k = k0 + f / (BN / 4);
-                rb[i] = ld4(B + (long long)k * p.ldb + c, p.b_vec, (k < K) ? (N - c) : 0);
+                rb_n[i] = (k < K) ? (N - c) : 0;
+                if constexpr (VEC) rb[i] = ldv4(B + (long long)min(k, K - 1) * ldb + min(c, clast));
+                else rb[i] = lds4(B + (long long)k * ldb + c, rb_n[i]);
             }
         } else if constexpr (BKD == VBG_OP_WT_R) {     // dgrad weights: k = tap*Cout + co, col = ci
-            const int Cout = p.geo.Cs;                  // gather source of A is dY: Cs == Cout
-            const int taps = p.geo.kh * p.geo.kw;
+            const int Cout = geo.Cs;                  // gather source of A is dY: Cs == Cout
+            const int taps = geo.kh * geo.kw;
             const int tap = k0 / Cout;
             const int co0 = k0 - tap * Cout;
 #pragma unroll
@@ -315,7 +237,8 @@ __global__ __launch_bounds__(256) void gemm_kernel(const vbg_gemm_desc p) {
                 const int f = tid + i * 256;
                 const int c = n0 + (f % (BN / 4)) * 4;
                 const int co = co0 + f / (BN / 4);
-                rb[i] = ld4(B + ((long long)co * taps + tap) * N + c, p.b_vec, N - c);
+                rb_n[i] = N - c;
+                rb[i] = ldv4(B + ((long long)co * taps + tap) * N + min(c, N - 4));
             }
         } else {                                        // VBG_OP_CONV_R: k = pixel, col = (tap, ci)
 #pragma unroll
@@ -323,64 +246,43 @@ __global__ __launch_bounds__(256) void gemm_kernel(const vbg_gemm_desc p) {
                 const int f = tid + i * 256;
                 const int c = n0 + (f % (BN / 4)) * 4;
                 const int pix = k0 + f / (BN / 4);
-                bool ok = (pix < K) && (c < N);
-                const int px = pix % p.geo.Wr;
-                const int t = pix / p.geo.Wr;
-                const int py = t % p.geo.Hr;
-                const int pn = t / p.geo.Hr;
-                const int sy = py * p.geo.stride - p.geo.pad + b_dy[i];
-                const int sx = px * p.geo.stride - p.geo.pad + b_dx[i];
-                ok = ok && sy >= 0 && sy < p.geo.Hs && sx >= 0 && sx < p.geo.Ws;
-                const long long off = (((long long)pn * p.geo.Hs + sy) * p.geo.Ws + sx) * p.geo.Cs + b_ci[i];
-                rb[i] = ld4(B + (ok ? off : 0), true, ok ? 4 : 0);
+                const int pc = min(pix, K - 1);
+                const int px = pc % geo.Wr;
+                const int t = pc / geo.Wr;
+                const int py = t % geo.Hr;
+                const int pn = t / geo.Hr;
+                const int sy = py * geo.stride - geo.pad + b_dy[i];
+                const int sx = px * geo.stride - geo.pad + b_dx[i];
+                const bool ok = (pix < K) && (c < N) && sy >= 0 && sy < geo.Hs && sx >= 0 && sx < geo.Ws;
+                const long long off = (((long long)pn * geo.Hs + sy) * geo.Ws + sx) * geo.Cs + b_ci[i];
+                rb_n[i] = ok ? 4 : 0;
+                rb[i] = ldv4(B + (ok ? off : 0));
             }
         }
     };
 
+    const int a_prologue = p.a_prologue;
+    const float a_scale = p.a_scale;
     auto store_tiles = [&](int buf) {
-        float* as = As + buf * BK * SA;
-        float* bs = Bs + buf * BK * SB;
-        if constexpr (VEC) {
+        float* as = As + buf * ASZ;
+        float* bs = Bs + buf * BSZ;
 #pragma unroll
-            for (int i = 0; i < NA; ++i) {
-                ra[i] = mask4(ra[i], ra_n[i]);
-                if (p.a_prologue == 1) {
-                    ra[i].x = fmaxf(ra[i].x, 0.f) * p.a_scale; ra[i].y = fmaxf(ra[i].y, 0.f) * p.a_scale;
-                    ra[i].z = fmaxf(ra[i].z, 0.f) * p.a_scale; ra[i].w = fmaxf(ra[i].w, 0.f) * p.a_scale;
-                }
+        for (int i = 0; i < NA; ++i) {
+            float4 v = mask4(ra[i], ra_n[i]);
+            if (a_prologue == 1) {
+                v.x = fmaxf(v.x, 0.f) * a_scale; v.y = fmaxf(v.y, 0.f) * a_scale;
+                v.z = fmaxf(v.z, 0.f) * a_scale; v.w = fmaxf(v.w, 0.f) * a_scale;
             }
-#pragma unroll
-            for (int i = 0; i < NB; ++i) rb[i] = mask4(rb[i], rb_n[i]);
+            const int f = tid + i * 256;
+            if constexpr (A_KC) *reinterpret_cast<float4*>(&as[(f / KF) * SKR + (f % KF) * 4]) = v;
+            else *reinterpret_cast<float4*>(&as[(f / (BM / 4)) * SA + (f % (BM / 4)) * 4]) = v;
         }
-        if constexpr (A_KC) {
 #pragma unroll
-            for (int i = 0; i < NA; ++i) {
-                const int f = tid + i * 256;
-                const int row = f / KF, k = (f % KF) * 4;
-                as[(k + 0) * SA + row] = ra[i].x; as[(k + 1) * SA + row] = ra[i].y;
-                as[(k + 2) * SA + row] = ra[i].z; as[(k + 3) * SA + row] = ra[i].w;
-            }
-        } else {
-#pragma unroll
-            for (int i = 0; i < NA; ++i) {
-                const int f = tid + i * 256;
-                *reinterpret_cast<float4*>(&as[(f / (BM / 4)) * SA + (f % (BM / 4)) * 4]) = ra[i];
-            }
-        }
-        if constexpr (B_KC) {
-#pragma unroll
-            for (int i = 0; i < NB; ++i) {
-                const int f = tid + i * 256;
-                const int row = f / KF, k = (f % KF) * 4;
-                bs[(k + 0) * SB + row] = rb[i].x; bs[(k + 1) * SB + row] = rb[i].y;
-                bs[(k + 2) * SB + row] = rb[i].z; bs[(k + 3) * SB + row] = rb[i].w;
-            }
-        } else {
-#pragma unroll
-            for (int i = 0; i < NB; ++i) {
-                const int f = tid + i * 256;
-                *reinterpret_cast<float4*>(&bs[(f / (BN / 4)) * SB + (f % (BN / 4)) * 4]) = rb[i];
-            }
+        for (int i = 0; i < NB; ++i) {
+            const float4 v = mask4(rb[i], rb_n[i]);
+            const int f = tid + i * 256;
+            if constexpr (B_KC) *reinterpret_cast<float4*>(&bs[(f / KF) * SKR + (f % KF) * 4]) = v;
+            else *reinterpret_cast<float4*>(&bs[(f / (BN / 4)) * SB + (f % (BN / 4)) * 4]) = v;
         }
     };
 
@@ -396,42 +298,57 @@ __global__ __launch_bounds__(256) void gemm_kernel(const vbg_gemm_desc p) {
 #pragma unroll
             for (int r = 0; r < 16; ++r) acc[i][j][r] = 0.f;
 
+    // MFMA step j of k-group g uses k = 8g + 4*lk + j (same permutation for A and B)
+    const int a_off = A_KC ? (wm * WM + lr) * SKR + 4 * lk : 4 * lk * SA + wm * WM + lr;
+    const int b_off = B_KC ? (wn * WN + lr) * SKR + 4 * lk : 4 * lk * SB + wn * WN + lr;
+    auto read_frag = [&](const float* as, const float* bs, int g, float (&fa)[TM][4], float (&fb)[TN][4]) {
+#pragma unroll
+        for (int i = 0; i < TM; ++i) {
+            if constexpr (A_KC) {
+                const float4 v = *reinterpret_cast<const float4*>(as + i * 32 * SKR + 8 * g);
+                fa[i][0] = v.x; fa[i][1] = v.y; fa[i][2] = v.z; fa[i][3] = v.w;
+            } else {
+#pragma unroll
+                for (int j = 0; j < 4; ++j) fa[i][j] = as[(8 * g + j) * SA + i * 32];
+            }
+        }
+#pragma unroll
+        for (int i = 0; i < TN; ++i) {
+            if constexpr (B_KC) {
+                const float4 v = *reinterpret_cast<const float4*>(bs + i * 32 * SKR + 8 * g);
+                fb[i][0] = v.x; fb[i][1] = v.y; fb[i][2] = v.z; fb[i][3] = v.w;
+            } else {
+#pragma unroll
+                for (int j = 0; j < 4; ++j) fb[i][j] = bs[(8 * g + j) * SB + i * 32];
+            }
+        }
+    };
+    auto mma_group = [&](const float (&fa)[TM][4], const float (&fb)[TN][4]) {
+#pragma unroll
+        for (int j = 0; j < 4; ++j)
+#pragma unroll
+            for (int i = 0; i < TM; ++i)
+#pragma unroll
+                for (int n = 0; n < TN; ++n)
+                    acc[i][n] = __builtin_amdgcn_mfma_f32_32x32x2f32(fa[i][j], fb[n][j], acc[i][n], 0, 0, 0);
+    };
+
     load_tiles(kt0);
     store_tiles(0);
     __syncthreads();
     for (int kt = kt0; kt < kt1; ++kt) {
         const int buf = (kt - kt0) & 1;
         if (kt + 1 < kt1) load_tiles(kt + 1);
-        const float* as = As + buf * BK * SA + wm * WM + lr + lk * SA;
-        const float* bs = Bs + buf * BK * SB + wn * WN + lr + lk * SB;
-        // fragments of k-step ks+1 are fetched while the MFMAs of k-step ks run (two register sets)
-        float a0[TM], b0[TN], a1[TM], b1[TN];
+        const float* as = As + buf * ASZ + a_off;
+        const float* bs = Bs + buf * BSZ + b_off;
+        float fa0[TM][4], fb0[TN][4], fa1[TM][4], fb1[TN][4];
+        read_frag(as, bs, 0, fa0, fb0);
 #pragma unroll
-        for (int i = 0; i < TM; ++i) a0[i] = as[i * 32];
-#pragma unroll
-        for (int j = 0; j < TN; ++j) b0[j] = bs[j * 32];
-#pragma unroll
-        for (int ks = 0; ks < BK / 2; ks += 2) {
-#pragma unroll
-            for (int i = 0; i < TM; ++i) a1[i] = as[(ks + 1) * 2 * SA + i * 32];
-#pragma unroll
-            for (int j = 0; j < TN; ++j) b1[j] = bs[(ks + 1) * 2 * SB + j * 32];
-#pragma unroll
-            for (int i = 0; i < TM; ++i)
-#pragma unroll
-                for (int j = 0; j < TN; ++j)
-                    acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x2f32(a0[i], b0[j], acc[i][j], 0, 0, 0);
-            if (ks + 2 < BK / 2) {
-#pragma unroll
-                for (int i = 0; i < TM; ++i) a0[i] = as[(ks + 2) * 2 * SA + i * 32];
-#pragma unroll
-                for (int j = 0; j < TN; ++j) b0[j] = bs[(ks + 2) * 2 * SB + j * 32];
-            }
-#pragma unroll
-            for (int i = 0; i < TM; ++i)
-#pragma unroll
-                for (int j = 0; j < TN; ++j)
-                    acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x2f32(a1[i], b1[j], acc[i][j], 0, 0, 0);
+        for (int g = 0; g < NG; g += 2) {
+            read_frag(as, bs, g + 1, fa1, fb1);
+            mma_group(fa0, fb0);
+            if (g + 2 < NG) read_frag(as, bs, g + 2, fa0, fb0);
+            mma_group(fa1, fb1);
         }
         if (kt + 1 < kt1) store_tiles(buf ^ 1);
         __syncthreads();
@@ -522,6 +439,7 @@ extern "C" int vbg_gemm(const vbg_gemm_desc* desc, void* stream) {
     if (d.epi == VBG_EPI_GELU_DUAL) VBG_CHECK_ARG(d.C2 != nullptr);
     if (d.accumulate) VBG_CHECK_ARG(d.epi == VBG_EPI_NONE);
     VBG_CHECK_ARG(d.a_nseg >= 0 && d.a_nseg <= 4);
+    VBG_CHECK_ARG(d.bk == 0 || d.bk == 16 || d.bk == 32);
     if (d.a_nseg == 0) {
         d.a_nseg = 1; d.a_seg_ptr[0] = d.A; d.a_seg_kend[0] = d.K; d.a_seg_ld[0] = d.lda; d.a_seg_shift[0] = 0;
     }
@@ -529,7 +447,7 @@ extern "C" int vbg_gemm(const vbg_gemm_desc* desc, void* stream) {
         VBG_CHECK_ARG(d.a_kind == VBG_OP_DENSE_K && d.grp == nullptr && d.a_seg_kend[d.a_nseg - 1] == d.K);
         for (int i = 0; i < d.a_nseg; ++i) {
             VBG_CHECK_ARG(d.a_seg_kend[i] % 16 == 0 && d.a_seg_ptr[i] != nullptr);
-            if (d.a_seg_kend[i] % 32 != 0) d.bk = 16;
+            if (d.a_seg_kend[i] % 32 != 0) d.bk = 16;          // a k-tile must stay inside one segment
             if (d.a_seg_shift[i] > 0) VBG_CHECK_ARG(d.a_H > 0 && d.a_W > 0);
         }
     }
@@ -542,20 +460,18 @@ extern "C" int vbg_gemm(const vbg_gemm_desc* desc, void* stream) {
     const bool conv = d.a_kind == VBG_OP_CONV_K || d.b_kind == VBG_OP_CONV_R || d.b_kind == VBG_OP_WT_R;
     if (conv) {
         VBG_CHECK_ARG(d.geo.Cs % 16 == 0 && d.geo.kh > 0 && d.geo.kw > 0 && d.geo.stride > 0);
-        if (d.geo.Cs % 32 != 0) d.bk = 16;      // a k-tile must stay inside one filter tap
         VBG_CHECK_ARG(d.grp == nullptr);
+        if (d.geo.Cs % 32 != 0) d.bk = 16;                      // a k-tile must stay inside one filter tap
     }
-    if (d.a_kind == VBG_OP_CONV_K) d.a_vec = ((uintptr_t)d.A % 16 == 0) && (d.geo.Cs % 4 == 0);
-    if (d.b_kind == VBG_OP_CONV_R) d.b_vec = ((uintptr_t)d.B % 16 == 0) && (d.geo.Cs % 4 == 0);
-    if (d.b_kind == VBG_OP_WT_R) d.b_vec = ((uintptr_t)d.B % 16 == 0) && (d.N % 4 == 0);
+    // the gathered side of a conv operand is float4-legal by construction; the DENSE side keeps the caller's flag
+    if (d.a_kind == VBG_OP_CONV_K) { VBG_CHECK_ARG((uintptr_t)d.A % 16 == 0); d.a_vec = 1; }
+    if (d.b_kind == VBG_OP_CONV_R) { VBG_CHECK_ARG((uintptr_t)d.B % 16 == 0 && d.N % 4 == 0); d.b_vec = 1; }
+    if (d.b_kind == VBG_OP_WT_R) { VBG_CHECK_ARG((uintptr_t)d.B % 16 == 0 && d.N % 4 == 0 && d.geo.dgrad == 1); d.b_vec = 1; }
     if (d.a_kind == VBG_OP_DENSE_K && d.b_kind == VBG_OP_DENSE_K) return launch_pair<VBG_OP_DENSE_K, VBG_OP_DENSE_K>(d, groups, maxM, maxN, s);
     if (d.a_kind == VBG_OP_DENSE_K && d.b_kind == VBG_OP_DENSE_R) return launch_pair<VBG_OP_DENSE_K, VBG_OP_DENSE_R>(d, groups, maxM, maxN, s);
     if (d.a_kind == VBG_OP_DENSE_R && d.b_kind == VBG_OP_DENSE_R) return launch_pair<VBG_OP_DENSE_R, VBG_OP_DENSE_R>(d, groups, maxM, maxN, s);
     if (d.a_kind == VBG_OP_CONV_K && d.b_kind == VBG_OP_DENSE_K) return launch_pair<VBG_OP_CONV_K, VBG_OP_DENSE_K>(d, groups, maxM, maxN, s);
-    if (d.a_kind == VBG_OP_CONV_K && d.b_kind == VBG_OP_WT_R) {
-        VBG_CHECK_ARG(d.geo.dgrad == 1 && d.N % 4 == 0);
-        return launch_pair<VBG_OP_CONV_K, VBG_OP_WT_R>(d, groups, maxM, maxN, s);
-    }
+    if (d.a_kind == VBG_OP_CONV_K && d.b_kind == VBG_OP_WT_R) return launch_pair<VBG_OP_CONV_K, VBG_OP_WT_R>(d, groups, maxM, maxN, s);
     if (d.a_kind == VBG_OP_DENSE_R && d.b_kind == VBG_OP_CONV_R) {
         VBG_CHECK_ARG(d.N == d.geo.kh * d.geo.kw * d.geo.Cs);
         return launch_pair<VBG_OP_DENSE_R, VBG_OP_CONV_R>(d, groups, maxM, maxN, s);
