@@ -165,7 +165,9 @@ def test_gemm_segments(ops):
 
 
 @pytest.mark.parametrize("Cin,Cout,k,stride,pad,H,W", [(16, 32, 3, 1, 1, 9, 11), (64, 128, 3, 2, 1, 16, 20), (64, 128, 1, 2, 0, 16, 20),
-                                                        (128, 48, 1, 1, 0, 7, 5), (256, 256, 3, 1, 1, 7, 7), (32, 16, 7, 2, 3, 20, 18)])
+                                                        (128, 48, 1, 1, 0, 7, 5), (256, 256, 3, 1, 1, 7, 7), (32, 16, 7, 2, 3, 20, 18),
+                                                        (512, 512, 3, 1, 1, 3, 4), (256, 512, 3, 2, 1, 6, 8), (256, 512, 1, 2, 0, 6, 8),
+                                                        (256, 256, 3, 1, 1, 6, 8), (128, 256, 3, 2, 1, 12, 16), (512, 256, 1, 1, 0, 3, 4)])
 def test_conv(ops, Cin, Cout, k, stride, pad, H, W):
     B = 3
     x = rnd(B, Cin, H, W, seed=30).requires_grad_(True)
@@ -494,6 +496,50 @@ def test_transform(ops, golden):
     b1 = torch.zeros(1, 64, 64, 3, device=d)
     ops.normalize_resize(img.to(d), 64, 64, cfg.image_mean, cfg.image_std, b1, 0)
     assert close(b1.permute(0, 3, 1, 2), torch.from_numpy(g["ident_batch"]), 1e-6, 1e-6)
+
+
+
+# ------------------------------------------------------------------------------------------
+# conv + batch-stat BN (+res, +relu) block, forward and backward, against an fp64 CPU reference:
+# the rigorous check behind the looser end-to-end gradient tolerances (tests/test_gpu_model.py)
+# ------------------------------------------------------------------------------------------
+def _block_ref(B, Cin, Cout, H, W, stride, k, relu, res, dt):
+    g = torch.Generator().manual_seed(0)
+    x = torch.randn(B, Cin, H, W, generator=g)
+    w = torch.randn(Cout, Cin, k, k, generator=g) / (Cin * k * k) ** 0.5
+    gam = 1 + 0.1 * torch.randn(Cout, generator=g)
+    bet = 0.05 * torch.randn(Cout, generator=g)
+    Ho, Wo = (H + 2 * (k // 2) - k) // stride + 1, (W + 2 * (k // 2) - k) // stride + 1
+    r = torch.randn(B, Cout, Ho, Wo, generator=g) if res else None
+    gy = torch.randn(B, Cout, Ho, Wo, generator=g)
+    xr, wr, gr, br = (t.to(dt).requires_grad_(True) for t in (x, w, gam, bet))
+    y = F.batch_norm(F.conv2d(xr, wr, None, stride, k // 2), None, None, gr, br, True, 0.1, 1e-5)
+    if res:
+        y = y + r.to(dt)
+    if relu:
+        y = torch.relu(y)
+    y.backward(gy.to(dt))
+    return (y.detach(), xr.grad, wr.grad, gr.grad, br.grad), (x, w, gam, bet, r, gy)
+
+
+@pytest.mark.parametrize("cfgk", [(2, 256, 512, 6, 8, 2, 3, True, False), (2, 256, 512, 6, 8, 2, 1, False, False),
+                                  (2, 512, 512, 3, 4, 1, 3, True, True), (4, 64, 64, 32, 32, 1, 3, True, True)])
+def test_conv_bn_block_vs_fp64(cfgk):
+    from vbg import functions as Fn
+    B, Cin, Cout, H, W, stride, k, relu, res = cfgk
+    ref64, (x, w, gam, bet, r, gy) = _block_ref(*cfgk, torch.float64)
+    d = dev()
+    xh = x.permute(0, 2, 3, 1).contiguous().to(d).requires_grad_(True)
+    wd = w.to(d).contiguous(memory_format=torch.channels_last).requires_grad_(True)
+    gd, bd = gam.to(d).requires_grad_(True), bet.to(d).requires_grad_(True)
+    rm, rv = torch.zeros(Cout, device=d), torch.ones(Cout, device=d)
+    rh = None if r is None else r.permute(0, 2, 3, 1).contiguous().to(d)
+    y = Fn.ConvBnFn.apply(xh, wd, gd, bd, rm, rv, rh, stride, k // 2, relu, True, 0.1, 1e-5, False)
+    y.backward(gy.permute(0, 2, 3, 1).contiguous().to(d))
+    got = (y.detach().permute(0, 3, 1, 2).cpu(), xh.grad.permute(0, 3, 1, 2).cpu(), wd.grad.cpu(), gd.grad.cpu(), bd.grad.cpu())
+    for a, b in zip(got, ref64):
+        rel = float((a.double() - b).norm() / (b.norm() + 1e-30))
+        assert rel < 5e-6, rel          # fp32 rounding level
 
 
 # ------------------------------------------------------------------------------------------

@@ -68,6 +68,8 @@ def gemm_raw(M, N, K, A, lda, a_kind, B, ldb, b_kind, Cout, ldc, *, bias=None, e
     d.bias = None if bias is None else bias.data_ptr()
     d.epi, d.alpha, d.accumulate, d.splitk, d.tile = epi, float(alpha), int(bool(accumulate)), int(splitk), int(tile)
     d.bk = int(bk)
+    if _FORCE[0] or _FORCE[1]:          # debugging / conditioning experiments: force one tile configuration
+        d.tile, d.bk = _FORCE[0] or d.tile, _FORCE[1] or d.bk
     if grp is not None:
         d.grp, d.ngroups = grp.data_ptr(), int(ngroups)
         d.grp_maxM, d.grp_maxN = int(grp_max[0]), int(grp_max[1])
@@ -108,6 +110,9 @@ _GEMM_PROF = None
 def set_gemm_profiler(p):
     global _GEMM_PROF
     _GEMM_PROF = p
+
+
+_FORCE = [0, 0]
 
 
 def _pick_splitk(M, N, Kred, bk=16):
