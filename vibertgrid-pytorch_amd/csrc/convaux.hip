@@ -19,23 +19,60 @@ static inline int ew_grid(long long n, int block) {
 // ------------------------------------------------------------------------------------------
 // BatchNorm.  x is [M, C] (NHWC rows).  Block: 64 channels x 4 row lanes, BN_ROWS rows per block.
 // ------------------------------------------------------------------------------------------
-constexpr int BN_ROWS = 512;
+constexpr int BN_ROWS = 256;      // rows per block
 
-__global__ __launch_bounds__(256) void bn_stats_kernel(const float* __restrict__ x, long long M, int C, double* stats) {
-    __shared__ double sh[2][4][64];
-    const int cl = threadIdx.x & 63, rl = threadIdx.x >> 6;
-    const int c = blockIdx.x * 64 + cl;
+// Reduction layout shared by bn_stats / bn_bwd_reduce: a block covers up to 64 channel QUADS (float4) x RL row lanes
+// (256 threads); every load is a float4 so a wave touches >= 1 KB of contiguous NHWC rows; per-thread partials in fp32
+// over <= BN_ROWS/RL rows, cross-lane reduction through LDS in fp64, one fp64 atomic per channel per block.
+template <bool BWD>
+__global__ __launch_bounds__(256) void bn_reduce_kernel(const float* __restrict__ a, const float* __restrict__ y,
+                                                        const float* __restrict__ x, long long M, int C,
+                                                        const float* __restrict__ mean, const float* __restrict__ invstd,
+                                                        int relu, double* out) {
+    __shared__ double sh[2][256][4];
+    const int C4 = C >> 2;
+    const int QB = min(C4, 64);                     // quads handled per block
+    const int RL = 256 / QB;                        // row lanes
+    const int q = threadIdx.x % QB, rl = threadIdx.x / QB;
+    const int cq = blockIdx.x * 64 + q;             // channel quad
     const long long r0 = (long long)blockIdx.y * BN_ROWS;
     const long long r1 = min(M, r0 + BN_ROWS);
-    float s = 0.f, q = 0.f;
-    if (c < C)
-        for (long long r = r0 + rl; r < r1; r += 4) { const float v = x[r * C + c]; s += v; q += v * v; }
-    sh[0][rl][cl] = (double)s;
-    sh[1][rl][cl] = (double)q;
+    float4 s = make_float4(0.f, 0.f, 0.f, 0.f), t = make_float4(0.f, 0.f, 0.f, 0.f);
+    if (cq < C4) {
+        float4 mu = make_float4(0.f, 0.f, 0.f, 0.f), is = mu;
+        if (BWD) { mu = reinterpret_cast<const float4*>(mean)[cq]; is = reinterpret_cast<const float4*>(invstd)[cq]; }
+        for (long long r = r0 + rl; r < r1; r += RL) {
+            const long long o = r * C4 + cq;
+            float4 v = reinterpret_cast<const float4*>(a)[o];
+            if (!BWD) {
+                s.x += v.x; s.y += v.y; s.z += v.z; s.w += v.w;
+                t.x += v.x * v.x; t.y += v.y * v.y; t.z += v.z * v.z; t.w += v.w * v.w;
+            } else {
+                if (relu) {
+                    const float4 yv = reinterpret_cast<const float4*>(y)[o];
+                    v.x = yv.x > 0.f ? v.x : 0.f; v.y = yv.y > 0.f ? v.y : 0.f;
+                    v.z = yv.z > 0.f ? v.z : 0.f; v.w = yv.w > 0.f ? v.w : 0.f;
+                }
+                const float4 xv = reinterpret_cast<const float4*>(x)[o];
+                s.x += v.x; s.y += v.y; s.z += v.z; s.w += v.w;
+                t.x += v.x * ((xv.x - mu.x) * is.x); t.y += v.y * ((xv.y - mu.y) * is.y);
+                t.z += v.z * ((xv.z - mu.z) * is.z); t.w += v.w * ((xv.w - mu.w) * is.w);
+            }
+        }
+    }
+    sh[0][threadIdx.x][0] = s.x; sh[0][threadIdx.x][1] = s.y; sh[0][threadIdx.x][2] = s.z; sh[0][threadIdx.x][3] = s.w;
+    sh[1][threadIdx.x][0] = t.x; sh[1][threadIdx.x][1] = t.y; sh[1][threadIdx.x][2] = t.z; sh[1][threadIdx.x][3] = t.w;
     __syncthreads();
-    if (rl == 0 && c < C) {
-        unsafeAtomicAdd(stats + c, sh[0][0][cl] + sh[0][1][cl] + sh[0][2][cl] + sh[0][3][cl]);
-        unsafeAtomicAdd(stats + C + c, sh[1][0][cl] + sh[1][1][cl] + sh[1][2][cl] + sh[1][3][cl]);
+    if (rl == 0 && cq < C4) {
+        double a0[4] = {0, 0, 0, 0}, a1[4] = {0, 0, 0, 0};
+        for (int l = 0; l < RL; ++l)
+#pragma unroll
+            for (int j = 0; j < 4; ++j) { a0[j] += sh[0][l * QB + q][j]; a1[j] += sh[1][l * QB + q][j]; }
+#pragma unroll
+        for (int j = 0; j < 4; ++j) {
+            unsafeAtomicAdd(out + cq * 4 + j, a0[j]);
+            unsafeAtomicAdd(out + C + cq * 4 + j, a1[j]);
+        }
     }
 }
 
@@ -79,34 +116,6 @@ __global__ void bn_apply_kernel(const float* __restrict__ x, const float* __rest
         }
         if (relu) { o.x = fmaxf(o.x, 0.f); o.y = fmaxf(o.y, 0.f); o.z = fmaxf(o.z, 0.f); o.w = fmaxf(o.w, 0.f); }
         reinterpret_cast<float4*>(y)[i] = o;
-    }
-}
-
-__global__ __launch_bounds__(256) void bn_bwd_reduce_kernel(const float* __restrict__ dy, const float* __restrict__ y,
-                                                            const float* __restrict__ x, long long M, int C,
-                                                            const float* __restrict__ mean, const float* __restrict__ invstd,
-                                                            int relu, double* sums) {
-    __shared__ double sh[2][4][64];
-    const int cl = threadIdx.x & 63, rl = threadIdx.x >> 6;
-    const int c = blockIdx.x * 64 + cl;
-    const long long r0 = (long long)blockIdx.y * BN_ROWS;
-    const long long r1 = min(M, r0 + BN_ROWS);
-    float s = 0.f, q = 0.f;
-    if (c < C) {
-        const float mu = mean[c], is = invstd[c];
-        for (long long r = r0 + rl; r < r1; r += 4) {
-            float g = dy[r * C + c];
-            if (relu && !(y[r * C + c] > 0.f)) g = 0.f;
-            s += g;
-            q += g * ((x[r * C + c] - mu) * is);
-        }
-    }
-    sh[0][rl][cl] = (double)s;
-    sh[1][rl][cl] = (double)q;
-    __syncthreads();
-    if (rl == 0 && c < C) {
-        unsafeAtomicAdd(sums + c, sh[0][0][cl] + sh[0][1][cl] + sh[0][2][cl] + sh[0][3][cl]);
-        unsafeAtomicAdd(sums + C + c, sh[1][0][cl] + sh[1][1][cl] + sh[1][2][cl] + sh[1][3][cl]);
     }
 }
 
@@ -317,9 +326,11 @@ using namespace vbg;
 #define ALIGNED16(p) (((uintptr_t)(p)) % 16 == 0)
 
 extern "C" int vbg_bn_stats(const float* x, long long M, int C, double* stats_accum, void* stream) {
-    VBG_CHECK_ARG(x && stats_accum && M >= 0 && C > 0);
+    VBG_CHECK_ARG(x && stats_accum && M >= 0 && C > 0 && C % 4 == 0 && ALIGNED16(x));
+    VBG_CHECK_ARG(C / 4 <= 64 ? (256 % (C / 4) == 0) : (C / 4) % 64 == 0);
     if (M == 0) return VBG_OK;
-    VBG_LAUNCH(bn_stats_kernel, dim3(cdiv(C, 64), cdiv(M, BN_ROWS)), dim3(256), 0, S_, x, M, C, stats_accum);
+    VBG_LAUNCH((bn_reduce_kernel<false>), dim3(cdiv(C / 4, 64), cdiv(M, BN_ROWS)), dim3(256), 0, S_, x, nullptr, nullptr, M, C, nullptr,
+               nullptr, 0, stats_accum);
     VBG_LAUNCH_RET();
 }
 
@@ -344,10 +355,12 @@ extern "C" int vbg_bn_apply(const float* x, const float* res, long long M, int C
 
 extern "C" int vbg_bn_bwd_reduce(const float* dy, const float* y, const float* x, long long M, int C, const float* mean,
                                  const float* invstd, int relu, double* sums_accum, void* stream) {
-    VBG_CHECK_ARG(dy && x && mean && invstd && sums_accum && M >= 0 && C > 0 && (!relu || y));
+    VBG_CHECK_ARG(dy && x && mean && invstd && sums_accum && M >= 0 && C > 0 && (!relu || y) && C % 4 == 0);
+    VBG_CHECK_ARG(ALIGNED16(dy) && ALIGNED16(x) && ALIGNED16(mean) && ALIGNED16(invstd) && (!relu || ALIGNED16(y)));
+    VBG_CHECK_ARG(C / 4 <= 64 ? (256 % (C / 4) == 0) : (C / 4) % 64 == 0);
     if (M == 0) return VBG_OK;
-    VBG_LAUNCH(bn_bwd_reduce_kernel, dim3(cdiv(C, 64), cdiv(M, BN_ROWS)), dim3(256), 0, S_, dy, y, x, M, C, mean, invstd,
-                       relu, sums_accum);
+    VBG_LAUNCH((bn_reduce_kernel<true>), dim3(cdiv(C / 4, 64), cdiv(M, BN_ROWS)), dim3(256), 0, S_, dy, y, x, M, C, mean, invstd, relu,
+               sums_accum);
     VBG_LAUNCH_RET();
 }
 

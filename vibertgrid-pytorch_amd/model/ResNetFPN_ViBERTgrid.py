@@ -68,7 +68,7 @@ class EarlyFusionLayer(nn.Module):
     def forward(self, x, grid):
         x = self.block_1(x)
         w = self.early_fusion.weight
-        x = Fn.SegLinearFn.apply(w.reshape(w.shape[0], -1), self.early_fusion.bias, (0, 0), (0, 0), x, grid)
+        x = Fn.SegLinearFn.apply(w, self.early_fusion.bias, (0, 0), (0, 0), x, grid)
         return self.layers(x)
 
 
@@ -94,7 +94,7 @@ class _FPN(nn.Module):
         x_7 = conv(Fn.UpAddFn.apply(x_6, conv(x_1, self.skip_3)), self.merge_3)
         w = self.fuse.weight
         hw = (x_7.shape[1], x_7.shape[2])
-        return Fn.SegLinearFn.apply(w.reshape(w.shape[0], -1), None, (3, 2, 1, 0), hw, x_4, x_5, x_6, x_7)
+        return Fn.SegLinearFn.apply(w, None, (3, 2, 1, 0), hw, x_4, x_5, x_6, x_7)
 
 
 class ResNetFPN_ViBERTgrid(_FPN):
@@ -194,7 +194,7 @@ class ResNetFPN_ViBERTgrid_Pretrained(_FPN):
         x_1 = r.layer1(Fn.MaxPoolFn.apply(conv_bn(input, r.conv1, r.bn1, None, True)))
         x_2 = r.layer2[0](x_1)
         w = self.early_fusion.weight
-        x_2 = Fn.SegLinearFn.apply(w.reshape(w.shape[0], -1), None, (0, 0), (0, 0), x_2, BERTgrid)
+        x_2 = Fn.SegLinearFn.apply(w, None, (0, 0), (0, 0), x_2, BERTgrid)
         for i in range(1, self.num_block_ly2):
             x_2 = r.layer2[i](x_2)
         x_3 = r.layer3(x_2)

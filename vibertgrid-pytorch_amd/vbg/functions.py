@@ -26,6 +26,27 @@ def _c(t):
     return t if t.is_contiguous() else t.contiguous()
 
 
+# ----------------------------------------------------------------------------------------------
+# Gradient sink: when a parameter's `.grad` is a persistent view into a flat gradient buffer (vbg/optim.FlatGroup, zeroed
+# once per step), the weight-gradient GEMMs accumulate STRAIGHT into it (C += dY^T X) and autograd gets None for that
+# input: no temporary dW, no extra read-modify-write pass, no allocator churn.  `GRAD_READY` (set by FlatReducer) is told
+# when a sunk gradient is complete so the bucket all-reduce can start, exactly like a post-accumulate hook would.
+# ----------------------------------------------------------------------------------------------
+GRAD_SINK = set()          # id(param)
+GRAD_READY = [None]        # callable(param) or None
+
+
+def wgrad_dest(w):
+    if id(w) in GRAD_SINK and w.grad is not None:
+        return w.grad
+    return None
+
+
+def wgrad_done(w):
+    if GRAD_READY[0] is not None:
+        GRAD_READY[0](w)
+
+
 class SyncCtx:
     """Process group for SyncBatchNorm statistics (train_SROIE.py:202-203 `convert_sync_batchnorm`)."""
     group = None
@@ -36,6 +57,18 @@ class SyncCtx:
 
 
 # ----------------------------------------------------------------------------------------------
+def _linear_wgrad(w_param, dy, x):
+    """dW = dy^T x : into the flat gradient buffer when the parameter is sunk (returns None), else a fresh tensor"""
+    dst = wgrad_dest(w_param)
+    if dst is not None:
+        ops.linear_wgrad(dy, x, dst, accumulate=True)
+        wgrad_done(w_param)
+        return None
+    dw = torch.empty_like(w_param)
+    ops.linear_wgrad(dy, x, dw, accumulate=False)
+    return dw
+
+
 class LinearFn(torch.autograd.Function):
     """y = x @ w^T + b (optional fused ReLU)."""
 
@@ -45,6 +78,7 @@ class LinearFn(torch.autograd.Function):
         y = ops.linear_fwd(x, w, b, EPI_RELU if relu else EPI_NONE)
         ctx.relu = relu
         ctx.has_bias = b is not None
+        ctx.w_ref = w
         ctx.save_for_backward(x, w, y if relu else None)
         return y
 
@@ -55,8 +89,7 @@ class LinearFn(torch.autograd.Function):
         if ctx.relu:
             dy = ops.relu_bwd_(y, dy.clone())
         dx = ops.linear_dgrad(dy, w) if ctx.needs_input_grad[0] else None
-        dw = torch.empty_like(w)
-        ops.linear_wgrad(dy, x, dw, accumulate=False)
+        dw = _linear_wgrad(ctx.w_ref, dy, x)
         db = ops.colsum(dy) if ctx.has_bias else None
         return dx, dw, db, None
 
@@ -67,7 +100,10 @@ class SegLinearFn(torch.autograd.Function):
     and late fusion (field_type_classification_head.py:185-188)."""
 
     @staticmethod
-    def forward(ctx, w2d, b, shifts, hw, *xs):
+    def forward(ctx, w, b, shifts, hw, *xs):
+        """w: [N, K] linear weight or [N, K, 1, 1] (channels_last) 1x1 conv weight"""
+        ctx.w_ref = w
+        w2d = w.reshape(w.shape[0], -1)
         xs = [_c(x) for x in xs]
         chans = [x.shape[-1] for x in xs]
         K = sum(chans)
@@ -93,7 +129,10 @@ class SegLinearFn(torch.autograd.Function):
         N, K = w2d.shape
         dy = _c(dy)
         dy2 = dy.view(-1, N)
-        dw = torch.empty_like(w2d)
+        dst = wgrad_dest(ctx.w_ref)
+        sunk = dst is not None
+        dw = dst.reshape(N, K) if sunk else torch.empty_like(w2d)
+        assert dw.is_contiguous() and (not sunk or dw.data_ptr() == dst.data_ptr())
         pooled = {0: dy}
         dxs = []
         koff = 0
@@ -109,12 +148,18 @@ class SegLinearFn(torch.autograd.Function):
                 ops.gemm_raw(Ms, c, N, g2, N, OP_DENSE_K, w2d, K, OP_DENSE_R, dx, c, b_ptr_off=koff)
             dxs.append(dx)
             sk = ops._pick_splitk(N, c, Ms)
-            if sk > 1:
+            if sk > 1 and not sunk:
                 dw[:, koff:koff + c].zero_()
-            ops.gemm_raw(N, c, Ms, g2, N, OP_DENSE_R, x.view(-1, c), c, OP_DENSE_R, dw, K, c_ptr_off=koff, accumulate=sk > 1, splitk=sk)
+            ops.gemm_raw(N, c, Ms, g2, N, OP_DENSE_R, x.view(-1, c), c, OP_DENSE_R, dw, K, c_ptr_off=koff, accumulate=sunk or sk > 1,
+                         splitk=sk)
             koff += c
         db = ops.colsum(dy2) if ctx.has_bias else None
-        return (dw, db, None, None, *dxs)
+        if sunk:
+            wgrad_done(ctx.w_ref)
+            dw_ret = None
+        else:
+            dw_ret = dw.view(ctx.w_ref.shape)
+        return (dw_ret, db, None, None, *dxs)
 
 
 # ----------------------------------------------------------------------------------------------
@@ -133,7 +178,21 @@ def _conv_any(x, w4, stride, pad, bias=None):
     return ops.conv2d_fwd(x, w4, stride, pad, bias), None
 
 
-def _conv_wgrad_any(dy, x, col, w4_shape, stride, pad):
+def _conv_wgrad_any(dy, x, col, w4_shape, stride, pad, w_param=None):
+    """-> OIHW-shaped gradient for autograd, or None when accumulated straight into the sunk flat gradient"""
+    dst = wgrad_dest(w_param) if w_param is not None else None
+    if dst is not None:
+        dw = ohwi(dst)
+        assert dw.data_ptr() == dst.data_ptr()
+        if col is not None:
+            Cout, kh, kw, Cin = w4_shape
+            K = kh * kw * Cin
+            sk = ops._pick_splitk(Cout, K, col.shape[0])
+            ops.gemm_raw(Cout, K, col.shape[0], dy, Cout, OP_DENSE_R, col, col.shape[1], OP_DENSE_R, dw, K, accumulate=True, splitk=sk)
+        else:
+            ops.conv2d_wgrad(dy, x, dw, stride, pad, accumulate=True)
+        wgrad_done(w_param)
+        return None
     dw = torch.empty(w4_shape, device=dy.device, dtype=f32)
     if col is not None:
         Cout, kh, kw, Cin = w4_shape
@@ -145,7 +204,7 @@ def _conv_wgrad_any(dy, x, col, w4_shape, stride, pad):
         ops.gemm_raw(Cout, K, Mpix, dy, Cout, OP_DENSE_R, col, col.shape[1], OP_DENSE_R, dw, K, accumulate=sk > 1, splitk=sk)
     else:
         ops.conv2d_wgrad(dy, x, dw, stride, pad, accumulate=False)
-    return dw
+    return oihw_grad_like(dw)
 
 
 class ConvFn(torch.autograd.Function):
@@ -157,6 +216,7 @@ class ConvFn(torch.autograd.Function):
         w4 = ohwi(w)
         y, col = _conv_any(x, w4, stride, pad, b)
         ctx.stride, ctx.pad, ctx.has_bias = stride, pad, b is not None
+        ctx.w_ref = w
         ctx.save_for_backward(x, w4, col)
         return y
 
@@ -165,9 +225,9 @@ class ConvFn(torch.autograd.Function):
         x, w4, col = ctx.saved_tensors
         dy = _c(dy)
         dx = ops.conv2d_dgrad(dy, w4, tuple(x.shape), ctx.stride, ctx.pad) if ctx.needs_input_grad[0] else None
-        dw = _conv_wgrad_any(dy, x, col, tuple(w4.shape), ctx.stride, ctx.pad)
+        dw = _conv_wgrad_any(dy, x, col, tuple(w4.shape), ctx.stride, ctx.pad, ctx.w_ref)
         db = ops.colsum(dy.view(-1, dy.shape[-1])) if ctx.has_bias else None
-        return dx, oihw_grad_like(dw), db, None, None
+        return dx, dw, db, None, None
 
 
 class ConvBnFn(torch.autograd.Function):
@@ -196,6 +256,7 @@ class ConvBnFn(torch.autograd.Function):
         r2 = None if res is None else _c(res).view(-1, C)
         y = ops.bn_apply(z2, r2, mean, invstd, gamma, beta, relu).view(z.shape)
         ctx.cfg = (stride, pad, relu, training, count, res is not None, sync)
+        ctx.w_ref = w
         ctx.save_for_backward(x, w4, col, z, y if relu else None, mean, invstd, gamma, count_dev)
         return y
 
@@ -217,9 +278,9 @@ class ConvBnFn(torch.autograd.Function):
         dz2, dres2 = ops.bn_bwd_apply(dy2, y2, z2, mean, invstd, gamma, sums, count, relu, has_res, None, None, count_dev)
         dz = dz2.view(z.shape)
         dx = ops.conv2d_dgrad(dz, w4, tuple(x.shape), stride, pad) if ctx.needs_input_grad[0] else None
-        dw = _conv_wgrad_any(dz, x, col, tuple(w4.shape), stride, pad)
+        dw = _conv_wgrad_any(dz, x, col, tuple(w4.shape), stride, pad, ctx.w_ref)
         dres = dres2.view(z.shape) if has_res else None
-        return dx, oihw_grad_like(dw), dgamma, dbeta, None, None, dres, None, None, None, None, None, None, None
+        return dx, dw, dgamma, dbeta, None, None, dres, None, None, None, None, None, None, None
 
 
 class MaxPoolFn(torch.autograd.Function):
@@ -327,6 +388,7 @@ class BertEmbedFn(torch.autograd.Function):
         type0 = typ[0].contiguous()
         out, xhat, rstd = ops.embed_ln_fwd(ids, pos_ids, word, pos, type0, gamma, beta, eps, p, seed, sid)
         ctx.cfg = (p, seed, sid, word.shape, pos.shape, typ.shape)
+        ctx.w_refs = (word, pos)
         ctx.save_for_backward(xhat, rstd, ids, pos_ids, gamma)
         return out
 
@@ -335,12 +397,20 @@ class BertEmbedFn(torch.autograd.Function):
         xhat, rstd, ids, pos_ids, gamma = ctx.saved_tensors
         p, seed, sid, wshape, pshape, tshape = ctx.cfg
         dev = dout.device
-        dword = torch.zeros(wshape, device=dev, dtype=f32)
-        dpos = torch.zeros(pshape, device=dev, dtype=f32)
+        rword, rpos = ctx.w_refs
+        sw, sp = wgrad_dest(rword), wgrad_dest(rpos)
+        dword = sw if sw is not None else torch.zeros(wshape, device=dev, dtype=f32)      # 94 MB table: scatter-add in place
+        dpos = sp if sp is not None else torch.zeros(pshape, device=dev, dtype=f32)
         dtyp = torch.zeros(tshape, device=dev, dtype=f32)
         dg = torch.zeros_like(gamma)
         db = torch.zeros_like(gamma)
         ops.embed_ln_bwd(_c(dout), xhat, rstd, ids, pos_ids, gamma, p, seed, sid, dword, dpos, dtyp[0], dg, db)
+        if sw is not None:
+            wgrad_done(rword)
+            dword = None
+        if sp is not None:
+            wgrad_done(rpos)
+            dpos = None
         return dword, dpos, dtyp, dg, db, None, None, None, None, None, None
 
 
@@ -379,6 +449,7 @@ class BertLayerFn(torch.autograd.Function):
         fo = ops.linear_fwd(g, wo2, bo2)
         y, xh2, rs2 = ops.dropout_add_ln_fwd(fo, x1, g2, b2, eps, p, seed, sid + 2)
         ctx.meta, ctx.cfg = meta, (eps, p, seed, sid)
+        ctx.w_refs = (wq, wk, wv, wo, wi, wo2)
         ctx.save_for_backward(x, wq, wk, wv, wo, g1, wi, wo2, g2, qkv, P, ctxv, xh1, rs1, x1, h, g, xh2, rs2)
         return y
 
@@ -394,20 +465,18 @@ class BertLayerFn(torch.autograd.Function):
         dg2, db2 = z(g2), z(g2)
         dfo, dx1 = ops.dropout_add_ln_bwd(_c(dy), xh2, rs2, g2, p, seed, sid + 2, dg2, db2)
         # FFN
-        dwo2 = torch.empty_like(wo2)
-        ops.linear_wgrad(dfo, g, dwo2, accumulate=False)
+        rq, rk, rv, ro, ri, ro2 = ctx.w_refs
+        dwo2 = _linear_wgrad(ro2, dfo, g)
         dbo2 = ops.colsum(dfo)
         dh_ = ops.linear_dgrad(dfo, wo2)
         ops.gelu_bwd_(h, dh_)
-        dwi = torch.empty_like(wi)
-        ops.linear_wgrad(dh_, x1, dwi, accumulate=False)
+        dwi = _linear_wgrad(ri, dh_, x1)
         dbi = ops.colsum(dh_)
         ops.linear_dgrad(dh_, wi, out=dx1, accumulate=True)
         # LN1
         dg1, db1 = z(g1), z(g1)
         dao, dx = ops.dropout_add_ln_bwd(dx1, xh1, rs1, g1, p, seed, sid + 1, dg1, db1)
-        dwo = torch.empty_like(wo)
-        ops.linear_wgrad(dao, ctxv, dwo, accumulate=False)
+        dwo = _linear_wgrad(ro, dao, ctxv)
         dbo = ops.colsum(dao)
         dctx = ops.linear_dgrad(dao, wo)
         # attention backward (grouped GEMMs + row softmax backward)
@@ -424,11 +493,9 @@ class BertLayerFn(torch.autograd.Function):
                      grp_max=(meta.maxlen, dh), c_ptr_off=hid)
         # QKV projections
         dws = []
-        for j, w in enumerate((wq, wk, wv)):
+        for j, (w, wr) in enumerate(((wq, rq), (wk, rk), (wv, rv))):
             dj = dqkv[:, j * hid:(j + 1) * hid]
-            dw = torch.empty_like(w)
-            ops.linear_wgrad(dj, x, dw, accumulate=False)
-            dws.append(dw)
+            dws.append(_linear_wgrad(wr, dj, x))
             ops.linear_dgrad(dj, w, out=dx, accumulate=True)
         dbqkv = ops.colsum(dqkv)
         return (dx, dws[0], dbqkv[:hid], dws[1], dbqkv[hid:2 * hid], dws[2], dbqkv[2 * hid:], dwo, dbo, dg1, db1, dwi, dbi, dwo2, dbo2,

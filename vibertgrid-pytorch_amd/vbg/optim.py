@@ -20,6 +20,7 @@ from typing import Dict, List, Tuple
 import torch
 import torch.distributed as dist
 
+from . import functions as Fn
 from . import ops
 
 STATIC_UNUSED = ("pooler.", "resnet.fc.")
@@ -53,6 +54,7 @@ class FlatGroup:
             v.copy_(p.data)
             p.data = v
             p.grad = _phys_view(self.gflat, off, p.data)
+            Fn.GRAD_SINK.add(id(p))          # weight-gradient GEMMs accumulate straight into this view
 
     def zero_grad(self):
         self.gflat.zero_()
@@ -139,8 +141,10 @@ class FlatReducer:
         self.world = dist.get_world_size(group) if self.enabled else 1
         self.buckets = []          # (tensor view, pending count)
         self.handles = []
+        self.bucket_of = {}        # id(param) -> bucket index
         if not self.enabled:
             return
+        Fn.GRAD_READY[0] = self._param_ready      # sunk gradients (written by the wgrad kernels) report here
         cap = int(bucket_mb * (1 << 20) / 4)
         for o in optimizers:
             o.grad_scale = 1.0 / self.world
@@ -157,7 +161,13 @@ class FlatReducer:
         idx = len(self.buckets)
         self.buckets.append([view, len(members), len(members)])
         for p in members:
-            p.register_post_accumulate_grad_hook(lambda _p, idx=idx: self._ready(idx))
+            self.bucket_of[id(p)] = idx
+            p.register_post_accumulate_grad_hook(lambda _p, idx=idx: self._ready(idx))       # autograd-accumulated gradients
+
+    def _param_ready(self, p):
+        idx = self.bucket_of.get(id(p))
+        if idx is not None:
+            self._ready(idx)
 
     def _ready(self, idx):
         b = self.buckets[idx]
