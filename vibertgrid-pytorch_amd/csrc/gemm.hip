@@ -41,8 +41,12 @@ __device__ __forceinline__ float4 lds4(const float* ptr, int nvalid) {
     return v;
 }
 
-template <int BM, int BN, int BK, int AK, int BKD, bool VEC>
-__global__ __launch_bounds__(256) void gemm_kernel(const vbg_gemm_desc p) {
+// NT = threads per block: 256 (4 waves, 2x2, LDS double buffered, one barrier per k-tile) or 64 (ONE wave owns the
+// whole tile: wave-private single LDS buffer, no barrier at all -- a wave's DS operations execute in order).
+template <int BM, int BN, int BK, int NT, int AK, int BKD, bool VEC>
+__global__ __launch_bounds__(NT) void gemm_kernel(const vbg_gemm_desc p) {
+    constexpr int WGM = (NT == 256) ? 2 : 1, WGN = (NT == 256) ? 2 : 1;
+    constexpr int NBUF = (NT == 64) ? 1 : 2;
     constexpr int KF = BK / 4;                 // float4 chunks per row of a K-contiguous tile
     constexpr int NG = BK / 8;                 // k-groups (8 k = 4 MFMA steps) per tile
     constexpr bool A_KC = (AK == VBG_OP_DENSE_K || AK == VBG_OP_CONV_K);
@@ -51,13 +55,13 @@ __global__ __launch_bounds__(256) void gemm_kernel(const vbg_gemm_desc p) {
     constexpr int SA = BM + 4, SB = BN + 4;    // k-row stride of a k-major (row-contiguous) LDS tile
     constexpr int ASZ = A_KC ? BM * SKR : BK * SA;
     constexpr int BSZ = B_KC ? BN * SKR : BK * SB;
-    constexpr int NA = BM * KF / 256;
-    constexpr int NB = BN * KF / 256;
-    constexpr int WM = BM / 2, WN = BN / 2;
+    constexpr int NA = BM * KF / NT;
+    constexpr int NB = BN * KF / NT;
+    constexpr int WM = BM / WGM, WN = BN / WGN;
     constexpr int TM = WM / 32, TN = WN / 32;
-    __shared__ __attribute__((aligned(16))) float smem[2 * (ASZ + BSZ)];
+    __shared__ __attribute__((aligned(16))) float smem[NBUF * (ASZ + BSZ)];
     float* const As = smem;
-    float* const Bs = smem + 2 * ASZ;
+    float* const Bs = smem + NBUF * ASZ;
 
     const vbg_conv_geo geo = p.geo;            // uniform descriptor fields live in SGPRs for the whole kernel
     const int tid = threadIdx.x;
@@ -92,7 +96,7 @@ __global__ __launch_bounds__(256) void gemm_kernel(const vbg_gemm_desc p) {
     if constexpr (A_KC) {
 #pragma unroll
         for (int i = 0; i < NA; ++i) {
-            const int f = tid + i * 256;
+            const int f = tid + i * NT;
             const int gm = m0 + f / KF;
             a_rv[i] = gm < M;
             a_n[i] = a_y[i] = a_x[i] = 0;
@@ -111,7 +115,7 @@ __global__ __launch_bounds__(256) void gemm_kernel(const vbg_gemm_desc p) {
     if constexpr (BKD == VBG_OP_CONV_R) {
 #pragma unroll
         for (int i = 0; i < NB; ++i) {
-            const int f = tid + i * 256;
+            const int f = tid + i * NT;
             const int c = min(n0 + (f % (BN / 4)) * 4, N - 4);
             const int tap = c / geo.Cs;
             b_ci[i] = c - tap * geo.Cs;
@@ -138,7 +142,7 @@ __global__ __launch_bounds__(256) void gemm_kernel(const vbg_gemm_desc p) {
         const int sh = p.a_seg_shift[sg];
 #pragma unroll
         for (int i = 0; i < NA; ++i) {
-            const int f = tid + i * 256;
+            const int f = tid + i * NT;
             long long row = min(m0 + f / KF, M - 1);
             if (sh > 0) row = ((long long)a_n[i] * (p.a_H >> sh) + (a_y[i] >> sh)) * (p.a_W >> sh) + (a_x[i] >> sh);
             a_roff[i] = row * ld;
@@ -151,7 +155,7 @@ __global__ __launch_bounds__(256) void gemm_kernel(const vbg_gemm_desc p) {
     long long b_roff[NB];
     if constexpr (BKD == VBG_OP_DENSE_K) {
 #pragma unroll
-        for (int i = 0; i < NB; ++i) b_roff[i] = (long long)min(n0 + (tid + i * 256) / KF, N - 1) * p.ldb;
+        for (int i = 0; i < NB; ++i) b_roff[i] = (long long)min(n0 + (tid + i * NT) / KF, N - 1) * p.ldb;
     }
     const long long lda = p.lda, ldb = p.ldb;
 
@@ -163,7 +167,7 @@ __global__ __launch_bounds__(256) void gemm_kernel(const vbg_gemm_desc p) {
             if (seg + 1 < p.a_nseg && k0 >= seg_kbeg + seg_kspan) enter_segment(seg + 1);     // rare, uniform
 #pragma unroll
             for (int i = 0; i < NA; ++i) {
-                const int f = tid + i * 256;
+                const int f = tid + i * NT;
                 const int kk = k0 - seg_kbeg + (f % KF) * 4;
                 ra_n[i] = a_rv[i] ? (seg_kspan - kk) : 0;
                 if constexpr (VEC) ra[i] = ldv4(seg_base + a_roff[i] + min(kk, seg_klast));
@@ -176,7 +180,7 @@ __global__ __launch_bounds__(256) void gemm_kernel(const vbg_gemm_desc p) {
             const int dy = tap / geo.kw, dx = tap - dy * geo.kw;
 #pragma unroll
             for (int i = 0; i < NA; ++i) {
-                const int f = tid + i * 256;
+                const int f = tid + i * NT;
                 int sy, sx;
                 bool ok = a_rv[i];
                 if (!geo.dgrad) {
@@ -196,7 +200,7 @@ __global__ __launch_bounds__(256) void gemm_kernel(const vbg_gemm_desc p) {
             const int rlast = ((M + 3) & ~3) - 4;
 #pragma unroll
             for (int i = 0; i < NA; ++i) {
-                const int f = tid + i * 256;
+                const int f = tid + i * NT;
                 const int r = m0 + (f % (BM / 4)) * 4;
                 const int k = k0 + f / (BM / 4);
                 ra_n[i] = (k < K) ? (M - r) : 0;
@@ -209,7 +213,7 @@ __global__ __launch_bounds__(256) void gemm_kernel(const vbg_gemm_desc p) {
             const int klast = ((K + 3) & ~3) - 4;
 #pragma unroll
             for (int i = 0; i < NB; ++i) {
-                const int f = tid + i * 256;
+                const int f = tid + i * NT;
                 const int kk = k0 + (f % KF) * 4;
                 const int col = n0 + f / KF;
                 rb_n[i] = (col < N) ? (K - kk) : 0;
@@ -220,7 +224,7 @@ __global__ __launch_bounds__(256) void gemm_kernel(const vbg_gemm_desc p) {
             const int clast = ((N + 3) & ~3) - 4;
 #pragma unroll
             for (int i = 0; i < NB; ++i) {
-                const int f = tid + i * 256;
+                const int f = tid + i * NT;
                 const int c = n0 + (f % (BN / 4)) * 4;
                 const int k = k0 + f / (BN / 4);
                 rb_n[i] = (k < K) ? (N - c) : 0;
@@ -234,7 +238,7 @@ __global__ __launch_bounds__(256) void gemm_kernel(const vbg_gemm_desc p) {
             const int co0 = k0 - tap * Cout;
 #pragma unroll
             for (int i = 0; i < NB; ++i) {
-                const int f = tid + i * 256;
+                const int f = tid + i * NT;
                 const int c = n0 + (f % (BN / 4)) * 4;
                 const int co = co0 + f / (BN / 4);
                 rb_n[i] = N - c;
@@ -243,7 +247,7 @@ __global__ __launch_bounds__(256) void gemm_kernel(const vbg_gemm_desc p) {
         } else {                                        // VBG_OP_CONV_R: k = pixel, col = (tap, ci)
 #pragma unroll
             for (int i = 0; i < NB; ++i) {
-                const int f = tid + i * 256;
+                const int f = tid + i * NT;
                 const int c = n0 + (f % (BN / 4)) * 4;
                 const int pix = k0 + f / (BN / 4);
                 const int pc = min(pix, K - 1);
@@ -273,14 +277,14 @@ __global__ __launch_bounds__(256) void gemm_kernel(const vbg_gemm_desc p) {
                 v.x = fmaxf(v.x, 0.f) * a_scale; v.y = fmaxf(v.y, 0.f) * a_scale;
                 v.z = fmaxf(v.z, 0.f) * a_scale; v.w = fmaxf(v.w, 0.f) * a_scale;
             }
-            const int f = tid + i * 256;
+            const int f = tid + i * NT;
             if constexpr (A_KC) *reinterpret_cast<float4*>(&as[(f / KF) * SKR + (f % KF) * 4]) = v;
             else *reinterpret_cast<float4*>(&as[(f / (BM / 4)) * SA + (f % (BM / 4)) * 4]) = v;
         }
 #pragma unroll
         for (int i = 0; i < NB; ++i) {
             const float4 v = mask4(rb[i], rb_n[i]);
-            const int f = tid + i * 256;
+            const int f = tid + i * NT;
             if constexpr (B_KC) *reinterpret_cast<float4*>(&bs[(f / KF) * SKR + (f % KF) * 4]) = v;
             else *reinterpret_cast<float4*>(&bs[(f / (BN / 4)) * SB + (f % (BN / 4)) * 4]) = v;
         }
@@ -288,7 +292,7 @@ __global__ __launch_bounds__(256) void gemm_kernel(const vbg_gemm_desc p) {
 
     // ---------------- main loop ---------------------------------------------------------
     const int lane = tid & 63, wave = tid >> 6;
-    const int wm = wave >> 1, wn = wave & 1;
+    const int wm = (WGN == 2) ? (wave >> 1) : wave, wn = (WGN == 2) ? (wave & 1) : 0;
     const int lr = lane & 31, lk = lane >> 5;
     f32x16 acc[TM][TN];
 #pragma unroll
@@ -335,28 +339,37 @@ __global__ __launch_bounds__(256) void gemm_kernel(const vbg_gemm_desc p) {
 
     load_tiles(kt0);
     store_tiles(0);
-    __syncthreads();
+    if constexpr (NT > 64) __syncthreads();
     for (int kt = kt0; kt < kt1; ++kt) {
-        const int buf = (kt - kt0) & 1;
+        const int buf = (NBUF == 2) ? ((kt - kt0) & 1) : 0;
         if (kt + 1 < kt1) load_tiles(kt + 1);
         const float* as = As + buf * ASZ + a_off;
         const float* bs = Bs + buf * BSZ + b_off;
+        // Program order is pinned with sched_barrier: hipcc otherwise sinks the ds_reads of group g+1 BELOW the dependent
+        // MFMA chain of group g (it re-uses one register set), exposing the LDS latency once per 8 MFMAs.
         float fa0[TM][4], fb0[TN][4], fa1[TM][4], fb1[TN][4];
         read_frag(as, bs, 0, fa0, fb0);
 #pragma unroll
         for (int g = 0; g < NG; g += 2) {
             read_frag(as, bs, g + 1, fa1, fb1);
+            __builtin_amdgcn_sched_barrier(0);
             mma_group(fa0, fb0);
+            __builtin_amdgcn_sched_barrier(0);
             if (g + 2 < NG) read_frag(as, bs, g + 2, fa0, fb0);
+            __builtin_amdgcn_sched_barrier(0);
             mma_group(fa1, fb1);
+            __builtin_amdgcn_sched_barrier(0);
         }
-        if (kt + 1 < kt1) store_tiles(buf ^ 1);
-        __syncthreads();
+        if (kt + 1 < kt1) store_tiles((NBUF == 2) ? (buf ^ 1) : 0);
+        if constexpr (NT > 64) __syncthreads();
     }
 
     // ---------------- epilogue ----------------------------------------------------------
     const bool add_bias = (bias != nullptr) && (split == 0);
-    const bool atomic = p.accumulate && p.splitk > 1;
+    const int accumulate = p.accumulate, epi = p.epi;
+    const bool atomic = accumulate && p.splitk > 1;
+    const float alpha = p.alpha;
+    const long long ldc = p.ldc;
 #pragma unroll
     for (int j = 0; j < TN; ++j) {
         const int n = n0 + wn * WN + j * 32 + lr;
@@ -364,36 +377,52 @@ __global__ __launch_bounds__(256) void gemm_kernel(const vbg_gemm_desc p) {
         const float bv = add_bias ? bias[n] : 0.f;
 #pragma unroll
         for (int i = 0; i < TM; ++i) {
+            const int mb = m0 + wm * WM + i * 32 + 4 * lk;
+            float* cp = C + (long long)mb * ldc + n;
+            if (accumulate && !atomic) {
+                // single owner per element: read-modify-write with ALL loads issued before the first store
+                float old[16];
+#pragma unroll
+                for (int r = 0; r < 16; ++r) {
+                    const int dm = (r & 3) + 8 * (r >> 2);
+                    old[r] = (mb + dm < M) ? cp[(long long)dm * ldc] : 0.f;
+                }
+#pragma unroll
+                for (int r = 0; r < 16; ++r) {
+                    const int dm = (r & 3) + 8 * (r >> 2);
+                    if (mb + dm < M) cp[(long long)dm * ldc] = old[r] + (acc[i][j][r] * alpha + bv);
+                }
+                continue;
+            }
 #pragma unroll
             for (int r = 0; r < 16; ++r) {
-                const int m = m0 + wm * WM + i * 32 + (r & 3) + 8 * (r >> 2) + 4 * lk;
-                if (m >= M) continue;
-                float v = acc[i][j][r] * p.alpha + bv;
-                const long long o = (long long)m * p.ldc + n;
+                const int dm = (r & 3) + 8 * (r >> 2);
+                if (mb + dm >= M) continue;
+                const float v = acc[i][j][r] * alpha + bv;
+                const long long o = (long long)dm * ldc;
                 if (atomic) {
-                    unsafeAtomicAdd(C + o, v);
-                } else if (p.accumulate) {
-                    C[o] += v;                       // single owner per element: plain read-modify-write
-                } else if (p.epi == VBG_EPI_RELU) {
-                    C[o] = fmaxf(v, 0.f);
-                } else if (p.epi == VBG_EPI_GELU_DUAL) {
-                    C[o] = v;
-                    C2[o] = gelu_erf(v);
+                    unsafeAtomicAdd(cp + o, v);
+                } else if (epi == VBG_EPI_RELU) {
+                    cp[o] = fmaxf(v, 0.f);
+                } else if (epi == VBG_EPI_GELU_DUAL) {
+                    cp[o] = v;
+                    C2[(long long)(mb + dm) * ldc + n] = gelu_erf(v);
                 } else {
-                    C[o] = v;
+                    cp[o] = v;
                 }
             }
         }
     }
 }
 
-template <int BM, int BN, int BK, int AK, int BKD, bool VEC>
+template <int BM, int BN, int BK, int NT, int AK, int BKD, bool VEC>
 static void launch_one(const vbg_gemm_desc& d, int groups, int maxM, int maxN, hipStream_t s) {
     dim3 g(cdiv(maxM, BM), cdiv(maxN, BN), groups * d.splitk);
-    VBG_LAUNCH((gemm_kernel<BM, BN, BK, AK, BKD, VEC>), g, dim3(256), 0, s, d);
+    VBG_LAUNCH((gemm_kernel<BM, BN, BK, NT, AK, BKD, VEC>), g, dim3(NT), 0, s, d);
 }
 
-// tile code: BM*1000+BN (128128, 128064, 64064); 0 = heuristic.  bk: 16 / 32; 0 = heuristic.
+// tile code: BM*1000+BN (128128, 128064, 64064); 0 = heuristic.  (A barrier-free one-wave-per-tile variant (NT = 64) was
+// measured 25-40 % slower than the 4-wave blocks on every shape and is not instantiated.)  bk: 16 / 32; 0 = heuristic.
 static void pick_tile(const vbg_gemm_desc& d, int groups, int maxM, int maxN, int& tile, int& bk) {
     tile = d.tile;
     bk = d.bk;
@@ -413,15 +442,15 @@ static int launch_pair(const vbg_gemm_desc& d, int groups, int maxM, int maxN, h
     int tile, bk;
     pick_tile(d, groups, maxM, maxN, tile, bk);
     if (!(d.a_vec && d.b_vec)) {                         // unaligned operands: general scalar-load path
-        launch_one<64, 64, 16, AK, BKD, false>(d, groups, maxM, maxN, s);
+        launch_one<64, 64, 16, 256, AK, BKD, false>(d, groups, maxM, maxN, s);
     } else if (bk == 32) {
-        if (tile == 128128) launch_one<128, 128, 32, AK, BKD, true>(d, groups, maxM, maxN, s);
-        else if (tile == 128064) launch_one<128, 64, 32, AK, BKD, true>(d, groups, maxM, maxN, s);
-        else launch_one<64, 64, 32, AK, BKD, true>(d, groups, maxM, maxN, s);
+        if (tile == 128128) launch_one<128, 128, 32, 256, AK, BKD, true>(d, groups, maxM, maxN, s);
+        else if (tile == 128064) launch_one<128, 64, 32, 256, AK, BKD, true>(d, groups, maxM, maxN, s);
+        else launch_one<64, 64, 32, 256, AK, BKD, true>(d, groups, maxM, maxN, s);
     } else {
-        if (tile == 128128) launch_one<128, 128, 16, AK, BKD, true>(d, groups, maxM, maxN, s);
-        else if (tile == 128064) launch_one<128, 64, 16, AK, BKD, true>(d, groups, maxM, maxN, s);
-        else launch_one<64, 64, 16, AK, BKD, true>(d, groups, maxM, maxN, s);
+        if (tile == 128128) launch_one<128, 128, 16, 256, AK, BKD, true>(d, groups, maxM, maxN, s);
+        else if (tile == 128064) launch_one<128, 64, 16, 256, AK, BKD, true>(d, groups, maxM, maxN, s);
+        else launch_one<64, 64, 16, 256, AK, BKD, true>(d, groups, maxM, maxN, s);
     }
     VBG_LAUNCH_RET();
 }
