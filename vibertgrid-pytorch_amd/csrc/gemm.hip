@@ -123,6 +123,21 @@ __global__ __launch_bounds__(NT) void gemm_kernel(const vbg_gemm_desc p) {
             b_dx[i] = tap - b_dy[i] * geo.kw;
         }
     }
+    // CONV_R: the reduction index is the output pixel; each thread walks its pixel forward by BK per k-tile and keeps
+    // (image, y, x) incrementally (one division at kernel start instead of two per float4 per tile)
+    int b_pn[NB], b_py[NB], b_px[NB];
+    const int pix_dq = (BKD == VBG_OP_CONV_R) ? BK / max(geo.Wr, 1) : 0;
+    const int pix_dr = (BKD == VBG_OP_CONV_R) ? BK - pix_dq * geo.Wr : 0;
+    if constexpr (BKD == VBG_OP_CONV_R) {
+#pragma unroll
+        for (int i = 0; i < NB; ++i) {
+            const int pix = kt0 * BK + (tid + i * NT) / (BN / 4);
+            b_px[i] = pix % geo.Wr;
+            const int t = pix / geo.Wr;
+            b_py[i] = t % geo.Hr;
+            b_pn[i] = t / geo.Hr;
+        }
+    }
 
     float4 ra[NA], rb[NB];
     int ra_n[NA], rb_n[NB];        // #valid elements of each float4 (zero-masking is deferred to store_tiles)
@@ -250,15 +265,16 @@ __global__ __launch_bounds__(NT) void gemm_kernel(const vbg_gemm_desc p) {
                 const int f = tid + i * NT;
                 const int c = n0 + (f % (BN / 4)) * 4;
                 const int pix = k0 + f / (BN / 4);
-                const int pc = min(pix, K - 1);
-                const int px = pc % geo.Wr;
-                const int t = pc / geo.Wr;
-                const int py = t % geo.Hr;
-                const int pn = t / geo.Hr;
-                const int sy = py * geo.stride - geo.pad + b_dy[i];
-                const int sx = px * geo.stride - geo.pad + b_dx[i];
+                const int sy = b_py[i] * geo.stride - geo.pad + b_dy[i];
+                const int sx = b_px[i] * geo.stride - geo.pad + b_dx[i];
                 const bool ok = (pix < K) && (c < N) && sy >= 0 && sy < geo.Hs && sx >= 0 && sx < geo.Ws;
-                const long long off = (((long long)pn * geo.Hs + sy) * geo.Ws + sx) * geo.Cs + b_ci[i];
+                const long long off = (((long long)b_pn[i] * geo.Hs + sy) * geo.Ws + sx) * geo.Cs + b_ci[i];
+                // advance this thread's pixel by BK for the next k-tile
+                b_px[i] += pix_dr;
+                const int cx = b_px[i] >= geo.Wr;
+                b_px[i] -= cx ? geo.Wr : 0;
+                b_py[i] += pix_dq + cx;
+                while (b_py[i] >= geo.Hr) { b_py[i] -= geo.Hr; ++b_pn[i]; }
                 rb_n[i] = ok ? 4 : 0;
                 rb[i] = ldv4(B + (ok ? off : 0));
             }
