@@ -120,22 +120,31 @@ __global__ void bn_apply_kernel(const float* __restrict__ x, const float* __rest
 }
 
 __global__ void bn_bwd_apply_kernel(const float* __restrict__ dy, const float* __restrict__ y, const float* __restrict__ x,
-                                    long long M, int C, const float* __restrict__ mean, const float* __restrict__ invstd,
+                                    long long M, int C4, int C, const float* __restrict__ mean, const float* __restrict__ invstd,
                                     const float* __restrict__ gamma, const double* __restrict__ sums, double count,
                                     const double* __restrict__ count_dev, int relu, float* __restrict__ dx,
                                     float* __restrict__ dres) {
     if (count_dev) count = count_dev[0];
-    const long long total = M * C;
+    const float icnt = (float)(1.0 / count);
+    const long long total = M * C4;
     const long long stride = (long long)gridDim.x * blockDim.x;
     for (long long i = (long long)blockIdx.x * blockDim.x + threadIdx.x; i < total; i += stride) {
-        const int c = (int)(i % C);
-        float g = dy[i];
-        if (relu && !(y[i] > 0.f)) g = 0.f;
-        const float is = invstd[c];
-        const float xh = (x[i] - mean[c]) * is;
-        const float mg = (float)(sums[c] / count), mgx = (float)(sums[C + c] / count);
-        dx[i] = gamma[c] * is * (g - mg - xh * mgx);
-        if (dres) dres[i] = g;
+        const int c4 = (int)(i % C4), c = c4 * 4;
+        float4 g = reinterpret_cast<const float4*>(dy)[i];
+        if (relu) {
+            const float4 yv = reinterpret_cast<const float4*>(y)[i];
+            g.x = yv.x > 0.f ? g.x : 0.f; g.y = yv.y > 0.f ? g.y : 0.f; g.z = yv.z > 0.f ? g.z : 0.f; g.w = yv.w > 0.f ? g.w : 0.f;
+        }
+        const float4 xv = reinterpret_cast<const float4*>(x)[i];
+        const float4 mu = reinterpret_cast<const float4*>(mean)[c4], is = reinterpret_cast<const float4*>(invstd)[c4];
+        const float4 ga = reinterpret_cast<const float4*>(gamma)[c4];
+        float4 o;
+        o.x = ga.x * is.x * (g.x - (float)sums[c + 0] * icnt - (xv.x - mu.x) * is.x * ((float)sums[C + c + 0] * icnt));
+        o.y = ga.y * is.y * (g.y - (float)sums[c + 1] * icnt - (xv.y - mu.y) * is.y * ((float)sums[C + c + 1] * icnt));
+        o.z = ga.z * is.z * (g.z - (float)sums[c + 2] * icnt - (xv.z - mu.z) * is.z * ((float)sums[C + c + 2] * icnt));
+        o.w = ga.w * is.w * (g.w - (float)sums[c + 3] * icnt - (xv.w - mu.w) * is.w * ((float)sums[C + c + 3] * icnt));
+        reinterpret_cast<float4*>(dx)[i] = o;
+        if (dres) reinterpret_cast<float4*>(dres)[i] = g;
     }
 }
 
@@ -369,8 +378,10 @@ extern "C" int vbg_bn_bwd_apply(const float* dy, const float* y, const float* x,
                                 const double* count_dev, int relu, float* dx, float* dres, float* dgamma_accum,
                                 float* dbeta_accum, void* stream) {
     VBG_CHECK_ARG(dy && x && mean && invstd && gamma && sums && dx && M >= 0 && C > 0 && (count > 0 || count_dev) && (!relu || y));
-    if (M > 0) VBG_LAUNCH(bn_bwd_apply_kernel, dim3(ew_grid(M * C, 256)), dim3(256), 0, S_, dy, y, x, M, C, mean, invstd,
-                                  gamma, sums, count, count_dev, relu, dx, dres);
+    VBG_CHECK_ARG(C % 4 == 0 && ALIGNED16(dy) && ALIGNED16(x) && ALIGNED16(dx) && ALIGNED16(mean) && ALIGNED16(invstd) &&
+                  ALIGNED16(gamma) && (!relu || ALIGNED16(y)) && (!dres || ALIGNED16(dres)));
+    if (M > 0) VBG_LAUNCH(bn_bwd_apply_kernel, dim3(ew_grid(M * (C / 4), 256)), dim3(256), 0, S_, dy, y, x, M, C / 4, C, mean, invstd,
+                          gamma, sums, count, count_dev, relu, dx, dres);
     if (dgamma_accum && dbeta_accum)
         VBG_LAUNCH(bn_param_grad_kernel, dim3(cdiv(C, 256)), dim3(256), 0, S_, sums, C, dgamma_accum, dbeta_accum);
     VBG_LAUNCH_RET();

@@ -127,84 +127,116 @@ __global__ __launch_bounds__(LN_THREADS) void embed_ln_bwd_kernel(
     }
 }
 
-__global__ __launch_bounds__(LN_THREADS) void dropout_add_ln_fwd_kernel(
+// ---- wave-per-row LayerNorm kernels (hidden % 256 == 0, hidden <= 1024): each lane owns float4 chunks lane + 64*j,
+// no block-level barrier; a block of 256 threads handles 4 rows per pass and LN_WROWS passes (backward keeps the
+// dgamma / dbeta partial sums of its columns in registers across all its rows, one atomic per column per wave).
+constexpr int LN_V = 4;            // max float4 per lane (hidden <= 1024)
+constexpr int LN_WROWS = 8;        // rows per wave in the backward kernel
+
+__device__ __forceinline__ float4 drop4(float4 v, uint32_t thr, float ks, uint64_t seed, uint64_t sid, uint64_t idx) {
+    if (thr) {
+        v.x = rng_keep(seed, sid, idx + 0, thr) ? v.x * ks : 0.f; v.y = rng_keep(seed, sid, idx + 1, thr) ? v.y * ks : 0.f;
+        v.z = rng_keep(seed, sid, idx + 2, thr) ? v.z * ks : 0.f; v.w = rng_keep(seed, sid, idx + 3, thr) ? v.w * ks : 0.f;
+    }
+    return v;
+}
+
+__global__ __launch_bounds__(256) void dropout_add_ln_fwd_kernel(
     const float* __restrict__ x, const float* __restrict__ res, int rows, int hidden, const float* __restrict__ gamma,
     const float* __restrict__ beta, float eps, uint32_t drop_thr, float keep_scale, uint64_t seed, uint64_t sid,
     float* __restrict__ y, float* __restrict__ xhat_out, float* __restrict__ rstd_out) {
-    __shared__ float sh[16];
-    const int t = blockIdx.x;
+    const int lane = threadIdx.x & 63;
+    const int t = blockIdx.x * 4 + (threadIdx.x >> 6);
     if (t >= rows) return;
-    float z[LN_MAXPER], xh[LN_MAXPER];
+    const int nv = hidden >> 8;                      // float4 per lane
+    const long long base = (long long)t * hidden;
+    float4 z[LN_V];
+    float s = 0.f;
 #pragma unroll
-    for (int j = 0; j < LN_MAXPER; ++j) {
-        const int c = threadIdx.x + j * LN_THREADS;
-        z[j] = 0.f;
-        if (c < hidden) {
-            float v = x[(long long)t * hidden + c];
-            if (drop_thr) v = rng_keep(seed, sid, (uint64_t)t * hidden + c, drop_thr) ? v * keep_scale : 0.f;
-            z[j] = v + res[(long long)t * hidden + c];
+    for (int j = 0; j < LN_V; ++j) {
+        if (j < nv) {
+            const int c = (lane + 64 * j) * 4;
+            float4 v = drop4(*reinterpret_cast<const float4*>(x + base + c), drop_thr, keep_scale, seed, sid, (uint64_t)base + c);
+            const float4 r = *reinterpret_cast<const float4*>(res + base + c);
+            v.x += r.x; v.y += r.y; v.z += r.z; v.w += r.w;
+            z[j] = v;
+            s += (v.x + v.y) + (v.z + v.w);
         }
     }
-    float rstd;
-    ln_forward_row(z, hidden, eps, sh, xh, rstd);
+    const float mean = wave_sum(s) / (float)hidden;
+    float q = 0.f;
 #pragma unroll
-    for (int j = 0; j < LN_MAXPER; ++j) {
-        const int c = threadIdx.x + j * LN_THREADS;
-        if (c < hidden) {
-            y[(long long)t * hidden + c] = xh[j] * gamma[c] + beta[c];
-            xhat_out[(long long)t * hidden + c] = xh[j];
+    for (int j = 0; j < LN_V; ++j)
+        if (j < nv) {
+            const float a = z[j].x - mean, b = z[j].y - mean, c = z[j].z - mean, d = z[j].w - mean;
+            q += (a * a + b * b) + (c * c + d * d);
         }
-    }
-    if (threadIdx.x == 0) rstd_out[t] = rstd;
+    const float rstd = 1.0f / sqrtf(wave_sum(q) / (float)hidden + eps);
+#pragma unroll
+    for (int j = 0; j < LN_V; ++j)
+        if (j < nv) {
+            const int c = (lane + 64 * j) * 4;
+            const float4 g = *reinterpret_cast<const float4*>(gamma + c), b = *reinterpret_cast<const float4*>(beta + c);
+            float4 xh, o;
+            xh.x = (z[j].x - mean) * rstd; xh.y = (z[j].y - mean) * rstd; xh.z = (z[j].z - mean) * rstd; xh.w = (z[j].w - mean) * rstd;
+            o.x = xh.x * g.x + b.x; o.y = xh.y * g.y + b.y; o.z = xh.z * g.z + b.z; o.w = xh.w * g.w + b.w;
+            *reinterpret_cast<float4*>(y + base + c) = o;
+            *reinterpret_cast<float4*>(xhat_out + base + c) = xh;
+        }
+    if (lane == 0) rstd_out[t] = rstd;
 }
 
-__global__ __launch_bounds__(LN_THREADS) void dropout_add_ln_bwd_kernel(
+__global__ __launch_bounds__(256) void dropout_add_ln_bwd_kernel(
     const float* __restrict__ dy, const float* __restrict__ xhat, const float* __restrict__ rstd, int rows, int hidden,
     const float* __restrict__ gamma, uint32_t drop_thr, float keep_scale, uint64_t seed, uint64_t sid,
     float* __restrict__ dx, float* __restrict__ dres, float* dgamma, float* dbeta) {
-    __shared__ float sh[16];
-    float gam[LN_MAXPER], ag[LN_MAXPER], ab[LN_MAXPER];
+    const int lane = threadIdx.x & 63;
+    const int nv = hidden >> 8;
+    const int t0 = (blockIdx.x * 4 + (threadIdx.x >> 6)) * LN_WROWS;
+    float4 gam[LN_V], ag[LN_V], ab[LN_V];
 #pragma unroll
-    for (int j = 0; j < LN_MAXPER; ++j) {
-        const int c = threadIdx.x + j * LN_THREADS;
-        gam[j] = (c < hidden) ? gamma[c] : 0.f;
-        ag[j] = ab[j] = 0.f;
+    for (int j = 0; j < LN_V; ++j) {
+        ag[j] = ab[j] = make_float4(0.f, 0.f, 0.f, 0.f);
+        gam[j] = (j < nv) ? *reinterpret_cast<const float4*>(gamma + (lane + 64 * j) * 4) : ag[j];
     }
-    const int t0 = blockIdx.x * LN_ROWS_PER_BLOCK;
-    for (int t = t0; t < min(rows, t0 + LN_ROWS_PER_BLOCK); ++t) {
-        float g[LN_MAXPER], xh[LN_MAXPER], dz[LN_MAXPER];
+    for (int t = t0; t < min(rows, t0 + LN_WROWS); ++t) {
+        const long long base = (long long)t * hidden;
+        float4 g[LN_V], xh[LN_V];
+        float s1 = 0.f, s2 = 0.f;
 #pragma unroll
-        for (int j = 0; j < LN_MAXPER; ++j) {
-            const int c = threadIdx.x + j * LN_THREADS;
-            g[j] = xh[j] = 0.f;
-            if (c < hidden) {
-                g[j] = dy[(long long)t * hidden + c];
-                xh[j] = xhat[(long long)t * hidden + c];
-                ag[j] += g[j] * xh[j];
-                ab[j] += g[j];
+        for (int j = 0; j < LN_V; ++j)
+            if (j < nv) {
+                const int c = (lane + 64 * j) * 4;
+                g[j] = *reinterpret_cast<const float4*>(dy + base + c);
+                xh[j] = *reinterpret_cast<const float4*>(xhat + base + c);
+                ag[j].x += g[j].x * xh[j].x; ag[j].y += g[j].y * xh[j].y; ag[j].z += g[j].z * xh[j].z; ag[j].w += g[j].w * xh[j].w;
+                ab[j].x += g[j].x; ab[j].y += g[j].y; ab[j].z += g[j].z; ab[j].w += g[j].w;
+                const float a = g[j].x * gam[j].x, b = g[j].y * gam[j].y, c2 = g[j].z * gam[j].z, d = g[j].w * gam[j].w;
+                s1 += (a + b) + (c2 + d);
+                s2 += (a * xh[j].x + b * xh[j].y) + (c2 * xh[j].z + d * xh[j].w);
             }
-        }
-        ln_backward_row(g, xh, gam, rstd[t], hidden, sh, dz);
+        const float m1 = wave_sum(s1) / (float)hidden, m2 = wave_sum(s2) / (float)hidden;
+        const float rs = rstd[t];
 #pragma unroll
-        for (int j = 0; j < LN_MAXPER; ++j) {
-            const int c = threadIdx.x + j * LN_THREADS;
-            if (c < hidden) {
-                const long long o = (long long)t * hidden + c;
-                dres[o] = dz[j];
-                float v = dz[j];
-                if (drop_thr) v = rng_keep(seed, sid, (uint64_t)t * hidden + c, drop_thr) ? v * keep_scale : 0.f;
-                dx[o] = v;
+        for (int j = 0; j < LN_V; ++j)
+            if (j < nv) {
+                const int c = (lane + 64 * j) * 4;
+                float4 dz;
+                dz.x = rs * (g[j].x * gam[j].x - m1 - xh[j].x * m2); dz.y = rs * (g[j].y * gam[j].y - m1 - xh[j].y * m2);
+                dz.z = rs * (g[j].z * gam[j].z - m1 - xh[j].z * m2); dz.w = rs * (g[j].w * gam[j].w - m1 - xh[j].w * m2);
+                *reinterpret_cast<float4*>(dres + base + c) = dz;
+                *reinterpret_cast<float4*>(dx + base + c) = drop4(dz, drop_thr, keep_scale, seed, sid, (uint64_t)base + c);
             }
-        }
     }
 #pragma unroll
-    for (int j = 0; j < LN_MAXPER; ++j) {
-        const int c = threadIdx.x + j * LN_THREADS;
-        if (c < hidden) {
-            unsafeAtomicAdd(dgamma + c, ag[j]);
-            unsafeAtomicAdd(dbeta + c, ab[j]);
+    for (int j = 0; j < LN_V; ++j)
+        if (j < nv) {
+            const int c = (lane + 64 * j) * 4;
+            unsafeAtomicAdd(dgamma + c + 0, ag[j].x); unsafeAtomicAdd(dgamma + c + 1, ag[j].y);
+            unsafeAtomicAdd(dgamma + c + 2, ag[j].z); unsafeAtomicAdd(dgamma + c + 3, ag[j].w);
+            unsafeAtomicAdd(dbeta + c + 0, ab[j].x); unsafeAtomicAdd(dbeta + c + 1, ab[j].y);
+            unsafeAtomicAdd(dbeta + c + 2, ab[j].z); unsafeAtomicAdd(dbeta + c + 3, ab[j].w);
         }
-    }
 }
 
 // ------------------------------------------------------------------------------------------
@@ -395,10 +427,11 @@ extern "C" int vbg_dropout_add_ln_fwd(const float* x, const float* res, int rows
                                       const float* beta, float eps, float drop_p, unsigned long long seed,
                                       unsigned long long sid, float* y, float* xhat, float* rstd, void* stream) {
     VBG_CHECK_ARG(x && res && gamma && beta && y && xhat && rstd);
-    VBG_CHECK_ARG(hidden > 0 && hidden <= LN_THREADS * LN_MAXPER && drop_p >= 0.f && drop_p < 1.f);
+    VBG_CHECK_ARG(hidden > 0 && hidden % 256 == 0 && hidden <= 256 * LN_V && drop_p >= 0.f && drop_p < 1.f);
+    VBG_CHECK_ARG(((uintptr_t)x | (uintptr_t)res | (uintptr_t)gamma | (uintptr_t)beta | (uintptr_t)y | (uintptr_t)xhat) % 16 == 0);
     if (rows <= 0) return VBG_OK;
-    VBG_LAUNCH(dropout_add_ln_fwd_kernel, dim3(rows), dim3(LN_THREADS), 0, (hipStream_t)stream, x, res, rows, hidden,
-                       gamma, beta, eps, drop_threshold(drop_p), 1.0f / (1.0f - drop_p), seed, sid, y, xhat, rstd);
+    VBG_LAUNCH(dropout_add_ln_fwd_kernel, dim3(cdiv(rows, 4)), dim3(256), 0, (hipStream_t)stream, x, res, rows, hidden,
+               gamma, beta, eps, drop_threshold(drop_p), 1.0f / (1.0f - drop_p), seed, sid, y, xhat, rstd);
     VBG_LAUNCH_RET();
 }
 
@@ -406,11 +439,11 @@ extern "C" int vbg_dropout_add_ln_bwd(const float* dy, const float* xhat, const 
                                       const float* gamma, float drop_p, unsigned long long seed, unsigned long long sid,
                                       float* dx, float* dres, float* dgamma, float* dbeta, void* stream) {
     VBG_CHECK_ARG(dy && xhat && rstd && gamma && dx && dres && dgamma && dbeta);
-    VBG_CHECK_ARG(hidden > 0 && hidden <= LN_THREADS * LN_MAXPER && drop_p >= 0.f && drop_p < 1.f);
+    VBG_CHECK_ARG(hidden > 0 && hidden % 256 == 0 && hidden <= 256 * LN_V && drop_p >= 0.f && drop_p < 1.f);
+    VBG_CHECK_ARG(((uintptr_t)dy | (uintptr_t)xhat | (uintptr_t)gamma | (uintptr_t)dx | (uintptr_t)dres) % 16 == 0);
     if (rows <= 0) return VBG_OK;
-    VBG_LAUNCH(dropout_add_ln_bwd_kernel, dim3(cdiv(rows, LN_ROWS_PER_BLOCK)), dim3(LN_THREADS), 0,
-                       (hipStream_t)stream, dy, xhat, rstd, rows, hidden, gamma, drop_threshold(drop_p),
-                       1.0f / (1.0f - drop_p), seed, sid, dx, dres, dgamma, dbeta);
+    VBG_LAUNCH(dropout_add_ln_bwd_kernel, dim3(cdiv(rows, 4 * LN_WROWS)), dim3(256), 0, (hipStream_t)stream, dy, xhat, rstd, rows,
+               hidden, gamma, drop_threshold(drop_p), 1.0f / (1.0f - drop_p), seed, sid, dx, dres, dgamma, dbeta);
     VBG_LAUNCH_RET();
 }
 
