@@ -131,7 +131,7 @@ __global__ __launch_bounds__(LN_THREADS) void embed_ln_bwd_kernel(
 // no block-level barrier; a block of 256 threads handles 4 rows per pass and LN_WROWS passes (backward keeps the
 // dgamma / dbeta partial sums of its columns in registers across all its rows, one atomic per column per wave).
 constexpr int LN_V = 4;            // max float4 per lane (hidden <= 1024)
-constexpr int LN_WROWS = 8;        // rows per wave in the backward kernel
+constexpr int LN_WROWS = 2;        // rows per wave in the backward kernel (8 rows per block -> >= 2 blocks per CU at cfg2)
 
 __device__ __forceinline__ float4 drop4(float4 v, uint32_t thr, float ks, uint64_t seed, uint64_t sid, uint64_t idx) {
     if (thr) {
@@ -228,15 +228,21 @@ __global__ __launch_bounds__(256) void dropout_add_ln_bwd_kernel(
                 *reinterpret_cast<float4*>(dx + base + c) = drop4(dz, drop_thr, keep_scale, seed, sid, (uint64_t)base + c);
             }
     }
+    // cross-wave reduction of the column partials through LDS, then ONE atomic per column per block
+    __shared__ float red[2][4][256 * LN_V];
+    const int w = threadIdx.x >> 6;
 #pragma unroll
     for (int j = 0; j < LN_V; ++j)
         if (j < nv) {
             const int c = (lane + 64 * j) * 4;
-            unsafeAtomicAdd(dgamma + c + 0, ag[j].x); unsafeAtomicAdd(dgamma + c + 1, ag[j].y);
-            unsafeAtomicAdd(dgamma + c + 2, ag[j].z); unsafeAtomicAdd(dgamma + c + 3, ag[j].w);
-            unsafeAtomicAdd(dbeta + c + 0, ab[j].x); unsafeAtomicAdd(dbeta + c + 1, ab[j].y);
-            unsafeAtomicAdd(dbeta + c + 2, ab[j].z); unsafeAtomicAdd(dbeta + c + 3, ab[j].w);
+            *reinterpret_cast<float4*>(&red[0][w][c]) = ag[j];
+            *reinterpret_cast<float4*>(&red[1][w][c]) = ab[j];
         }
+    __syncthreads();
+    for (int c = threadIdx.x; c < hidden; c += 256) {
+        unsafeAtomicAdd(dgamma + c, (red[0][0][c] + red[0][1][c]) + (red[0][2][c] + red[0][3][c]));
+        unsafeAtomicAdd(dbeta + c, (red[1][0][c] + red[1][1][c]) + (red[1][2][c] + red[1][3][c]));
+    }
 }
 
 // ------------------------------------------------------------------------------------------
