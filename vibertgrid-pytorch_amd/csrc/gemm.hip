@@ -358,25 +358,42 @@ __global__ __launch_bounds__(NT) void gemm_kernel(const vbg_gemm_desc p) {
     if constexpr (NT > 64) __syncthreads();
     for (int kt = kt0; kt < kt1; ++kt) {
         const int buf = (NBUF == 2) ? ((kt - kt0) & 1) : 0;
-        if (kt + 1 < kt1) load_tiles(kt + 1);
+        const bool more = kt + 1 < kt1;
         const float* as = As + buf * ASZ + a_off;
         const float* bs = Bs + buf * BSZ + b_off;
-        // Program order is pinned with sched_barrier: hipcc otherwise sinks the ds_reads of group g+1 BELOW the dependent
-        // MFMA chain of group g (it re-uses one register set), exposing the LDS latency once per 8 MFMAs.
+        // Order inside one k-tile (pinned with sched_barrier; hipcc otherwise sinks the ds_reads below the dependent MFMA
+        // chains and parks all non-MFMA work before/after the whole MFMA block):
+        //   fragments g0, g1  ->  MFMA g0  ->  next tile's address math + global loads  ->  fragments / MFMA g1..  ->
+        //   mask + ds_write of the prefetched tile BEFORE the last MFMA group  ->  last MFMA group  ->  barrier
         float fa0[TM][4], fb0[TN][4], fa1[TM][4], fb1[TN][4];
         read_frag(as, bs, 0, fa0, fb0);
-#pragma unroll
-        for (int g = 0; g < NG; g += 2) {
-            read_frag(as, bs, g + 1, fa1, fb1);
-            __builtin_amdgcn_sched_barrier(0);
-            mma_group(fa0, fb0);
-            __builtin_amdgcn_sched_barrier(0);
-            if (g + 2 < NG) read_frag(as, bs, g + 2, fa0, fb0);
+        read_frag(as, bs, 1, fa1, fb1);
+        __builtin_amdgcn_sched_barrier(0);
+        mma_group(fa0, fb0);
+        __builtin_amdgcn_sched_barrier(0);
+        if (more) load_tiles(kt + 1);
+        __builtin_amdgcn_sched_barrier(0);
+        if constexpr (NG == 2) {
+            if (more) store_tiles((NBUF == 2) ? (buf ^ 1) : 0);
             __builtin_amdgcn_sched_barrier(0);
             mma_group(fa1, fb1);
+        } else {
+#pragma unroll
+            for (int g = 2; g < NG; g += 2) {
+                read_frag(as, bs, g, fa0, fb0);
+                __builtin_amdgcn_sched_barrier(0);
+                mma_group(fa1, fb1);
+                __builtin_amdgcn_sched_barrier(0);
+                read_frag(as, bs, g + 1, fa1, fb1);
+                __builtin_amdgcn_sched_barrier(0);
+                mma_group(fa0, fb0);
+                __builtin_amdgcn_sched_barrier(0);
+            }
+            if (more) store_tiles((NBUF == 2) ? (buf ^ 1) : 0);
             __builtin_amdgcn_sched_barrier(0);
+            mma_group(fa1, fb1);
         }
-        if (kt + 1 < kt1) store_tiles((NBUF == 2) ? (buf ^ 1) : 0);
+        __builtin_amdgcn_sched_barrier(0);
         if constexpr (NT > 64) __syncthreads();
     }
 
