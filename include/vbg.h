@@ -173,6 +173,10 @@ int vbg_bn_bwd_apply(const float* dy, const float* y, const float* x, long long 
                      const float* invstd, const float* gamma, const double* sums, double count, const double* count_dev,
                      int relu, float* dx,
                      float* dres, float* dgamma_accum, float* dbeta_accum, void* stream);
+/* dbeta += (float)sums[0..C), dgamma += (float)sums[C..2C): the BatchNorm affine gradients from the LOCAL backward sums
+   (call before a SyncBN all-reduce of `sums`; torch.nn.SyncBatchNorm leaves weight/bias gradients per-rank for DDP to average,
+   model/ResNetFPN_ViBERTgrid.py:196-206 `norm_layer`) */
+int vbg_bn_param_grad(const double* sums, int C, float* dgamma_accum, float* dbeta_accum, void* stream);
 int vbg_maxpool3x3s2_fwd(const float* x, int B, int H, int W, int C, float* y, int* argmax, void* stream);
 int vbg_maxpool3x3s2_bwd(const float* dy, const int* argmax, int B, int Ho, int Wo, int C, int H, int W,
                          float* dx_zeroed, void* stream);

@@ -387,6 +387,12 @@ extern "C" int vbg_bn_bwd_apply(const float* dy, const float* y, const float* x,
     VBG_LAUNCH_RET();
 }
 
+extern "C" int vbg_bn_param_grad(const double* sums, int C, float* dgamma_accum, float* dbeta_accum, void* stream) {
+    VBG_CHECK_ARG(sums && dgamma_accum && dbeta_accum && C > 0);
+    VBG_LAUNCH(bn_param_grad_kernel, dim3(cdiv(C, 256)), dim3(256), 0, S_, sums, C, dgamma_accum, dbeta_accum);
+    VBG_LAUNCH_RET();
+}
+
 extern "C" int vbg_maxpool3x3s2_fwd(const float* x, int B, int H, int W, int C, float* y, int* argmax, void* stream) {
     VBG_CHECK_ARG(x && y && argmax && B >= 0 && H > 0 && W > 0 && C > 0);
     const int Ho = (H + 2 - 3) / 2 + 1, Wo = (W + 2 - 3) / 2 + 1;

@@ -27,17 +27,17 @@ def _c(t):
 
 
 # ----------------------------------------------------------------------------------------------
-# Gradient sink: when a parameter's `.grad` is a persistent view into a flat gradient buffer (vbg/optim.FlatGroup, zeroed
-# once per step), the weight-gradient GEMMs accumulate STRAIGHT into it (C += dY^T X) and autograd gets None for that
-# input: no temporary dW, no extra read-modify-write pass, no allocator churn.  `GRAD_READY` (set by FlatReducer) is told
+# Gradient sink: when a parameter is marked `_vbg_sunk` (vbg/optim.FlatGroup: its `.grad` is a persistent view into a flat
+# gradient buffer that is zeroed once per step), the weight-gradient GEMMs, bias column sums and normalisation-layer
+# reductions accumulate STRAIGHT into it and autograd gets None for that input: no temporary gradient, no extra
+# read-modify-write pass, no allocator churn.  `GRAD_READY` (set by FlatReducer) is told
 # when a sunk gradient is complete so the bucket all-reduce can start, exactly like a post-accumulate hook would.
 # ----------------------------------------------------------------------------------------------
-GRAD_SINK = set()          # id(param)
 GRAD_READY = [None]        # callable(param) or None
 
 
 def wgrad_dest(w):
-    if id(w) in GRAD_SINK and w.grad is not None:
+    if getattr(w, "_vbg_sunk", False) and w.grad is not None:
         return w.grad
     return None
 
@@ -45,6 +45,32 @@ def wgrad_dest(w):
 def wgrad_done(w):
     if GRAD_READY[0] is not None:
         GRAD_READY[0](w)
+
+
+def _bias_grad(b_param, dy2d):
+    """column sums of dy: added into the sunk flat gradient (autograd gets None) or returned as a fresh tensor"""
+    dst = wgrad_dest(b_param)
+    if dst is not None:
+        ops.colsum(dy2d, out=dst, accumulate=True)
+        wgrad_done(b_param)
+        return None
+    return ops.colsum(dy2d)
+
+
+def _affine_dest(gamma_param, beta_param):
+    """(dgamma, dbeta, sunk): accumulation targets for the normalisation-layer kernels (they += into them)"""
+    dg, db = wgrad_dest(gamma_param), wgrad_dest(beta_param)
+    if dg is not None and db is not None:
+        return dg, db, True
+    return torch.zeros_like(gamma_param), torch.zeros_like(beta_param), False
+
+
+def _affine_done(gamma_param, beta_param, dg, db, sunk):
+    if sunk:
+        wgrad_done(gamma_param)
+        wgrad_done(beta_param)
+        return None, None
+    return dg, db
 
 
 class SyncCtx:
@@ -78,7 +104,7 @@ class LinearFn(torch.autograd.Function):
         y = ops.linear_fwd(x, w, b, EPI_RELU if relu else EPI_NONE)
         ctx.relu = relu
         ctx.has_bias = b is not None
-        ctx.w_ref = w
+        ctx.w_ref, ctx.b_ref = w, b
         ctx.save_for_backward(x, w, y if relu else None)
         return y
 
@@ -90,7 +116,7 @@ class LinearFn(torch.autograd.Function):
             dy = ops.relu_bwd_(y, dy.clone())
         dx = ops.linear_dgrad(dy, w) if ctx.needs_input_grad[0] else None
         dw = _linear_wgrad(ctx.w_ref, dy, x)
-        db = ops.colsum(dy) if ctx.has_bias else None
+        db = _bias_grad(ctx.b_ref, dy) if ctx.has_bias else None
         return dx, dw, db, None
 
 
@@ -102,7 +128,7 @@ class SegLinearFn(torch.autograd.Function):
     @staticmethod
     def forward(ctx, w, b, shifts, hw, *xs):
         """w: [N, K] linear weight or [N, K, 1, 1] (channels_last) 1x1 conv weight"""
-        ctx.w_ref = w
+        ctx.w_ref, ctx.b_ref = w, b
         w2d = w.reshape(w.shape[0], -1)
         xs = [_c(x) for x in xs]
         chans = [x.shape[-1] for x in xs]
@@ -153,7 +179,7 @@ class SegLinearFn(torch.autograd.Function):
             ops.gemm_raw(N, c, Ms, g2, N, OP_DENSE_R, x.view(-1, c), c, OP_DENSE_R, dw, K, c_ptr_off=koff, accumulate=sunk or sk > 1,
                          splitk=sk)
             koff += c
-        db = ops.colsum(dy2) if ctx.has_bias else None
+        db = _bias_grad(ctx.b_ref, dy2) if ctx.has_bias else None
         if sunk:
             wgrad_done(ctx.w_ref)
             dw_ret = None
@@ -216,7 +242,7 @@ class ConvFn(torch.autograd.Function):
         w4 = ohwi(w)
         y, col = _conv_any(x, w4, stride, pad, b)
         ctx.stride, ctx.pad, ctx.has_bias = stride, pad, b is not None
-        ctx.w_ref = w
+        ctx.w_ref, ctx.b_ref = w, b
         ctx.save_for_backward(x, w4, col)
         return y
 
@@ -226,7 +252,7 @@ class ConvFn(torch.autograd.Function):
         dy = _c(dy)
         dx = ops.conv2d_dgrad(dy, w4, tuple(x.shape), ctx.stride, ctx.pad) if ctx.needs_input_grad[0] else None
         dw = _conv_wgrad_any(dy, x, col, tuple(w4.shape), ctx.stride, ctx.pad, ctx.w_ref)
-        db = ops.colsum(dy.view(-1, dy.shape[-1])) if ctx.has_bias else None
+        db = _bias_grad(ctx.b_ref, dy.view(-1, dy.shape[-1])) if ctx.has_bias else None
         return dx, dw, db, None, None
 
 
@@ -256,7 +282,7 @@ class ConvBnFn(torch.autograd.Function):
         r2 = None if res is None else _c(res).view(-1, C)
         y = ops.bn_apply(z2, r2, mean, invstd, gamma, beta, relu).view(z.shape)
         ctx.cfg = (stride, pad, relu, training, count, res is not None, sync)
-        ctx.w_ref = w
+        ctx.w_ref, ctx.affine = w, (gamma, beta)
         ctx.save_for_backward(x, w4, col, z, y if relu else None, mean, invstd, gamma, count_dev)
         return y
 
@@ -271,8 +297,9 @@ class ConvBnFn(torch.autograd.Function):
         y2 = None if y is None else y.view(-1, C)
         sums = torch.zeros((2 * C,), device=dy.device, dtype=torch.float64)
         ops.bn_bwd_reduce(dy2, y2, z2, mean, invstd, relu, sums)
-        dbeta = sums[:C].to(f32)
-        dgamma = sums[C:].to(f32)
+        dgamma, dbeta, sunk = _affine_dest(*ctx.affine)           # from the LOCAL sums: the gradient exchange averages them
+        ops.bn_param_grad(sums, dgamma, dbeta)
+        dgamma, dbeta = _affine_done(*ctx.affine, dgamma, dbeta, sunk)
         if sync:
             dist.all_reduce(sums, group=SyncCtx.group)
         dz2, dres2 = ops.bn_bwd_apply(dy2, y2, z2, mean, invstd, gamma, sums, count, relu, has_res, None, None, count_dev)
@@ -388,7 +415,7 @@ class BertEmbedFn(torch.autograd.Function):
         type0 = typ[0].contiguous()
         out, xhat, rstd = ops.embed_ln_fwd(ids, pos_ids, word, pos, type0, gamma, beta, eps, p, seed, sid)
         ctx.cfg = (p, seed, sid, word.shape, pos.shape, typ.shape)
-        ctx.w_refs = (word, pos)
+        ctx.w_refs = (word, pos, typ, gamma, beta)
         ctx.save_for_backward(xhat, rstd, ids, pos_ids, gamma)
         return out
 
@@ -397,13 +424,12 @@ class BertEmbedFn(torch.autograd.Function):
         xhat, rstd, ids, pos_ids, gamma = ctx.saved_tensors
         p, seed, sid, wshape, pshape, tshape = ctx.cfg
         dev = dout.device
-        rword, rpos = ctx.w_refs
-        sw, sp = wgrad_dest(rword), wgrad_dest(rpos)
+        rword, rpos, rtyp, rgamma, rbeta = ctx.w_refs
+        sw, sp, st = wgrad_dest(rword), wgrad_dest(rpos), wgrad_dest(rtyp)
         dword = sw if sw is not None else torch.zeros(wshape, device=dev, dtype=f32)      # 94 MB table: scatter-add in place
         dpos = sp if sp is not None else torch.zeros(pshape, device=dev, dtype=f32)
-        dtyp = torch.zeros(tshape, device=dev, dtype=f32)
-        dg = torch.zeros_like(gamma)
-        db = torch.zeros_like(gamma)
+        dtyp = st if st is not None else torch.zeros(tshape, device=dev, dtype=f32)
+        dg, db, sunk = _affine_dest(rgamma, rbeta)
         ops.embed_ln_bwd(_c(dout), xhat, rstd, ids, pos_ids, gamma, p, seed, sid, dword, dpos, dtyp[0], dg, db)
         if sw is not None:
             wgrad_done(rword)
@@ -411,7 +437,25 @@ class BertEmbedFn(torch.autograd.Function):
         if sp is not None:
             wgrad_done(rpos)
             dpos = None
+        if st is not None:
+            wgrad_done(rtyp)
+            dtyp = None
+        dg, db = _affine_done(rgamma, rbeta, dg, db, sunk)
         return dword, dpos, dtyp, dg, db, None, None, None, None, None, None
+
+
+def _back_to_back(a, b, c):
+    """three equal-size fp32 tensors stored consecutively (vbg/optim.FlatGroup lays the Q/K/V projections out this way)"""
+    n = 4 * a.numel()
+    sa, sb, sc = (t.untyped_storage().data_ptr() for t in (a, b, c))
+    return (sa == sb == sc and a.numel() == b.numel() == c.numel() and a.is_contiguous() and b.is_contiguous() and c.is_contiguous()
+            and b.data_ptr() == a.data_ptr() + n and c.data_ptr() == b.data_ptr() + n)
+
+
+def _stack3(a):
+    """view of `a` and the two tensors stored right behind it as one [3*rows, ...] tensor"""
+    shape = (3 * a.shape[0],) + tuple(a.shape[1:])
+    return torch.as_strided(a.detach(), shape, a.stride())
 
 
 class AttnMeta:
@@ -432,8 +476,12 @@ class BertLayerFn(torch.autograd.Function):
         H, dh = meta.heads, meta.dh
         dev = x.device
         qkv = torch.empty((ntok, 3 * hid), device=dev, dtype=f32)
-        for j, (w, b) in enumerate(((wq, bq), (wk, bk), (wv, bv))):
-            ops.gemm_raw(ntok, hid, hid, x, hid, OP_DENSE_K, w, hid, OP_DENSE_K, qkv, 3 * hid, bias=b, c_ptr_off=j * hid)
+        fused_qkv = _back_to_back(wq, wk, wv) and _back_to_back(bq, bk, bv)
+        if fused_qkv:              # one [ntok,hid] x [3*hid,hid]^T GEMM over the stacked projections
+            ops.linear_fwd(x, _stack3(wq), _stack3(bq), out=qkv)
+        else:
+            for j, (w, b) in enumerate(((wq, bq), (wk, bk), (wv, bv))):
+                ops.gemm_raw(ntok, hid, hid, x, hid, OP_DENSE_K, w, hid, OP_DENSE_K, qkv, 3 * hid, bias=b, c_ptr_off=j * hid)
         # scores -> probabilities (in place), grouped over (sequence, head)
         P = torch.empty((meta.s_elems,), device=dev, dtype=f32)
         ops.gemm_raw(0, 0, 0, qkv, 3 * hid, OP_DENSE_K, qkv, 3 * hid, OP_DENSE_K, P, meta.ld, grp=meta.t_qk, ngroups=meta.ngroups,
@@ -450,6 +498,7 @@ class BertLayerFn(torch.autograd.Function):
         y, xh2, rs2 = ops.dropout_add_ln_fwd(fo, x1, g2, b2, eps, p, seed, sid + 2)
         ctx.meta, ctx.cfg = meta, (eps, p, seed, sid)
         ctx.w_refs = (wq, wk, wv, wo, wi, wo2)
+        ctx.b_refs = (bq, bk, bv, bo, bi, bo2, g1, b1, g2, b2)
         ctx.save_for_backward(x, wq, wk, wv, wo, g1, wi, wo2, g2, qkv, P, ctxv, xh1, rs1, x1, h, g, xh2, rs2)
         return y
 
@@ -461,23 +510,25 @@ class BertLayerFn(torch.autograd.Function):
         ntok, hid = x.shape
         H, dh = meta.heads, meta.dh
         dev = x.device
-        z = lambda t: torch.zeros_like(t)
-        dg2, db2 = z(g2), z(g2)
+        rbq, rbk, rbv, rbo, rbi, rbo2, rg1, rb1, rg2, rb2 = ctx.b_refs
+        dg2, db2, sunk2 = _affine_dest(rg2, rb2)
         dfo, dx1 = ops.dropout_add_ln_bwd(_c(dy), xh2, rs2, g2, p, seed, sid + 2, dg2, db2)
+        dg2, db2 = _affine_done(rg2, rb2, dg2, db2, sunk2)
         # FFN
         rq, rk, rv, ro, ri, ro2 = ctx.w_refs
         dwo2 = _linear_wgrad(ro2, dfo, g)
-        dbo2 = ops.colsum(dfo)
+        dbo2 = _bias_grad(rbo2, dfo)
         dh_ = ops.linear_dgrad(dfo, wo2)
         ops.gelu_bwd_(h, dh_)
         dwi = _linear_wgrad(ri, dh_, x1)
-        dbi = ops.colsum(dh_)
+        dbi = _bias_grad(rbi, dh_)
         ops.linear_dgrad(dh_, wi, out=dx1, accumulate=True)
         # LN1
-        dg1, db1 = z(g1), z(g1)
+        dg1, db1, sunk1 = _affine_dest(rg1, rb1)
         dao, dx = ops.dropout_add_ln_bwd(dx1, xh1, rs1, g1, p, seed, sid + 1, dg1, db1)
+        dg1, db1 = _affine_done(rg1, rb1, dg1, db1, sunk1)
         dwo = _linear_wgrad(ro, dao, ctxv)
-        dbo = ops.colsum(dao)
+        dbo = _bias_grad(rbo, dao)
         dctx = ops.linear_dgrad(dao, wo)
         # attention backward (grouped GEMMs + row softmax backward)
         dP = torch.empty_like(P)
@@ -492,13 +543,21 @@ class BertLayerFn(torch.autograd.Function):
         ops.gemm_raw(0, 0, 0, dP, meta.ld, OP_DENSE_R, qkv, 3 * hid, OP_DENSE_R, dqkv, 3 * hid, grp=meta.t_dk, ngroups=meta.ngroups,
                      grp_max=(meta.maxlen, dh), c_ptr_off=hid)
         # QKV projections
-        dws = []
-        for j, (w, wr) in enumerate(((wq, rq), (wk, rk), (wv, rv))):
+        gq = [wgrad_dest(t) for t in (rq, rk, rv, rbq, rbk, rbv)]
+        if (all(t is not None for t in gq) and _back_to_back(wq, wk, wv) and _back_to_back(*gq[:3]) and _back_to_back(*gq[3:])):
+            ops.linear_wgrad(dqkv, x, _stack3(gq[0]), accumulate=True)
+            ops.colsum(dqkv, out=_stack3(gq[3]), accumulate=True)
+            ops.linear_dgrad(dqkv, _stack3(wq), out=dx, accumulate=True)
+            for t in (rq, rk, rv, rbq, rbk, rbv):
+                wgrad_done(t)
+            return (dx, None, None, None, None, None, None, dwo, dbo, dg1, db1, dwi, dbi, dwo2, dbo2, dg2, db2, None, None, None, None, None)
+        dws, dbs = [], []
+        for j, (w, wr, br) in enumerate(((wq, rq, rbq), (wk, rk, rbk), (wv, rv, rbv))):
             dj = dqkv[:, j * hid:(j + 1) * hid]
             dws.append(_linear_wgrad(wr, dj, x))
+            dbs.append(_bias_grad(br, dj))
             ops.linear_dgrad(dj, w, out=dx, accumulate=True)
-        dbqkv = ops.colsum(dqkv)
-        return (dx, dws[0], dbqkv[:hid], dws[1], dbqkv[hid:2 * hid], dws[2], dbqkv[2 * hid:], dwo, dbo, dg1, db1, dwi, dbi, dwo2, dbo2,
+        return (dx, dws[0], dbs[0], dws[1], dbs[1], dws[2], dbs[2], dwo, dbo, dg1, db1, dwi, dbi, dwo2, dbo2,
                 dg2, db2, None, None, None, None, None)
 
 

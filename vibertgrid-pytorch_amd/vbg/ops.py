@@ -410,6 +410,10 @@ def bn_bwd_apply(dy, y, x, mean, invstd, gamma, sums, count, relu, want_dres, dg
     return dx, dres
 
 
+def bn_param_grad(sums, dgamma, dbeta):
+    check(lib.vbg_bn_param_grad(P(sums), dgamma.numel(), P(dgamma), P(dbeta), _stream()), "vbg_bn_param_grad")
+
+
 def maxpool_fwd(x):
     B, H, W, C_ = x.shape
     Ho, Wo = conv_out_hw(H, W, 3, 2, 1)

@@ -36,8 +36,31 @@ def _phys_view(flat: torch.Tensor, off: int, p: torch.Tensor) -> torch.Tensor:
     return chunk.view(p.shape)
 
 
+def _fusion_order(named):
+    """Same parameters, ordered so that each attention block's query/key/value weights (and then their biases) sit back to
+    back in the flat buffers: the three projections then run as ONE [3*hidden, hidden] GEMM forward and backward
+    (vbg/functions.BertLayerFn).  The optimizers are element-wise, so the order is otherwise irrelevant."""
+    by_name = dict(named)
+    out, used = [], set()
+    for name, p in named:
+        if name in used:
+            continue
+        if name.endswith("attention.self.query.weight"):
+            stem = name[:-len("query.weight")]
+            block = [stem + k for k in ("query.weight", "key.weight", "value.weight", "query.bias", "key.bias", "value.bias")]
+            if all(b in by_name for b in block):
+                for b in block:
+                    out.append((b, by_name[b]))
+                    used.add(b)
+                continue
+        out.append((name, p))
+        used.add(name)
+    return out
+
+
 class FlatGroup:
     def __init__(self, named: List[Tuple[str, torch.nn.Parameter]], device):
+        named = _fusion_order(named)
         self.names = [n for n, _ in named]
         self.params = [p for _, p in named]
         sizes = [p.numel() for p in self.params]
@@ -54,7 +77,7 @@ class FlatGroup:
             v.copy_(p.data)
             p.data = v
             p.grad = _phys_view(self.gflat, off, p.data)
-            Fn.GRAD_SINK.add(id(p))          # weight-gradient GEMMs accumulate straight into this view
+            p._vbg_sunk = True               # weight-gradient GEMMs accumulate straight into this view
 
     def zero_grad(self):
         self.gflat.zero_()
@@ -142,6 +165,7 @@ class FlatReducer:
         self.buckets = []          # (tensor view, pending count)
         self.handles = []
         self.bucket_of = {}        # id(param) -> bucket index
+        self._reported = set()     # sunk parameters already counted this step
         if not self.enabled:
             return
         Fn.GRAD_READY[0] = self._param_ready      # sunk gradients (written by the wgrad kernels) report here
@@ -165,8 +189,11 @@ class FlatReducer:
             p.register_post_accumulate_grad_hook(lambda _p, idx=idx: self._ready(idx))       # autograd-accumulated gradients
 
     def _param_ready(self, p):
+        """a sunk gradient is complete (each sunk parameter feeds exactly one autograd node per step in this model;
+        a repeated report for the same parameter is ignored rather than double-counted)"""
         idx = self.bucket_of.get(id(p))
-        if idx is not None:
+        if idx is not None and id(p) not in self._reported:
+            self._reported.add(id(p))
             self._ready(idx)
 
     def _ready(self, idx):
@@ -186,3 +213,4 @@ class FlatReducer:
         for h in self.handles:
             h.wait()
         self.handles = []
+        self._reported.clear()
