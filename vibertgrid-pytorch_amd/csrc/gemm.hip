@@ -24,29 +24,52 @@
 
 namespace vbg {
 
-__device__ __forceinline__ float4 ldv4(const float* p) { return *reinterpret_cast<const float4*>(p); }
-// keep the first `nvalid` of 4 elements (branch-free: v_cndmask)
+typedef unsigned u32x4 __attribute__((ext_vector_type(4)));
+// Every global read of the k-loop is a BUFFER load: address = descriptor base (SGPRs, advanced per k-tile with
+// scalar adds) + a per-thread byte offset that does not change from tile to tile.  VALU instructions issue through
+// the same port as the MFMAs (tools/mfma_lds.hip: +80 VALU per 16 MFMA costs 20 %), so the loop keeps per-thread
+// address arithmetic, clamping and zero-masking out of it: a lane that must read zero (row outside the operand,
+// convolution padding, reduction tail) carries VO_INVALID, which is outside every descriptor -> the load returns 0.
+constexpr unsigned VO_INVALID = 0x80000000u;
+constexpr long long NREC_MAX = 0x80000000ll;
+__device__ __forceinline__ __amdgpu_buffer_rsrc_t make_rsrc(const float* base, long long nbytes) {
+    const long long n = nbytes < NREC_MAX ? nbytes : NREC_MAX;
+    return __builtin_amdgcn_make_buffer_rsrc(const_cast<float*>(base), 0, (int)(unsigned)n, 0x00020000);
+}
+// one float4 of an operand: a single 16-byte load (VEC) or four dword loads with their own validity (NE = 4)
+template <int NE>
+__device__ __forceinline__ float4 bload(__amdgpu_buffer_rsrc_t r, const unsigned (&vo)[NE]) {
+    if constexpr (NE == 1) {
+        const u32x4 v = __builtin_amdgcn_raw_buffer_load_b128(r, (int)vo[0], 0, 0);
+        return make_float4(__uint_as_float(v[0]), __uint_as_float(v[1]), __uint_as_float(v[2]), __uint_as_float(v[3]));
+    } else {
+        float4 o;
+        o.x = __uint_as_float(__builtin_amdgcn_raw_buffer_load_b32(r, (int)vo[0], 0, 0));
+        o.y = __uint_as_float(__builtin_amdgcn_raw_buffer_load_b32(r, (int)vo[1], 0, 0));
+        o.z = __uint_as_float(__builtin_amdgcn_raw_buffer_load_b32(r, (int)vo[2], 0, 0));
+        o.w = __uint_as_float(__builtin_amdgcn_raw_buffer_load_b32(r, (int)vo[3], 0, 0));
+        return o;
+    }
+}
+// keep the first `nvalid` of 4 elements (branch-free: v_cndmask); only used on the reduction-tail tile
 __device__ __forceinline__ float4 mask4(float4 v, int nvalid) {
     v.x = nvalid > 0 ? v.x : 0.f; v.y = nvalid > 1 ? v.y : 0.f;
     v.z = nvalid > 2 ? v.z : 0.f; v.w = nvalid > 3 ? v.w : 0.f;
     return v;
 }
-// general path: element-wise guarded loads (unaligned operands, tiny classifier layers)
-__device__ __forceinline__ float4 lds4(const float* ptr, int nvalid) {
-    float4 v = make_float4(0.f, 0.f, 0.f, 0.f);
-    if (nvalid > 0) v.x = ptr[0];
-    if (nvalid > 1) v.y = ptr[1];
-    if (nvalid > 2) v.z = ptr[2];
-    if (nvalid > 3) v.w = ptr[3];
-    return v;
+// byte offsets of the NE pieces of a float4 that starts `elem` floats behind the descriptor base
+template <int NE>
+__device__ __forceinline__ void set_vo(unsigned (&vo)[NE], long long elem, bool ok, int nvalid = 4) {
+#pragma unroll
+    for (int e = 0; e < NE; ++e) vo[e] = (ok && (NE == 1 || e < nvalid)) ? (unsigned)((elem + e) * 4) : VO_INVALID;
 }
 
-// NT = threads per block: 256 (4 waves, 2x2, LDS double buffered, one barrier per k-tile) or 64 (ONE wave owns the
-// whole tile: wave-private single LDS buffer, no barrier at all -- a wave's DS operations execute in order).
+// NT = threads per block (256: 4 waves in 2x2, LDS double buffered, one barrier per k-tile).
 template <int BM, int BN, int BK, int NT, int AK, int BKD, bool VEC>
 __global__ __launch_bounds__(NT) void gemm_kernel(const vbg_gemm_desc p) {
-    constexpr int WGM = (NT == 256) ? 2 : 1, WGN = (NT == 256) ? 2 : 1;
-    constexpr int NBUF = (NT == 64) ? 1 : 2;
+    constexpr int WGM = 2, WGN = 2;
+    constexpr int NBUF = 2;
+    constexpr int NE = VEC ? 1 : 4;            // separately addressed pieces per float4
     constexpr int KF = BK / 4;                 // float4 chunks per row of a K-contiguous tile
     constexpr int NG = BK / 8;                 // k-groups (8 k = 4 MFMA steps) per tile
     constexpr bool A_KC = (AK == VBG_OP_DENSE_K || AK == VBG_OP_CONV_K);
@@ -59,6 +82,7 @@ __global__ __launch_bounds__(NT) void gemm_kernel(const vbg_gemm_desc p) {
     constexpr int NB = BN * KF / NT;
     constexpr int WM = BM / WGM, WN = BN / WGN;
     constexpr int TM = WM / 32, TN = WN / 32;
+    static_assert(NT == 256, "4-wave blocks only");
     __shared__ __attribute__((aligned(16))) float smem[NBUF * (ASZ + BSZ)];
     float* const As = smem;
     float* const Bs = smem + NBUF * ASZ;
@@ -88,16 +112,25 @@ __global__ __launch_bounds__(NT) void gemm_kernel(const vbg_gemm_desc p) {
     const int kt1 = min(nkt, kt0 + per);
     if (kt0 >= kt1) return;
 
-    // ---------------- per-thread loader state -----------------------------------------
-    // K-contiguous kinds : float4 #i (f = tid + 256 i) covers row f / KF, k offset (f % KF) * 4
-    // row-contiguous kinds: float4 #i covers rows (f % (BR/4)) * 4 .. +3, k index f / (BR/4)
-    int a_n[NA], a_y[NA], a_x[NA];          // row -> (image, y, x) for conv / shifted segments
+    // ---------------- loader state -------------------------------------------------------
+    // K-contiguous kinds : float4 #i (f = tid + NT i) covers tile row f / KF, k offset (f % KF) * 4
+    // row-contiguous kinds: float4 #i covers tile rows (f % (BR/4)) * 4 .. +3, k index f / (BR/4)
+    // Scalars (SGPR): k0 = first k of the NEXT tile to load, descriptor bases abase / bbase (pointing at that tile),
+    // remaining bytes for the k-major kinds (their reduction tail falls off the descriptor and reads 0).
+    int k0 = kt0 * BK;
+    const float* abase = A;
+    const float* bbase = B;
+    long long a_rem = NREC_MAX, b_rem = NREC_MAX;
+    unsigned avo[NA][NE], bvo[NB][NE];
+    const int kcA = (tid % KF) * 4;            // k offset of this thread's float4s in a K-contiguous tile (NT % KF == 0)
+
+    // ---- A -------------------------------------------------------------------------------
+    int a_n[NA], a_y[NA], a_x[NA];             // tile row -> (image, y, x) for conv / up-sampled segments
     bool a_rv[NA];
     if constexpr (A_KC) {
 #pragma unroll
         for (int i = 0; i < NA; ++i) {
-            const int f = tid + i * NT;
-            const int gm = m0 + f / KF;
+            const int gm = m0 + (tid + i * NT) / KF;
             a_rv[i] = gm < M;
             a_n[i] = a_y[i] = a_x[i] = 0;
             if (AK == VBG_OP_CONV_K || p.a_H > 0) {
@@ -111,174 +144,233 @@ __global__ __launch_bounds__(NT) void gemm_kernel(const vbg_gemm_desc p) {
             }
         }
     }
-    int b_dy[NB], b_dx[NB], b_ci[NB];       // B CONV_R: columns (tap, ci) are fixed per thread
-    if constexpr (BKD == VBG_OP_CONV_R) {
-#pragma unroll
-        for (int i = 0; i < NB; ++i) {
-            const int f = tid + i * NT;
-            const int c = min(n0 + (f % (BN / 4)) * 4, N - 4);
-            const int tap = c / geo.Cs;
-            b_ci[i] = c - tap * geo.Cs;
-            b_dy[i] = tap / geo.kw;
-            b_dx[i] = tap - b_dy[i] * geo.kw;
-        }
-    }
-    // CONV_R: the reduction index is the output pixel; each thread walks its pixel forward by BK per k-tile and keeps
-    // (image, y, x) incrementally (one division at kernel start instead of two per float4 per tile)
-    int b_pn[NB], b_py[NB], b_px[NB];
-    const int pix_dq = (BKD == VBG_OP_CONV_R) ? BK / max(geo.Wr, 1) : 0;
-    const int pix_dr = (BKD == VBG_OP_CONV_R) ? BK - pix_dq * geo.Wr : 0;
-    if constexpr (BKD == VBG_OP_CONV_R) {
-#pragma unroll
-        for (int i = 0; i < NB; ++i) {
-            const int pix = kt0 * BK + (tid + i * NT) / (BN / 4);
-            b_px[i] = pix % geo.Wr;
-            const int t = pix / geo.Wr;
-            b_py[i] = t % geo.Hr;
-            b_pn[i] = t / geo.Hr;
-        }
-    }
-
-    float4 ra[NA], rb[NB];
-    int ra_n[NA], rb_n[NB];        // #valid elements of each float4 (zero-masking is deferred to store_tiles)
-
-    // DENSE_K A: state of the CURRENT K segment stays in registers; the kernarg arrays are only read again when
-    // the k-loop crosses into the next segment (a dependent chain of scalar loads per k-tile was the top stall).
-    int seg = 0, seg_kbeg = 0, seg_kspan = 0, seg_klast = 0;
-    const float* seg_base = nullptr;
-    long long a_roff[NA];
+    // DENSE_K A: K segments (early / late / P_fuse fusion read several tensors in place, some through a nearest
+    // 2^shift up-sampling); the kernarg arrays are only read when the k-loop crosses into the next segment
+    int seg = 0, seg_kend = K;
     auto enter_segment = [&](int sg) {
         seg = sg;
-        seg_base = p.a_seg_ptr[sg] + (A - p.A);                         // + group offset
+        const int kbeg = (sg == 0) ? 0 : p.a_seg_kend[sg - 1];
+        seg_kend = (p.a_nseg == 1) ? K : p.a_seg_kend[sg];
         const long long ld = p.a_seg_ld[sg];
-        seg_kbeg = (sg == 0) ? 0 : p.a_seg_kend[sg - 1];
-        seg_kspan = ((p.a_nseg == 1) ? K : p.a_seg_kend[sg]) - seg_kbeg;
-        seg_klast = ((seg_kspan + 3) & ~3) - 4;
         const int sh = p.a_seg_shift[sg];
+        const float* sp = p.a_seg_ptr[sg] + (A - p.A);                  // + group offset
+        if (sh == 0) sp += (long long)m0 * ld;
+        abase = sp + (k0 - kbeg);
 #pragma unroll
         for (int i = 0; i < NA; ++i) {
-            const int f = tid + i * NT;
-            long long row = min(m0 + f / KF, M - 1);
+            long long row = (tid + i * NT) / KF;
             if (sh > 0) row = ((long long)a_n[i] * (p.a_H >> sh) + (a_y[i] >> sh)) * (p.a_W >> sh) + (a_x[i] >> sh);
-            a_roff[i] = row * ld;
+            set_vo<NE>(avo[i], row * ld + kcA, a_rv[i]);
+        }
+    };
+    // CONV_K A: gathered NHWC source; offsets are relative to the image of the block's first output pixel and are
+    // recomputed only when the k-loop moves to the next filter tap (every Cs / BK tiles)
+    int a_tap = 0, a_c0 = 0, a_dy = 0, a_dx = 0;
+    bool a_dirty = true;
+    const float* a_img = A;
+    auto conv_a_offsets = [&]() {
+#pragma unroll
+        for (int i = 0; i < NA; ++i) {
+            int sy, sx;
+            bool ok = a_rv[i];
+            if (!geo.dgrad) {
+                sy = a_y[i] * geo.stride - geo.pad + a_dy;
+                sx = a_x[i] * geo.stride - geo.pad + a_dx;
+            } else {
+                const int ty = a_y[i] + geo.pad - a_dy, tx = a_x[i] + geo.pad - a_dx;
+                sy = ty / geo.stride; sx = tx / geo.stride;
+                ok = ok && ty >= 0 && tx >= 0 && (sy * geo.stride == ty) && (sx * geo.stride == tx);
+            }
+            ok = ok && sy >= 0 && sy < geo.Hs && sx >= 0 && sx < geo.Ws;
+            set_vo<NE>(avo[i], (((long long)a_n[i] * geo.Hs + sy) * geo.Ws + sx) * geo.Cs + kcA, ok);
         }
     };
     if constexpr (AK == VBG_OP_DENSE_K) {
         enter_segment(0);
-        while (seg + 1 < p.a_nseg && kt0 * BK >= seg_kbeg + seg_kspan) enter_segment(seg + 1);
-    }
-    long long b_roff[NB];
-    if constexpr (BKD == VBG_OP_DENSE_K) {
+        while (seg + 1 < p.a_nseg && k0 >= seg_kend) enter_segment(seg + 1);
+    } else if constexpr (AK == VBG_OP_CONV_K) {
+        const int nb = m0 / (geo.Hr * geo.Wr);
+        a_img = A + (long long)nb * geo.Hs * geo.Ws * geo.Cs;
 #pragma unroll
-        for (int i = 0; i < NB; ++i) b_roff[i] = (long long)min(n0 + (tid + i * NT) / KF, N - 1) * p.ldb;
+        for (int i = 0; i < NA; ++i) a_n[i] -= nb;
+        a_tap = k0 / geo.Cs;
+        a_c0 = k0 - a_tap * geo.Cs;
+        a_dy = a_tap / geo.kw;
+        a_dx = a_tap - a_dy * geo.kw;
+        abase = a_img + a_c0;
+    } else {  // VBG_OP_DENSE_R : elem(row, k) = A[k*lda + row]
+        abase = A + (long long)k0 * p.lda + m0;
+        a_rem = ((long long)(K - k0) * p.lda) * 4;
+#pragma unroll
+        for (int i = 0; i < NA; ++i) {
+            const int f = tid + i * NT;
+            const int rl = (f % (BM / 4)) * 4;
+            set_vo<NE>(avo[i], (long long)(f / (BM / 4)) * p.lda + rl, m0 + rl < M, M - m0 - rl);
+        }
     }
-    const long long lda = p.lda, ldb = p.ldb;
+    // ---- B -------------------------------------------------------------------------------
+    int b_tap = 0, b_co0 = 0;                  // WT_R: k = tap * Cout + co
+    int b_dy[NB], b_dx[NB], b_ci[NB];          // CONV_R: columns (tap, ci) are fixed per thread
+    bool b_cv[NB];
+    int b_pn[NB], b_py[NB], b_px[NB];          // CONV_R: the reduction index is the output pixel; each thread walks its pixel
+    const int pix_dq = (BKD == VBG_OP_CONV_R) ? BK / max(geo.Wr, 1) : 0;       // forward by BK per k-tile
+    const int pix_dr = (BKD == VBG_OP_CONV_R) ? BK - pix_dq * geo.Wr : 0;
+    int b_img_n = 0, b_img_pix = 0;            // CONV_R: image / in-image pixel of the tile's first reduction pixel (scalar walk)
+    const int b_hw = (BKD == VBG_OP_CONV_R) ? geo.Hr * geo.Wr : 1;
+    if constexpr (BKD == VBG_OP_DENSE_K) {      // elem(col, k) = B[col*ldb + k]
+        bbase = B + (long long)n0 * p.ldb + k0;
+#pragma unroll
+        for (int i = 0; i < NB; ++i) {
+            const int rl = (tid + i * NT) / KF;
+            set_vo<NE>(bvo[i], (long long)rl * p.ldb + kcA, n0 + rl < N);
+        }
+    } else if constexpr (BKD == VBG_OP_DENSE_R) {   // elem(col, k) = B[k*ldb + col]
+        bbase = B + (long long)k0 * p.ldb + n0;
+        b_rem = ((long long)(K - k0) * p.ldb) * 4;
+#pragma unroll
+        for (int i = 0; i < NB; ++i) {
+            const int f = tid + i * NT;
+            const int cl = (f % (BN / 4)) * 4;
+            set_vo<NE>(bvo[i], (long long)(f / (BN / 4)) * p.ldb + cl, n0 + cl < N, N - n0 - cl);
+        }
+    } else if constexpr (BKD == VBG_OP_WT_R) {      // dgrad weights [Cout][taps][Cin]: k = tap*Cout + co, col = ci
+        const int Cout = geo.Cs, taps = geo.kh * geo.kw;
+        b_tap = k0 / Cout;
+        b_co0 = k0 - b_tap * Cout;
+        bbase = B + ((long long)b_co0 * taps + b_tap) * N + n0;
+#pragma unroll
+        for (int i = 0; i < NB; ++i) {
+            const int f = tid + i * NT;
+            const int cl = (f % (BN / 4)) * 4;
+            set_vo<NE>(bvo[i], (long long)(f / (BN / 4)) * taps * N + cl, n0 + cl < N);
+        }
+    } else {                                        // VBG_OP_CONV_R: k = pixel, col = (tap, ci)
+        b_img_n = k0 / b_hw;
+        b_img_pix = k0 - b_img_n * b_hw;
+        bbase = B + (long long)b_img_n * geo.Hs * geo.Ws * geo.Cs;
+#pragma unroll
+        for (int i = 0; i < NB; ++i) {
+            const int f = tid + i * NT;
+            const int c = n0 + (f % (BN / 4)) * 4;
+            b_cv[i] = c < N;
+            const int cc = min(c, N - 4);
+            const int tap = cc / geo.Cs;
+            b_ci[i] = cc - tap * geo.Cs;
+            b_dy[i] = tap / geo.kw;
+            b_dx[i] = tap - b_dy[i] * geo.kw;
+            const int pix = k0 + f / (BN / 4);
+            b_px[i] = pix % geo.Wr;
+            const int t = pix / geo.Wr;
+            b_py[i] = t % geo.Hr;
+            b_pn[i] = t / geo.Hr - b_img_n;        // relative to the descriptor's image
+        }
+    }
 
-    auto load_tiles = [&](int kt) {
-        const int k0 = kt * BK;
+    float4 ra[NA], rb[NB];
+    int st_rem_a = BK, st_rem_b = BK;      // valid reduction length of the tile held in ra / rb (only < BK on a K-contiguous tail)
+
+    // loads the tile at k0 into ra / rb and advances every piece of scalar state to the next tile
+    auto load_tiles = [&]() {
         // ------------------------------ A ------------------------------
         if constexpr (AK == VBG_OP_DENSE_K) {
-            // host normalises a_nseg >= 1 (segment 0 = {A, K, lda, 0} for the plain case)
-            if (seg + 1 < p.a_nseg && k0 >= seg_kbeg + seg_kspan) enter_segment(seg + 1);     // rare, uniform
+            if (seg + 1 < p.a_nseg && k0 >= seg_kend) enter_segment(seg + 1);     // rare, uniform
+            const int rem = seg_kend - k0;
+            st_rem_a = rem;
+            const __amdgpu_buffer_rsrc_t r = make_rsrc(abase, NREC_MAX);
+            if (rem >= BK) {
 #pragma unroll
-            for (int i = 0; i < NA; ++i) {
-                const int f = tid + i * NT;
-                const int kk = k0 - seg_kbeg + (f % KF) * 4;
-                ra_n[i] = a_rv[i] ? (seg_kspan - kk) : 0;
-                if constexpr (VEC) ra[i] = ldv4(seg_base + a_roff[i] + min(kk, seg_klast));
-                else ra[i] = lds4(seg_base + a_roff[i] + kk, ra_n[i]);
-            }
-        } else if constexpr (AK == VBG_OP_CONV_K) {
-            const int Cs = geo.Cs;
-            const int tap = k0 / Cs;
-            const int c0 = k0 - tap * Cs;
-            const int dy = tap / geo.kw, dx = tap - dy * geo.kw;
+                for (int i = 0; i < NA; ++i) ra[i] = bload<NE>(r, avo[i]);
+            } else {                      // reduction tail: chunks (elements) at or beyond K must not be touched
 #pragma unroll
-            for (int i = 0; i < NA; ++i) {
-                const int f = tid + i * NT;
-                int sy, sx;
-                bool ok = a_rv[i];
-                if (!geo.dgrad) {
-                    sy = a_y[i] * geo.stride - geo.pad + dy;
-                    sx = a_x[i] * geo.stride - geo.pad + dx;
-                } else {
-                    const int ty = a_y[i] + geo.pad - dy, tx = a_x[i] + geo.pad - dx;
-                    sy = ty / geo.stride; sx = tx / geo.stride;
-                    ok = ok && ty >= 0 && tx >= 0 && (sy * geo.stride == ty) && (sx * geo.stride == tx);
+                for (int i = 0; i < NA; ++i) {
+                    unsigned vo[NE];
+#pragma unroll
+                    for (int e = 0; e < NE; ++e) vo[e] = (kcA + e < rem) ? avo[i][e] : VO_INVALID;
+                    ra[i] = bload<NE>(r, vo);
                 }
-                ok = ok && sy >= 0 && sy < geo.Hs && sx >= 0 && sx < geo.Ws;
-                const long long off = (((long long)a_n[i] * geo.Hs + sy) * geo.Ws + sx) * Cs + c0 + (f % KF) * 4;
-                ra_n[i] = ok ? 4 : 0;
-                ra[i] = ldv4(A + (ok ? off : 0));                      // conv operands are always 16-byte aligned
             }
-        } else {  // VBG_OP_DENSE_R : elem(row, k) = A[k*lda + row]
-            const int rlast = ((M + 3) & ~3) - 4;
+            abase += BK;
+        } else if constexpr (AK == VBG_OP_CONV_K) {
+            if (a_dirty) { conv_a_offsets(); a_dirty = false; }
+            const __amdgpu_buffer_rsrc_t r = make_rsrc(abase, NREC_MAX);
 #pragma unroll
-            for (int i = 0; i < NA; ++i) {
-                const int f = tid + i * NT;
-                const int r = m0 + (f % (BM / 4)) * 4;
-                const int k = k0 + f / (BM / 4);
-                ra_n[i] = (k < K) ? (M - r) : 0;
-                if constexpr (VEC) ra[i] = ldv4(A + (long long)min(k, K - 1) * lda + min(r, rlast));
-                else ra[i] = lds4(A + (long long)k * lda + r, ra_n[i]);
+            for (int i = 0; i < NA; ++i) ra[i] = bload<NE>(r, avo[i]);
+            a_c0 += BK;
+            abase += BK;
+            if (a_c0 >= geo.Cs) {
+                a_c0 = 0; abase = a_img; a_dirty = true;
+                if (++a_dx == geo.kw) { a_dx = 0; ++a_dy; }
             }
+        } else {
+            const __amdgpu_buffer_rsrc_t r = make_rsrc(abase, a_rem);
+#pragma unroll
+            for (int i = 0; i < NA; ++i) ra[i] = bload<NE>(r, avo[i]);
+            abase += (long long)BK * p.lda;
+            a_rem -= (long long)BK * p.lda * 4;
         }
         // ------------------------------ B ------------------------------
-        if constexpr (BKD == VBG_OP_DENSE_K) {      // elem(col, k) = B[col*ldb + k]
-            const int klast = ((K + 3) & ~3) - 4;
+        if constexpr (BKD == VBG_OP_DENSE_K) {
+            const int rem = K - k0;
+            st_rem_b = rem;
+            const __amdgpu_buffer_rsrc_t r = make_rsrc(bbase, NREC_MAX);
+            if (rem >= BK) {
 #pragma unroll
-            for (int i = 0; i < NB; ++i) {
-                const int f = tid + i * NT;
-                const int kk = k0 + (f % KF) * 4;
-                const int col = n0 + f / KF;
-                rb_n[i] = (col < N) ? (K - kk) : 0;
-                if constexpr (VEC) rb[i] = ldv4(B + b_roff[i] + min(kk, klast));
-                else rb[i] = lds4(B + b_roff[i] + kk, rb_n[i]);
-            }
-        } else if constexpr (BKD == VBG_OP_DENSE_R) {   // elem(col, k) = B[k*ldb + col]
-            const int clast = ((N + 3) & ~3) - 4;
+                for (int i = 0; i < NB; ++i) rb[i] = bload<NE>(r, bvo[i]);
+            } else {
 #pragma unroll
-            for (int i = 0; i < NB; ++i) {
-                const int f = tid + i * NT;
-                const int c = n0 + (f % (BN / 4)) * 4;
-                const int k = k0 + f / (BN / 4);
-                rb_n[i] = (k < K) ? (N - c) : 0;
-                if constexpr (VEC) rb[i] = ldv4(B + (long long)min(k, K - 1) * ldb + min(c, clast));
-                else rb[i] = lds4(B + (long long)k * ldb + c, rb_n[i]);
+                for (int i = 0; i < NB; ++i) {
+                    unsigned vo[NE];
+#pragma unroll
+                    for (int e = 0; e < NE; ++e) vo[e] = (kcA + e < rem) ? bvo[i][e] : VO_INVALID;
+                    rb[i] = bload<NE>(r, vo);
+                }
             }
-        } else if constexpr (BKD == VBG_OP_WT_R) {     // dgrad weights: k = tap*Cout + co, col = ci
-            const int Cout = geo.Cs;                  // gather source of A is dY: Cs == Cout
+            bbase += BK;
+        } else if constexpr (BKD == VBG_OP_DENSE_R) {
+            const __amdgpu_buffer_rsrc_t r = make_rsrc(bbase, b_rem);
+#pragma unroll
+            for (int i = 0; i < NB; ++i) rb[i] = bload<NE>(r, bvo[i]);
+            bbase += (long long)BK * p.ldb;
+            b_rem -= (long long)BK * p.ldb * 4;
+        } else if constexpr (BKD == VBG_OP_WT_R) {
+            const __amdgpu_buffer_rsrc_t r = make_rsrc(bbase, NREC_MAX);
+#pragma unroll
+            for (int i = 0; i < NB; ++i) rb[i] = bload<NE>(r, bvo[i]);
             const int taps = geo.kh * geo.kw;
-            const int tap = k0 / Cout;
-            const int co0 = k0 - tap * Cout;
-#pragma unroll
-            for (int i = 0; i < NB; ++i) {
-                const int f = tid + i * NT;
-                const int c = n0 + (f % (BN / 4)) * 4;
-                const int co = co0 + f / (BN / 4);
-                rb_n[i] = N - c;
-                rb[i] = ldv4(B + ((long long)co * taps + tap) * N + min(c, N - 4));
+            b_co0 += BK;
+            bbase += (long long)BK * taps * N;
+            if (b_co0 >= geo.Cs) {
+                b_co0 = 0; ++b_tap;
+                bbase = B + (long long)b_tap * N + n0;
             }
-        } else {                                        // VBG_OP_CONV_R: k = pixel, col = (tap, ci)
+        } else {
+            const __amdgpu_buffer_rsrc_t r = make_rsrc(bbase, NREC_MAX);
 #pragma unroll
             for (int i = 0; i < NB; ++i) {
-                const int f = tid + i * NT;
-                const int c = n0 + (f % (BN / 4)) * 4;
-                const int pix = k0 + f / (BN / 4);
+                const int pix = k0 + (tid + i * NT) / (BN / 4);
                 const int sy = b_py[i] * geo.stride - geo.pad + b_dy[i];
                 const int sx = b_px[i] * geo.stride - geo.pad + b_dx[i];
-                const bool ok = (pix < K) && (c < N) && sy >= 0 && sy < geo.Hs && sx >= 0 && sx < geo.Ws;
-                const long long off = (((long long)b_pn[i] * geo.Hs + sy) * geo.Ws + sx) * geo.Cs + b_ci[i];
+                const bool ok = (pix < K) && b_cv[i] && sy >= 0 && sy < geo.Hs && sx >= 0 && sx < geo.Ws;
+                unsigned vo[NE];
+                set_vo<NE>(vo, (((long long)b_pn[i] * geo.Hs + sy) * geo.Ws + sx) * geo.Cs + b_ci[i], ok);
+                rb[i] = bload<NE>(r, vo);
                 // advance this thread's pixel by BK for the next k-tile
                 b_px[i] += pix_dr;
                 const int cx = b_px[i] >= geo.Wr;
                 b_px[i] -= cx ? geo.Wr : 0;
                 b_py[i] += pix_dq + cx;
                 while (b_py[i] >= geo.Hr) { b_py[i] -= geo.Hr; ++b_pn[i]; }
-                rb_n[i] = ok ? 4 : 0;
-                rb[i] = ldv4(B + (ok ? off : 0));
+            }
+            // the descriptor follows the image of the next tile's first pixel (scalar walk)
+            b_img_pix += BK;
+            while (b_img_pix >= b_hw) {
+                b_img_pix -= b_hw;
+                bbase += (long long)geo.Hs * geo.Ws * geo.Cs;
+#pragma unroll
+                for (int i = 0; i < NB; ++i) --b_pn[i];
             }
         }
+        k0 += BK;
     };
 
     const int a_prologue = p.a_prologue;
@@ -288,7 +380,10 @@ __global__ __launch_bounds__(NT) void gemm_kernel(const vbg_gemm_desc p) {
         float* bs = Bs + buf * BSZ;
 #pragma unroll
         for (int i = 0; i < NA; ++i) {
-            float4 v = mask4(ra[i], ra_n[i]);
+            float4 v = ra[i];
+            if constexpr (AK == VBG_OP_DENSE_K && VEC) {
+                if (st_rem_a < BK) v = mask4(v, st_rem_a - kcA);          // uniform branch, tail tile only
+            }
             if (a_prologue == 1) {
                 v.x = fmaxf(v.x, 0.f) * a_scale; v.y = fmaxf(v.y, 0.f) * a_scale;
                 v.z = fmaxf(v.z, 0.f) * a_scale; v.w = fmaxf(v.w, 0.f) * a_scale;
@@ -299,7 +394,10 @@ __global__ __launch_bounds__(NT) void gemm_kernel(const vbg_gemm_desc p) {
         }
 #pragma unroll
         for (int i = 0; i < NB; ++i) {
-            const float4 v = mask4(rb[i], rb_n[i]);
+            float4 v = rb[i];
+            if constexpr (BKD == VBG_OP_DENSE_K && VEC) {
+                if (st_rem_b < BK) v = mask4(v, st_rem_b - kcA);
+            }
             const int f = tid + i * NT;
             if constexpr (B_KC) *reinterpret_cast<float4*>(&bs[(f / KF) * SKR + (f % KF) * 4]) = v;
             else *reinterpret_cast<float4*>(&bs[(f / (BN / 4)) * SB + (f % (BN / 4)) * 4]) = v;
@@ -308,7 +406,7 @@ __global__ __launch_bounds__(NT) void gemm_kernel(const vbg_gemm_desc p) {
 
     // ---------------- main loop ---------------------------------------------------------
     const int lane = tid & 63, wave = tid >> 6;
-    const int wm = (WGN == 2) ? (wave >> 1) : wave, wn = (WGN == 2) ? (wave & 1) : 0;
+    const int wm = wave >> 1, wn = wave & 1;
     const int lr = lane & 31, lk = lane >> 5;
     f32x16 acc[TM][TN];
 #pragma unroll
@@ -353,11 +451,11 @@ __global__ __launch_bounds__(NT) void gemm_kernel(const vbg_gemm_desc p) {
                     acc[i][n] = __builtin_amdgcn_mfma_f32_32x32x2f32(fa[i][j], fb[n][j], acc[i][n], 0, 0, 0);
     };
 
-    load_tiles(kt0);
+    load_tiles();
     store_tiles(0);
-    if constexpr (NT > 64) __syncthreads();
+    __syncthreads();
     for (int kt = kt0; kt < kt1; ++kt) {
-        const int buf = (NBUF == 2) ? ((kt - kt0) & 1) : 0;
+        const int buf = (kt - kt0) & 1;
         const bool more = kt + 1 < kt1;
         const float* as = As + buf * ASZ + a_off;
         const float* bs = Bs + buf * BSZ + b_off;
@@ -371,10 +469,10 @@ __global__ __launch_bounds__(NT) void gemm_kernel(const vbg_gemm_desc p) {
         __builtin_amdgcn_sched_barrier(0);
         mma_group(fa0, fb0);
         __builtin_amdgcn_sched_barrier(0);
-        if (more) load_tiles(kt + 1);
+        if (more) load_tiles();
         __builtin_amdgcn_sched_barrier(0);
         if constexpr (NG == 2) {
-            if (more) store_tiles((NBUF == 2) ? (buf ^ 1) : 0);
+            if (more) store_tiles(buf ^ 1);
             __builtin_amdgcn_sched_barrier(0);
             mma_group(fa1, fb1);
         } else {
@@ -389,12 +487,12 @@ __global__ __launch_bounds__(NT) void gemm_kernel(const vbg_gemm_desc p) {
                 mma_group(fa0, fb0);
                 __builtin_amdgcn_sched_barrier(0);
             }
-            if (more) store_tiles((NBUF == 2) ? (buf ^ 1) : 0);
+            if (more) store_tiles(buf ^ 1);
             __builtin_amdgcn_sched_barrier(0);
             mma_group(fa1, fb1);
         }
         __builtin_amdgcn_sched_barrier(0);
-        if constexpr (NT > 64) __syncthreads();
+        __syncthreads();
     }
 
     // ---------------- epilogue ----------------------------------------------------------
