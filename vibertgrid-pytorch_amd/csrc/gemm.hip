@@ -20,6 +20,7 @@
 //    k = 8g+4+j at step j).  Row-contiguous operands are stored [k][rows+4] and read with ds_read_b32;
 //  * fragments of k-group g+1 are fetched while the MFMAs of group g issue (two register sets).
 #include "vbg_common.h"
+#include <type_traits>
 #include "../../include/vbg.h"
 
 namespace vbg {
@@ -268,16 +269,20 @@ __global__ __launch_bounds__(NT) void gemm_kernel(const vbg_gemm_desc p) {
 
     float4 ra[NA], rb[NB];
     int st_rem_a = BK, st_rem_b = BK;      // valid reduction length of the tile held in ra / rb (only < BK on a K-contiguous tail)
+    // Only the K-contiguous dense kinds need per-thread work on the reduction tail (K % BK != 0); that code is compiled
+    // into a separate copy of the k-tile body (TAIL = true) which runs for the single tile that needs it.
+    constexpr bool HAS_TAIL = (AK == VBG_OP_DENSE_K || BKD == VBG_OP_DENSE_K);
 
     // loads the tile at k0 into ra / rb and advances every piece of scalar state to the next tile
-    auto load_tiles = [&]() {
+    auto load_tiles = [&](auto tail_tag) {
+        constexpr bool TAIL = decltype(tail_tag)::value;
         // ------------------------------ A ------------------------------
         if constexpr (AK == VBG_OP_DENSE_K) {
             if (seg + 1 < p.a_nseg && k0 >= seg_kend) enter_segment(seg + 1);     // rare, uniform
             const int rem = seg_kend - k0;
             st_rem_a = rem;
             const __amdgpu_buffer_rsrc_t r = make_rsrc(abase, NREC_MAX);
-            if (rem >= BK) {
+            if constexpr (!TAIL) {
 #pragma unroll
                 for (int i = 0; i < NA; ++i) ra[i] = bload<NE>(r, avo[i]);
             } else {                      // reduction tail: chunks (elements) at or beyond K must not be touched
@@ -313,7 +318,7 @@ __global__ __launch_bounds__(NT) void gemm_kernel(const vbg_gemm_desc p) {
             const int rem = K - k0;
             st_rem_b = rem;
             const __amdgpu_buffer_rsrc_t r = make_rsrc(bbase, NREC_MAX);
-            if (rem >= BK) {
+            if constexpr (!TAIL) {
 #pragma unroll
                 for (int i = 0; i < NB; ++i) rb[i] = bload<NE>(r, bvo[i]);
             } else {
@@ -375,15 +380,14 @@ __global__ __launch_bounds__(NT) void gemm_kernel(const vbg_gemm_desc p) {
 
     const int a_prologue = p.a_prologue;
     const float a_scale = p.a_scale;
-    auto store_tiles = [&](int buf) {
+    auto store_tiles = [&](auto tail_tag, int buf) {
+        constexpr bool TAIL = decltype(tail_tag)::value;
         float* as = As + buf * ASZ;
         float* bs = Bs + buf * BSZ;
 #pragma unroll
         for (int i = 0; i < NA; ++i) {
             float4 v = ra[i];
-            if constexpr (AK == VBG_OP_DENSE_K && VEC) {
-                if (st_rem_a < BK) v = mask4(v, st_rem_a - kcA);          // uniform branch, tail tile only
-            }
+            if constexpr (AK == VBG_OP_DENSE_K && VEC && TAIL) v = mask4(v, st_rem_a - kcA);
             if (a_prologue == 1) {
                 v.x = fmaxf(v.x, 0.f) * a_scale; v.y = fmaxf(v.y, 0.f) * a_scale;
                 v.z = fmaxf(v.z, 0.f) * a_scale; v.w = fmaxf(v.w, 0.f) * a_scale;
@@ -395,9 +399,7 @@ __global__ __launch_bounds__(NT) void gemm_kernel(const vbg_gemm_desc p) {
 #pragma unroll
         for (int i = 0; i < NB; ++i) {
             float4 v = rb[i];
-            if constexpr (BKD == VBG_OP_DENSE_K && VEC) {
-                if (st_rem_b < BK) v = mask4(v, st_rem_b - kcA);
-            }
+            if constexpr (BKD == VBG_OP_DENSE_K && VEC && TAIL) v = mask4(v, st_rem_b - kcA);
             const int f = tid + i * NT;
             if constexpr (B_KC) *reinterpret_cast<float4*>(&bs[(f / KF) * SKR + (f % KF) * 4]) = v;
             else *reinterpret_cast<float4*>(&bs[(f / (BN / 4)) * SB + (f % (BN / 4)) * 4]) = v;
@@ -451,28 +453,34 @@ __global__ __launch_bounds__(NT) void gemm_kernel(const vbg_gemm_desc p) {
                     acc[i][n] = __builtin_amdgcn_mfma_f32_32x32x2f32(fa[i][j], fb[n][j], acc[i][n], 0, 0, 0);
     };
 
-    load_tiles();
-    store_tiles(0);
+    using yes_t = std::integral_constant<bool, true>;
+    using no_t = std::integral_constant<bool, false>;
+    const int ntiles = kt1 - kt0;
+    const bool tail_in_range = HAS_TAIL && kt1 == nkt && (K % BK) != 0;      // the LAST tile of this block is a reduction tail
+    if (tail_in_range && ntiles == 1) { load_tiles(yes_t{}); store_tiles(yes_t{}, 0); }
+    else { load_tiles(no_t{}); store_tiles(no_t{}, 0); }
     __syncthreads();
-    for (int kt = kt0; kt < kt1; ++kt) {
-        const int buf = (kt - kt0) & 1;
-        const bool more = kt + 1 < kt1;
+    // One k-tile: compute tile `it` from LDS buffer it & 1 while (MORE) the next tile is fetched and stored into the other
+    // buffer.  Order (pinned with sched_barrier; hipcc otherwise sinks the ds_reads below the dependent MFMA chains and
+    // parks all non-MFMA work before/after the whole MFMA block):
+    //   fragments g0, g1  ->  MFMA g0  ->  next tile's buffer loads  ->  fragments / MFMA g1..  ->
+    //   ds_write of the prefetched tile BEFORE the last MFMA group  ->  last MFMA group  ->  barrier
+    // The steady-state loop holds exactly one copy of the body (MORE, no tail); the tail-loading and the final tile are
+    // peeled after it, so the loop carries no per-tile branches on them.
+    auto k_tile = [&](auto tail_tag, auto more_tag, int buf) {
+        constexpr bool MORE = decltype(more_tag)::value;
         const float* as = As + buf * ASZ + a_off;
         const float* bs = Bs + buf * BSZ + b_off;
-        // Order inside one k-tile (pinned with sched_barrier; hipcc otherwise sinks the ds_reads below the dependent MFMA
-        // chains and parks all non-MFMA work before/after the whole MFMA block):
-        //   fragments g0, g1  ->  MFMA g0  ->  next tile's address math + global loads  ->  fragments / MFMA g1..  ->
-        //   mask + ds_write of the prefetched tile BEFORE the last MFMA group  ->  last MFMA group  ->  barrier
         float fa0[TM][4], fb0[TN][4], fa1[TM][4], fb1[TN][4];
         read_frag(as, bs, 0, fa0, fb0);
         read_frag(as, bs, 1, fa1, fb1);
         __builtin_amdgcn_sched_barrier(0);
         mma_group(fa0, fb0);
         __builtin_amdgcn_sched_barrier(0);
-        if (more) load_tiles();
+        if constexpr (MORE) load_tiles(tail_tag);
         __builtin_amdgcn_sched_barrier(0);
         if constexpr (NG == 2) {
-            if (more) store_tiles(buf ^ 1);
+            if constexpr (MORE) store_tiles(tail_tag, buf ^ 1);
             __builtin_amdgcn_sched_barrier(0);
             mma_group(fa1, fb1);
         } else {
@@ -487,13 +495,20 @@ __global__ __launch_bounds__(NT) void gemm_kernel(const vbg_gemm_desc p) {
                 mma_group(fa0, fb0);
                 __builtin_amdgcn_sched_barrier(0);
             }
-            if (more) store_tiles(buf ^ 1);
+            if constexpr (MORE) store_tiles(tail_tag, buf ^ 1);
             __builtin_amdgcn_sched_barrier(0);
             mma_group(fa1, fb1);
         }
         __builtin_amdgcn_sched_barrier(0);
-        __syncthreads();
+        if constexpr (MORE) __syncthreads();
+    };
+    int it = 0;
+    const int n_plain = ntiles - 1 - ((tail_in_range && ntiles >= 2) ? 1 : 0);
+    for (; it < n_plain; ++it) k_tile(no_t{}, yes_t{}, it & 1);
+    if constexpr (HAS_TAIL) {
+        if (tail_in_range && ntiles >= 2) { k_tile(yes_t{}, yes_t{}, it & 1); ++it; }
     }
+    k_tile(no_t{}, no_t{}, it & 1);
 
     // ---------------- epilogue ----------------------------------------------------------
     const bool add_bias = (bias != nullptr) && (split == 0);
