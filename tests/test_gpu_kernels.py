@@ -167,7 +167,11 @@ def test_gemm_segments(ops):
 @pytest.mark.parametrize("Cin,Cout,k,stride,pad,H,W", [(16, 32, 3, 1, 1, 9, 11), (64, 128, 3, 2, 1, 16, 20), (64, 128, 1, 2, 0, 16, 20),
                                                         (128, 48, 1, 1, 0, 7, 5), (256, 256, 3, 1, 1, 7, 7), (32, 16, 7, 2, 3, 20, 18),
                                                         (512, 512, 3, 1, 1, 3, 4), (256, 512, 3, 2, 1, 6, 8), (256, 512, 1, 2, 0, 6, 8),
-                                                        (256, 256, 3, 1, 1, 6, 8), (128, 256, 3, 2, 1, 12, 16), (512, 256, 1, 1, 0, 3, 4)])
+                                                        (256, 256, 3, 1, 1, 6, 8), (128, 256, 3, 2, 1, 12, 16), (512, 256, 1, 1, 0, 3, 4),
+                                                        # weight-gradient gather fast paths: a k-tile is a piece of one pixel row ...
+                                                        (32, 32, 3, 1, 1, 5, 32), (32, 64, 3, 2, 1, 6, 64), (16, 32, 3, 1, 1, 4, 16), (64, 64, 3, 1, 1, 3, 64),
+                                                        # ... or whole rows of one image
+                                                        (64, 32, 3, 1, 1, 8, 8), (32, 64, 3, 2, 1, 16, 16), (64, 128, 1, 2, 0, 16, 16), (64, 64, 3, 1, 1, 16, 4)])
 def test_conv(ops, Cin, Cout, k, stride, pad, H, W):
     B = 3
     x = rnd(B, Cin, H, W, seed=30).requires_grad_(True)

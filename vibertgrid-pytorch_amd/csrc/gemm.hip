@@ -218,6 +218,15 @@ __global__ __launch_bounds__(NT) void gemm_kernel(const vbg_gemm_desc p) {
     const int pix_dr = (BKD == VBG_OP_CONV_R) ? BK - pix_dq * geo.Wr : 0;
     int b_img_n = 0, b_img_pix = 0;            // CONV_R: image / in-image pixel of the tile's first reduction pixel (scalar walk)
     const int b_hw = (BKD == VBG_OP_CONV_R) ? geo.Hr * geo.Wr : 1;
+    // CONV_R fast path: when a k-tile is a piece of one pixel row (Wr % BK == 0) or a whole number of rows of one image
+    // (BK % Wr == 0, Hr*Wr % BK == 0), a thread's pixel keeps its position RELATIVE to the tile's first pixel, whose
+    // (y0, xs) walk in SGPRs: source row = y0*stride + b_cy, source column = xs*stride + b_cx with per-thread constants,
+    // the address splits into a scalar part (descriptor base) + the constant b_co, and only the two range checks stay VALU.
+    const bool b_fast = (BKD == VBG_OP_CONV_R) && ((geo.Wr % BK == 0) || (BK % geo.Wr == 0 && b_hw % BK == 0));
+    int b_cy[NB], b_cx[NB];
+    unsigned b_co[NB];
+    int b_y0 = 0, b_xs = 0;
+    const float* b_imgp = B;
     if constexpr (BKD == VBG_OP_DENSE_K) {      // elem(col, k) = B[col*ldb + k]
         bbase = B + (long long)n0 * p.ldb + k0;
 #pragma unroll
@@ -249,6 +258,9 @@ __global__ __launch_bounds__(NT) void gemm_kernel(const vbg_gemm_desc p) {
         b_img_n = k0 / b_hw;
         b_img_pix = k0 - b_img_n * b_hw;
         bbase = B + (long long)b_img_n * geo.Hs * geo.Ws * geo.Cs;
+        b_imgp = bbase;
+        b_y0 = b_img_pix / geo.Wr;
+        b_xs = b_img_pix - b_y0 * geo.Wr;
 #pragma unroll
         for (int i = 0; i < NB; ++i) {
             const int f = tid + i * NT;
@@ -264,6 +276,12 @@ __global__ __launch_bounds__(NT) void gemm_kernel(const vbg_gemm_desc p) {
             const int t = pix / geo.Wr;
             b_py[i] = t % geo.Hr;
             b_pn[i] = t / geo.Hr - b_img_n;        // relative to the descriptor's image
+            // fast path constants (offsets are biased by +pad rows / columns so they are never negative)
+            const int kl = f / (BN / 4);
+            const int ry = kl / geo.Wr, rx = kl - ry * geo.Wr;
+            b_cy[i] = ry * geo.stride - geo.pad + b_dy[i];
+            b_cx[i] = rx * geo.stride - geo.pad + b_dx[i];
+            b_co[i] = b_cv[i] ? (unsigned)((((long long)(b_cy[i] + geo.pad) * geo.Ws + (b_cx[i] + geo.pad)) * geo.Cs + b_ci[i]) * 4) : VO_INVALID;
         }
     }
 
@@ -348,6 +366,19 @@ __global__ __launch_bounds__(NT) void gemm_kernel(const vbg_gemm_desc p) {
                 b_co0 = 0; ++b_tap;
                 bbase = B + (long long)b_tap * N + n0;
             }
+        } else if (b_fast) {
+            const int ys = b_y0 * geo.stride, xs = b_xs * geo.stride;
+            const __amdgpu_buffer_rsrc_t r =
+                make_rsrc(b_imgp + ((long long)(ys - geo.pad) * geo.Ws + (xs - geo.pad)) * geo.Cs, NREC_MAX);
+#pragma unroll
+            for (int i = 0; i < NB; ++i) {
+                const bool ok = (unsigned)(ys + b_cy[i]) < (unsigned)geo.Hs && (unsigned)(xs + b_cx[i]) < (unsigned)geo.Ws;
+                unsigned vo[1] = {ok ? b_co[i] : VO_INVALID};
+                rb[i] = bload<1>(r, vo);
+            }
+            b_xs += BK;
+            while (b_xs >= geo.Wr) { b_xs -= geo.Wr; ++b_y0; }
+            if (b_y0 >= geo.Hr) { b_y0 -= geo.Hr; b_imgp += (long long)geo.Hs * geo.Ws * geo.Cs; }
         } else {
             const __amdgpu_buffer_rsrc_t r = make_rsrc(bbase, NREC_MAX);
 #pragma unroll

@@ -3,6 +3,8 @@ memory and streams only; every function below launches hand-written HIP kernels 
 stream and never synchronises.  No fallbacks: tensors must live on a GPU."""
 import ctypes as C
 
+import os
+
 import torch
 
 from .lib import (EPI_GELU_DUAL, EPI_NONE, EPI_RELU, OP_CONV_K, OP_CONV_R, OP_DENSE_K, OP_DENSE_R, OP_WT_R, ConvGeo,
@@ -117,12 +119,12 @@ _FORCE = [0, 0]
 
 def _pick_splitk(M, N, Kred, bk=32):
     """Split the reduction of a weight-gradient GEMM so the launch has ~3072 blocks (4 co-resident 64x64 blocks on each
-    of the 256 CUs, a few rounds), keeping >= 8 k-tiles per split.  Measured on MI355X (tools/gemm_bench.py sweep):
+    of the 256 CUs, a few rounds), keeping >= 8 k-tiles per split (>= 16 beyond 64 splits: the atomic epilogue grows with them).  Measured on MI355X (tools/gemm_bench.py sweep):
     +33 % on the BERT FFN wgrads, +35 % on the 256->256 conv wgrads versus filling the chip only once."""
     tiles64 = ((M + 63) // 64) * ((N + 63) // 64)
     nkt = (Kred + bk - 1) // bk
     want = (3072 + tiles64 // 2) // max(tiles64, 1)
-    return int(max(1, min(want, nkt // 8, 64)))
+    return int(max(1, min(want, max(min(nkt // 8, 64), min(nkt // 16, 256)))))
 
 
 def linear_fwd(x, w, bias=None, epi=EPI_NONE, out=None, out2=None):
