@@ -155,28 +155,35 @@ int vbg_label_raster(const int* owner, const int* seg_class, long long ncell, in
 /* ------------------------------------------------------------------------------------------
  * a6-a9, a11. convolution trunk helpers (NHWC): BatchNorm (Sync-able), max-pool, FPN resampling
  * ------------------------------------------------------------------------------------------ */
-/* per-channel sum / sum of squares over rows of x[M,C] (fp64 accumulators, all-reducible for SyncBN):
- * stats[0..C) += sum, stats[C..2C) += sumsq */
-int vbg_bn_stats(const float* x, long long M, int C, double* stats_accum, void* stream);
-/* from (global) sums over `count` rows (count_dev, if non-NULL, is a device scalar that overrides `count`:
- * the all-reduced row count under SyncBN): mean, invstd; running <- (1-mom)*running + mom*{mean, unbiased var} */
-int vbg_bn_finalize(const double* stats, double count, const double* count_dev, int C, float eps, float momentum, float* mean, float* invstd,
-                    float* running_mean, float* running_var, void* stream);
+/* The two reductions below spread their fp64 partial sums over vbg_bn_slots() SLOT ROWS of 2*C doubles (same-address
+ * atomics serialise; consumers fold the slots): `slots_accum` is [vbg_bn_slots()][2*C], zeroed by the caller. */
+int vbg_bn_slots(void);
+/* per-channel sum / sum of squares over rows of x[M,C] (torch.nn.BatchNorm2d training statistics,
+ * model/ResNetFPN_ViBERTgrid.py:116-123): slot[s][0..C) += sum, slot[s][C..2C) += sumsq */
+int vbg_bn_stats(const float* x, long long M, int C, double* slots_accum, void* stream);
+/* from sums over `count` rows held in `nslots` slot rows (nslots = 1: already folded, e.g. after a SyncBN all-reduce;
+ * count_dev, if non-NULL, is a device scalar that overrides `count`: the all-reduced row count): mean, invstd;
+ * running <- (1-mom)*running + mom*{mean, unbiased var} */
+int vbg_bn_finalize(const double* stats, int nslots, double count, const double* count_dev, int C, float eps, float momentum,
+                    float* mean, float* invstd, float* running_mean, float* running_var, void* stream);
 /* y = relu?( (x-mean)*invstd*gamma + beta (+ res) ) */
 int vbg_bn_apply(const float* x, const float* res, long long M, int C, const float* mean, const float* invstd,
                  const float* gamma, const float* beta, int relu, float* y, void* stream);
-/* backward reductions: sums[0..C) += sum(g), sums[C..2C) += sum(g*xhat), g = dy*(y>0 if relu) */
+/* backward reductions: slot[s][0..C) += sum(g), slot[s][C..2C) += sum(g*xhat), g = dy*(y>0 if relu) */
 int vbg_bn_bwd_reduce(const float* dy, const float* y, const float* x, long long M, int C, const float* mean,
-                      const float* invstd, int relu, double* sums_accum, void* stream);
-/* dx = gamma*invstd*(g - sum_g/count - xhat*sum_gx/count); dres = g (optional); dgamma += sum_gx, dbeta += sum_g */
+                      const float* invstd, int relu, double* slots_accum, void* stream);
+/* dx = gamma*invstd*(g - sum_g/count - xhat*sum_gx/count) from FOLDED sums[2*C]; dres = g (optional);
+ * dgamma += sum_gx, dbeta += sum_g (optional) */
 int vbg_bn_bwd_apply(const float* dy, const float* y, const float* x, long long M, int C, const float* mean,
                      const float* invstd, const float* gamma, const double* sums, double count, const double* count_dev,
                      int relu, float* dx,
                      float* dres, float* dgamma_accum, float* dbeta_accum, void* stream);
-/* dbeta += (float)sums[0..C), dgamma += (float)sums[C..2C): the BatchNorm affine gradients from the LOCAL backward sums
-   (call before a SyncBN all-reduce of `sums`; torch.nn.SyncBatchNorm leaves weight/bias gradients per-rank for DDP to average,
+/* fold `nslots` slot rows: folded[0..2C) = sum over slots (optional output), and (optional) the BatchNorm affine
+   gradients from these LOCAL sums: dbeta += (float)folded[0..C), dgamma += (float)folded[C..2C)  (call before a SyncBN
+   all-reduce of `folded`; torch.nn.SyncBatchNorm leaves weight/bias gradients per-rank for DDP to average,
    model/ResNetFPN_ViBERTgrid.py:196-206 `norm_layer`) */
-int vbg_bn_param_grad(const double* sums, int C, float* dgamma_accum, float* dbeta_accum, void* stream);
+int vbg_bn_param_grad(const double* slots, int nslots, int C, double* folded, float* dgamma_accum, float* dbeta_accum,
+                      void* stream);
 int vbg_maxpool3x3s2_fwd(const float* x, int B, int H, int W, int C, float* y, int* argmax, void* stream);
 int vbg_maxpool3x3s2_bwd(const float* dy, const int* argmax, int B, int Ho, int Wo, int C, int H, int W,
                          float* dx_zeroed, void* stream);

@@ -419,9 +419,10 @@ def test_owner_map_random_large(ops):
 # ------------------------------------------------------------------------------------------
 # conv helpers
 # ------------------------------------------------------------------------------------------
+@pytest.mark.parametrize("shape", [(3, 64, 9, 7), (4, 64, 64, 48), (2, 512, 5, 3), (2, 16, 33, 31), (1, 256, 40, 24)])
 @pytest.mark.parametrize("relu,res", [(True, False), (True, True), (False, False)])
-def test_batchnorm(ops, relu, res):
-    B, C_, H, W = 3, 64, 9, 7
+def test_batchnorm(ops, relu, res, shape):
+    B, C_, H, W = shape
     x = rnd(B, C_, H, W, seed=80).requires_grad_(True)
     r = rnd(B, C_, H, W, seed=81).requires_grad_(True)
     gam, bet = (1 + 0.1 * rnd(C_, seed=82)).requires_grad_(True), rnd(C_, seed=83).requires_grad_(True)
@@ -436,18 +437,21 @@ def test_batchnorm(ops, relu, res):
     d = dev()
     x2 = x.detach().permute(0, 2, 3, 1).reshape(-1, C_).contiguous().to(d)
     r2 = r.detach().permute(0, 2, 3, 1).reshape(-1, C_).contiguous().to(d) if res else None
-    stats = torch.zeros(2 * C_, dtype=torch.float64, device=d)
-    ops.bn_stats(x2, stats)
+    stats = ops.bn_stats(x2)
     rmd, rvd = torch.zeros(C_, device=d), torch.ones(C_, device=d)
-    mean, invstd = ops.bn_finalize(stats, x2.shape[0], 1e-5, 0.1, rmd, rvd)
+    mean, invstd = ops.bn_finalize(stats, C_, ops.bn_slots(), x2.shape[0], 1e-5, 0.1, rmd, rvd)
+    folded = ops.bn_fold(stats, C_)
+    assert close(folded[:C_].float() / x2.shape[0], x.detach().mean((0, 2, 3)), 1e-5, 1e-6)
+    m1, i1 = ops.bn_finalize(folded, C_, 1, x2.shape[0], 1e-5, 0.1, None, None)          # the SyncBN route: folded sums, one slot
+    assert torch.equal(m1, mean) and torch.equal(i1, invstd)
     assert close(rmd, rm, 1e-5, 1e-6) and close(rvd, rv, 1e-5, 1e-6)
     yo = ops.bn_apply(x2, r2, mean, invstd, gam.detach().to(d), bet.detach().to(d), relu)
     assert close(yo, y.permute(0, 2, 3, 1).reshape(-1, C_), 1e-4, 1e-5)
     g2 = gy.permute(0, 2, 3, 1).reshape(-1, C_).contiguous().to(d)
-    sums = torch.zeros(2 * C_, dtype=torch.float64, device=d)
-    ops.bn_bwd_reduce(g2, yo, x2, mean, invstd, relu, sums)
+    slots = ops.bn_bwd_reduce(g2, yo, x2, mean, invstd, relu)
     dg, db = torch.zeros(C_, device=d), torch.zeros(C_, device=d)
-    dx, dres = ops.bn_bwd_apply(g2, yo, x2, mean, invstd, gam.detach().to(d), sums, x2.shape[0], relu, res, dg, db)
+    sums = ops.bn_param_grad(slots, C_, dg, db)
+    dx, dres = ops.bn_bwd_apply(g2, yo, x2, mean, invstd, gam.detach().to(d), sums, x2.shape[0], relu, res, None, None)
     assert close(dx, x.grad.permute(0, 2, 3, 1).reshape(-1, C_), 1e-3, 1e-5)
     assert close(dg, gam.grad, 1e-3, 1e-4) and close(db, bet.grad, 1e-3, 1e-4)
     if res:

@@ -17,30 +17,35 @@ static inline int ew_grid(long long n, int block) {
 }
 
 // ------------------------------------------------------------------------------------------
-// BatchNorm.  x is [M, C] (NHWC rows).  Block: 64 channels x 4 row lanes, BN_ROWS rows per block.
+// BatchNorm.  x is [M, C] (NHWC rows).
 // ------------------------------------------------------------------------------------------
-constexpr int BN_ROWS = 256;      // rows per block
-
 // Reduction layout shared by bn_stats / bn_bwd_reduce: a block covers up to 64 channel QUADS (float4) x RL row lanes
 // (256 threads); every load is a float4 so a wave touches >= 1 KB of contiguous NHWC rows; per-thread partials in fp32
-// over <= BN_ROWS/RL rows, cross-lane reduction through LDS in fp64, one fp64 atomic per channel per block.
+// over its rows, cross-lane reduction through LDS in fp64, one fp64 atomic per channel per block.
+// Same-address fp64 atomics serialise at ~0.1 us each on MI355X (measured: 2048 row-blocks -> 190 us for a 134 MB
+// tensor), so (a) the block sums land in one of VBG_BN_SLOTS slot rows (slot = row-block % slots; the consumers fold
+// the slots) and (b) the host picks rows-per-block so the grid has ~512 blocks (tools/bn_bench.py sweep: 5.5 TB/s on the
+// 134 MB stem map; more blocks only add atomics): <= 16 atomics per address, and small maps (layer4: 2048 rows) still
+// spread over > 100 blocks instead of 16.
+constexpr int BN_SLOTS = 32;
 template <bool BWD>
 __global__ __launch_bounds__(256) void bn_reduce_kernel(const float* __restrict__ a, const float* __restrict__ y,
                                                         const float* __restrict__ x, long long M, int C,
                                                         const float* __restrict__ mean, const float* __restrict__ invstd,
-                                                        int relu, double* out) {
+                                                        int relu, int rows_per_block, double* out) {
     __shared__ double sh[2][256][4];
     const int C4 = C >> 2;
     const int QB = min(C4, 64);                     // quads handled per block
     const int RL = 256 / QB;                        // row lanes
     const int q = threadIdx.x % QB, rl = threadIdx.x / QB;
     const int cq = blockIdx.x * 64 + q;             // channel quad
-    const long long r0 = (long long)blockIdx.y * BN_ROWS;
-    const long long r1 = min(M, r0 + BN_ROWS);
+    const long long r0 = (long long)blockIdx.y * rows_per_block;
+    const long long r1 = min(M, r0 + rows_per_block);
     float4 s = make_float4(0.f, 0.f, 0.f, 0.f), t = make_float4(0.f, 0.f, 0.f, 0.f);
-    if (cq < C4) {
+    if (cq < C4 && rl < RL) {
         float4 mu = make_float4(0.f, 0.f, 0.f, 0.f), is = mu;
         if (BWD) { mu = reinterpret_cast<const float4*>(mean)[cq]; is = reinterpret_cast<const float4*>(invstd)[cq]; }
+#pragma unroll 4
         for (long long r = r0 + rl; r < r1; r += RL) {
             const long long o = r * C4 + cq;
             float4 v = reinterpret_cast<const float4*>(a)[o];
@@ -68,22 +73,44 @@ __global__ __launch_bounds__(256) void bn_reduce_kernel(const float* __restrict_
         for (int l = 0; l < RL; ++l)
 #pragma unroll
             for (int j = 0; j < 4; ++j) { a0[j] += sh[0][l * QB + q][j]; a1[j] += sh[1][l * QB + q][j]; }
+        double* o = out + (size_t)(blockIdx.y % BN_SLOTS) * 2 * C;
 #pragma unroll
         for (int j = 0; j < 4; ++j) {
-            unsafeAtomicAdd(out + cq * 4 + j, a0[j]);
-            unsafeAtomicAdd(out + C + cq * 4 + j, a1[j]);
+            unsafeAtomicAdd(o + cq * 4 + j, a0[j]);
+            unsafeAtomicAdd(o + C + cq * 4 + j, a1[j]);
         }
     }
 }
 
-__global__ void bn_finalize_kernel(const double* __restrict__ stats, double count, const double* __restrict__ count_dev, int C,
+// rows per block so that the reduction grid has about 512 blocks (a multiple of the row-lane count, >= 2 rows per lane)
+static inline int bn_rows_per_block(long long M, int C) {
+    const int C4 = C / 4, QB = C4 < 64 ? C4 : 64, RL = 256 / QB, CG = cdiv(C4, 64);
+    long long r = cdiv(M * CG, 512);
+    if (r < 2 * RL) r = 2 * RL;
+    r = cdiv(r, RL) * RL;
+    return (int)r;
+}
+
+__device__ __forceinline__ double fold_slots(const double* __restrict__ slots, int nslots, int C, int idx) {
+    double v[4] = {0.0, 0.0, 0.0, 0.0};          // independent loads, all in flight together
+    int s = 0;
+#pragma unroll 2
+    for (; s + 3 < nslots; s += 4) {
+#pragma unroll
+        for (int j = 0; j < 4; ++j) v[j] += slots[(size_t)(s + j) * 2 * C + idx];
+    }
+    for (; s < nslots; ++s) v[0] += slots[(size_t)s * 2 * C + idx];
+    return (v[0] + v[1]) + (v[2] + v[3]);
+}
+
+__global__ void bn_finalize_kernel(const double* __restrict__ stats, int nslots, double count, const double* __restrict__ count_dev, int C,
                                    float eps, float momentum, float* mean, float* invstd, float* running_mean,
                                    float* running_var) {
     const int c = blockIdx.x * blockDim.x + threadIdx.x;
     if (c >= C) return;
     if (count_dev) count = count_dev[0];
-    const double m = stats[c] / count;
-    double var = stats[C + c] / count - m * m;
+    const double m = fold_slots(stats, nslots, C, c) / count;
+    double var = fold_slots(stats, nslots, C, C + c) / count - m * m;
     if (var < 0.0) var = 0.0;
     mean[c] = (float)m;
     invstd[c] = (float)(1.0 / sqrt(var + (double)eps));
@@ -148,11 +175,14 @@ __global__ void bn_bwd_apply_kernel(const float* __restrict__ dy, const float* _
     }
 }
 
-__global__ void bn_param_grad_kernel(const double* __restrict__ sums, int C, float* dgamma, float* dbeta) {
+__global__ void bn_param_grad_kernel(const double* __restrict__ slots, int nslots, int C, double* __restrict__ folded, float* dgamma,
+                                     float* dbeta) {
     const int c = blockIdx.x * blockDim.x + threadIdx.x;
     if (c >= C) return;
-    dbeta[c] += (float)sums[c];
-    dgamma[c] += (float)sums[C + c];
+    const double sg = fold_slots(slots, nslots, C, c), sgx = fold_slots(slots, nslots, C, C + c);
+    if (folded) { folded[c] = sg; folded[C + c] = sgx; }
+    if (dbeta) dbeta[c] += (float)sg;
+    if (dgamma) dgamma[c] += (float)sgx;
 }
 
 // ------------------------------------------------------------------------------------------
@@ -338,15 +368,19 @@ extern "C" int vbg_bn_stats(const float* x, long long M, int C, double* stats_ac
     VBG_CHECK_ARG(x && stats_accum && M >= 0 && C > 0 && C % 4 == 0 && ALIGNED16(x));
     VBG_CHECK_ARG(C / 4 <= 64 ? (256 % (C / 4) == 0) : (C / 4) % 64 == 0);
     if (M == 0) return VBG_OK;
-    VBG_LAUNCH((bn_reduce_kernel<false>), dim3(cdiv(C / 4, 64), cdiv(M, BN_ROWS)), dim3(256), 0, S_, x, nullptr, nullptr, M, C, nullptr,
-               nullptr, 0, stats_accum);
+    const int rpb = bn_rows_per_block(M, C);
+    VBG_LAUNCH((bn_reduce_kernel<false>), dim3(cdiv(C / 4, 64), cdiv(M, rpb)), dim3(256), 0, S_, x, nullptr, nullptr, M, C, nullptr,
+               nullptr, 0, rpb, stats_accum);
     VBG_LAUNCH_RET();
 }
 
-extern "C" int vbg_bn_finalize(const double* stats, double count, const double* count_dev, int C, float eps, float momentum,
+extern "C" int vbg_bn_slots(void) { return BN_SLOTS; }
+
+extern "C" int vbg_bn_finalize(const double* stats, int nslots, double count, const double* count_dev, int C, float eps, float momentum,
                                float* mean, float* invstd, float* running_mean, float* running_var, void* stream) {
-    VBG_CHECK_ARG(stats && mean && invstd && C > 0 && (count > 0 || count_dev) && ((running_mean == nullptr) == (running_var == nullptr)));
-    VBG_LAUNCH(bn_finalize_kernel, dim3(cdiv(C, 256)), dim3(256), 0, S_, stats, count, count_dev, C, eps, momentum, mean,
+    VBG_CHECK_ARG(stats && nslots >= 1 && mean && invstd && C > 0 && (count > 0 || count_dev) &&
+                  ((running_mean == nullptr) == (running_var == nullptr)));
+    VBG_LAUNCH(bn_finalize_kernel, dim3(cdiv(C, 256)), dim3(256), 0, S_, stats, nslots, count, count_dev, C, eps, momentum, mean,
                        invstd, running_mean, running_var);
     VBG_LAUNCH_RET();
 }
@@ -368,8 +402,9 @@ extern "C" int vbg_bn_bwd_reduce(const float* dy, const float* y, const float* x
     VBG_CHECK_ARG(ALIGNED16(dy) && ALIGNED16(x) && ALIGNED16(mean) && ALIGNED16(invstd) && (!relu || ALIGNED16(y)));
     VBG_CHECK_ARG(C / 4 <= 64 ? (256 % (C / 4) == 0) : (C / 4) % 64 == 0);
     if (M == 0) return VBG_OK;
-    VBG_LAUNCH((bn_reduce_kernel<true>), dim3(cdiv(C / 4, 64), cdiv(M, BN_ROWS)), dim3(256), 0, S_, dy, y, x, M, C, mean, invstd, relu,
-               sums_accum);
+    const int rpb = bn_rows_per_block(M, C);
+    VBG_LAUNCH((bn_reduce_kernel<true>), dim3(cdiv(C / 4, 64), cdiv(M, rpb)), dim3(256), 0, S_, dy, y, x, M, C, mean, invstd, relu,
+               rpb, sums_accum);
     VBG_LAUNCH_RET();
 }
 
@@ -383,13 +418,14 @@ extern "C" int vbg_bn_bwd_apply(const float* dy, const float* y, const float* x,
     if (M > 0) VBG_LAUNCH(bn_bwd_apply_kernel, dim3(ew_grid(M * (C / 4), 256)), dim3(256), 0, S_, dy, y, x, M, C / 4, C, mean, invstd,
                           gamma, sums, count, count_dev, relu, dx, dres);
     if (dgamma_accum && dbeta_accum)
-        VBG_LAUNCH(bn_param_grad_kernel, dim3(cdiv(C, 256)), dim3(256), 0, S_, sums, C, dgamma_accum, dbeta_accum);
+        VBG_LAUNCH(bn_param_grad_kernel, dim3(cdiv(C, 256)), dim3(256), 0, S_, sums, 1, C, (double*)nullptr, dgamma_accum, dbeta_accum);
     VBG_LAUNCH_RET();
 }
 
-extern "C" int vbg_bn_param_grad(const double* sums, int C, float* dgamma_accum, float* dbeta_accum, void* stream) {
-    VBG_CHECK_ARG(sums && dgamma_accum && dbeta_accum && C > 0);
-    VBG_LAUNCH(bn_param_grad_kernel, dim3(cdiv(C, 256)), dim3(256), 0, S_, sums, C, dgamma_accum, dbeta_accum);
+extern "C" int vbg_bn_param_grad(const double* slots, int nslots, int C, double* folded, float* dgamma_accum, float* dbeta_accum,
+                                 void* stream) {
+    VBG_CHECK_ARG(slots && nslots >= 1 && C > 0 && ((dgamma_accum == nullptr) == (dbeta_accum == nullptr)) && (folded || dgamma_accum));
+    VBG_LAUNCH(bn_param_grad_kernel, dim3(cdiv(C, 256)), dim3(256), 0, S_, slots, nslots, C, folded, dgamma_accum, dbeta_accum);
     VBG_LAUNCH_RET();
 }
 

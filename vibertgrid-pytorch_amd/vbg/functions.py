@@ -269,14 +269,17 @@ class ConvBnFn(torch.autograd.Function):
         z2 = z.view(-1, C)
         M = z2.shape[0]
         if training:
-            stats = torch.zeros((2 * C + 1,), device=x.device, dtype=torch.float64)
-            ops.bn_stats(z2, stats)
+            stats = ops.bn_stats(z2)
             count, count_dev = float(M), None
             if sync:
-                stats[2 * C] = M
-                dist.all_reduce(stats, group=SyncCtx.group)
-                count_dev = stats[2 * C:]                  # global row count stays on the device (no sync)
-            mean, invstd = ops.bn_finalize(stats[:2 * C], count, eps, momentum, running_mean, running_var, count_dev)
+                glob = torch.empty((2 * C + 1,), device=x.device, dtype=torch.float64)
+                ops.bn_fold(stats, C, out=glob)
+                glob[2 * C] = M
+                dist.all_reduce(glob, group=SyncCtx.group)
+                count_dev = glob[2 * C:]                   # global row count stays on the device (no sync)
+                mean, invstd = ops.bn_finalize(glob, C, 1, count, eps, momentum, running_mean, running_var, count_dev)
+            else:
+                mean, invstd = ops.bn_finalize(stats, C, ops.bn_slots(), count, eps, momentum, running_mean, running_var)
         else:
             mean, invstd, count, count_dev = running_mean, torch.rsqrt(running_var + eps), float(M), None
         r2 = None if res is None else _c(res).view(-1, C)
@@ -295,10 +298,9 @@ class ConvBnFn(torch.autograd.Function):
         dy2 = _c(dy).view(-1, C)
         z2 = z.view(-1, C)
         y2 = None if y is None else y.view(-1, C)
-        sums = torch.zeros((2 * C,), device=dy.device, dtype=torch.float64)
-        ops.bn_bwd_reduce(dy2, y2, z2, mean, invstd, relu, sums)
+        slots = ops.bn_bwd_reduce(dy2, y2, z2, mean, invstd, relu)
         dgamma, dbeta, sunk = _affine_dest(*ctx.affine)           # from the LOCAL sums: the gradient exchange averages them
-        ops.bn_param_grad(sums, dgamma, dbeta)
+        sums = ops.bn_param_grad(slots, C, dgamma, dbeta)
         dgamma, dbeta = _affine_done(*ctx.affine, dgamma, dbeta, sunk)
         if sync:
             dist.all_reduce(sums, group=SyncCtx.group)

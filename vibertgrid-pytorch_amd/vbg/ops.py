@@ -377,16 +377,36 @@ def label_raster(owner, seg_class):
 # ----------------------------------------------------------------------------------------------
 # conv helpers
 # ----------------------------------------------------------------------------------------------
-def bn_stats(x2d, stats):
+_BN_SLOTS = [0]
+
+
+def bn_slots():
+    if not _BN_SLOTS[0]:
+        _BN_SLOTS[0] = int(lib.vbg_bn_slots())
+    return _BN_SLOTS[0]
+
+
+def bn_stats(x2d, extra=0):
+    """-> zero-initialised-then-accumulated slot rows [slots*2C (+extra)] fp64 (per-channel sum, sum of squares)"""
     M, C_ = x2d.shape
+    stats = torch.zeros((bn_slots() * 2 * C_ + extra,), device=x2d.device, dtype=torch.float64)
     check(lib.vbg_bn_stats(P(x2d), M, C_, P(stats), _stream()), "vbg_bn_stats")
+    return stats
 
 
-def bn_finalize(stats, count, eps, momentum, running_mean, running_var, count_dev=None):
-    C_ = stats.numel() // 2
+def bn_fold(slots, C_, out=None):
+    """sum the slot rows -> [2C] fp64"""
+    if out is None:
+        out = torch.empty((2 * C_,), device=slots.device, dtype=torch.float64)
+    check(lib.vbg_bn_param_grad(P(slots), bn_slots(), C_, P(out), None, None, _stream()), "vbg_bn_param_grad")
+    return out
+
+
+def bn_finalize(stats, C_, nslots, count, eps, momentum, running_mean, running_var, count_dev=None):
     mean = torch.empty((C_,), device=stats.device, dtype=f32)
     invstd = torch.empty_like(mean)
-    check(lib.vbg_bn_finalize(P(stats), float(count), P(count_dev), C_, eps, momentum, P(mean), P(invstd), P(running_mean), P(running_var), _stream()), "vbg_bn_finalize")
+    check(lib.vbg_bn_finalize(P(stats), int(nslots), float(count), P(count_dev), C_, eps, momentum, P(mean), P(invstd), P(running_mean),
+                              P(running_var), _stream()), "vbg_bn_finalize")
     return mean, invstd
 
 
@@ -398,9 +418,12 @@ def bn_apply(x2d, res2d, mean, invstd, gamma, beta, relu, out=None):
     return out
 
 
-def bn_bwd_reduce(dy, y, x, mean, invstd, relu, sums):
+def bn_bwd_reduce(dy, y, x, mean, invstd, relu):
+    """-> slot rows [slots*2C] fp64 of (sum g, sum g*xhat)"""
     M, C_ = x.shape
+    sums = torch.zeros((bn_slots() * 2 * C_,), device=x.device, dtype=torch.float64)
     check(lib.vbg_bn_bwd_reduce(P(dy), P(y), P(x), M, C_, P(mean), P(invstd), int(relu), P(sums), _stream()), "vbg_bn_bwd_reduce")
+    return sums
 
 
 def bn_bwd_apply(dy, y, x, mean, invstd, gamma, sums, count, relu, want_dres, dgamma, dbeta, count_dev=None):
@@ -412,8 +435,11 @@ def bn_bwd_apply(dy, y, x, mean, invstd, gamma, sums, count, relu, want_dres, dg
     return dx, dres
 
 
-def bn_param_grad(sums, dgamma, dbeta):
-    check(lib.vbg_bn_param_grad(P(sums), dgamma.numel(), P(dgamma), P(dbeta), _stream()), "vbg_bn_param_grad")
+def bn_param_grad(slots, C_, dgamma, dbeta):
+    """fold the slot rows (-> [2C] fp64, returned) and accumulate the affine gradients from them"""
+    folded = torch.empty((2 * C_,), device=slots.device, dtype=torch.float64)
+    check(lib.vbg_bn_param_grad(P(slots), bn_slots(), C_, P(folded), P(dgamma), P(dbeta), _stream()), "vbg_bn_param_grad")
+    return folded
 
 
 def maxpool_fwd(x):
