@@ -187,6 +187,10 @@ int vbg_bn_param_grad(const double* slots, int nslots, int C, double* folded, fl
 int vbg_maxpool3x3s2_fwd(const float* x, int B, int H, int W, int C, float* y, int* argmax, void* stream);
 int vbg_maxpool3x3s2_bwd(const float* dy, const int* argmax, int B, int Ho, int Wo, int C, int H, int W,
                          float* dx_zeroed, void* stream);
+/* nn.AvgPool2d(2, 2) of the ResNet-D projection shortcut (model/ResNetFPN_ViBERTgrid.py:222-236): x [B,H,W,C] ->
+ * y [B,H/2,W/2,C] (floor); bwd: dx [B,H,W,C] = dy/4 over each 2x2 window, 0 on a dropped trailing row / column */
+int vbg_avgpool2_fwd(const float* x, int B, int H, int W, int C, float* y, void* stream);
+int vbg_avgpool2_bwd(const float* dy, int B, int H, int W, int C, float* dx, void* stream);
 /* y[b,y,x,:] = lo[b,y/2,x/2,:] + skip[b,y,x,:]   (nearest x2 upsample + add) */
 int vbg_upsample2_add(const float* lo, const float* skip, int B, int H, int W, int C, float* y, void* stream);
 /* lo[b,y,x,:] (+)= sum of the f x f block of hi   (backward of nearest upsampling by f) */

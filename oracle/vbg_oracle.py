@@ -344,14 +344,18 @@ def _bn(sd, name, x, train, momentum=0.1, eps=1e-5):
 
 
 def _basic_block(sd, p, x, train, stride, names):
-    """BasicBlock (:106-184) / torchvision BasicBlock.  `names` maps logical -> key suffix."""
+    """BasicBlock (:106-184) / DBlock (:187-269) / torchvision BasicBlock.  `names` maps logical -> key suffix;
+    the ResNet-D block's projection shortcut is AvgPool2d(2,2) -> 1x1 conv (stride 1) -> BN (:222-236)."""
     c1, b1, c2, b2, sc_conv, sc_bn = names
     y = F.conv2d(x, sd[p + c1 + ".weight"], None, stride, 1)
     y = F.relu(_bn(sd, p + b1, y, train))
     y = F.conv2d(y, sd[p + c2 + ".weight"], None, 1, 1)
     y = _bn(sd, p + b2, y, train)
     if (p + sc_conv + ".weight") in sd:
-        s = F.conv2d(x, sd[p + sc_conv + ".weight"], None, stride, 0)
+        if names is _OWN_D:
+            s = F.conv2d(F.avg_pool2d(x, 2, 2), sd[p + sc_conv + ".weight"], None, 1, 0)
+        else:
+            s = F.conv2d(x, sd[p + sc_conv + ".weight"], None, stride, 0)
         s = _bn(sd, p + sc_bn, s, train)
     else:
         s = x
@@ -359,11 +363,13 @@ def _basic_block(sd, p, x, train, stride, names):
 
 
 _OWN = ("conv_1", "bn_1", "conv_2", "bn_2", "conv_shortcut.0", "conv_shortcut.1")
+_OWN_D = ("conv_1", "bn_1", "conv_2", "bn_2", "conv_shortcut.1", "conv_shortcut.2")      # Sequential(AvgPool2d, Conv2d, BatchNorm2d)
 _TV = ("conv1", "bn1", "conv2", "bn2", "downsample.0", "downsample.1")
 
 
 def backbone_forward(sd, x: Tensor, grid: Tensor, kind: str, train: bool, prefix="backbone.") -> Tensor:
-    """P_fuse [B,256,H/4,W/4].  kind in resnet_{18,34}_fpn[_pretrained]."""
+    """P_fuse [B,256,H/4,W/4].  kind in resnet_{18,34}_fpn[_pretrained] | resnet_{18,34}_D_fpn."""
+    _OWN = _OWN_D if "_D_" in kind else globals()["_OWN"]
     sizes = [2, 2, 2, 2] if "18" in kind else [3, 4, 6, 3]
     p = prefix
     if kind.endswith("_pretrained"):
@@ -771,11 +777,13 @@ def backbone_shapes(kind: str, grid_channel: int = 768, prefix="backbone.") -> D
         s[p + "conv_1.0.weight"] = (64, 3, 7, 7)
         _bn_shapes(s, p + "conv_1.1", 64)
 
+        sc = (1, 2) if "_D_" in kind else (0, 1)          # DBlock's shortcut Sequential starts with a parameter-free AvgPool2d
+
         def block(b, cin, c, down):
             s[b + "conv_1.weight"] = (c, cin if down else c, 3, 3)
             if down:
-                s[b + "conv_shortcut.0.weight"] = (c, cin, 1, 1)
-                _bn_shapes(s, b + "conv_shortcut.1", c)
+                s[b + f"conv_shortcut.{sc[0]}.weight"] = (c, cin, 1, 1)
+                _bn_shapes(s, b + f"conv_shortcut.{sc[1]}", c)
             _bn_shapes(s, b + "bn_1", c)
             s[b + "conv_2.weight"] = (c, c, 3, 3)
             _bn_shapes(s, b + "bn_2", c)

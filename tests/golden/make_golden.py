@@ -369,6 +369,27 @@ def gen_backbone(R):
     npz("backbone.npz", **out)
 
 
+def gen_backbone_d(R):
+    """ResNet-D variant (DBlock: avg-pool shortcut, model/ResNetFPN_ViBERTgrid.py:187-269, factory :692-711)"""
+    out = {}
+    g = torch.Generator().manual_seed(21)
+    x = torch.randn(2, 3, 64, 96, generator=g)
+    grid = torch.randn(2, 768, 8, 12, generator=g) * (torch.rand(2, 1, 8, 12, generator=g) > 0.5)      # = backbone.npz's x / grid
+    kind = "resnet_18_D_fpn"
+    net = R.resnet_18_D_fpn(grid_channel=768)
+    load_synth(net)
+    out[kind + "_keys"] = np.array(sorted(net.state_dict().keys()))
+    net.eval()
+    with torch.no_grad():
+        out[kind + "_eval"] = net(x, grid)
+    net.train()
+    with torch.no_grad():
+        out[kind + "_train"] = net(x, grid)
+    out[kind + "_rm"] = net.state_dict()["conv_4_x.0.conv_shortcut.2.running_mean"]
+    out[kind + "_rv"] = net.state_dict()["conv_4_x.0.conv_shortcut.2.running_var"]
+    npz("backbone_d.npz", **out)
+
+
 def gen_e2e(V, tmp):
     out = {}
     tokenizer = BertTokenizer(os.path.join(tmp, "bert-base-uncased", "vocab.txt"))
@@ -457,7 +478,7 @@ def main():
     import pipeline.custom_loss as L
     import pipeline.transform as T
 
-    which = sys.argv[1:] or ["transform", "windows", "aggregate", "scatter", "losses", "labels", "bert", "backbone", "e2e"]
+    which = sys.argv[1:] or ["transform", "windows", "aggregate", "scatter", "losses", "labels", "bert", "backbone", "backbone_d", "e2e"]
     if "transform" in which:
         gen_transform(T)
     if "windows" in which:
@@ -474,6 +495,8 @@ def main():
         gen_bert(tmp)
     if "backbone" in which:
         gen_backbone(R)
+    if "backbone_d" in which:
+        gen_backbone_d(R)
     if "e2e" in which:
         gen_e2e(V, tmp)
 

@@ -149,6 +149,22 @@ def test_backbone(golden, kind):
     assert torch.allclose(sd[key + ".running_var"], T(g[kind + "_rv"]), rtol=1e-5, atol=1e-6)
 
 
+def test_backbone_resnet_d(golden):
+    """a6 DBlock variant (avg-pool projection shortcut): oracle vs the reference's resnet_18_D_fpn, incl. the key inventory"""
+    g, gi = golden("backbone_d.npz"), golden("backbone.npz")
+    kind = "resnet_18_D_fpn"
+    shapes = O.backbone_shapes(kind, 768, prefix="")
+    ref_keys = set(str(k) for k in g[kind + "_keys"])
+    assert ref_keys == set(shapes.keys())
+    sd = O.synth_state_dict(shapes)
+    x, grid = T(gi["x"]), T(gi["grid"])
+    with torch.no_grad():
+        assert torch.allclose(O.backbone_forward(sd, x, grid, kind, False, prefix=""), T(g[kind + "_eval"]), rtol=1e-4, atol=1e-4)
+        assert torch.allclose(O.backbone_forward(sd, x, grid, kind, True, prefix=""), T(g[kind + "_train"]), rtol=1e-3, atol=1e-3)
+    assert torch.allclose(sd["conv_4_x.0.conv_shortcut.2.running_mean"], T(g[kind + "_rm"]), rtol=1e-5, atol=1e-6)
+    assert torch.allclose(sd["conv_4_x.0.conv_shortcut.2.running_var"], T(g[kind + "_rv"]), rtol=1e-5, atol=1e-6)
+
+
 def _e2e_inputs(g):
     imgs = [T(g[f"img{b}"]) for b in range(2)]
     coors = [T(g[f"coor{b}"]) for b in range(2)]

@@ -239,6 +239,43 @@ __global__ void upsample2_add_kernel(const float* __restrict__ lo, const float* 
     }
 }
 
+// AvgPool2d(2, 2) of the ResNet-D projection shortcut (model/ResNetFPN_ViBERTgrid.py:224): floor output size, odd trailing
+// row / column dropped; BWD spreads dy/4 over the 2x2 window (zero for a dropped trailing row / column)
+template <bool BWD>
+__global__ void avgpool2_kernel(const float* __restrict__ src, int B, int H, int W, int C4, float* __restrict__ dst) {
+    const int Ho = H / 2, Wo = W / 2;
+    const long long total = (long long)B * (BWD ? H : Ho) * (BWD ? W : Wo) * C4;
+    const long long stride = (long long)gridDim.x * blockDim.x;
+    for (long long i = (long long)blockIdx.x * blockDim.x + threadIdx.x; i < total; i += stride) {
+        const int c4 = (int)(i % C4);
+        long long t = i / C4;
+        if (!BWD) {
+            const int x = (int)(t % Wo); t /= Wo;
+            const int y = (int)(t % Ho);
+            const int b = (int)(t / Ho);
+            float4 acc = make_float4(0.f, 0.f, 0.f, 0.f);
+#pragma unroll
+            for (int dy = 0; dy < 2; ++dy)
+#pragma unroll
+                for (int dx = 0; dx < 2; ++dx) {
+                    const float4 v = reinterpret_cast<const float4*>(src)[(((long long)b * H + 2 * y + dy) * W + 2 * x + dx) * C4 + c4];
+                    acc.x += v.x; acc.y += v.y; acc.z += v.z; acc.w += v.w;
+                }
+            reinterpret_cast<float4*>(dst)[i] = make_float4(acc.x * 0.25f, acc.y * 0.25f, acc.z * 0.25f, acc.w * 0.25f);
+        } else {
+            const int x = (int)(t % W); t /= W;
+            const int y = (int)(t % H);
+            const int b = (int)(t / H);
+            float4 g = make_float4(0.f, 0.f, 0.f, 0.f);
+            if ((y >> 1) < Ho && (x >> 1) < Wo) {
+                g = reinterpret_cast<const float4*>(src)[(((long long)b * Ho + (y >> 1)) * Wo + (x >> 1)) * C4 + c4];
+                g.x *= 0.25f; g.y *= 0.25f; g.z *= 0.25f; g.w *= 0.25f;
+            }
+            reinterpret_cast<float4*>(dst)[i] = g;
+        }
+    }
+}
+
 __global__ void sumpool_kernel(const float* __restrict__ hi, int B, int H, int W, int C4, int f, float* lo, int accumulate) {
     const int Hl = H / f, Wl = W / f;
     const long long total = (long long)B * Hl * Wl * C4;
@@ -453,6 +490,22 @@ extern "C" int vbg_upsample2_add(const float* lo, const float* skip, int B, int 
     const long long total = (long long)B * H * W * (C / 4);
     if (total == 0) return VBG_OK;
     VBG_LAUNCH(upsample2_add_kernel, dim3(ew_grid(total, 256)), dim3(256), 0, S_, lo, skip, B, H, W, C / 4, y);
+    VBG_LAUNCH_RET();
+}
+
+extern "C" int vbg_avgpool2_fwd(const float* x, int B, int H, int W, int C, float* y, void* stream) {
+    VBG_CHECK_ARG(x && y && B >= 0 && H >= 2 && W >= 2 && C > 0 && C % 4 == 0 && ALIGNED16(x) && ALIGNED16(y));
+    const long long total = (long long)B * (H / 2) * (W / 2) * (C / 4);
+    if (total == 0) return VBG_OK;
+    VBG_LAUNCH((avgpool2_kernel<false>), dim3(ew_grid(total, 256)), dim3(256), 0, S_, x, B, H, W, C / 4, y);
+    VBG_LAUNCH_RET();
+}
+
+extern "C" int vbg_avgpool2_bwd(const float* dy, int B, int H, int W, int C, float* dx, void* stream) {
+    VBG_CHECK_ARG(dy && dx && B >= 0 && H >= 2 && W >= 2 && C > 0 && C % 4 == 0 && ALIGNED16(dy) && ALIGNED16(dx));
+    const long long total = (long long)B * H * W * (C / 4);
+    if (total == 0) return VBG_OK;
+    VBG_LAUNCH((avgpool2_kernel<true>), dim3(ew_grid(total, 256)), dim3(256), 0, S_, dy, B, H, W, C / 4, dx);
     VBG_LAUNCH_RET();
 }
 

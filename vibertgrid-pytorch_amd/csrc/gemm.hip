@@ -611,7 +611,9 @@ static void pick_tile(const vbg_gemm_desc& d, int groups, int maxM, int maxN, in
         const long t128 = (long)cdiv(maxM, 128) * cdiv(maxN, 128) * groups * d.splitk;
         tile = (maxN >= 256 && t128 >= 1536 && d.a_kind != VBG_OP_DENSE_R) ? 128128 : 64064;
     }
-    if (bk == 0) bk = 32;
+    // short reductions are latency / output bound: the 20 KB BK=16 tiles double the resident blocks per CU (measured on the
+    // attention score GEMMs, K = 64: 49 -> 63 TF/s)
+    if (bk == 0) bk = (!d.grp && d.K <= 128) ? 16 : 32;
 }
 
 template <int AK, int BKD>

@@ -58,6 +58,25 @@ class BasicBlock(nn.Module):
         return conv_bn(y, self.conv_2, self.bn_2, s, True)
 
 
+class DBlock(BasicBlock):
+    """ResNet-D flavour of the basic block (reference :187-269): the projection shortcut is
+    AvgPool2d(2, 2) -> 1x1 conv (stride 1) -> BN, so `conv_shortcut` holds (pool, conv, bn) = keys .1 / .2"""
+
+    def __init__(self, in_channel: int, out_channel: int, downsample: bool = False) -> None:
+        super().__init__(in_channel, out_channel, downsample)
+        if downsample:
+            self.conv_shortcut = nn.Sequential(nn.AvgPool2d(kernel_size=2, stride=2),
+                                               nn.Conv2d(in_channel, out_channel, 1, 1, 0, bias=False), nn.BatchNorm2d(out_channel))
+
+    def forward(self, x):
+        y = conv_bn(x, self.conv_1, self.bn_1, None, True)
+        if isinstance(self.conv_shortcut, nn.Identity):
+            s = x
+        else:
+            s = conv_bn(Fn.AvgPool2Fn.apply(x), self.conv_shortcut[1], self.conv_shortcut[2], None, False)
+        return conv_bn(y, self.conv_2, self.bn_2, s, True)
+
+
 class EarlyFusionLayer(nn.Module):
     def __init__(self, block, in_channel: int, out_channel: int, block_num: int, grid_channel: int, downsample=True) -> None:
         super().__init__()
@@ -214,8 +233,8 @@ def resnet_34_fpn(grid_channel: int, pretrained: bool = False) -> nn.Module:
 
 
 def resnet_18_D_fpn(grid_channel: int) -> nn.Module:
-    raise NotImplementedError("ResNet-D (avg-pool shortcut) backbones are not built yet; use resnet_18_fpn[_pretrained]")
+    return ResNetFPN_ViBERTgrid(DBlock, [2, 2, 2, 2], grid_channel)
 
 
 def resnet_34_D_fpn(grid_channel: int) -> nn.Module:
-    raise NotImplementedError("ResNet-D (avg-pool shortcut) backbones are not built yet; use resnet_34_fpn[_pretrained]")
+    return ResNetFPN_ViBERTgrid(DBlock, [3, 4, 6, 3], grid_channel)

@@ -71,6 +71,8 @@ SIGNATURES = {
     "vbg_bn_param_grad": (c_int, [c_vp, c_int, c_int, c_vp, c_vp, c_vp, c_vp]),
     "vbg_maxpool3x3s2_fwd": (c_int, [c_vp, c_int, c_int, c_int, c_int, c_vp, c_vp, c_vp]),
     "vbg_maxpool3x3s2_bwd": (c_int, [c_vp, c_vp, c_int, c_int, c_int, c_int, c_int, c_int, c_vp, c_vp]),
+    "vbg_avgpool2_fwd": (c_int, [c_vp, c_int, c_int, c_int, c_int, c_vp, c_vp]),
+    "vbg_avgpool2_bwd": (c_int, [c_vp, c_int, c_int, c_int, c_int, c_vp, c_vp]),
     "vbg_upsample2_add": (c_int, [c_vp, c_vp, c_int, c_int, c_int, c_int, c_vp, c_vp]),
     "vbg_sumpool": (c_int, [c_vp, c_int, c_int, c_int, c_int, c_int, c_vp, c_int, c_vp]),
     "vbg_nchw_to_nhwc": (c_int, [c_vp, c_int, c_int, c_int, c_vp, c_vp]),

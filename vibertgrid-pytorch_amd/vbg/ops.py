@@ -458,6 +458,20 @@ def maxpool_bwd(dy, am, H, W):
     return dx
 
 
+def avgpool2_fwd(x):
+    B, H, W, C_ = x.shape
+    y = torch.empty((B, H // 2, W // 2, C_), device=x.device, dtype=f32)
+    check(lib.vbg_avgpool2_fwd(P(x), B, H, W, C_, P(y), _stream()), "vbg_avgpool2_fwd")
+    return y
+
+
+def avgpool2_bwd(dy, H, W):
+    B, _, _, C_ = dy.shape
+    dx = torch.empty((B, H, W, C_), device=dy.device, dtype=f32)
+    check(lib.vbg_avgpool2_bwd(P(dy), B, H, W, C_, P(dx), _stream()), "vbg_avgpool2_bwd")
+    return dx
+
+
 def upsample2_add(lo, skip):
     B, H, W, C_ = skip.shape
     y = torch.empty_like(skip)
