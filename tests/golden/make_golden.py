@@ -390,6 +390,64 @@ def gen_backbone_d(R):
     npz("backbone_d.npz", **out)
 
 
+def make_roberta_dir(top, name, layers, vocab):
+    """local stand-in for `roberta-base` (RobertaConfig: 514 positions, 1 token type, pad id 1, LN eps 1e-5)"""
+    import json
+    from transformers import RobertaConfig
+    d = os.path.join(top, name)
+    os.makedirs(d, exist_ok=True)
+    RobertaConfig(vocab_size=vocab, max_position_embeddings=514, type_vocab_size=1, num_hidden_layers=layers, hidden_dropout_prob=0.0,
+                  attention_probs_dropout_prob=0.0, layer_norm_eps=1e-5).save_pretrained(d)
+    voc = {"<s>": 0, "<pad>": 1, "</s>": 2, "<unk>": 3}
+    for i in range(4, vocab):
+        voc[f"t{i}"] = i
+    json.dump(voc, open(os.path.join(d, "vocab.json"), "w"))
+    open(os.path.join(d, "merges.txt"), "w").write("#version: 0.2\n")
+    return d
+
+
+def gen_e2e_roberta(V, tmp):
+    """cfg3 / cfg5 flavour of the whole model: RobertaModel (RoBERTa position ids, one token type) + 4 classes, resnet_18_fpn;
+    same documents as e2e.npz but with a PAD hole inside document 1 and class labels < 4."""
+    from transformers import RobertaTokenizer
+    d = make_roberta_dir(tmp, "roberta-base", layers=2, vocab=1300)
+    tokenizer = RobertaTokenizer(os.path.join(d, "vocab.json"), os.path.join(d, "merges.txt"))
+    net = V.ViBERTgridNet(num_classes=4, image_mean=[0.9248, 0.9224, 0.9215], image_std=[0.1532, 0.1545, 0.1536],
+                          image_min_size=[96], image_max_size=128, test_image_min_size=96,
+                          bert_model="roberta-base", tokenizer=tokenizer, backbone="resnet_18_fpn", grid_mode="mean",
+                          loss_weights=None, num_hard_positive_main_1=4, num_hard_negative_main_1=4,
+                          num_hard_positive_main_2=6, num_hard_negative_main_2=6,
+                          loss_aux_sample_list=[64, 128, 64], num_hard_positive_aux=64, num_hard_negative_aux=64,
+                          loss_control_lambda=1, add_pos_neg=True, classifier_mode="simp", ohem_random=True,
+                          layer_mode="single", work_mode="eval")
+    load_synth(net)
+    e = np.load(os.path.join(HERE, "e2e.npz"))
+    B = 2
+    imgs = tuple(torch.from_numpy(e[f"img{b}"]) for b in range(B))
+    coors = tuple(torch.from_numpy(e[f"coor{b}"]) for b in range(B))
+    segs = tuple(torch.from_numpy(e[f"seg{b}"]) for b in range(B))
+    classes = tuple(torch.from_numpy(e[f"class{b}"]) % 4 for b in range(B))
+    corpus, mask = torch.from_numpy(e["corpus"]), torch.from_numpy(e["mask"])
+    out = {"classes0": classes[0], "classes1": classes[1]}
+    net.eval()
+    random.seed(7)
+    with torch.no_grad():
+        loss, pm, ps, gt, pred = net(imgs, segs, classes, coors, corpus, mask)
+    out.update(eval_loss=loss, gt=gt, pred=pred, pred_ss=ps[:, :, ::8, ::8])
+    net.train()
+    random.seed(7)
+    loss = net(imgs, segs, classes, coors, corpus, mask)
+    loss.backward()
+    out["train_loss"] = loss
+    gn = {k: (0.0 if p.grad is None else float(p.grad.double().norm())) for k, p in net.named_parameters()
+          if not k.startswith("BERTgrid_generator.")}
+    out["gradnorm_keys"] = np.array(sorted(gn.keys()))
+    out["gradnorm_vals"] = np.array([gn[k] for k in sorted(gn.keys())])
+    out["keys"] = np.array(list(shapes_of(net).keys()))
+    out["key_shapes"] = np.array([str(v) for v in shapes_of(net).values()])
+    npz("e2e_roberta.npz", **out)
+
+
 def gen_e2e(V, tmp):
     out = {}
     tokenizer = BertTokenizer(os.path.join(tmp, "bert-base-uncased", "vocab.txt"))
@@ -478,7 +536,7 @@ def main():
     import pipeline.custom_loss as L
     import pipeline.transform as T
 
-    which = sys.argv[1:] or ["transform", "windows", "aggregate", "scatter", "losses", "labels", "bert", "backbone", "backbone_d", "e2e"]
+    which = sys.argv[1:] or ["transform", "windows", "aggregate", "scatter", "losses", "labels", "bert", "backbone", "backbone_d", "e2e", "e2e_roberta"]
     if "transform" in which:
         gen_transform(T)
     if "windows" in which:
@@ -499,6 +557,8 @@ def main():
         gen_backbone_d(R)
     if "e2e" in which:
         gen_e2e(V, tmp)
+    if "e2e_roberta" in which:
+        gen_e2e_roberta(V, tmp)
 
 
 if __name__ == "__main__":

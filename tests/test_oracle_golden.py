@@ -180,6 +180,50 @@ def e2e_cfg(backbone):
                     num_hard_negative_aux=64, ohem_random=True, bert=O.BertCfg(layers=2, dropout=0.0))
 
 
+def roberta_cfg():
+    return O.NetCfg(num_classes=4, image_min_size=(96,), image_max_size=128, test_image_min_size=96, backbone="resnet_18_fpn",
+                    num_hard_positive_main_1=4, num_hard_negative_main_1=4, num_hard_positive_main_2=6,
+                    num_hard_negative_main_2=6, loss_aux_sample_list=(64, 128, 64), num_hard_positive_aux=64,
+                    num_hard_negative_aux=64, ohem_random=True, bert=O.BertCfg(layers=2, dropout=0.0, roberta=True, ln_eps=1e-5))
+
+
+def roberta_inputs(golden):
+    g, e = golden("e2e_roberta.npz"), golden("e2e.npz")
+    imgs, segs, _, coors, corpus, mask = _e2e_inputs(e)
+    return g, (imgs, segs, [T(g["classes0"]), T(g["classes1"])], coors, corpus, mask)
+
+
+def test_e2e_roberta(golden):
+    """cfg3 / cfg5 flavour: RobertaModel container (514 positions, padding_idx position rule, 1 token type, LN eps 1e-5) and
+    4 classes, against the reference run of tests/golden/make_golden.py::gen_e2e_roberta"""
+    g, batch = roberta_inputs(golden)
+    cfg = roberta_cfg()
+    shapes = O.state_shapes(cfg, vocab=1300, max_pos=514, type_vocab=1)
+    ref_shapes = {str(k): str(v) for k, v in zip(g["keys"], g["key_shapes"])}
+    extra_ok = lambda k: k.endswith("position_ids") or k.endswith("token_type_ids")
+    assert {k for k in set(ref_shapes) - set(shapes) if not extra_ok(k)} == set()
+    assert set(shapes) - set(ref_shapes) == set()
+    for k, v in shapes.items():
+        assert ref_shapes[k] == str(tuple(v)), (k, ref_shapes[k], v)
+    sd = O.synth_state_dict(shapes)
+    random.seed(7)
+    with torch.no_grad():
+        loss, pm, ps, gt, pred = O.forward({k: v.clone() for k, v in sd.items()}, cfg, *batch, training=False)
+    assert np.array_equal(gt.numpy(), g["gt"])
+    assert torch.allclose(pred, T(g["pred"]), rtol=1e-4, atol=1e-5)
+    assert torch.allclose(ps[:, :, ::8, ::8], T(g["pred_ss"]), rtol=1e-3, atol=1e-4)
+    assert torch.allclose(loss, T(g["eval_loss"]), rtol=1e-4)
+    sdg = {k: (v.clone().requires_grad_(True) if v.is_floating_point() and "running" not in k else v.clone()) for k, v in sd.items()}
+    random.seed(7)
+    out = O.forward(sdg, cfg, *batch, training=True)
+    out[0].backward()
+    assert torch.allclose(out[0].detach(), T(g["train_loss"]), rtol=1e-4)
+    for k, v in zip([str(k) for k in g["gradnorm_keys"]], g["gradnorm_vals"]):
+        gr = sdg[k].grad
+        n = 0.0 if gr is None else float(gr.double().norm())
+        assert abs(n - v) <= 2e-3 * max(abs(v), 1e-3), (k, n, v)
+
+
 @pytest.mark.parametrize("tag,backbone", [("r18", "resnet_18_fpn"), ("r34p", "resnet_34_fpn_pretrained")])
 def test_e2e(golden, tag, backbone):
     g = golden("e2e.npz")
