@@ -198,6 +198,13 @@ def main():
         dist.all_reduce(t, op=dist.ReduceOp.MAX)
         dt = float(t.item())
     launches, flops, ms = prof.summary()
+    # HBM-side bytes per launch of the same kernel: rocprofv3 PMC passes of this command (cannot be collected in-process),
+    # summarised in profiles/ by the round that produced them; null when the file is absent
+    traffic = None
+    tf = os.path.join(os.path.dirname(os.path.abspath(__file__)), "profiles", "r01_gemm_hbm_traffic.json")
+    if os.path.exists(tf):
+        with open(tf) as fh:
+            traffic = round(float(json.load(fh)["bytes_per_launch"]), 0)
 
     if rank == 0:
         docs = B * world * args.steps
@@ -213,9 +220,9 @@ def main():
                        "global_batch": B * world, "seq_len": 512, "parallelism": f"dp{world}" + ("+syncbn" if sync_bn else ""),
                        "last_loss": round(float(last), 4)},
             "step_mfma_frac": round(value / world * F_STEP_GF / 1e3 / PEAK_F32_TF, 4),
-            "roofline": {"bound": "mfma", "kernel": "vbg::gemm_kernel<64,64,32,DENSE_K,DENSE_K,true> (fp32 MFMA NT GEMM: BERT linears, 1x1 convs)",
+            "roofline": {"bound": "mfma", "kernel": "vbg::gemm_kernel<*,*,*,DENSE_K,DENSE_K> (fp32 MFMA NT GEMM: BERT linears, 1x1 convs; every ungrouped launch)",
                          "achieved": round(ach, 2), "peak": PEAK_F32_TF, "unit": "TFLOP/s", "frac": round(ach / PEAK_F32_TF, 4),
-                         "traffic": None, "launches": launches, "avg_us": round(1e3 * ms / max(launches, 1), 2)},
+                         "traffic": traffic, "launches": launches, "avg_us": round(1e3 * ms / max(launches, 1), 2)},
         }
         if world == 1 and not args.no_cpu_baseline:
             out["cpu_baseline"] = cpu_baseline(min(os.cpu_count() or 1, 16))   # >16 threads only adds oversubscription for these small ops

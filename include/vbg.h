@@ -71,6 +71,13 @@ typedef struct vbg_gemm_desc {
 } vbg_gemm_desc;
 
 int vbg_gemm(const vbg_gemm_desc* desc, void* stream);
+/* Measurement hooks (bench.py `roofline`; no reference counterpart): the same launch with the dispatch's own begin / end
+ * timestamps delivered to two events (hipExtLaunchKernel start / stop events: no barrier packets around the kernel, the figure
+ * rocprofv3's kernel trace reports), plus create / destroy / elapsed for those events (hipEvent_t passed as void*). */
+int vbg_gemm_timed(const vbg_gemm_desc* desc, void* stream, void* start_event, void* stop_event);
+int vbg_timer_create(void** event);
+int vbg_timer_destroy(void* event);
+int vbg_timer_elapsed_ms(void* start_event, void* stop_event, float* ms);
 
 /* column sums: out[n] (+)= sum_m x[m*ld + n]   (bias gradients) */
 int vbg_colsum(const float* x, long long ld, int M, int N, float* out, int accumulate, void* stream);

@@ -21,6 +21,7 @@
 //  * fragments of k-group g+1 are fetched while the MFMAs of group g issue (two register sets).
 #include "vbg_common.h"
 #include <type_traits>
+#include <hip/hip_ext.h>
 #include "../../include/vbg.h"
 
 namespace vbg {
@@ -612,10 +613,16 @@ __global__ __launch_bounds__(NT) void gemm_kernel(const vbg_gemm_desc p) {
     }
 }
 
+// optional per-dispatch timing (vbg_gemm_timed): the start / stop events receive the dispatch packet's own begin / end
+// timestamps -- what rocprofv3's kernel trace reads -- with no barrier packets around the kernel
+struct launch_timer { hipEvent_t start = nullptr, stop = nullptr; };
+
 template <int BM, int BN, int BK, int NT, int AK, int BKD, bool VEC>
-static void launch_one(const vbg_gemm_desc& d, int groups, int maxM, int maxN, hipStream_t s) {
+static void launch_one(const vbg_gemm_desc& d, int groups, int maxM, int maxN, hipStream_t s, const launch_timer& t) {
     dim3 g(cdiv(maxM, BM), cdiv(maxN, BN), groups * d.splitk);
-    VBG_LAUNCH((gemm_kernel<BM, BN, BK, NT, AK, BKD, VEC>), g, dim3(NT), 0, s, d);
+    (void)hipGetLastError();
+    if (t.start && t.stop) hipExtLaunchKernelGGL((gemm_kernel<BM, BN, BK, NT, AK, BKD, VEC>), g, dim3(NT), 0, s, t.start, t.stop, 0, d);
+    else hipLaunchKernelGGL((gemm_kernel<BM, BN, BK, NT, AK, BKD, VEC>), g, dim3(NT), 0, s, d);
 }
 
 // tile code: BM*1000+BN (128128, 128064, 64064); 0 = heuristic.  (A barrier-free one-wave-per-tile variant (NT = 64) was
@@ -637,26 +644,26 @@ static void pick_tile(const vbg_gemm_desc& d, int groups, int maxM, int maxN, in
 }
 
 template <int AK, int BKD>
-static int launch_pair(const vbg_gemm_desc& d, int groups, int maxM, int maxN, hipStream_t s) {
+static int launch_pair(const vbg_gemm_desc& d, int groups, int maxM, int maxN, hipStream_t s, const launch_timer& t) {
     int tile, bk;
     pick_tile(d, groups, maxM, maxN, tile, bk);
     if (!(d.a_vec && d.b_vec)) {                         // unaligned operands: general scalar-load path
-        launch_one<64, 64, 16, 256, AK, BKD, false>(d, groups, maxM, maxN, s);
+        launch_one<64, 64, 16, 256, AK, BKD, false>(d, groups, maxM, maxN, s, t);
     } else if (bk == 32) {
-        if (tile == 128128) launch_one<128, 128, 32, 256, AK, BKD, true>(d, groups, maxM, maxN, s);
-        else if (tile == 128064) launch_one<128, 64, 32, 256, AK, BKD, true>(d, groups, maxM, maxN, s);
-        else launch_one<64, 64, 32, 256, AK, BKD, true>(d, groups, maxM, maxN, s);
+        if (tile == 128128) launch_one<128, 128, 32, 256, AK, BKD, true>(d, groups, maxM, maxN, s, t);
+        else if (tile == 128064) launch_one<128, 64, 32, 256, AK, BKD, true>(d, groups, maxM, maxN, s, t);
+        else launch_one<64, 64, 32, 256, AK, BKD, true>(d, groups, maxM, maxN, s, t);
     } else {
-        if (tile == 128128) launch_one<128, 128, 16, 256, AK, BKD, true>(d, groups, maxM, maxN, s);
-        else if (tile == 128064) launch_one<128, 64, 16, 256, AK, BKD, true>(d, groups, maxM, maxN, s);
-        else launch_one<64, 64, 16, 256, AK, BKD, true>(d, groups, maxM, maxN, s);
+        if (tile == 128128) launch_one<128, 128, 16, 256, AK, BKD, true>(d, groups, maxM, maxN, s, t);
+        else if (tile == 128064) launch_one<128, 64, 16, 256, AK, BKD, true>(d, groups, maxM, maxN, s, t);
+        else launch_one<64, 64, 16, 256, AK, BKD, true>(d, groups, maxM, maxN, s, t);
     }
     VBG_LAUNCH_RET();
 }
 
 }  // namespace vbg
 
-extern "C" int vbg_gemm(const vbg_gemm_desc* desc, void* stream) {
+static int gemm_dispatch(const vbg_gemm_desc* desc, void* stream, const vbg::launch_timer& t) {
     using namespace vbg;
     VBG_CHECK_ARG(desc != nullptr);
     vbg_gemm_desc d = *desc;
@@ -695,14 +702,45 @@ extern "C" int vbg_gemm(const vbg_gemm_desc* desc, void* stream) {
     if (d.a_kind == VBG_OP_CONV_K) { VBG_CHECK_ARG((uintptr_t)d.A % 16 == 0); d.a_vec = 1; }
     if (d.b_kind == VBG_OP_CONV_R) { VBG_CHECK_ARG((uintptr_t)d.B % 16 == 0 && d.N % 4 == 0); d.b_vec = 1; }
     if (d.b_kind == VBG_OP_WT_R) { VBG_CHECK_ARG((uintptr_t)d.B % 16 == 0 && d.N % 4 == 0 && d.geo.dgrad == 1); d.b_vec = 1; }
-    if (d.a_kind == VBG_OP_DENSE_K && d.b_kind == VBG_OP_DENSE_K) return launch_pair<VBG_OP_DENSE_K, VBG_OP_DENSE_K>(d, groups, maxM, maxN, s);
-    if (d.a_kind == VBG_OP_DENSE_K && d.b_kind == VBG_OP_DENSE_R) return launch_pair<VBG_OP_DENSE_K, VBG_OP_DENSE_R>(d, groups, maxM, maxN, s);
-    if (d.a_kind == VBG_OP_DENSE_R && d.b_kind == VBG_OP_DENSE_R) return launch_pair<VBG_OP_DENSE_R, VBG_OP_DENSE_R>(d, groups, maxM, maxN, s);
-    if (d.a_kind == VBG_OP_CONV_K && d.b_kind == VBG_OP_DENSE_K) return launch_pair<VBG_OP_CONV_K, VBG_OP_DENSE_K>(d, groups, maxM, maxN, s);
-    if (d.a_kind == VBG_OP_CONV_K && d.b_kind == VBG_OP_WT_R) return launch_pair<VBG_OP_CONV_K, VBG_OP_WT_R>(d, groups, maxM, maxN, s);
+    if (d.a_kind == VBG_OP_DENSE_K && d.b_kind == VBG_OP_DENSE_K) return launch_pair<VBG_OP_DENSE_K, VBG_OP_DENSE_K>(d, groups, maxM, maxN, s, t);
+    if (d.a_kind == VBG_OP_DENSE_K && d.b_kind == VBG_OP_DENSE_R) return launch_pair<VBG_OP_DENSE_K, VBG_OP_DENSE_R>(d, groups, maxM, maxN, s, t);
+    if (d.a_kind == VBG_OP_DENSE_R && d.b_kind == VBG_OP_DENSE_R) return launch_pair<VBG_OP_DENSE_R, VBG_OP_DENSE_R>(d, groups, maxM, maxN, s, t);
+    if (d.a_kind == VBG_OP_CONV_K && d.b_kind == VBG_OP_DENSE_K) return launch_pair<VBG_OP_CONV_K, VBG_OP_DENSE_K>(d, groups, maxM, maxN, s, t);
+    if (d.a_kind == VBG_OP_CONV_K && d.b_kind == VBG_OP_WT_R) return launch_pair<VBG_OP_CONV_K, VBG_OP_WT_R>(d, groups, maxM, maxN, s, t);
     if (d.a_kind == VBG_OP_DENSE_R && d.b_kind == VBG_OP_CONV_R) {
         VBG_CHECK_ARG(d.N == d.geo.kh * d.geo.kw * d.geo.Cs);
-        return launch_pair<VBG_OP_DENSE_R, VBG_OP_CONV_R>(d, groups, maxM, maxN, s);
+        return launch_pair<VBG_OP_DENSE_R, VBG_OP_CONV_R>(d, groups, maxM, maxN, s, t);
     }
     return VBG_EARG;
+}
+
+extern "C" int vbg_gemm(const vbg_gemm_desc* desc, void* stream) { return gemm_dispatch(desc, stream, vbg::launch_timer{}); }
+
+extern "C" int vbg_gemm_timed(const vbg_gemm_desc* desc, void* stream, void* start_event, void* stop_event) {
+    VBG_CHECK_ARG(start_event && stop_event);
+    vbg::launch_timer t;
+    t.start = (hipEvent_t)start_event;
+    t.stop = (hipEvent_t)stop_event;
+    return gemm_dispatch(desc, stream, t);
+}
+
+extern "C" int vbg_timer_create(void** event) {
+    VBG_CHECK_ARG(event);
+    hipEvent_t e;
+    const hipError_t err = hipEventCreate(&e);
+    if (err != hipSuccess) return (int)err;
+    *event = (void*)e;
+    return VBG_OK;
+}
+
+extern "C" int vbg_timer_destroy(void* event) {
+    VBG_CHECK_ARG(event);
+    const hipError_t err = hipEventDestroy((hipEvent_t)event);
+    return err == hipSuccess ? VBG_OK : (int)err;
+}
+
+extern "C" int vbg_timer_elapsed_ms(void* start_event, void* stop_event, float* ms) {
+    VBG_CHECK_ARG(start_event && stop_event && ms);
+    const hipError_t err = hipEventElapsedTime(ms, (hipEvent_t)start_event, (hipEvent_t)stop_event);
+    return err == hipSuccess ? VBG_OK : (int)err;
 }

@@ -501,7 +501,7 @@ class BertLayerFn(torch.autograd.Function):
         # scores -> probabilities (in place), grouped over (sequence, head)
         P = torch.empty((meta.s_elems,), device=dev, dtype=f32)
         ops.gemm_raw(0, 0, 0, qkv, 3 * hid, OP_DENSE_K, qkv, 3 * hid, OP_DENSE_K, P, meta.ld, grp=meta.t_qk, ngroups=meta.ngroups,
-                     grp_max=(meta.maxlen, meta.maxlen), b_ptr_off=hid, bk=16 if dh <= 128 else 0)
+                     grp_max=(meta.maxlen, meta.maxlen), b_ptr_off=hid, bk=16 if dh <= 128 else 0, tile=64064 if dh <= 128 else 0)
         sid = layer * 8
         ops.softmax_fwd(P, meta.soff, meta.lens, meta.ldp, meta.ngroups, H, meta.maxlen, 1.0 / (dh ** 0.5), p, seed, sid + 0)
         ctxv = torch.empty((ntok, hid), device=dev, dtype=f32)
@@ -549,7 +549,7 @@ class BertLayerFn(torch.autograd.Function):
         # attention backward (grouped GEMMs + row softmax backward)
         dP = torch.empty_like(P)
         ops.gemm_raw(0, 0, 0, dctx, hid, OP_DENSE_K, qkv, 3 * hid, OP_DENSE_K, dP, meta.ld, grp=meta.t_dp, ngroups=meta.ngroups,
-                     grp_max=(meta.maxlen, meta.maxlen), b_ptr_off=2 * hid, bk=16 if dh <= 128 else 0)
+                     grp_max=(meta.maxlen, meta.maxlen), b_ptr_off=2 * hid, bk=16 if dh <= 128 else 0, tile=64064 if dh <= 128 else 0)
         dqkv = torch.empty_like(qkv)
         ops.gemm_raw(0, 0, 0, P, meta.ld, OP_DENSE_R, dctx, hid, OP_DENSE_R, dqkv, 3 * hid, grp=meta.t_dv, ngroups=meta.ngroups,
                      grp_max=(meta.maxlen, dh), c_ptr_off=2 * hid, a_relu_scale=1.0 / (1.0 - p))

@@ -41,6 +41,10 @@ EPI_NONE, EPI_RELU, EPI_GELU_DUAL = 0, 1, 2
 SIGNATURES = {
     "vbg_version": (c_int, []),
     "vbg_gemm": (c_int, [C.POINTER(GemmDesc), c_vp]),
+    "vbg_gemm_timed": (c_int, [C.POINTER(GemmDesc), c_vp, c_vp, c_vp]),
+    "vbg_timer_create": (c_int, [c_vp]),
+    "vbg_timer_destroy": (c_int, [c_vp]),
+    "vbg_timer_elapsed_ms": (c_int, [c_vp, c_vp, c_vp]),
     "vbg_colsum": (c_int, [c_vp, c_ll, c_int, c_int, c_vp, c_int, c_vp]),
     "vbg_im2col": (c_int, [c_vp, c_int, c_int, c_int, c_int, c_int, c_int, c_int, c_int, c_int, c_vp, c_vp]),
     "vbg_normalize_resize": (c_int, [c_vp, c_int, c_int, c_int, c_int, C.POINTER(c_f), C.POINTER(c_f), c_vp, c_int, c_int, c_int, c_vp]),

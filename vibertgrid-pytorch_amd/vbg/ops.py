@@ -77,33 +77,51 @@ def gemm_raw(M, N, K, A, lda, a_kind, B, ldb, b_kind, Cout, ldc, *, bias=None, e
         d.grp_maxM, d.grp_maxN = int(grp_max[0]), int(grp_max[1])
     prof = _GEMM_PROF
     if prof is not None and prof.match(a_kind, b_kind, grp is not None):
-        e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
-        e0.record()
-        check(lib.vbg_gemm(C.byref(d), _stream()), "vbg_gemm")
-        e1.record()
+        e0, e1 = prof.events()
+        check(lib.vbg_gemm_timed(C.byref(d), _stream(), e0, e1), "vbg_gemm_timed")
         prof.add(2.0 * M * N * K, e0, e1)
         return
     check(lib.vbg_gemm(C.byref(d), _stream()), "vbg_gemm")
 
 
 class GemmProfiler:
-    """Optional HIP-event timing of ONE GEMM variant (bench.py roofline): events are recorded on the stream the
-    kernel is launched on (torch's current stream), flops = 2*M*N*K of that launch."""
+    """Optional timing of ONE GEMM variant (bench.py roofline).  Each matching launch goes through `vbg_gemm_timed`: the two
+    events receive the dispatch packet's own begin / end timestamps (hipExtLaunchKernel start / stop events) on the stream the
+    kernel is launched on -- the quantity rocprofv3's kernel trace reports -- without the barrier packets a hipEventRecord pair
+    would put around every kernel.  flops = 2*M*N*K of that launch."""
 
     def __init__(self, a_kind, b_kind, grouped=False):
         self.key = (a_kind, b_kind, grouped)
         self.records = []
+        self.pool = []
 
     def match(self, a_kind, b_kind, grouped):
         return (a_kind, b_kind, grouped) == self.key
+
+    def events(self):
+        out = []
+        for _ in range(2):
+            h = C.c_void_p()
+            check(lib.vbg_timer_create(C.byref(h)), "vbg_timer_create")
+            out.append(h)
+        return out
 
     def add(self, flops, e0, e1):
         self.records.append((flops, e0, e1))
 
     def summary(self):
-        """-> (launches, total_flops, total_ms)  (call after a device sync)"""
-        ms = sum(e0.elapsed_time(e1) for _, e0, e1 in self.records)
-        return len(self.records), sum(f for f, _, _ in self.records), ms
+        """-> (launches, total_flops, total_ms)  (call after a device sync); releases the events"""
+        ms = 0.0
+        for _, e0, e1 in self.records:
+            v = C.c_float()
+            check(lib.vbg_timer_elapsed_ms(e0, e1, C.byref(v)), "vbg_timer_elapsed_ms")
+            ms += v.value
+        out = (len(self.records), sum(f for f, _, _ in self.records), ms)
+        for _, e0, e1 in self.records:
+            lib.vbg_timer_destroy(e0)
+            lib.vbg_timer_destroy(e1)
+        self.records = []
+        return out
 
 
 _GEMM_PROF = None
