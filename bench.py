@@ -121,6 +121,8 @@ def main():
     ap.add_argument("--batch", type=int, default=8, help="documents per GPU (BASELINE config: 8)")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-syncbn", action="store_true")
+    ap.add_argument("--h2d", action="store_true", help="include the packed pinned H2D transfer of the batch in every step "
+                    "(PCIe-inclusive rate quoted in DESIGN.md; never the headline value)")
     args = ap.parse_args()
 
     world = int(os.environ.get("WORLD_SIZE", "1"))
@@ -162,8 +164,13 @@ def main():
     mv = lambda ts: tuple(t.to(dev) for t in ts)
     dbatch = (mv(batch[0]), mv(batch[1]), mv(batch[2]), mv(batch[3]), batch[4].to(dev), batch[5].to(dev))
 
+    packed = None
+    if args.h2d:
+        from vbg.batch import PackedBatch
+        packed = PackedBatch.pack(*batch)
+
     def step():
-        loss = net(*dbatch)
+        loss = net(*(packed.to(dev) if packed is not None else dbatch))
         val = loss.item()
         opt_cnn.zero_grad()
         opt_bert.zero_grad()
@@ -218,7 +225,7 @@ def main():
             "config": {"workload": "SROIE line-level cfg2: resnet_34_fpn_pretrained + bert-base-uncased (12L, vocab 30522, random init), "
                                    "512x512, T=512 tokens, S=128 segments, batch 8/GPU, fwd+bwd+SGD/AdamW, dropout 0.1, simp classifier",
                        "global_batch": B * world, "seq_len": 512, "parallelism": f"dp{world}" + ("+syncbn" if sync_bn else ""),
-                       "last_loss": round(float(last), 4)},
+                       "last_loss": round(float(last), 4), **({"h2d_in_step": packed.nbytes()} if packed is not None else {})},
             "step_mfma_frac": round(value / world * F_STEP_GF / 1e3 / PEAK_F32_TF, 4),
             "roofline": {"bound": "mfma", "kernel": "vbg::gemm_kernel<*,*,*,DENSE_K,DENSE_K> (fp32 MFMA NT GEMM: BERT linears, 1x1 convs; every ungrouped launch)",
                          "achieved": round(ach, 2), "peak": PEAK_F32_TF, "unit": "TFLOP/s", "frac": round(ach / PEAK_F32_TF, 4),

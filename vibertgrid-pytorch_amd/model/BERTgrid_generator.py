@@ -18,6 +18,7 @@ import torch
 import torch.nn as nn
 
 from vbg import functions as Fn
+from vbg.batch import host_mirror
 from vbg import ops
 
 CLS_ID, SEP_ID = 101, 102      # hard-coded in the reference for every model family (:88-93)
@@ -119,10 +120,13 @@ class BERTgridGenerator(nn.Module):
         """-> (token states [ntok, hidden] on device, packing)"""
         cfg = self.model.config
         dev = corpus.device
-        host = torch.cat([corpus.reshape(-1).long(), mask.reshape(-1).long()]).cpu().numpy()      # one D2H sync
-        n = corpus.numel()
+        hc, hm = host_mirror(corpus), host_mirror(mask)
+        if hc is None or hm is None:
+            host = torch.cat([corpus.reshape(-1).long(), mask.reshape(-1).long()]).cpu().numpy()      # one D2H sync
+            n = corpus.numel()
+            hc, hm = host[:n].reshape(corpus.shape), host[n:].reshape(corpus.shape)
         roberta = getattr(cfg, "model_type", "bert") == "roberta"
-        pk = pack_windows(host[:n].reshape(corpus.shape), host[n:].reshape(corpus.shape), roberta)
+        pk = pack_windows(np.asarray(hc, dtype=np.int64), np.asarray(hm, dtype=np.int64), roberta)
         heads, hidden = cfg.num_attention_heads, cfg.hidden_size
         dh = hidden // heads
         tabs, soff, s_elems, maxlen, ld = attention_tables(pk.seq_len, heads, dh, hidden)
@@ -177,7 +181,11 @@ class BERTgridGenerator(nn.Module):
         dev = corpus.device
         x, pk = self._encode(corpus, mask)
         B = corpus.shape[0]
-        seg_host = torch.cat([s.reshape(-1).long() for s in seg_indices]).cpu().numpy() if B else np.zeros(0, np.int64)
+        mirrors = [host_mirror(s) for s in seg_indices]
+        if B and all(m is not None for m in mirrors):          # uploaded through vbg.batch.PackedBatch: no device->host copy
+            seg_host = np.concatenate([np.asarray(m, dtype=np.int64).reshape(-1) for m in mirrors])
+        else:
+            seg_host = torch.cat([s.reshape(-1).long() for s in seg_indices]).cpu().numpy() if B else np.zeros(0, np.int64)
         tok_rows, starts, lens, counts = [], [], [], []
         o = base = 0
         for b in range(B):
