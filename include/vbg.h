@@ -244,6 +244,26 @@ int vbg_gather_i32(const int* src, const int* idx, long long n, int* out, void* 
 int vbg_sum_f32(const float* x, long long n, float* out_accum, void* stream);
 
 /* ------------------------------------------------------------------------------------------
+ * a12 (classifier_mode full / crf). row subsets and the linear-chain CRF
+ * ------------------------------------------------------------------------------------------ */
+/* dst[r,:] = src[idx[r],:]  /  dst[idx[r],:] += src[r,:]  : `fuse_embeddings[pred_pos_neg_mask]` and its backward
+ * (model/field_type_classification_head.py:371, 389-395) */
+int vbg_gather_rows(const float* src, const int* idx, long long n, int C, float* dst, void* stream);
+int vbg_scatter_rows_add(const float* src, const int* idx, long long n, int C, float* dst_accum, void* stream);
+/* CRF over `ndoc` documents whose segments are the row ranges doc_off[d]..doc_off[d+1] of emissions [N, ntag] (ntag <= 64,
+ * trans[i*ntag + j] = score of j -> i, model/crf.py:33-46).  fwd: forward algorithm (:48-79) and gold path score (:81-97):
+ * nll[d] = (log Z_d - score_d) / n_d (:147-151); alpha [N, ntag] and logz [ndoc] are kept for bwd, which writes
+ * demissions [N, ntag] and accumulates dtrans [ntag, ntag], both scaled by gout[d].  viterbi (:99-145): best tag per row,
+ * path score per document; backptr [N, ntag] is workspace. */
+int vbg_crf_nll_fwd(const float* emissions, const int* tags, const int* doc_off, int ndoc, const float* trans, int ntag,
+                    int start_tag, int stop_tag, float* alpha, float* logz, float* nll, void* stream);
+int vbg_crf_nll_bwd(const float* emissions, const int* tags, const int* doc_off, int ndoc, const float* trans, int ntag,
+                    int start_tag, int stop_tag, const float* alpha, const float* logz, const float* gout, float* demissions,
+                    float* dtrans_accum, void* stream);
+int vbg_crf_viterbi(const float* emissions, const int* doc_off, int ndoc, const float* trans, int ntag, int start_tag,
+                    int stop_tag, int* backptr, int* path, float* score, void* stream);
+
+/* ------------------------------------------------------------------------------------------
  * a15. optimizers on flat fp32 ranges  (torch.optim.SGD / AdamW; train_SROIE.py:223-235)
  * ------------------------------------------------------------------------------------------ */
 int vbg_sgd_step(float* p, const float* g, float* mom, long long n, float lr, float momentum, float wd,

@@ -74,6 +74,8 @@ class NetCfg:
     ohem_random: bool = True
     loss_control_lambda: float = 1.0
     add_pos_neg: bool = True
+    classifier_mode: str = "simp"            # simp | full | crf
+    layer_mode: str = "multi"                # BinaryClassifier / CRF emission net: single | multi
     bert: BertCfg = field(default_factory=BertCfg)
 
 
@@ -482,6 +484,56 @@ def ce_ohem(logits: Tensor, target: Tensor, npos: int, nneg: int, weight: Option
     return (sp.sum() + sn.sum()) / (kp + kn)
 
 
+def bce_random_sample(logit: Tensor, target: Tensor, sample_list: Optional[Sequence[int]]) -> Tensor:
+    """BCELossRandomSample, reduction='mean' (pipeline/custom_loss.py:204-290).  The two categories are split by the SIGN OF
+    THE PREDICTION (`mask = input > 0`, :250), category 0 = input <= 0 sampled with sample_list[0], category 1 = input > 0
+    with sample_list[1]; python `random.sample` only when the category holds >= k elements.  float64 [1]."""
+    if logit.dim() == 2:
+        logit = logit.squeeze(1)
+    if sample_list is None:
+        return F.binary_cross_entropy_with_logits(logit.float(), target)
+    ce = F.binary_cross_entropy_with_logits(logit.float(), target, reduction="none")
+    m = logit > 0
+    total = torch.zeros((1,), dtype=torch.float64)
+    kept = 0
+    for idx in range(2):
+        cur = ce[~m] if idx == 0 else ce[m]
+        k = sample_list[idx]
+        keep = min(k, cur.shape[0])
+        kept += keep
+        if keep == k:
+            cur = cur[torch.tensor(_pyrandom.sample(range(int(cur.shape[0])), keep), dtype=torch.long)]
+        total = total + cur.sum()
+    return total / kept
+
+
+def bce_ohem(logit: Tensor, target: Tensor, npos: int, nneg: int, rand: bool = False) -> Tensor:
+    """BCELossOHEM, reduction='mean' (pipeline/custom_loss.py:293-382): positives = target != 0; optional random pre-sample of
+    2k; descending sort; the same `sorted_loss[sorted_index[:k]]` quirk as the CE version (:344-346, :354-356); when the keep
+    count is <= 0 the whole category stays in the sum while the denominator adds that count.  0-dim fp32."""
+    if npos == -1 and nneg == -1:
+        return F.binary_cross_entropy_with_logits(logit.float(), target)
+    ce = F.binary_cross_entropy_with_logits(logit.float(), target, reduction="none")
+    m = target == 0
+    pos, neg = ce[~m], ce[m]
+    if rand:
+        if 2 * npos < pos.shape[0]:
+            pos = pos[torch.tensor(_pyrandom.sample(range(int(pos.shape[0])), 2 * npos), dtype=torch.long)]
+        if 2 * nneg < neg.shape[0]:
+            neg = neg[torch.tensor(_pyrandom.sample(range(int(neg.shape[0])), 2 * nneg), dtype=torch.long)]
+
+    def pick(v, k):
+        sv, si = torch.sort(v, descending=True, stable=OHEM_STABLE_SORT)
+        keep = min(sv.shape[0], k)
+        if 0 < keep < sv.shape[0]:
+            sv = sv[si[:keep]]
+        return sv, keep
+
+    sp, kp = pick(pos, npos)
+    sn, kn = pick(neg, nneg)
+    return (sp.sum() + sn.sum()) / (kp + kn)
+
+
 # --------------------------------------------------------------------------------------
 # a9. auxiliary semantic segmentation head (simp)  (model/semantic_segmentation_head.py:66-78,
 #     288-352)
@@ -503,6 +555,26 @@ def seg_head(sd, p_fuse, seg_classes, coors, cfg: NetCfg, train: bool):
     w = None if cfg.loss_weights is None else torch.tensor(list(cfg.loss_weights), dtype=torch.float32)
     l1 = ce_random_sample(x1, pos_neg, cfg.loss_aux_sample_list)        # aux_loss_1 never weighted (:279-283)
     l2 = ce_ohem(x2, cls, cfg.num_hard_positive_aux, cfg.num_hard_negative_aux, w, rand=False)
+    return l1 + l2, x1, x2
+
+
+def seg_head_full(sd, p_fuse, seg_classes, coors, cfg: NetCfg, train: bool, prefix="semantic_segmentation_head."):
+    """SemanticSegmentationClassifier, the two-stage variant used by classifier_mode full / crf
+    (model/semantic_segmentation_head.py:100-233): aux_loss_1 as in the simplified head; then, on the pixels PREDICTED
+    positive (`softmax(x_out_1).argmax(1) == 1`), one 1x1 conv (ncls -> 1) per foreground class on x_out_2 with a BCE-OHEM loss
+    (never the random pre-sample, :138-153) against `class_label == idx + 1`."""
+    x1, x2 = seg_head_logits(sd, p_fuse, train, prefix + "ss_encoder.")
+    H, W = x1.shape[-2:]
+    pos_neg, cls = label_raster(seg_classes, coors, H, W)
+    l1 = ce_random_sample(x1, pos_neg, cfg.loss_aux_sample_list)
+    pos_mask = x1.softmax(dim=1).argmax(dim=1) == 1
+    l2 = torch.zeros((1,))
+    if int(pos_mask.int().sum()) != 0:
+        for ci in range(cfg.num_classes - 1):
+            q = f"{prefix}ss_binary_classifier_{ci}.conv1."
+            pred = F.conv2d(x2, sd[q + "weight"], sd[q + "bias"])[pos_mask.unsqueeze(1)]
+            lab = (cls[pos_mask] == (ci + 1)).float()
+            l2 = l2 + bce_ohem(pred, lab, cfg.num_hard_positive_aux, cfg.num_hard_negative_aux, False)
     return l1 + l2, x1, x2
 
 
@@ -609,6 +681,106 @@ def simp_head(sd, fuse: Tensor, seg_classes: Sequence[Tensor], cfg: NetCfg,
     return loss, label.int(), pc.detach().softmax(1), pc
 
 
+def _binary_net(sd, p, x, layer_mode):
+    """BinaryClassifier (model/field_type_classification_head.py:111-127): `layer` is a SingleLayer or a MultipleLayer -> [N,1]"""
+    if layer_mode == "single":
+        return F.linear(x, sd[p + "layer.linear.weight"], sd[p + "layer.linear.bias"])
+    return _mlp(sd, p + "layer.", x)
+
+
+def full_head(sd, fuse: Tensor, seg_classes: Sequence[Tensor], cfg: NetCfg, prefix="field_type_classification_head."):
+    """FieldTypeClassification.forward (model/field_type_classification_head.py:334-407): a binary key / non-key net with
+    BCELossRandomSample([num_hard_negative_1, num_hard_positive_1]), then one binary net per foreground class evaluated ONLY on
+    the rows PREDICTED positive (sigmoid >= 0.5), each with its BCELossOHEM.  -> (loss, labels int32, class_pred [N,ncls])."""
+    label = torch.cat(list(seg_classes), 0).long()
+    fuse = fuse.reshape(-1, fuse.shape[-1])
+    assert fuse.shape[0] == label.shape[0]
+    pn = _binary_net(sd, prefix + "pos_neg_classification_net.", fuse, cfg.layer_mode).squeeze(1)
+    l_pn = bce_random_sample(pn, (label > 0).float(), [cfg.num_hard_negative_main_1, cfg.num_hard_positive_main_1])
+    m = pn.detach().sigmoid().ge(0.5)
+    pos = fuse[m]
+    pred = torch.zeros((fuse.shape[0], cfg.num_classes), dtype=pn.dtype)
+    pred[:, 0] = pn.detach().sigmoid()
+    l_c = torch.zeros((1,))
+    if pos.shape[0] != 0:
+        for ci in range(cfg.num_classes - 1):
+            cp = _binary_net(sd, f"{prefix}category_classification_net_{ci}.", pos, cfg.layer_mode).squeeze(1)
+            lab = (label[m] == (ci + 1)).float()
+            l_c = l_c + bce_ohem(cp, lab, cfg.num_hard_positive_main_2, cfg.num_hard_negative_main_2, cfg.ohem_random)
+            pred[:, ci + 1][m] = cp.detach().sigmoid()
+    return l_pn + l_c, label.int(), pred
+
+
+def crf_forward_alg(feats: Tensor, trans: Tensor, start: int, stop: int) -> Tensor:
+    """log partition function of the linear-chain CRF (model/crf.py:48-79); trans[i, j] = score of j -> i"""
+    T = trans.shape[0]
+    fv = torch.full((T,), -10000.0)
+    fv[start] = 0.0
+    for feat in feats:
+        fv = torch.logsumexp(fv.view(1, T) + trans + feat.view(T, 1), dim=1)
+    return torch.logsumexp(fv + trans[stop], dim=0)
+
+
+def crf_score(feats: Tensor, tags: Tensor, trans: Tensor, start: int, stop: int) -> Tensor:
+    """score of the given tag sequence (model/crf.py:81-97)"""
+    tg = torch.cat([torch.tensor([start], dtype=torch.long), tags.long()])
+    s = torch.zeros(())
+    for i in range(feats.shape[0]):
+        s = s + trans[tg[i + 1], tg[i]] + feats[i, tg[i + 1]]
+    return s + trans[stop, tg[-1]]
+
+
+def crf_viterbi(feats: Tensor, trans: Tensor, start: int, stop: int):
+    """(best path score, best tag sequence) (model/crf.py:99-145); first maximal index on ties like torch.max"""
+    T = trans.shape[0]
+    fv = torch.full((T,), -10000.0)
+    fv[start] = 0.0
+    back = []
+    for feat in feats:
+        cand = fv.view(1, T) + trans                      # [next, prev]
+        best = cand.argmax(dim=1)
+        back.append(best)
+        fv = cand.gather(1, best.view(T, 1)).squeeze(1) + feat
+    term = fv + trans[stop]
+    cur = int(term.argmax())
+    score = term[cur]
+    path = [cur]
+    for bp in reversed(back):
+        cur = int(bp[cur])
+        path.append(cur)
+    assert path.pop() == start
+    path.reverse()
+    return score, path
+
+
+def crf_head(sd, fuse: Tensor, seg_classes: Sequence[Tensor], cfg: NetCfg, train: bool, prefix="field_type_classification_head."):
+    """CRFFieldTypeClassification.forward (model/field_type_classification_head.py:669-718): emissions over ncls + 2 tags
+    (START = ncls, STOP = ncls + 1); training: mean over documents of (log Z - gold score) / len; eval: Viterbi tags."""
+    label = torch.cat(list(seg_classes), 0)
+    fuse = fuse.reshape(-1, fuse.shape[-1])
+    p = prefix + "category_classification_net."
+    em = F.linear(fuse, sd[p + "linear.weight"], sd[p + "linear.bias"]) if cfg.layer_mode == "single" else _mlp(sd, p, fuse)
+    trans = sd[prefix + "crf_layer.transitions"]
+    start, stop = cfg.num_classes, cfg.num_classes + 1
+    score = torch.zeros((1,))
+    o = 0
+    tags_out = []
+    for c in seg_classes:
+        n = int(c.shape[0])
+        f, t = em[o:o + n], label[o:o + n]
+        o += n
+        if train:
+            score = score + (crf_forward_alg(f, trans, start, stop) - crf_score(f, t, trans, start, stop)) / n
+        else:
+            sc, path = crf_viterbi(f, trans, start, stop)
+            score = score + sc
+            tags_out.append(torch.tensor(path))
+    score = score / len(seg_classes)
+    if train:
+        return score, label.int(), em.detach().float()
+    return score, label.int(), torch.cat(tags_out, 0).unsqueeze(1).float()
+
+
 # --------------------------------------------------------------------------------------
 # a14. the whole forward  (model/ViBERTgrid_net.py:501-544)
 # --------------------------------------------------------------------------------------
@@ -622,10 +794,19 @@ def forward(sd: Dict[str, Tensor], cfg: NetCfg, image, seg_indices, segment_clas
     embs = [seg_aggregate(emb[b], mask[b], seg_indices[b], cfg.grid_mode) for b in range(emb.shape[0])]
     grid = grid_scatter(embs, icoors, H, W, cfg.stride)
     p_fuse = backbone_forward(sd, batch, grid, cfg.backbone, training)
-    loss_aux, pred_mask, pred_ss = seg_head(sd, p_fuse, segment_classes, icoors, cfg, training)
+    if cfg.classifier_mode == "simp":
+        loss_aux, pred_mask, pred_ss = seg_head(sd, p_fuse, segment_classes, icoors, cfg, training)
+    else:                                                 # full and crf share the two-stage seg head (:384-396, :443-456)
+        loss_aux, pred_mask, pred_ss = seg_head_full(sd, p_fuse, segment_classes, icoors, cfg, training)
     roi = roi_align(p_fuse, [c.float() for c in icoors], cfg.roi_shape, 1.0 / float(cfg.p_fuse_stride))
     fuse = late_fusion(sd, roi, embs, training)
-    loss_c, gt, pred, logits = simp_head(sd, fuse, segment_classes, cfg)
+    logits = None
+    if cfg.classifier_mode == "simp":
+        loss_c, gt, pred, logits = simp_head(sd, fuse, segment_classes, cfg)
+    elif cfg.classifier_mode == "full":
+        loss_c, gt, pred = full_head(sd, fuse, segment_classes, cfg)
+    else:
+        loss_c, gt, pred = crf_head(sd, fuse, segment_classes, cfg, training)
     total = loss_c + cfg.loss_control_lambda * loss_aux
     out = (total, pred_mask, pred_ss, gt, pred)
     if return_intermediates:
@@ -807,7 +988,7 @@ def backbone_shapes(kind: str, grid_channel: int = 768, prefix="backbone.") -> D
     return s
 
 
-def head_shapes(ncls: int, hidden: int = 768, roi: int = 7, fuse: int = 1024) -> Dict[str, tuple]:
+def head_shapes(ncls: int, hidden: int = 768, roi: int = 7, fuse: int = 1024, mode: str = "simp", layer_mode: str = "multi") -> Dict[str, tuple]:
     s = {}
     p = "late_fusion_net.ROI_embedding_net."
     s[p + "conv_1.weight"] = (256, 256, 3, 3)
@@ -818,13 +999,32 @@ def head_shapes(ncls: int, hidden: int = 768, roi: int = 7, fuse: int = 1024) ->
     s[p + "linear.bias"] = (1024,)
     s["late_fusion_net.fuse_embedding_net.linear.weight"] = (1024, hidden + 1024)
     s["late_fusion_net.fuse_embedding_net.linear.bias"] = (1024,)
-    for net, n in (("pos_neg_classification_net", 2), ("category_classification_net", ncls)):
-        q = f"field_type_classification_head.{net}."
-        s[q + "linear_1.weight"] = (fuse // 2, fuse)
-        s[q + "linear_1.bias"] = (fuse // 2,)
-        s[q + "linear_2.weight"] = (n, fuse // 2)
-        s[q + "linear_2.bias"] = (n,)
-    e = "semantic_segmentation_head.semantic_segmentation_encoder."
+    def net_shapes(q, n, single):
+        if single:
+            s[q + "linear.weight"] = (n, fuse)
+            s[q + "linear.bias"] = (n,)
+        else:
+            s[q + "linear_1.weight"] = (fuse // 2, fuse)
+            s[q + "linear_1.bias"] = (fuse // 2,)
+            s[q + "linear_2.weight"] = (n, fuse // 2)
+            s[q + "linear_2.bias"] = (n,)
+
+    h = "field_type_classification_head."
+    if mode == "simp":                                    # always the 2-layer MLP (the "sigle" typo, :474)
+        net_shapes(h + "pos_neg_classification_net.", 2, False)
+        net_shapes(h + "category_classification_net.", ncls, False)
+    elif mode == "full":
+        net_shapes(h + "pos_neg_classification_net.layer.", 1, layer_mode == "single")
+        for ci in range(ncls - 1):
+            net_shapes(f"{h}category_classification_net_{ci}.layer.", 1, layer_mode == "single")
+    else:
+        net_shapes(h + "category_classification_net.", ncls + 2, layer_mode == "single")
+        s[h + "crf_layer.transitions"] = (ncls + 2, ncls + 2)
+    e = "semantic_segmentation_head.semantic_segmentation_encoder." if mode == "simp" else "semantic_segmentation_head.ss_encoder."
+    if mode != "simp":
+        for ci in range(ncls - 1):
+            s[f"semantic_segmentation_head.ss_binary_classifier_{ci}.conv1.weight"] = (1, ncls, 1, 1)
+            s[f"semantic_segmentation_head.ss_binary_classifier_{ci}.conv1.bias"] = (1,)
     s[e + "conv_1.weight"] = (256, 256, 3, 3)
     _bn_shapes(s, e + "bn_1", 256)
     s[e + "conv_2.weight"] = (256, 256, 3, 3)
@@ -844,7 +1044,7 @@ def state_shapes(cfg: NetCfg, vocab: int, max_pos: int = 512, type_vocab: int = 
     s.update(backbone_shapes(cfg.backbone, cfg.bert.hidden))
     if dup_bert:
         s.update(bert_shapes("BERTgrid_generator.model.", cfg.bert, vocab, max_pos, type_vocab))
-    s.update(head_shapes(cfg.num_classes, cfg.bert.hidden, cfg.roi_shape))
+    s.update(head_shapes(cfg.num_classes, cfg.bert.hidden, cfg.roi_shape, mode=cfg.classifier_mode, layer_mode=cfg.layer_mode))
     return s
 
 

@@ -301,6 +301,94 @@ def gen_losses(L):
     npz("losses.npz", **out)
 
 
+def gen_losses_bce(L):
+    """BCELossRandomSample / BCELossOHEM (pipeline/custom_loss.py:204-382), the losses of classifier_mode full"""
+    out = {}
+    g = torch.Generator().manual_seed(13)
+    # random sample: categories split by the sign of the PREDICTION; both categories larger than k
+    x = torch.randn(300, generator=g, requires_grad=True)
+    t = (torch.rand(300, generator=g) > 0.6).float()
+    random.seed(3)
+    l = L.BCELossRandomSample(sample_list=[32, 48])(x, t)
+    l.backward()
+    out.update(rs_x=x, rs_t=t, rs_loss=l, rs_grad=x.grad)
+    # random sample with one category smaller than its k (kept whole), [N,1] input
+    x1 = (torch.randn(40, 1, generator=g) - 1.5).requires_grad_(True)
+    t1 = (torch.rand(40, generator=g) > 0.5).float()
+    random.seed(4)
+    l1 = L.BCELossRandomSample(sample_list=[16, 16])(x1, t1)
+    l1.backward()
+    out.update(rs2_x=x1, rs2_t=t1, rs2_loss=l1, rs2_grad=x1.grad)
+    # OHEM without random
+    x2 = torch.randn(400, generator=g, requires_grad=True)
+    t2 = (torch.rand(400, generator=g) > 0.7).float()
+    l2 = L.BCELossOHEM(num_hard_positive=32, num_hard_negative=32)(x2, t2)
+    l2.backward()
+    out.update(oh_x=x2, oh_t=t2, oh_loss=l2, oh_grad=x2.grad)
+    # OHEM with random pre-sampling
+    x3 = torch.randn(300, generator=g, requires_grad=True)
+    t3 = (torch.rand(300, generator=g) > 0.5).float()
+    random.seed(5)
+    l3 = L.BCELossOHEM(num_hard_positive=16, num_hard_negative=16, random=True)(x3, t3)
+    l3.backward()
+    out.update(ohr_x=x3, ohr_t=t3, ohr_loss=l3, ohr_grad=x3.grad)
+    # fewer elements than k, and no positives at all
+    x4 = torch.randn(9, generator=g, requires_grad=True)
+    t4 = torch.zeros(9)
+    l4 = L.BCELossOHEM(num_hard_positive=16, num_hard_negative=4)(x4, t4)
+    l4.backward()
+    out.update(few_x=x4, few_t=t4, few_loss=l4, few_grad=x4.grad)
+    npz("losses_bce.npz", **out)
+
+
+def gen_e2e_modes(V, tmp):
+    """classifier_mode full (layer_mode multi) and crf (layer_mode single) of the whole model on the e2e.npz documents:
+    two-stage seg head + two-stage classifier / CRF head (model/field_type_classification_head.py:193-407, 591-718, model/crf.py)"""
+    tokenizer = BertTokenizer(os.path.join(tmp, "bert-base-uncased", "vocab.txt"))
+    e = np.load(os.path.join(HERE, "e2e.npz"))
+    B = 2
+    imgs = tuple(torch.from_numpy(e[f"img{b}"]) for b in range(B))
+    coors = tuple(torch.from_numpy(e[f"coor{b}"]) for b in range(B))
+    segs = tuple(torch.from_numpy(e[f"seg{b}"]) for b in range(B))
+    classes = tuple(torch.from_numpy(e[f"class{b}"]) for b in range(B))
+    corpus, mask = torch.from_numpy(e["corpus"]), torch.from_numpy(e["mask"])
+    out = {}
+    for mode, layer_mode in (("full", "multi"), ("crf", "single")):
+        net = V.ViBERTgridNet(num_classes=5, image_mean=[0.9248, 0.9224, 0.9215], image_std=[0.1532, 0.1545, 0.1536],
+                              image_min_size=[96], image_max_size=128, test_image_min_size=96,
+                              bert_model="bert-base-uncased", tokenizer=tokenizer, backbone="resnet_18_fpn", grid_mode="mean",
+                              loss_weights=None, num_hard_positive_main_1=4, num_hard_negative_main_1=4,
+                              num_hard_positive_main_2=3, num_hard_negative_main_2=3,
+                              loss_aux_sample_list=[64, 128, 64], num_hard_positive_aux=64, num_hard_negative_aux=64,
+                              loss_control_lambda=1, add_pos_neg=True, classifier_mode=mode, ohem_random=True,
+                              layer_mode=layer_mode, work_mode="eval",
+                              tag_to_idx={f"c{i}": i for i in range(5)} if mode == "crf" else None)
+        load_synth(net)
+        if mode == "crf":          # the constructor's constraints on the transitions, re-applied over the synthetic values (model/crf.py:42-45)
+            tr = net.field_type_classification_head.crf_layer.transitions
+            tr.data = tr.data * 3.0
+            tr.data[5, :] = -10000
+            tr.data[:, 6] = -10000
+            out["crf_transitions"] = tr.data.clone()
+        net.eval()
+        random.seed(7)
+        with torch.no_grad():
+            loss, pm, ps, gt, pred = net(imgs, segs, classes, coors, corpus, mask)
+        out.update({f"{mode}_eval_loss": loss, f"{mode}_gt": gt, f"{mode}_pred": pred, f"{mode}_pred_ss": ps[:, :, ::8, ::8]})
+        net.train()
+        random.seed(7)
+        loss = net(imgs, segs, classes, coors, corpus, mask)
+        loss.backward()
+        out[f"{mode}_train_loss"] = loss
+        gn = {k: (0.0 if p.grad is None else float(p.grad.double().norm())) for k, p in net.named_parameters()
+              if not k.startswith("BERTgrid_generator.")}
+        out[f"{mode}_gradnorm_keys"] = np.array(sorted(gn.keys()))
+        out[f"{mode}_gradnorm_vals"] = np.array([gn[k] for k in sorted(gn.keys())])
+        out[f"{mode}_keys"] = np.array(list(shapes_of(net).keys()))
+        out[f"{mode}_key_shapes"] = np.array([str(v) for v in shapes_of(net).values()])
+    npz("e2e_modes.npz", **out)
+
+
 def gen_labels(S):
     head = S.SimplifiedSemanticSegmentationClassifier(p_fuse_channel=8, num_classes=5,
                                                       loss_1_sample_list=[4, 4, 4], num_hard_positive=4,
@@ -536,7 +624,7 @@ def main():
     import pipeline.custom_loss as L
     import pipeline.transform as T
 
-    which = sys.argv[1:] or ["transform", "windows", "aggregate", "scatter", "losses", "labels", "bert", "backbone", "backbone_d", "e2e", "e2e_roberta"]
+    which = sys.argv[1:] or ["transform", "windows", "aggregate", "scatter", "losses", "labels", "bert", "backbone", "backbone_d", "e2e", "e2e_roberta", "losses_bce", "e2e_modes"]
     if "transform" in which:
         gen_transform(T)
     if "windows" in which:
@@ -559,6 +647,10 @@ def main():
         gen_e2e(V, tmp)
     if "e2e_roberta" in which:
         gen_e2e_roberta(V, tmp)
+    if "losses_bce" in which:
+        gen_losses_bce(L)
+    if "e2e_modes" in which:
+        gen_e2e_modes(V, tmp)
 
 
 if __name__ == "__main__":

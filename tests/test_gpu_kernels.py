@@ -2,6 +2,7 @@
 torch-CPU fp32 statement of the same op.  Integer/index work is bit-exact; fp32 tolerances are
 written at each assert.  Needs a real MI355X."""
 import math
+import random
 
 import numpy as np
 import pytest
@@ -640,3 +641,85 @@ def test_optimizers(ops):
         opt.step()
         ops.adamw_step(pd, g.to(d), md, vd, 5e-5, 0.9, 0.999, 1e-8, 0.01, i + 1)
     assert close(pd, p, 1e-6, 1e-7)
+
+
+# ------------------------------------------------------------------------------------------
+# classifier_mode full / crf: row subsets, BCE losses, linear-chain CRF
+# ------------------------------------------------------------------------------------------
+def test_gather_scatter_rows(ops):
+    from vbg import functions as Fn
+    d = dev()
+    x = rnd(37, 24, seed=200).to(d).requires_grad_(True)
+    idx = torch.tensor([5, 0, 36, 17, 3], dtype=torch.int32, device=d)
+    y = Fn.GatherRowsFn.apply(x, idx)
+    assert torch.equal(y, x.detach()[idx.long()])
+    gy = rnd(5, 24, seed=201).to(d)
+    y.backward(gy)
+    ref = torch.zeros(37, 24, device=d)
+    ref[idx.long()] = gy
+    assert torch.equal(x.grad, ref)
+    assert Fn.GatherRowsFn.apply(x, idx[:0]).shape == (0, 24)
+
+
+def test_bce_losses_vs_reference_golden(golden):
+    """a13: BCELossRandomSample / BCELossOHEM on the HIP path against the reference's values and gradients"""
+    from pipeline.custom_loss import BCELossOHEM, BCELossRandomSample
+    g = golden("losses_bce.npz")
+    d = dev()
+    for tag, seed, sl in (("rs", 3, [32, 48]), ("rs2", 4, [16, 16])):
+        x = torch.from_numpy(g[tag + "_x"]).to(d).requires_grad_(True)
+        random.seed(seed)
+        l = BCELossRandomSample(sample_list=sl)(x, torch.from_numpy(g[tag + "_t"]).to(d))
+        assert l.dtype == torch.float64 and l.shape == (1,)
+        assert abs(float(l) - float(g[tag + "_loss"])) <= 2e-6 * abs(float(g[tag + "_loss"]))
+        l.backward()
+        assert torch.allclose(x.grad.cpu(), torch.from_numpy(g[tag + "_grad"]), rtol=1e-4, atol=1e-7)
+    for tag, seed, kp, kn, rnd_ in (("oh", None, 32, 32, False), ("ohr", 5, 16, 16, True), ("few", None, 16, 4, False)):
+        x = torch.from_numpy(g[tag + "_x"]).to(d).requires_grad_(True)
+        if seed is not None:
+            random.seed(seed)
+        l = BCELossOHEM(num_hard_positive=kp, num_hard_negative=kn, random=rnd_)(x, torch.from_numpy(g[tag + "_t"]).to(d))
+        assert l.dim() == 0 and abs(float(l) - float(g[tag + "_loss"])) <= 2e-6 * abs(float(g[tag + "_loss"]))
+        l.backward()
+        assert torch.allclose(x.grad.cpu(), torch.from_numpy(g[tag + "_grad"]), rtol=1e-4, atol=1e-7)
+
+
+@pytest.mark.parametrize("ntag,lens", [(7, [8, 7]), (14, [1, 30, 0, 5]), (3, [4]), (64, [6, 9])])
+def test_crf_vs_oracle(ops, ntag, lens):
+    """a12 crf: forward-algorithm NLL (+ gradients w.r.t. emissions and transitions) and Viterbi against the oracle
+    (itself checked against brute force and the reference run, tests/test_oracle_golden.py)"""
+    from vbg import functions as Fn
+    g = torch.Generator().manual_seed(300 + ntag)
+    N = sum(lens)
+    em = torch.randn(N, ntag, generator=g)
+    trans = torch.randn(ntag, ntag, generator=g) * 2
+    start, stop = ntag - 2, ntag - 1
+    trans[start, :] = -10000
+    trans[:, stop] = -10000
+    tags = torch.randint(0, ntag - 2, (N,), generator=g)
+    off = [0]
+    for n in lens:
+        off.append(off[-1] + n)
+    d = dev()
+    emd, trd = em.to(d).requires_grad_(True), trans.to(d).requires_grad_(True)
+    doc_off = torch.tensor(off, dtype=torch.int32, device=d)
+    nll = Fn.CrfNllFn.apply(emd, trd, tags.int().to(d), doc_off, start, stop)
+    w = torch.randn(len(lens), generator=g)
+    (nll * w.to(d)).sum().backward()
+    emr, trr = em.clone().requires_grad_(True), trans.clone().requires_grad_(True)
+    ref = []
+    for k, n in enumerate(lens):
+        f, t = emr[off[k]:off[k + 1]], tags[off[k]:off[k + 1]]
+        ref.append((O.crf_forward_alg(f, trr, start, stop) - O.crf_score(f, t, trr, start, stop)) / n if n else torch.zeros(()))
+    ref = torch.stack(ref)
+    (ref * w).sum().backward()
+    assert torch.allclose(nll.detach().cpu(), ref.detach(), rtol=1e-5, atol=1e-5)
+    assert torch.allclose(emd.grad.cpu(), emr.grad, rtol=1e-4, atol=1e-6)
+    assert torch.allclose(trd.grad.cpu(), trr.grad, rtol=1e-4, atol=2e-6)
+    path, score = ops.crf_viterbi(em.to(d), doc_off, trans.to(d), start, stop)
+    for k, n in enumerate(lens):
+        if n == 0:
+            continue
+        sc, p = O.crf_viterbi(em[off[k]:off[k + 1]], trans, start, stop)
+        assert path[off[k]:off[k + 1]].cpu().tolist() == p
+        assert abs(float(score[k]) - float(sc)) <= 1e-4 * max(1.0, abs(float(sc)))

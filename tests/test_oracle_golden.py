@@ -123,6 +123,93 @@ def test_losses(golden):
     assert torch.allclose(x.grad, T(g["few_grad"]), rtol=1e-5, atol=1e-8)
 
 
+def test_losses_bce(golden):
+    """a13: BCELossRandomSample (categories by the sign of the prediction) and BCELossOHEM against the reference"""
+    g = golden("losses_bce.npz")
+    for tag, seed, sl in (("rs", 3, [32, 48]), ("rs2", 4, [16, 16])):
+        x = T(g[tag + "_x"]).clone().requires_grad_(True)
+        random.seed(seed)
+        l = O.bce_random_sample(x, T(g[tag + "_t"]), sl)
+        assert l.dtype == torch.float64 and l.shape == (1,)
+        assert torch.allclose(l, T(g[tag + "_loss"]), rtol=1e-6)
+        l.backward()
+        assert torch.allclose(x.grad, T(g[tag + "_grad"]), rtol=1e-5, atol=1e-8)
+    for tag, seed, kp, kn, rnd in (("oh", None, 32, 32, False), ("ohr", 5, 16, 16, True), ("few", None, 16, 4, False)):
+        x = T(g[tag + "_x"]).clone().requires_grad_(True)
+        if seed is not None:
+            random.seed(seed)
+        l = O.bce_ohem(x, T(g[tag + "_t"]), kp, kn, rnd)
+        assert l.dim() == 0 and torch.allclose(l, T(g[tag + "_loss"]), rtol=1e-6)
+        l.backward()
+        assert torch.allclose(x.grad, T(g[tag + "_grad"]), rtol=1e-5, atol=1e-8)
+
+
+def test_crf_small():
+    """CRF forward algorithm / Viterbi of the oracle against brute force over all tag sequences"""
+    import itertools
+    g = torch.Generator().manual_seed(9)
+    T_, n = 5, 4
+    feats, trans = torch.randn(n, T_, generator=g), torch.randn(T_, T_, generator=g)
+    start, stop = 3, 4
+    scores = {}
+    for seq in itertools.product(range(T_), repeat=n):
+        scores[seq] = float(O.crf_score(feats, torch.tensor(seq), trans, start, stop))
+    logz = torch.logsumexp(torch.tensor(list(scores.values())), 0)
+    assert abs(float(O.crf_forward_alg(feats, trans, start, stop)) - float(logz)) < 1e-4
+    best = max(scores, key=scores.get)
+    sc, path = O.crf_viterbi(feats, trans, start, stop)
+    assert tuple(path) == best and abs(float(sc) - scores[best]) < 1e-5
+
+
+def modes_cfg(mode):
+    return O.NetCfg(num_classes=5, image_min_size=(96,), image_max_size=128, test_image_min_size=96, backbone="resnet_18_fpn",
+                    num_hard_positive_main_1=4, num_hard_negative_main_1=4, num_hard_positive_main_2=3,
+                    num_hard_negative_main_2=3, loss_aux_sample_list=(64, 128, 64), num_hard_positive_aux=64,
+                    num_hard_negative_aux=64, ohem_random=True, bert=O.BertCfg(layers=2, dropout=0.0),
+                    classifier_mode=mode, layer_mode="multi" if mode == "full" else "single")
+
+
+def modes_state(g, mode):
+    cfg = modes_cfg(mode)
+    sd = O.synth_state_dict(O.state_shapes(cfg, vocab=1200))
+    if mode == "crf":
+        sd["field_type_classification_head.crf_layer.transitions"] = T(g["crf_transitions"]).clone()
+    return cfg, sd
+
+
+@pytest.mark.parametrize("mode", ["full", "crf"])
+def test_e2e_modes(golden, mode):
+    """a9 two-stage seg head, a12 full / crf classifiers, a13 BCE losses: whole model against the reference run"""
+    g = golden("e2e_modes.npz")
+    batch = _e2e_inputs(golden("e2e.npz"))
+    cfg, sd = modes_state(g, mode)
+    ref_shapes = {str(k): str(v) for k, v in zip(g[mode + "_keys"], g[mode + "_key_shapes"])}
+    extra_ok = lambda k: k.endswith("position_ids") or k.endswith("token_type_ids")
+    shapes = O.state_shapes(cfg, vocab=1200)
+    assert {k for k in set(ref_shapes) - set(shapes) if not extra_ok(k)} == set() and set(shapes) - set(ref_shapes) == set()
+    for k, v in shapes.items():
+        assert ref_shapes[k] == str(tuple(v)), (k, ref_shapes[k], v)
+    random.seed(7)
+    with torch.no_grad():
+        loss, pm, ps, gt, pred = O.forward({k: v.clone() for k, v in sd.items()}, cfg, *batch, training=False)
+    assert np.array_equal(gt.numpy(), g[mode + "_gt"])
+    if mode == "crf":
+        assert np.array_equal(pred.numpy(), g["crf_pred"])                      # Viterbi tags
+    else:
+        assert torch.allclose(pred, T(g["full_pred"]), rtol=1e-4, atol=1e-5)
+    assert torch.allclose(ps[:, :, ::8, ::8], T(g[mode + "_pred_ss"]), rtol=1e-3, atol=1e-4)
+    assert torch.allclose(loss.float(), T(g[mode + "_eval_loss"]).float(), rtol=1e-4)
+    sdg = {k: (v.clone().requires_grad_(True) if v.is_floating_point() and "running" not in k else v.clone()) for k, v in sd.items()}
+    random.seed(7)
+    out = O.forward(sdg, cfg, *batch, training=True)
+    out[0].backward()
+    assert torch.allclose(out[0].detach().float(), T(g[mode + "_train_loss"]).float(), rtol=1e-4)
+    for k, v in zip([str(k) for k in g[mode + "_gradnorm_keys"]], g[mode + "_gradnorm_vals"]):
+        gr = sdg[k].grad
+        n = 0.0 if gr is None else float(gr.double().norm())
+        assert abs(n - v) <= 2e-3 * max(abs(v), 1e-3), (k, n, v)
+
+
 def test_bert(golden):
     g = golden("bert.npz")
     bc = O.BertCfg(layers=int(g["layers"]), dropout=0.0)

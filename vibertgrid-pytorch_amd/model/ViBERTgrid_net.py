@@ -152,13 +152,28 @@ class ViBERTgridNet(nn.Module):
                     p_fuse_channel=self.p_fuse_channel, num_classes=self.num_tokens, loss_weights=lw,
                     loss_1_sample_list=loss_aux_sample_list, num_hard_positive=num_hard_positive_aux,
                     num_hard_negative=num_hard_negative_aux)
-        elif self.classifier_mode == "full":
-            self.field_type_classification_head = FieldTypeClassification()
-            self.semantic_segmentation_head = None if inference else SemanticSegmentationClassifier()
         else:
-            assert tag_to_idx is not None, "tag_to_idx cannot be None in crf mode"
-            self.field_type_classification_head = CRFFieldTypeClassification()
-            self.semantic_segmentation_head = None if inference else SemanticSegmentationClassifier()
+            lw = None if inference else getattr(self, "loss_weights", None)
+            lw = None if lw is None else lw.to(torch.float32)
+            if self.classifier_mode == "full":
+                if inference:
+                    self.field_type_classification_head = FieldTypeClassification(
+                        num_classes=self.num_tokens, fuse_embedding_channel=self.late_fusion_fuse_embedding_channel, layer_mode=layer_mode,
+                        work_mode=self.work_mode)
+                else:
+                    self.field_type_classification_head = FieldTypeClassification(
+                        num_classes=self.num_tokens, fuse_embedding_channel=self.late_fusion_fuse_embedding_channel, loss_weights=lw,
+                        num_hard_positive_1=num_hard_positive_main_1, num_hard_negative_1=num_hard_negative_main_1,
+                        num_hard_positive_2=num_hard_positive_main_2, num_hard_negative_2=num_hard_negative_main_2, random=ohem_random,
+                        layer_mode=layer_mode, work_mode=self.work_mode)
+            else:
+                assert tag_to_idx is not None, "tag_to_idx cannot be None in crf mode"
+                self.field_type_classification_head = CRFFieldTypeClassification(
+                    tag_to_idx=tag_to_idx, fuse_embedding_channel=self.late_fusion_fuse_embedding_channel, layer_mode=layer_mode)
+            # both modes use the paper's two-stage segmentation head (reference :384-396, :443-456)
+            self.semantic_segmentation_head = None if inference else SemanticSegmentationClassifier(
+                p_fuse_channel=self.p_fuse_channel, num_classes=self.num_tokens, loss_weights=lw, loss_1_sample_list=loss_aux_sample_list,
+                num_hard_positive=num_hard_positive_aux, num_hard_negative=num_hard_negative_aux)
 
     # the reference flips work_mode on train()/eval() (:462-468), even for a model built in another mode
     def train(self, mode: bool = True):
@@ -197,6 +212,19 @@ class ViBERTgridNet(nn.Module):
                 coors: torch.Tensor, corpus: torch.Tensor, mask: torch.Tensor):
         batch, icoors, packed, B, H, W = self._trunk(image, seg_indices, coors, corpus, mask)
         seg_head, cls_head = self.semantic_segmentation_head, self.field_type_classification_head
+        if self.classifier_mode != "simp":
+            # two-stage heads: their selections depend on predictions, so they resolve their own plans, in the reference's order
+            # (segmentation head first, then the classifier: the host RNG draws line up)
+            emb_cat, p_fuse = self._features(batch, packed, B, H, W, seg_indices, corpus, mask)
+            train_only = self.work_mode == "train" and self.training
+            loss_aux, pred_mask, pred_ss = seg_head(p_fuse, segment_classes, icoors, materialize=not train_only)
+            roi = self.grid_roi_align_net(p_fuse, icoors, None, packed=packed)
+            fuse = self.late_fusion_net(roi, emb_cat)
+            loss_c, gt_label, pred_label = cls_head(fuse, segment_classes)
+            total_loss = loss_c + self.loss_control_lambda * loss_aux
+            if train_only:
+                return total_loss
+            return total_loss, pred_mask, pred_ss, gt_label, pred_label
         # label-only work of all four losses first: ONE device->host copy, host RNG draws in the reference's order
         classes = torch.cat([c.reshape(-1) for c in segment_classes]).int()
         pos_neg, cls_map = seg_head.make_labels(packed, classes, B, H, W)

@@ -14,7 +14,7 @@ import torch
 import torch.nn as nn
 
 from model.ResNetFPN_ViBERTgrid import _cl, conv, conv_bn
-from pipeline.custom_loss import CrossEntropyLossOHEM, CrossEntropyLossRandomSample, resolve_plans
+from pipeline.custom_loss import BCELossOHEM, CrossEntropyLossOHEM, CrossEntropyLossRandomSample, resolve_plans
 from vbg import ops
 
 
@@ -79,7 +79,69 @@ class SimplifiedSemanticSegmentationClassifier(nn.Module):
         return l1 + l2, None, None
 
 
-class SemanticSegmentationClassifier(nn.Module):
-    def __init__(self, *a, **k):
+class SemanticSegmentationBinaryClassifier(nn.Module):
+    def __init__(self, in_channels: int) -> None:
         super().__init__()
-        raise NotImplementedError("classifier_mode 'full'/'crf' (binary per-class seg head) is not built yet; use 'simp'")
+        self.conv1 = nn.Conv2d(in_channels, 1, kernel_size=1)
+        _cl(self)
+
+    def forward(self, x):
+        return conv(x, self.conv1)
+
+
+class _Proxy(object):
+    def __init__(self, module, prefix):
+        self.module, self.prefix = module, prefix
+
+    def __getitem__(self, i):
+        return getattr(self.module, self.prefix + str(i))
+
+
+class SemanticSegmentationClassifier(nn.Module):
+    """the paper's two-stage auxiliary head used by classifier_mode full / crf (reference :100-233): aux_loss_1 as in the simplified
+    head; on the pixels PREDICTED positive (`softmax(x_out_1).argmax(1) == 1`) one 1x1 conv (ncls -> 1) per foreground class with a
+    BCE-OHEM loss against `class_label == idx + 1`.  Everything stays at P_fuse resolution: the per-class 1x1 convs commute with
+    the nearest x4 upsampling like conv_3_1 / conv_3_2 do, the predicted-positive set is the x4 replication of the low-resolution
+    argmax, and the losses index low-resolution logits by full-resolution pixel."""
+
+    def __init__(self, p_fuse_channel: int, num_classes: int, loss_weights: torch.Tensor = None, loss_1_sample_list: List = None,
+                 num_hard_positive: int = -1, num_hard_negative: int = -1) -> None:
+        super().__init__()
+        self.num_classes = num_classes
+        self.ss_encoder = SemanticSegmentationEncoder(p_fuse_channel, num_classes)
+        self.aux_loss_1 = CrossEntropyLossRandomSample(sample_list=loss_1_sample_list)
+        for idx in range(num_classes - 1):
+            self.add_module(f"ss_binary_classifier_{idx}", SemanticSegmentationBinaryClassifier(in_channels=num_classes))
+            self.add_module(f"aux_loss_2_{idx}", BCELossOHEM(num_hard_positive=num_hard_positive, num_hard_negative=num_hard_negative,
+                                                             weight=loss_weights))
+        self.ss_binary_classifier = _Proxy(self, "ss_binary_classifier_")
+        self.aux_loss_2 = _Proxy(self, "aux_loss_2_")
+
+    def forward(self, fuse_feature: torch.Tensor, seg_classes: Tuple[torch.Tensor], coors: Tuple[torch.Tensor], prepared=None,
+                materialize: bool = True):
+        from model.BERTgrid_generator import BERTgridGenerator
+        x1, x2 = self.ss_encoder(fuse_feature)
+        B, h, w, _ = x1.shape
+        H, W = 4 * h, 4 * w
+        packed = BERTgridGenerator.pack_boxes(tuple(c.int() for c in coors))
+        classes = torch.cat([c.reshape(-1) for c in seg_classes]).int()
+        boxes, box_off, _ = packed
+        owner = ops.owner_map(boxes, box_off, B, H, W, 1)
+        pos_neg, cls = ops.label_raster(owner, classes)
+        pos_neg, cls = pos_neg.view(-1), cls.view(-1)
+        plan = self.aux_loss_1.plan(pos_neg, 3)
+        resolve_plans([plan])
+        loss = self.aux_loss_1(x1.reshape(-1, 3), pos_neg, plan, 2, H, W)
+        # predicted-positive pixels: low-resolution argmax == 1, replicated x4 (torch.argmax keeps the first maximum, like softmax().argmax())
+        pm = (x1.detach().argmax(dim=-1) == 1)
+        l2 = torch.zeros((1,), device=x1.device)
+        if bool(pm.any()):
+            pmf = pm.repeat_interleave(4, dim=1).repeat_interleave(4, dim=2).reshape(-1)
+            for ci in range(self.num_classes - 1):
+                logit = self.ss_binary_classifier[ci](x2).reshape(-1, 1)                     # low-resolution rows
+                key = torch.where(pmf, (cls == ci + 1).to(torch.int32), torch.full_like(cls, 2))
+                l2 = l2 + self.aux_loss_2[ci](logit, keyed_labels=key, up_shift=2, H=H, W=W)
+        loss = loss + l2
+        if materialize:
+            return loss, ops.upsample_nhwc_to_nchw(x1.detach(), 4), ops.upsample_nhwc_to_nchw(x2.detach(), 4)
+        return loss, None, None

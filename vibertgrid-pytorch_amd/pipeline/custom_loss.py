@@ -67,16 +67,17 @@ class RandomSamplePlan:
 
 
 class OhemPlan:
-    """label-only part of CrossEntropyLossOHEM (positives = label != 0)."""
+    """label-only part of CrossEntropyLossOHEM (positives = label != 0).  `keyed`: labels are 1 (positive) / 0 (negative) /
+    anything else = not part of the loss (BCE-OHEM over a predicted-positive subset, semantic_segmentation_head.py:216-226)."""
 
-    def __init__(self, labels_i32: torch.Tensor, num_pos: int, num_neg: int, rand: bool):
+    def __init__(self, labels_i32: torch.Tensor, num_pos: int, num_neg: int, rand: bool, keyed: bool = False):
         self.labels, self.num_pos, self.num_neg, self.rand = labels_i32, num_pos, num_neg, rand
         self.plain = (num_pos == -1 and num_neg == -1)
         self.cats: List[_Cat] = []
         if not self.plain:
-            for eq in (False, True):          # positives first, like the reference
+            for value, eq in (((1, True), (0, True)) if keyed else ((0, False), (0, True))):          # positives first, like the reference
                 c = _Cat()
-                c.idx, c.cnt_dev = ops.compact(labels_i32, 0, eq)
+                c.idx, c.cnt_dev = ops.compact(labels_i32, value, eq)
                 self.cats.append(c)
 
     def count_tensors(self):
@@ -137,8 +138,8 @@ class CrossEntropyLossOHEM(torch.nn.Module):
         self.num_hard_positive, self.num_hard_negative, self.random = num_hard_positive, num_hard_negative, random
         self.register_buffer("weight", weight)
 
-    def plan(self, labels_i32):
-        return OhemPlan(labels_i32, self.num_hard_positive, self.num_hard_negative, self.random)
+    def plan(self, labels_i32, keyed: bool = False):
+        return OhemPlan(labels_i32, self.num_hard_positive, self.num_hard_negative, self.random, keyed)
 
     def forward(self, logits2d: torch.Tensor, labels_i32: torch.Tensor, plan: OhemPlan = None, up_shift: int = 0, H: int = 0,
                 W: int = 0) -> torch.Tensor:
@@ -151,14 +152,13 @@ class CrossEntropyLossOHEM(torch.nn.Module):
                 raise NotImplementedError("weighted plain mean CE is not on the model's path")
             elem = torch.arange(n, dtype=torch.int32, device=logits2d.device)
             return Fn.SelectedCEFn.apply(logits2d, elem, labels_i32, None, 1.0 / n, up_shift, H, W)
-        ce_all = ops.ce_fwd(logits2d.detach(), None, labels_i32, n, self.weight, up_shift, H, W)
         elems, keeps = [], []
         for c, k in zip(plan.cats, (self.num_hard_positive, self.num_hard_negative)):
             m = int(c.elem.numel())
             keep = min(m, k)
             keeps.append(keep)
             if 0 < keep < m:
-                v = ops.gather_f32(ce_all, c.elem)
+                v = ops.ce_fwd(logits2d.detach(), c.elem.contiguous(), labels_i32, m, self.weight, up_shift, H, W)   # losses of this category only
                 _, si = ops.sort_desc(v)                       # si[r] = position (in c.elem) of rank r
                 ranks = ops.gather_i32(si, si[:keep].contiguous())   # the reference's sorted_loss[sorted_index[:k]]
                 elems.append(ops.gather_i32(c.elem, ranks))
@@ -173,3 +173,64 @@ class CrossEntropyLossOHEM(torch.nn.Module):
         if total is None:
             total = logits2d.sum() * 0.0
         return total
+
+
+# ----------------------------------------------------------------------------------------------
+# binary variants (classifier_mode full): reference `BCELossRandomSample` :204-290, `BCELossOHEM` :293-382
+# ----------------------------------------------------------------------------------------------
+def _two_column(logit: torch.Tensor) -> torch.Tensor:
+    """BCE-with-logits(x, t) is exactly the 2-class cross entropy of the logit pair (0, x) with target t
+    (logsumexp(0, x) - t*x = max(x, 0) + log1p(exp(-|x|)) - t*x), so the CE kernels serve both."""
+    x = logit.reshape(-1, 1).to(torch.float32)
+    return torch.cat([torch.zeros_like(x), x], dim=1)
+
+
+class BCELossRandomSample(torch.nn.Module):
+    """categories are split by the SIGN OF THE PREDICTION (`mask = input > 0`, :250): category 0 = input <= 0 sampled with
+    sample_list[0], category 1 = input > 0 with sample_list[1]; float64 [1] like the reference."""
+
+    def __init__(self, sample_list: List, weight: Optional[torch.Tensor] = None, reduction: str = "mean") -> None:
+        super().__init__()
+        assert reduction == "mean", "only the reduction the model uses is implemented"
+        if weight is not None:
+            raise NotImplementedError("element-wise BCE weights are not on the model's path")
+        assert sample_list is not None and len(sample_list) == 2, "sample list must contain two elements"
+        self.sample_list = sample_list
+
+    def forward(self, input: torch.Tensor, target: torch.Tensor) -> torch.Tensor:
+        assert input.dim() == 1 or (input.dim() == 2 and input.shape[1] == 1), "invalid shape"
+        x = input.reshape(-1)
+        keys = (x.detach() > 0).to(torch.int32)
+        labels = (target.reshape(-1) != 0).to(torch.int32)
+        plan = RandomSamplePlan(keys, 2, self.sample_list)
+        resolve_plans([plan])
+        logits2 = _two_column(x)
+        total = torch.zeros((1,), dtype=torch.float64, device=x.device)
+        for c in plan.cats:
+            if c.elem.numel():
+                total = total + Fn.SelectedCEFn.apply(logits2, c.elem.contiguous(), labels, None, 1.0, 0, 0, 0).double()
+        return total / plan.num_keep_total
+
+
+class BCELossOHEM(torch.nn.Module):
+    """positives = target != 0; everything else (random pre-sample, descending sort, the `sorted[sorted_index[:k]]` quirk,
+    mean over the keep counts) is the CE version on the logit pair (0, x)."""
+
+    def __init__(self, num_hard_positive: int = -1, num_hard_negative: int = -1, weight: Optional[torch.Tensor] = None,
+                 reduction: str = "mean", random: bool = False) -> None:
+        super().__init__()
+        if weight is not None:
+            raise NotImplementedError("element-wise BCE weights are not on the model's path")
+        self.ce = CrossEntropyLossOHEM(num_hard_positive, num_hard_negative, None, reduction, random)
+
+    def forward(self, input: torch.Tensor, target: torch.Tensor = None, keyed_labels: torch.Tensor = None, up_shift: int = 0,
+                H: int = 0, W: int = 0) -> torch.Tensor:
+        """input: logits [n] / [n,1] (or low-resolution rows when H > 0); either `target` (0/1 per element) or
+        `keyed_labels` int32 over the full-resolution elements: 1 positive, 0 negative, other = outside the loss."""
+        logits2 = _two_column(input)
+        if keyed_labels is None:
+            labels = (target.reshape(-1) != 0).to(torch.int32)
+            return self.ce(logits2, labels)
+        plan = self.ce.plan(keyed_labels, keyed=True)
+        resolve_plans([plan])
+        return self.ce(logits2, keyed_labels, plan, up_shift, H, W)

@@ -577,6 +577,45 @@ class BertLayerFn(torch.autograd.Function):
                 dg2, db2, None, None, None, None, None)
 
 
+class GatherRowsFn(torch.autograd.Function):
+    """rows `idx` of x (`fuse_embeddings[pred_pos_neg_mask]`, field_type_classification_head.py:371); bwd scatters them back"""
+
+    @staticmethod
+    def forward(ctx, x, idx):
+        x = _c(x)
+        ctx.shape = x.shape
+        ctx.save_for_backward(idx)
+        return ops.gather_rows(x, idx)
+
+    @staticmethod
+    def backward(ctx, dy):
+        (idx,) = ctx.saved_tensors
+        dx = torch.zeros(ctx.shape, device=dy.device, dtype=f32)
+        ops.scatter_rows_add(_c(dy), idx, dx)
+        return dx, None
+
+
+class CrfNllFn(torch.autograd.Function):
+    """per-document CRF negative log-likelihood / length (model/crf.py:147-151) for all documents of the batch at once"""
+
+    @staticmethod
+    def forward(ctx, em, trans, tags, doc_off, start, stop):
+        em, trans = _c(em), _c(trans)
+        nll, alpha, logz = ops.crf_nll_fwd(em, tags, doc_off, trans, start, stop)
+        ctx.cfg = (start, stop)
+        ctx.t_ref = trans
+        ctx.save_for_backward(em, trans, tags, doc_off, alpha, logz)
+        return nll
+
+    @staticmethod
+    def backward(ctx, dnll):
+        em, trans, tags, doc_off, alpha, logz = ctx.saved_tensors
+        start, stop = ctx.cfg
+        dtrans = torch.zeros_like(trans)
+        dem = ops.crf_nll_bwd(em, tags, doc_off, trans, start, stop, alpha, logz, _c(dnll).to(f32), dtrans)
+        return dem, dtrans, None, None, None, None
+
+
 # ----------------------------------------------------------------------------------------------
 # losses
 # ----------------------------------------------------------------------------------------------

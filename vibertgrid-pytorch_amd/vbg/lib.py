@@ -94,6 +94,11 @@ SIGNATURES = {
     "vbg_gather_i32": (c_int, [c_vp, c_vp, c_ll, c_vp, c_vp]),
     "vbg_sum_f32": (c_int, [c_vp, c_ll, c_vp, c_vp]),
     "vbg_sumsq": (c_int, [c_vp, c_ll, c_vp, c_vp]),
+    "vbg_gather_rows": (c_int, [c_vp, c_vp, c_ll, c_int, c_vp, c_vp]),
+    "vbg_scatter_rows_add": (c_int, [c_vp, c_vp, c_ll, c_int, c_vp, c_vp]),
+    "vbg_crf_nll_fwd": (c_int, [c_vp, c_vp, c_vp, c_int, c_vp, c_int, c_int, c_int, c_vp, c_vp, c_vp, c_vp]),
+    "vbg_crf_nll_bwd": (c_int, [c_vp, c_vp, c_vp, c_int, c_vp, c_int, c_int, c_int, c_vp, c_vp, c_vp, c_vp, c_vp, c_vp]),
+    "vbg_crf_viterbi": (c_int, [c_vp, c_vp, c_int, c_vp, c_int, c_int, c_int, c_vp, c_vp, c_vp, c_vp]),
     "vbg_sgd_step": (c_int, [c_vp, c_vp, c_vp, c_ll, c_f, c_f, c_f, c_int, c_f, c_vp]),
     "vbg_adamw_step": (c_int, [c_vp, c_vp, c_vp, c_vp, c_ll, c_f, c_f, c_f, c_f, c_f, c_int, c_f, c_vp]),
 }

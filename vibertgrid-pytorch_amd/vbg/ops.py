@@ -610,6 +610,49 @@ def gather_i32(src, idx):
     return out
 
 
+def gather_rows(src, idx):
+    n, C_ = idx.numel(), src.shape[1]
+    out = torch.empty((n, C_), device=src.device, dtype=f32)
+    check(lib.vbg_gather_rows(P(src), P(idx), n, C_, P(out), _stream()), "vbg_gather_rows")
+    return out
+
+
+def scatter_rows_add(src, idx, dst):
+    check(lib.vbg_scatter_rows_add(P(src), P(idx), idx.numel(), src.shape[1], P(dst), _stream()), "vbg_scatter_rows_add")
+    return dst
+
+
+def crf_nll_fwd(em, tags, doc_off, trans, start, stop):
+    """-> (nll [ndoc], alpha [N, ntag], logz [ndoc])"""
+    N, ntag = em.shape
+    ndoc = doc_off.numel() - 1
+    alpha = torch.empty((N, ntag), device=em.device, dtype=f32)
+    logz = torch.empty((ndoc,), device=em.device, dtype=f32)
+    nll = torch.empty((ndoc,), device=em.device, dtype=f32)
+    check(lib.vbg_crf_nll_fwd(P(em), P(tags), P(doc_off), ndoc, P(trans), ntag, start, stop, P(alpha), P(logz), P(nll), _stream()),
+          "vbg_crf_nll_fwd")
+    return nll, alpha, logz
+
+
+def crf_nll_bwd(em, tags, doc_off, trans, start, stop, alpha, logz, gout, dtrans):
+    N, ntag = em.shape
+    dem = torch.empty_like(em)
+    check(lib.vbg_crf_nll_bwd(P(em), P(tags), P(doc_off), doc_off.numel() - 1, P(trans), ntag, start, stop, P(alpha), P(logz), P(gout),
+                              P(dem), P(dtrans), _stream()), "vbg_crf_nll_bwd")
+    return dem
+
+
+def crf_viterbi(em, doc_off, trans, start, stop):
+    """-> (path int32 [N], score [ndoc])"""
+    N, ntag = em.shape
+    ndoc = doc_off.numel() - 1
+    bp = torch.empty((max(N, 1), ntag), device=em.device, dtype=i32)
+    path = torch.empty((N,), device=em.device, dtype=i32)
+    score = torch.empty((ndoc,), device=em.device, dtype=f32)
+    check(lib.vbg_crf_viterbi(P(em), P(doc_off), ndoc, P(trans), ntag, start, stop, P(bp), P(path), P(score), _stream()), "vbg_crf_viterbi")
+    return path, score
+
+
 def sum_f32(x, out):
     check(lib.vbg_sum_f32(P(x), x.numel(), P(out), _stream()), "vbg_sum_f32")
     return out
