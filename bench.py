@@ -61,7 +61,7 @@ def synthetic_batch(B, H, W, T, S, ncls, vocab, seed):
     return imgs, tuple(segs), tuple(classes), tuple(coors), corpus, mask
 
 
-def build_model(tmp, backbone="resnet_34_fpn_pretrained", layers=12, vocab=VOCAB, dropout=0.1):
+def build_model(tmp, backbone="resnet_34_fpn_pretrained", layers=12, vocab=VOCAB, dropout=0.1, img=512, ncls=NCLS):
     import warnings
     from transformers import BertTokenizer
     from model.ViBERTgrid_net import ViBERTgridNet
@@ -72,8 +72,8 @@ def build_model(tmp, backbone="resnet_34_fpn_pretrained", layers=12, vocab=VOCAB
         with warnings.catch_warnings():
             warnings.simplefilter("ignore")
             # work_mode="eval" builds BERT from its config (no checkpoint download); .train() flips work_mode to "train"
-            net = ViBERTgridNet(num_classes=NCLS, image_mean=[0.9248, 0.9224, 0.9215], image_std=[0.1532, 0.1545, 0.1536],
-                                image_min_size=[512], image_max_size=512, test_image_min_size=512, bert_model="bert-base-uncased",
+            net = ViBERTgridNet(num_classes=ncls, image_mean=[0.9248, 0.9224, 0.9215], image_std=[0.1532, 0.1545, 0.1536],
+                                image_min_size=[img], image_max_size=img, test_image_min_size=img, bert_model="bert-base-uncased",
                                 tokenizer=BertTokenizer(os.path.join(d, "vocab.txt")), backbone=backbone, grid_mode="mean",
                                 loss_weights=None, num_hard_positive_main_1=16, num_hard_negative_main_1=16,
                                 num_hard_positive_main_2=32, num_hard_negative_main_2=32, loss_aux_sample_list=[256, 512, 256],
@@ -121,6 +121,9 @@ def main():
     ap.add_argument("--batch", type=int, default=8, help="documents per GPU (BASELINE config: 8)")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-syncbn", action="store_true")
+    ap.add_argument("--shape", default="cfg2", choices=["cfg2", "cfg4", "cfg5"],
+                    help="cfg2 (default, the BASELINE metric's configuration); cfg4 / cfg5: the other §8 shapes as exploratory runs "
+                         "(char-level S=T=512, 12 classes, vocab 21128 / 1024x1024 images), reported under config.workload")
     ap.add_argument("--h2d", action="store_true", help="include the packed pinned H2D transfer of the batch in every step "
                     "(PCIe-inclusive rate quoted in DESIGN.md; never the headline value)")
     args = ap.parse_args()
@@ -148,7 +151,10 @@ def main():
     tmp = tempfile.mkdtemp(prefix="vbg_bench_")
     import contextlib
     with contextlib.redirect_stdout(sys.stderr):        # the reference's ctor prints; stdout carries the ONE JSON line only
-        net = build_model(tmp)
+        shape = {"cfg2": dict(img=512, S=128, ncls=NCLS, vocab=VOCAB, backbone="resnet_34_fpn_pretrained"),
+                 "cfg4": dict(img=512, S=512, ncls=12, vocab=21128, backbone="resnet_34_fpn"),
+                 "cfg5": dict(img=1024, S=128, ncls=NCLS, vocab=VOCAB, backbone="resnet_34_fpn")}[args.shape]
+        net = build_model(tmp, backbone=shape["backbone"], vocab=shape["vocab"], img=shape["img"], ncls=shape["ncls"])
     sync_bn = world > 1 and not args.no_syncbn
     if sync_bn:
         net = torch.nn.SyncBatchNorm.convert_sync_batchnorm(net)      # example_config.yaml syncBN: True
@@ -160,7 +166,7 @@ def main():
     reducer = FlatReducer(opts)
 
     B = args.batch
-    batch = synthetic_batch(B, 512, 512, 512, 128, NCLS, VOCAB, 1234 + rank)
+    batch = synthetic_batch(B, shape["img"], shape["img"], 512, shape["S"], shape["ncls"], shape["vocab"], 1234 + rank)
     mv = lambda ts: tuple(t.to(dev) for t in ts)
     dbatch = (mv(batch[0]), mv(batch[1]), mv(batch[2]), mv(batch[3]), batch[4].to(dev), batch[5].to(dev))
 
@@ -222,11 +228,12 @@ def main():
             "value": round(value, 3), "unit": "docs/sec", "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
             "ms_per_step": round(1e3 * dt / args.steps, 3), "higher_is_better": True, "scaling": "weak", "vs_baseline": None,
             "dtype": "f32", "data": "synthetic",
-            "config": {"workload": "SROIE line-level cfg2: resnet_34_fpn_pretrained + bert-base-uncased (12L, vocab 30522, random init), "
-                                   "512x512, T=512 tokens, S=128 segments, batch 8/GPU, fwd+bwd+SGD/AdamW, dropout 0.1, simp classifier",
+            "config": {"workload": ("SROIE line-level cfg2: resnet_34_fpn_pretrained + bert-base-uncased (12L, vocab 30522, random init), "
+                                    "512x512, T=512 tokens, S=128 segments, batch 8/GPU, fwd+bwd+SGD/AdamW, dropout 0.1, simp classifier")
+                       if args.shape == "cfg2" else f"EXPLORATORY {args.shape}: {shape}, T=512, batch {B}/GPU (not the BASELINE metric's configuration)",
                        "global_batch": B * world, "seq_len": 512, "parallelism": f"dp{world}" + ("+syncbn" if sync_bn else ""),
                        "last_loss": round(float(last), 4), **({"h2d_in_step": packed.nbytes()} if packed is not None else {})},
-            "step_mfma_frac": round(value / world * F_STEP_GF / 1e3 / PEAK_F32_TF, 4),
+            "step_mfma_frac": round(value / world * {"cfg2": F_STEP_GF, "cfg4": 862.4, "cfg5": 1715.3}[args.shape] / 1e3 / PEAK_F32_TF, 4),
             "roofline": {"bound": "mfma", "kernel": "vbg::gemm_kernel<*,*,*,DENSE_K,DENSE_K> (fp32 MFMA NT GEMM: BERT linears, 1x1 convs; every ungrouped launch)",
                          "achieved": round(ach, 2), "peak": PEAK_F32_TF, "unit": "TFLOP/s", "frac": round(ach / PEAK_F32_TF, 4),
                          "traffic": traffic, "launches": launches, "avg_us": round(1e3 * ms / max(launches, 1), 2)},
