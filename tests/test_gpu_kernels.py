@@ -643,6 +643,21 @@ def test_optimizers(ops):
     assert close(pd, p, 1e-6, 1e-7)
 
 
+@pytest.mark.parametrize("M,N,ld", [(300, 768, 768), (4128, 3072, 3072), (97, 64, 64), (513, 16, 16), (50, 13, 13), (1000, 2304, 2304),
+                                    (700, 768, 2304), (33, 1000, 1000), (5, 4, 4)])
+def test_colsum(ops, M, N, ld):
+    """bias gradients: vector path (float4, N % 4 == 0, aligned rows), strided views (a Q/K/V slice of dqkv) and the scalar path"""
+    x = rnd(M, ld, seed=400 + N)
+    xd = x.to(dev())
+    v = xd[:, :N] if ld == N else xd[:, N:2 * N]
+    ref = (x[:, :N] if ld == N else x[:, N:2 * N]).double().sum(0)
+    out = ops.colsum(v)
+    assert close(out, ref.float(), 1e-5, 1e-4 * math.sqrt(M))
+    acc = torch.ones(N, device=dev())
+    ops.colsum(v, out=acc, accumulate=True)
+    assert close(acc, (ref + 1).float(), 1e-5, 1e-4 * math.sqrt(M))
+
+
 # ------------------------------------------------------------------------------------------
 # classifier_mode full / crf: row subsets, BCE losses, linear-chain CRF
 # ------------------------------------------------------------------------------------------

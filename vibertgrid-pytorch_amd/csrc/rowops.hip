@@ -379,6 +379,33 @@ __global__ __launch_bounds__(256) void colsum_kernel(const float* __restrict__ x
     if (rl == 0 && c < N) unsafeAtomicAdd(out + c, sh[0][threadIdx.x] + sh[1][threadIdx.x] + sh[2][threadIdx.x] + sh[3][threadIdx.x]);
 }
 
+// vector variant (16-byte aligned rows, N % 4 == 0): a block covers up to 64 column QUADS x RL row lanes and a row range sized
+// so that the grid has ~1024 blocks; float4 loads (a wave reads whole 1 KB row pieces), one fp32 atomic per column per block
+__global__ __launch_bounds__(256) void colsum_vec_kernel(const float* __restrict__ x, long long ld4, int M, int N4, int rows_per_block,
+                                                         float* out) {
+    __shared__ float4 sh[256];
+    const int QB = min(N4, 64), RL = 256 / QB;
+    const int q = threadIdx.x % QB, rl = threadIdx.x / QB;
+    const int cq = blockIdx.x * 64 + q;
+    const int r0 = blockIdx.y * rows_per_block, r1 = min(M, r0 + rows_per_block);
+    float4 s = make_float4(0.f, 0.f, 0.f, 0.f);
+    if (cq < N4 && rl < RL) {
+#pragma unroll 4
+        for (int r = r0 + rl; r < r1; r += RL) {
+            const float4 v = reinterpret_cast<const float4*>(x)[(long long)r * ld4 + cq];
+            s.x += v.x; s.y += v.y; s.z += v.z; s.w += v.w;
+        }
+    }
+    sh[threadIdx.x] = s;
+    __syncthreads();
+    if (rl == 0 && cq < N4) {
+        float4 a = sh[q];
+        for (int l = 1; l < RL; ++l) { const float4 v = sh[l * QB + q]; a.x += v.x; a.y += v.y; a.z += v.z; a.w += v.w; }
+        unsafeAtomicAdd(out + cq * 4 + 0, a.x); unsafeAtomicAdd(out + cq * 4 + 1, a.y);
+        unsafeAtomicAdd(out + cq * 4 + 2, a.z); unsafeAtomicAdd(out + cq * 4 + 3, a.w);
+    }
+}
+
 // plain row softmax for the returned class probabilities ([rows, cols], cols small)
 __global__ void row_softmax_kernel(const float* __restrict__ x, int rows, int cols, float* __restrict__ y) {
     const int r = blockIdx.x * blockDim.x + threadIdx.x;
@@ -511,7 +538,17 @@ extern "C" int vbg_colsum(const float* x, long long ld, int M, int N, float* out
         if (e != hipSuccess) return (int)e;
     }
     if (M == 0) return VBG_OK;
-    VBG_LAUNCH(colsum_kernel, dim3(cdiv(N, 64), cdiv(M, 256)), dim3(256), 0, s, x, ld, M, N, out);
+    const int N4 = N / 4;
+    const bool quads_ok = N % 4 == 0 && (N4 <= 64 ? (256 % N4 == 0) : true);
+    if (quads_ok && ld % 4 == 0 && ((uintptr_t)x % 16 == 0)) {
+        const int QB = N4 < 64 ? N4 : 64, RL = 256 / QB, CG = cdiv(N4, 64);
+        long long rpb = cdiv((long long)M * CG, 1024);
+        if (rpb < 4 * RL) rpb = 4 * RL;
+        rpb = cdiv(rpb, RL) * RL;
+        VBG_LAUNCH(colsum_vec_kernel, dim3(CG, cdiv(M, rpb)), dim3(256), 0, s, x, ld / 4, M, N4, (int)rpb, out);
+    } else {
+        VBG_LAUNCH(colsum_kernel, dim3(cdiv(N, 64), cdiv(M, 256)), dim3(256), 0, s, x, ld, M, N, out);
+    }
     VBG_LAUNCH_RET();
 }
 
