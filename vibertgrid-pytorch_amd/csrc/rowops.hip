@@ -380,7 +380,7 @@ __global__ __launch_bounds__(256) void colsum_kernel(const float* __restrict__ x
 }
 
 // vector variant (16-byte aligned rows, N % 4 == 0): a block covers up to 64 column QUADS x RL row lanes and a row range sized
-// so that the grid has ~1024 blocks; float4 loads (a wave reads whole 1 KB row pieces), one fp32 atomic per column per block
+// so that the grid has ~192 blocks; float4 loads (a wave reads whole 1 KB row pieces), one fp32 atomic per column per block
 __global__ __launch_bounds__(256) void colsum_vec_kernel(const float* __restrict__ x, long long ld4, int M, int N4, int rows_per_block,
                                                          float* out) {
     __shared__ float4 sh[256];
@@ -542,7 +542,7 @@ extern "C" int vbg_colsum(const float* x, long long ld, int M, int N, float* out
     const bool quads_ok = N % 4 == 0 && (N4 <= 64 ? (256 % N4 == 0) : true);
     if (quads_ok && ld % 4 == 0 && ((uintptr_t)x % 16 == 0)) {
         const int QB = N4 < 64 ? N4 : 64, RL = 256 / QB, CG = cdiv(N4, 64);
-        long long rpb = cdiv((long long)M * CG, 1024);
+        long long rpb = cdiv((long long)M * CG, 192);       // ~192 blocks: the same-address atomics, not the loads, set the time (sweep: 128..2048)
         if (rpb < 4 * RL) rpb = 4 * RL;
         rpb = cdiv(rpb, RL) * RL;
         VBG_LAUNCH(colsum_vec_kernel, dim3(CG, cdiv(M, rpb)), dim3(256), 0, s, x, ld / 4, M, N4, (int)rpb, out);
