@@ -113,10 +113,13 @@ int vbg_embed_ln_bwd(const float* dout, const float* xhat, const float* rstd, co
 int vbg_dropout_add_ln_fwd(const float* x, const float* res, int rows, int hidden, const float* gamma,
                            const float* beta, float eps, float drop_p, unsigned long long seed,
                            unsigned long long stream_id, float* y, float* xhat, float* rstd, void* stream);
-/* dx (to the dense output), dres (added into `dres_accum` if accumulate else written), dgamma/dbeta += */
+/* dx (to the dense output), dres, dgamma/dbeta +=.  `slots_ws` (optional): fp32 [vbg_ln_slots()][2][hidden] workspace that is ZERO
+ * on entry and left zero on exit; with it the per-block column sums are spread over the slot rows and folded by a second tiny
+ * launch (same-address atomics serialise: ~500 blocks per column at cfg2), without it they go straight into dgamma/dbeta */
+int vbg_ln_slots(void);
 int vbg_dropout_add_ln_bwd(const float* dy, const float* xhat, const float* rstd, int rows, int hidden,
                            const float* gamma, float drop_p, unsigned long long seed, unsigned long long stream_id,
-                           float* dx, float* dres, float* dgamma, float* dbeta, void* stream);
+                           float* dx, float* dres, float* dgamma, float* dbeta, float* slots_ws, void* stream);
 /* attention probabilities, in place on the grouped score buffer: for group g (= seq*heads + head)
  * rows L=len[g/heads], row stride ldp[g/heads], block offset off[g]; P = softmax(S*scale);
  * dropped entries are stored NEGATED (sign bit = dropped), kept entries unscaled; pad columns = 0. */

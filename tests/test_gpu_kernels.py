@@ -229,8 +229,9 @@ def test_embed_ln(ops):
     assert close(dg, gam.grad, 1e-3, 1e-3) and close(db, bet.grad, 1e-3, 1e-3)
 
 
-def test_dropout_add_ln(ops):
-    rows, Hd = 133, 768
+@pytest.mark.parametrize("rows,Hd", [(133, 768), (1037, 768), (600, 256)])
+def test_dropout_add_ln(ops, rows, Hd):
+    """rows >= 512 takes the slot-workspace path of the backward (column sums spread over slot rows, folded, workspace left zero)"""
     x, r = rnd(rows, Hd, seed=50).requires_grad_(True), rnd(rows, Hd, seed=51).requires_grad_(True)
     gam, bet = (1 + 0.1 * rnd(Hd, seed=52)).requires_grad_(True), rnd(Hd, seed=53).requires_grad_(True)
     y = F.layer_norm(x + r, (Hd,), gam, bet, 1e-12)
@@ -243,6 +244,10 @@ def test_dropout_add_ln(ops):
     dx, dres = ops.dropout_add_ln_bwd(gy.to(d), xhat, rstd, gam.detach().to(d), 0.0, 1, 0, dg, db)
     assert close(dx, x.grad, 1e-3, 1e-5) and close(dres, r.grad, 1e-3, 1e-5)
     assert close(dg, gam.grad, 1e-3, 1e-3) and close(db, bet.grad, 1e-3, 1e-3)
+    # a second call accumulates into dgamma / dbeta and finds the workspace clean
+    ops.dropout_add_ln_bwd(gy.to(d), xhat, rstd, gam.detach().to(d), 0.0, 1, 0, dg, db)
+    assert close(dg, 2 * gam.grad, 1e-3, 2e-3) and close(db, 2 * bet.grad, 1e-3, 2e-3)
+    assert all(float(w.abs().max()) == 0.0 for w in ops._LN_WS.values())
     # dropout: same mask forward and backward, keep rate ~ 1-p, kept values scaled by 1/(1-p)
     p = 0.1
     one = torch.ones(rows, Hd, device=d)

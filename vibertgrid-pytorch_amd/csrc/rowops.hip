@@ -132,6 +132,7 @@ __global__ __launch_bounds__(LN_THREADS) void embed_ln_bwd_kernel(
 // dgamma / dbeta partial sums of its columns in registers across all its rows, one atomic per column per wave).
 constexpr int LN_V = 4;            // max float4 per lane (hidden <= 1024)
 constexpr int LN_WROWS = 2;        // rows per wave in the backward kernel (8 rows per block -> >= 2 blocks per CU at cfg2)
+constexpr int LN_SLOTS = 32;       // slot rows of the dgamma / dbeta workspace
 
 __device__ __forceinline__ float4 drop4(float4 v, uint32_t thr, float ks, uint64_t seed, uint64_t sid, uint64_t idx) {
     if (thr) {
@@ -189,7 +190,7 @@ __global__ __launch_bounds__(256) void dropout_add_ln_fwd_kernel(
 __global__ __launch_bounds__(256) void dropout_add_ln_bwd_kernel(
     const float* __restrict__ dy, const float* __restrict__ xhat, const float* __restrict__ rstd, int rows, int hidden,
     const float* __restrict__ gamma, uint32_t drop_thr, float keep_scale, uint64_t seed, uint64_t sid,
-    float* __restrict__ dx, float* __restrict__ dres, float* dgamma, float* dbeta) {
+    float* __restrict__ dx, float* __restrict__ dres, float* dgamma, float* dbeta, float* slots) {
     const int lane = threadIdx.x & 63;
     const int nv = hidden >> 8;
     const int t0 = (blockIdx.x * 4 + (threadIdx.x >> 6)) * LN_WROWS;
@@ -239,10 +240,27 @@ __global__ __launch_bounds__(256) void dropout_add_ln_bwd_kernel(
             *reinterpret_cast<float4*>(&red[1][w][c]) = ab[j];
         }
     __syncthreads();
+    // same-address atomics serialise (~516 blocks at cfg2): with a slot workspace the block sums land in one of LN_SLOTS slot
+    // rows and ln_fold_kernel adds the slots into dgamma / dbeta (and clears them for the next call)
+    float* dg = slots ? slots + (size_t)(blockIdx.x % LN_SLOTS) * 2 * hidden : dgamma;
+    float* db = slots ? dg + hidden : dbeta;
     for (int c = threadIdx.x; c < hidden; c += 256) {
-        unsafeAtomicAdd(dgamma + c, (red[0][0][c] + red[0][1][c]) + (red[0][2][c] + red[0][3][c]));
-        unsafeAtomicAdd(dbeta + c, (red[1][0][c] + red[1][1][c]) + (red[1][2][c] + red[1][3][c]));
+        unsafeAtomicAdd(dg + c, (red[0][0][c] + red[0][1][c]) + (red[0][2][c] + red[0][3][c]));
+        unsafeAtomicAdd(db + c, (red[1][0][c] + red[1][1][c]) + (red[1][2][c] + red[1][3][c]));
     }
+}
+
+__global__ void ln_fold_kernel(float* __restrict__ slots, int hidden, float* dgamma, float* dbeta) {
+    const int c = blockIdx.x * blockDim.x + threadIdx.x;
+    if (c >= 2 * hidden) return;
+    float v[4] = {0.f, 0.f, 0.f, 0.f};
+#pragma unroll 2
+    for (int s = 0; s < LN_SLOTS; s += 4) {
+#pragma unroll
+        for (int j = 0; j < 4; ++j) { v[j] += slots[(size_t)(s + j) * 2 * hidden + c]; slots[(size_t)(s + j) * 2 * hidden + c] = 0.f; }
+    }
+    const float t = (v[0] + v[1]) + (v[2] + v[3]);
+    if (c < hidden) dgamma[c] += t; else dbeta[c - hidden] += t;
 }
 
 // ------------------------------------------------------------------------------------------
@@ -470,13 +488,14 @@ extern "C" int vbg_dropout_add_ln_fwd(const float* x, const float* res, int rows
 
 extern "C" int vbg_dropout_add_ln_bwd(const float* dy, const float* xhat, const float* rstd, int rows, int hidden,
                                       const float* gamma, float drop_p, unsigned long long seed, unsigned long long sid,
-                                      float* dx, float* dres, float* dgamma, float* dbeta, void* stream) {
+                                      float* dx, float* dres, float* dgamma, float* dbeta, float* slots_ws, void* stream) {
     VBG_CHECK_ARG(dy && xhat && rstd && gamma && dx && dres && dgamma && dbeta);
     VBG_CHECK_ARG(hidden > 0 && hidden % 256 == 0 && hidden <= 256 * LN_V && drop_p >= 0.f && drop_p < 1.f);
     VBG_CHECK_ARG(((uintptr_t)dy | (uintptr_t)xhat | (uintptr_t)gamma | (uintptr_t)dx | (uintptr_t)dres) % 16 == 0);
     if (rows <= 0) return VBG_OK;
     VBG_LAUNCH(dropout_add_ln_bwd_kernel, dim3(cdiv(rows, 4 * LN_WROWS)), dim3(256), 0, (hipStream_t)stream, dy, xhat, rstd, rows,
-               hidden, gamma, drop_threshold(drop_p), 1.0f / (1.0f - drop_p), seed, sid, dx, dres, dgamma, dbeta);
+               hidden, gamma, drop_threshold(drop_p), 1.0f / (1.0f - drop_p), seed, sid, dx, dres, dgamma, dbeta, slots_ws);
+    if (slots_ws) VBG_LAUNCH(ln_fold_kernel, dim3(cdiv(2 * hidden, 256)), dim3(256), 0, (hipStream_t)stream, slots_ws, hidden, dgamma, dbeta);
     VBG_LAUNCH_RET();
 }
 
@@ -559,5 +578,7 @@ extern "C" int vbg_row_softmax(const float* x, int rows, int cols, float* y, voi
     VBG_LAUNCH(row_softmax_kernel, dim3(cdiv(rows, 256)), dim3(256), 0, (hipStream_t)stream, x, rows, cols, y);
     VBG_LAUNCH_RET();
 }
+
+extern "C" int vbg_ln_slots(void) { return LN_SLOTS; }
 
 extern "C" int vbg_version(void) { return VBG_VERSION; }

@@ -52,7 +52,8 @@ SIGNATURES = {
     "vbg_embed_ln_fwd": (c_int, [c_vp, c_vp, c_int, c_int, c_vp, c_vp, c_vp, c_vp, c_vp, c_f, c_f, c_ull, c_ull, c_vp, c_vp, c_vp, c_vp]),
     "vbg_embed_ln_bwd": (c_int, [c_vp, c_vp, c_vp, c_vp, c_vp, c_int, c_int, c_vp, c_f, c_ull, c_ull, c_vp, c_vp, c_vp, c_vp, c_vp, c_vp]),
     "vbg_dropout_add_ln_fwd": (c_int, [c_vp, c_vp, c_int, c_int, c_vp, c_vp, c_f, c_f, c_ull, c_ull, c_vp, c_vp, c_vp, c_vp]),
-    "vbg_dropout_add_ln_bwd": (c_int, [c_vp, c_vp, c_vp, c_int, c_int, c_vp, c_f, c_ull, c_ull, c_vp, c_vp, c_vp, c_vp, c_vp]),
+    "vbg_ln_slots": (c_int, []),
+    "vbg_dropout_add_ln_bwd": (c_int, [c_vp, c_vp, c_vp, c_int, c_int, c_vp, c_f, c_ull, c_ull, c_vp, c_vp, c_vp, c_vp, c_vp, c_vp]),
     "vbg_softmax_fwd": (c_int, [c_vp, c_vp, c_vp, c_vp, c_int, c_int, c_int, c_f, c_f, c_ull, c_ull, c_vp]),
     "vbg_softmax_bwd": (c_int, [c_vp, c_vp, c_vp, c_vp, c_vp, c_int, c_int, c_int, c_f, c_f, c_vp]),
     "vbg_row_softmax": (c_int, [c_vp, c_int, c_int, c_vp, c_vp]),

@@ -304,12 +304,25 @@ def dropout_add_ln_fwd(x, res, gamma, beta, eps, p, seed, sid):
     return y, xhat, rstd
 
 
+_LN_WS = {}
+
+
+def _ln_workspace(device, hidden):
+    """persistent zero workspace of the LayerNorm backward (the kernel pair leaves it zero again); one per device and stream"""
+    key = (device, hidden, torch.cuda.current_stream(device).cuda_stream)
+    ws = _LN_WS.get(key)
+    if ws is None:
+        ws = _LN_WS[key] = torch.zeros((int(lib.vbg_ln_slots()) * 2 * hidden,), device=device, dtype=f32)
+    return ws
+
+
 def dropout_add_ln_bwd(dy, xhat, rstd, gamma, p, seed, sid, dgamma, dbeta):
     rows, hidden = xhat.shape
     dx = torch.empty_like(xhat)
     dres = torch.empty_like(xhat)
+    ws = _ln_workspace(xhat.device, hidden) if rows >= 512 else None
     check(lib.vbg_dropout_add_ln_bwd(P(dy), P(xhat), P(rstd), rows, hidden, P(gamma), p, seed, sid, P(dx), P(dres), P(dgamma),
-                                     P(dbeta), _stream()), "vbg_dropout_add_ln_bwd")
+                                     P(dbeta), P(ws), _stream()), "vbg_dropout_add_ln_bwd")
     return dx, dres
 
 
