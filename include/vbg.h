@@ -166,7 +166,9 @@ int vbg_label_raster(const int* owner, const int* seg_class, long long ncell, in
  * a6-a9, a11. convolution trunk helpers (NHWC): BatchNorm (Sync-able), max-pool, FPN resampling
  * ------------------------------------------------------------------------------------------ */
 /* The two reductions below spread their fp64 partial sums over vbg_bn_slots() SLOT ROWS of 2*C doubles (same-address
- * atomics serialise; consumers fold the slots): `slots_accum` is [vbg_bn_slots()][2*C], zeroed by the caller. */
+ * atomics serialise; consumers fold the slots): `slots_accum` is [vbg_bn_slots()][2*C], zero on entry.  The folding entry
+ * points take `clear_slots`: non-zero = zero the slot rows behind the read, so one persistent workspace serves every layer
+ * without fill launches. */
 int vbg_bn_slots(void);
 /* per-channel sum / sum of squares over rows of x[M,C] (torch.nn.BatchNorm2d training statistics,
  * model/ResNetFPN_ViBERTgrid.py:116-123): slot[s][0..C) += sum, slot[s][C..2C) += sumsq */
@@ -174,7 +176,7 @@ int vbg_bn_stats(const float* x, long long M, int C, double* slots_accum, void* 
 /* from sums over `count` rows held in `nslots` slot rows (nslots = 1: already folded, e.g. after a SyncBN all-reduce;
  * count_dev, if non-NULL, is a device scalar that overrides `count`: the all-reduced row count): mean, invstd;
  * running <- (1-mom)*running + mom*{mean, unbiased var} */
-int vbg_bn_finalize(const double* stats, int nslots, double count, const double* count_dev, int C, float eps, float momentum,
+int vbg_bn_finalize(double* stats, int nslots, int clear_slots, double count, const double* count_dev, int C, float eps, float momentum,
                     float* mean, float* invstd, float* running_mean, float* running_var, void* stream);
 /* y = relu?( (x-mean)*invstd*gamma + beta (+ res) ) */
 int vbg_bn_apply(const float* x, const float* res, long long M, int C, const float* mean, const float* invstd,
@@ -192,7 +194,7 @@ int vbg_bn_bwd_apply(const float* dy, const float* y, const float* x, long long 
    gradients from these LOCAL sums: dbeta += (float)folded[0..C), dgamma += (float)folded[C..2C)  (call before a SyncBN
    all-reduce of `folded`; torch.nn.SyncBatchNorm leaves weight/bias gradients per-rank for DDP to average,
    model/ResNetFPN_ViBERTgrid.py:196-206 `norm_layer`) */
-int vbg_bn_param_grad(const double* slots, int nslots, int C, double* folded, float* dgamma_accum, float* dbeta_accum,
+int vbg_bn_param_grad(double* slots, int nslots, int clear_slots, int C, double* folded, float* dgamma_accum, float* dbeta_accum,
                       void* stream);
 int vbg_maxpool3x3s2_fwd(const float* x, int B, int H, int W, int C, float* y, int* argmax, void* stream);
 int vbg_maxpool3x3s2_bwd(const float* dy, const int* argmax, int B, int Ho, int Wo, int C, int H, int W,

@@ -446,7 +446,9 @@ def test_batchnorm(ops, relu, res, shape):
     stats = ops.bn_stats(x2)
     rmd, rvd = torch.zeros(C_, device=d), torch.ones(C_, device=d)
     mean, invstd = ops.bn_finalize(stats, C_, ops.bn_slots(), x2.shape[0], 1e-5, 0.1, rmd, rvd)
-    folded = ops.bn_fold(stats, C_)
+    assert float(stats.abs().max()) == 0.0                       # the slot workspace is cleared behind the read
+    folded = ops.bn_fold(ops.bn_stats(x2), C_)
+    assert float(stats.abs().max()) == 0.0
     assert close(folded[:C_].float() / x2.shape[0], x.detach().mean((0, 2, 3)), 1e-5, 1e-6)
     m1, i1 = ops.bn_finalize(folded, C_, 1, x2.shape[0], 1e-5, 0.1, None, None)          # the SyncBN route: folded sums, one slot
     assert torch.equal(m1, mean) and torch.equal(i1, invstd)

@@ -91,7 +91,9 @@ static inline int bn_rows_per_block(long long M, int C) {
     return (int)r;
 }
 
-__device__ __forceinline__ double fold_slots(const double* __restrict__ slots, int nslots, int C, int idx) {
+// sum of one column over the slot rows; with `clear` the slots are zeroed behind the read, so a persistent workspace is ready
+// for the next reduction without a fill launch
+__device__ __forceinline__ double fold_slots(double* __restrict__ slots, int nslots, int C, int idx, bool clear) {
     double v[4] = {0.0, 0.0, 0.0, 0.0};          // independent loads, all in flight together
     int s = 0;
 #pragma unroll 2
@@ -100,17 +102,19 @@ __device__ __forceinline__ double fold_slots(const double* __restrict__ slots, i
         for (int j = 0; j < 4; ++j) v[j] += slots[(size_t)(s + j) * 2 * C + idx];
     }
     for (; s < nslots; ++s) v[0] += slots[(size_t)s * 2 * C + idx];
+    if (clear)
+        for (s = 0; s < nslots; ++s) slots[(size_t)s * 2 * C + idx] = 0.0;
     return (v[0] + v[1]) + (v[2] + v[3]);
 }
 
-__global__ void bn_finalize_kernel(const double* __restrict__ stats, int nslots, double count, const double* __restrict__ count_dev, int C,
+__global__ void bn_finalize_kernel(double* __restrict__ stats, int nslots, int clear, double count, const double* __restrict__ count_dev, int C,
                                    float eps, float momentum, float* mean, float* invstd, float* running_mean,
                                    float* running_var) {
     const int c = blockIdx.x * blockDim.x + threadIdx.x;
     if (c >= C) return;
     if (count_dev) count = count_dev[0];
-    const double m = fold_slots(stats, nslots, C, c) / count;
-    double var = fold_slots(stats, nslots, C, C + c) / count - m * m;
+    const double m = fold_slots(stats, nslots, C, c, clear) / count;
+    double var = fold_slots(stats, nslots, C, C + c, clear) / count - m * m;
     if (var < 0.0) var = 0.0;
     mean[c] = (float)m;
     invstd[c] = (float)(1.0 / sqrt(var + (double)eps));
@@ -175,11 +179,11 @@ __global__ void bn_bwd_apply_kernel(const float* __restrict__ dy, const float* _
     }
 }
 
-__global__ void bn_param_grad_kernel(const double* __restrict__ slots, int nslots, int C, double* __restrict__ folded, float* dgamma,
+__global__ void bn_param_grad_kernel(double* __restrict__ slots, int nslots, int clear, int C, double* __restrict__ folded, float* dgamma,
                                      float* dbeta) {
     const int c = blockIdx.x * blockDim.x + threadIdx.x;
     if (c >= C) return;
-    const double sg = fold_slots(slots, nslots, C, c), sgx = fold_slots(slots, nslots, C, C + c);
+    const double sg = fold_slots(slots, nslots, C, c, clear), sgx = fold_slots(slots, nslots, C, C + c, clear);
     if (folded) { folded[c] = sg; folded[C + c] = sgx; }
     if (dbeta) dbeta[c] += (float)sg;
     if (dgamma) dgamma[c] += (float)sgx;
@@ -413,11 +417,11 @@ extern "C" int vbg_bn_stats(const float* x, long long M, int C, double* stats_ac
 
 extern "C" int vbg_bn_slots(void) { return BN_SLOTS; }
 
-extern "C" int vbg_bn_finalize(const double* stats, int nslots, double count, const double* count_dev, int C, float eps, float momentum,
+extern "C" int vbg_bn_finalize(double* stats, int nslots, int clear_slots, double count, const double* count_dev, int C, float eps, float momentum,
                                float* mean, float* invstd, float* running_mean, float* running_var, void* stream) {
     VBG_CHECK_ARG(stats && nslots >= 1 && mean && invstd && C > 0 && (count > 0 || count_dev) &&
                   ((running_mean == nullptr) == (running_var == nullptr)));
-    VBG_LAUNCH(bn_finalize_kernel, dim3(cdiv(C, 256)), dim3(256), 0, S_, stats, nslots, count, count_dev, C, eps, momentum, mean,
+    VBG_LAUNCH(bn_finalize_kernel, dim3(cdiv(C, 256)), dim3(256), 0, S_, stats, nslots, clear_slots, count, count_dev, C, eps, momentum, mean,
                        invstd, running_mean, running_var);
     VBG_LAUNCH_RET();
 }
@@ -455,14 +459,14 @@ extern "C" int vbg_bn_bwd_apply(const float* dy, const float* y, const float* x,
     if (M > 0) VBG_LAUNCH(bn_bwd_apply_kernel, dim3(ew_grid(M * (C / 4), 256)), dim3(256), 0, S_, dy, y, x, M, C / 4, C, mean, invstd,
                           gamma, sums, count, count_dev, relu, dx, dres);
     if (dgamma_accum && dbeta_accum)
-        VBG_LAUNCH(bn_param_grad_kernel, dim3(cdiv(C, 256)), dim3(256), 0, S_, sums, 1, C, (double*)nullptr, dgamma_accum, dbeta_accum);
+        VBG_LAUNCH(bn_param_grad_kernel, dim3(cdiv(C, 256)), dim3(256), 0, S_, const_cast<double*>(sums), 1, 0, C, (double*)nullptr, dgamma_accum, dbeta_accum);
     VBG_LAUNCH_RET();
 }
 
-extern "C" int vbg_bn_param_grad(const double* slots, int nslots, int C, double* folded, float* dgamma_accum, float* dbeta_accum,
-                                 void* stream) {
+extern "C" int vbg_bn_param_grad(double* slots, int nslots, int clear_slots, int C, double* folded, float* dgamma_accum,
+                                 float* dbeta_accum, void* stream) {
     VBG_CHECK_ARG(slots && nslots >= 1 && C > 0 && ((dgamma_accum == nullptr) == (dbeta_accum == nullptr)) && (folded || dgamma_accum));
-    VBG_LAUNCH(bn_param_grad_kernel, dim3(cdiv(C, 256)), dim3(256), 0, S_, slots, nslots, C, folded, dgamma_accum, dbeta_accum);
+    VBG_LAUNCH(bn_param_grad_kernel, dim3(cdiv(C, 256)), dim3(256), 0, S_, slots, nslots, clear_slots, C, folded, dgamma_accum, dbeta_accum);
     VBG_LAUNCH_RET();
 }
 

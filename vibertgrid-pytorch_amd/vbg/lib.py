@@ -69,11 +69,11 @@ SIGNATURES = {
     "vbg_label_raster": (c_int, [c_vp, c_vp, c_ll, c_vp, c_vp, c_vp]),
     "vbg_bn_stats": (c_int, [c_vp, c_ll, c_int, c_vp, c_vp]),
     "vbg_bn_slots": (c_int, []),
-    "vbg_bn_finalize": (c_int, [c_vp, c_int, c_d, c_vp, c_int, c_f, c_f, c_vp, c_vp, c_vp, c_vp, c_vp]),
+    "vbg_bn_finalize": (c_int, [c_vp, c_int, c_int, c_d, c_vp, c_int, c_f, c_f, c_vp, c_vp, c_vp, c_vp, c_vp]),
     "vbg_bn_apply": (c_int, [c_vp, c_vp, c_ll, c_int, c_vp, c_vp, c_vp, c_vp, c_int, c_vp, c_vp]),
     "vbg_bn_bwd_reduce": (c_int, [c_vp, c_vp, c_vp, c_ll, c_int, c_vp, c_vp, c_int, c_vp, c_vp]),
     "vbg_bn_bwd_apply": (c_int, [c_vp, c_vp, c_vp, c_ll, c_int, c_vp, c_vp, c_vp, c_vp, c_d, c_vp, c_int, c_vp, c_vp, c_vp, c_vp, c_vp]),
-    "vbg_bn_param_grad": (c_int, [c_vp, c_int, c_int, c_vp, c_vp, c_vp, c_vp]),
+    "vbg_bn_param_grad": (c_int, [c_vp, c_int, c_int, c_int, c_vp, c_vp, c_vp, c_vp]),
     "vbg_maxpool3x3s2_fwd": (c_int, [c_vp, c_int, c_int, c_int, c_int, c_vp, c_vp, c_vp]),
     "vbg_maxpool3x3s2_bwd": (c_int, [c_vp, c_vp, c_int, c_int, c_int, c_int, c_int, c_int, c_vp, c_vp]),
     "vbg_avgpool2_fwd": (c_int, [c_vp, c_int, c_int, c_int, c_int, c_vp, c_vp]),

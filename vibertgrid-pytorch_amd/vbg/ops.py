@@ -417,27 +417,41 @@ def bn_slots():
     return _BN_SLOTS[0]
 
 
-def bn_stats(x2d, extra=0):
-    """-> zero-initialised-then-accumulated slot rows [slots*2C (+extra)] fp64 (per-channel sum, sum of squares)"""
+_BN_WS = {}
+
+
+def _bn_workspace(device, C_):
+    """persistent zero slot rows [slots*2C] fp64 (one per device, stream and width): every reduction that writes into it is folded
+    -- and the slots cleared again -- by the very next launch (bn_finalize / bn_fold / bn_param_grad), so no per-layer fills"""
+    key = (device, C_, torch.cuda.current_stream(device).cuda_stream)
+    ws = _BN_WS.get(key)
+    if ws is None:
+        ws = _BN_WS[key] = torch.zeros((bn_slots() * 2 * C_,), device=device, dtype=torch.float64)
+    return ws
+
+
+def bn_stats(x2d):
+    """per-channel (sum, sum of squares) partials in the persistent slot workspace; MUST be consumed by bn_finalize / bn_fold next"""
     M, C_ = x2d.shape
-    stats = torch.zeros((bn_slots() * 2 * C_ + extra,), device=x2d.device, dtype=torch.float64)
+    stats = _bn_workspace(x2d.device, C_)
     check(lib.vbg_bn_stats(P(x2d), M, C_, P(stats), _stream()), "vbg_bn_stats")
     return stats
 
 
 def bn_fold(slots, C_, out=None):
-    """sum the slot rows -> [2C] fp64"""
+    """sum the slot rows -> [2C] fp64 (and clear them)"""
     if out is None:
         out = torch.empty((2 * C_,), device=slots.device, dtype=torch.float64)
-    check(lib.vbg_bn_param_grad(P(slots), bn_slots(), C_, P(out), None, None, _stream()), "vbg_bn_param_grad")
+    check(lib.vbg_bn_param_grad(P(slots), bn_slots(), 1, C_, P(out), None, None, _stream()), "vbg_bn_param_grad")
     return out
 
 
 def bn_finalize(stats, C_, nslots, count, eps, momentum, running_mean, running_var, count_dev=None):
+    """nslots > 1: `stats` is the slot workspace (cleared behind the read); nslots == 1: already folded sums"""
     mean = torch.empty((C_,), device=stats.device, dtype=f32)
     invstd = torch.empty_like(mean)
-    check(lib.vbg_bn_finalize(P(stats), int(nslots), float(count), P(count_dev), C_, eps, momentum, P(mean), P(invstd), P(running_mean),
-                              P(running_var), _stream()), "vbg_bn_finalize")
+    check(lib.vbg_bn_finalize(P(stats), int(nslots), int(nslots > 1), float(count), P(count_dev), C_, eps, momentum, P(mean), P(invstd),
+                              P(running_mean), P(running_var), _stream()), "vbg_bn_finalize")
     return mean, invstd
 
 
@@ -450,9 +464,9 @@ def bn_apply(x2d, res2d, mean, invstd, gamma, beta, relu, out=None):
 
 
 def bn_bwd_reduce(dy, y, x, mean, invstd, relu):
-    """-> slot rows [slots*2C] fp64 of (sum g, sum g*xhat)"""
+    """(sum g, sum g*xhat) partials in the persistent slot workspace; MUST be consumed by bn_param_grad next"""
     M, C_ = x.shape
-    sums = torch.zeros((bn_slots() * 2 * C_,), device=x.device, dtype=torch.float64)
+    sums = _bn_workspace(x.device, C_)
     check(lib.vbg_bn_bwd_reduce(P(dy), P(y), P(x), M, C_, P(mean), P(invstd), int(relu), P(sums), _stream()), "vbg_bn_bwd_reduce")
     return sums
 
@@ -467,9 +481,9 @@ def bn_bwd_apply(dy, y, x, mean, invstd, gamma, sums, count, relu, want_dres, dg
 
 
 def bn_param_grad(slots, C_, dgamma, dbeta):
-    """fold the slot rows (-> [2C] fp64, returned) and accumulate the affine gradients from them"""
+    """fold the slot rows (-> [2C] fp64, returned; slots cleared) and accumulate the affine gradients from them"""
     folded = torch.empty((2 * C_,), device=slots.device, dtype=torch.float64)
-    check(lib.vbg_bn_param_grad(P(slots), bn_slots(), C_, P(folded), P(dgamma), P(dbeta), _stream()), "vbg_bn_param_grad")
+    check(lib.vbg_bn_param_grad(P(slots), bn_slots(), 1, C_, P(folded), P(dgamma), P(dbeta), _stream()), "vbg_bn_param_grad")
     return folded
 
 
