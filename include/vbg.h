@@ -197,8 +197,9 @@ int vbg_bn_bwd_apply(const float* dy, const float* y, const float* x, long long 
 int vbg_bn_param_grad(double* slots, int nslots, int clear_slots, int C, double* folded, float* dgamma_accum, float* dbeta_accum,
                       void* stream);
 int vbg_maxpool3x3s2_fwd(const float* x, int B, int H, int W, int C, float* y, int* argmax, void* stream);
+/* bwd: every dx element is WRITTEN (gather over the <= 4 windows that contain it; no atomics, no zero fill needed) */
 int vbg_maxpool3x3s2_bwd(const float* dy, const int* argmax, int B, int Ho, int Wo, int C, int H, int W,
-                         float* dx_zeroed, void* stream);
+                         float* dx, void* stream);
 /* nn.AvgPool2d(2, 2) of the ResNet-D projection shortcut (model/ResNetFPN_ViBERTgrid.py:222-236): x [B,H,W,C] ->
  * y [B,H/2,W/2,C] (floor); bwd: dx [B,H,W,C] = dy/4 over each 2x2 window, 0 on a dropped trailing row / column */
 int vbg_avgpool2_fwd(const float* x, int B, int H, int W, int C, float* y, void* stream);

@@ -217,13 +217,33 @@ __global__ void maxpool_fwd_kernel(const float* __restrict__ x, int B, int H, in
     }
 }
 
-__global__ void maxpool_bwd_kernel(const float* __restrict__ dy, const int* __restrict__ argmax, int HoWo, int C, int HW,
-                                   long long total, float* dx) {
+// gather form: an input pixel belongs to at most 2 x 2 windows of the 3x3 / stride 2 / pad 1 pooling (rows floor(y/2) and, for odd
+// y, floor(y/2) + 1); it receives the gradient of every window whose recorded argmax it is.  No atomics, every dx element is
+// written exactly once (the destination needs no zero fill).
+__global__ void maxpool_bwd_kernel(const float* __restrict__ dy, const int* __restrict__ argmax, int B, int Ho, int Wo, int C4, int H,
+                                   int W, float* __restrict__ dx) {
+    const long long total = (long long)B * H * W * C4;
     const long long stride = (long long)gridDim.x * blockDim.x;
     for (long long i = (long long)blockIdx.x * blockDim.x + threadIdx.x; i < total; i += stride) {
-        const int c = (int)(i % C);
-        const long long b = i / ((long long)HoWo * C);
-        unsafeAtomicAdd(dx + (b * HW + argmax[i]) * C + c, dy[i]);
+        const int c4 = (int)(i % C4);
+        long long t = i / C4;
+        const int x = (int)(t % W); t /= W;
+        const int y = (int)(t % H);
+        const int b = (int)(t / H);
+        const int me = y * W + x;
+        float4 g = make_float4(0.f, 0.f, 0.f, 0.f);
+        for (int oy = y >> 1; oy <= ((y + 1) >> 1); ++oy) {
+            if (oy >= Ho) continue;
+            for (int ox = x >> 1; ox <= ((x + 1) >> 1); ++ox) {
+                if (ox >= Wo) continue;
+                const long long o = (((long long)b * Ho + oy) * Wo + ox) * C4 + c4;
+                const int4 am = reinterpret_cast<const int4*>(argmax)[o];
+                const float4 d = reinterpret_cast<const float4*>(dy)[o];
+                g.x += am.x == me ? d.x : 0.f; g.y += am.y == me ? d.y : 0.f;
+                g.z += am.z == me ? d.z : 0.f; g.w += am.w == me ? d.w : 0.f;
+            }
+        }
+        reinterpret_cast<float4*>(dx)[i] = g;
     }
 }
 
@@ -379,23 +399,29 @@ __global__ void rescale_boxes_kernel(const long long* __restrict__ in, int n, fl
 
 __global__ void im2col_kernel(const float* __restrict__ x, int B, int H, int W, int C, int kh, int kw, int stride, int pad,
                               int Ho, int Wo, int Kpad, float* __restrict__ out) {
-    const long long total = (long long)B * Ho * Wo * Kpad;
+    // one thread per (output pixel, 4 consecutive k): the pixel is decoded once, the row is written as float4 (Kpad % 4 == 0)
+    const int KQ = Kpad >> 2, K = kh * kw * C;
+    const long long total = (long long)B * Ho * Wo * KQ;
     const long long gstride = (long long)gridDim.x * blockDim.x;
-    const int K = kh * kw * C;
     for (long long i = (long long)blockIdx.x * blockDim.x + threadIdx.x; i < total; i += gstride) {
-        const int k = (int)(i % Kpad);
-        long long t = i / Kpad;
-        const int ox = (int)(t % Wo); t /= Wo;
-        const int oy = (int)(t % Ho);
-        const int b = (int)(t / Ho);
-        float v = 0.f;
-        if (k < K) {
-            const int c = k % C, tap = k / C;
-            const int dy = tap / kw, dx = tap - dy * kw;
-            const int iy = oy * stride - pad + dy, ix = ox * stride - pad + dx;
-            if (iy >= 0 && iy < H && ix >= 0 && ix < W) v = x[(((long long)b * H + iy) * W + ix) * C + c];
+        const long long pix = i / KQ;
+        const int k0 = (int)(i - pix * KQ) * 4;
+        const int p = (int)pix;                          // < 2^31 output pixels
+        const int ox = p % Wo, t = p / Wo, oy = t % Ho, b = t / Ho;
+        const float* img = x + (long long)b * H * W * C;
+        float v[4];
+#pragma unroll
+        for (int j = 0; j < 4; ++j) {
+            const int k = k0 + j;
+            v[j] = 0.f;
+            if (k < K) {
+                const int tap = k / C, c = k - tap * C;
+                const int dy = tap / kw, dx = tap - dy * kw;
+                const int iy = oy * stride - pad + dy, ix = ox * stride - pad + dx;
+                if (iy >= 0 && iy < H && ix >= 0 && ix < W) v[j] = img[(iy * W + ix) * C + c];
+            }
         }
-        out[i] = v;
+        reinterpret_cast<float4*>(out)[i] = make_float4(v[0], v[1], v[2], v[3]);
     }
 }
 
@@ -481,11 +507,12 @@ extern "C" int vbg_maxpool3x3s2_fwd(const float* x, int B, int H, int W, int C, 
 
 extern "C" int vbg_maxpool3x3s2_bwd(const float* dy, const int* argmax, int B, int Ho, int Wo, int C, int H, int W,
                                     float* dx_zeroed, void* stream) {
-    VBG_CHECK_ARG(dy && argmax && dx_zeroed && B >= 0 && Ho > 0 && Wo > 0 && C > 0);
+    VBG_CHECK_ARG(dy && argmax && dx_zeroed && B >= 0 && Ho > 0 && Wo > 0 && C > 0 && C % 4 == 0);
+    VBG_CHECK_ARG(ALIGNED16(dy) && ALIGNED16(argmax) && ALIGNED16(dx_zeroed) && Ho == (H + 2 - 3) / 2 + 1 && Wo == (W + 2 - 3) / 2 + 1);
     const long long total = (long long)B * Ho * Wo * C;
     if (total == 0) return VBG_OK;
-    VBG_LAUNCH(maxpool_bwd_kernel, dim3(ew_grid(total, 256)), dim3(256), 0, S_, dy, argmax, Ho * Wo, C, H * W, total,
-                       dx_zeroed);
+    VBG_LAUNCH(maxpool_bwd_kernel, dim3(ew_grid((long long)B * H * W * (C / 4), 256)), dim3(256), 0, S_, dy, argmax, B, Ho, Wo, C / 4, H, W,
+               dx_zeroed);
     VBG_LAUNCH_RET();
 }
 
@@ -562,9 +589,10 @@ extern "C" int vbg_rescale_boxes(const long long* in, int S, float ratio_h, floa
 
 extern "C" int vbg_im2col(const float* x, int B, int H, int W, int C, int kh, int kw, int stride, int pad, int Kpad, float* out,
                           void* stream) {
-    VBG_CHECK_ARG(x && out && Kpad >= kh * kw * C && stride > 0);
+    VBG_CHECK_ARG(x && out && Kpad >= kh * kw * C && Kpad % 4 == 0 && stride > 0 && ALIGNED16(out));
     const int Ho = (H + 2 * pad - kh) / stride + 1, Wo = (W + 2 * pad - kw) / stride + 1;
-    const long long total = (long long)B * Ho * Wo * Kpad;
+    VBG_CHECK_ARG((long long)B * Ho * Wo < (1ll << 31) && (long long)H * W * C < (1ll << 31));
+    const long long total = (long long)B * Ho * Wo * (Kpad / 4);
     if (total == 0) return VBG_OK;
     VBG_LAUNCH(im2col_kernel, dim3(ew_grid(total, 256)), dim3(256), 0, S_, x, B, H, W, C, kh, kw, stride, pad, Ho, Wo, Kpad,
                        out);

@@ -498,7 +498,7 @@ def maxpool_fwd(x):
 
 def maxpool_bwd(dy, am, H, W):
     B, Ho, Wo, C_ = dy.shape
-    dx = torch.zeros((B, H, W, C_), device=dy.device, dtype=f32)
+    dx = torch.empty((B, H, W, C_), device=dy.device, dtype=f32)
     check(lib.vbg_maxpool3x3s2_bwd(P(dy), P(am), B, Ho, Wo, C_, H, W, P(dx), _stream()), "vbg_maxpool_bwd")
     return dx
 
