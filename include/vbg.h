@@ -62,7 +62,9 @@ typedef struct vbg_gemm_desc {
     vbg_conv_geo geo;
     float* C; long long ldc; float* C2; const float* bias;  /* bias[N] or NULL                      */
     int epi; float alpha; int accumulate;                   /* C += result (atomic only if splitk>1)*/
-    int splitk;                                             /* >1 requires accumulate               */
+    int splitk;                                             /* >1 requires accumulate; 1 = never split; 0 = the library may zero C and
+                                                               split a long reduction with few output tiles (linear epilogues only;
+                                                               atomic order is not reproducible run to run)                         */
     int tile;                                               /* 0 auto, BM*1000+BN: 128128/128064/64064 */
     /* grouped problems: grp[g*8 + {0..6}] = M, N, K, offA, offB, offC, offBias (elements; offsets */
     /* are relative to A/B/C/bias and may be negative); NULL = single problem                       */

@@ -669,7 +669,7 @@ static int gemm_dispatch(const vbg_gemm_desc* desc, void* stream, const vbg::lau
     vbg_gemm_desc d = *desc;
     VBG_CHECK_ARG(d.A && d.B && d.C);
     VBG_CHECK_ARG(d.M >= 0 && d.N >= 0 && d.K >= 0);
-    if (d.splitk < 1) d.splitk = 1;
+    VBG_CHECK_ARG(d.splitk >= 0);
     if (d.splitk > 1) VBG_CHECK_ARG(d.accumulate == 1);
     if (d.epi == VBG_EPI_GELU_DUAL) VBG_CHECK_ARG(d.C2 != nullptr);
     if (d.accumulate) VBG_CHECK_ARG(d.epi == VBG_EPI_NONE);
@@ -697,6 +697,27 @@ static int gemm_dispatch(const vbg_gemm_desc* desc, void* stream, const vbg::lau
         VBG_CHECK_ARG(d.geo.Cs % 16 == 0 && d.geo.kh > 0 && d.geo.kw > 0 && d.geo.stride > 0);
         VBG_CHECK_ARG(d.grp == nullptr);
         if (d.geo.Cs % 32 != 0) d.bk = 16;                      // a k-tile must stay inside one filter tap
+    }
+    // Automatic split-K for forward / dgrad products whose output has too few tiles to fill the chip but a long reduction
+    // (layer4 convolutions: 2048 x 512 outputs = 256 tiles, K = 4608: 73 TF/s unsplit): the (small) output is zeroed here and the
+    // splits accumulate with atomics.  Only where the epilogue is linear (no ReLU / GELU; the bias is added by split 0).
+    // Opt-in (splitk == 0): the atomic accumulation order is not reproducible run to run, so inference paths keep splitk = 1.
+    const bool auto_split = d.splitk == 0;
+    if (d.splitk < 1) d.splitk = 1;
+    if (auto_split && !d.accumulate && d.epi == VBG_EPI_NONE && !d.grp && d.a_nseg == 1) {
+        const long tiles = (long)cdiv(d.M, 64) * cdiv(d.N, 64);
+        const int nkt = cdiv(d.K, 32);
+        if (tiles <= 384 && nkt >= 48) {
+            int sk = (int)(1024 / tiles);
+            if (sk > nkt / 12) sk = nkt / 12;
+            if (sk > 8) sk = 8;
+            if (sk >= 2) {
+                const hipError_t e = hipMemset2DAsync(d.C, (size_t)d.ldc * 4, 0, (size_t)d.N * 4, (size_t)d.M, s);
+                if (e != hipSuccess) return (int)e;
+                d.splitk = sk;
+                d.accumulate = 1;
+            }
+        }
     }
     // the gathered side of a conv operand is float4-legal by construction; the DENSE side keeps the caller's flag
     if (d.a_kind == VBG_OP_CONV_K) { VBG_CHECK_ARG((uintptr_t)d.A % 16 == 0); d.a_vec = 1; }

@@ -68,6 +68,10 @@ def gemm_raw(M, N, K, A, lda, a_kind, B, ldb, b_kind, Cout, ldc, *, bias=None, e
     d.C, d.ldc = Cout.data_ptr() + 4 * c_ptr_off, int(ldc)
     d.C2 = None if C2 is None else C2.data_ptr() + 4 * c_ptr_off
     d.bias = None if bias is None else bias.data_ptr()
+    if splitk == 1 and not accumulate and torch.is_grad_enabled():
+        splitk = 0          # training: let the library split few-tile / long-K products; no_grad (inference, eval) stays bit-reproducible
+    if splitk == 0 and accumulate:
+        splitk = 1
     d.epi, d.alpha, d.accumulate, d.splitk, d.tile = epi, float(alpha), int(bool(accumulate)), int(splitk), int(tile)
     d.bk = int(bk)
     if _FORCE[0] or _FORCE[1]:          # debugging / conditioning experiments: force one tile configuration
@@ -168,7 +172,7 @@ def linear_dgrad(dy, w, out=None, accumulate=False):
     if out is None:
         assert not accumulate
         out = torch.empty((M, K), device=dy.device, dtype=f32)
-    gemm_raw(M, K, N, dy, dy.stride(0), OP_DENSE_K, w, w.stride(0), OP_DENSE_R, out, out.stride(0), accumulate=accumulate)
+    gemm_raw(M, K, N, dy, dy.stride(0), OP_DENSE_K, w, w.stride(0), OP_DENSE_R, out, out.stride(0), accumulate=accumulate, splitk=_BWD_SPLIT)
     return out
 
 
@@ -225,6 +229,9 @@ def conv2d_fwd(x, w_ohwi, stride, pad, bias=None, out=None):
     return out
 
 
+_BWD_SPLIT = 0          # backward products run with grad mode off; they are training-only, so the library may always split them
+
+
 def conv2d_dgrad(dy, w_ohwi, x_shape, stride, pad, out=None, accumulate=False):
     """dx NHWC [B,H,W,Cin] (+)= conv_transpose(dy NHWC [B,Ho,Wo,Cout], w)."""
     _chk_f32(dy, w_ohwi)
@@ -237,11 +244,11 @@ def conv2d_dgrad(dy, w_ohwi, x_shape, stride, pad, out=None, accumulate=False):
         out = torch.empty(x_shape, device=dy.device, dtype=f32)
     M = B * H * W
     if kh == 1 and kw == 1 and stride == 1 and pad == 0:
-        gemm_raw(M, Cin, Cout, dy, Cout, OP_DENSE_K, w_ohwi, Cin, OP_DENSE_R, out, Cin, accumulate=accumulate)
+        gemm_raw(M, Cin, Cout, dy, Cout, OP_DENSE_K, w_ohwi, Cin, OP_DENSE_R, out, Cin, accumulate=accumulate, splitk=_BWD_SPLIT)
     else:
         assert Cout % 16 == 0 and Cin % 4 == 0
         gemm_raw(M, Cin, kh * kw * Cout, dy, Cout, OP_CONV_K, w_ohwi, Cin, OP_WT_R, out, Cin, accumulate=accumulate,
-                 geo=conv_geo(Ho, Wo, Cout, H, W, kh, kw, stride, pad, 1))
+                 geo=conv_geo(Ho, Wo, Cout, H, W, kh, kw, stride, pad, 1), splitk=_BWD_SPLIT)
     return out
 
 
