@@ -1,0 +1,74 @@
+#!/usr/bin/env python3
+"""Summarise the rocprofv3 runs of gpurun_out/ into the committed profiles/ (round-1 names).
+
+expects: gpurun_out/prof_e (kernel-trace + stats of `bench.py --steps 10 --warmup 3`), gpurun_out/pmc_f / pmc_w (FETCH_SIZE / WRITE_SIZE
+passes of `bench.py --steps 3 --warmup 1`), gpurun_out/gemm_shapes.txt, gpurun_out/bench_line.json"""
+import collections, csv, json, os, re, shutil, subprocess, sys
+R = os.path.dirname(os.path.dirname(os.path.abspath(__file__))) + "/"
+G = R + "gpurun_out/"
+
+
+def agg(path):
+    a = collections.defaultdict(lambda: [0, 0.0, 0.0])
+    for r in csv.DictReader(open(path)):
+        m = re.search(r'gemm_kernel<(\d+), (\d+), (\d+), 256, (\d), (\d), (true|false)>', r['Kernel_Name'])
+        if not m:
+            continue
+        k = m.groups() + (r['Grid_Size'],)
+        a[k][0] += 1; a[k][1] += float(r['Counter_Value']); a[k][2] += (int(r['End_Timestamp']) - int(r['Start_Timestamp'])) / 1e3
+    return a
+
+
+f, w = agg(G + 'pmc_f/f_counter_collection.csv'), agg(G + 'pmc_w/w_counter_collection.csv')
+lines = ["# rocprofv3 --kernel-trace --pmc FETCH_SIZE  /  --pmc WRITE_SIZE  (two separate passes) over `python bench.py --steps 3 --warmup 1 --no-cpu-baseline`",
+         "# per-launch averages for every vbg::gemm_kernel instantiation x grid.  Units: rocprofv3 reports KB; FETCH_SIZE is DOUBLED per",
+         "# MI355X_MICROARCH.md (gfx950 tallies 128-B requests at 64 B); WRITE_SIZE is taken as is (it reproduces known output sizes exactly,",
+         "# e.g. 131072x256 fp32 = 134.2 MB).  FETCH counts L2 misses (Infinity-Cache hits included), not DRAM reads.",
+         "# columns: BM BN BK A-kind B-kind vec | grid threads | launches/step | fetch MB | write MB | avg us (under the profiler)"]
+nf = nw = n = 0
+for k in sorted(f, key=lambda k: -f[k][1]):
+    fm = 2 * f[k][1] / f[k][0] * 1024 / 1e6
+    wm = w[k][1] / w[k][0] * 1024 / 1e6 if k in w else float('nan')
+    lines.append(f"{k[0]:>4}{k[1]:>4}{k[2]:>3}  A{k[3]} B{k[4]} {k[5]:5s} grid {int(k[6]):>8d}  x{f[k][0] / 4:6.1f}  fetch {fm:8.1f} MB  write {wm:8.1f} MB  {f[k][2] / f[k][0]:8.1f} us")
+    grouped = k[:3] in (('128', '128', '16'), ('64', '64', '16')) and k[6] in ('786432', '3145728')
+    if k[3] == '0' and k[4] == '0' and not grouped:
+        nf += 2 * f[k][1] * 1024; nw += w[k][1] * 1024 if k in w else 0; n += f[k][0]
+tot_f = sum(2 * v[1] * 1024 for v in f.values()) / 4
+tot_w = sum(v[1] * 1024 for v in w.values()) / 4
+lines.append(f"# all GEMM launches: fetch {tot_f / 1e9:.1f} GB + write {tot_w / 1e9:.1f} GB per step (before the XCD-aware block->tile map: fetch 112.7 GB per step)")
+lines.append(f"# ungrouped dense NT GEMM (A0 B0; the launches bench.py's roofline times): {n / 4:.0f} launches/step, fetch {nf / n / 1e6:.1f} MB + write {nw / n / 1e6:.1f} MB per launch")
+open(R + 'profiles/r01_gemm_hbm_traffic.txt', 'w').write("\n".join(lines) + "\n")
+json.dump({"kernel": "vbg::gemm_kernel<*,*,*,DENSE_K,DENSE_K> (every ungrouped dense NT launch of one bench step: the launches bench.py times)",
+           "launches_per_step": n / 4, "fetch_bytes_per_launch": nf / n, "write_bytes_per_launch": nw / n, "bytes_per_launch": (nf + nw) / n,
+           "source": "profiles/r01_gemm_hbm_traffic.txt (rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE, separate passes; FETCH_SIZE x2 gfx950 correction; L2 misses incl. Infinity-Cache hits)"},
+          open(R + 'profiles/r01_gemm_hbm_traffic.json', 'w'), indent=1)
+print(lines[-2]); print(lines[-1])
+shutil.copy(G + 'prof_e/e_kernel_stats.csv', R + 'profiles/r01_bench_kernel_stats.csv')
+shutil.copy(G + 'prof_e/e_domain_stats.csv', R + 'profiles/r01_bench_domain_stats.csv')
+shutil.copy(G + 'gemm_shapes.txt', R + 'profiles/r01_gemm_shapes.txt')
+shutil.copy(G + 'bench_line.json', R + 'profiles/r01_bench_line.json')
+tab = subprocess.run([sys.executable, R + 'tools/hbm_table.py', G + 'prof_e/e_kernel_trace.csv', '13'], capture_output=True, text=True).stdout
+open(R + 'profiles/r01_hbm_kernels.txt', 'w').write("# tools/hbm_table.py over the kernel trace of `bench.py --steps 10 --warmup 3` (13 steps): achieved HBM-side bandwidth of the\n"
+                                                    "# streaming kernels = algorithmic bytes per step (cfg2 shapes, fp32, every tensor read / written once) / kernel time per step\n" + tab)
+print(tab)
+rows = list(csv.DictReader(open(R + 'profiles/r01_bench_kernel_stats.csv')))
+tot = sum(float(r['TotalDurationNs']) for r in rows) / 13 / 1e6
+cat = collections.OrderedDict()
+for r in rows:
+    nme, v = r['Name'], float(r['TotalDurationNs']) / 13 / 1e6
+    if 'gemm_kernel' in nme:
+        m = re.search(r'256, (\d), (\d)', nme)
+        key = {('0', '0'): 'dense NT (fwd, 1x1)', ('0', '1'): 'dense NN (dgrad)', ('1', '1'): 'dense TN (wgrad)', ('2', '0'): 'conv fwd', ('2', '4'): 'conv dgrad', ('1', '3'): 'conv wgrad'}[m.groups()]
+    elif 'bn_' in nme: key = 'BatchNorm'
+    elif 'ln_' in nme or 'softmax' in nme or 'gelu' in nme: key = 'LN/softmax/GELU'
+    elif 'adamw' in nme or 'sgd' in nme: key = 'optimizers'
+    elif 'at::native' in nme or 'rocclr' in nme: key = 'torch plumbing'
+    else: key = 'other vbg kernels'
+    cat[key] = cat.get(key, 0) + v
+print("kernel ms/step", round(tot, 2))
+for k, v in cat.items():
+    print(f"{k:22s} {v:6.2f} ms {100 * v / tot:5.1f} %")
+for r in rows:
+    if 'gemm_kernel' in r['Name'] and ', 0, 0, ' in r['Name']:
+        print(r['Name'][:64], int(r['Calls']) // 13, round(float(r['AverageNs']) / 1e3, 1))
+print(open(R + 'profiles/r01_bench_line.json').read()[:2000])
