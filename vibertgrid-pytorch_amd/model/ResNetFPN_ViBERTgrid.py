@@ -84,11 +84,14 @@ class EarlyFusionLayer(nn.Module):
         self.early_fusion = nn.Conv2d(out_channel + grid_channel, out_channel, kernel_size=1)       # bias=True (:305-309)
         self.layers = nn.Sequential(*[block(in_channel, out_channel, downsample=False) for _ in range(block_num - 1)])
 
-    def forward(self, x, grid):
-        x = self.block_1(x)
+    def fuse(self, x, grid):
+        """early fusion of the (already computed) block_1 output with the grid, then the rest of the layer"""
         w = self.early_fusion.weight
         x = Fn.SegLinearFn.apply(w, self.early_fusion.bias, (0, 0), (0, 0), x, grid)
         return self.layers(x)
+
+    def forward(self, x, grid):
+        return self.fuse(self.block_1(x), grid)
 
 
 class _FPN(nn.Module):
@@ -133,13 +136,21 @@ class ResNetFPN_ViBERTgrid(_FPN):
         return nn.Sequential(*[block(in_channel if i == 0 else out_channel, out_channel, downsample=(downsample and i == 0))
                                for i in range(block_num)])
 
-    def forward(self, input, grid):
-        """input NHWC [B,H,W,3]; grid NHWC [B,H/8,W/8,768] -> P_fuse NHWC [B,H/4,W/4,256]"""
+    def stage1(self, input):
+        """everything in front of the early fusion (independent of the BERTgrid): -> (C2, first block of conv_3_x)"""
         x_1 = conv_bn(input, self.conv_1[0], self.conv_1[1], None, True)
         x_1 = self.conv_2_x(Fn.MaxPoolFn.apply(x_1))
-        x_2 = self.conv_3_x(x_1, grid)
+        return x_1, self.conv_3_x.block_1(x_1)
+
+    def stage2(self, pre, grid):
+        x_1, x_2 = pre
+        x_2 = self.conv_3_x.fuse(x_2, grid)
         x_3 = self.conv_4_x(x_2)
         return self._fpn(x_1, x_2, x_3, self.conv_5_x(x_3))
+
+    def forward(self, input, grid):
+        """input NHWC [B,H,W,3]; grid NHWC [B,H/8,W/8,768] -> P_fuse NHWC [B,H/4,W/4,256]"""
+        return self.stage2(self.stage1(input), grid)
 
 
 class _TvBlock(nn.Module):
@@ -208,16 +219,24 @@ class ResNetFPN_ViBERTgrid_Pretrained(_FPN):
         self._build_fpn(pyramid_channel, fuse_channel)
         _cl(self)
 
-    def forward(self, input, BERTgrid):
+    def stage1(self, input):
+        """everything in front of the early fusion (independent of the BERTgrid): -> (C2, layer2[0] output)"""
         r = self.resnet
         x_1 = r.layer1(Fn.MaxPoolFn.apply(conv_bn(input, r.conv1, r.bn1, None, True)))
-        x_2 = r.layer2[0](x_1)
+        return x_1, r.layer2[0](x_1)
+
+    def stage2(self, pre, BERTgrid):
+        r = self.resnet
+        x_1, x_2 = pre
         w = self.early_fusion.weight
         x_2 = Fn.SegLinearFn.apply(w, None, (0, 0), (0, 0), x_2, BERTgrid)
         for i in range(1, self.num_block_ly2):
             x_2 = r.layer2[i](x_2)
         x_3 = r.layer3(x_2)
         return self._fpn(x_1, x_2, x_3, r.layer4(x_3))
+
+    def forward(self, input, BERTgrid):
+        return self.stage2(self.stage1(input), BERTgrid)
 
 
 def resnet_18_fpn(grid_channel: int, pretrained: bool = False) -> nn.Module:

@@ -93,15 +93,38 @@ class OhemPlan:
                 c.elem = ops.gather_i32(c.idx, sel)
 
 
+class PendingCounts:
+    """the category counts of several plans on their way to the host: one asynchronous D2H copy into pinned memory + an event, so
+    the caller can enqueue more device work (the whole BERT / CNN trunk) before it needs the numbers"""
+
+    def __init__(self, plans):
+        self.plans = plans
+        tens = [t for p in plans for t in p.count_tensors()]
+        self.host = None
+        if tens:
+            dev = torch.cat(tens)
+            self.host = torch.empty(dev.shape, dtype=dev.dtype, pin_memory=True)
+            self.host.copy_(dev, non_blocking=True)
+            self.event = torch.cuda.Event()
+            self.event.record()
+            self._keep = dev
+
+    def finish(self):
+        """wait for the copy only (not for work enqueued after it), then the host-side random draws in the reference's order"""
+        counts = []
+        if self.host is not None:
+            self.event.synchronize()
+            counts = self.host.tolist()
+        o = 0
+        for p in self.plans:
+            k = len(p.count_tensors())
+            p.resolve(counts[o:o + k])
+            o += k
+
+
 def resolve_plans(plans):
     """One D2H copy for the category counts of all plans, then the host-side random draws in order."""
-    tens = [t for p in plans for t in p.count_tensors()]
-    counts = torch.cat(tens).cpu().tolist() if tens else []
-    o = 0
-    for p in plans:
-        k = len(p.count_tensors())
-        p.resolve(counts[o:o + k])
-        o += k
+    PendingCounts(plans).finish()
 
 
 class CrossEntropyLossRandomSample(torch.nn.Module):
