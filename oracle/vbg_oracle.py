@@ -869,6 +869,8 @@ def synth_tensor(key: str, shape, kind: str) -> Tensor:
 def synth_kind(key: str, shape) -> str:
     if key.endswith("num_batches_tracked") or key.endswith("position_ids") or key.endswith("token_type_ids"):
         return "skip"
+    if "_loss" in key.rsplit(".", 2)[-2] and key.endswith(".weight"):       # class-weight buffers of the loss modules: set by the config
+        return "skip"
     if key.endswith("running_var"):
         return "var"
     if key.endswith("running_mean"):
@@ -1045,6 +1047,10 @@ def state_shapes(cfg: NetCfg, vocab: int, max_pos: int = 512, type_vocab: int = 
     if dup_bert:
         s.update(bert_shapes("BERTgrid_generator.model.", cfg.bert, vocab, max_pos, type_vocab))
     s.update(head_shapes(cfg.num_classes, cfg.bert.hidden, cfg.roi_shape, mode=cfg.classifier_mode, layer_mode=cfg.layer_mode))
+    if cfg.loss_weights is not None and cfg.classifier_mode == "simp":
+        # nn.CrossEntropyLoss keeps its class weights as a BUFFER, so the reference's state_dict carries them ([probe], simp mode)
+        s["field_type_classification_head.field_type_classification_loss.weight"] = (len(cfg.loss_weights),)
+        s["semantic_segmentation_head.aux_loss_2.weight"] = (len(cfg.loss_weights),)
     return s
 
 
