@@ -515,6 +515,27 @@ def test_transform(ops, golden):
 
 
 
+def test_transform_module_vs_reference_golden(golden):
+    """a1 through the drop-in class: eval size, the TRAIN-mode size draw from torch's global CPU RNG, zero padding to multiples of
+    32, the (ImageList, boxes) return convention and bit-exact boxes against the reference's outputs"""
+    from pipeline.transform import GeneralizedViBERTgridTransform, ImageList
+    g = golden("transform.npz")
+    d = dev()
+    tr = GeneralizedViBERTgridTransform([0.9248, 0.9224, 0.9215], [0.1532, 0.1545, 0.1536], [48, 64], 56, 80)
+    imgs = tuple(torch.from_numpy(g[f"img{i}"]).to(d) for i in range(3))
+    coors = tuple(torch.from_numpy(g[f"coor{i}"]).to(d) for i in range(3))
+    for mode, seed in (("eval", None), ("train", 123)):
+        getattr(tr, mode)()
+        if seed is not None:
+            torch.manual_seed(seed)
+        il, oc = tr(imgs, coors)
+        assert isinstance(il, ImageList)
+        assert np.array_equal(np.array(il.image_sizes), g[mode + "_sizes"])
+        assert close(il.tensors, torch.from_numpy(g[mode + "_batch"]), 1e-4, 1e-4)
+        for i in range(3):
+            assert oc[i].dtype == torch.int32 and np.array_equal(oc[i].cpu().numpy(), g[f"{mode}_coor{i}"])
+
+
 # ------------------------------------------------------------------------------------------
 # conv + batch-stat BN (+res, +relu) block, forward and backward, against an fp64 CPU reference:
 # the rigorous check behind the looser end-to-end gradient tolerances (tests/test_gpu_model.py)
