@@ -211,6 +211,13 @@ def main():
         dist.all_reduce(t, op=dist.ReduceOp.MAX)
         dt = float(t.item())
     launches, flops, ms = prof.summary()
+    ranks_in_sync = None
+    if world > 1:          # self-check of the gradient exchange: every rank must hold bit-identical parameters after the timed steps
+        chk = torch.stack([o.group.pflat.double().sum() for o in opts] + [o.group.pflat.double().abs().sum() for o in opts])
+        lo, hi = chk.clone(), chk.clone()
+        dist.all_reduce(lo, op=dist.ReduceOp.MIN)
+        dist.all_reduce(hi, op=dist.ReduceOp.MAX)
+        ranks_in_sync = bool(torch.equal(lo, hi))
     # HBM-side bytes per launch of the same kernel: rocprofv3 PMC passes of this command (cannot be collected in-process),
     # summarised in profiles/ by the round that produced them; null when the file is absent
     traffic = None
@@ -232,7 +239,7 @@ def main():
                                     "512x512, T=512 tokens, S=128 segments, batch 8/GPU, fwd+bwd+SGD/AdamW, dropout 0.1, simp classifier")
                        if args.shape == "cfg2" else f"EXPLORATORY {args.shape}: {shape}, T=512, batch {B}/GPU (not the BASELINE metric's configuration)",
                        "global_batch": B * world, "seq_len": 512, "parallelism": f"dp{world}" + ("+syncbn" if sync_bn else ""),
-                       "last_loss": round(float(last), 4), **({"h2d_in_step": packed.nbytes()} if packed is not None else {})},
+                       "last_loss": round(float(last), 4), **({"ranks_in_sync": ranks_in_sync} if ranks_in_sync is not None else {}), **({"h2d_in_step": packed.nbytes()} if packed is not None else {})},
             "step_mfma_frac": round(value / world * {"cfg2": F_STEP_GF, "cfg4": 862.4, "cfg5": 1715.3}[args.shape] / 1e3 / PEAK_F32_TF, 4),
             "roofline": {"bound": "mfma", "kernel": "vbg::gemm_kernel<*,*,*,DENSE_K,DENSE_K> (fp32 MFMA NT GEMM: BERT linears, 1x1 convs; every ungrouped launch)",
                          "achieved": round(ach, 2), "peak": PEAK_F32_TF, "unit": "TFLOP/s", "frac": round(ach / PEAK_F32_TF, 4),
