@@ -15,10 +15,18 @@ from vbg.lib import OP_CONV_K, OP_CONV_R, OP_DENSE_K, OP_DENSE_R, OP_WT_R
 dev = torch.device("cuda")
 
 
-def timeit(fn, reps=10):
-    for _ in range(2):
-        fn()
+def timeit(fn, reps=20):
+    """time `reps` calls after ~50 ms of the same call: the device needs tens of milliseconds of sustained load to reach its loaded
+    clock state (measured: the same 4128x3072x768 GEMM reads 209 us cold and 168 us after ~150 launches), and the training step,
+    which is what these numbers stand for, never lets it idle"""
+    import time
+    fn()
     torch.cuda.synchronize()
+    t0 = time.perf_counter()
+    while time.perf_counter() - t0 < 0.05:
+        for _ in range(10):
+            fn()
+        torch.cuda.synchronize()
     e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
     e0.record()
     for _ in range(reps):
