@@ -633,8 +633,9 @@ static void pick_tile(const vbg_gemm_desc& d, int groups, int maxM, int maxN, in
     if (tile == 64) tile = 64064;
     if (tile == 128) tile = 128128;
     if (tile == 0) {
-        // measured on MI355X (tools/gemm_bench.py): 64x64 wins almost everywhere (8 waves/SIMD hide the LDS/barrier
-        // phases); 128x128 only pays for very large M with N >= 256 (FPN merge / seg-head convs)
+        // measured on MI355X (tools/gemm_bench.py): 64x64 wins almost everywhere (4 blocks = 16 waves per CU hide the LDS / barrier
+        // phases); for very large M with N >= 256 (FPN merge / seg-head convs) 128x128 ties in isolation (130 TF/s both) and is
+        // 0.7 % better for the training step as a whole (fewer LDS reads per MFMA, lower power), so it stays for those
         const long t128 = (long)cdiv(maxM, 128) * cdiv(maxN, 128) * groups * d.splitk;
         tile = (maxN >= 256 && t128 >= 1536 && d.a_kind != VBG_OP_DENSE_R) ? 128128 : 64064;
     }
