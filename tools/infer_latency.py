@@ -1,0 +1,27 @@
+#!/usr/bin/env python3
+"""Deployment-style latency of ViBERTgridNet.inference (reference deployment/inference_SROIE.py:143-151 prints the same
+quantity): one document at a time, 512x512, T = 512 tokens, S = 128 segments, resnet_34_fpn_pretrained + bert-base (12 layers)."""
+import contextlib, os, sys, tempfile, time
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+sys.path.insert(0, ROOT); sys.path.insert(0, os.path.join(ROOT, "vibertgrid-pytorch_amd"))
+import torch
+import bench
+
+dev = torch.device("cuda")
+with contextlib.redirect_stdout(sys.stderr):
+    net = bench.build_model(tempfile.mkdtemp()).to(dev).eval()
+for B in (1, 8):
+    batch = bench.synthetic_batch(B, 512, 512, 512, 128, 5, 30522, 7)
+    mv = lambda ts: tuple(t.to(dev) for t in ts)
+    args = (mv(batch[0]), mv(batch[1]), mv(batch[3]), batch[4].to(dev), batch[5].to(dev))
+    with torch.no_grad():
+        for _ in range(5):
+            net.inference(*args)
+        torch.cuda.synchronize()
+        t0 = time.perf_counter()
+        n = 30
+        for _ in range(n):
+            p = net.inference(*args)
+            p.cpu()                      # the caller reads the probabilities
+        dt = (time.perf_counter() - t0) / n
+    print(f"inference batch {B}: {dt * 1e3:.2f} ms per call, {B / dt:.1f} docs/s")
