@@ -3,6 +3,7 @@
 //   F_LDSW  2 ds_write_b128 per thread per tile               F_GLD   2 global float4 loads per thread per tile (L2 resident)
 #include <hip/hip_runtime.h>
 #include <stdio.h>
+// build: /opt/rocm/bin/hipcc --offload-arch=gfx950 -O3 tools/mfma_lds.hip -o tools/mfma_lds.bin ; run: ./tools/mfma_lds.bin
 typedef float f32x16 __attribute__((ext_vector_type(16)));
 typedef float f32x4 __attribute__((ext_vector_type(4)));
 enum { F_LDSR = 1, F_BAR = 2, F_LDSW = 4, F_GLD = 8, F_VALU = 16, F_SALU = 32 };   // F_VALU: +80 VALU ops / tile, F_SALU: +40 SALU ops / tile
