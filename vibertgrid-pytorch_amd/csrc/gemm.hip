@@ -568,6 +568,53 @@ __global__ __launch_bounds__(NT) void gemm_kernel(const vbg_gemm_desc p) {
     const bool atomic = accumulate && p.splitk > 1;
     const float alpha = p.alpha;
     const long long ldc = p.ldc;
+    // Plain stores go through LDS: the accumulator layout gives each lane single floats of 16 different rows (16 dword stores per
+    // 32x32 tile, 128 contiguous bytes per row); staged through the (now idle) operand tiles, every thread writes float4s of
+    // complete 64-float row pieces instead.  Output-bound products (attention scores, K = 64) are limited by exactly this.
+    constexpr int CTS = BN + 4;
+    constexpr bool STAGE_OK = BM * CTS <= NBUF * (ASZ + BSZ);
+    if (STAGE_OK && !accumulate && (ldc & 3) == 0 && (((uintptr_t)C) & 15) == 0 && (epi != VBG_EPI_GELU_DUAL || (((uintptr_t)C2) & 15) == 0)) {
+        __syncthreads();                                  // every wave is done with the operand tiles
+        float* const Ct = smem;
+#pragma unroll
+        for (int j = 0; j < TN; ++j)
+#pragma unroll
+            for (int i = 0; i < TM; ++i)
+#pragma unroll
+                for (int r = 0; r < 16; ++r)
+                    Ct[(wm * WM + i * 32 + (r & 3) + 8 * (r >> 2) + 4 * lk) * CTS + wn * WN + j * 32 + lr] = acc[i][j][r] * alpha;
+        __syncthreads();
+        constexpr int QN = BN / 4;                        // float4 per tile row
+#pragma unroll
+        for (int q = 0; q < BM * QN / NT; ++q) {
+            const int idx = tid + q * NT;
+            const int row = idx / QN, c = (idx % QN) * 4;
+            const int gm = m0 + row, gn = n0 + c;
+            if (gm >= M || gn >= N) continue;
+            float4 v = *reinterpret_cast<const float4*>(&Ct[row * CTS + c]);
+            if (add_bias) {
+                v.x += bias[gn];
+                if (gn + 1 < N) v.y += bias[gn + 1];
+                if (gn + 2 < N) v.z += bias[gn + 2];
+                if (gn + 3 < N) v.w += bias[gn + 3];
+            }
+            float* cp = C + (long long)gm * ldc + gn;
+            if (gn + 3 < N) {
+                if (epi == VBG_EPI_RELU) v = make_float4(fmaxf(v.x, 0.f), fmaxf(v.y, 0.f), fmaxf(v.z, 0.f), fmaxf(v.w, 0.f));
+                *reinterpret_cast<float4*>(cp) = v;
+                if (epi == VBG_EPI_GELU_DUAL)
+                    *reinterpret_cast<float4*>(C2 + (long long)gm * ldc + gn) = make_float4(gelu_erf(v.x), gelu_erf(v.y), gelu_erf(v.z), gelu_erf(v.w));
+            } else {
+                const float e[4] = {v.x, v.y, v.z, v.w};
+                for (int t = 0; t < 4 && gn + t < N; ++t) {
+                    const float x = (epi == VBG_EPI_RELU) ? fmaxf(e[t], 0.f) : e[t];
+                    cp[t] = x;
+                    if (epi == VBG_EPI_GELU_DUAL) C2[(long long)gm * ldc + gn + t] = gelu_erf(x);
+                }
+            }
+        }
+        return;
+    }
 #pragma unroll
     for (int j = 0; j < TN; ++j) {
         const int n = n0 + wn * WN + j * 32 + lr;
