@@ -573,7 +573,7 @@ __global__ __launch_bounds__(NT) void gemm_kernel(const vbg_gemm_desc p) {
     // complete 64-float row pieces instead.  Output-bound products (attention scores, K = 64) are limited by exactly this.
     constexpr int CTS = BN + 4;
     constexpr bool STAGE_OK = BM * CTS <= NBUF * (ASZ + BSZ);
-    if (STAGE_OK && !accumulate && (ldc & 3) == 0 && (((uintptr_t)C) & 15) == 0 && (epi != VBG_EPI_GELU_DUAL || (((uintptr_t)C2) & 15) == 0)) {
+    if (STAGE_OK && !atomic && (ldc & 3) == 0 && (((uintptr_t)C) & 15) == 0 && (epi != VBG_EPI_GELU_DUAL || (((uintptr_t)C2) & 15) == 0)) {
         __syncthreads();                                  // every wave is done with the operand tiles
         float* const Ct = smem;
 #pragma unroll
@@ -600,6 +600,10 @@ __global__ __launch_bounds__(NT) void gemm_kernel(const vbg_gemm_desc p) {
             }
             float* cp = C + (long long)gm * ldc + gn;
             if (gn + 3 < N) {
+                if (accumulate) {                          // single owner per element: plain read-modify-write
+                    const float4 o = *reinterpret_cast<const float4*>(cp);
+                    v.x += o.x; v.y += o.y; v.z += o.z; v.w += o.w;
+                }
                 if (epi == VBG_EPI_RELU) v = make_float4(fmaxf(v.x, 0.f), fmaxf(v.y, 0.f), fmaxf(v.z, 0.f), fmaxf(v.w, 0.f));
                 *reinterpret_cast<float4*>(cp) = v;
                 if (epi == VBG_EPI_GELU_DUAL)
@@ -607,7 +611,7 @@ __global__ __launch_bounds__(NT) void gemm_kernel(const vbg_gemm_desc p) {
             } else {
                 const float e[4] = {v.x, v.y, v.z, v.w};
                 for (int t = 0; t < 4 && gn + t < N; ++t) {
-                    const float x = (epi == VBG_EPI_RELU) ? fmaxf(e[t], 0.f) : e[t];
+                    const float x = (epi == VBG_EPI_RELU) ? fmaxf(e[t], 0.f) : e[t] + (accumulate ? cp[t] : 0.f);
                     cp[t] = x;
                     if (epi == VBG_EPI_GELU_DUAL) C2[(long long)gm * ldc + gn + t] = gelu_erf(x);
                 }
