@@ -140,13 +140,14 @@ _FORCE = [0, 0]
 
 
 def _pick_splitk(M, N, Kred, bk=32):
-    """Split the reduction of a weight-gradient GEMM so the launch has ~3072 blocks (4 co-resident 64x64 blocks on each
-    of the 256 CUs, a few rounds), keeping >= 8 k-tiles per split (>= 16 beyond 64 splits: the atomic epilogue grows with them).  Measured on MI355X (tools/gemm_bench.py sweep):
-    +33 % on the BERT FFN wgrads, +35 % on the 256->256 conv wgrads versus filling the chip only once."""
+    """Split the reduction of a weight-gradient GEMM so the launch has ~2048 blocks (two rounds of the 1024 resident 64x64 blocks),
+    keeping >= 20 k-tiles per split (>= 16 beyond 64 splits: the atomic epilogue grows with them).  Measured on MI355X with every
+    shape warmed up (round 1): e.g. 768x768 K4128: 16 splits 76 TF/s -> 6 splits 90; 3072x768: 5 -> 4 splits 110 -> 116;
+    256->256 3x3 conv on 32x32 maps: 21 -> 12 splits 91 -> 97 TF/s."""
     tiles64 = ((M + 63) // 64) * ((N + 63) // 64)
     nkt = (Kred + bk - 1) // bk
-    want = (3072 + tiles64 // 2) // max(tiles64, 1)
-    return int(max(1, min(want, max(min(nkt // 8, 64), min(nkt // 16, 256)))))
+    want = (2048 + tiles64 // 2) // max(tiles64, 1)
+    return int(max(1, min(want, max(min(nkt // 20, 64), min(nkt // 16, 256)))))
 
 
 def linear_fwd(x, w, bias=None, epi=EPI_NONE, out=None, out2=None):
