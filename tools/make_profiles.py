@@ -47,6 +47,38 @@ shutil.copy(G + 'prof_e/e_kernel_stats.csv', R + 'profiles/r01_bench_kernel_stat
 shutil.copy(G + 'prof_e/e_domain_stats.csv', R + 'profiles/r01_bench_domain_stats.csv')
 shutil.copy(G + 'gemm_shapes.txt', R + 'profiles/r01_gemm_shapes.txt')
 shutil.copy(G + 'bench_line.json', R + 'profiles/r01_bench_line.json')
+# ---- MFMA utilisation per instantiation (gpurun_out/pmc_m: SQ_VALU_MFMA_BUSY_CYCLES ... GRBM_GUI_ACTIVE pass of `bench.py --steps 3 --warmup 1`)
+if os.path.exists(G + 'pmc_m/m_counter_collection.csv'):
+    disp = collections.OrderedDict()
+    for r in csv.DictReader(open(G + 'pmc_m/m_counter_collection.csv')):
+        if 'gemm_kernel' not in r['Kernel_Name']:
+            continue
+        d = disp.setdefault(r['Dispatch_Id'], {'name': r['Kernel_Name'], 'ns': int(r['End_Timestamp']) - int(r['Start_Timestamp'])})
+        d[r['Counter_Name']] = float(r['Counter_Value'])
+    ag = collections.defaultdict(lambda: collections.defaultdict(float))
+    ctrs = ('SQ_VALU_MFMA_BUSY_CYCLES', 'SQ_WAVE_CYCLES', 'SQ_WAIT_ANY', 'SQ_WAIT_INST_ANY', 'SQ_ACTIVE_INST_ANY', 'SQ_LDS_BANK_CONFLICT', 'GRBM_GUI_ACTIVE')
+    for d in disp.values():
+        k = re.search(r'gemm_kernel<(\d+), (\d+), (\d+), 256, (\d), (\d), (true|false)>', d['name']).groups()
+        a_ = ag[k]; a_['n'] += 1; a_['ns'] += d['ns']
+        for c in ctrs:
+            a_[c] += d.get(c, 0.0)
+    names = {'0': 'DENSE_K', '1': 'DENSE_R', '2': 'CONV_K', '3': 'CONV_R', '4': 'WT_R'}
+    out = ["# rocprofv3 --kernel-trace --pmc " + " ".join(ctrs),
+           "# over `python bench.py --steps 3 --warmup 1 --no-cpu-baseline`, summed per gemm_kernel instantiation over the 4 steps.",
+           "# mfma_util = SQ_VALU_MFMA_BUSY_CYCLES / (kernel time * clock * 1024 SIMDs), clock = GRBM_GUI_ACTIVE / time / 8 XCDs;",
+           "# wait/active columns are fractions of SQ_WAVE_CYCLES.",
+           "tile,A,B,vec,launches_per_step,ms_per_step,clock_GHz,mfma_util,wait_any,wait_inst_any,active_inst_any,lds_bank_conflict_cycles"]
+    tb = tc = 0
+    for k, a_ in sorted(ag.items(), key=lambda kv: -kv[1]['ns']):
+        clk = a_['GRBM_GUI_ACTIVE'] / a_['ns'] / 8
+        cap = a_['ns'] * clk * 1024
+        tb += a_['SQ_VALU_MFMA_BUSY_CYCLES']; tc += cap
+        wc = a_['SQ_WAVE_CYCLES'] or 1
+        out.append(f"{k[0]}x{k[1]}x{k[2]},{names[k[3]]},{names[k[4]]},{k[5]},{a_['n'] / 4:.1f},{a_['ns'] / 4 / 1e6:.3f},{clk:.2f},{a_['SQ_VALU_MFMA_BUSY_CYCLES'] / cap:.3f},"
+                   f"{a_['SQ_WAIT_ANY'] / wc:.3f},{a_['SQ_WAIT_INST_ANY'] / wc:.3f},{a_['SQ_ACTIVE_INST_ANY'] / wc:.3f},{a_['SQ_LDS_BANK_CONFLICT']:.0f}")
+    out.append(f"# all GEMM / conv kernels of the step: MFMA pipe busy {tb / tc:.3f} of the time they run")
+    open(R + 'profiles/r01_gemm_mfma_util.txt', 'w').write("\n".join(out) + "\n")
+    print(out[-1])
 tab = subprocess.run([sys.executable, R + 'tools/hbm_table.py', G + 'prof_e/e_kernel_trace.csv', '13'], capture_output=True, text=True).stdout
 open(R + 'profiles/r01_hbm_kernels.txt', 'w').write("# tools/hbm_table.py over the kernel trace of `bench.py --steps 10 --warmup 3` (13 steps): achieved HBM-side bandwidth of the\n"
                                                     "# streaming kernels = algorithmic bytes per step (cfg2 shapes, fp32, every tensor read / written once) / kernel time per step\n" + tab)
