@@ -8,17 +8,20 @@
 // late / P_fuse fusions (K segments read from several tensors in place; :315-321, :502-506,
 // model/field_type_classification_head.py:181-188) and all their dgrad / wgrad products.
 //
-// Structure (256 threads = 4 waves in 2x2, block tile BMxBN, k-tile BK, LDS double buffered):
-//  * global -> registers: every load of the vector path is an UNCONDITIONAL float4 from a clamped
-//    (always legal) address; nothing consumes the registers until the LDS-store phase after the
-//    MFMAs of the current tile (zero-masking and the optional A prologue happen there), so the next
-//    tile's loads stay in flight behind the compute and the k-loop has no divergent branches;
-//  * registers -> LDS: one 16-byte ds_write per float4 for both layouts.  K-contiguous operands are
-//    stored row-major [row][BK+4]: the 144-/80-byte row stride puts 16 consecutive rows on 16
-//    different 16-byte slots, so the fragment read is ONE conflict-free ds_read_b128 per 32 rows per
-//    8 k (the MFMA k index is permuted identically for A and B: lanes 0-31 take k = 8g+j, lanes 32-63
-//    k = 8g+4+j at step j).  Row-contiguous operands are stored [k][rows+4] and read with ds_read_b32;
-//  * fragments of k-group g+1 are fetched while the MFMAs of group g issue (two register sets).
+// Structure (256 threads = 4 waves in 2x2, block tile BMxBN, k-tile BK, LDS double buffered, one barrier per k-tile):
+//  * block -> tile: XCD-aware (workgroup b runs on XCD b % 8; each XCD walks its own band of tiles so its 4 MB L2 keeps the
+//    row / column panels it is using);
+//  * global -> registers: BUFFER loads with a scalar descriptor base advanced per k-tile and per-thread byte offsets that stay
+//    constant from tile to tile; lanes that must read zero carry an out-of-range offset.  VALU instructions share the issue port
+//    with the MFMAs (tools/mfma_lds.hip), so the steady-state loop has ~4 of them per 16 MFMAs; the loads of tile t+1 are issued
+//    after the first MFMA group of tile t and written to LDS before its last group;
+//  * registers -> LDS: one 16-byte ds_write per float4 for both layouts.  K-contiguous operands are stored row-major [row][BK+4]:
+//    the 144-/80-byte row stride puts 16 consecutive rows on 16 different 16-byte slots, so the fragment read is ONE conflict-free
+//    ds_read_b128 per 32 rows per 8 k (the MFMA k index is permuted identically for A and B: lanes 0-31 take k = 8g+j, lanes
+//    32-63 k = 8g+4+j at step j).  Row-contiguous operands are stored [k][rows+4] and read with ds_read_b32;
+//  * the reduction tail (K % BK != 0) and the last tile run in peeled copies of the k-tile body, the loop itself holds one copy;
+//  * epilogue: plain and single-owner accumulating stores are staged through the idle operand tiles in LDS and leave as float4
+//    row pieces; split-K partial sums use float atomics.
 #include "vbg_common.h"
 #include <type_traits>
 #include <hip/hip_ext.h>
