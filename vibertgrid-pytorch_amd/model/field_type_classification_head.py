@@ -1,7 +1,8 @@
-"""Word-level field-type classification: ROI embedding, late fusion and the simplified classifier.
+"""Word-level field-type classification: ROI embedding, late fusion and the three classifier heads.
 
 Mirrors reference model/field_type_classification_head.py — `ROIEmbedding` :26-75, `SingleLayer` /
-`MultipleLayer` :78-110, `LateFusion` :130-190, `SimplifiedFieldTypeClassification` :410-588 — with the
+`MultipleLayer` :78-110, `BinaryClassifier` :111-127, `LateFusion` :130-190, `FieldTypeClassification` :193-407 (full),
+`SimplifiedFieldTypeClassification` :410-588 (simp), `CRFFieldTypeClassification` :591-718 (crf) — with the
 same parameter names.  The ROI convolutions are one implicit GEMM over all ROIs (M = N_roi*49), the
 concat of ROI and BERT embeddings is a two-operand GEMM (no torch.cat), the MLPs fuse bias+ReLU into
 the GEMM epilogue, the OHEM losses are device-driven (pipeline/custom_loss.py).

@@ -1,7 +1,8 @@
-"""Auxiliary semantic segmentation head (simplified variant) on MI355X kernels.
+"""Auxiliary semantic segmentation heads (simplified and two-stage variants) on MI355X kernels.
 
-Mirrors reference model/semantic_segmentation_head.py: `SemanticSegmentationEncoder` :23-78 and
-`SimplifiedSemanticSegmentationClassifier` :236-352 (same parameter names).  Differences in HOW:
+Mirrors reference model/semantic_segmentation_head.py: `SemanticSegmentationEncoder` :23-78,
+`SimplifiedSemanticSegmentationClassifier` :236-352 (classifier_mode simp) and `SemanticSegmentationClassifier` :100-233 with its
+per-class `SemanticSegmentationBinaryClassifier` :81-97 (classifier_mode full / crf), same parameter names.  Differences in HOW:
 * the two 1x1 classifiers run at P_fuse resolution; nearest x4 upsampling commutes exactly with a
   1x1 conv + bias, so the reference's [B,256,H,W] activation (268 MB/doc at 512x512) never exists;
 * labels are rasterised by one owner-map kernel at stride 1 (bit-exact last-writer-wins) instead of
