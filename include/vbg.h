@@ -70,6 +70,10 @@ typedef struct vbg_gemm_desc {
     /* are relative to A/B/C/bias and may be negative); NULL = single problem                       */
     const long long* grp; int ngroups; int grp_maxM, grp_maxN;
     int bk;                                                 /* k-tile depth: 0 auto, 16 or 32       */
+    /* optional BatchNorm statistics of the OUTPUT, fused into the epilogue (the conv in front of a training-mode BatchNorm,
+       model/ResNetFPN_ViBERTgrid.py:116-123): per column sum and sum of squares of the stored values are added (fp64 atomics) into
+       slot row (row-tile index % stats_slots) of stats[stats_slots][2*N]; needs splitk == 1, no accumulate, ldc % 4 == 0, C 16-B aligned */
+    double* stats; int stats_slots;
 } vbg_gemm_desc;
 
 int vbg_gemm(const vbg_gemm_desc* desc, void* stream);

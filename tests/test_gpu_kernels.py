@@ -671,6 +671,26 @@ def test_optimizers(ops):
     assert close(pd, p, 1e-6, 1e-7)
 
 
+@pytest.mark.parametrize("M,N,K,tile", [(300, 64, 96, 0), (4100, 256, 64, 0), (777, 132, 200, 0), (5000, 256, 288, 128128), (130, 16, 147, 0)])
+def test_gemm_fused_bn_statistics(ops, M, N, K, tile):
+    """the GEMM epilogue adds the per-column sum / sum of squares of its output into the BatchNorm slot rows (what vbg_bn_stats
+    computes in a separate pass): output unchanged, folded statistics equal the fp64 sums of the stored values"""
+    from vbg.lib import OP_DENSE_K
+    d = dev()
+    x, w = rnd(M, K, seed=700 + N).to(d), rnd(N, K, seed=701 + N).to(d)
+    y0, y1 = torch.empty(M, N, device=d), torch.empty(M, N, device=d)
+    with torch.no_grad():
+        ops.gemm_raw(M, N, K, x, K, OP_DENSE_K, w, K, OP_DENSE_K, y0, N, tile=tile)
+        ws = ops._bn_workspace(d, N)
+        assert float(ws.abs().max()) == 0.0
+        ops.gemm_raw(M, N, K, x, K, OP_DENSE_K, w, K, OP_DENSE_K, y1, N, tile=tile, stats=ws)
+    assert torch.equal(y0, y1)
+    folded = ops.bn_fold(ws, N)
+    ref = torch.cat([y0.double().sum(0), (y0.double() ** 2).sum(0)])
+    assert torch.allclose(folded, ref, rtol=1e-6, atol=1e-6 * M)
+    assert float(ws.abs().max()) == 0.0
+
+
 @pytest.mark.parametrize("M,N,ld", [(300, 768, 768), (4128, 3072, 3072), (97, 64, 64), (513, 16, 16), (50, 13, 13), (1000, 2304, 2304),
                                     (700, 768, 2304), (33, 1000, 1000), (5, 4, 4)])
 def test_colsum(ops, M, N, ld):

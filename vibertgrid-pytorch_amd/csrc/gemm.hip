@@ -588,6 +588,7 @@ __global__ __launch_bounds__(NT) void gemm_kernel(const vbg_gemm_desc p) {
                     Ct[(wm * WM + i * 32 + (r & 3) + 8 * (r >> 2) + 4 * lk) * CTS + wn * WN + j * 32 + lr] = acc[i][j][r] * alpha;
         __syncthreads();
         constexpr int QN = BN / 4;                        // float4 per tile row
+        float4 cs = make_float4(0.f, 0.f, 0.f, 0.f), cq = cs;       // fused BatchNorm statistics: this thread's column partials
 #pragma unroll
         for (int q = 0; q < BM * QN / NT; ++q) {
             const int idx = tid + q * NT;
@@ -602,6 +603,10 @@ __global__ __launch_bounds__(NT) void gemm_kernel(const vbg_gemm_desc p) {
                 if (gn + 3 < N) v.w += bias[gn + 3];
             }
             float* cp = C + (long long)gm * ldc + gn;
+            if (p.stats) {                                 // (N % 4 == 0 is checked on the host when statistics are requested)
+                cs.x += v.x; cs.y += v.y; cs.z += v.z; cs.w += v.w;
+                cq.x += v.x * v.x; cq.y += v.y * v.y; cq.z += v.z * v.z; cq.w += v.w * v.w;
+            }
             if (gn + 3 < N) {
                 if (accumulate) {                          // single owner per element: plain read-modify-write
                     const float4 o = *reinterpret_cast<const float4*>(cp);
@@ -618,6 +623,25 @@ __global__ __launch_bounds__(NT) void gemm_kernel(const vbg_gemm_desc p) {
                     cp[t] = x;
                     if (epi == VBG_EPI_GELU_DUAL) C2[(long long)gm * ldc + gn + t] = gelu_erf(x);
                 }
+            }
+        }
+        if (p.stats) {
+            // threads with the same idx % QN own the same 4 columns: reduce their partials through LDS (behind the staged tile),
+            // then one fp64 atomic per column and statistic into this row-tile's slot row
+            constexpr int RG = NT / QN;                    // row groups
+            float* red = smem;                             // [2][RG][BN], over the staged tile once every thread has read its pieces
+            static_assert(2 * (NT / (BN / 4)) * BN <= NBUF * (ASZ + BSZ), "no room for the statistics partials");
+            __syncthreads();
+            const int rg = tid / QN, c = (tid % QN) * 4;
+            *reinterpret_cast<float4*>(&red[(0 * RG + rg) * BN + c]) = cs;
+            *reinterpret_cast<float4*>(&red[(1 * RG + rg) * BN + c]) = cq;
+            __syncthreads();
+            for (int e = tid; e < 2 * BN; e += NT) {
+                const int st = e / BN, col = e - st * BN;
+                if (n0 + col >= N) continue;
+                double acc64 = 0.0;
+                for (int g2 = 0; g2 < RG; ++g2) acc64 += (double)red[(st * RG + g2) * BN + col];
+                unsafeAtomicAdd(p.stats + (size_t)(tile_m % (unsigned)p.stats_slots) * 2 * N + (size_t)st * N + n0 + col, acc64);
             }
         }
         return;
@@ -730,6 +754,10 @@ static int gemm_dispatch(const vbg_gemm_desc* desc, void* stream, const vbg::lau
     if (d.accumulate) VBG_CHECK_ARG(d.epi == VBG_EPI_NONE);
     VBG_CHECK_ARG(d.a_nseg >= 0 && d.a_nseg <= 4);
     VBG_CHECK_ARG(d.bk == 0 || d.bk == 16 || d.bk == 32);
+    if (d.stats) {          // fused output statistics ride on the LDS-staged store path of an unsplit, non-accumulating launch
+        VBG_CHECK_ARG(d.stats_slots >= 1 && d.splitk == 1 && !d.accumulate && d.grp == nullptr && d.N % 4 == 0 && d.ldc % 4 == 0 &&
+                      (uintptr_t)d.C % 16 == 0 && d.epi == VBG_EPI_NONE);
+    }
     if (d.a_nseg == 0) {
         d.a_nseg = 1; d.a_seg_ptr[0] = d.A; d.a_seg_kend[0] = d.K; d.a_seg_ld[0] = d.lda; d.a_seg_shift[0] = 0;
     }

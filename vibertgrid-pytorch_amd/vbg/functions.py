@@ -189,19 +189,22 @@ class SegLinearFn(torch.autograd.Function):
 
 
 # ----------------------------------------------------------------------------------------------
-def _conv_any(x, w4, stride, pad, bias=None):
-    """x NHWC; w4 = OHWI weight.  Cin=3 stem goes through im2col (K=147, row stride 148)."""
-    if x.shape[-1] % 16 != 0:
-        B, H, W, Cin = x.shape
-        Cout, kh, kw, _ = w4.shape
-        K = kh * kw * Cin
+def _conv_any(x, w4, stride, pad, bias=None, want_stats=False):
+    """x NHWC; w4 = OHWI weight.  Cin=3 stem goes through im2col (K=147, row stride 148).
+    want_stats: -> third result = BatchNorm slot workspace holding the output's column sums / sums of squares (fused into the GEMM
+    epilogue), or None when the product is one the library may split (the caller then runs ops.bn_stats)."""
+    B, H, W, Cin = x.shape
+    Cout, kh, kw, _ = w4.shape
+    K = kh * kw * Cin
+    Ho, Wo = ops.conv_out_hw(H, W, kh, stride, pad)
+    stats = ops._bn_workspace(x.device, Cout) if (want_stats and ops.fuse_stats_ok(B * Ho * Wo, Cout, K)) else None
+    if Cin % 16 != 0:
         Kp = (K + 3) // 4 * 4
         col = ops.im2col(x, kh, kw, stride, pad, Kp)
-        Ho, Wo = ops.conv_out_hw(H, W, kh, stride, pad)
         out = torch.empty((B, Ho, Wo, Cout), device=x.device, dtype=f32)
-        ops.gemm_raw(B * Ho * Wo, Cout, K, col, Kp, OP_DENSE_K, w4, K, OP_DENSE_K, out, Cout, bias=bias)
-        return out, col
-    return ops.conv2d_fwd(x, w4, stride, pad, bias), None
+        ops.gemm_raw(B * Ho * Wo, Cout, K, col, Kp, OP_DENSE_K, w4, K, OP_DENSE_K, out, Cout, bias=bias, stats=stats)
+        return out, col, stats
+    return ops.conv2d_fwd(x, w4, stride, pad, bias, stats=stats), None, stats
 
 
 def _conv_wgrad_any(dy, x, col, w4_shape, stride, pad, w_param=None):
@@ -240,7 +243,7 @@ class ConvFn(torch.autograd.Function):
     def forward(ctx, x, w, b, stride, pad):
         x = _c(x)
         w4 = ohwi(w)
-        y, col = _conv_any(x, w4, stride, pad, b)
+        y, col, _ = _conv_any(x, w4, stride, pad, b)
         ctx.stride, ctx.pad, ctx.has_bias = stride, pad, b is not None
         ctx.w_ref, ctx.b_ref = w, b
         ctx.save_for_backward(x, w4, col)
@@ -264,12 +267,13 @@ class ConvBnFn(torch.autograd.Function):
         x = _c(x)
         sync = bool(sync) and SyncCtx.active()
         w4 = ohwi(w)
-        z, col = _conv_any(x, w4, stride, pad)
+        z, col, stats = _conv_any(x, w4, stride, pad, want_stats=training)
         C = z.shape[-1]
         z2 = z.view(-1, C)
         M = z2.shape[0]
         if training:
-            stats = ops.bn_stats(z2)
+            if stats is None:
+                stats = ops.bn_stats(z2)
             count, count_dev = float(M), None
             if sync:
                 glob = torch.empty((2 * C + 1,), device=x.device, dtype=torch.float64)

@@ -40,8 +40,9 @@ def _chk_f32(*ts):
 # ----------------------------------------------------------------------------------------------
 def gemm_raw(M, N, K, A, lda, a_kind, B, ldb, b_kind, Cout, ldc, *, bias=None, epi=EPI_NONE, C2=None, accumulate=False,
              splitk=1, geo=None, segs=None, a_hw=(0, 0), a_relu_scale=None, grp=None, ngroups=0, grp_max=(0, 0), tile=0,
-             alpha=1.0, a_ptr_off=0, b_ptr_off=0, c_ptr_off=0, bk=0):
-    """A, B, Cout: tensors (their data_ptr + element offsets are used)."""
+             alpha=1.0, a_ptr_off=0, b_ptr_off=0, c_ptr_off=0, bk=0, stats=None):
+    """A, B, Cout: tensors (their data_ptr + element offsets are used).  stats: BatchNorm slot workspace [slots*2N] fp64 that receives the
+    per-column sum / sum of squares of the output (fused into the epilogue; the launch is then never split)."""
     d = GemmDesc()
     d.M, d.N, d.K = int(M), int(N), int(K)
     ap = A.data_ptr() + 4 * a_ptr_off
@@ -68,7 +69,9 @@ def gemm_raw(M, N, K, A, lda, a_kind, B, ldb, b_kind, Cout, ldc, *, bias=None, e
     d.C, d.ldc = Cout.data_ptr() + 4 * c_ptr_off, int(ldc)
     d.C2 = None if C2 is None else C2.data_ptr() + 4 * c_ptr_off
     d.bias = None if bias is None else bias.data_ptr()
-    if splitk == 1 and not accumulate and torch.is_grad_enabled():
+    if stats is not None:
+        d.stats, d.stats_slots = stats.data_ptr(), bn_slots()
+    if splitk == 1 and not accumulate and torch.is_grad_enabled() and stats is None:
         splitk = 0          # training: let the library split few-tile / long-K products; no_grad (inference, eval) stays bit-reproducible
     if splitk == 0 and accumulate:
         splitk = 1
@@ -212,7 +215,14 @@ def conv_out_hw(H, W, k, stride, pad):
     return (H + 2 * pad - k) // stride + 1, (W + 2 * pad - k) // stride + 1
 
 
-def conv2d_fwd(x, w_ohwi, stride, pad, bias=None, out=None):
+def fuse_stats_ok(M, N, K):
+    """fuse the BatchNorm statistics into the producing GEMM unless that GEMM is one the library would rather split (few tiles, long
+    reduction: the layer4 convolutions), mirroring the rule in csrc/gemm.hip"""
+    tiles = ((M + 63) // 64) * ((N + 63) // 64)
+    return N % 4 == 0 and not (tiles <= 384 and (K + 31) // 32 >= 48)
+
+
+def conv2d_fwd(x, w_ohwi, stride, pad, bias=None, out=None, stats=None):
     """x NHWC [B,H,W,Cin] contiguous; w_ohwi [Cout,kh,kw,Cin] contiguous -> y NHWC [B,Ho,Wo,Cout]."""
     _chk_f32(x, w_ohwi, bias)
     B, H, W, Cin = x.shape
@@ -223,10 +233,10 @@ def conv2d_fwd(x, w_ohwi, stride, pad, bias=None, out=None):
         out = torch.empty((B, Ho, Wo, Cout), device=x.device, dtype=f32)
     M, K = B * Ho * Wo, kh * kw * Cin
     if kh == 1 and kw == 1 and stride == 1 and pad == 0:
-        gemm_raw(M, Cout, K, x, Cin, OP_DENSE_K, w_ohwi, K, OP_DENSE_K, out, Cout, bias=bias)
+        gemm_raw(M, Cout, K, x, Cin, OP_DENSE_K, w_ohwi, K, OP_DENSE_K, out, Cout, bias=bias, stats=stats)
     else:
         gemm_raw(M, Cout, K, x, Cin, OP_CONV_K, w_ohwi, K, OP_DENSE_K, out, Cout, bias=bias,
-                 geo=conv_geo(H, W, Cin, Ho, Wo, kh, kw, stride, pad, 0))
+                 geo=conv_geo(H, W, Cin, Ho, Wo, kh, kw, stride, pad, 0), stats=stats)
     return out
 
 
