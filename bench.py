@@ -121,6 +121,9 @@ def main():
     ap.add_argument("--batch", type=int, default=8, help="documents per GPU (BASELINE config: 8)")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-syncbn", action="store_true")
+    ap.add_argument("--amp", action="store_true", help="time the `amp: True` path (bf16 matrix cores) as the headline value instead "
+                    "of fp32; the default run reports it beside the fp32 value under \"amp\"")
+    ap.add_argument("--no-amp-leg", action="store_true", help="skip the secondary amp measurement of the default run")
     ap.add_argument("--shape", default="cfg2", choices=["cfg2", "cfg4", "cfg5"],
                     help="cfg2 (default, the BASELINE metric's configuration); cfg4 / cfg5: the other §8 shapes as exploratory runs "
                          "(char-level S=T=512, 12 classes, vocab 21128 / 1024x1024 images), reported under config.workload")
@@ -175,8 +178,12 @@ def main():
         from vbg.batch import PackedBatch
         packed = PackedBatch.pack(*batch)
 
+    amp_on = [bool(args.amp)]
+
     def step():
-        loss = net(*(packed.to(dev) if packed is not None else dbatch))
+        # `amp: True` = the reference's autocast region around the model call (pipeline/train_val_utils.py:264)
+        with torch.autocast("cuda", dtype=torch.bfloat16, enabled=amp_on[0]):
+            loss = net(*(packed.to(dev) if packed is not None else dbatch))
         val = loss.item()
         opt_cnn.zero_grad()
         opt_bert.zero_grad()
@@ -211,6 +218,28 @@ def main():
         dist.all_reduce(t, op=dist.ReduceOp.MAX)
         dt = float(t.item())
     launches, flops, ms = prof.summary()
+    amp_leg = None
+    if not args.amp and not args.no_amp_leg:      # the same steps with `amp: True` (reported beside the fp32 headline, never as it)
+        amp_on[0] = True
+        for _ in range(2):
+            step()
+        if world > 1:
+            dist.barrier()
+        torch.cuda.synchronize()
+        t1 = time.perf_counter()
+        for _ in range(args.steps):
+            amp_last = step()
+        if world > 1:
+            dist.barrier()
+        torch.cuda.synchronize()
+        adt = time.perf_counter() - t1
+        if world > 1:
+            t = torch.tensor([adt], device=dev, dtype=torch.float64)
+            dist.all_reduce(t, op=dist.ReduceOp.MAX)
+            adt = float(t.item())
+        amp_on[0] = False
+        amp_leg = {"value": round(B * world * args.steps / adt, 3), "unit": "docs/sec", "ms_per_step": round(1e3 * adt / args.steps, 3),
+                   "dtype": "bf16 MFMA products, f32 accumulate / storage / everything else", "last_loss": round(float(amp_last), 4)}
     ranks_in_sync = None
     if world > 1:          # self-check of the gradient exchange: every rank must hold bit-identical parameters after the timed steps
         chk = torch.stack([o.group.pflat.double().sum() for o in opts] + [o.group.pflat.double().abs().sum() for o in opts])
@@ -234,7 +263,7 @@ def main():
             "metric": "training docs/sec, 512x512 img + seq_len 512, bert-base+resnet34; 1/2/4/8 GPU",
             "value": round(value, 3), "unit": "docs/sec", "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
             "ms_per_step": round(1e3 * dt / args.steps, 3), "higher_is_better": True, "scaling": "weak", "vs_baseline": None,
-            "dtype": "f32", "data": "synthetic",
+            "dtype": "bf16" if args.amp else "f32", "data": "synthetic",
             "config": {"workload": ("SROIE line-level cfg2: resnet_34_fpn_pretrained + bert-base-uncased (12L, vocab 30522, random init), "
                                     "512x512, T=512 tokens, S=128 segments, batch 8/GPU, fwd+bwd+SGD/AdamW, dropout 0.1, simp classifier")
                        if args.shape == "cfg2" else f"EXPLORATORY {args.shape}: {shape}, T=512, batch {B}/GPU (not the BASELINE metric's configuration)",
@@ -245,6 +274,8 @@ def main():
                          "achieved": round(ach, 2), "peak": PEAK_F32_TF, "unit": "TFLOP/s", "frac": round(ach / PEAK_F32_TF, 4),
                          "traffic": traffic, "launches": launches, "avg_us": round(1e3 * ms / max(launches, 1), 2)},
         }
+        if amp_leg is not None:
+            out["amp"] = amp_leg
         if world == 1 and not args.no_cpu_baseline:
             out["cpu_baseline"] = cpu_baseline(min(os.cpu_count() or 1, 16))   # >16 threads only adds oversubscription for these small ops
         print(json.dumps(out), flush=True)

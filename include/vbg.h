@@ -74,6 +74,9 @@ typedef struct vbg_gemm_desc {
        model/ResNetFPN_ViBERTgrid.py:116-123): per column sum and sum of squares of the stored values are added (fp64 atomics) into
        slot row (row-tile index % stats_slots) of stats[stats_slots][2*N]; needs splitk == 1, no accumulate, ldc % 4 == 0, C 16-B aligned */
     double* stats; int stats_slots;
+    /* amp: multiply on the bf16 matrix cores (operands stay fp32 in memory, are rounded to bf16 -- nearest even -- inside the
+       kernel, products accumulate in fp32; replaces torch.cuda.amp.autocast of pipeline/train_val_utils.py:264 for these ops) */
+    int bf16;
 } vbg_gemm_desc;
 
 int vbg_gemm(const vbg_gemm_desc* desc, void* stream);

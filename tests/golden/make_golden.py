@@ -610,6 +610,46 @@ def gen_e2e(V, tmp):
     npz("e2e.npz", **out)
 
 
+def gen_e2e_amp(V, tmp):
+    """`amp: True` (example_config.yaml:8): the reference's autocast region (pipeline/train_val_utils.py:264) around the r18 model
+    of e2e.npz on the same documents.  CUDA autocast (fp16) cannot run here; CPU autocast to bfloat16 is the closest thing the
+    reference itself can produce in this container -- same op list (conv / linear / matmul in reduced precision, normalisation
+    and losses in fp32), same 8-bit-mantissa-class rounding as the product's bf16 matrix cores."""
+    e = np.load(os.path.join(HERE, "e2e.npz"))
+    tokenizer = BertTokenizer(os.path.join(tmp, "bert-base-uncased", "vocab.txt"))
+    net = V.ViBERTgridNet(num_classes=5, image_mean=[0.9248, 0.9224, 0.9215], image_std=[0.1532, 0.1545, 0.1536],
+                          image_min_size=[96], image_max_size=128, test_image_min_size=96,
+                          bert_model="bert-base-uncased", tokenizer=tokenizer, backbone="resnet_18_fpn", grid_mode="mean",
+                          loss_weights=None, num_hard_positive_main_1=4, num_hard_negative_main_1=4,
+                          num_hard_positive_main_2=6, num_hard_negative_main_2=6,
+                          loss_aux_sample_list=[64, 128, 64], num_hard_positive_aux=64, num_hard_negative_aux=64,
+                          loss_control_lambda=1, add_pos_neg=True, classifier_mode="simp", ohem_random=True,
+                          layer_mode="single", work_mode="eval")
+    load_synth(net)
+    imgs = tuple(torch.from_numpy(e[f"img{b}"]) for b in range(2))
+    coors = tuple(torch.from_numpy(e[f"coor{b}"]) for b in range(2))
+    segs = tuple(torch.from_numpy(e[f"seg{b}"]) for b in range(2))
+    classes = tuple(torch.from_numpy(e[f"class{b}"]) for b in range(2))
+    corpus, mask = torch.from_numpy(e["corpus"]), torch.from_numpy(e["mask"])
+    out = {}
+    net.eval()
+    random.seed(7)
+    with torch.no_grad(), torch.autocast("cpu", dtype=torch.bfloat16):
+        loss, pm, ps, gt, pred = net(imgs, segs, classes, coors, corpus, mask)
+    out.update({"r18_eval_loss": loss.float(), "r18_pred": pred.float(), "r18_gt": gt, "r18_pred_ss": ps.float()[:, :, ::4, ::4]})
+    net.train()
+    random.seed(7)
+    with torch.autocast("cpu", dtype=torch.bfloat16):
+        loss = net(imgs, segs, classes, coors, corpus, mask)
+    loss.backward()
+    out["r18_train_loss"] = loss.float()
+    named = dict(net.named_parameters())
+    for k in ["late_fusion_net.fuse_embedding_net.linear.weight", "field_type_classification_head.category_classification_net.linear_2.weight",
+              "bert_model.encoder.layer.1.output.dense.weight"]:
+        out[f"r18_grad::{k}"] = named[k].grad.float().flatten()[:: max(1, named[k].numel() // 4096)][:4096]
+    npz("e2e_amp.npz", **out)
+
+
 def main():
     torch.set_num_threads(8)
     install_torchvision_stub()
@@ -624,7 +664,7 @@ def main():
     import pipeline.custom_loss as L
     import pipeline.transform as T
 
-    which = sys.argv[1:] or ["transform", "windows", "aggregate", "scatter", "losses", "labels", "bert", "backbone", "backbone_d", "e2e", "e2e_roberta", "losses_bce", "e2e_modes"]
+    which = sys.argv[1:] or ["transform", "windows", "aggregate", "scatter", "losses", "labels", "bert", "backbone", "backbone_d", "e2e", "e2e_roberta", "losses_bce", "e2e_modes", "e2e_amp"]
     if "transform" in which:
         gen_transform(T)
     if "windows" in which:
@@ -651,6 +691,8 @@ def main():
         gen_losses_bce(L)
     if "e2e_modes" in which:
         gen_e2e_modes(V, tmp)
+    if "e2e_amp" in which:
+        gen_e2e_amp(V, tmp)
 
 
 if __name__ == "__main__":

@@ -671,6 +671,56 @@ def test_optimizers(ops):
     assert close(pd, p, 1e-6, 1e-7)
 
 
+def _bf16_exact(t):
+    return t.bfloat16().float()
+
+
+@pytest.mark.parametrize("tile", [0, 64064, 128128])
+def test_amp_products_match_fp32_on_bf16_values(ops, tile):
+    """amp = the same products on the bf16 matrix cores: with operands that are exactly representable in bf16 the rounding inside
+    the kernel is the identity, every partial product is exact in fp32, and the result may differ from the fp32 form only by the
+    summation order -- checked for all six operand-kind pairs (linear / conv x fwd, dgrad, wgrad), ragged M/N/K included"""
+    d = dev()
+    ops._FORCE[0] = tile
+    try:
+        # linear: fwd (K-contig x K-contig), dgrad (K-contig x row-contig), wgrad (row-contig x row-contig), K tail 200 % 32 = 8
+        for M, N, K in [(300, 132, 200), (1100, 256, 512), (64, 64, 32)]:
+            x, w, dy = _bf16_exact(rnd(M, K, seed=1).to(d)), _bf16_exact(rnd(N, K, seed=2).to(d)), _bf16_exact(rnd(M, N, seed=3).to(d))
+            b = rnd(N, seed=4).to(d)
+            with torch.no_grad():
+                ref = (ops.linear_fwd(x, w, b), ops.linear_dgrad(dy, w), ops.linear_wgrad(dy, x, torch.zeros(N, K, device=d), accumulate=False))
+                with ops.amp_scope(True):
+                    got = (ops.linear_fwd(x, w, b), ops.linear_dgrad(dy, w), ops.linear_wgrad(dy, x, torch.zeros(N, K, device=d), accumulate=False))
+            for r, g in zip(ref, got):
+                assert torch.allclose(r, g, rtol=1e-5, atol=1e-5 * float(r.abs().max())), (M, N, K, float((r - g).abs().max()))
+        # convolutions (NHWC, OHWI): 3x3 s1, 3x3 s2, 1x1, 7x7-like taps on 64 channels
+        for (B, H, W, Ci, Co, k, st, pd) in [(2, 20, 24, 64, 96, 3, 1, 1), (2, 32, 32, 64, 128, 3, 2, 1), (3, 16, 16, 128, 64, 1, 1, 0), (1, 64, 64, 32, 256, 3, 1, 1)]:
+            x = _bf16_exact(rnd(B, H, W, Ci, seed=5).to(d))
+            w = _bf16_exact(rnd(Co, k, k, Ci, seed=6).to(d))
+            Ho, Wo = ops.conv_out_hw(H, W, k, st, pd)
+            dy = _bf16_exact(rnd(B, Ho, Wo, Co, seed=7).to(d))
+            with torch.no_grad():
+                ref = (ops.conv2d_fwd(x, w, st, pd), ops.conv2d_dgrad(dy, w, x.shape, st, pd), ops.conv2d_wgrad(dy, x, torch.zeros_like(w), st, pd, accumulate=False))
+                with ops.amp_scope(True):
+                    got = (ops.conv2d_fwd(x, w, st, pd), ops.conv2d_dgrad(dy, w, x.shape, st, pd), ops.conv2d_wgrad(dy, x, torch.zeros_like(w), st, pd, accumulate=False))
+            for r, g in zip(ref, got):
+                assert torch.allclose(r, g, rtol=1e-5, atol=1e-5 * float(r.abs().max())), ((B, H, W, Ci, Co, k, st), float((r - g).abs().max()))
+    finally:
+        ops._FORCE[0] = 0
+
+
+def test_amp_rounds_operands_to_bf16(ops):
+    """general fp32 operands: the amp product equals the fp64 product of the bf16-rounded (nearest-even) operands"""
+    d = dev()
+    x, w = rnd(500, 320, seed=11).to(d), rnd(192, 320, seed=12).to(d)
+    with torch.no_grad(), ops.amp_scope(True):
+        y = ops.linear_fwd(x, w)
+    ref = (x.bfloat16().double() @ w.bfloat16().double().t())
+    assert torch.allclose(y.double(), ref, rtol=1e-5, atol=1e-5 * float(ref.abs().max()))
+    exact = x.double() @ w.double().t()
+    assert float((y.double() - exact).abs().max()) > 1e-4 * float(exact.abs().max())          # (it IS a reduced-precision product)
+
+
 @pytest.mark.parametrize("M,N,K,tile", [(300, 64, 96, 0), (4100, 256, 64, 0), (777, 132, 200, 0), (5000, 256, 288, 128128), (130, 16, 147, 0)])
 def test_gemm_fused_bn_statistics(ops, M, N, K, tile):
     """the GEMM epilogue adds the per-column sum / sum of squares of its output into the BatchNorm slot rows (what vbg_bn_stats

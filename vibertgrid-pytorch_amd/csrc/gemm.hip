@@ -69,8 +69,18 @@ __device__ __forceinline__ void set_vo(unsigned (&vo)[NE], long long elem, bool 
     for (int e = 0; e < NE; ++e) vo[e] = (ok && (NE == 1 || e < nvalid)) ? (unsigned)((elem + e) * 4) : VO_INVALID;
 }
 
+// two floats -> two bf16 (round to nearest even) in one dword, `lo` in the low half
+__device__ __forceinline__ unsigned cvt_pk_bf16(float lo, float hi) {
+    unsigned r;
+    asm("v_cvt_pk_bf16_f32 %0, %1, %2" : "=v"(r) : "v"(lo), "v"(hi));
+    return r;
+}
+typedef __bf16 bf16x8 __attribute__((ext_vector_type(8)));
+
 // NT = threads per block (256: 4 waves in 2x2, LDS double buffered, one barrier per k-tile).
-template <int BM, int BN, int BK, int NT, int AK, int BKD, bool VEC>
+// HB ("amp"): the operands stay fp32 in HBM, are rounded to bf16 on their way into LDS and multiplied with
+// v_mfma_f32_32x32x16_bf16 (fp32 accumulate, 16x the fp32 matrix rate); loaders and epilogue are shared with the fp32 form.
+template <int BM, int BN, int BK, int NT, int AK, int BKD, bool VEC, bool HB = false>
 __global__ __launch_bounds__(NT) void gemm_kernel(const vbg_gemm_desc p) {
     constexpr int WGM = 2, WGN = 2;
     constexpr int NBUF = 2;
@@ -81,14 +91,18 @@ __global__ __launch_bounds__(NT) void gemm_kernel(const vbg_gemm_desc p) {
     constexpr bool B_KC = (BKD == VBG_OP_DENSE_K);
     constexpr int SKR = BK + 4;                // row stride of a row-major (K-contiguous) LDS tile
     constexpr int SA = BM + 4, SB = BN + 4;    // k-row stride of a k-major (row-contiguous) LDS tile
-    constexpr int ASZ = A_KC ? BM * SKR : BK * SA;
-    constexpr int BSZ = B_KC ? BN * SKR : BK * SB;
+    constexpr int SKH = BK + 8;                // HB: bf16 row stride; both operands are K-contiguous [row][BK+8] in LDS
+    constexpr int ASZ = HB ? BM * SKH / 2 : (A_KC ? BM * SKR : BK * SA);        // (floats)
+    constexpr int BSZ = HB ? BN * SKH / 2 : (B_KC ? BN * SKR : BK * SB);
+    constexpr int CTS = BN + 4;                // row stride of the staged output tile (epilogue)
+    constexpr int SMEM = (HB && BM * CTS > NBUF * (ASZ + BSZ)) ? BM * CTS : NBUF * (ASZ + BSZ);
+    static_assert(!HB || (VEC && BK % 16 == 0 && (BM * KF / NT) % 2 == 0 && (BN * KF / NT) % 2 == 0), "bf16 form: vector loads, paired k rows");
     constexpr int NA = BM * KF / NT;
     constexpr int NB = BN * KF / NT;
     constexpr int WM = BM / WGM, WN = BN / WGN;
     constexpr int TM = WM / 32, TN = WN / 32;
     static_assert(NT == 256, "4-wave blocks only");
-    __shared__ __attribute__((aligned(16))) float smem[NBUF * (ASZ + BSZ)];
+    __shared__ __attribute__((aligned(16))) float smem[SMEM];
     float* const As = smem;
     float* const Bs = smem + NBUF * ASZ;
 
@@ -148,6 +162,11 @@ __global__ __launch_bounds__(NT) void gemm_kernel(const vbg_gemm_desc p) {
     long long a_rem = NREC_MAX, b_rem = NREC_MAX;
     unsigned avo[NA][NE], bvo[NB][NE];
     const int kcA = (tid % KF) * 4;            // k offset of this thread's float4s in a K-contiguous tile (NT % KF == 0)
+    // row-contiguous kinds (BR4 float4 per k row of the tile): float4 #i covers tile rows r_row .. +3 at tile k index r_k(i).
+    // fp32 form: pass i takes k rows [i*NT/BR4, (i+1)*NT/BR4); bf16 form: passes 2j, 2j+1 take ADJACENT k rows, so that a
+    // thread can pack (k, k+1) pairs into dwords for the K-contiguous bf16 LDS tile.
+    auto r_row = [&](int BR4) { return (tid % BR4) * 4; };
+    auto r_k = [&](int i, int BR4) { return HB ? 2 * (tid / BR4) + (i & 1) + 2 * (NT / BR4) * (i >> 1) : tid / BR4 + i * (NT / BR4); };
 
     // ---- A -------------------------------------------------------------------------------
     int a_n[NA], a_y[NA], a_x[NA];             // tile row -> (image, y, x) for conv / up-sampled segments
@@ -228,9 +247,8 @@ __global__ __launch_bounds__(NT) void gemm_kernel(const vbg_gemm_desc p) {
         a_rem = ((long long)(K - k0) * p.lda) * 4;
 #pragma unroll
         for (int i = 0; i < NA; ++i) {
-            const int f = tid + i * NT;
-            const int rl = (f % (BM / 4)) * 4;
-            set_vo<NE>(avo[i], (long long)(f / (BM / 4)) * p.lda + rl, m0 + rl < M, M - m0 - rl);
+            const int rl = r_row(BM / 4);
+            set_vo<NE>(avo[i], (long long)r_k(i, BM / 4) * p.lda + rl, m0 + rl < M, M - m0 - rl);
         }
     }
     // ---- B -------------------------------------------------------------------------------
@@ -263,9 +281,8 @@ __global__ __launch_bounds__(NT) void gemm_kernel(const vbg_gemm_desc p) {
         b_rem = ((long long)(K - k0) * p.ldb) * 4;
 #pragma unroll
         for (int i = 0; i < NB; ++i) {
-            const int f = tid + i * NT;
-            const int cl = (f % (BN / 4)) * 4;
-            set_vo<NE>(bvo[i], (long long)(f / (BN / 4)) * p.ldb + cl, n0 + cl < N, N - n0 - cl);
+            const int cl = r_row(BN / 4);
+            set_vo<NE>(bvo[i], (long long)r_k(i, BN / 4) * p.ldb + cl, n0 + cl < N, N - n0 - cl);
         }
     } else if constexpr (BKD == VBG_OP_WT_R) {      // dgrad weights [Cout][taps][Cin]: k = tap*Cout + co, col = ci
         const int Cout = geo.Cs, taps = geo.kh * geo.kw;
@@ -274,9 +291,8 @@ __global__ __launch_bounds__(NT) void gemm_kernel(const vbg_gemm_desc p) {
         bbase = B + ((long long)b_co0 * taps + b_tap) * N + n0;
 #pragma unroll
         for (int i = 0; i < NB; ++i) {
-            const int f = tid + i * NT;
-            const int cl = (f % (BN / 4)) * 4;
-            set_vo<NE>(bvo[i], (long long)(f / (BN / 4)) * taps * N + cl, n0 + cl < N);
+            const int cl = r_row(BN / 4);
+            set_vo<NE>(bvo[i], (long long)r_k(i, BN / 4) * taps * N + cl, n0 + cl < N);
         }
     } else {                                        // VBG_OP_CONV_R: k = pixel, col = (tap, ci)
         b_img_n = k0 / b_hw;
@@ -287,21 +303,20 @@ __global__ __launch_bounds__(NT) void gemm_kernel(const vbg_gemm_desc p) {
         b_xs = b_img_pix - b_y0 * geo.Wr;
 #pragma unroll
         for (int i = 0; i < NB; ++i) {
-            const int f = tid + i * NT;
-            const int c = n0 + (f % (BN / 4)) * 4;
+            const int c = n0 + r_row(BN / 4);
             b_cv[i] = c < N;
             const int cc = min(c, N - 4);
             const int tap = cc / geo.Cs;
             b_ci[i] = cc - tap * geo.Cs;
             b_dy[i] = tap / geo.kw;
             b_dx[i] = tap - b_dy[i] * geo.kw;
-            const int pix = k0 + f / (BN / 4);
+            const int pix = k0 + r_k(i, BN / 4);
             b_px[i] = pix % geo.Wr;
             const int t = pix / geo.Wr;
             b_py[i] = t % geo.Hr;
             b_pn[i] = t / geo.Hr - b_img_n;        // relative to the descriptor's image
             // fast path constants (offsets are biased by +pad rows / columns so they are never negative)
-            const int kl = f / (BN / 4);
+            const int kl = r_k(i, BN / 4);
             const int ry = kl / geo.Wr, rx = kl - ry * geo.Wr;
             b_cy[i] = ry * geo.stride - geo.pad + b_dy[i];
             b_cx[i] = rx * geo.stride - geo.pad + b_dx[i];
@@ -407,7 +422,7 @@ __global__ __launch_bounds__(NT) void gemm_kernel(const vbg_gemm_desc p) {
             const __amdgpu_buffer_rsrc_t r = make_rsrc(bbase, NREC_MAX);
 #pragma unroll
             for (int i = 0; i < NB; ++i) {
-                const int pix = k0 + (tid + i * NT) / (BN / 4);
+                const int pix = k0 + r_k(i, BN / 4);
                 const int sy = b_py[i] * geo.stride - geo.pad + b_dy[i];
                 const int sx = b_px[i] * geo.stride - geo.pad + b_dx[i];
                 const bool ok = (pix < K) && b_cv[i] && sy >= 0 && sy < geo.Hs && sx >= 0 && sx < geo.Ws;
@@ -435,10 +450,56 @@ __global__ __launch_bounds__(NT) void gemm_kernel(const vbg_gemm_desc p) {
 
     const int a_prologue = p.a_prologue;
     const float a_scale = p.a_scale;
+    // bf16 form of one operand tile: K-contiguous float4s become 4 bf16 (one 8-byte ds_write); row-contiguous float4s of two
+    // adjacent k rows are packed pairwise (k, k+1) into one dword per tile row
+    auto store_half = [&](unsigned* dst, const auto& r, auto kc_tag, auto br4_tag) {
+        constexpr int n = std::extent<std::remove_reference_t<decltype(r)>>::value;
+        constexpr int BR4 = decltype(br4_tag)::value;
+        if constexpr (decltype(kc_tag)::value) {
+#pragma unroll
+            for (int i = 0; i < n; ++i) {
+                const int f = tid + i * NT;
+                uint2 w;
+                w.x = cvt_pk_bf16(r[i].x, r[i].y); w.y = cvt_pk_bf16(r[i].z, r[i].w);
+                *reinterpret_cast<uint2*>(&dst[((f / KF) * SKH + (f % KF) * 4) / 2]) = w;
+            }
+        } else {
+#pragma unroll
+            for (int i = 0; i < n; i += 2) {
+                const int row = r_row(BR4), k = r_k(i, BR4);
+                dst[((row + 0) * SKH + k) / 2] = cvt_pk_bf16(r[i].x, r[i + 1].x);
+                dst[((row + 1) * SKH + k) / 2] = cvt_pk_bf16(r[i].y, r[i + 1].y);
+                dst[((row + 2) * SKH + k) / 2] = cvt_pk_bf16(r[i].z, r[i + 1].z);
+                dst[((row + 3) * SKH + k) / 2] = cvt_pk_bf16(r[i].w, r[i + 1].w);
+            }
+        }
+    };
     auto store_tiles = [&](auto tail_tag, int buf) {
         constexpr bool TAIL = decltype(tail_tag)::value;
         float* as = As + buf * ASZ;
         float* bs = Bs + buf * BSZ;
+        if constexpr (HB) {
+            float4 va[NA], vb[NB];
+#pragma unroll
+            for (int i = 0; i < NA; ++i) {
+                float4 v = ra[i];
+                if constexpr (AK == VBG_OP_DENSE_K && TAIL) v = mask4(v, st_rem_a - kcA);
+                if (a_prologue == 1) {
+                    v.x = fmaxf(v.x, 0.f) * a_scale; v.y = fmaxf(v.y, 0.f) * a_scale;
+                    v.z = fmaxf(v.z, 0.f) * a_scale; v.w = fmaxf(v.w, 0.f) * a_scale;
+                }
+                va[i] = v;
+            }
+#pragma unroll
+            for (int i = 0; i < NB; ++i) {
+                float4 v = rb[i];
+                if constexpr (BKD == VBG_OP_DENSE_K && TAIL) v = mask4(v, st_rem_b - kcA);
+                vb[i] = v;
+            }
+            store_half(reinterpret_cast<unsigned*>(as), va, std::integral_constant<bool, A_KC>{}, std::integral_constant<int, BM / 4>{});
+            store_half(reinterpret_cast<unsigned*>(bs), vb, std::integral_constant<bool, B_KC>{}, std::integral_constant<int, BN / 4>{});
+            return;
+        }
 #pragma unroll
         for (int i = 0; i < NA; ++i) {
             float4 v = ra[i];
@@ -524,6 +585,34 @@ __global__ __launch_bounds__(NT) void gemm_kernel(const vbg_gemm_desc p) {
     // peeled after it, so the loop carries no per-tile branches on them.
     auto k_tile = [&](auto tail_tag, auto more_tag, int buf) {
         constexpr bool MORE = decltype(more_tag)::value;
+        if constexpr (HB) {
+            // lane (lr, lk) of MFMA step s reads the 8 bf16 k = 16 s + 8 lk .. +7 of its row: one ds_read_b128 per fragment
+            constexpr int KS = BK / 16;
+            const u32x4* as = reinterpret_cast<const u32x4*>(As + buf * ASZ) + ((wm * WM + lr) * SKH + 8 * lk) / 8;
+            const u32x4* bs = reinterpret_cast<const u32x4*>(Bs + buf * BSZ) + ((wn * WN + lr) * SKH + 8 * lk) / 8;
+            u32x4 fa[KS][TM], fb[KS][TN];
+#pragma unroll
+            for (int s = 0; s < KS; ++s) {
+#pragma unroll
+                for (int i = 0; i < TM; ++i) fa[s][i] = as[(i * 32 * SKH + 16 * s) / 8];
+#pragma unroll
+                for (int i = 0; i < TN; ++i) fb[s][i] = bs[(i * 32 * SKH + 16 * s) / 8];
+            }
+            __builtin_amdgcn_sched_barrier(0);
+            if constexpr (MORE) load_tiles(tail_tag);
+            __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+            for (int s = 0; s < KS; ++s)
+#pragma unroll
+                for (int i = 0; i < TM; ++i)
+#pragma unroll
+                    for (int n = 0; n < TN; ++n)
+                        acc[i][n] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(__builtin_bit_cast(bf16x8, fa[s][i]), __builtin_bit_cast(bf16x8, fb[s][n]),
+                                                                            acc[i][n], 0, 0, 0);
+            __builtin_amdgcn_sched_barrier(0);
+            if constexpr (MORE) { store_tiles(tail_tag, buf ^ 1); __syncthreads(); }
+            return;
+        }
         const float* as = As + buf * ASZ + a_off;
         const float* bs = Bs + buf * BSZ + b_off;
         float fa0[TM][4], fb0[TN][4], fa1[TM][4], fb1[TN][4];
@@ -574,8 +663,7 @@ __global__ __launch_bounds__(NT) void gemm_kernel(const vbg_gemm_desc p) {
     // Plain stores go through LDS: the accumulator layout gives each lane single floats of 16 different rows (16 dword stores per
     // 32x32 tile, 128 contiguous bytes per row); staged through the (now idle) operand tiles, every thread writes float4s of
     // complete 64-float row pieces instead.  Output-bound products (attention scores, K = 64) are limited by exactly this.
-    constexpr int CTS = BN + 4;
-    constexpr bool STAGE_OK = BM * CTS <= NBUF * (ASZ + BSZ);
+    constexpr bool STAGE_OK = BM * CTS <= SMEM;
     if (STAGE_OK && !atomic && (ldc & 3) == 0 && (((uintptr_t)C) & 15) == 0 && (epi != VBG_EPI_GELU_DUAL || (((uintptr_t)C2) & 15) == 0)) {
         __syncthreads();                                  // every wave is done with the operand tiles
         float* const Ct = smem;
@@ -630,7 +718,7 @@ __global__ __launch_bounds__(NT) void gemm_kernel(const vbg_gemm_desc p) {
             // then one fp64 atomic per column and statistic into this row-tile's slot row
             constexpr int RG = NT / QN;                    // row groups
             float* red = smem;                             // [2][RG][BN], over the staged tile once every thread has read its pieces
-            static_assert(2 * (NT / (BN / 4)) * BN <= NBUF * (ASZ + BSZ), "no room for the statistics partials");
+            static_assert(2 * (NT / (BN / 4)) * BN <= SMEM, "no room for the statistics partials");
             __syncthreads();
             const int rg = tid / QN, c = (tid % QN) * 4;
             *reinterpret_cast<float4*>(&red[(0 * RG + rg) * BN + c]) = cs;
@@ -695,12 +783,12 @@ __global__ __launch_bounds__(NT) void gemm_kernel(const vbg_gemm_desc p) {
 // timestamps -- what rocprofv3's kernel trace reads -- with no barrier packets around the kernel
 struct launch_timer { hipEvent_t start = nullptr, stop = nullptr; };
 
-template <int BM, int BN, int BK, int NT, int AK, int BKD, bool VEC>
+template <int BM, int BN, int BK, int NT, int AK, int BKD, bool VEC, bool HB = false>
 static void launch_one(const vbg_gemm_desc& d, int groups, int maxM, int maxN, hipStream_t s, const launch_timer& t) {
     dim3 g(cdiv(maxM, BM), cdiv(maxN, BN), groups * d.splitk);
     (void)hipGetLastError();
-    if (t.start && t.stop) hipExtLaunchKernelGGL((gemm_kernel<BM, BN, BK, NT, AK, BKD, VEC>), g, dim3(NT), 0, s, t.start, t.stop, 0, d);
-    else hipLaunchKernelGGL((gemm_kernel<BM, BN, BK, NT, AK, BKD, VEC>), g, dim3(NT), 0, s, d);
+    if (t.start && t.stop) hipExtLaunchKernelGGL((gemm_kernel<BM, BN, BK, NT, AK, BKD, VEC, HB>), g, dim3(NT), 0, s, t.start, t.stop, 0, d);
+    else hipLaunchKernelGGL((gemm_kernel<BM, BN, BK, NT, AK, BKD, VEC, HB>), g, dim3(NT), 0, s, d);
 }
 
 // tile code: BM*1000+BN (128128, 128064, 64064); 0 = heuristic.  (A barrier-free one-wave-per-tile variant (NT = 64) was
@@ -728,6 +816,13 @@ static int launch_pair(const vbg_gemm_desc& d, int groups, int maxM, int maxN, h
     pick_tile(d, groups, maxM, maxN, tile, bk);
     if (!(d.a_vec && d.b_vec)) {                         // unaligned operands: general scalar-load path
         launch_one<64, 64, 16, 256, AK, BKD, false>(d, groups, maxM, maxN, s, t);
+    } else if (d.bf16 && (d.bk == 0 || d.bk == 32)) {
+        // amp: bf16 matrix cores (fp32 operands rounded on the way into LDS).  The loop is bound by operand traffic, not by the
+        // MFMAs, so the larger tile wins as soon as it fills the chip.  (Products forced to 16-deep k-tiles -- channel counts
+        // that are not a multiple of 32 -- and unaligned operands stay on the fp32 form.)
+        if (d.tile == 0) tile = ((long)cdiv(maxM, 128) * cdiv(maxN, 128) * groups * d.splitk >= 256 && maxN >= 128) ? 128128 : 64064;
+        if (tile == 128128) launch_one<128, 128, 32, 256, AK, BKD, true, true>(d, groups, maxM, maxN, s, t);
+        else launch_one<64, 64, 32, 256, AK, BKD, true, true>(d, groups, maxM, maxN, s, t);
     } else if (bk == 32) {
         if (tile == 128128) launch_one<128, 128, 32, 256, AK, BKD, true>(d, groups, maxM, maxN, s, t);
         else if (tile == 128064) launch_one<128, 64, 32, 256, AK, BKD, true>(d, groups, maxM, maxN, s, t);

@@ -24,6 +24,7 @@ from model.field_type_classification_head import (CRFFieldTypeClassification, Fi
 from model.grid_roi_align import GridROIAlign
 from model.ResNetFPN_ViBERTgrid import resnet_18_D_fpn, resnet_18_fpn, resnet_34_D_fpn, resnet_34_fpn
 from model.semantic_segmentation_head import SemanticSegmentationClassifier, SimplifiedSemanticSegmentationClassifier
+from vbg import ops
 from pipeline.custom_loss import PendingCounts, resolve_plans  # noqa: F401
 from pipeline.transform import GeneralizedViBERTgridTransform, ImageList  # noqa: F401  (ImageList re-exported like the reference)
 
@@ -205,6 +206,7 @@ class ViBERTgridNet(nn.Module):
 
     def inference(self, image: Tuple[torch.Tensor], seg_indices: Tuple[torch.Tensor], coors: torch.Tensor, corpus: torch.Tensor,
                   mask: torch.Tensor):
+        ops.set_amp(torch.is_autocast_enabled("cuda"))
         batch, icoors, packed, B, H, W = self._trunk(image, seg_indices, coors, corpus, mask)
         emb_cat, p_fuse = self._features(batch, packed, B, H, W, seg_indices, corpus, mask)
         roi = self.grid_roi_align_net(p_fuse, icoors, None, packed=packed)
@@ -213,6 +215,9 @@ class ViBERTgridNet(nn.Module):
 
     def forward(self, image: Tuple[torch.Tensor], seg_indices: Tuple[torch.Tensor], segment_classes: Tuple[torch.Tensor],
                 coors: torch.Tensor, corpus: torch.Tensor, mask: torch.Tensor):
+        # `amp: True`: the caller wraps this call in torch.cuda.amp.autocast (reference pipeline/train_val_utils.py:264); the
+        # matrix products of this forward AND of its backward then run on the bf16 matrix cores (see vbg.ops.set_amp)
+        ops.set_amp(torch.is_autocast_enabled("cuda"))
         batch, icoors, packed, B, H, W = self._trunk(image, seg_indices, coors, corpus, mask)
         seg_head, cls_head = self.semantic_segmentation_head, self.field_type_classification_head
         if self.classifier_mode != "simp":

@@ -32,7 +32,7 @@ class GemmDesc(C.Structure):
                 ("C", c_vp), ("ldc", c_ll), ("C2", c_vp), ("bias", c_vp),
                 ("epi", c_int), ("alpha", c_f), ("accumulate", c_int), ("splitk", c_int), ("tile", c_int),
                 ("grp", c_vp), ("ngroups", c_int), ("grp_maxM", c_int), ("grp_maxN", c_int), ("bk", c_int),
-                ("stats", c_vp), ("stats_slots", c_int)]
+                ("stats", c_vp), ("stats_slots", c_int), ("bf16", c_int)]
 
 
 OP_DENSE_K, OP_DENSE_R, OP_CONV_K, OP_CONV_R, OP_WT_R = 0, 1, 2, 3, 4

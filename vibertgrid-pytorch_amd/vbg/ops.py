@@ -77,6 +77,10 @@ def gemm_raw(M, N, K, A, lda, a_kind, B, ldb, b_kind, Cout, ldc, *, bias=None, e
         splitk = 1
     d.epi, d.alpha, d.accumulate, d.splitk, d.tile = epi, float(alpha), int(bool(accumulate)), int(splitk), int(tile)
     d.bk = int(bk)
+    if _AMP[0]:
+        d.bf16 = 1
+        if bk == 16:
+            d.bk = 0        # (the 16-deep k-tiles are an fp32-form tuning; the bf16 form has one depth)
     if _FORCE[0] or _FORCE[1]:          # debugging / conditioning experiments: force one tile configuration
         d.tile, d.bk = _FORCE[0] or d.tile, _FORCE[1] or d.bk
     if grp is not None:
@@ -140,6 +144,33 @@ def set_gemm_profiler(p):
 
 
 _FORCE = [0, 0]
+
+# amp (reference: `with torch.cuda.amp.autocast(enabled=scaler is not None)` around the model call,
+# pipeline/train_val_utils.py:264): every GEMM / convolution product multiplies on the bf16 matrix cores.  Tensors stay fp32 in
+# memory (the kernel rounds operands to bf16 on their way into LDS and accumulates in fp32), so nothing else changes shape or
+# dtype and no loss scaling is needed for range (a GradScaler passed by the caller keeps working on the fp32 gradients).
+# ViBERTgridNet.forward latches torch.is_autocast_enabled() here; the backward of that forward sees the same setting.
+_AMP = [False]
+
+
+def set_amp(on: bool):
+    _AMP[0] = bool(on)
+
+
+def amp_enabled() -> bool:
+    return _AMP[0]
+
+
+class amp_scope:
+    def __init__(self, on=True):
+        self.on = on
+
+    def __enter__(self):
+        self.prev = _AMP[0]
+        _AMP[0] = bool(self.on)
+
+    def __exit__(self, *exc):
+        _AMP[0] = self.prev
 
 
 def _pick_splitk(M, N, Kred, bk=32):
