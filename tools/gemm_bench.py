@@ -45,7 +45,9 @@ def main():
     ap.add_argument("--tiles", default="0")
     ap.add_argument("--only", default="")
     ap.add_argument("--bks", default="0")
+    ap.add_argument("--amp", action="store_true", help="bf16 matrix-core form (amp)")
     args = ap.parse_args()
+    ops.set_amp(args.amp)
     tiles = [int(t) for t in args.tiles.split(",")]
     R = lambda *s: torch.randn(*s, device=dev)
     import itertools

@@ -820,7 +820,14 @@ static int launch_pair(const vbg_gemm_desc& d, int groups, int maxM, int maxN, h
         // amp: bf16 matrix cores (fp32 operands rounded on the way into LDS).  The loop is bound by operand traffic, not by the
         // MFMAs, so the larger tile wins as soon as it fills the chip.  (Products forced to 16-deep k-tiles -- channel counts
         // that are not a multiple of 32 -- and unaligned operands stay on the fp32 form.)
-        if (d.tile == 0) tile = ((long)cdiv(maxM, 128) * cdiv(maxN, 128) * groups * d.splitk >= 256 && maxN >= 128) ? 128128 : 64064;
+        // (tools/gemm_bench.py --amp: 128x128 wins for the forward kinds from ~512 tiles on -- 4128x3072x768 390 vs 326 TF/s, the
+        // 128x128-map convs 577 vs 401 -- and for the conv dgrad only on the largest maps; every wgrad and the small products
+        // are faster with 64x64 blocks)
+        if (d.tile == 0) {
+            const long t128 = (long)cdiv(maxM, 128) * cdiv(maxN, 128) * groups * d.splitk;
+            const bool big = (BKD == VBG_OP_DENSE_K && t128 >= 512) || (BKD == VBG_OP_WT_R && t128 >= 2048);
+            tile = (big && maxN >= 256 && AK != VBG_OP_DENSE_R) ? 128128 : 64064;
+        }
         if (tile == 128128) launch_one<128, 128, 32, 256, AK, BKD, true, true>(d, groups, maxM, maxN, s, t);
         else launch_one<64, 64, 32, 256, AK, BKD, true, true>(d, groups, maxM, maxN, s, t);
     } else if (bk == 32) {
