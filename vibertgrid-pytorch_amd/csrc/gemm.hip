@@ -78,10 +78,16 @@ __device__ __forceinline__ unsigned cvt_pk_bf16(float lo, float hi) {
 typedef __bf16 bf16x8 __attribute__((ext_vector_type(8)));
 
 // NT = threads per block (256: 4 waves in 2x2, LDS double buffered, one barrier per k-tile).
-// HB ("amp"): the operands stay fp32 in HBM, are rounded to bf16 on their way into LDS and multiplied with
+// PREC 1 ("amp"): the operands stay fp32 in HBM, are rounded to bf16 on their way into LDS and multiplied with
 // v_mfma_f32_32x32x16_bf16 (fp32 accumulate, 16x the fp32 matrix rate); loaders and epilogue are shared with the fp32 form.
-template <int BM, int BN, int BK, int NT, int AK, int BKD, bool VEC, bool HB = false>
+// PREC 3: fp32-grade products on the bf16 matrix cores.  Every operand element is split EXACTLY into three bf16 pieces
+// (x = hi + mid + lo: 8 + 8 + 8 significant bits, by truncation) held as three planes of the LDS tile, and a product is the sum
+// of the six piece products of order <= 2^-16 (hh, hm, mh, hl, lh, mm; each exact in fp32, accumulated in fp32).  The dropped
+// terms (ml, lm, ll) are <= 2^-23 of the product -- the size of the fp32 rounding of the product itself.
+template <int BM, int BN, int BK, int NT, int AK, int BKD, bool VEC, int PREC = 0>
 __global__ __launch_bounds__(NT) void gemm_kernel(const vbg_gemm_desc p) {
+    constexpr bool HB = PREC != 0;
+    constexpr int NP = PREC == 3 ? 3 : 1;      // bf16 planes per operand tile
     constexpr int WGM = 2, WGN = 2;
     constexpr int NBUF = 2;
     constexpr int NE = VEC ? 1 : 4;            // separately addressed pieces per float4
@@ -92,8 +98,15 @@ __global__ __launch_bounds__(NT) void gemm_kernel(const vbg_gemm_desc p) {
     constexpr int SKR = BK + 4;                // row stride of a row-major (K-contiguous) LDS tile
     constexpr int SA = BM + 4, SB = BN + 4;    // k-row stride of a k-major (row-contiguous) LDS tile
     constexpr int SKH = BK + 8;                // HB: bf16 row stride; both operands are K-contiguous [row][BK+8] in LDS
-    constexpr int ASZ = HB ? BM * SKH / 2 : (A_KC ? BM * SKR : BK * SA);        // (floats)
-    constexpr int BSZ = HB ? BN * SKH / 2 : (B_KC ? BN * SKR : BK * SB);
+    // Row-contiguous operands keep their tile rows in a permuted order in the bf16 forms: tile row r lives at LDS row
+    // (r % 4) * PS + r / 4 with PS = rows / 4 + 4.  A lane's four rows (r .. r+3, one float4 along the rows) then go to four
+    // row groups 16*k banks apart and the 16 lanes of a k row walk the banks in steps of 20 (2-way at worst, free for
+    // ds_write_b32; the plain order is 8-way: every 4th row is 16 banks on), while the fragment read stays conflict free:
+    // slot = 5 * (PS * (lr % 4) + lr / 4) is distinct over each of ds_read_b128's 16-lane groups exactly when PS = 4 mod 16.
+    constexpr int PSA = BM / 4 + 4, PSB = BN / 4 + 4;
+    constexpr int PA = (A_KC ? BM : 4 * PSA) * SKH / 2, PB = (B_KC ? BN : 4 * PSB) * SKH / 2;      // one bf16 plane (dwords)
+    constexpr int ASZ = HB ? NP * PA : (A_KC ? BM * SKR : BK * SA);             // (floats)
+    constexpr int BSZ = HB ? NP * PB : (B_KC ? BN * SKR : BK * SB);
     constexpr int CTS = BN + 4;                // row stride of the staged output tile (epilogue)
     constexpr int SMEM = (HB && BM * CTS > NBUF * (ASZ + BSZ)) ? BM * CTS : NBUF * (ASZ + BSZ);
     static_assert(!HB || (VEC && BK % 16 == 0 && (BM * KF / NT) % 2 == 0 && (BN * KF / NT) % 2 == 0), "bf16 form: vector loads, paired k rows");
@@ -452,25 +465,54 @@ __global__ __launch_bounds__(NT) void gemm_kernel(const vbg_gemm_desc p) {
     const float a_scale = p.a_scale;
     // bf16 form of one operand tile: K-contiguous float4s become 4 bf16 (one 8-byte ds_write); row-contiguous float4s of two
     // adjacent k rows are packed pairwise (k, k+1) into one dword per tile row
-    auto store_half = [&](unsigned* dst, const auto& r, auto kc_tag, auto br4_tag) {
+    // exact three-way split of a PAIR of floats into packed bf16 pairs (a in the low half): hi = top 16 bits, mid = top 16 bits of
+    // the (exact) remainder, lo = the (exact, <= 8 significant bits) remainder of that
+    auto split3 = [&](float a, float b, unsigned& hi, unsigned& mid, unsigned& lo) {
+        const float ra = a - __uint_as_float(__float_as_uint(a) & 0xffff0000u), rb = b - __uint_as_float(__float_as_uint(b) & 0xffff0000u);
+        const float sa = ra - __uint_as_float(__float_as_uint(ra) & 0xffff0000u), sb = rb - __uint_as_float(__float_as_uint(rb) & 0xffff0000u);
+        hi = __builtin_amdgcn_perm(__float_as_uint(b), __float_as_uint(a), 0x07060302u);
+        mid = __builtin_amdgcn_perm(__float_as_uint(rb), __float_as_uint(ra), 0x07060302u);
+        lo = __builtin_amdgcn_perm(__float_as_uint(sb), __float_as_uint(sa), 0x07060302u);
+    };
+    auto store_half = [&](unsigned* dst, const auto& r, auto kc_tag, auto br4_tag, auto plane_tag) {
         constexpr int n = std::extent<std::remove_reference_t<decltype(r)>>::value;
         constexpr int BR4 = decltype(br4_tag)::value;
+        constexpr int PS = BR4 + 4;
+        constexpr int PL = decltype(plane_tag)::value;          // plane stride (dwords)
         if constexpr (decltype(kc_tag)::value) {
 #pragma unroll
             for (int i = 0; i < n; ++i) {
                 const int f = tid + i * NT;
-                uint2 w;
-                w.x = cvt_pk_bf16(r[i].x, r[i].y); w.y = cvt_pk_bf16(r[i].z, r[i].w);
-                *reinterpret_cast<uint2*>(&dst[((f / KF) * SKH + (f % KF) * 4) / 2]) = w;
+                const int o = ((f / KF) * SKH + (f % KF) * 4) / 2;
+                if constexpr (PREC == 3) {
+                    uint2 h, m, l;
+                    split3(r[i].x, r[i].y, h.x, m.x, l.x);
+                    split3(r[i].z, r[i].w, h.y, m.y, l.y);
+                    *reinterpret_cast<uint2*>(&dst[o]) = h;
+                    *reinterpret_cast<uint2*>(&dst[o + PL]) = m;
+                    *reinterpret_cast<uint2*>(&dst[o + 2 * PL]) = l;
+                } else {
+                    uint2 w;
+                    w.x = cvt_pk_bf16(r[i].x, r[i].y); w.y = cvt_pk_bf16(r[i].z, r[i].w);
+                    *reinterpret_cast<uint2*>(&dst[o]) = w;
+                }
             }
         } else {
 #pragma unroll
             for (int i = 0; i < n; i += 2) {
-                const int row = r_row(BR4), k = r_k(i, BR4);
-                dst[((row + 0) * SKH + k) / 2] = cvt_pk_bf16(r[i].x, r[i + 1].x);
-                dst[((row + 1) * SKH + k) / 2] = cvt_pk_bf16(r[i].y, r[i + 1].y);
-                dst[((row + 2) * SKH + k) / 2] = cvt_pk_bf16(r[i].z, r[i + 1].z);
-                dst[((row + 3) * SKH + k) / 2] = cvt_pk_bf16(r[i].w, r[i + 1].w);
+                const int row4 = tid % BR4, k = r_k(i, BR4);
+                const float e0[4] = {r[i].x, r[i].y, r[i].z, r[i].w}, e1[4] = {r[i + 1].x, r[i + 1].y, r[i + 1].z, r[i + 1].w};
+#pragma unroll
+                for (int e = 0; e < 4; ++e) {
+                    const int o = ((e * PS + row4) * SKH + k) / 2;
+                    if constexpr (PREC == 3) {
+                        unsigned h, m, l;
+                        split3(e0[e], e1[e], h, m, l);
+                        dst[o] = h; dst[o + PL] = m; dst[o + 2 * PL] = l;
+                    } else {
+                        dst[o] = cvt_pk_bf16(e0[e], e1[e]);
+                    }
+                }
             }
         }
     };
@@ -496,8 +538,8 @@ __global__ __launch_bounds__(NT) void gemm_kernel(const vbg_gemm_desc p) {
                 if constexpr (BKD == VBG_OP_DENSE_K && TAIL) v = mask4(v, st_rem_b - kcA);
                 vb[i] = v;
             }
-            store_half(reinterpret_cast<unsigned*>(as), va, std::integral_constant<bool, A_KC>{}, std::integral_constant<int, BM / 4>{});
-            store_half(reinterpret_cast<unsigned*>(bs), vb, std::integral_constant<bool, B_KC>{}, std::integral_constant<int, BN / 4>{});
+            store_half(reinterpret_cast<unsigned*>(as), va, std::integral_constant<bool, A_KC>{}, std::integral_constant<int, BM / 4>{}, std::integral_constant<int, PA>{});
+            store_half(reinterpret_cast<unsigned*>(bs), vb, std::integral_constant<bool, B_KC>{}, std::integral_constant<int, BN / 4>{}, std::integral_constant<int, PB>{});
             return;
         }
 #pragma unroll
@@ -588,27 +630,37 @@ __global__ __launch_bounds__(NT) void gemm_kernel(const vbg_gemm_desc p) {
         if constexpr (HB) {
             // lane (lr, lk) of MFMA step s reads the 8 bf16 k = 16 s + 8 lk .. +7 of its row: one ds_read_b128 per fragment
             constexpr int KS = BK / 16;
-            const u32x4* as = reinterpret_cast<const u32x4*>(As + buf * ASZ) + ((wm * WM + lr) * SKH + 8 * lk) / 8;
-            const u32x4* bs = reinterpret_cast<const u32x4*>(Bs + buf * BSZ) + ((wn * WN + lr) * SKH + 8 * lk) / 8;
-            u32x4 fa[KS][TM], fb[KS][TN];
-#pragma unroll
-            for (int s = 0; s < KS; ++s) {
-#pragma unroll
-                for (int i = 0; i < TM; ++i) fa[s][i] = as[(i * 32 * SKH + 16 * s) / 8];
-#pragma unroll
-                for (int i = 0; i < TN; ++i) fb[s][i] = bs[(i * 32 * SKH + 16 * s) / 8];
-            }
-            __builtin_amdgcn_sched_barrier(0);
-            if constexpr (MORE) load_tiles(tail_tag);
-            __builtin_amdgcn_sched_barrier(0);
+            const int arow = A_KC ? wm * WM + lr : (lr & 3) * PSA + (wm * WM + lr) / 4;
+            const int brow = B_KC ? wn * WN + lr : (lr & 3) * PSB + (wn * WN + lr) / 4;
+            constexpr int AI = A_KC ? 32 : 8, BI = B_KC ? 32 : 8;          // LDS rows between a wave's 32-row fragments
+            const u32x4* as = reinterpret_cast<const u32x4*>(As + buf * ASZ) + (arow * SKH + 8 * lk) / 8;
+            const u32x4* bs = reinterpret_cast<const u32x4*>(Bs + buf * BSZ) + (brow * SKH + 8 * lk) / 8;
+            u32x4 fa[KS][NP][TM], fb[KS][NP][TN];
 #pragma unroll
             for (int s = 0; s < KS; ++s)
 #pragma unroll
-                for (int i = 0; i < TM; ++i)
+                for (int q = 0; q < NP; ++q) {
 #pragma unroll
-                    for (int n = 0; n < TN; ++n)
-                        acc[i][n] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(__builtin_bit_cast(bf16x8, fa[s][i]), __builtin_bit_cast(bf16x8, fb[s][n]),
-                                                                            acc[i][n], 0, 0, 0);
+                    for (int i = 0; i < TM; ++i) fa[s][q][i] = as[(q * 2 * PA + i * AI * SKH + 16 * s) / 8];
+#pragma unroll
+                    for (int i = 0; i < TN; ++i) fb[s][q][i] = bs[(q * 2 * PB + i * BI * SKH + 16 * s) / 8];
+                }
+            __builtin_amdgcn_sched_barrier(0);
+            if constexpr (MORE) load_tiles(tail_tag);
+            __builtin_amdgcn_sched_barrier(0);
+            // piece products, smallest first: (lo,hi) (hi,lo) (mid,mid) (mid,hi) (hi,mid) (hi,hi)
+            constexpr int NPP = PREC == 3 ? 6 : 1;
+            constexpr int qa[6] = {PREC == 3 ? 2 : 0, 0, 1, 1, 0, 0}, qb[6] = {0, 2, 1, 0, 1, 0};
+#pragma unroll
+            for (int s = 0; s < KS; ++s)
+#pragma unroll
+                for (int t = 0; t < NPP; ++t)
+#pragma unroll
+                    for (int i = 0; i < TM; ++i)
+#pragma unroll
+                        for (int n = 0; n < TN; ++n)
+                            acc[i][n] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(__builtin_bit_cast(bf16x8, fa[s][qa[t]][i]),
+                                                                                __builtin_bit_cast(bf16x8, fb[s][qb[t]][n]), acc[i][n], 0, 0, 0);
             __builtin_amdgcn_sched_barrier(0);
             if constexpr (MORE) { store_tiles(tail_tag, buf ^ 1); __syncthreads(); }
             return;
@@ -783,12 +835,12 @@ __global__ __launch_bounds__(NT) void gemm_kernel(const vbg_gemm_desc p) {
 // timestamps -- what rocprofv3's kernel trace reads -- with no barrier packets around the kernel
 struct launch_timer { hipEvent_t start = nullptr, stop = nullptr; };
 
-template <int BM, int BN, int BK, int NT, int AK, int BKD, bool VEC, bool HB = false>
+template <int BM, int BN, int BK, int NT, int AK, int BKD, bool VEC, int PREC = 0>
 static void launch_one(const vbg_gemm_desc& d, int groups, int maxM, int maxN, hipStream_t s, const launch_timer& t) {
     dim3 g(cdiv(maxM, BM), cdiv(maxN, BN), groups * d.splitk);
     (void)hipGetLastError();
-    if (t.start && t.stop) hipExtLaunchKernelGGL((gemm_kernel<BM, BN, BK, NT, AK, BKD, VEC, HB>), g, dim3(NT), 0, s, t.start, t.stop, 0, d);
-    else hipLaunchKernelGGL((gemm_kernel<BM, BN, BK, NT, AK, BKD, VEC, HB>), g, dim3(NT), 0, s, d);
+    if (t.start && t.stop) hipExtLaunchKernelGGL((gemm_kernel<BM, BN, BK, NT, AK, BKD, VEC, PREC>), g, dim3(NT), 0, s, t.start, t.stop, 0, d);
+    else hipLaunchKernelGGL((gemm_kernel<BM, BN, BK, NT, AK, BKD, VEC, PREC>), g, dim3(NT), 0, s, d);
 }
 
 // tile code: BM*1000+BN (128128, 128064, 64064); 0 = heuristic.  (A barrier-free one-wave-per-tile variant (NT = 64) was
@@ -816,7 +868,20 @@ static int launch_pair(const vbg_gemm_desc& d, int groups, int maxM, int maxN, h
     pick_tile(d, groups, maxM, maxN, tile, bk);
     if (!(d.a_vec && d.b_vec)) {                         // unaligned operands: general scalar-load path
         launch_one<64, 64, 16, 256, AK, BKD, false>(d, groups, maxM, maxN, s, t);
-    } else if (d.bf16 && (d.bk == 0 || d.bk == 32)) {
+    } else if (d.bf16 == 3 && d.bk != 16 && AK != VBG_OP_DENSE_R) {
+        // fp32-grade split form (tools/gemm_bench.py --split3), forward and dgrad kinds: 128x128x16 tiles (73 KB of LDS, two
+        // blocks per CU) from ~200 tiles on -- 4128x3072x768 125 vs 163 us for the fp32 form, the 128x128-map 3x3 convs 800 vs
+        // 1160 us; at most one wave of tiles runs them 32 deep (123 KB, one block per CU) -- and 64x64x32 (61 KB) below.  The
+        // weight-gradient kinds (row-contiguous A) and products forced to 16-deep k-tiles stay on the fp32 form: measured equal
+        // or slower there (the gathered B operand of the conv wgrad already spends the VALU slots the split needs).
+        if (d.tile == 0) {
+            const long t128 = (long)cdiv(maxM, 128) * cdiv(maxN, 128) * groups * d.splitk;
+            tile = (t128 >= 192 && maxN >= 128) ? (t128 <= 256 ? 128132 : 128128) : 64064;
+        }
+        if (tile == 128132 || (tile == 128128 && d.bk == 32)) launch_one<128, 128, 32, 256, AK, BKD, true, 3>(d, groups, maxM, maxN, s, t);
+        else if (tile == 128128) launch_one<128, 128, 16, 256, AK, BKD, true, 3>(d, groups, maxM, maxN, s, t);
+        else launch_one<64, 64, 32, 256, AK, BKD, true, 3>(d, groups, maxM, maxN, s, t);
+    } else if (d.bf16 == 1 && (d.bk == 0 || d.bk == 32)) {
         // amp: bf16 matrix cores (fp32 operands rounded on the way into LDS).  The loop is bound by operand traffic, not by the
         // MFMAs, so the larger tile wins as soon as it fills the chip.  (Products forced to 16-deep k-tiles -- channel counts
         // that are not a multiple of 32 -- and unaligned operands stay on the fp32 form.)
@@ -828,8 +893,8 @@ static int launch_pair(const vbg_gemm_desc& d, int groups, int maxM, int maxN, h
             const bool big = (BKD == VBG_OP_DENSE_K && t128 >= 512) || (BKD == VBG_OP_WT_R && t128 >= 2048);
             tile = (big && maxN >= 256 && AK != VBG_OP_DENSE_R) ? 128128 : 64064;
         }
-        if (tile == 128128) launch_one<128, 128, 32, 256, AK, BKD, true, true>(d, groups, maxM, maxN, s, t);
-        else launch_one<64, 64, 32, 256, AK, BKD, true, true>(d, groups, maxM, maxN, s, t);
+        if (tile == 128128) launch_one<128, 128, 32, 256, AK, BKD, true, 1>(d, groups, maxM, maxN, s, t);
+        else launch_one<64, 64, 32, 256, AK, BKD, true, 1>(d, groups, maxM, maxN, s, t);
     } else if (bk == 32) {
         if (tile == 128128) launch_one<128, 128, 32, 256, AK, BKD, true>(d, groups, maxM, maxN, s, t);
         else if (tile == 128064) launch_one<128, 64, 32, 256, AK, BKD, true>(d, groups, maxM, maxN, s, t);

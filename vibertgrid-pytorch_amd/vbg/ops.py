@@ -77,10 +77,10 @@ def gemm_raw(M, N, K, A, lda, a_kind, B, ldb, b_kind, Cout, ldc, *, bias=None, e
         splitk = 1
     d.epi, d.alpha, d.accumulate, d.splitk, d.tile = epi, float(alpha), int(bool(accumulate)), int(splitk), int(tile)
     d.bk = int(bk)
-    if _AMP[0]:
-        d.bf16 = 1
+    if _AMP[0] or _SPLIT3[0]:
+        d.bf16 = 1 if _AMP[0] else 3
         if bk == 16:
-            d.bk = 0        # (the 16-deep k-tiles are an fp32-form tuning; the bf16 form has one depth)
+            d.bk = 0        # (the 16-deep k-tiles are an fp32-form tuning)
     if _FORCE[0] or _FORCE[1]:          # debugging / conditioning experiments: force one tile configuration
         d.tile, d.bk = _FORCE[0] or d.tile, _FORCE[1] or d.bk
     if grp is not None:
@@ -151,6 +151,7 @@ _FORCE = [0, 0]
 # dtype and no loss scaling is needed for range (a GradScaler passed by the caller keeps working on the fp32 gradients).
 # ViBERTgridNet.forward latches torch.is_autocast_enabled() here; the backward of that forward sees the same setting.
 _AMP = [False]
+_SPLIT3 = [True]        # fp32-grade products as six bf16 piece products (exact three-way operand split), see csrc/gemm.hip
 
 
 def set_amp(on: bool):
