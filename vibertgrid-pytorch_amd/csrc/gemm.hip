@@ -178,8 +178,12 @@ __global__ __launch_bounds__(NT) void gemm_kernel(const vbg_gemm_desc p) {
     // row-contiguous kinds (BR4 float4 per k row of the tile): float4 #i covers tile rows r_row .. +3 at tile k index r_k(i).
     // fp32 form: pass i takes k rows [i*NT/BR4, (i+1)*NT/BR4); bf16 form: passes 2j, 2j+1 take ADJACENT k rows, so that a
     // thread can pack (k, k+1) pairs into dwords for the K-contiguous bf16 LDS tile.
-    auto r_row = [&](int BR4) { return (tid % BR4) * 4; };
-    auto r_k = [&](int i, int BR4) { return HB ? 2 * (tid / BR4) + (i & 1) + 2 * (NT / BR4) * (i >> 1) : tid / BR4 + i * (NT / BR4); };
+    // (bf16 forms, 128-row tiles: the 32 lanes of a half wave take 16 row groups x 2 k pairs instead of 32 row groups of one
+    // k pair -- their ds_write_b32 then hit every bank at most twice, see the LDS layout above)
+    auto r_c = [&](int BR4) { return (HB && BR4 == 32) ? (tid & 15) + 16 * ((tid >> 5) & 1) : tid % BR4; };
+    auto r_q = [&](int BR4) { return (HB && BR4 == 32) ? ((tid >> 4) & 1) + 2 * (tid >> 6) : tid / BR4; };
+    auto r_row = [&](int BR4) { return r_c(BR4) * 4; };
+    auto r_k = [&](int i, int BR4) { return HB ? 2 * r_q(BR4) + (i & 1) + 2 * (NT / BR4) * (i >> 1) : tid / BR4 + i * (NT / BR4); };
 
     // ---- A -------------------------------------------------------------------------------
     int a_n[NA], a_y[NA], a_x[NA];             // tile row -> (image, y, x) for conv / up-sampled segments
@@ -500,7 +504,7 @@ __global__ __launch_bounds__(NT) void gemm_kernel(const vbg_gemm_desc p) {
         } else {
 #pragma unroll
             for (int i = 0; i < n; i += 2) {
-                const int row4 = tid % BR4, k = r_k(i, BR4);
+                const int row4 = r_c(BR4), k = r_k(i, BR4);
                 const float e0[4] = {r[i].x, r[i].y, r[i].z, r[i].w}, e1[4] = {r[i + 1].x, r[i + 1].y, r[i + 1].z, r[i + 1].w};
 #pragma unroll
                 for (int e = 0; e < 4; ++e) {

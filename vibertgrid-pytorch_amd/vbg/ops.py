@@ -81,6 +81,8 @@ def gemm_raw(M, N, K, A, lda, a_kind, B, ldb, b_kind, Cout, ldc, *, bias=None, e
         d.bf16 = 1 if _AMP[0] else 3
         if bk == 16:
             d.bk = 0        # (the 16-deep k-tiles are an fp32-form tuning)
+        if grp is not None and not _AMP[0]:
+            d.bf16, d.bk = 0, int(bk)          # grouped (attention) products keep their tuned fp32 form: measured equal in the step
     if _FORCE[0] or _FORCE[1]:          # debugging / conditioning experiments: force one tile configuration
         d.tile, d.bk = _FORCE[0] or d.tile, _FORCE[1] or d.bk
     if grp is not None:
