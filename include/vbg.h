@@ -74,8 +74,16 @@ typedef struct vbg_gemm_desc {
        model/ResNetFPN_ViBERTgrid.py:116-123): per column sum and sum of squares of the stored values are added (fp64 atomics) into
        slot row (row-tile index % stats_slots) of stats[stats_slots][2*N]; needs splitk == 1, no accumulate, ldc % 4 == 0, C 16-B aligned */
     double* stats; int stats_slots;
-    /* amp: multiply on the bf16 matrix cores (operands stay fp32 in memory, are rounded to bf16 -- nearest even -- inside the
-       kernel, products accumulate in fp32; replaces torch.cuda.amp.autocast of pipeline/train_val_utils.py:264 for these ops) */
+    /* arithmetic form of the products.
+       0: v_mfma_f32_32x32x2_f32, exact fp32 products.
+       1: amp -- operands stay fp32 in memory, are rounded to bf16 (nearest even) inside the kernel and multiplied with
+          v_mfma_f32_32x32x16_bf16, fp32 accumulation; replaces torch.cuda.amp.autocast of pipeline/train_val_utils.py:264 for
+          these ops.
+       3: fp32-grade on the bf16 matrix cores -- every operand element is split exactly into three bf16 pieces inside the kernel and
+          each product is the fp32 sum of the six piece products of order <= 2^-16 (error <= 2^-23 of the product).
+       Forms 1 and 3 need 16-byte aligned operands (a_vec, b_vec); form 3 is not available for row-contiguous A (the library uses
+       form 0 there), and products whose geometry forces 16-deep k-tiles run as form 0.  Results of all forms agree to fp32
+       rounding for 0 / 3 and to bf16 operand rounding for 1. */
     int bf16;
 } vbg_gemm_desc;
 

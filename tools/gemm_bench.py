@@ -46,10 +46,11 @@ def main():
     ap.add_argument("--only", default="")
     ap.add_argument("--bks", default="0")
     ap.add_argument("--amp", action="store_true", help="bf16 matrix-core form (amp)")
-    ap.add_argument("--split3", action="store_true", help="fp32-grade bf16x3 split form")
+    ap.add_argument("--split3", action="store_true", help="(default) fp32-grade bf16x3 split form")
+    ap.add_argument("--fp32", action="store_true", help="fp32 MFMA form everywhere")
     args = ap.parse_args()
     ops.set_amp(args.amp)
-    ops._SPLIT3[0] = args.split3
+    ops._SPLIT3[0] = not args.fp32 and not args.amp
     tiles = [int(t) for t in args.tiles.split(",")]
     R = lambda *s: torch.randn(*s, device=dev)
     import itertools

@@ -24,7 +24,8 @@ act = lambda m, c: m * c * f4
 s_elems = 96 * 514 * 516 + 96 * 6 * 8                      # attention score blocks (8 long + 8 short sequences x 12 heads)
 tok = NTOK * HID * f4
 bytes_per_step = {
-    "bn_reduce_kernel<false>": sum(act(m, c) for m, c, r, a in bn),
+    # (forward statistics are fused into the producing conv's epilogue except for the split-K layer4 3x3 convs)
+    "bn_reduce_kernel<false>": 6 * act(B * 16 * 16, 512),
     "bn_apply_kernel": sum(act(m, c) * (2 + r) for m, c, r, a in bn),
     "bn_reduce_kernel<true>": sum(act(m, c) * (2 + a) for m, c, r, a in bn),
     "bn_bwd_apply_kernel": sum(act(m, c) * (3 + a + r) for m, c, r, a in bn),

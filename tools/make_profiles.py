@@ -11,10 +11,10 @@ G = R + "gpurun_out/"
 def agg(path):
     a = collections.defaultdict(lambda: [0, 0.0, 0.0])
     for r in csv.DictReader(open(path)):
-        m = re.search(r'gemm_kernel<(\d+), (\d+), (\d+), 256, (\d), (\d), (true|false)>', r['Kernel_Name'])
+        m = re.search(r'gemm_kernel<(\d+), (\d+), (\d+), 256, (\d), (\d), (true|false), (\d)>', r['Kernel_Name'])
         if not m:
             continue
-        k = m.groups() + (r['Grid_Size'],)
+        k = m.groups()[:6] + (r['Grid_Size'],) + (m.group(7),)
         a[k][0] += 1; a[k][1] += float(r['Counter_Value']); a[k][2] += (int(r['End_Timestamp']) - int(r['Start_Timestamp'])) / 1e3
     return a
 
@@ -24,13 +24,13 @@ lines = ["# rocprofv3 --kernel-trace --pmc FETCH_SIZE  /  --pmc WRITE_SIZE  (two
          "# per-launch averages for every vbg::gemm_kernel instantiation x grid.  Units: rocprofv3 reports KB; FETCH_SIZE is DOUBLED per",
          "# MI355X_MICROARCH.md (gfx950 tallies 128-B requests at 64 B); WRITE_SIZE is taken as is (it reproduces known output sizes exactly,",
          "# e.g. 131072x256 fp32 = 134.2 MB).  FETCH counts L2 misses (Infinity-Cache hits included), not DRAM reads.",
-         "# columns: BM BN BK A-kind B-kind vec | grid threads | launches/step | fetch MB | write MB | avg us (under the profiler)"]
+         "# columns: BM BN BK A-kind B-kind vec precision-form (0 fp32 MFMA, 3 bf16x3 split) | grid threads | launches/step | fetch MB | write MB | avg us (under the profiler)"]
 nf = nw = n = 0
 for k in sorted(f, key=lambda k: -f[k][1]):
     fm = 2 * f[k][1] / f[k][0] * 1024 / 1e6
     wm = w[k][1] / w[k][0] * 1024 / 1e6 if k in w else float('nan')
-    lines.append(f"{k[0]:>4}{k[1]:>4}{k[2]:>3}  A{k[3]} B{k[4]} {k[5]:5s} grid {int(k[6]):>8d}  x{f[k][0] / 4:6.1f}  fetch {fm:8.1f} MB  write {wm:8.1f} MB  {f[k][2] / f[k][0]:8.1f} us")
-    grouped = k[:3] in (('128', '128', '16'), ('64', '64', '16')) and k[6] in ('786432', '3145728')
+    lines.append(f"{k[0]:>4}{k[1]:>4}{k[2]:>3}  A{k[3]} B{k[4]} {k[5]:5s} prec{k[7]} grid {int(k[6]):>8d}  x{f[k][0] / 4:6.1f}  fetch {fm:8.1f} MB  write {wm:8.1f} MB  {f[k][2] / f[k][0]:8.1f} us")
+    grouped = k[7] == '0' and k[5] == 'true'            # (fp32-form DENSE_K x DENSE_K launches are the grouped attention-score products and the unaligned stem)
     if k[3] == '0' and k[4] == '0' and not grouped:
         nf += 2 * f[k][1] * 1024; nw += w[k][1] * 1024 if k in w else 0; n += f[k][0]
 tot_f = sum(2 * v[1] * 1024 for v in f.values()) / 4
@@ -58,7 +58,7 @@ if os.path.exists(G + 'pmc_m/m_counter_collection.csv'):
     ag = collections.defaultdict(lambda: collections.defaultdict(float))
     ctrs = ('SQ_VALU_MFMA_BUSY_CYCLES', 'SQ_WAVE_CYCLES', 'SQ_WAIT_ANY', 'SQ_WAIT_INST_ANY', 'SQ_ACTIVE_INST_ANY', 'SQ_LDS_BANK_CONFLICT', 'GRBM_GUI_ACTIVE')
     for d in disp.values():
-        k = re.search(r'gemm_kernel<(\d+), (\d+), (\d+), 256, (\d), (\d), (true|false)>', d['name']).groups()
+        k = re.search(r'gemm_kernel<(\d+), (\d+), (\d+), 256, (\d), (\d), (true|false), (\d)>', d['name']).groups()
         a_ = ag[k]; a_['n'] += 1; a_['ns'] += d['ns']
         for c in ctrs:
             a_[c] += d.get(c, 0.0)
@@ -67,14 +67,14 @@ if os.path.exists(G + 'pmc_m/m_counter_collection.csv'):
            "# over `python bench.py --steps 3 --warmup 1 --no-cpu-baseline`, summed per gemm_kernel instantiation over the 4 steps.",
            "# mfma_util = SQ_VALU_MFMA_BUSY_CYCLES / (kernel time * clock * 1024 SIMDs), clock = GRBM_GUI_ACTIVE / time / 8 XCDs;",
            "# wait/active columns are fractions of SQ_WAVE_CYCLES.",
-           "tile,A,B,vec,launches_per_step,ms_per_step,clock_GHz,mfma_util,wait_any,wait_inst_any,active_inst_any,lds_bank_conflict_cycles"]
+           "tile,A,B,vec,form,launches_per_step,ms_per_step,clock_GHz,mfma_util,wait_any,wait_inst_any,active_inst_any,lds_bank_conflict_cycles"]
     tb = tc = 0
     for k, a_ in sorted(ag.items(), key=lambda kv: -kv[1]['ns']):
         clk = a_['GRBM_GUI_ACTIVE'] / a_['ns'] / 8
         cap = a_['ns'] * clk * 1024
         tb += a_['SQ_VALU_MFMA_BUSY_CYCLES']; tc += cap
         wc = a_['SQ_WAVE_CYCLES'] or 1
-        out.append(f"{k[0]}x{k[1]}x{k[2]},{names[k[3]]},{names[k[4]]},{k[5]},{a_['n'] / 4:.1f},{a_['ns'] / 4 / 1e6:.3f},{clk:.2f},{a_['SQ_VALU_MFMA_BUSY_CYCLES'] / cap:.3f},"
+        out.append(f"{k[0]}x{k[1]}x{k[2]},{names[k[3]]},{names[k[4]]},{k[5]},prec{k[6]},{a_['n'] / 4:.1f},{a_['ns'] / 4 / 1e6:.3f},{clk:.2f},{a_['SQ_VALU_MFMA_BUSY_CYCLES'] / cap:.3f},"
                    f"{a_['SQ_WAIT_ANY'] / wc:.3f},{a_['SQ_WAIT_INST_ANY'] / wc:.3f},{a_['SQ_ACTIVE_INST_ANY'] / wc:.3f},{a_['SQ_LDS_BANK_CONFLICT']:.0f}")
     out.append(f"# all GEMM / conv kernels of the step: MFMA pipe busy {tb / tc:.3f} of the time they run")
     open(R + 'profiles/r01_gemm_mfma_util.txt', 'w').write("\n".join(out) + "\n")
