@@ -3,6 +3,8 @@
 import os
 import re
 
+import pytest
+
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 
 
@@ -36,3 +38,30 @@ def test_gemm_desc_layout_matches_header():
     # offsets are part of the ABI; recompute them with a tiny C program equivalent: natural alignment
     assert C.sizeof(ConvGeo) == 40
     assert GemmDesc.A.offset == 16 and GemmDesc.a_seg_ptr.offset % 8 == 0 and GemmDesc.grp.offset % 8 == 0
+
+
+def test_gemm_desc_offsets_against_the_c_compiler(tmp_path):
+    """every field of vbg_gemm_desc / vbg_conv_geo: offsetof + sizeof from gcc over include/vbg.h == the ctypes mirror"""
+    import ctypes as C
+    import shutil
+    import subprocess
+    from vbg.lib import GemmDesc, ConvGeo
+    if shutil.which("gcc") is None:
+        pytest.skip("no C compiler")
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    src = ['#include <stdio.h>', '#include <stddef.h>', '#include "vbg.h"', 'int main(void) {']
+    for st, cls in (("vbg_gemm_desc", GemmDesc), ("vbg_conv_geo", ConvGeo)):
+        src.append(f'printf("{st} sizeof %zu\\n", sizeof({st}));')
+        for name, _ in cls._fields_:
+            src.append(f'printf("{st} {name} %zu\\n", offsetof({st}, {name}));')
+    src += ['return 0; }']
+    cfile = tmp_path / "off.c"
+    cfile.write_text("\n".join(src))
+    exe = str(tmp_path / "off")
+    subprocess.run(["gcc", "-I", os.path.join(root, "include"), str(cfile), "-o", exe], check=True)
+    out = subprocess.run([exe], check=True, capture_output=True, text=True).stdout.split("\n")
+    got = {(a, b): int(c) for a, b, c in (ln.split() for ln in out if ln)}
+    for st, cls in (("vbg_gemm_desc", GemmDesc), ("vbg_conv_geo", ConvGeo)):
+        assert got[(st, "sizeof")] == C.sizeof(cls)
+        for name, _ in cls._fields_:
+            assert got[(st, name)] == getattr(cls, name).offset, (st, name)
