@@ -76,6 +76,18 @@ __device__ __forceinline__ unsigned cvt_pk_bf16(float lo, float hi) {
     return r;
 }
 typedef __bf16 bf16x8 __attribute__((ext_vector_type(8)));
+// scheduling pipeline of a bf16 k-tile body: after every MFMA its share of the NV VALU and ND LDS-write instructions of the region
+template <int M, int NM, int NV, int ND>
+struct sched_pipe {
+    static __device__ __forceinline__ void run() {
+        __builtin_amdgcn_sched_group_barrier(0x008, 1, 0);
+        constexpr int v = ((M + 1) * NV) / NM - (M * NV) / NM;
+        if constexpr (v > 0) __builtin_amdgcn_sched_group_barrier(0x002, v, 0);
+        constexpr int w = ((M + 1) * ND) / NM - (M * ND) / NM;
+        if constexpr (w > 0) __builtin_amdgcn_sched_group_barrier(0x200, w, 0);
+        if constexpr (M + 1 < NM) sched_pipe<M + 1, NM, NV, ND>::run();
+    }
+};
 
 // NT = threads per block (256: 4 waves in 2x2, LDS double buffered, one barrier per k-tile).
 // PREC 1 ("amp"): the operands stay fp32 in HBM, are rounded to bf16 on their way into LDS and multiplied with
@@ -655,18 +667,40 @@ __global__ __launch_bounds__(NT) void gemm_kernel(const vbg_gemm_desc p) {
             // piece products, smallest first: (lo,hi) (hi,lo) (mid,mid) (mid,hi) (hi,mid) (hi,hi)
             constexpr int NPP = PREC == 3 ? 6 : 1;
             constexpr int qa[6] = {PREC == 3 ? 2 : 0, 0, 1, 1, 0, 0}, qb[6] = {0, 2, 1, 0, 1, 0};
+            auto mma_range = [&](auto t0_tag, auto t1_tag) {
 #pragma unroll
-            for (int s = 0; s < KS; ++s)
+                for (int s = 0; s < KS; ++s)
 #pragma unroll
-                for (int t = 0; t < NPP; ++t)
+                    for (int t = decltype(t0_tag)::value; t < decltype(t1_tag)::value; ++t)
 #pragma unroll
-                    for (int i = 0; i < TM; ++i)
+                        for (int i = 0; i < TM; ++i)
 #pragma unroll
-                        for (int n = 0; n < TN; ++n)
-                            acc[i][n] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(__builtin_bit_cast(bf16x8, fa[s][qa[t]][i]),
-                                                                                __builtin_bit_cast(bf16x8, fb[s][qb[t]][n]), acc[i][n], 0, 0, 0);
-            __builtin_amdgcn_sched_barrier(0);
-            if constexpr (MORE) { store_tiles(tail_tag, buf ^ 1); __syncthreads(); }
+                            for (int n = 0; n < TN; ++n)
+                                acc[i][n] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(__builtin_bit_cast(bf16x8, fa[s][qa[t]][i]),
+                                                                                    __builtin_bit_cast(bf16x8, fb[s][qb[t]][n]), acc[i][n], 0, 0, 0);
+            };
+            using i0 = std::integral_constant<int, 0>;
+            using ih = std::integral_constant<int, NPP / 3>;
+            using i1 = std::integral_constant<int, NPP>;
+            if constexpr (PREC == 3 && MORE) {
+                // first half of the piece products covers the latency of the loads just issued; the split of the loaded tile and its
+                // LDS writes are then issued into the gaps of the second half (a 32x32x16 bf16 MFMA holds the matrix pipe for 32
+                // cycles = ~8 issue slots)
+                mma_range(i0{}, ih{});
+                __builtin_amdgcn_sched_barrier(0);
+                mma_range(ih{}, i1{});
+                store_tiles(tail_tag, buf ^ 1);
+                constexpr int NM2 = KS * (NPP - NPP / 3) * TM * TN;
+                constexpr int NV = (NA + NB) * 22;
+                constexpr int ND = NP * ((A_KC ? NA : 2 * NA) + (B_KC ? NB : 2 * NB));
+                sched_pipe<0, NM2, NV, ND>::run();
+                __builtin_amdgcn_sched_barrier(0);
+                __syncthreads();
+            } else {
+                mma_range(i0{}, i1{});
+                __builtin_amdgcn_sched_barrier(0);
+                if constexpr (MORE) { store_tiles(tail_tag, buf ^ 1); __syncthreads(); }
+            }
             return;
         }
         const float* as = As + buf * ASZ + a_off;
