@@ -631,27 +631,56 @@ __global__ __launch_bounds__(NT) void gemm_kernel(const vbg_gemm_desc p) {
     using no_t = std::integral_constant<bool, false>;
     const int ntiles = kt1 - kt0;
     const bool tail_in_range = HAS_TAIL && kt1 == nkt && (K % BK) != 0;      // the LAST tile of this block is a reduction tail
-    if (tail_in_range && ntiles == 1) { load_tiles(yes_t{}); store_tiles(yes_t{}, 0); }
-    else { load_tiles(no_t{}); store_tiles(no_t{}, 0); }
-    __syncthreads();
-    // One k-tile: compute tile `it` from LDS buffer it & 1 while (MORE) the next tile is fetched and stored into the other
-    // buffer.  Order (pinned with sched_barrier; hipcc otherwise sinks the ds_reads below the dependent MFMA chains and
-    // parks all non-MFMA work before/after the whole MFMA block):
-    //   fragments g0, g1  ->  MFMA g0  ->  next tile's buffer loads  ->  fragments / MFMA g1..  ->
-    //   ds_write of the prefetched tile BEFORE the last MFMA group  ->  last MFMA group  ->  barrier
-    // The steady-state loop holds exactly one copy of the body (MORE, no tail); the tail-loading and the final tile are
-    // peeled after it, so the loop carries no per-tile branches on them.
-    auto k_tile = [&](auto tail_tag, auto more_tag, int buf) {
-        constexpr bool MORE = decltype(more_tag)::value;
-        if constexpr (HB) {
-            // lane (lr, lk) of MFMA step s reads the 8 bf16 k = 16 s + 8 lk .. +7 of its row: one ds_read_b128 per fragment
-            constexpr int KS = BK / 16;
-            const int arow = A_KC ? wm * WM + lr : (lr & 3) * PSA + (wm * WM + lr) / 4;
-            const int brow = B_KC ? wn * WN + lr : (lr & 3) * PSB + (wn * WN + lr) / 4;
-            constexpr int AI = A_KC ? 32 : 8, BI = B_KC ? 32 : 8;          // LDS rows between a wave's 32-row fragments
+    if constexpr (HB && BK == 32) {
+        // ---- bf16 forms, 32-deep k-tiles: two tiles in flight --------------------------------------------------------------------------
+        // Their MFMA phase is 4-16x shorter than the fp32 form's and no longer covers the latency of the loads issued in the
+        // same iteration (measured: ~2700 cycles per 128x128x16 k-tile against 768 cycles of MFMAs).  So iteration `it`:
+        // fragments of tile it from LDS  ->  tile it+1, loaded one whole iteration ago, moves from the load registers to the
+        // staging registers  ->  the loads of tile it+2 are issued  ->  MFMAs of tile it, the split / conversion of the staged
+        // tile and its LDS writes issued into the gaps of the last piece products  ->  barrier.
+        // The iteration kinds (loads: none / plain / reduction tail; with or without a tile to store) are compile-time copies of
+        // one body that run one after the other -- no branch arms around MFMA blocks (those cost accumulator copies).
+        // (Measured against the one-tile-in-flight loop below: 5-12 % faster on every 64x64x32 and 128x128x32 product; the
+        // 128x128x16 products -- short iterations, two blocks per CU -- are 3-10 % slower with it and keep the loop below.)
+        float4 sa[NA], sb[NB];
+        const bool ht = HAS_TAIL && tail_in_range;          // the LAST tile is a K-contiguous reduction tail
+        auto stage = [&](bool tail) {
+#pragma unroll
+            for (int i = 0; i < NA; ++i) sa[i] = ra[i];
+#pragma unroll
+            for (int i = 0; i < NB; ++i) sb[i] = rb[i];
+            if (HAS_TAIL && tail) {                          // (uniform) partial float4 chunks of the tail
+                if constexpr (AK == VBG_OP_DENSE_K) {
+#pragma unroll
+                    for (int i = 0; i < NA; ++i) sa[i] = mask4(sa[i], st_rem_a - kcA);
+                }
+                if constexpr (BKD == VBG_OP_DENSE_K) {
+#pragma unroll
+                    for (int i = 0; i < NB; ++i) sb[i] = mask4(sb[i], st_rem_b - kcA);
+                }
+            }
+            if (a_prologue == 1) {
+#pragma unroll
+                for (int i = 0; i < NA; ++i) {
+                    sa[i].x = fmaxf(sa[i].x, 0.f) * a_scale; sa[i].y = fmaxf(sa[i].y, 0.f) * a_scale;
+                    sa[i].z = fmaxf(sa[i].z, 0.f) * a_scale; sa[i].w = fmaxf(sa[i].w, 0.f) * a_scale;
+                }
+            }
+        };
+        auto store_staged = [&](int buf) {
+            store_half(reinterpret_cast<unsigned*>(As + buf * ASZ), sa, std::integral_constant<bool, A_KC>{}, std::integral_constant<int, BM / 4>{}, std::integral_constant<int, PA>{});
+            store_half(reinterpret_cast<unsigned*>(Bs + buf * BSZ), sb, std::integral_constant<bool, B_KC>{}, std::integral_constant<int, BN / 4>{}, std::integral_constant<int, PB>{});
+        };
+        constexpr int KS = BK / 16;
+        constexpr int NPP = PREC == 3 ? 6 : 1;
+        const int arow = A_KC ? wm * WM + lr : (lr & 3) * PSA + (wm * WM + lr) / 4;
+        const int brow = B_KC ? wn * WN + lr : (lr & 3) * PSB + (wn * WN + lr) / 4;
+        constexpr int AI = A_KC ? 32 : 8, BI = B_KC ? 32 : 8;              // LDS rows between a wave's 32-row fragments
+        u32x4 fa[KS][NP][TM], fb[KS][NP][TN];
+        // lane (lr, lk) of MFMA step s reads the 8 bf16 k = 16 s + 8 lk .. +7 of its row: one ds_read_b128 per fragment and plane
+        auto read_frags = [&](int buf) {
             const u32x4* as = reinterpret_cast<const u32x4*>(As + buf * ASZ) + (arow * SKH + 8 * lk) / 8;
             const u32x4* bs = reinterpret_cast<const u32x4*>(Bs + buf * BSZ) + (brow * SKH + 8 * lk) / 8;
-            u32x4 fa[KS][NP][TM], fb[KS][NP][TN];
 #pragma unroll
             for (int s = 0; s < KS; ++s)
 #pragma unroll
@@ -661,35 +690,39 @@ __global__ __launch_bounds__(NT) void gemm_kernel(const vbg_gemm_desc p) {
 #pragma unroll
                     for (int i = 0; i < TN; ++i) fb[s][q][i] = bs[(q * 2 * PB + i * BI * SKH + 16 * s) / 8];
                 }
-            __builtin_amdgcn_sched_barrier(0);
-            if constexpr (MORE) load_tiles(tail_tag);
-            __builtin_amdgcn_sched_barrier(0);
-            // piece products, smallest first: (lo,hi) (hi,lo) (mid,mid) (mid,hi) (hi,mid) (hi,hi)
-            constexpr int NPP = PREC == 3 ? 6 : 1;
+        };
+        // piece products, smallest first: (lo,hi) (hi,lo) (mid,mid) (mid,hi) (hi,mid) (hi,hi)
+        auto mma_range = [&](auto t0_tag, auto t1_tag) {
             constexpr int qa[6] = {PREC == 3 ? 2 : 0, 0, 1, 1, 0, 0}, qb[6] = {0, 2, 1, 0, 1, 0};
-            auto mma_range = [&](auto t0_tag, auto t1_tag) {
 #pragma unroll
-                for (int s = 0; s < KS; ++s)
+            for (int s = 0; s < KS; ++s)
 #pragma unroll
-                    for (int t = decltype(t0_tag)::value; t < decltype(t1_tag)::value; ++t)
+                for (int t = decltype(t0_tag)::value; t < decltype(t1_tag)::value; ++t)
 #pragma unroll
-                        for (int i = 0; i < TM; ++i)
+                    for (int i = 0; i < TM; ++i)
 #pragma unroll
-                            for (int n = 0; n < TN; ++n)
-                                acc[i][n] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(__builtin_bit_cast(bf16x8, fa[s][qa[t]][i]),
-                                                                                    __builtin_bit_cast(bf16x8, fb[s][qb[t]][n]), acc[i][n], 0, 0, 0);
-            };
-            using i0 = std::integral_constant<int, 0>;
-            using ih = std::integral_constant<int, NPP / 3>;
-            using i1 = std::integral_constant<int, NPP>;
-            if constexpr (PREC == 3 && MORE) {
-                // first half of the piece products covers the latency of the loads just issued; the split of the loaded tile and its
-                // LDS writes are then issued into the gaps of the second half (a 32x32x16 bf16 MFMA holds the matrix pipe for 32
-                // cycles = ~8 issue slots)
+                        for (int n = 0; n < TN; ++n)
+                            acc[i][n] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(__builtin_bit_cast(bf16x8, fa[s][qa[t]][i]),
+                                                                                __builtin_bit_cast(bf16x8, fb[s][qb[t]][n]), acc[i][n], 0, 0, 0);
+        };
+        using i0 = std::integral_constant<int, 0>;
+        using ih = std::integral_constant<int, NPP / 3>;
+        using i1 = std::integral_constant<int, NPP>;
+        auto body = [&](auto load_tag, auto store_tag, int buf, bool stage_tail) {
+            constexpr int LOAD = decltype(load_tag)::value;       // 0 none, 1 plain, 2 reduction tail
+            constexpr bool STORE = decltype(store_tag)::value;
+            read_frags(buf);
+            __builtin_amdgcn_sched_barrier(0);
+            if constexpr (STORE) stage(stage_tail);
+            __builtin_amdgcn_sched_barrier(0);
+            if constexpr (LOAD == 1) load_tiles(no_t{});
+            if constexpr (LOAD == 2) load_tiles(yes_t{});
+            __builtin_amdgcn_sched_barrier(0);
+            if constexpr (STORE && PREC == 3) {
                 mma_range(i0{}, ih{});
                 __builtin_amdgcn_sched_barrier(0);
                 mma_range(ih{}, i1{});
-                store_tiles(tail_tag, buf ^ 1);
+                store_staged(buf ^ 1);
                 constexpr int NM2 = KS * (NPP - NPP / 3) * TM * TN;
                 constexpr int NV = (NA + NB) * 22;
                 constexpr int ND = NP * ((A_KC ? NA : 2 * NA) + (B_KC ? NB : 2 * NB));
@@ -699,50 +732,139 @@ __global__ __launch_bounds__(NT) void gemm_kernel(const vbg_gemm_desc p) {
             } else {
                 mma_range(i0{}, i1{});
                 __builtin_amdgcn_sched_barrier(0);
-                if constexpr (MORE) { store_tiles(tail_tag, buf ^ 1); __syncthreads(); }
+                if constexpr (STORE) { store_staged(buf ^ 1); __syncthreads(); }
             }
-            return;
+        };
+        using ld_none = std::integral_constant<int, 0>;
+        using ld_plain = std::integral_constant<int, 1>;
+        using ld_tail = std::integral_constant<int, 2>;
+        if (ht && ntiles == 1) load_tiles(yes_t{}); else load_tiles(no_t{});
+        stage(ht && ntiles == 1);
+        store_staged(0);
+        if (ntiles >= 2) { if (ht && ntiles == 2) load_tiles(yes_t{}); else load_tiles(no_t{}); }
+        __syncthreads();
+        int it = 0;
+        const int n_steady = ntiles - 2 - (ht ? 1 : 0);
+        for (; it < n_steady; ++it) body(ld_plain{}, yes_t{}, it & 1, false);
+        if constexpr (HAS_TAIL) {
+            if (ht && ntiles >= 3) { body(ld_tail{}, yes_t{}, it & 1, false); ++it; }
         }
-        const float* as = As + buf * ASZ + a_off;
-        const float* bs = Bs + buf * BSZ + b_off;
-        float fa0[TM][4], fb0[TN][4], fa1[TM][4], fb1[TN][4];
-        read_frag(as, bs, 0, fa0, fb0);
-        read_frag(as, bs, 1, fa1, fb1);
-        __builtin_amdgcn_sched_barrier(0);
-        mma_group(fa0, fb0);
-        __builtin_amdgcn_sched_barrier(0);
-        if constexpr (MORE) load_tiles(tail_tag);
-        __builtin_amdgcn_sched_barrier(0);
-        if constexpr (NG == 2) {
-            if constexpr (MORE) store_tiles(tail_tag, buf ^ 1);
-            __builtin_amdgcn_sched_barrier(0);
-            mma_group(fa1, fb1);
-        } else {
+        if (ntiles >= 2) { body(ld_none{}, yes_t{}, it & 1, ht); ++it; }
+        body(ld_none{}, no_t{}, it & 1, false);
+    } else {
+        if (tail_in_range && ntiles == 1) { load_tiles(yes_t{}); store_tiles(yes_t{}, 0); }
+        else { load_tiles(no_t{}); store_tiles(no_t{}, 0); }
+        __syncthreads();
+        // One k-tile: compute tile `it` from LDS buffer it & 1 while (MORE) the next tile is fetched and stored into the other
+        // buffer.  Order (pinned with sched_barrier; hipcc otherwise sinks the ds_reads below the dependent MFMA chains and
+        // parks all non-MFMA work before/after the whole MFMA block):
+        //   fragments g0, g1  ->  MFMA g0  ->  next tile's buffer loads  ->  fragments / MFMA g1..  ->
+        //   ds_write of the prefetched tile BEFORE the last MFMA group  ->  last MFMA group  ->  barrier
+        // The steady-state loop holds exactly one copy of the body (MORE, no tail); the tail-loading and the final tile are
+        // peeled after it, so the loop carries no per-tile branches on them.
+        auto k_tile = [&](auto tail_tag, auto more_tag, int buf) {
+            constexpr bool MORE = decltype(more_tag)::value;
+            if constexpr (HB) {
+                // lane (lr, lk) of MFMA step s reads the 8 bf16 k = 16 s + 8 lk .. +7 of its row: one ds_read_b128 per fragment
+                constexpr int KS = BK / 16;
+                const int arow = A_KC ? wm * WM + lr : (lr & 3) * PSA + (wm * WM + lr) / 4;
+                const int brow = B_KC ? wn * WN + lr : (lr & 3) * PSB + (wn * WN + lr) / 4;
+                constexpr int AI = A_KC ? 32 : 8, BI = B_KC ? 32 : 8;          // LDS rows between a wave's 32-row fragments
+                const u32x4* as = reinterpret_cast<const u32x4*>(As + buf * ASZ) + (arow * SKH + 8 * lk) / 8;
+                const u32x4* bs = reinterpret_cast<const u32x4*>(Bs + buf * BSZ) + (brow * SKH + 8 * lk) / 8;
+                u32x4 fa[KS][NP][TM], fb[KS][NP][TN];
 #pragma unroll
-            for (int g = 2; g < NG; g += 2) {
-                read_frag(as, bs, g, fa0, fb0);
+                for (int s = 0; s < KS; ++s)
+#pragma unroll
+                    for (int q = 0; q < NP; ++q) {
+#pragma unroll
+                        for (int i = 0; i < TM; ++i) fa[s][q][i] = as[(q * 2 * PA + i * AI * SKH + 16 * s) / 8];
+#pragma unroll
+                        for (int i = 0; i < TN; ++i) fb[s][q][i] = bs[(q * 2 * PB + i * BI * SKH + 16 * s) / 8];
+                    }
+                __builtin_amdgcn_sched_barrier(0);
+                if constexpr (MORE) load_tiles(tail_tag);
+                __builtin_amdgcn_sched_barrier(0);
+                // piece products, smallest first: (lo,hi) (hi,lo) (mid,mid) (mid,hi) (hi,mid) (hi,hi)
+                constexpr int NPP = PREC == 3 ? 6 : 1;
+                constexpr int qa[6] = {PREC == 3 ? 2 : 0, 0, 1, 1, 0, 0}, qb[6] = {0, 2, 1, 0, 1, 0};
+                auto mma_range = [&](auto t0_tag, auto t1_tag) {
+#pragma unroll
+                    for (int s = 0; s < KS; ++s)
+#pragma unroll
+                        for (int t = decltype(t0_tag)::value; t < decltype(t1_tag)::value; ++t)
+#pragma unroll
+                            for (int i = 0; i < TM; ++i)
+#pragma unroll
+                                for (int n = 0; n < TN; ++n)
+                                    acc[i][n] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(__builtin_bit_cast(bf16x8, fa[s][qa[t]][i]),
+                                                                                        __builtin_bit_cast(bf16x8, fb[s][qb[t]][n]), acc[i][n], 0, 0, 0);
+                };
+                using i0 = std::integral_constant<int, 0>;
+                using ih = std::integral_constant<int, NPP / 3>;
+                using i1 = std::integral_constant<int, NPP>;
+                if constexpr (PREC == 3 && MORE) {
+                    // first half of the piece products covers the latency of the loads just issued; the split of the loaded tile and its
+                    // LDS writes are then issued into the gaps of the second half (a 32x32x16 bf16 MFMA holds the matrix pipe for 32
+                    // cycles = ~8 issue slots)
+                    mma_range(i0{}, ih{});
+                    __builtin_amdgcn_sched_barrier(0);
+                    mma_range(ih{}, i1{});
+                    store_tiles(tail_tag, buf ^ 1);
+                    constexpr int NM2 = KS * (NPP - NPP / 3) * TM * TN;
+                    constexpr int NV = (NA + NB) * 22;
+                    constexpr int ND = NP * ((A_KC ? NA : 2 * NA) + (B_KC ? NB : 2 * NB));
+                    sched_pipe<0, NM2, NV, ND>::run();
+                    __builtin_amdgcn_sched_barrier(0);
+                    __syncthreads();
+                } else {
+                    mma_range(i0{}, i1{});
+                    __builtin_amdgcn_sched_barrier(0);
+                    if constexpr (MORE) { store_tiles(tail_tag, buf ^ 1); __syncthreads(); }
+                }
+                return;
+            }
+            const float* as = As + buf * ASZ + a_off;
+            const float* bs = Bs + buf * BSZ + b_off;
+            float fa0[TM][4], fb0[TN][4], fa1[TM][4], fb1[TN][4];
+            read_frag(as, bs, 0, fa0, fb0);
+            read_frag(as, bs, 1, fa1, fb1);
+            __builtin_amdgcn_sched_barrier(0);
+            mma_group(fa0, fb0);
+            __builtin_amdgcn_sched_barrier(0);
+            if constexpr (MORE) load_tiles(tail_tag);
+            __builtin_amdgcn_sched_barrier(0);
+            if constexpr (NG == 2) {
+                if constexpr (MORE) store_tiles(tail_tag, buf ^ 1);
                 __builtin_amdgcn_sched_barrier(0);
                 mma_group(fa1, fb1);
+            } else {
+#pragma unroll
+                for (int g = 2; g < NG; g += 2) {
+                    read_frag(as, bs, g, fa0, fb0);
+                    __builtin_amdgcn_sched_barrier(0);
+                    mma_group(fa1, fb1);
+                    __builtin_amdgcn_sched_barrier(0);
+                    read_frag(as, bs, g + 1, fa1, fb1);
+                    __builtin_amdgcn_sched_barrier(0);
+                    mma_group(fa0, fb0);
+                    __builtin_amdgcn_sched_barrier(0);
+                }
+                if constexpr (MORE) store_tiles(tail_tag, buf ^ 1);
                 __builtin_amdgcn_sched_barrier(0);
-                read_frag(as, bs, g + 1, fa1, fb1);
-                __builtin_amdgcn_sched_barrier(0);
-                mma_group(fa0, fb0);
-                __builtin_amdgcn_sched_barrier(0);
+                mma_group(fa1, fb1);
             }
-            if constexpr (MORE) store_tiles(tail_tag, buf ^ 1);
             __builtin_amdgcn_sched_barrier(0);
-            mma_group(fa1, fb1);
+            if constexpr (MORE) __syncthreads();
+        };
+        int it = 0;
+        const int n_plain = ntiles - 1 - ((tail_in_range && ntiles >= 2) ? 1 : 0);
+        for (; it < n_plain; ++it) k_tile(no_t{}, yes_t{}, it & 1);
+        if constexpr (HAS_TAIL) {
+            if (tail_in_range && ntiles >= 2) { k_tile(yes_t{}, yes_t{}, it & 1); ++it; }
         }
-        __builtin_amdgcn_sched_barrier(0);
-        if constexpr (MORE) __syncthreads();
-    };
-    int it = 0;
-    const int n_plain = ntiles - 1 - ((tail_in_range && ntiles >= 2) ? 1 : 0);
-    for (; it < n_plain; ++it) k_tile(no_t{}, yes_t{}, it & 1);
-    if constexpr (HAS_TAIL) {
-        if (tail_in_range && ntiles >= 2) { k_tile(yes_t{}, yes_t{}, it & 1); ++it; }
+        k_tile(no_t{}, no_t{}, it & 1);
     }
-    k_tile(no_t{}, no_t{}, it & 1);
 
     // ---------------- epilogue ----------------------------------------------------------
     const bool add_bias = (bias != nullptr) && (split == 0);
