@@ -1028,15 +1028,20 @@ static int launch_pair(const vbg_gemm_desc& d, int groups, int maxM, int maxN, h
     pick_tile(d, groups, maxM, maxN, tile, bk);
     if (!(d.a_vec && d.b_vec)) {                         // unaligned operands: general scalar-load path
         launch_one<64, 64, 16, 256, AK, BKD, false>(d, groups, maxM, maxN, s, t);
-    } else if (d.bf16 == 3 && d.bk != 16 && AK != VBG_OP_DENSE_R) {
-        // fp32-grade split form (tools/gemm_bench.py --split3), forward and dgrad kinds: 128x128x16 tiles (73 KB of LDS, two
-        // blocks per CU) from ~200 tiles on -- 4128x3072x768 125 vs 163 us for the fp32 form, the 128x128-map 3x3 convs 800 vs
-        // 1160 us; at most one wave of tiles runs them 32 deep (123 KB, one block per CU) -- and 64x64x32 (61 KB) below.  The
-        // weight-gradient kinds (row-contiguous A) and products forced to 16-deep k-tiles stay on the fp32 form: measured equal
-        // or slower there (the gathered B operand of the conv wgrad already spends the VALU slots the split needs).
+    } else if (d.bf16 == 3 && d.bk != 16 &&
+               (AK != VBG_OP_DENSE_R || d.tile != 0 || BKD == VBG_OP_DENSE_R ||
+                (BKD == VBG_OP_CONV_R && d.K / d.splitk >= 2048 && maxM >= 128 && maxN >= 128))) {
+        // fp32-grade split form (tools/gemm_bench.py; --fp32 for the other form).  Forward and dgrad kinds: 128x128x16 tiles (73 KB
+        // of LDS, two blocks per CU) from ~200 tiles on -- 4128x3072x768 116 vs 163 us for the fp32 form, the 128x128-map 3x3
+        // convs 760 vs 1160 us; at most one wave of tiles runs them 32 deep (123 KB, one block per CU; two tiles in flight) -- and
+        // 64x64x32 (61 KB) below.  Weight gradients (row-contiguous A): the dense ones as 64x64x32 (157 vs 168 us on 3072x768x4128),
+        // the convolution ones only where a split keeps >= 64 k-tiles (the 128x128-map and RoI convs: 128x128x32, 1078 vs 1297
+        // and 465 vs 576 us) -- the short-reduction conv wgrads are 5-10 % slower than the fp32 form (their gathered B operand
+        // already spends the VALU slots the split needs) and stay on it, as do products forced to 16-deep k-tiles.
         if (d.tile == 0) {
             const long t128 = (long)cdiv(maxM, 128) * cdiv(maxN, 128) * groups * d.splitk;
-            tile = (t128 >= 192 && maxN >= 128) ? (t128 <= 256 ? 128132 : 128128) : 64064;
+            if (AK == VBG_OP_DENSE_R) tile = (BKD == VBG_OP_CONV_R) ? 128132 : 64064;
+            else tile = (t128 >= 192 && maxN >= 128) ? (t128 <= 256 ? 128132 : 128128) : 64064;
         }
         if (tile == 128132 || (tile == 128128 && d.bk == 32)) launch_one<128, 128, 32, 256, AK, BKD, true, 3>(d, groups, maxM, maxN, s, t);
         else if (tile == 128128) launch_one<128, 128, 16, 256, AK, BKD, true, 3>(d, groups, maxM, maxN, s, t);
