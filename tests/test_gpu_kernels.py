@@ -709,6 +709,46 @@ def test_amp_products_match_fp32_on_bf16_values(ops, tile):
         ops._FORCE[0] = 0
 
 
+def test_split_form_is_fp32_grade(ops):
+    """the default arithmetic form (exact 3-way bf16 split, six piece products, vbg_gemm_desc.bf16 = 3) against fp64, next to the
+    fp32 matrix pipe on the same operands: errors of the same size (both are fp32 roundings of exact products summed in fp32) for
+    every operand-kind pair, operands with a wide dynamic range included"""
+    d = dev()
+    g = torch.Generator().manual_seed(5)
+    scale = torch.exp2(torch.randint(-12, 12, (1, 640), generator=g).float())          # column scales 2^-12 .. 2^11
+    x, w, dy = (torch.randn(900, 640, generator=g) * scale).to(d), (torch.randn(300, 640, generator=g) / scale).to(d), torch.randn(900, 300, generator=g).to(d)
+    refs = (x.double() @ w.double().t(), dy.double() @ w.double(), dy.double().t() @ x.double())
+
+    def run():
+        with torch.no_grad():
+            return (ops.linear_fwd(x, w), ops.linear_dgrad(dy, w), ops.linear_wgrad(dy, x, torch.zeros(300, 640, device=d), accumulate=False))
+
+    def errs(outs):
+        # relative to the size of the terms that were summed (|a| @ |b|), the natural unit of a dot product's rounding error
+        mags = (x.double().abs() @ w.double().abs().t(), dy.double().abs() @ w.double().abs(), dy.double().abs().t() @ x.double().abs())
+        return [float(((o.double() - r).abs() / m).max()) for o, r, m in zip(outs, refs, mags)]
+
+    assert ops.precision() == "split"
+    e_split = errs(run())
+    ops.set_precision("fp32")
+    try:
+        e_fp32 = errs(run())
+    finally:
+        ops.set_precision("split")
+    for a, b in zip(e_split, e_fp32):
+        assert a <= 2e-6 and b <= 2e-6 and a <= 3 * b + 1e-8, (e_split, e_fp32)
+    # convolution kinds
+    xi, wi = rnd(2, 24, 24, 64, seed=21).to(d), rnd(96, 3, 3, 64, seed=22).to(d)
+    dyi = rnd(2, 24, 24, 96, seed=23).to(d)
+    xn, wn = xi.permute(0, 3, 1, 2).double().requires_grad_(True), wi.permute(0, 3, 1, 2).double().requires_grad_(True)
+    y = torch.nn.functional.conv2d(xn, wn, padding=1)
+    y.backward(dyi.permute(0, 3, 1, 2).double())
+    with torch.no_grad():
+        got = (ops.conv2d_fwd(xi, wi, 1, 1), ops.conv2d_dgrad(dyi, wi, xi.shape, 1, 1), ops.conv2d_wgrad(dyi, xi, torch.zeros_like(wi), 1, 1, accumulate=False))
+    for o, r in zip(got, (y.detach().permute(0, 2, 3, 1), xn.grad.permute(0, 2, 3, 1), wn.grad.permute(0, 2, 3, 1))):
+        assert float((o.double() - r).abs().max()) <= 2e-6 * float(r.abs().max())
+
+
 def test_amp_rounds_operands_to_bf16(ops):
     """general fp32 operands: the amp product equals the fp64 product of the bf16-rounded (nearest-even) operands"""
     d = dev()

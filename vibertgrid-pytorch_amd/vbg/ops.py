@@ -156,6 +156,17 @@ _AMP = [False]
 _SPLIT3 = [True]        # fp32-grade products as six bf16 piece products (exact three-way operand split), see csrc/gemm.hip
 
 
+def set_precision(form: str):
+    """arithmetic form of the non-amp products: "split" (default; fp32-grade, six bf16 piece products) or "fp32" (fp32 matrix
+    pipe everywhere; bit-reproducible against the split form only to fp32 rounding)"""
+    assert form in ("split", "fp32"), form
+    _SPLIT3[0] = form == "split"
+
+
+def precision() -> str:
+    return "split" if _SPLIT3[0] else "fp32"
+
+
 def set_amp(on: bool):
     _AMP[0] = bool(on)
 
