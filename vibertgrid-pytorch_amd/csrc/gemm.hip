@@ -1,7 +1,11 @@
-// fp32 MFMA GEMM / implicit-GEMM convolution family for gfx950 (MI355X).
+// MFMA GEMM / implicit-GEMM convolution family for gfx950 (MI355X).
 //
-// One kernel template computes  C[M,N] (+)= opA[M,K] * opB[K,N]  with exact-fp32 matrix cores
-// (v_mfma_f32_32x32x2_f32: bitwise an fmaf chain, 157 TF peak) for every contraction on the
+// One kernel template computes  C[M,N] (+)= opA[M,K] * opB[K,N]  on fp32 tensors in one of three arithmetic forms (PREC):
+//   0  v_mfma_f32_32x32x2_f32, exact fp32 products (bitwise an fmaf chain, 157 TF peak);
+//   3  fp32-grade on the bf16 matrix cores: exact three-way bf16 split of every operand element on its way into LDS, six
+//      v_mfma_f32_32x32x16_bf16 piece products per k-step, fp32 accumulation (2500 / 6 = 417 TF fp32-equivalent peak) -- default;
+//   1  amp: operands rounded to bf16, one bf16 MFMA per k-step;
+// for every contraction on the
 // ViBERTgrid hot path: BERT linears and attention products (reference: transformers BertModel
 // called at model/BERTgrid_generator.py:134), the ResNet-FPN convolutions as implicit GEMM over
 // NHWC activations (model/ResNetFPN_ViBERTgrid.py:478-508, 612-648), the concat-free early /
@@ -1050,13 +1054,15 @@ static int launch_pair(const vbg_gemm_desc& d, int groups, int maxM, int maxN, h
         // amp: bf16 matrix cores (fp32 operands rounded on the way into LDS).  The loop is bound by operand traffic, not by the
         // MFMAs, so the larger tile wins as soon as it fills the chip.  (Products forced to 16-deep k-tiles -- channel counts
         // that are not a multiple of 32 -- and unaligned operands stay on the fp32 form.)
-        // (tools/gemm_bench.py --amp: 128x128 wins for the forward kinds from ~512 tiles on -- 4128x3072x768 390 vs 326 TF/s, the
-        // 128x128-map convs 577 vs 401 -- and for the conv dgrad only on the largest maps; every wgrad and the small products
-        // are faster with 64x64 blocks)
+        // (tools/gemm_bench.py --amp, profiles/r01_gemm_shapes_amp.txt: 128x128 wins for the forward and dgrad kinds from ~512
+        // tiles on -- 4128x3072x768 49 vs 59 us, the 128x128-map convs 262 vs 377 us -- and for the weight gradients with many
+        // output tiles or a long reduction per split; everything smaller is faster with 64x64 blocks)
         if (d.tile == 0) {
-            const long t128 = (long)cdiv(maxM, 128) * cdiv(maxN, 128) * groups * d.splitk;
-            const bool big = (BKD == VBG_OP_DENSE_K && t128 >= 512) || (BKD == VBG_OP_WT_R && t128 >= 2048);
-            tile = (big && maxN >= 256 && AK != VBG_OP_DENSE_R) ? 128128 : 64064;
+            const long t128 = (long)cdiv(maxM, 128) * cdiv(maxN, 128) * groups;
+            bool big;
+            if (AK == VBG_OP_DENSE_R) big = maxM >= 128 && maxN >= 128 && (t128 >= 512 || d.K / d.splitk >= 2048);
+            else big = t128 * d.splitk >= 512 && maxN >= 256;
+            tile = big ? 128128 : 64064;
         }
         if (tile == 128128) launch_one<128, 128, 32, 256, AK, BKD, true, 1>(d, groups, maxM, maxN, s, t);
         else launch_one<64, 64, 32, 256, AK, BKD, true, 1>(d, groups, maxM, maxN, s, t);
