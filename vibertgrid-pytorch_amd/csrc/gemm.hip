@@ -31,6 +31,10 @@
 #include <hip/hip_ext.h>
 #include "../../include/vbg.h"
 
+#ifndef VBG_PIPE2_X16
+#define VBG_PIPE2_X16 0
+#endif
+
 namespace vbg {
 
 typedef unsigned u32x4 __attribute__((ext_vector_type(4)));
@@ -42,14 +46,14 @@ typedef unsigned u32x4 __attribute__((ext_vector_type(4)));
 constexpr unsigned VO_INVALID = 0x80000000u;
 constexpr long long NREC_MAX = 0x80000000ll;
 __device__ __forceinline__ __amdgpu_buffer_rsrc_t make_rsrc(const float* base, long long nbytes) {
-    const long long n = nbytes < NREC_MAX ? nbytes : NREC_MAX;
+    const long long n = nbytes < 0 ? 0 : (nbytes < NREC_MAX ? nbytes : NREC_MAX);      // (a tile past the end of the reduction: nothing valid)
     return __builtin_amdgcn_make_buffer_rsrc(const_cast<float*>(base), 0, (int)(unsigned)n, 0x00020000);
 }
 // one float4 of an operand: a single 16-byte load (VEC) or four dword loads with their own validity (NE = 4)
 template <int NE>
-__device__ __forceinline__ float4 bload(__amdgpu_buffer_rsrc_t r, const unsigned (&vo)[NE]) {
+__device__ __forceinline__ float4 bload(__amdgpu_buffer_rsrc_t r, const unsigned (&vo)[NE], unsigned inv = 0) {
     if constexpr (NE == 1) {
-        const u32x4 v = __builtin_amdgcn_raw_buffer_load_b128(r, (int)vo[0], 0, 0);
+        const u32x4 v = __builtin_amdgcn_raw_buffer_load_b128(r, (int)(vo[0] | inv), 0, 0);     // inv = VO_INVALID: the whole tile reads 0
         return make_float4(__uint_as_float(v[0]), __uint_as_float(v[1]), __uint_as_float(v[2]), __uint_as_float(v[3]));
     } else {
         float4 o;
@@ -103,6 +107,7 @@ struct sched_pipe {
 template <int BM, int BN, int BK, int NT, int AK, int BKD, bool VEC, int PREC = 0>
 __global__ __launch_bounds__(NT) void gemm_kernel(const vbg_gemm_desc p) {
     constexpr bool HB = PREC != 0;
+    constexpr bool PIPE2_X16 = VBG_PIPE2_X16;      // 16-deep bf16 k-tiles on the two-tiles-in-flight loop as well (measured, see below)
     constexpr int NP = PREC == 3 ? 3 : 1;      // bf16 planes per operand tile
     constexpr int WGM = 2, WGN = 2;
     constexpr int NBUF = 2;
@@ -364,24 +369,24 @@ __global__ __launch_bounds__(NT) void gemm_kernel(const vbg_gemm_desc p) {
     constexpr bool HAS_TAIL = (AK == VBG_OP_DENSE_K || BKD == VBG_OP_DENSE_K);
 
     // loads the tile at k0 into ra / rb and advances every piece of scalar state to the next tile
-    auto load_tiles = [&](auto tail_tag) {
+    auto load_tiles_to = [&](auto tail_tag, auto& RA, auto& RB, int& REMA, int& REMB, unsigned inv) {
         constexpr bool TAIL = decltype(tail_tag)::value;
         // ------------------------------ A ------------------------------
         if constexpr (AK == VBG_OP_DENSE_K) {
             if (seg + 1 < p.a_nseg && k0 >= seg_kend) enter_segment(seg + 1);     // rare, uniform
             const int rem = seg_kend - k0;
-            st_rem_a = rem;
+            REMA = rem;
             const __amdgpu_buffer_rsrc_t r = make_rsrc(abase, NREC_MAX);
             if constexpr (!TAIL) {
 #pragma unroll
-                for (int i = 0; i < NA; ++i) ra[i] = bload<NE>(r, avo[i]);
+                for (int i = 0; i < NA; ++i) RA[i] = bload<NE>(r, avo[i], inv);
             } else {                      // reduction tail: chunks (elements) at or beyond K must not be touched
 #pragma unroll
                 for (int i = 0; i < NA; ++i) {
                     unsigned vo[NE];
 #pragma unroll
                     for (int e = 0; e < NE; ++e) vo[e] = (kcA + e < rem) ? avo[i][e] : VO_INVALID;
-                    ra[i] = bload<NE>(r, vo);
+                    RA[i] = bload<NE>(r, vo, inv);
                 }
             }
             abase += BK;
@@ -389,7 +394,7 @@ __global__ __launch_bounds__(NT) void gemm_kernel(const vbg_gemm_desc p) {
             if (a_dirty) { conv_a_offsets(); a_dirty = false; }
             const __amdgpu_buffer_rsrc_t r = make_rsrc(abase, NREC_MAX);
 #pragma unroll
-            for (int i = 0; i < NA; ++i) ra[i] = bload<NE>(r, avo[i]);
+            for (int i = 0; i < NA; ++i) RA[i] = bload<NE>(r, avo[i], inv);
             a_c0 += BK;
             abase += BK;
             if (a_c0 >= geo.Cs) {
@@ -399,38 +404,38 @@ __global__ __launch_bounds__(NT) void gemm_kernel(const vbg_gemm_desc p) {
         } else {
             const __amdgpu_buffer_rsrc_t r = make_rsrc(abase, a_rem);
 #pragma unroll
-            for (int i = 0; i < NA; ++i) ra[i] = bload<NE>(r, avo[i]);
+            for (int i = 0; i < NA; ++i) RA[i] = bload<NE>(r, avo[i], inv);
             abase += (long long)BK * p.lda;
             a_rem -= (long long)BK * p.lda * 4;
         }
         // ------------------------------ B ------------------------------
         if constexpr (BKD == VBG_OP_DENSE_K) {
             const int rem = K - k0;
-            st_rem_b = rem;
+            REMB = rem;
             const __amdgpu_buffer_rsrc_t r = make_rsrc(bbase, NREC_MAX);
             if constexpr (!TAIL) {
 #pragma unroll
-                for (int i = 0; i < NB; ++i) rb[i] = bload<NE>(r, bvo[i]);
+                for (int i = 0; i < NB; ++i) RB[i] = bload<NE>(r, bvo[i], inv);
             } else {
 #pragma unroll
                 for (int i = 0; i < NB; ++i) {
                     unsigned vo[NE];
 #pragma unroll
                     for (int e = 0; e < NE; ++e) vo[e] = (kcA + e < rem) ? bvo[i][e] : VO_INVALID;
-                    rb[i] = bload<NE>(r, vo);
+                    RB[i] = bload<NE>(r, vo, inv);
                 }
             }
             bbase += BK;
         } else if constexpr (BKD == VBG_OP_DENSE_R) {
             const __amdgpu_buffer_rsrc_t r = make_rsrc(bbase, b_rem);
 #pragma unroll
-            for (int i = 0; i < NB; ++i) rb[i] = bload<NE>(r, bvo[i]);
+            for (int i = 0; i < NB; ++i) RB[i] = bload<NE>(r, bvo[i], inv);
             bbase += (long long)BK * p.ldb;
             b_rem -= (long long)BK * p.ldb * 4;
         } else if constexpr (BKD == VBG_OP_WT_R) {
             const __amdgpu_buffer_rsrc_t r = make_rsrc(bbase, NREC_MAX);
 #pragma unroll
-            for (int i = 0; i < NB; ++i) rb[i] = bload<NE>(r, bvo[i]);
+            for (int i = 0; i < NB; ++i) RB[i] = bload<NE>(r, bvo[i], inv);
             const int taps = geo.kh * geo.kw;
             b_co0 += BK;
             bbase += (long long)BK * taps * N;
@@ -446,7 +451,7 @@ __global__ __launch_bounds__(NT) void gemm_kernel(const vbg_gemm_desc p) {
             for (int i = 0; i < NB; ++i) {
                 const bool ok = (unsigned)(ys + b_cy[i]) < (unsigned)geo.Hs && (unsigned)(xs + b_cx[i]) < (unsigned)geo.Ws;
                 unsigned vo[1] = {ok ? b_co[i] : VO_INVALID};
-                rb[i] = bload<1>(r, vo);
+                RB[i] = bload<1>(r, vo, inv);
             }
             b_xs += BK;
             while (b_xs >= geo.Wr) { b_xs -= geo.Wr; ++b_y0; }
@@ -461,7 +466,7 @@ __global__ __launch_bounds__(NT) void gemm_kernel(const vbg_gemm_desc p) {
                 const bool ok = (pix < K) && b_cv[i] && sy >= 0 && sy < geo.Hs && sx >= 0 && sx < geo.Ws;
                 unsigned vo[NE];
                 set_vo<NE>(vo, (((long long)b_pn[i] * geo.Hs + sy) * geo.Ws + sx) * geo.Cs + b_ci[i], ok);
-                rb[i] = bload<NE>(r, vo);
+                RB[i] = bload<NE>(r, vo, inv);
                 // advance this thread's pixel by BK for the next k-tile
                 b_px[i] += pix_dr;
                 const int cx = b_px[i] >= geo.Wr;
@@ -480,6 +485,7 @@ __global__ __launch_bounds__(NT) void gemm_kernel(const vbg_gemm_desc p) {
         }
         k0 += BK;
     };
+    auto load_tiles = [&](auto tail_tag) { load_tiles_to(tail_tag, ra, rb, st_rem_a, st_rem_b, 0u); };
 
     const int a_prologue = p.a_prologue;
     const float a_scale = p.a_scale;
@@ -635,45 +641,42 @@ __global__ __launch_bounds__(NT) void gemm_kernel(const vbg_gemm_desc p) {
     using no_t = std::integral_constant<bool, false>;
     const int ntiles = kt1 - kt0;
     const bool tail_in_range = HAS_TAIL && kt1 == nkt && (K % BK) != 0;      // the LAST tile of this block is a reduction tail
-    if constexpr (HB && BK == 32) {
-        // ---- bf16 forms, 32-deep k-tiles: two tiles in flight --------------------------------------------------------------------------
-        // Their MFMA phase is 4-16x shorter than the fp32 form's and no longer covers the latency of the loads issued in the
-        // same iteration (measured: ~2700 cycles per 128x128x16 k-tile against 768 cycles of MFMAs).  So iteration `it`:
-        // fragments of tile it from LDS  ->  tile it+1, loaded one whole iteration ago, moves from the load registers to the
-        // staging registers  ->  the loads of tile it+2 are issued  ->  MFMAs of tile it, the split / conversion of the staged
-        // tile and its LDS writes issued into the gaps of the last piece products  ->  barrier.
-        // The iteration kinds (loads: none / plain / reduction tail; with or without a tile to store) are compile-time copies of
-        // one body that run one after the other -- no branch arms around MFMA blocks (those cost accumulator copies).
-        // (Measured against the one-tile-in-flight loop below: 5-12 % faster on every 64x64x32 and 128x128x32 product; the
-        // 128x128x16 products -- short iterations, two blocks per CU -- are 3-10 % slower with it and keep the loop below.)
-        float4 sa[NA], sb[NB];
-        const bool ht = HAS_TAIL && tail_in_range;          // the LAST tile is a K-contiguous reduction tail
-        auto stage = [&](bool tail) {
-#pragma unroll
-            for (int i = 0; i < NA; ++i) sa[i] = ra[i];
-#pragma unroll
-            for (int i = 0; i < NB; ++i) sb[i] = rb[i];
-            if (HAS_TAIL && tail) {                          // (uniform) partial float4 chunks of the tail
+    if constexpr (HB && (BK == 32 || PIPE2_X16)) {
+        // ---- bf16 forms: two tiles in flight ---------------------------------------------------------------------------
+        // Their MFMA phase is 4-16x shorter than the fp32 form's and no longer covers the latency of loads issued in the same
+        // iteration (measured: ~2700 cycles per 128x128x16 k-tile against 768 cycles of MFMAs).  Two register sets: tile j
+        // lives in set j & 1.  Iteration `it`: fragments of tile it from LDS  ->  loads of tile it+2 issued into the set tile it
+        // came from  ->  MFMAs of tile it, with the split / conversion of tile it+1 (loaded a whole iteration ago, other set) and
+        // its LDS writes issued into the gaps of the last piece products  ->  barrier.
+        // Every iteration is the same code (even / odd copy for the two set assignments): tiles beyond the block's range are
+        // loaded with every lane's offset marked invalid (they read 0, no memory traffic) and stored as zeros, K-contiguous
+        // operands always use the chunk-masked tail form of the load -- no run-time branch arms around the MFMA blocks (those
+        // cost accumulator copies), no peeled iteration kinds.
+        float4 ra2[NA], rb2[NB];
+        int rem_a1 = BK, rem_b1 = BK, rem_a2 = BK, rem_b2 = BK;
+        using load_t = std::integral_constant<bool, HAS_TAIL>;
+        auto fix = [&](auto& RA, auto& RB, int rema, int remb) {      // in place, before the split: partial chunks of a tail, prologue
+            if (HAS_TAIL && (rema < BK || remb < BK)) {              // (uniform)
                 if constexpr (AK == VBG_OP_DENSE_K) {
 #pragma unroll
-                    for (int i = 0; i < NA; ++i) sa[i] = mask4(sa[i], st_rem_a - kcA);
+                    for (int i = 0; i < NA; ++i) RA[i] = mask4(RA[i], rema - kcA);
                 }
                 if constexpr (BKD == VBG_OP_DENSE_K) {
 #pragma unroll
-                    for (int i = 0; i < NB; ++i) sb[i] = mask4(sb[i], st_rem_b - kcA);
+                    for (int i = 0; i < NB; ++i) RB[i] = mask4(RB[i], remb - kcA);
                 }
             }
             if (a_prologue == 1) {
 #pragma unroll
                 for (int i = 0; i < NA; ++i) {
-                    sa[i].x = fmaxf(sa[i].x, 0.f) * a_scale; sa[i].y = fmaxf(sa[i].y, 0.f) * a_scale;
-                    sa[i].z = fmaxf(sa[i].z, 0.f) * a_scale; sa[i].w = fmaxf(sa[i].w, 0.f) * a_scale;
+                    RA[i].x = fmaxf(RA[i].x, 0.f) * a_scale; RA[i].y = fmaxf(RA[i].y, 0.f) * a_scale;
+                    RA[i].z = fmaxf(RA[i].z, 0.f) * a_scale; RA[i].w = fmaxf(RA[i].w, 0.f) * a_scale;
                 }
             }
         };
-        auto store_staged = [&](int buf) {
-            store_half(reinterpret_cast<unsigned*>(As + buf * ASZ), sa, std::integral_constant<bool, A_KC>{}, std::integral_constant<int, BM / 4>{}, std::integral_constant<int, PA>{});
-            store_half(reinterpret_cast<unsigned*>(Bs + buf * BSZ), sb, std::integral_constant<bool, B_KC>{}, std::integral_constant<int, BN / 4>{}, std::integral_constant<int, PB>{});
+        auto store_set = [&](auto& RA, auto& RB, int buf) {
+            store_half(reinterpret_cast<unsigned*>(As + buf * ASZ), RA, std::integral_constant<bool, A_KC>{}, std::integral_constant<int, BM / 4>{}, std::integral_constant<int, PA>{});
+            store_half(reinterpret_cast<unsigned*>(Bs + buf * BSZ), RB, std::integral_constant<bool, B_KC>{}, std::integral_constant<int, BN / 4>{}, std::integral_constant<int, PB>{});
         };
         constexpr int KS = BK / 16;
         constexpr int NPP = PREC == 3 ? 6 : 1;
@@ -712,49 +715,50 @@ __global__ __launch_bounds__(NT) void gemm_kernel(const vbg_gemm_desc p) {
         using i0 = std::integral_constant<int, 0>;
         using ih = std::integral_constant<int, NPP / 3>;
         using i1 = std::integral_constant<int, NPP>;
-        auto body = [&](auto load_tag, auto store_tag, int buf, bool stage_tail) {
-            constexpr int LOAD = decltype(load_tag)::value;       // 0 none, 1 plain, 2 reduction tail
-            constexpr bool STORE = decltype(store_tag)::value;
-            read_frags(buf);
+        // one iteration; P = it & 1 (static): tile it and it+2 use set P (P = 0: ra / rb), tile it+1 the other set
+        auto body = [&](auto par_tag, int it) {
+            constexpr int P = decltype(par_tag)::value;
+            auto& LA = P ? ra2 : ra;
+            auto& LB = P ? rb2 : rb;
+            auto& SA = P ? ra : ra2;
+            auto& SB = P ? rb : rb2;
+            int& lrem_a = P ? rem_a2 : rem_a1;
+            int& lrem_b = P ? rem_b2 : rem_b1;
+            const int srem_a = P ? rem_a1 : rem_a2, srem_b = P ? rem_b1 : rem_b2;
+            read_frags(P);
             __builtin_amdgcn_sched_barrier(0);
-            if constexpr (STORE) stage(stage_tail);
+            load_tiles_to(load_t{}, LA, LB, lrem_a, lrem_b, it + 2 < ntiles ? 0u : VO_INVALID);
             __builtin_amdgcn_sched_barrier(0);
-            if constexpr (LOAD == 1) load_tiles(no_t{});
-            if constexpr (LOAD == 2) load_tiles(yes_t{});
+            fix(SA, SB, srem_a, srem_b);
             __builtin_amdgcn_sched_barrier(0);
-            if constexpr (STORE && PREC == 3) {
+            if constexpr (PREC == 3) {
                 mma_range(i0{}, ih{});
                 __builtin_amdgcn_sched_barrier(0);
                 mma_range(ih{}, i1{});
-                store_staged(buf ^ 1);
+                store_set(SA, SB, P ^ 1);
                 constexpr int NM2 = KS * (NPP - NPP / 3) * TM * TN;
                 constexpr int NV = (NA + NB) * 22;
                 constexpr int ND = NP * ((A_KC ? NA : 2 * NA) + (B_KC ? NB : 2 * NB));
                 sched_pipe<0, NM2, NV, ND>::run();
-                __builtin_amdgcn_sched_barrier(0);
-                __syncthreads();
             } else {
                 mma_range(i0{}, i1{});
                 __builtin_amdgcn_sched_barrier(0);
-                if constexpr (STORE) { store_staged(buf ^ 1); __syncthreads(); }
+                store_set(SA, SB, P ^ 1);
             }
+            __builtin_amdgcn_sched_barrier(0);
+            __syncthreads();
         };
-        using ld_none = std::integral_constant<int, 0>;
-        using ld_plain = std::integral_constant<int, 1>;
-        using ld_tail = std::integral_constant<int, 2>;
-        if (ht && ntiles == 1) load_tiles(yes_t{}); else load_tiles(no_t{});
-        stage(ht && ntiles == 1);
-        store_staged(0);
-        if (ntiles >= 2) { if (ht && ntiles == 2) load_tiles(yes_t{}); else load_tiles(no_t{}); }
+        load_tiles_to(load_t{}, ra, rb, rem_a1, rem_b1, 0u);
+        load_tiles_to(load_t{}, ra2, rb2, rem_a2, rem_b2, ntiles > 1 ? 0u : VO_INVALID);
+        fix(ra, rb, rem_a1, rem_b1);
+        store_set(ra, rb, 0);
         __syncthreads();
         int it = 0;
-        const int n_steady = ntiles - 2 - (ht ? 1 : 0);
-        for (; it < n_steady; ++it) body(ld_plain{}, yes_t{}, it & 1, false);
-        if constexpr (HAS_TAIL) {
-            if (ht && ntiles >= 3) { body(ld_tail{}, yes_t{}, it & 1, false); ++it; }
+        for (; it + 1 < ntiles; it += 2) {
+            body(std::integral_constant<int, 0>{}, it);
+            body(std::integral_constant<int, 1>{}, it + 1);
         }
-        if (ntiles >= 2) { body(ld_none{}, yes_t{}, it & 1, ht); ++it; }
-        body(ld_none{}, no_t{}, it & 1, false);
+        if (it < ntiles) body(std::integral_constant<int, 0>{}, it);
     } else {
         if (tail_in_range && ntiles == 1) { load_tiles(yes_t{}); store_tiles(yes_t{}, 0); }
         else { load_tiles(no_t{}); store_tiles(no_t{}, 0); }
