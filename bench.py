@@ -125,7 +125,9 @@ def main():
     ap.add_argument("--no-syncbn", action="store_true")
     ap.add_argument("--amp", action="store_true", help="time the `amp: True` path (bf16 matrix cores) as the headline value instead "
                     "of fp32; the default run reports it beside the fp32 value under \"amp\"")
-    ap.add_argument("--no-amp-leg", action="store_true", help="skip the secondary amp measurement of the default run")
+    ap.add_argument("--no-amp-leg", action="store_true", help="skip the secondary amp / fp32-MFMA measurements of the default run")
+    ap.add_argument("--fp32-mfma", action="store_true", help="time the step with every product on the fp32 matrix pipe "
+                    "(vbg.ops.set_precision('fp32')) as the headline instead of the fp32-grade split form")
     ap.add_argument("--shape", default="cfg2", choices=["cfg2", "cfg4", "cfg5"],
                     help="cfg2 (default, the BASELINE metric's configuration); cfg4 / cfg5: the other §8 shapes as exploratory runs "
                          "(char-level S=T=512, 12 classes, vocab 21128 / 1024x1024 images), reported under config.workload")
@@ -181,6 +183,8 @@ def main():
         packed = PackedBatch.pack(*batch)
 
     amp_on = [bool(args.amp)]
+    if args.fp32_mfma:
+        ops.set_precision("fp32")
 
     def step():
         # `amp: True` = the reference's autocast region around the model call (pipeline/train_val_utils.py:264)
@@ -240,6 +244,29 @@ def main():
             dist.all_reduce(t, op=dist.ReduceOp.MAX)
             adt = float(t.item())
         amp_on[0] = False
+        # ... and with every product on the fp32 matrix pipe (the form the split form replaces)
+        fp32_leg = None
+        if not args.fp32_mfma:
+            ops.set_precision("fp32")
+            for _ in range(2):
+                step()
+            if world > 1:
+                dist.barrier()
+            torch.cuda.synchronize()
+            t2 = time.perf_counter()
+            for _ in range(args.steps):
+                step()
+            if world > 1:
+                dist.barrier()
+            torch.cuda.synchronize()
+            fdt = time.perf_counter() - t2
+            if world > 1:
+                t = torch.tensor([fdt], device=dev, dtype=torch.float64)
+                dist.all_reduce(t, op=dist.ReduceOp.MAX)
+                fdt = float(t.item())
+            ops.set_precision("split")
+            fp32_leg = {"value": round(B * world * args.steps / fdt, 3), "unit": "docs/sec", "ms_per_step": round(1e3 * fdt / args.steps, 3),
+                        "dtype": "f32 MFMA (v_mfma_f32_32x32x2_f32) for every product"}
         amp_leg = {"value": round(B * world * args.steps / adt, 3), "unit": "docs/sec", "ms_per_step": round(1e3 * adt / args.steps, 3),
                    "dtype": "bf16 MFMA products, f32 accumulate / storage / everything else", "last_loss": round(float(amp_last), 4)}
     ranks_in_sync = None
@@ -261,12 +288,15 @@ def main():
         docs = B * world * args.steps
         value = docs / dt
         ach = (flops / (ms * 1e-3)) / 1e12 if ms > 0 else 0.0
+        form_products = 1 if (args.amp or args.fp32_mfma) else SPLIT_PRODUCTS
+        form_peak = PEAK_F32_TF if args.fp32_mfma else PEAK_BF16_TF / form_products
         out = {
             "metric": "training docs/sec, 512x512 img + seq_len 512, bert-base+resnet34; 1/2/4/8 GPU",
             "value": round(value, 3), "unit": "docs/sec", "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
             "ms_per_step": round(1e3 * dt / args.steps, 3), "higher_is_better": True, "scaling": "weak", "vs_baseline": None,
             "dtype": "bf16" if args.amp else "f32", "data": "synthetic",
             "arithmetic": ("bf16 MFMA products of fp32 tensors, f32 accumulate" if args.amp else
+                           "f32 MFMA for every product" if args.fp32_mfma else
                            "fp32-grade: exact 3-way bf16 split of every operand, 6 bf16 MFMA piece products per product, f32 accumulate (attention products and the short-reduction conv weight gradients on the f32 MFMA)"),
             "config": {"workload": ("SROIE line-level cfg2: resnet_34_fpn_pretrained + bert-base-uncased (12L, vocab 30522, random init), "
                                     "512x512, T=512 tokens, S=128 segments, batch 8/GPU, fwd+bwd+SGD/AdamW, dropout 0.1, simp classifier")
@@ -278,14 +308,16 @@ def main():
             # matrix-core roofline in algorithmic (fp32-equivalent) flops is the bf16 peak / 6; `mfma_rate` is what the pipe executes
             "roofline": {"bound": "mfma",
                          "kernel": ("vbg::gemm_kernel<*,*,*,DENSE_K,DENSE_K,*,1> (bf16 MFMA NT GEMM, amp; every ungrouped launch)" if args.amp else
+                                    "vbg::gemm_kernel<*,*,*,DENSE_K,DENSE_K,*,0> (fp32 MFMA NT GEMM; every ungrouped launch)" if args.fp32_mfma else
                                     "vbg::gemm_kernel<*,*,*,DENSE_K,DENSE_K,*,3> (fp32-grade NT GEMM as 6 bf16 MFMA piece products: BERT linears, 1x1 convs; every ungrouped launch)"),
-                         "achieved": round(ach, 2), "peak": round(PEAK_BF16_TF / (1 if args.amp else SPLIT_PRODUCTS), 1), "unit": "TFLOP/s",
-                         "frac": round(ach / (PEAK_BF16_TF / (1 if args.amp else SPLIT_PRODUCTS)), 4),
+                         "achieved": round(ach, 2), "peak": round(form_peak, 1), "unit": "TFLOP/s", "frac": round(ach / form_peak, 4),
                          "traffic": traffic, "launches": launches, "avg_us": round(1e3 * ms / max(launches, 1), 2),
-                         "mfma_rate": round(ach * (1 if args.amp else SPLIT_PRODUCTS), 1), "vs_fp32_mfma_peak": round(ach / PEAK_F32_TF, 4)},
+                         "mfma_rate": round(ach * form_products, 1), "vs_fp32_mfma_peak": round(ach / PEAK_F32_TF, 4)},
         }
         if amp_leg is not None:
             out["amp"] = amp_leg
+            if fp32_leg is not None:
+                out["fp32_mfma"] = fp32_leg
         if world == 1 and not args.no_cpu_baseline:
             out["cpu_baseline"] = cpu_baseline(min(os.cpu_count() or 1, 16))   # >16 threads only adds oversubscription for these small ops
         print(json.dumps(out), flush=True)
