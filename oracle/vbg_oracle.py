@@ -340,7 +340,11 @@ def label_raster(seg_classes: Sequence[Tensor], coors: Sequence[Tensor], H: int,
 # --------------------------------------------------------------------------------------
 # a6-a8. ResNet-FPN backbone with early fusion  (model/ResNetFPN_ViBERTgrid.py)
 # --------------------------------------------------------------------------------------
+BN_FROZEN = False      # True: every BatchNorm uses its running statistics even in a training step (modules put in eval() mode)
+
+
 def _bn(sd, name, x, train, momentum=0.1, eps=1e-5):
+    train = train and not BN_FROZEN
     return F.batch_norm(x, sd[name + ".running_mean"], sd[name + ".running_var"], sd[name + ".weight"],
                         sd[name + ".bias"], train, momentum, eps)
 

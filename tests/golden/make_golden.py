@@ -650,6 +650,100 @@ def gen_e2e_amp(V, tmp):
     npz("e2e_amp.npz", **out)
 
 
+def gen_full(V, tmp, name):
+    """Full-scale reference runs (12-layer bert-base / roberta-base dims, real vocab sizes, resnet-34, 512x512 / 1024x1024, T=512 ->
+    two windows): tests/full_scale.py defines the cases and the seeded inputs; the outputs of model/ViBERTgrid_net.py:501-544 in
+    eval mode (5-tuple) and train mode (loss, gradients) are stored.  Dropout 0 (the masks of two RNGs cannot agree)."""
+    sys.path.insert(0, os.path.join(ROOT, "tests"))
+    import full_scale as F
+    c = F.CASES[name]
+    top = os.path.join(tmp, "full_" + name)
+    os.makedirs(top, exist_ok=True)
+    if c["roberta"]:
+        from transformers import RobertaConfig, RobertaTokenizer
+        d = os.path.join(top, c["bert"])
+        os.makedirs(d, exist_ok=True)
+        RobertaConfig(vocab_size=c["vocab"], max_position_embeddings=514, type_vocab_size=1, num_hidden_layers=12, hidden_dropout_prob=0.0,
+                      attention_probs_dropout_prob=0.0, layer_norm_eps=1e-5).save_pretrained(d)
+        voc = {"<s>": 0, "<pad>": 1, "</s>": 2, "<unk>": 3}
+        voc.update({f"t{i}": i for i in range(4, c["vocab"])})
+        json.dump(voc, open(os.path.join(d, "vocab.json"), "w"))
+        open(os.path.join(d, "merges.txt"), "w").write("#version: 0.2\n")
+        tokenizer = RobertaTokenizer(os.path.join(d, "vocab.json"), os.path.join(d, "merges.txt"))
+    else:
+        d = make_bert_dir(top, c["bert"], layers=12, vocab=c["vocab"])
+        tokenizer = BertTokenizer(os.path.join(d, "vocab.txt"))
+    cwd = os.getcwd()
+    os.chdir(top)
+    try:
+        net = V.ViBERTgridNet(num_classes=c["ncls"], image_mean=[0.9248, 0.9224, 0.9215], image_std=[0.1532, 0.1545, 0.1536],
+                              image_min_size=[c["img"]], image_max_size=c["img"], test_image_min_size=c["img"],
+                              bert_model=c["bert"], tokenizer=tokenizer, backbone=c["backbone"], grid_mode="mean",
+                              work_mode="eval", **F.loss_kwargs(name))
+    finally:
+        os.chdir(cwd)
+    load_synth(net)
+    batch = F.inputs(name)
+    imgs, segs, classes, coors, corpus, mask = batch
+    out = {"checksums": np.array(F.checksums(batch))}
+    import time
+    t0 = time.time()
+    net.eval()
+    random.seed(7)
+    with torch.no_grad():
+        loss, pm, ps, gt, pred = net(imgs, segs, classes, coors, corpus, mask)
+    print(name, "eval forward", round(time.time() - t0, 1), "s")
+    out.update(eval_loss=loss, gt=gt, pred=pred, pred_mask=pm[:, :, 5::16, 3::16], pred_ss=ps[:, :, 5::16, 3::16])
+    net.train()
+    if c.get("bn_frozen"):
+        for m in net.modules():
+            if isinstance(m, torch.nn.modules.batchnorm._BatchNorm):
+                m.eval()
+    random.seed(7)
+    t0 = time.time()
+    loss = net(imgs, segs, classes, coors, corpus, mask)
+    loss.backward()
+    print(name, "train step", round(time.time() - t0, 1), "s")
+    out["train_loss"] = loss
+    named = dict(net.named_parameters())
+    gn = {k: (0.0 if p.grad is None else float(p.grad.double().norm())) for k, p in named.items() if not k.startswith("BERTgrid_generator.")}
+    out["gradnorm_keys"] = np.array(sorted(gn.keys()))
+    out["gradnorm_vals"] = np.array([gn[k] for k in sorted(gn.keys())])
+    for k in (sorted(gn.keys()) if c.get("plain") else F.GRAD_PICK + F.GRAD_PICK_BACKBONE[c["backbone"]]):
+        if named[k].grad is not None:
+            out[f"grad::{k}"] = F.sample(named[k].grad, 1024 if c.get("plain") else 4096)
+    sd = net.state_dict()
+    bnk = "backbone.resnet.bn1" if c["backbone"].endswith("pretrained") else "backbone.conv_1.1"
+    out["bn_rm"], out["bn_rv"] = sd[bnk + ".running_mean"].clone(), sd[bnk + ".running_var"].clone()
+    if c.get("plain"):
+        # conditioning of the reference ITSELF: the same step with every floating-point weight moved by about one ulp
+        # (w * (1 + 1.2e-7 * N(0,1)), seeded) -> per-parameter relative L2 distance of the sampled gradients.  Any implementation,
+        # however exact, differs from the reference by rounding errors of this size at every operation, so this is the floor a
+        # gradient comparison at this model size can be held to (train-mode BN: median 6e-3; frozen BN: 4e-4).
+        first = {k: out[f"grad::{k}"].clone() for k in sorted(gn.keys()) if f"grad::{k}" in out}
+        net.zero_grad()
+        sd1 = load_synth(net)
+        gen = torch.Generator().manual_seed(1)
+        with torch.no_grad():
+            for k, p in net.named_parameters():
+                if not k.startswith("BERTgrid_generator."):
+                    p.mul_(1 + 1.2e-7 * torch.randn(p.shape, generator=gen))
+        random.seed(7)
+        loss2 = net(imgs, segs, classes, coors, corpus, mask)
+        loss2.backward()
+        out["train_loss_1ulp"] = loss2
+        keys, vals = [], []
+        for k, a in first.items():
+            b = F.sample(named[k].grad, 1024).double()
+            keys.append(k)
+            vals.append(float((a.double() - b).norm() / (a.double().norm() + 1e-30)))
+        out["ulpnoise_keys"], out["ulpnoise_vals"] = np.array(keys), np.array(vals)
+        print(name, "1-ulp gradient noise: median", float(np.median(vals)), "max", float(np.max(vals)))
+    out["keys"] = np.array(list(shapes_of(net).keys()))
+    out["key_shapes"] = np.array([str(v) for v in shapes_of(net).values()])
+    npz(f"full_{name}.npz", **out)
+
+
 def main():
     torch.set_num_threads(8)
     install_torchvision_stub()
@@ -664,7 +758,7 @@ def main():
     import pipeline.custom_loss as L
     import pipeline.transform as T
 
-    which = sys.argv[1:] or ["transform", "windows", "aggregate", "scatter", "losses", "labels", "bert", "backbone", "backbone_d", "e2e", "e2e_roberta", "losses_bce", "e2e_modes", "e2e_amp"]
+    which = sys.argv[1:] or ["transform", "windows", "aggregate", "scatter", "losses", "labels", "bert", "backbone", "backbone_d", "e2e", "e2e_roberta", "losses_bce", "e2e_modes", "e2e_amp", "full_cfg2", "full_cfg4", "full_cfg5", "full_cfg2p", "full_cfg2e"]
     if "transform" in which:
         gen_transform(T)
     if "windows" in which:
@@ -693,6 +787,9 @@ def main():
         gen_e2e_modes(V, tmp)
     if "e2e_amp" in which:
         gen_e2e_amp(V, tmp)
+    for name in ("cfg2", "cfg4", "cfg5", "cfg2p", "cfg2e"):
+        if "full_" + name in which:
+            gen_full(V, tmp, name)
 
 
 if __name__ == "__main__":

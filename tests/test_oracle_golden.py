@@ -355,3 +355,41 @@ def test_e2e(golden, tag, backbone):
             ref = T(g[name])
             rel = float((samp - ref).norm() / ref.norm())
             assert rel < 5e-3, (k, rel)
+
+
+def test_oracle_full_scale_vs_reference(golden):
+    """The oracle at FULL scale (12-layer bert-base, vocab 30522, resnet-34 torchvision layout, 512x512, two token windows, ragged
+    second document) against the reference's outputs in tests/golden/full_cfg2e.npz (default plain losses, frozen BatchNorm in the
+    training step): class probabilities, both losses and every sampled parameter gradient."""
+    import random
+    import full_scale as F
+    name = "cfg2e"
+    g, c, cfg = golden(f"full_{name}.npz"), F.CASES[name], F.net_cfg(name)
+    batch = F.inputs(name)
+    assert np.array_equal(np.array(F.checksums(batch)), g["checksums"])
+    sd = O.synth_state_dict(O.state_shapes(cfg, vocab=c["vocab"], max_pos=c["max_pos"], type_vocab=c["type_vocab"], dup_bert=False))
+    random.seed(7)
+    with torch.no_grad():
+        loss, pm, ps, gt, pred = O.forward({k: v.clone() for k, v in sd.items()}, cfg, *batch, training=False)
+    assert np.array_equal(gt.numpy(), g["gt"])
+    assert torch.allclose(pred, T(g["pred"]), rtol=1e-4, atol=1e-5)
+    assert torch.allclose(ps[:, :, 5::16, 3::16], T(g["pred_ss"]), rtol=1e-4, atol=1e-5)
+    assert abs(float(loss) - float(np.asarray(g["eval_loss"]).reshape(-1)[0])) <= 1e-5 * abs(float(loss))
+    sdg = {k: (v.requires_grad_(True) if v.is_floating_point() and "running" not in k else v) for k, v in sd.items()}
+    O.BN_FROZEN = True
+    try:
+        random.seed(7)
+        tl = O.forward(sdg, cfg, *batch, training=True)[0]
+        tl.backward()
+    finally:
+        O.BN_FROZEN = False
+    assert abs(float(tl.detach()) - float(np.asarray(g["train_loss"]).reshape(-1)[0])) <= 1e-5 * abs(float(tl.detach()))
+    bad = []
+    for f in g.files:
+        if f.startswith("grad::") and "key.bias" not in f:
+            k = f[6:]
+            a, b = F.sample(sdg[k].grad, 1024).double(), T(g[f]).double()
+            r = float((a - b).norm() / (b.norm() + 1e-30))
+            if r > 1e-3:
+                bad.append((k, r))
+    assert not bad, bad[:8]

@@ -34,10 +34,15 @@ class _Cat:
 class RandomSamplePlan:
     """label-only part of CrossEntropyLossRandomSample."""
 
-    def __init__(self, labels_i32: torch.Tensor, ncls_logits: int, sample_list: Sequence[int]):
+    def __init__(self, labels_i32: torch.Tensor, ncls_logits: int, sample_list: Optional[Sequence[int]]):
         self.labels = labels_i32
-        self.sample_list = list(sample_list)
         self.cats: List[_Cat] = []
+        self.plain = sample_list is None          # reference :36-44: plain (weighted) mean CE over every element
+        self.num_keep_total = 0
+        if self.plain:
+            self.sample_list = None
+            return
+        self.sample_list = list(sample_list)
         ncat = len(sample_list)
         if ncat == 2 and ncls_logits >= 2:
             spec = [(0, True), (0, False)]
@@ -55,6 +60,8 @@ class RandomSamplePlan:
     def resolve(self, counts: Sequence[int]):
         dev = self.labels.device
         self.num_keep_total = 0
+        if self.plain:
+            return
         for c, n, k in zip(self.cats, counts, self.sample_list):
             c.n = int(n)
             keep = min(k, c.n)
@@ -127,6 +134,19 @@ def resolve_plans(plans):
     PendingCounts(plans).finish()
 
 
+def plain_mean_ce(logits2d: torch.Tensor, labels_i32: torch.Tensor, weight: Optional[torch.Tensor], up_shift: int, H: int,
+                  W: int) -> torch.Tensor:
+    """`F.cross_entropy(input, target, weight, reduction="mean")` over EVERY element (the reference's path for
+    `sample_list=None` :36-44 and `num_hard_* == -1` :127-136): sum_i w[t_i] CE_i / sum_i w[t_i]; 0-dim fp32."""
+    n = labels_i32.numel()
+    elem = torch.arange(n, dtype=torch.int32, device=logits2d.device)
+    if weight is None:
+        return Fn.SelectedCEFn.apply(logits2d, elem, labels_i32, None, 1.0 / n, up_shift, H, W)
+    w = weight.to(device=logits2d.device, dtype=torch.float32)
+    denom = (torch.bincount(labels_i32.long(), minlength=w.numel()).to(torch.float32) * w).sum()
+    return Fn.SelectedCEFn.apply(logits2d, elem, labels_i32, w, 1.0, up_shift, H, W) / denom
+
+
 class CrossEntropyLossRandomSample(torch.nn.Module):
     def __init__(self, sample_list: Optional[List], weight: Optional[torch.Tensor] = None, reduction: str = "mean") -> None:
         super().__init__()
@@ -142,10 +162,11 @@ class CrossEntropyLossRandomSample(torch.nn.Module):
     def forward(self, logits2d: torch.Tensor, labels_i32: torch.Tensor, plan: RandomSamplePlan = None, up_shift: int = 0,
                 H: int = 0, W: int = 0) -> torch.Tensor:
         """logits2d [rows, C] fp32 (rows = low-res pixels when H > 0); labels int32 flat (full resolution)."""
-        assert self.sample_list is not None, "sample_list=None (plain CE) is not used by the model"
         if plan is None:
             plan = self.plan(labels_i32, logits2d.shape[1])
             resolve_plans([plan])
+        if plan.plain:
+            return plain_mean_ce(logits2d, labels_i32, self.weight, up_shift, H, W)
         total = torch.zeros((1,), dtype=torch.float64, device=logits2d.device)
         for c in plan.cats:
             if c.elem.numel():
@@ -169,12 +190,8 @@ class CrossEntropyLossOHEM(torch.nn.Module):
         if plan is None:
             plan = self.plan(labels_i32)
             resolve_plans([plan])
-        n = labels_i32.numel()
         if plan.plain:
-            if self.weight is not None:
-                raise NotImplementedError("weighted plain mean CE is not on the model's path")
-            elem = torch.arange(n, dtype=torch.int32, device=logits2d.device)
-            return Fn.SelectedCEFn.apply(logits2d, elem, labels_i32, None, 1.0 / n, up_shift, H, W)
+            return plain_mean_ce(logits2d, labels_i32, self.weight, up_shift, H, W)
         elems, keeps = [], []
         for c, k in zip(plan.cats, (self.num_hard_positive, self.num_hard_negative)):
             m = int(c.elem.numel())
@@ -201,6 +218,12 @@ class CrossEntropyLossOHEM(torch.nn.Module):
 # ----------------------------------------------------------------------------------------------
 # binary variants (classifier_mode full): reference `BCELossRandomSample` :204-290, `BCELossOHEM` :293-382
 # ----------------------------------------------------------------------------------------------
+_BCE_WEIGHT_MSG = ("the binary (BCE) losses of classifier_mode 'full' / 'crf' take no `weight`: the reference hands its per-CLASS "
+                   "`loss_weights` to F.binary_cross_entropy_with_logits as a per-ELEMENT weight (pipeline/custom_loss.py:228-241, "
+                   ":312-333), which only broadcasts when the number of elements happens to equal num_classes; "
+                   "use loss_weights=None with these modes, or classifier_mode='simp' for class-weighted losses")
+
+
 def _two_column(logit: torch.Tensor) -> torch.Tensor:
     """BCE-with-logits(x, t) is exactly the 2-class cross entropy of the logit pair (0, x) with target t
     (logsumexp(0, x) - t*x = max(x, 0) + log1p(exp(-|x|)) - t*x), so the CE kernels serve both."""
@@ -216,7 +239,7 @@ class BCELossRandomSample(torch.nn.Module):
         super().__init__()
         assert reduction == "mean", "only the reduction the model uses is implemented"
         if weight is not None:
-            raise NotImplementedError("element-wise BCE weights are not on the model's path")
+            raise NotImplementedError(_BCE_WEIGHT_MSG)
         assert sample_list is not None and len(sample_list) == 2, "sample list must contain two elements"
         self.sample_list = sample_list
 
@@ -243,7 +266,7 @@ class BCELossOHEM(torch.nn.Module):
                  reduction: str = "mean", random: bool = False) -> None:
         super().__init__()
         if weight is not None:
-            raise NotImplementedError("element-wise BCE weights are not on the model's path")
+            raise NotImplementedError(_BCE_WEIGHT_MSG)
         self.ce = CrossEntropyLossOHEM(num_hard_positive, num_hard_negative, None, reduction, random)
 
     def forward(self, input: torch.Tensor, target: torch.Tensor = None, keyed_labels: torch.Tensor = None, up_shift: int = 0,

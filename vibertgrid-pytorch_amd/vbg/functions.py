@@ -297,7 +297,6 @@ class ConvBnFn(torch.autograd.Function):
     def backward(ctx, dy):
         x, w4, col, z, y, mean, invstd, gamma, count_dev = ctx.saved_tensors
         stride, pad, relu, training, count, has_res, sync = ctx.cfg
-        assert training, "BatchNorm backward is implemented for training mode only"
         C = z.shape[-1]
         dy2 = _c(dy).view(-1, C)
         z2 = z.view(-1, C)
@@ -306,7 +305,11 @@ class ConvBnFn(torch.autograd.Function):
         dgamma, dbeta, sunk = _affine_dest(*ctx.affine)           # from the LOCAL sums: the gradient exchange averages them
         sums = ops.bn_param_grad(slots, C, dgamma, dbeta)
         dgamma, dbeta = _affine_done(*ctx.affine, dgamma, dbeta, sunk)
-        if sync:
+        if not training:
+            # frozen statistics (module in eval mode inside a training step): mean / var are constants, so the two batch-coupling
+            # terms of the input gradient vanish -> dz = gamma * invstd * dy (same kernel, zero sums); dgamma / dbeta as above
+            sums = torch.zeros_like(sums)
+        elif sync:
             dist.all_reduce(sums, group=SyncCtx.group)
         dz2, dres2 = ops.bn_bwd_apply(dy2, y2, z2, mean, invstd, gamma, sums, count, relu, has_res, None, None, count_dev)
         dz = dz2.view(z.shape)
