@@ -25,13 +25,18 @@ class _Toy(torch.nn.Module):
         self.conv = torch.nn.Conv2d(4, 4, 3, padding=1).to(memory_format=torch.channels_last)
         self.pooler = torch.nn.Linear(3, 3)                   # never used: must stay out of the flat buffers
 
-    def forward(self, x, img):
-        return self.head(self.bert_model(x)).sum() + self.conv(img).square().mean()
+    def forward(self, x, img, skip_conv=False):
+        y = self.head(self.bert_model(x)).sum()
+        return y if skip_conv else y + self.conv(img).square().mean()
+
+
+STEPS = 3
 
 
 def _worker(rank, world, port, out):
     os.environ.update(MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port))
     dist.init_process_group("gloo", rank=rank, world_size=world)
+    from vbg import functions as Fn
     from vbg.optim import FlatGroup, FlatReducer, split_parameters
 
     class Opt:          # the reducer only needs .group and .grad_scale (the fused steps themselves are GPU kernels)
@@ -48,13 +53,21 @@ def _worker(rank, world, port, out):
     assert red.enabled and len(red.buckets) >= 3 and all(o.grad_scale == 0.5 for o in opts)
     # channels_last conv weight keeps its physical layout inside the flat buffer
     assert net.conv.weight.is_contiguous(memory_format=torch.channels_last)
-    for step in range(2):
+    assert dist.get_world_size(Fn.SyncCtx.group) == 2 and Fn.SyncCtx.group is not None      # SyncBN statistics: own group
+    for step in range(STEPS):
         g = torch.Generator().manual_seed(100 + rank + 10 * step)
         x, img = torch.randn(4, 6, generator=g), torch.randn(2, 4, 5, 5, generator=g)
         for o in opts:
             o.group.zero_grad()
-        net(x, img).backward()
+        # data-dependent graph (classifier_mode full / crf): in the last step rank 1 skips a sub-module, so its conv bucket never
+        # completes during backward -- the fixed launch sequence must keep both ranks pairing the same buffers
+        net(x, img, skip_conv=(step == STEPS - 1 and rank == 1)).backward()
+        if step > 0:
+            assert red.order is not None and sorted(red.order) == list(range(len(red.buckets)))
         red.finish()
+    orders = [None, None]
+    dist.all_gather_object(orders, red.order)
+    assert orders[0] == orders[1]
     res = {n: p.grad.clone() for n, p in net.named_parameters() if p.grad is not None}
     if rank == 0:
         torch.save(res, out)
@@ -70,11 +83,11 @@ def test_flat_reducer_two_ranks(tmp_path):
     net = _Toy()
     exp = None
     for rank in range(2):
-        g = torch.Generator().manual_seed(100 + rank + 10)
+        g = torch.Generator().manual_seed(100 + rank + 10 * (STEPS - 1))
         x, img = torch.randn(4, 6, generator=g), torch.randn(2, 4, 5, 5, generator=g)
         net.zero_grad()
-        net(x, img).backward()
-        cur = {n: p.grad.clone() for n, p in net.named_parameters() if p.grad is not None}
+        net(x, img, skip_conv=(rank == 1)).backward()
+        cur = {n: (p.grad.clone() if p.grad is not None else torch.zeros_like(p)) for n, p in net.named_parameters() if "pooler" not in n}
         exp = cur if exp is None else {k: exp[k] + cur[k] for k in exp}
     assert set(got) == set(exp)
     for k in exp:

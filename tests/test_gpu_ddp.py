@@ -1,0 +1,149 @@
+"""Data-parallel step on the real model and the real kernels (reference train_SROIE.py:202-210: convert_sync_batchnorm + DDP):
+two ranks share the ONE GPU of the test box over gloo -- SyncBatchNorm through the bn_fold -> all_reduce -> bn_finalize route and
+its backward, gradients sunk into the flat buffers by the weight-gradient GEMMs (GRAD_READY notifications), FlatReducer's ordered
+bucket launches, FusedSGD / FusedAdamW with the 1/world scale.
+
+(i)  2 ranks x 1 document with SyncBN == 1 process x 2 documents: loss and every parameter gradient (the default plain mean
+     losses, equal segment counts -> the global means are the averages of the per-rank means, so the identity is exact in math);
+(ii) after 3 optimizer steps both ranks hold bit-identical flat parameter buffers.
+Needs a real MI355X."""
+import os
+import random
+import socket
+
+import pytest
+import torch
+import torch.distributed as dist
+import torch.multiprocessing as mp
+
+pytestmark = pytest.mark.gpu
+
+import vbg_oracle as O
+
+
+def _free_port():
+    s = socket.socket()
+    s.bind(("127.0.0.1", 0))
+    p = s.getsockname()[1]
+    s.close()
+    return p
+
+
+CFG = dict(num_classes=5, image_min_size=(256,), image_max_size=256, test_image_min_size=256, backbone="resnet_18_fpn",
+           num_hard_positive_main_1=-1, num_hard_negative_main_1=-1, num_hard_positive_main_2=-1, num_hard_negative_main_2=-1,
+           loss_aux_sample_list=None, num_hard_positive_aux=-1, num_hard_negative_aux=-1, ohem_random=False)
+
+
+def _cfg():
+    return O.NetCfg(bert=O.BertCfg(layers=2, dropout=0.0), **CFG)
+
+
+def _docs():
+    g = torch.Generator().manual_seed(77)
+    B, H, W, T_, S = 2, 256, 256, 24, 8
+    imgs = tuple(torch.rand(3, H, W, generator=g) for _ in range(B))
+    coors = []
+    for _ in range(B):
+        x1 = torch.randint(0, W - 73, (S,), generator=g)
+        y1 = torch.randint(0, H - 25, (S,), generator=g)
+        w = torch.randint(8, 73, (S,), generator=g)
+        h = torch.randint(8, 25, (S,), generator=g)
+        coors.append(torch.stack([x1, y1, x1 + w, y1 + h], 1).long())
+    segs = tuple(torch.arange(S, dtype=torch.int32).repeat_interleave(T_ // S) for _ in range(B))
+    classes = tuple(torch.randint(0, 5, (S,), generator=g).int() for _ in range(B))
+    corpus = torch.randint(1000, 1200, (B, T_), generator=g)
+    mask = torch.ones(B, T_, dtype=torch.int32)
+    return imgs, segs, classes, tuple(coors), corpus, mask
+
+
+def _slice(batch, lo, hi):
+    imgs, segs, classes, coors, corpus, mask = batch
+    return imgs[lo:hi], segs[lo:hi], classes[lo:hi], coors[lo:hi], corpus[lo:hi], mask[lo:hi]
+
+
+def _build(tmp, sync_bn):
+    from test_gpu_model import build_product, load_synth
+    cfg = _cfg()
+    net = build_product(tmp, "resnet_18_fpn", cfg)
+    load_synth(net, cfg, 1200)
+    if sync_bn:
+        net = torch.nn.SyncBatchNorm.convert_sync_batchnorm(net)
+    return net
+
+
+def _worker(rank, world, port, tmp):
+    import sys
+    here = os.path.dirname(os.path.abspath(__file__))
+    for p in (here, os.path.join(os.path.dirname(here), "oracle"), os.path.join(os.path.dirname(here), "vibertgrid-pytorch_amd")):
+        if p not in sys.path:
+            sys.path.insert(0, p)
+    os.environ.update(MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port))
+    torch.cuda.set_device(0)
+    dev = torch.device("cuda", 0)
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    from test_gpu_model import to_dev
+    from vbg.optim import FlatReducer, FusedAdamW, FusedSGD, split_parameters
+    net = _build(os.path.join(tmp, f"rank{rank}"), sync_bn=True).to(dev).train()
+    assert any(isinstance(m, torch.nn.SyncBatchNorm) for m in net.modules())
+    cnn, bert = split_parameters(net)
+    opts = [FusedSGD(cnn, dev, lr=0.005, momentum=0.9, weight_decay=0.005), FusedAdamW(bert, dev, lr=5e-5, weight_decay=0.01)]
+    red = FlatReducer(opts)
+    dbatch = to_dev(_slice(_docs(), rank, rank + 1), dev)
+    res = {}
+    for step in range(3):
+        random.seed(5)
+        loss = net(*dbatch)
+        for o in opts:
+            o.zero_grad()
+        loss.backward()
+        red.finish()
+        if step == 0:
+            res["loss"] = float(loss.detach())
+            res["grads"] = {n: (p.grad.detach() / world).cpu().clone() for n, p in net.named_parameters()
+                            if p.grad is not None and not n.startswith("BERTgrid_generator.")}
+            res["rm"] = net.backbone.conv_1[1].running_mean.cpu().clone()
+        for o in opts:
+            o.step()
+    torch.cuda.synchronize()
+    res["order"] = red.order
+    res["nbuckets"] = len(red.buckets)
+    res["pflat"] = [o.group.pflat.cpu().clone() for o in opts]
+    torch.save(res, os.path.join(tmp, f"res{rank}.pt"))
+    dist.barrier()
+    dist.destroy_process_group()
+
+
+def test_two_ranks_syncbn_equals_one_process(tmp_path):
+    from test_gpu_model import to_dev
+    tmp = str(tmp_path)
+    port = _free_port()
+    mp.spawn(_worker, args=(2, port, tmp), nprocs=2, join=True)
+    r0, r1 = (torch.load(os.path.join(tmp, f"res{r}.pt")) for r in range(2))
+    # (ii) both ranks hold bit-identical parameters after 3 steps, and they launched their buckets in the same sequence
+    assert r0["order"] == r1["order"] and sorted(r0["order"]) == list(range(r0["nbuckets"]))
+    for a, b in zip(r0["pflat"], r1["pflat"]):
+        assert torch.equal(a, b)
+    # the gradients after the exchange are the same tensor on both ranks
+    for k in r0["grads"]:
+        assert torch.equal(r0["grads"][k], r1["grads"][k]), k
+    # (i) one process, both documents, plain BatchNorm
+    dev = torch.device("cuda")
+    net = _build(os.path.join(tmp, "single"), sync_bn=False).to(dev).train()
+    random.seed(5)
+    loss = net(*to_dev(_docs(), dev))
+    loss.backward()
+    avg_loss = 0.5 * (r0["loss"] + r1["loss"])
+    print("loss single", float(loss.detach()), "mean of ranks", avg_loss)
+    assert abs(float(loss.detach()) - avg_loss) <= 1e-5 * abs(avg_loss)
+    assert torch.allclose(net.backbone.conv_1[1].running_mean.cpu(), r0["rm"], rtol=1e-5, atol=1e-7)      # global statistics
+    worst = []
+    for n, p in net.named_parameters():
+        if n.startswith("BERTgrid_generator.") or p.grad is None:
+            continue
+        a, b = r0["grads"][n].double(), p.grad.detach().cpu().double()
+        if "key.bias" in n:
+            continue
+        worst.append((float((a - b).norm() / (b.norm() + 1e-30)), n))
+    worst.sort(reverse=True)
+    print("2 ranks + SyncBN vs 1 process, rel-L2 of gradients, worst:", worst[:5], "median", worst[len(worst) // 2])
+    assert worst[0][0] < 1e-4, worst[:8]

@@ -1,0 +1,193 @@
+"""The reference's training-loop plumbing around the model, on the HIP product:
+(a) `amp: True` exactly as pipeline/train_val_utils.py:264-278 writes it -- torch.cuda.amp.autocast + ONE GradScaler shared by two
+    optimizers (scale(loss).backward(), scaler.step(opt_cnn), scaler.step(opt_bert), scaler.update()) -- with torch.optim.SGD / AdamW
+    and with FusedSGD / FusedAdamW (torch.optim.Optimizer subclasses: `StepLR(optimizer=...)` of train_SROIE.py:247 works on them);
+(b) optimizer checkpoints in torch.optim's own format, interchangeable in both directions (train_SROIE.py:385-387 saves
+    `optimizer_cnn.state_dict()`, resume loads it);
+(c) model checkpoint round trip: saved from the DDP-wrapped model (`module.` prefixes, train_SROIE.py:377-416), loaded the way
+    eval_SROIE.py:335-337 does (strip the prefix, strict=False) -> eval outputs bit-equal.
+Needs a real MI355X."""
+import os
+import random
+
+import numpy as np
+import pytest
+import torch
+
+pytestmark = pytest.mark.gpu
+
+from test_gpu_model import build_product, load_synth, to_dev
+from test_oracle_golden import _e2e_inputs, e2e_cfg
+
+
+def _net(tmp_path, tag, dev):
+    cfg = e2e_cfg("resnet_18_fpn")
+    net = build_product(tmp_path / tag, "resnet_18_fpn", cfg)
+    load_synth(net, cfg, 1200)
+    return net.to(dev).train()
+
+
+def _torch_opts(net):
+    pc = [p for n, p in net.named_parameters() if "bert_model" not in n]
+    pb = [p for n, p in net.named_parameters() if "bert_model" in n]
+    return (torch.optim.SGD(pc, lr=0.005, momentum=0.9, weight_decay=0.005),
+            torch.optim.AdamW(pb, lr=5e-5, betas=(0.9, 0.999), eps=1e-8, weight_decay=0.01))
+
+
+def _fused_opts(net, dev):
+    from vbg.optim import FusedAdamW, FusedSGD, split_parameters
+    # unused=() keeps pooler / fc in the lists like the reference's optimizers do (their indices then line up in checkpoints)
+    cnn, bert = split_parameters(net, unused=())
+    return (FusedSGD(cnn, dev, lr=0.005, momentum=0.9, weight_decay=0.005),
+            FusedAdamW(bert, dev, lr=5e-5, betas=(0.9, 0.999), eps=1e-8, weight_decay=0.01))
+
+
+def _dist(na, nb):
+    a, b = dict(na.named_parameters()), dict(nb.named_parameters())
+    return max((float((a[k].detach() - b[k].detach()).norm() / (a[k].detach().norm() + 1e-12)), k) for k in a if "pooler" not in k and "key.bias" not in k)
+    # (key.bias: analytically zero gradient -- softmax is shift invariant -- so AdamW normalises pure rounding noise to +-lr steps)
+
+
+@pytest.mark.parametrize("dtype", [torch.float16, torch.bfloat16])
+def test_gradscaler_loop_torch_and_fused(golden, tmp_path, dtype):
+    """(Trajectories of two runs are only compared after the FIRST step: on this 2-document fixture a 1e-7 parameter difference
+    moves the next step's gradients by 1e-3..3e-2 in either implementation, tools/conditioning.py.)"""
+    dev = torch.device("cuda")
+    dbatch = to_dev(_e2e_inputs(golden("e2e.npz")), dev)
+    nets, losses, scales, after1 = {}, {}, {}, {}
+    for mode in ("torch", "fused"):
+        net = _net(tmp_path, mode, dev)
+        oc, ob = _torch_opts(net) if mode == "torch" else _fused_opts(net, dev)
+        sched = torch.optim.lr_scheduler.StepLR(optimizer=oc, step_size=2, gamma=0.1)          # train_SROIE.py:247
+        scaler = torch.amp.GradScaler("cuda", growth_interval=2)
+        ls = []
+        for step in range(5):
+            random.seed(100 + step)
+            with torch.autocast("cuda", dtype=dtype):
+                loss = net(*dbatch)
+            ls.append(loss.item())
+            oc.zero_grad()
+            ob.zero_grad()
+            scaler.scale(loss).backward()
+            if step == 0:          # the scaled gradients really sit in the parameters' .grad (the flat views for the fused pair)
+                gmax = max(float(p.grad.abs().max()) for p in net.parameters() if p.grad is not None)
+                assert gmax > 100.0, gmax
+            scaler.step(oc)
+            scaler.step(ob)
+            scaler.update()
+            sched.step()
+            if step == 0:
+                after1[mode] = {k: v.detach().clone() for k, v in net.named_parameters()}
+        nets[mode], losses[mode], scales[mode] = net, ls, scaler.get_scale()
+        assert all(np.isfinite(ls)), ls
+        assert abs(oc.param_groups[0]["lr"] - 0.005 * 0.1 ** 2) < 1e-12          # StepLR drove the (fused) optimizer's lr
+    assert scales["torch"] == scales["fused"] and scales["torch"] > 65536.0       # the scaler saw finite gradients in both loops and grew
+    worst = max((float((after1["torch"][k] - after1["fused"][k]).norm() / (after1["torch"][k].norm() + 1e-12)), k)
+                for k in after1["torch"] if "pooler" not in k and "key.bias" not in k)
+    print("torch.optim vs fused after one GradScaler step, worst parameter distance:", worst)
+    # unscale_ + step did the same thing to the same gradients.  (1e-3, not 1e-5 as in the fp32 test of test_gpu_model.py: the two
+    # runs' bf16 products see operands that differ by atomics-order noise, a rounding flip is 2^-9, and AdamW's first step is
+    # lr * sign(g) -- a flipped sign on a near-zero gradient element moves that weight by 2 lr = 1e-4.)
+    assert worst[0] < 1e-3, worst
+    assert losses["fused"][-1] < losses["fused"][0] and losses["torch"][-1] < losses["torch"][0]          # and both train
+
+
+def test_optimizer_state_dict_interchange(golden, tmp_path):
+    """one real step with each optimizer pair, checkpoints in torch.optim's format cross-loaded, then further steps on IDENTICAL
+    (synthetic) gradients so that only the optimizer state carried by the checkpoint decides the outcome"""
+    dev = torch.device("cuda")
+    dbatch = to_dev(_e2e_inputs(golden("e2e.npz")), dev)
+    nt, nf = _net(tmp_path, "t", dev), _net(tmp_path, "f", dev)
+    ot, of = _torch_opts(nt), _fused_opts(nf, dev)
+    g1 = None
+    for net, opts in ((nt, ot), (nf, of)):
+        random.seed(0)
+        loss = net(*dbatch)
+        for o in opts:
+            o.zero_grad()
+        loss.backward()
+        if g1 is None:
+            g1 = {n: p.grad.detach().clone() for n, p in net.named_parameters() if p.grad is not None}
+        for o in opts:
+            o.step()
+    assert _dist(nt, nf)[0] < 1e-5
+    ck_t = [o.state_dict() for o in ot]
+    ck_f = [o.state_dict() for o in of]
+    for a, b, fo in zip(ck_t, ck_f, of):                      # same format: per-parameter state under the parameter's index
+        assert set(a.keys()) == set(b.keys()) == {"state", "param_groups"}
+        assert a["param_groups"][0]["params"] == b["param_groups"][0]["params"]
+        assert set(a["param_groups"][0].keys()) == set(b["param_groups"][0].keys())
+        ia = set(a["state"].keys())
+        assert ia <= set(b["state"].keys())
+        for i in ia:
+            if "key.bias" in fo.group.ref_names[i]:
+                continue
+            assert set(a["state"][i].keys()) == set(b["state"][i].keys())
+            for k, v in a["state"][i].items():
+                w = b["state"][i][k]
+                v, w = v.double().cpu(), w.double().cpu()
+                assert v.shape == w.shape and float((v - w).norm()) <= 1e-4 * float(v.norm()) + 1e-12, (i, k)
+    path = str(tmp_path / "opt.pth")
+    torch.save({"optimizer_cnn": ck_t[0], "optimizer_bert": ck_t[1], "fused_cnn": ck_f[0], "fused_bert": ck_f[1]}, path)
+    ck = torch.load(path, map_location="cpu")
+    # resume: fused <- torch checkpoint, torch <- fused checkpoint (model weights from the run that wrote the checkpoint)
+    nt2, nf2 = _net(tmp_path, "t2", dev), _net(tmp_path, "f2", dev)
+    nt2.load_state_dict(nf.state_dict())
+    nf2.load_state_dict(nt.state_dict())
+    ot2, of2 = _torch_opts(nt2), _fused_opts(nf2, dev)
+    ot2[0].load_state_dict(ck["fused_cnn"])
+    ot2[1].load_state_dict(ck["fused_bert"])
+    of2[0].load_state_dict(ck["optimizer_cnn"])
+    of2[1].load_state_dict(ck["optimizer_bert"])
+    assert of2[1].steps == 1 and of2[0].steps == 1
+    for c in (0.7, -0.4, 1.3):
+        for net, opts in ((nt, ot), (nf, of), (nt2, ot2), (nf2, of2)):
+            for n, p in net.named_parameters():
+                if n in g1:
+                    if p.grad is None:
+                        p.grad = torch.zeros_like(p)
+                    p.grad.copy_(g1[n] * c)
+            for o in opts:
+                o.step()
+    for tag, other in (("fused uninterrupted", nf), ("fused <- torch checkpoint", nf2), ("torch <- fused checkpoint", nt2)):
+        worst = _dist(nt, other)
+        print(tag, "vs uninterrupted torch.optim run:", worst)
+        assert worst[0] < 2e-5, (tag, worst)
+
+
+def test_checkpoint_round_trip_like_eval_script(golden, tmp_path):
+    dev = torch.device("cuda")
+    dbatch = to_dev(_e2e_inputs(golden("e2e.npz")), dev)
+    net = _net(tmp_path, "a", dev)
+    oc, ob = _fused_opts(net, dev)
+    for s in range(2):                                  # a little training, so the checkpoint is not the synthetic init
+        random.seed(s)
+        loss = net(*dbatch)
+        oc.zero_grad()
+        ob.zero_grad()
+        loss.backward()
+        oc.step()
+        ob.step()
+    net.eval()
+    random.seed(9)
+    with torch.no_grad():
+        ref = net(*dbatch)
+    # train_SROIE.py:377-416: `model` is the DDP wrapper there, so every key carries the `module.` prefix
+    path = str(tmp_path / "ckpt.pth")
+    torch.save({"model": {"module." + k: v for k, v in net.state_dict().items()}, "optimizer_cnn": oc.state_dict(),
+                "optimizer_bert": ob.state_dict(), "epoch": 3}, path)
+    # eval_SROIE.py:335-337
+    fresh = build_product(tmp_path / "b", "resnet_18_fpn", e2e_cfg("resnet_18_fpn")).to(dev)
+    checkpoint = torch.load(path, map_location="cpu")["model"]
+    model_weights = {k.replace("module.", ""): v for k, v in checkpoint.items()}
+    res = fresh.load_state_dict(model_weights, strict=False)
+    assert not res.unexpected_keys and all(k.endswith(("position_ids", "token_type_ids")) for k in res.missing_keys), res
+    fresh.eval()
+    random.seed(9)
+    with torch.no_grad():
+        out = fresh(*dbatch)
+    for a, b in zip(ref, out):
+        assert torch.equal(a, b)
+    # the duplicated BERT registration (bert_model. / BERTgrid_generator.model.) stays ONE storage after loading
+    assert fresh.bert_model.embeddings.word_embeddings.weight.data_ptr() == \
+        fresh.BERTgrid_generator.model.embeddings.word_embeddings.weight.data_ptr()

@@ -11,11 +11,16 @@ pipeline/train_val_utils.py:272-284, designed for MI355X instead of translated:
 * data parallel: the flat gradient buffer is cut into large contiguous buckets; a bucket is all-reduced
   (RCCL over xGMI, async, its own stream) as soon as autograd has accumulated its last gradient, so the
   exchange overlaps the rest of backward; no bucket copies (gradients ARE the bucket); the 1/world
-  averaging is folded into the optimizer kernels.  Parameters that never receive a gradient
+  averaging is folded into the optimizer kernels.  The flat buffers hold the parameters in REVERSE forward order (heads first,
+  stem / word embeddings last), so contiguous buckets complete roughly in the order autograd produces them; buckets are launched
+  strictly in ONE sequence that is identical on every rank (the completion order rank 0 observed in its first step, broadcast
+  once), so data-dependent graphs (classifier_mode full / crf: a per-class net may get no gradient on one rank) can never make two
+  ranks issue collectives in different orders.  SyncBatchNorm statistics travel on their OWN process group (own communicator and
+  stream), so a 4 KB statistics all-reduce on the critical path never queues behind a 32 MB bucket.  Parameters that never receive a gradient
   (`bert_model.pooler.*`, `backbone.resnet.fc.*`) are kept out of the buffers, which is what
   `find_unused_parameters=True` + "skip params with grad None" amounts to in the reference.
 """
-from typing import Dict, List, Tuple
+from typing import Dict, List, Sequence, Tuple
 
 import torch
 import torch.distributed as dist
@@ -37,11 +42,15 @@ def _phys_view(flat: torch.Tensor, off: int, p: torch.Tensor) -> torch.Tensor:
 
 
 def _fusion_order(named):
-    """Same parameters, ordered so that each attention block's query/key/value weights (and then their biases) sit back to
-    back in the flat buffers: the three projections then run as ONE [3*hidden, hidden] GEMM forward and backward
-    (vbg/functions.BertLayerFn).  The optimizers are element-wise, so the order is otherwise irrelevant."""
+    """Same parameters in the order of the flat buffers:
+    * each attention block's query/key/value weights (and then their biases) sit back to back, so the three projections run as
+      ONE [3*hidden, hidden] GEMM forward and backward (vbg/functions.BertLayerFn);
+    * the units (such a block, or a single parameter) are laid out in REVERSE registration (= forward) order, so the
+      contiguous gradient buckets of FlatReducer fill up in roughly the order backward produces them: heads, FPN, trunk
+      top-down, stem last; encoder layer 11 ... 0, the embedding tables last.
+    The optimizers are element-wise, so the order is otherwise irrelevant."""
     by_name = dict(named)
-    out, used = [], set()
+    units, used = [], set()
     for name, p in named:
         if name in used:
             continue
@@ -49,17 +58,17 @@ def _fusion_order(named):
             stem = name[:-len("query.weight")]
             block = [stem + k for k in ("query.weight", "key.weight", "value.weight", "query.bias", "key.bias", "value.bias")]
             if all(b in by_name for b in block):
-                for b in block:
-                    out.append((b, by_name[b]))
-                    used.add(b)
+                units.append([(b, by_name[b]) for b in block])
+                used.update(block)
                 continue
-        out.append((name, p))
+        units.append([(name, p)])
         used.add(name)
-    return out
+    return [np_ for u in reversed(units) for np_ in u]
 
 
 class FlatGroup:
     def __init__(self, named: List[Tuple[str, torch.nn.Parameter]], device):
+        self.ref_names = [n for n, _ in named]            # the caller's (= reference's) parameter order, for state_dict indices
         named = _fusion_order(named)
         self.names = [n for n, _ in named]
         self.params = [p for _, p in named]
@@ -85,40 +94,100 @@ class FlatGroup:
             if p.grad is None or p.grad.data_ptr() != self.gflat.data_ptr() + 4 * off:
                 p.grad = _phys_view(self.gflat, off, p.data)
 
+    def view(self, flat: torch.Tensor, i: int) -> torch.Tensor:
+        """parameter i's slice of another flat buffer of this layout (optimizer state), shaped / laid out like the parameter"""
+        return _phys_view(flat, self.offsets[i], self.params[i].data)
 
-def split_parameters(model: torch.nn.Module):
-    """(cnn_named, bert_named) exactly like train_SROIE.py:215-221, minus the statically unused tensors."""
+
+def split_parameters(model: torch.nn.Module, unused: Sequence[str] = STATIC_UNUSED):
+    """(cnn_named, bert_named) exactly like train_SROIE.py:215-221, minus the tensors that never receive a gradient
+    (`unused`: name fragments; the reference keeps them in its optimizers, where `grad is None` makes every step skip them)."""
     cnn, bert = [], []
     for name, p in model.named_parameters():
-        if not p.requires_grad or any(u in name for u in STATIC_UNUSED):
+        if not p.requires_grad or any(u in name for u in unused):
             continue
         (bert if "bert_model" in name else cnn).append((name, p))
     return cnn, bert
 
 
-class _FlatOptimizer:
+def _torch_defaults(cls, **kw):
+    """the param_group keys of the torch optimizer this one stands in for (so a checkpoint written here loads into it)"""
+    return dict(cls([torch.nn.Parameter(torch.zeros(1))], **kw).defaults)
+
+
+class _FlatOptimizer(torch.optim.Optimizer):
+    """A torch.optim.Optimizer whose parameters, gradients and state live in flat buffers and whose step is one HIP launch.
+    Being an Optimizer, it plugs into the reference's loop unchanged: `StepLR(optimizer=...)` (train_SROIE.py:247) and
+    `scaler.step(optimizer)` / `scaler.unscale_` (pipeline/train_val_utils.py:274-278) operate on `param_groups` and on the
+    `.grad` views; `state_dict()` / `load_state_dict()` use torch's own optimizer checkpoint format (per-parameter state keyed by
+    the parameter's index in the caller's list), so optimizer checkpoints interchange with torch.optim.SGD / AdamW
+    (train_SROIE.py:377-416 saves them, resume loads them).
+    One deliberate difference: the step is element-wise over the whole flat range, so a parameter that received NO gradient in a
+    step still gets weight decay / momentum applied (torch skips `grad is None` parameters).  On this model that only concerns the
+    per-class nets of classifier_mode full in steps where no segment was predicted positive."""
+
+    _state_names: Tuple[str, ...] = ()
+
     def __init__(self, named, device, defaults: Dict):
+        named = list(named)
         self.group = FlatGroup(named, device)
-        self.param_groups = [dict(defaults, params=self.group.params)]      # same knobs the reference's loop writes (lr, weight_decay)
+        super().__init__([p for _, p in named], defaults)
         self.grad_scale = 1.0
         self.steps = 0
 
     def zero_grad(self, set_to_none: bool = False):
         self.group.zero_grad()
 
+    # ---- checkpoint format of torch.optim ---------------------------------------------------------------------------
+    def _flat_state(self) -> Dict[str, torch.Tensor]:
+        raise NotImplementedError
+
     def state_dict(self):
-        return {"steps": self.steps, "param_groups": [{k: v for k, v in g.items() if k != "params"} for g in self.param_groups],
-                "state": {k: v for k, v in self.__dict__.items() if isinstance(v, torch.Tensor)}}
+        g = self.group
+        pos = {n: i for i, n in enumerate(g.names)}
+        state = {}
+        if self.steps > 0:
+            for ref_i, n in enumerate(g.ref_names):
+                i = pos[n]
+                st = {k: g.view(flat, i).clone() for k, flat in self._flat_state().items()}
+                if "exp_avg" in st:
+                    st = {"step": torch.tensor(float(self.steps)), **st}
+                state[ref_i] = st
+        groups = [dict({k: v for k, v in pg.items() if k != "params"}, params=list(range(len(g.ref_names)))) for pg in self.param_groups]
+        return {"state": state, "param_groups": groups}
+
+    def load_state_dict(self, sd):
+        g = self.group
+        pos = {n: i for i, n in enumerate(g.names)}
+        for pg, src in zip(self.param_groups, sd["param_groups"]):
+            pg.update({k: v for k, v in src.items() if k != "params"})
+        flats = self._flat_state()
+        for f in flats.values():
+            f.zero_()
+        self.steps = 0
+        for ref_i, st in sd["state"].items():
+            i = pos[g.ref_names[int(ref_i)]]
+            for k, flat in flats.items():
+                if k in st and st[k] is not None:
+                    g.view(flat, i).copy_(st[k])
+            if "step" in st:
+                self.steps = max(self.steps, int(float(st["step"])))
+            elif flats:
+                self.steps = max(self.steps, 1)
 
 
 class FusedSGD(_FlatOptimizer):
     """torch.optim.SGD(momentum, weight_decay) semantics (dampening 0, no nesterov) over a flat buffer."""
 
     def __init__(self, named, device, lr, momentum=0.0, weight_decay=0.0):
-        super().__init__(named, device, dict(lr=lr, momentum=momentum, weight_decay=weight_decay))
+        super().__init__(named, device, _torch_defaults(torch.optim.SGD, lr=lr, momentum=momentum, weight_decay=weight_decay))
         self.mom = torch.zeros_like(self.group.pflat)
 
-    def step(self):
+    def _flat_state(self):
+        return {"momentum_buffer": self.mom}
+
+    @torch.no_grad()
+    def step(self, closure=None):
         g = self.param_groups[0]
         ops.sgd_step(self.group.pflat, self.group.gflat, self.mom, float(g["lr"]), float(g["momentum"]), float(g["weight_decay"]),
                      self.steps == 0, self.grad_scale)
@@ -129,11 +198,15 @@ class FusedAdamW(_FlatOptimizer):
     """torch.optim.AdamW semantics (decoupled weight decay, bias correction, amsgrad off)."""
 
     def __init__(self, named, device, lr, betas=(0.9, 0.999), eps=1e-8, weight_decay=0.01):
-        super().__init__(named, device, dict(lr=lr, betas=betas, eps=eps, weight_decay=weight_decay))
+        super().__init__(named, device, _torch_defaults(torch.optim.AdamW, lr=lr, betas=betas, eps=eps, weight_decay=weight_decay))
         self.m = torch.zeros_like(self.group.pflat)
         self.v = torch.zeros_like(self.group.pflat)
 
-    def step(self):
+    def _flat_state(self):
+        return {"exp_avg": self.m, "exp_avg_sq": self.v}
+
+    @torch.no_grad()
+    def step(self, closure=None):
         g = self.param_groups[0]
         self.steps += 1
         ops.adamw_step(self.group.pflat, self.group.gflat, self.m, self.v, float(g["lr"]), float(g["betas"][0]), float(g["betas"][1]),
@@ -155,19 +228,37 @@ def clip_grad_norm_(optimizers, max_norm: float, norm_scale: float = 1.0) -> flo
 
 
 class FlatReducer:
-    """Bucketed, overlapped gradient all-reduce over the flat buffers (replaces DistributedDataParallel's reducer)."""
+    """Bucketed, overlapped gradient all-reduce over the flat buffers (replaces DistributedDataParallel's reducer,
+    train_SROIE.py:206-210).
 
-    def __init__(self, optimizers, bucket_mb: float = 64.0, group=None):
+    Ordering contract (what keeps N ranks from ever pairing different buffers): bucket collectives are issued in ONE fixed
+    sequence `self.order`, bucket `order[k]` only after `order[0..k-1]` have been issued; whatever has not completed by the end
+    of backward is flushed by `finish()` in the same sequence.  Step 1 launches nothing during backward: it records the order
+    in which this rank's buckets completed; `finish()` then takes rank 0's record as the sequence for every rank (one
+    broadcast) -- from step 2 on the buckets fire during backward.  A rank whose graph skips a sub-module in some step simply
+    issues the affected bucket (and everything behind it) from `finish()`; the sequence is unchanged."""
+
+    def __init__(self, optimizers, bucket_mb: float = 32.0, group=None, sync_bn_group="new"):
         self.enabled = dist.is_available() and dist.is_initialized() and dist.get_world_size(group) > 1
         self.pg = group
         self.optimizers = optimizers
         self.world = dist.get_world_size(group) if self.enabled else 1
-        self.buckets = []          # (tensor view, pending count)
+        self.buckets = []          # [tensor view, member count, pending count]
         self.handles = []
         self.bucket_of = {}        # id(param) -> bucket index
         self._reported = set()     # sunk parameters already counted this step
+        self.order = None          # the agreed launch sequence (bucket indices); None until the first finish()
+        self._observed = []        # completion order seen in the current step
+        self._complete = set()
+        self._next = 0             # position in `order` of the next bucket to issue
         if not self.enabled:
             return
+        if sync_bn_group == "new":
+            # SyncBatchNorm statistics on their own communicator (collective call: every rank constructs its reducer)
+            ranks = list(range(dist.get_world_size())) if group is None else dist.get_process_group_ranks(group)
+            Fn.SyncCtx.group = dist.new_group(ranks=ranks)
+        elif sync_bn_group is not None:
+            Fn.SyncCtx.group = sync_bn_group
         Fn.GRAD_READY[0] = self._param_ready      # sunk gradients (written by the wgrad kernels) report here
         cap = int(bucket_mb * (1 << 20) / 4)
         for o in optimizers:
@@ -196,21 +287,40 @@ class FlatReducer:
             self._reported.add(id(p))
             self._ready(idx)
 
+    def _issue(self, idx):
+        self.handles.append(dist.all_reduce(self.buckets[idx][0], group=self.pg, async_op=True))
+
     def _ready(self, idx):
         b = self.buckets[idx]
         b[2] -= 1
-        if b[2] == 0:
-            self.handles.append(dist.all_reduce(b[0], group=self.pg, async_op=True))
+        if b[2] != 0:
+            return
+        self._observed.append(idx)
+        self._complete.add(idx)
+        if self.order is None:
+            return
+        while self._next < len(self.order) and self.order[self._next] in self._complete:
+            self._issue(self.order[self._next])
+            self._next += 1
 
     def finish(self):
-        """wait for every bucket (call after backward, before the optimizer steps); re-arms the counters"""
+        """issue what backward left over (in sequence), wait for every bucket (call after backward, before the optimizer
+        steps), re-arm the counters"""
         if not self.enabled:
             return
-        for b in self.buckets:
-            if b[2] != 0:          # a parameter got no gradient this step (zero rows): reduce what is there
-                self.handles.append(dist.all_reduce(b[0], group=self.pg, async_op=True))
-            b[2] = b[1]
+        if self.order is None:
+            seen = self._observed + [i for i in range(len(self.buckets)) if i not in self._complete]
+            t = torch.tensor(seen, dtype=torch.int64, device=self.buckets[0][0].device)
+            dist.broadcast(t, src=dist.get_global_rank(self.pg, 0) if self.pg is not None else 0, group=self.pg)
+            self.order = [int(i) for i in t.tolist()]
+            assert sorted(self.order) == list(range(len(self.buckets)))
+        while self._next < len(self.order):        # a parameter got no gradient this step (zero rows): reduce what is there
+            self._issue(self.order[self._next])
+            self._next += 1
         for h in self.handles:
             h.wait()
         self.handles = []
+        for b in self.buckets:
+            b[2] = b[1]
         self._reported.clear()
+        self._observed, self._complete, self._next = [], set(), 0
