@@ -96,6 +96,52 @@ int vbg_timer_create(void** event);
 int vbg_timer_destroy(void* event);
 int vbg_timer_elapsed_ms(void* start_event, void* stop_event, float* ms);
 
+/* ------------------------------------------------------------------------------------------
+ * Plane GEMM: the same fp32-grade NT product as vbg_gemm form 3, from operands that were split into bf16 planes ONCE
+ * (by vbg_split_planes / vbg_split_planes_t or by a producing epilogue) instead of inside every block of every product.
+ * A plane operand is [3][rows][ld] bf16 (hi, mid, lo: x = hi + mid + lo exactly), K-contiguous, ld a multiple of 8 and
+ * >= K, K a multiple of 32 (the split kernels zero-pad).  C[M,N] (+)= alpha * A[M,K] * B[N,K]^T (+ bias[N]).
+ * Replaces: torch.nn.functional.linear inside transformers BertModel (model/BERTgrid_generator.py:134) and its autograd
+ * products (dgrad with the transposed weight planes, wgrad with transposed activation planes), the MLP heads
+ * (model/field_type_classification_head.py:78-110).
+ * ------------------------------------------------------------------------------------------ */
+#define VBG_PLANE_MAX_GROUPS 4
+typedef struct vbg_plane_group {                                  /* one problem of a grouped plane GEMM launch */
+    const unsigned short* A; const unsigned short* B; float* C;
+    long long a_plane, lda, b_plane, ldb, ldc;
+    int M, N;
+    int tiles_m, tiles_n;                                         /* filled by the library */
+} vbg_plane_group;
+typedef struct vbg_plane_gemm_desc {
+    int M, N, K;
+    const unsigned short* A; long long a_plane; long long lda;   /* plane stride / row stride in elements */
+    const unsigned short* B; long long b_plane; long long ldb;
+    float* C; long long ldc; float* C2; const float* bias;       /* C may be NULL when only Cp is wanted   */
+    /* optional: the stored value (after bias / ReLU / GELU) split into planes [3][M][ldp] -- the A operand of the next product */
+    unsigned short* Cp; long long c_plane; long long ldp;
+    int epi; float alpha; int accumulate;                         /* C += result (atomics only if splitk > 1) */
+    int splitk;                                                   /* >1 requires accumulate */
+    int tile;                                                     /* 0 auto; 256128 / 128128 / 128129 / 128130 / 128064 / 64064 */
+    /* trans != 0 ("TN"): C[M,N] (+)= alpha * sum_k A[k,M] * B[k,N] -- the reduction index is the operands' ROW index: A planes
+       [3][K][lda], B planes [3][K][ldb], lda / ldb multiples of 32 (zero padded), K any length.  The weight gradient dW = dY^T X
+       straight from the planes of dY and X that the data-gradient / forward products already use (LDS transpose reads). */
+    int trans;
+    /* ngroups > 0: a grouped launch -- grp[0..ngroups) are independent problems of ONE reduction length K (and one `trans`,
+       `accumulate`, `alpha`) that share the grid, so their partial rounds of output tiles fill the chip together (the four weight
+       gradients of an encoder layer: 432 tiles in 2 rounds instead of 4 launches of <= 144 tiles on 256 CUs).  No bias / epilogue. */
+    int ngroups;
+    vbg_plane_group grp[VBG_PLANE_MAX_GROUPS];
+} vbg_plane_gemm_desc;
+int vbg_plane_gemm(const vbg_plane_gemm_desc* desc, void* stream);
+int vbg_plane_gemm_timed(const vbg_plane_gemm_desc* desc, void* stream, void* start_event, void* stop_event);
+/* x [rows][cols] fp32 (row stride ldx) -> planes [3][rows][ldp] (plane stride `plane` elements), columns cols..ldp-1 zero;
+ * relu != 0: the pieces of max(x, 0) */
+int vbg_split_planes(const float* x, long long ldx, int rows, int cols, unsigned short* out, int ldp, long long plane, int relu,
+                     void* stream);
+/* x [rows][cols] fp32 -> TRANSPOSED planes [3][cols][ldp], ldp >= rows (multiple of 32), entries rows..ldp-1 zero */
+int vbg_split_planes_t(const float* x, long long ldx, int rows, int cols, unsigned short* out, int ldp, long long plane,
+                       void* stream);
+
 /* column sums: out[n] (+)= sum_m x[m*ld + n]   (bias gradients) */
 int vbg_colsum(const float* x, long long ld, int M, int N, float* out, int accumulate, void* stream);
 

@@ -1,0 +1,570 @@
+// Plane GEMM: fp32-grade NT products from operands that are ALREADY split into bf16 planes in HBM.
+//
+// The split form of gemm.hip (PREC 3) splits every fp32 operand element into three bf16 pieces on its way into LDS -- per block,
+// per tile it re-reads, ~5.5 VALU per element sharing the issue port with the MFMAs (matrix pipe busy 26-37 % in the BERT GEMMs,
+// profiles/r01_gemm_mfma_util.txt).  Here the split happens ONCE per tensor (vbg_split_planes / vbg_split_planes_t, or the
+// producing kernel's epilogue): an operand is three bf16 planes [3][rows][ld] (hi, mid, lo: x = hi + mid + lo exactly, 8 + 8 + 8
+// significant bits by truncation), K-contiguous, ld a multiple of 32 (zero padded).  The k-loop then has no VALU work at all:
+//   * global -> LDS by `buffer_load_dwordx4 ... lds` (LDS-DMA, 1 KiB = 16 rows x 64 B of one plane per wave instruction; rows past
+//     the operand carry an out-of-range offset and land as zeros), the next k-tile in flight behind the current tile's MFMAs;
+//   * LDS image [plane][row][32 k] bf16 with the 16-byte chunk index XOR-swizzled by (row >> 2) & 3 -- applied on the SOURCE
+//     address of the DMA, the image itself is lane-linear -- so every ds_read_b128 fragment read is conflict free;
+//   * per 16-deep k-step and 32x32 accumulator the six piece products of order <= 2^-16, smallest first:
+//     (lo,hi) (hi,lo) (mid,mid) (mid,hi) (hi,mid) (hi,hi) as v_mfma_f32_32x32x16_bf16, fp32 accumulation.
+// Arithmetic is identical to gemm.hip PREC 3 (same pieces, same products, same order), so results agree bit for bit up to the
+// k-tile summation order.  Reference products replaced: every nn.Linear of transformers BertModel (model/BERTgrid_generator.py:134)
+// forward / dgrad / wgrad, the 1x1 convolutions of model/ResNetFPN_ViBERTgrid.py, the heads' MLPs.
+#include "vbg_common.h"
+#include <type_traits>
+#include <hip/hip_ext.h>
+#include "../../include/vbg.h"
+
+namespace vbg {
+
+typedef unsigned pg_u32x4 __attribute__((ext_vector_type(4)));
+typedef __bf16 pg_bf16x8 __attribute__((ext_vector_type(8)));
+constexpr unsigned PG_INVALID = 0x80000000u;
+
+__device__ __forceinline__ __amdgpu_buffer_rsrc_t pg_rsrc(const void* base) {
+    return __builtin_amdgcn_make_buffer_rsrc(const_cast<void*>(base), 0, (int)0x80000000u, 0x00020000);
+}
+
+typedef short pg_v4s __attribute__((ext_vector_type(4)));
+typedef __attribute__((address_space(3))) pg_v4s* pg_lds_v4s;
+
+// TRANS = false: C[M,N] = A[M,K] B[N,K]^T, both operands K-contiguous ("NT").
+// TRANS = true : C[M,N] = sum_k A[k,M] B[k,N] ("TN": the weight gradient dW = dY^T X straight from the UNtransposed planes of dY
+//   [tokens][M] and X [tokens][N]; the reduction index is the operands' ROW index).  The LDS image of a k-tile is then [32 k][128
+//   cols] per plane (256-byte rows, 64-byte chunks XOR-swizzled by k & 3) and a fragment -- 8 consecutive k of one column -- is
+//   two ds_read_b64_tr_b16: each 16-lane group reads a [4 k][16 col] block, lane i supplying the address of (k = i / 4, cols
+//   4 (i % 4)..+3) and receiving the 4 k of column i (lane semantics verified on the hardware, tools/probes/tr_probe.hip).
+//   Rows past the reduction length fall off the per-plane buffer descriptors and read 0.
+template <int BM, int BN, int WGM, int WGN, int NST, bool TRANS>
+__global__ __launch_bounds__(WGM * WGN * 64) void plane_gemm_kernel(const vbg_plane_gemm_desc p) {
+    static_assert(!TRANS || (BM == 128 && BN == 128), "TN: 128-column operand tiles (256-byte LDS rows)");
+    constexpr int NW = WGM * WGN, NT = NW * 64;
+    constexpr int BK = 32;
+    constexpr int WM = BM / WGM, WN = BN / WGN, TM = WM / 32, TN = WN / 32;
+    constexpr int PA = BM * 64, PB = BN * 64;                  // bytes of one plane of a stage (64 B per row)
+    constexpr int STAGE = 3 * (PA + PB);
+    constexpr int NIA = 3 * BM / 16 / NW, NIB = 3 * BN / 16 / NW;      // DMA instructions per wave and stage
+    static_assert((3 * BM / 16) % NW == 0 && (3 * BN / 16) % NW == 0, "DMA units must divide over the waves");
+    static_assert(NST == 2 || NST == 3, "two or three LDS stages");
+    constexpr int CTS = BN + 4;
+    constexpr int SMEM = (NST * STAGE > BM * CTS * 4) ? NST * STAGE : BM * CTS * 4;
+    __shared__ __attribute__((aligned(1024))) unsigned char smem[SMEM];          // (the ONE LDS object of the kernel)
+
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    // problem of this block: the descriptor's own, or (grouped launch: several independent products of one reduction length in
+    // one grid, so that their partial rounds of tiles share the chip) entry g of p.grp
+    const unsigned short* pA = p.A;
+    const unsigned short* pB = p.B;
+    float* pC = p.C;
+    int M = p.M, N = p.N;
+    long long a_plane = p.a_plane, b_plane = p.b_plane, lda = p.lda, ldb = p.ldb, ldc_ = p.ldc;
+    // ---- XCD-aware block -> tile map (same scheme as gemm.hip): workgroup b runs on XCD b % 8; XCD k owns the k-th contiguous
+    //      eighth of the tile sequence, and the sequence walks each problem's tile grid in bands of 8 row tiles ------------------
+    constexpr unsigned XCDS = 8, XCD_GROUP = 8;
+    const unsigned lin = blockIdx.x + gridDim.x * (blockIdx.y + gridDim.y * blockIdx.z);
+    const unsigned total = gridDim.x * gridDim.y * gridDim.z;
+    const unsigned xcd = lin % XCDS, local = lin / XCDS;
+    const unsigned per_xcd = (total + XCDS - 1) / XCDS, tall = (total % XCDS) ? (total % XCDS) : XCDS;
+    const unsigned pid = xcd < tall ? xcd * per_xcd + local : tall * per_xcd + (xcd - tall) * (per_xcd - 1) + local;
+    unsigned gx = gridDim.x, gy = gridDim.y;
+    const unsigned slice = gridDim.x * gridDim.y;
+    const int split = (int)(pid / slice);
+    unsigned rem = pid - (unsigned)split * slice;
+    if (p.ngroups > 0) {
+        int g = 0;
+        while (g + 1 < p.ngroups && rem >= (unsigned)(p.grp[g].tiles_m * p.grp[g].tiles_n)) { rem -= p.grp[g].tiles_m * p.grp[g].tiles_n; ++g; }
+        pA = p.grp[g].A; pB = p.grp[g].B; pC = p.grp[g].C;
+        M = p.grp[g].M; N = p.grp[g].N;
+        a_plane = p.grp[g].a_plane; b_plane = p.grp[g].b_plane; lda = p.grp[g].lda; ldb = p.grp[g].ldb; ldc_ = p.grp[g].ldc;
+        gx = p.grp[g].tiles_m; gy = p.grp[g].tiles_n;
+    }
+    const unsigned band = XCD_GROUP * gy, bid = rem / band, first = bid * XCD_GROUP;
+    const unsigned bm = min(gx - first, XCD_GROUP), inb = rem - bid * band;
+    const unsigned tile_m = first + inb % bm, tile_n = inb / bm;
+    const int m0 = (int)tile_m * BM, n0 = (int)tile_n * BN;
+    if (m0 >= M || n0 >= N) return;
+    const int nkt = (p.K + BK - 1) / BK;
+    const int per = (nkt + p.splitk - 1) / p.splitk;
+    const int kt0 = split * per, kt1 = min(nkt, kt0 + per);
+    if (kt0 >= kt1) return;
+    const int ntiles = kt1 - kt0;
+
+    // ---- DMA addressing: lane l of a unit (plane q, 16-row block rb) fills LDS bytes [16 l, 16 l + 16) of the unit's 1 KiB =
+    //      row rb*16 + l/4, physical chunk l%4, from logical chunk (l%4) ^ ((row >> 2) & 3) of that row ------------------------
+    unsigned avo[NIA], bvo[NIB];
+    int alds[NIA], blds[NIB];
+    const unsigned short* abase;
+    const unsigned short* bbase;
+    long long a_rem = 0, b_rem = 0;                 // TRANS: bytes left in a plane behind the descriptor base (rows >= K read 0)
+    if constexpr (!TRANS) {
+        const int lrow = lane >> 2;
+        const int lchunk = (lane & 3) ^ ((lane >> 4) & 3);
+#pragma unroll
+        for (int i = 0; i < NIA; ++i) {
+            const int u = wave + NW * i, q = u / (BM / 16), rb = u % (BM / 16);
+            const int r = rb * 16 + lrow;
+            avo[i] = (m0 + r < M) ? (unsigned)(((long long)q * a_plane + (long long)r * lda) * 2 + lchunk * 16) : PG_INVALID;
+            alds[i] = __builtin_amdgcn_readfirstlane(q * PA + rb * 1024);
+        }
+#pragma unroll
+        for (int i = 0; i < NIB; ++i) {
+            const int u = wave + NW * i, q = u / (BN / 16), rb = u % (BN / 16);
+            const int r = rb * 16 + lrow;
+            bvo[i] = (n0 + r < N) ? (unsigned)(((long long)q * b_plane + (long long)r * ldb) * 2 + lchunk * 16) : PG_INVALID;
+            blds[i] = __builtin_amdgcn_readfirstlane(3 * PA + q * PB + rb * 1024);
+        }
+        abase = pA + (long long)m0 * lda + (long long)kt0 * BK;
+        bbase = pB + (long long)n0 * ldb + (long long)kt0 * BK;
+    } else {
+        // unit (plane q, 4-row block rb): lane l fills LDS bytes [16 l, +16) of the unit's 1 KiB = k-row rb*4 + l/16, physical
+        // 16-byte piece l%16, from logical 64-byte chunk (piece / 4) ^ (row & 3)
+        const int lrow = lane >> 4, piece = lane & 15;
+        const int lcol = ((((piece >> 2) ^ (lrow & 3)) << 2) + (piece & 3)) * 8;          // source column (elements)
+        const int mpad = (M + 31) / 32 * 32, npad = (N + 31) / 32 * 32;                   // (plane rows are zero padded to 32)
+#pragma unroll
+        for (int i = 0; i < NIA; ++i) {
+            const int u = wave + NW * i, rb = u % 8;
+            avo[i] = (m0 + lcol < mpad) ? (unsigned)(((long long)(rb * 4 + lrow) * lda + lcol) * 2) : PG_INVALID;
+            alds[i] = __builtin_amdgcn_readfirstlane((u / 8) * PA + rb * 1024);
+        }
+#pragma unroll
+        for (int i = 0; i < NIB; ++i) {
+            const int u = wave + NW * i, rb = u % 8;
+            bvo[i] = (n0 + lcol < npad) ? (unsigned)(((long long)(rb * 4 + lrow) * ldb + lcol) * 2) : PG_INVALID;
+            blds[i] = __builtin_amdgcn_readfirstlane(3 * PA + (u / 8) * PB + rb * 1024);
+        }
+        abase = pA + (long long)kt0 * BK * lda + m0;
+        bbase = pB + (long long)kt0 * BK * ldb + n0;
+        a_rem = ((long long)(p.K - kt0 * BK) * lda - m0) * 2;
+        b_rem = ((long long)(p.K - kt0 * BK) * ldb - n0) * 2;
+    }
+    typedef __attribute__((address_space(3))) void* lds_ptr;
+    // `inv` = PG_INVALID for a tile past the block's range: every lane's offset falls outside the descriptor, the DMA writes zeros
+    // into a stage nobody reads and moves no memory -- the loop body stays branch free (one scheduling region per half iteration)
+    auto issue = [&](int stage, unsigned inv) {
+        unsigned char* sb = smem + stage * STAGE;
+        if constexpr (!TRANS) {
+            const __amdgpu_buffer_rsrc_t ra = pg_rsrc(abase), rb = pg_rsrc(bbase);
+#pragma unroll
+            for (int i = 0; i < NIA; ++i)
+                __builtin_amdgcn_raw_ptr_buffer_load_lds(ra, (lds_ptr)(sb + alds[i]), 16, (int)(avo[i] | inv), 0, 0, 0);
+#pragma unroll
+            for (int i = 0; i < NIB; ++i)
+                __builtin_amdgcn_raw_ptr_buffer_load_lds(rb, (lds_ptr)(sb + blds[i]), 16, (int)(bvo[i] | inv), 0, 0, 0);
+            abase += BK;
+            bbase += BK;
+        } else {
+            // one descriptor per plane, ending behind the last row of the reduction (NIA == NIB == 3: unit i of a wave = plane i)
+            static_assert(NIA == 3 && NIB == 3, "TN: 8 waves, one plane per DMA instruction of a wave");
+            const int na = (int)(a_rem < 0 ? 0 : (a_rem > 0x7fffffffll ? 0x7fffffffll : a_rem));
+            const int nb = (int)(b_rem < 0 ? 0 : (b_rem > 0x7fffffffll ? 0x7fffffffll : b_rem));
+#pragma unroll
+            for (int i = 0; i < 3; ++i) {
+                const __amdgpu_buffer_rsrc_t ra = __builtin_amdgcn_make_buffer_rsrc(const_cast<unsigned short*>(abase + i * a_plane), 0, na, 0x00020000);
+                __builtin_amdgcn_raw_ptr_buffer_load_lds(ra, (lds_ptr)(sb + alds[i]), 16, (int)(avo[i] | inv), 0, 0, 0);
+            }
+#pragma unroll
+            for (int i = 0; i < 3; ++i) {
+                const __amdgpu_buffer_rsrc_t rb = __builtin_amdgcn_make_buffer_rsrc(const_cast<unsigned short*>(bbase + i * b_plane), 0, nb, 0x00020000);
+                __builtin_amdgcn_raw_ptr_buffer_load_lds(rb, (lds_ptr)(sb + blds[i]), 16, (int)(bvo[i] | inv), 0, 0, 0);
+            }
+            abase += (long long)BK * lda;
+            bbase += (long long)BK * ldb;
+            a_rem -= (long long)BK * lda * 2;
+            b_rem -= (long long)BK * ldb * 2;
+        }
+    };
+
+    // ---- fragments ---------------------------------------------------------------------------------------------------
+    const int wm = wave / WGN, wn = wave % WGN;
+    const int lr = lane & 31, lk = lane >> 5;
+    const int sw = (lr >> 2) & 3;
+    // byte offset of lane's 16-byte fragment of k-step s inside a 32-row fragment block: row lr, logical chunk 2 s + lk
+    const int fo0 = TRANS ? 0 : lr * 64 + (((0 + lk) ^ sw) << 4), fo1 = TRANS ? 4096 : lr * 64 + (((2 + lk) ^ sw) << 4);
+    // TRANS: byte offset of this lane's tr-read address inside a plane tile for fragment block i (32 columns), k-step 0, half 0
+    const int i16 = lane & 15, tg = (lane >> 4) & 1;
+    int ta[TM], tb[TN];
+#pragma unroll
+    for (int i = 0; i < TM; ++i) ta[i] = (8 * lk + (i16 >> 2)) * 256 + (((wm * TM + i) ^ (i16 >> 2)) << 6) + (16 * tg + 4 * (i16 & 3)) * 2;
+#pragma unroll
+    for (int j = 0; j < TN; ++j) tb[j] = (8 * lk + (i16 >> 2)) * 256 + (((wn * TN + j) ^ (i16 >> 2)) << 6) + (16 * tg + 4 * (i16 & 3)) * 2;
+    f32x16 acc[TM][TN];
+#pragma unroll
+    for (int i = 0; i < TM; ++i)
+#pragma unroll
+        for (int j = 0; j < TN; ++j)
+#pragma unroll
+            for (int r = 0; r < 16; ++r) acc[i][j][r] = 0.f;
+
+    pg_u32x4 fa0[3][TM], fb0[3][TN], fa1[3][TM], fb1[3][TN];       // fragment sets of k-step 0 / 1 of a tile
+    auto read_frags = [&](int stage, int fo, pg_u32x4 (&fa)[3][TM], pg_u32x4 (&fb)[3][TN]) {
+        if constexpr (TRANS) {
+            typedef __attribute__((address_space(3))) unsigned char* lds_bytes;
+            lds_bytes as = (lds_bytes)(smem + stage * STAGE + fo), bs = (lds_bytes)(smem + stage * STAGE + 3 * PA + fo);
+#pragma unroll
+            for (int q = 0; q < 3; ++q) {
+#pragma unroll
+                for (int i = 0; i < TM; ++i) {
+                    const pg_v4s lo = __builtin_amdgcn_ds_read_tr16_b64_v4i16((pg_lds_v4s)(as + q * PA + ta[i]));
+                    const pg_v4s hi = __builtin_amdgcn_ds_read_tr16_b64_v4i16((pg_lds_v4s)(as + q * PA + ta[i] + 1024));
+                    const uint2 l2 = __builtin_bit_cast(uint2, lo), h2 = __builtin_bit_cast(uint2, hi);
+                    fa[q][i] = pg_u32x4{l2.x, l2.y, h2.x, h2.y};
+                }
+#pragma unroll
+                for (int j = 0; j < TN; ++j) {
+                    const pg_v4s lo = __builtin_amdgcn_ds_read_tr16_b64_v4i16((pg_lds_v4s)(bs + q * PB + tb[j]));
+                    const pg_v4s hi = __builtin_amdgcn_ds_read_tr16_b64_v4i16((pg_lds_v4s)(bs + q * PB + tb[j] + 1024));
+                    const uint2 l2 = __builtin_bit_cast(uint2, lo), h2 = __builtin_bit_cast(uint2, hi);
+                    fb[q][j] = pg_u32x4{l2.x, l2.y, h2.x, h2.y};
+                }
+            }
+            return;
+        }
+        const unsigned char* as = smem + stage * STAGE + (wm * WM) * 64 + fo;
+        const unsigned char* bs = smem + stage * STAGE + 3 * PA + (wn * WN) * 64 + fo;
+#pragma unroll
+        for (int q = 0; q < 3; ++q) {
+#pragma unroll
+            for (int i = 0; i < TM; ++i) fa[q][i] = *reinterpret_cast<const pg_u32x4*>(as + q * PA + i * 32 * 64);
+#pragma unroll
+            for (int j = 0; j < TN; ++j) fb[q][j] = *reinterpret_cast<const pg_u32x4*>(bs + q * PB + j * 32 * 64);
+        }
+    };
+    // piece products, smallest first: (lo,hi) (hi,lo) (mid,mid) (mid,hi) (hi,mid) (hi,hi)
+    auto mma = [&](const pg_u32x4 (&fa)[3][TM], const pg_u32x4 (&fb)[3][TN]) {
+        constexpr int qa[6] = {2, 0, 1, 1, 0, 0}, qb[6] = {0, 2, 1, 0, 1, 0};
+#pragma unroll
+        for (int t = 0; t < 6; ++t)
+#pragma unroll
+            for (int i = 0; i < TM; ++i)
+#pragma unroll
+                for (int j = 0; j < TN; ++j)
+                    acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(__builtin_bit_cast(pg_bf16x8, fa[qa[t]][i]),
+                                                                        __builtin_bit_cast(pg_bf16x8, fb[qb[t]][j]), acc[i][j], 0, 0, 0);
+    };
+
+    // ---- k loop ---------------------------------------------------------------------------------------------------------
+    // Fragments are read one k-step ahead of the MFMAs that use them (set 1 of tile t behind the products of set 0, set 0 of tile
+    // t+1 behind the products of set 1), so ds_read latency never sits between two MFMA groups.
+    // NST = 3: tile t+2 travels while tile t is multiplied; tile t+1 landed an iteration ago and is published by the ONE barrier
+    // in the middle of iteration t (counted vmcnt: the DMA of tile t+2 stays in flight across it), after which set 0 of tile t+1
+    // is read -- no bubble after the barrier.  NST = 2 (the 8-wave tile, 2 waves per SIMD cover each other): tile t+1 travels
+    // during tile t, barrier at the end of the iteration.
+    constexpr int NIW = NIA + NIB;
+    constexpr int NMMA = 6 * TM * TN, NRD = (TRANS ? 6 : 3) * (TM + TN);
+    issue(0, 0u);
+    if constexpr (NST == 3) {
+        issue(1, ntiles > 1 ? 0u : PG_INVALID);
+        asm volatile("s_waitcnt vmcnt(%0)" ::"n"(NIW) : "memory");
+    } else {
+        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+    }
+    __builtin_amdgcn_s_barrier();
+    auto settle0 = [&]() {
+#pragma unroll
+        for (int q = 0; q < 3; ++q) {
+#pragma unroll
+            for (int i = 0; i < TM; ++i) asm volatile("" ::"v"(fa0[q][i]));
+#pragma unroll
+            for (int j = 0; j < TN; ++j) asm volatile("" ::"v"(fb0[q][j]));
+        }
+    };
+    read_frags(0, fo0, fa0, fb0);
+    settle0();
+    int cur = 0;                                   // stage of tile t
+    for (int t = 0; t < ntiles; ++t) {
+        const int nxt = (cur + 1 == NST) ? 0 : cur + 1;
+        const int nn = (nxt + 1 == NST) ? 0 : nxt + 1;
+        // ---- first half: products of set 0; set 1 of this tile is read and the DMA of tile t+NST-1 is issued in their gaps ----
+        __builtin_amdgcn_sched_barrier(0);
+        issue(NST == 3 ? nn : nxt, t + NST - 1 < ntiles ? 0u : PG_INVALID);
+        read_frags(cur, fo1, fa1, fb1);
+        mma(fa0, fb0);
+        // (a 32x32x16 bf16 MFMA holds the matrix pipe for 32 cycles = ~8 issue slots: one LDS read and one DMA per gap ride free)
+#pragma unroll
+        for (int g = 0; g < NMMA; ++g) {
+            __builtin_amdgcn_sched_group_barrier(0x008, 1, 0);
+            if (g < NRD) __builtin_amdgcn_sched_group_barrier(0x100, 1, 0);
+            if (g < NIW) { __builtin_amdgcn_sched_group_barrier(0x004, 2, 0); __builtin_amdgcn_sched_group_barrier(0x020, 1, 0); }
+        }
+        __builtin_amdgcn_sched_barrier(0);
+        if constexpr (NST == 3) {
+            // tile t+1 must have landed (this wave's share; the DMA just issued stays in flight), and this wave's reads of the stage
+            // the NEXT iteration's DMA overwrites must be done, before anybody passes the barrier
+            asm volatile("s_waitcnt vmcnt(%0) lgkmcnt(0)" ::"n"(NIW) : "memory");
+            __builtin_amdgcn_s_barrier();
+            __builtin_amdgcn_sched_barrier(0);
+            read_frags(nxt, fo0, fa0, fb0);          // (unconditional: past the last tile it reads stale LDS that nobody uses)
+            mma(fa1, fb1);
+#pragma unroll
+            for (int g = 0; g < NMMA; ++g) {
+                __builtin_amdgcn_sched_group_barrier(0x008, 1, 0);
+                if (g < NRD) __builtin_amdgcn_sched_group_barrier(0x100, 1, 0);
+            }
+        } else {
+            mma(fa1, fb1);
+            __builtin_amdgcn_sched_barrier(0);
+            asm volatile("s_waitcnt vmcnt(0) lgkmcnt(0)" ::: "memory");
+            __builtin_amdgcn_s_barrier();
+            __builtin_amdgcn_sched_barrier(0);
+            read_frags(nxt, fo0, fa0, fb0);
+        }
+        __builtin_amdgcn_sched_barrier(0);
+        // (compiler bookkeeping: a use of the freshly read set-0 registers at the END of the iteration, behind the MFMAs, makes
+        // hipcc place its lgkmcnt wait for them here -- where the data arrived long ago -- instead of a conservative lgkmcnt(0)
+        // in front of the next iteration's first MFMA, which would also wait for the set-1 reads issued just before it)
+        settle0();
+        cur = nxt;
+    }
+    __syncthreads();                               // every wave is done with the operand stages: the output tile is staged there
+
+    // ---- epilogue: staged through LDS, float4 row pieces ------------------------------------------------------------------
+    const float* bias = p.bias;
+    const bool add_bias = (bias != nullptr) && (split == 0);
+    const int accumulate = p.accumulate, epi = p.epi;
+    const bool atomic = accumulate && p.splitk > 1;
+    const float alpha = p.alpha;
+    const long long ldc = ldc_;
+    float* const C = pC;
+    float* const C2 = p.C2;
+    float* const Ct = reinterpret_cast<float*>(smem);
+#pragma unroll
+    for (int j = 0; j < TN; ++j)
+#pragma unroll
+        for (int i = 0; i < TM; ++i)
+#pragma unroll
+            for (int r = 0; r < 16; ++r)
+                Ct[(wm * WM + i * 32 + (r & 3) + 8 * (r >> 2) + 4 * lk) * CTS + wn * WN + j * 32 + lr] = acc[i][j][r] * alpha;
+    __syncthreads();
+    constexpr int QN = BN / 4;
+    // optional bf16 planes of the stored value (the A operand of the next product): [3][M][ldp], K-contiguous = along n here
+    unsigned short* const Cp = p.Cp;
+#pragma unroll
+    for (int q = 0; q < BM * QN / NT; ++q) {
+        const int idx = tid + q * NT;
+        const int row = idx / QN, c = (idx % QN) * 4;
+        const int gm = m0 + row, gn = n0 + c;
+        if (gm >= M || gn >= N) continue;
+        float4 v = *reinterpret_cast<const float4*>(&Ct[row * CTS + c]);
+        if (add_bias) {
+            const float4 b = *reinterpret_cast<const float4*>(bias + gn);
+            v.x += b.x; v.y += b.y; v.z += b.z; v.w += b.w;
+        }
+        float* cp = C + (long long)gm * ldc + gn;
+        if (atomic) {
+            unsafeAtomicAdd(cp + 0, v.x); unsafeAtomicAdd(cp + 1, v.y); unsafeAtomicAdd(cp + 2, v.z); unsafeAtomicAdd(cp + 3, v.w);
+            continue;
+        }
+        if (accumulate) {
+            const float4 o = *reinterpret_cast<const float4*>(cp);
+            v.x += o.x; v.y += o.y; v.z += o.z; v.w += o.w;
+        }
+        if (epi == VBG_EPI_RELU) v = make_float4(fmaxf(v.x, 0.f), fmaxf(v.y, 0.f), fmaxf(v.z, 0.f), fmaxf(v.w, 0.f));
+        if (C) *reinterpret_cast<float4*>(cp) = v;
+        if (epi == VBG_EPI_GELU_DUAL) {
+            v = make_float4(gelu_erf(v.x), gelu_erf(v.y), gelu_erf(v.z), gelu_erf(v.w));
+            if (C2) *reinterpret_cast<float4*>(C2 + (long long)gm * ldc + gn) = v;
+        }
+        if (Cp) {
+            const float e[4] = {v.x, v.y, v.z, v.w};
+            unsigned short h[4], m[4], l[4];
+#pragma unroll
+            for (int t = 0; t < 4; ++t) {
+                const unsigned u = __float_as_uint(e[t]);
+                const float r1 = e[t] - __uint_as_float(u & 0xffff0000u);
+                const unsigned u1 = __float_as_uint(r1);
+                const float r2 = r1 - __uint_as_float(u1 & 0xffff0000u);
+                h[t] = (unsigned short)(u >> 16); m[t] = (unsigned short)(u1 >> 16); l[t] = (unsigned short)(__float_as_uint(r2) >> 16);
+            }
+            unsigned short* o = Cp + (long long)gm * p.ldp + gn;
+            *reinterpret_cast<uint2*>(o) = make_uint2(h[0] | ((unsigned)h[1] << 16), h[2] | ((unsigned)h[3] << 16));
+            *reinterpret_cast<uint2*>(o + p.c_plane) = make_uint2(m[0] | ((unsigned)m[1] << 16), m[2] | ((unsigned)m[3] << 16));
+            *reinterpret_cast<uint2*>(o + 2 * p.c_plane) = make_uint2(l[0] | ((unsigned)l[1] << 16), l[2] | ((unsigned)l[3] << 16));
+        }
+    }
+}
+
+// exact three-way split of one float: top 16 bits, top 16 bits of the (exact) remainder, the (exact, <= 8 bit) rest
+__device__ __forceinline__ void pg_split3(float x, unsigned short& h, unsigned short& m, unsigned short& l) {
+    const unsigned u = __float_as_uint(x);
+    const float r1 = x - __uint_as_float(u & 0xffff0000u);
+    const unsigned u1 = __float_as_uint(r1);
+    const float r2 = r1 - __uint_as_float(u1 & 0xffff0000u);
+    h = (unsigned short)(u >> 16); m = (unsigned short)(u1 >> 16); l = (unsigned short)(__float_as_uint(r2) >> 16);
+}
+
+// x [rows][cols] fp32 (row stride ldx) -> planes [3][rows][ldp] bf16, columns cols..ldp-1 zero.  One thread = 8 columns.
+__global__ __launch_bounds__(256) void split_planes_kernel(const float* __restrict__ x, long long ldx, int rows, int cols,
+                                                            unsigned short* __restrict__ out, int ldp, long long plane, int relu) {
+    const int cpr = ldp / 8;
+    const long long n = (long long)rows * cpr;
+    const long long stride = (long long)gridDim.x * blockDim.x;
+    for (long long i = (long long)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += stride) {
+        const int r = (int)(i / cpr), c = (int)(i % cpr) * 8;
+        float e[8];
+        if (c + 8 <= cols && ((ldx & 3) == 0) && ((((uintptr_t)x) & 15) == 0)) {
+            const float4 a = *reinterpret_cast<const float4*>(x + (long long)r * ldx + c);
+            const float4 b = *reinterpret_cast<const float4*>(x + (long long)r * ldx + c + 4);
+            e[0] = a.x; e[1] = a.y; e[2] = a.z; e[3] = a.w; e[4] = b.x; e[5] = b.y; e[6] = b.z; e[7] = b.w;
+        } else {
+#pragma unroll
+            for (int t = 0; t < 8; ++t) e[t] = (c + t < cols) ? x[(long long)r * ldx + c + t] : 0.f;
+        }
+        unsigned short h[8], m[8], l[8];
+#pragma unroll
+        for (int t = 0; t < 8; ++t) pg_split3(relu ? fmaxf(e[t], 0.f) : e[t], h[t], m[t], l[t]);
+        unsigned short* o = out + (long long)r * ldp + c;
+        auto pack = [](const unsigned short* s) {
+            return make_uint4(s[0] | ((unsigned)s[1] << 16), s[2] | ((unsigned)s[3] << 16), s[4] | ((unsigned)s[5] << 16), s[6] | ((unsigned)s[7] << 16));
+        };
+        *reinterpret_cast<uint4*>(o) = pack(h);
+        *reinterpret_cast<uint4*>(o + plane) = pack(m);
+        *reinterpret_cast<uint4*>(o + 2 * plane) = pack(l);
+    }
+}
+
+// x [rows][cols] fp32 -> TRANSPOSED planes [3][cols][ldp] bf16 with ldp >= rows (multiple of 32), entries rows..ldp-1 zero:
+// out[q][c][r] = piece_q(x[r][c]).  64 x 64 tiles through LDS.
+__global__ __launch_bounds__(256) void split_planes_t_kernel(const float* __restrict__ x, long long ldx, int rows, int cols,
+                                                              unsigned short* __restrict__ out, int ldp, long long plane) {
+    __shared__ float t[64][65];
+    const int r0 = blockIdx.x * 64, c0 = blockIdx.y * 64;
+    const int tid = threadIdx.x;
+    const bool vec = ((ldx & 3) == 0) && ((((uintptr_t)x) & 15) == 0);
+#pragma unroll
+    for (int i = 0; i < 4; ++i) {
+        const int f = tid + i * 256, r = f / 16, c = (f % 16) * 4;
+        float4 v = make_float4(0.f, 0.f, 0.f, 0.f);
+        if (r0 + r < rows) {
+            const float* src = x + (long long)(r0 + r) * ldx + c0 + c;
+            if (vec && c0 + c + 4 <= cols) v = *reinterpret_cast<const float4*>(src);
+            else {
+                if (c0 + c + 0 < cols) v.x = src[0];
+                if (c0 + c + 1 < cols) v.y = src[1];
+                if (c0 + c + 2 < cols) v.z = src[2];
+                if (c0 + c + 3 < cols) v.w = src[3];
+            }
+        }
+        t[r][c] = v.x; t[r][c + 1] = v.y; t[r][c + 2] = v.z; t[r][c + 3] = v.w;
+    }
+    __syncthreads();
+#pragma unroll
+    for (int i = 0; i < 2; ++i) {
+        const int f = tid + i * 256, c = f / 8, rg = (f % 8) * 8;
+        if (c0 + c >= cols || r0 + rg >= ldp) continue;
+        unsigned short h[8], m[8], l[8];
+#pragma unroll
+        for (int e = 0; e < 8; ++e) pg_split3(t[rg + e][c], h[e], m[e], l[e]);
+        unsigned short* o = out + (long long)(c0 + c) * ldp + r0 + rg;
+        auto pack = [](const unsigned short* s) {
+            return make_uint4(s[0] | ((unsigned)s[1] << 16), s[2] | ((unsigned)s[3] << 16), s[4] | ((unsigned)s[5] << 16), s[6] | ((unsigned)s[7] << 16));
+        };
+        *reinterpret_cast<uint4*>(o) = pack(h);
+        *reinterpret_cast<uint4*>(o + plane) = pack(m);
+        *reinterpret_cast<uint4*>(o + 2 * plane) = pack(l);
+    }
+}
+
+template <int BM, int BN, int WGM, int WGN, int NST, bool TRANS = false>
+static void pg_launch(const vbg_plane_gemm_desc& d, hipStream_t s, hipEvent_t e0, hipEvent_t e1) {
+    dim3 g(cdiv(d.M, BM), cdiv(d.N, BN), d.splitk);
+    if (d.ngroups > 0) {
+        int total = 0;
+        for (int i = 0; i < d.ngroups; ++i) total += d.grp[i].tiles_m * d.grp[i].tiles_n;
+        g = dim3(total, 1, d.splitk);
+    }
+    (void)hipGetLastError();
+    if (e0 && e1) hipExtLaunchKernelGGL((plane_gemm_kernel<BM, BN, WGM, WGN, NST, TRANS>), g, dim3(WGM * WGN * 64), 0, s, e0, e1, 0, d);
+    else hipLaunchKernelGGL((plane_gemm_kernel<BM, BN, WGM, WGN, NST, TRANS>), g, dim3(WGM * WGN * 64), 0, s, d);
+}
+
+}  // namespace vbg
+
+using namespace vbg;
+
+static int plane_gemm_dispatch(const vbg_plane_gemm_desc* desc, void* stream, void* e0, void* e1) {
+    VBG_CHECK_ARG(desc != nullptr);
+    vbg_plane_gemm_desc d = *desc;
+    if (d.ngroups > 0) {          // grouped: the first entry also stands in the descriptor's own fields for the shared checks below
+        VBG_CHECK_ARG(d.ngroups <= VBG_PLANE_MAX_GROUPS && d.Cp == nullptr && d.bias == nullptr && d.C2 == nullptr);
+        for (int i = 0; i < d.ngroups; ++i) {
+            vbg_plane_group& g = d.grp[i];
+            VBG_CHECK_ARG(g.A && g.B && g.C && g.M > 0 && g.N > 0 && g.N % 4 == 0 && g.ldc % 4 == 0 && ((uintptr_t)g.C & 15) == 0);
+            VBG_CHECK_ARG(((uintptr_t)g.A & 15) == 0 && ((uintptr_t)g.B & 15) == 0 && g.a_plane % 8 == 0 && g.b_plane % 8 == 0);
+            if (d.trans) VBG_CHECK_ARG(g.lda % 32 == 0 && g.ldb % 32 == 0 && g.lda >= g.M && g.ldb >= g.N);
+            else VBG_CHECK_ARG(g.lda % 8 == 0 && g.ldb % 8 == 0 && g.lda >= d.K && g.ldb >= d.K);
+            VBG_CHECK_ARG(2 * g.a_plane * 2 + 256 * g.lda * 2 < 0x7fffffffll && 2 * g.b_plane * 2 + 256 * g.ldb * 2 < 0x7fffffffll);
+            const int bm = (d.trans || d.tile != 64064) ? 128 : 64, bn = bm;
+            g.tiles_m = (g.M + bm - 1) / bm;
+            g.tiles_n = (g.N + bn - 1) / bn;
+        }
+        d.A = d.grp[0].A; d.B = d.grp[0].B; d.C = d.grp[0].C; d.M = d.grp[0].M; d.N = d.grp[0].N;
+        d.a_plane = d.grp[0].a_plane; d.b_plane = d.grp[0].b_plane; d.lda = d.grp[0].lda; d.ldb = d.grp[0].ldb; d.ldc = d.grp[0].ldc;
+        if (!d.trans && d.tile != 64064) d.tile = 128129;
+    }
+    VBG_CHECK_ARG(d.A && d.B && (d.C || d.Cp));
+    VBG_CHECK_ARG(d.M >= 0 && d.N >= 0 && d.K > 0);
+    if (d.trans) VBG_CHECK_ARG(d.lda % 32 == 0 && d.ldb % 32 == 0 && d.lda >= d.M && d.ldb >= d.N);
+    else VBG_CHECK_ARG(d.K % 32 == 0 && d.lda % 8 == 0 && d.ldb % 8 == 0 && d.lda >= d.K && d.ldb >= d.K);
+    VBG_CHECK_ARG(((uintptr_t)d.A & 15) == 0 && ((uintptr_t)d.B & 15) == 0 && (d.a_plane % 8) == 0 && (d.b_plane % 8) == 0);
+    VBG_CHECK_ARG(d.N % 4 == 0 && d.ldc % 4 == 0 && ((uintptr_t)d.C & 15) == 0 && ((uintptr_t)d.C2 & 15) == 0 && ((uintptr_t)d.bias & 15) == 0);
+    // 32-bit DMA offsets: the three planes of the rows a block touches must sit within 2 GiB of the block's first row
+    VBG_CHECK_ARG(2 * d.a_plane * 2 + (long long)256 * d.lda * 2 < 0x7fffffffll && 2 * d.b_plane * 2 + (long long)256 * d.ldb * 2 < 0x7fffffffll);
+    if (d.splitk < 1) d.splitk = 1;
+    if (d.splitk > 1) VBG_CHECK_ARG(d.accumulate == 1 && d.C);
+    if (d.accumulate) VBG_CHECK_ARG(d.epi == VBG_EPI_NONE && d.Cp == nullptr);
+    if (d.epi == VBG_EPI_GELU_DUAL) VBG_CHECK_ARG(d.C2 != nullptr || d.Cp != nullptr);
+    if (d.Cp) VBG_CHECK_ARG(d.ldp % 8 == 0 && d.ldp >= d.N && ((uintptr_t)d.Cp & 7) == 0 && d.c_plane % 4 == 0);
+    if (d.M == 0 || d.N == 0) return VBG_OK;
+    hipStream_t s = (hipStream_t)stream;
+    int tile = d.tile;
+    if (d.trans) {
+        if (tile == 128130) pg_launch<128, 128, 2, 4, 3, true>(d, s, (hipEvent_t)e0, (hipEvent_t)e1);
+        else pg_launch<128, 128, 4, 2, 3, true>(d, s, (hipEvent_t)e0, (hipEvent_t)e1);
+        VBG_LAUNCH_RET();
+    }
+    if (tile == 0) {
+        const long t128 = (long)cdiv(d.M, 128) * cdiv(d.N, 128) * d.splitk;
+        tile = (t128 >= 200 && d.N >= 128) ? 128128 : 64064;
+    }
+    if (tile == 256128) pg_launch<256, 128, 4, 2, 2>(d, s, (hipEvent_t)e0, (hipEvent_t)e1);
+    else if (tile == 128128) pg_launch<128, 128, 2, 2, 3>(d, s, (hipEvent_t)e0, (hipEvent_t)e1);
+    else if (tile == 128129) pg_launch<128, 128, 4, 2, 3>(d, s, (hipEvent_t)e0, (hipEvent_t)e1);      // 8 waves of 32 x 64
+    else if (tile == 128130) pg_launch<128, 128, 2, 4, 3>(d, s, (hipEvent_t)e0, (hipEvent_t)e1);      // 8 waves of 64 x 32
+    else if (tile == 128064) pg_launch<128, 64, 2, 2, 3>(d, s, (hipEvent_t)e0, (hipEvent_t)e1);
+    else if (tile == 64064) pg_launch<64, 64, 2, 2, 3>(d, s, (hipEvent_t)e0, (hipEvent_t)e1);
+    else return VBG_EARG;
+    VBG_LAUNCH_RET();
+}
+
+extern "C" int vbg_plane_gemm(const vbg_plane_gemm_desc* desc, void* stream) { return plane_gemm_dispatch(desc, stream, nullptr, nullptr); }
+
+extern "C" int vbg_plane_gemm_timed(const vbg_plane_gemm_desc* desc, void* stream, void* start_event, void* stop_event) {
+    VBG_CHECK_ARG(start_event && stop_event);
+    return plane_gemm_dispatch(desc, stream, start_event, stop_event);
+}
+
+extern "C" int vbg_split_planes(const float* x, long long ldx, int rows, int cols, unsigned short* out, int ldp, long long plane,
+                                int relu, void* stream) {
+    VBG_CHECK_ARG(rows >= 0 && cols >= 0 && ldp % 32 == 0 && ldp >= cols && plane >= (long long)rows * ldp && plane % 8 == 0);
+    if (rows == 0 || cols == 0) return VBG_OK;
+    VBG_CHECK_ARG(x && out && ((uintptr_t)out & 15) == 0);
+    const long long n = (long long)rows * (ldp / 8);
+    long long g = (n + 255) / 256;
+    if (g > 256 * 16) g = 256 * 16;
+    VBG_LAUNCH(split_planes_kernel, dim3((unsigned)g), dim3(256), 0, (hipStream_t)stream, x, ldx, rows, cols, out, ldp, plane, relu);
+    VBG_LAUNCH_RET();
+}
+
+extern "C" int vbg_split_planes_t(const float* x, long long ldx, int rows, int cols, unsigned short* out, int ldp, long long plane,
+                                  void* stream) {
+    VBG_CHECK_ARG(rows >= 0 && cols >= 0 && ldp % 32 == 0 && ldp >= rows && plane >= (long long)cols * ldp && plane % 8 == 0);
+    if (rows == 0 || cols == 0) return VBG_OK;
+    VBG_CHECK_ARG(x && out && ((uintptr_t)out & 15) == 0);
+    VBG_LAUNCH(split_planes_t_kernel, dim3(cdiv(ldp, 64), cdiv(cols, 64)), dim3(256), 0, (hipStream_t)stream, x, ldx, rows, cols, out, ldp, plane);
+    VBG_LAUNCH_RET();
+}

@@ -95,6 +95,21 @@ def _linear_wgrad(w_param, dy, x):
     return dw
 
 
+def _plane_wgrad(w_param, dy, x):
+    """dW = dy^T x from transposed planes (both operands K-contiguous along the token index); into the flat gradient buffer when
+    the parameter is sunk (returns None), else a fresh tensor"""
+    N, K = dy.shape[1], x.shape[1]
+    pa, pb = ops.split_planes_t(dy), ops.split_planes_t(x)
+    dst = wgrad_dest(w_param)
+    if dst is not None:
+        ops.plane_gemm(pa, pb, dst, accumulate=True, tile=ops._wgrad_tile(N, K))
+        wgrad_done(w_param)
+        return None
+    dw = torch.empty_like(w_param)
+    ops.plane_gemm(pa, pb, dw, tile=ops._wgrad_tile(N, K))
+    return dw
+
+
 class LinearFn(torch.autograd.Function):
     """y = x @ w^T + b (optional fused ReLU)."""
 
@@ -500,7 +515,10 @@ class BertLayerFn(torch.autograd.Function):
         dev = x.device
         qkv = torch.empty((ntok, 3 * hid), device=dev, dtype=f32)
         fused_qkv = _back_to_back(wq, wk, wv) and _back_to_back(bq, bk, bv)
-        if fused_qkv:              # one [ntok,hid] x [3*hid,hid]^T GEMM over the stacked projections
+        planes = ops.planes_enabled() and fused_qkv and hid % 32 == 0 and wi.shape[0] % 32 == 0
+        if planes:                 # operands split into bf16 planes once (csrc/gemm_planes.hip), weights once per optimizer step
+            ops.plane_gemm(ops.split_planes(x), ops.weight_planes(_stack3(wq)), qkv, bias=_stack3(bq), tile=ops._dense_tile(ntok, 3 * hid))
+        elif fused_qkv:            # one [ntok,hid] x [3*hid,hid]^T GEMM over the stacked projections
             ops.linear_fwd(x, _stack3(wq), _stack3(bq), out=qkv)
         else:
             for j, (w, b) in enumerate(((wq, bq), (wk, bk), (wv, bv))):
@@ -514,12 +532,23 @@ class BertLayerFn(torch.autograd.Function):
         ctxv = torch.empty((ntok, hid), device=dev, dtype=f32)
         ops.gemm_raw(0, 0, 0, P, meta.ld, OP_DENSE_K, qkv, 3 * hid, OP_DENSE_R, ctxv, hid, grp=meta.t_pv, ngroups=meta.ngroups,
                      grp_max=(meta.maxlen, dh), b_ptr_off=2 * hid, a_relu_scale=1.0 / (1.0 - p))
-        ao = ops.linear_fwd(ctxv, wo, bo)
-        x1, xh1, rs1 = ops.dropout_add_ln_fwd(ao, x, g1, b1, eps, p, seed, sid + 1)
-        h, g = ops.linear_fwd(x1, wi, bi, EPI_GELU_DUAL)
-        fo = ops.linear_fwd(g, wo2, bo2)
+        if planes:
+            ao = ops.plane_gemm(ops.split_planes(ctxv), ops.weight_planes(wo), torch.empty((ntok, hid), device=dev, dtype=f32), bias=bo, tile=ops._dense_tile(ntok, hid))
+            x1, xh1, rs1 = ops.dropout_add_ln_fwd(ao, x, g1, b1, eps, p, seed, sid + 1)
+            inter = wi.shape[0]
+            h, g = torch.empty((ntok, inter), device=dev, dtype=f32), torch.empty((ntok, inter), device=dev, dtype=f32)
+            pg = ops.planes_empty(ntok, inter, dev)          # gelu(h) leaves the FFN1 epilogue as planes: the A operand of FFN2
+            ops.plane_gemm(ops.split_planes(x1), ops.weight_planes(wi), h, bias=bi, epi=EPI_GELU_DUAL, C2=g, out_planes=pg,
+                           tile=ops._dense_tile(ntok, inter, True))
+            fo = ops.plane_gemm(pg, ops.weight_planes(wo2), torch.empty((ntok, hid), device=dev, dtype=f32), bias=bo2, tile=ops._dense_tile(ntok, hid))
+        else:
+            ao = ops.linear_fwd(ctxv, wo, bo)
+            x1, xh1, rs1 = ops.dropout_add_ln_fwd(ao, x, g1, b1, eps, p, seed, sid + 1)
+            h, g = ops.linear_fwd(x1, wi, bi, EPI_GELU_DUAL)
+            fo = ops.linear_fwd(g, wo2, bo2)
         y, xh2, rs2 = ops.dropout_add_ln_fwd(fo, x1, g2, b2, eps, p, seed, sid + 2)
         ctx.meta, ctx.cfg = meta, (eps, p, seed, sid)
+        ctx.planes = planes
         ctx.w_refs = (wq, wk, wv, wo, wi, wo2)
         ctx.b_refs = (bq, bk, bv, bo, bi, bo2, g1, b1, g2, b2)
         ctx.save_for_backward(x, wq, wk, wv, wo, g1, wi, wo2, g2, qkv, P, ctxv, xh1, rs1, x1, h, g, xh2, rs2)
@@ -539,20 +568,36 @@ class BertLayerFn(torch.autograd.Function):
         dg2, db2 = _affine_done(rg2, rb2, dg2, db2, sunk2)
         # FFN
         rq, rk, rv, ro, ri, ro2 = ctx.w_refs
-        dwo2 = _linear_wgrad(ro2, dfo, g)
-        dbo2 = _bias_grad(rbo2, dfo)
-        dh_ = ops.linear_dgrad(dfo, wo2)
-        ops.gelu_bwd_(h, dh_)
-        dwi = _linear_wgrad(ri, dh_, x1)
-        dbi = _bias_grad(rbi, dh_)
-        ops.linear_dgrad(dh_, wi, out=dx1, accumulate=True)
+        planes = ctx.planes
+        if planes:
+            dwo2 = _plane_wgrad(ro2, dfo, g)
+            dbo2 = _bias_grad(rbo2, dfo)
+            dh_ = ops.plane_gemm(ops.split_planes(dfo), ops.weight_planes(wo2, True), torch.empty_like(h),
+                                 tile=ops._dense_tile(ntok, h.shape[1], True))
+            ops.gelu_bwd_(h, dh_)
+            dwi = _plane_wgrad(ri, dh_, x1)
+            dbi = _bias_grad(rbi, dh_)
+            ops.plane_gemm(ops.split_planes(dh_), ops.weight_planes(wi, True), dx1, accumulate=True, tile=ops._dense_tile(ntok, hid))
+        else:
+            dwo2 = _linear_wgrad(ro2, dfo, g)
+            dbo2 = _bias_grad(rbo2, dfo)
+            dh_ = ops.linear_dgrad(dfo, wo2)
+            ops.gelu_bwd_(h, dh_)
+            dwi = _linear_wgrad(ri, dh_, x1)
+            dbi = _bias_grad(rbi, dh_)
+            ops.linear_dgrad(dh_, wi, out=dx1, accumulate=True)
         # LN1
         dg1, db1, sunk1 = _affine_dest(rg1, rb1)
         dao, dx = ops.dropout_add_ln_bwd(dx1, xh1, rs1, g1, p, seed, sid + 1, dg1, db1)
         dg1, db1 = _affine_done(rg1, rb1, dg1, db1, sunk1)
-        dwo = _linear_wgrad(ro, dao, ctxv)
-        dbo = _bias_grad(rbo, dao)
-        dctx = ops.linear_dgrad(dao, wo)
+        if planes:
+            dwo = _plane_wgrad(ro, dao, ctxv)
+            dbo = _bias_grad(rbo, dao)
+            dctx = ops.plane_gemm(ops.split_planes(dao), ops.weight_planes(wo, True), torch.empty_like(ctxv), tile=ops._dense_tile(ntok, hid))
+        else:
+            dwo = _linear_wgrad(ro, dao, ctxv)
+            dbo = _bias_grad(rbo, dao)
+            dctx = ops.linear_dgrad(dao, wo)
         # attention backward (grouped GEMMs + row softmax backward)
         dP = torch.empty_like(P)
         ops.gemm_raw(0, 0, 0, dctx, hid, OP_DENSE_K, qkv, 3 * hid, OP_DENSE_K, dP, meta.ld, grp=meta.t_dp, ngroups=meta.ngroups,
@@ -568,9 +613,15 @@ class BertLayerFn(torch.autograd.Function):
         # QKV projections
         gq = [wgrad_dest(t) for t in (rq, rk, rv, rbq, rbk, rbv)]
         if (all(t is not None for t in gq) and _back_to_back(wq, wk, wv) and _back_to_back(*gq[:3]) and _back_to_back(*gq[3:])):
-            ops.linear_wgrad(dqkv, x, _stack3(gq[0]), accumulate=True)
-            ops.colsum(dqkv, out=_stack3(gq[3]), accumulate=True)
-            ops.linear_dgrad(dqkv, _stack3(wq), out=dx, accumulate=True)
+            if planes:
+                ops.plane_gemm(ops.split_planes_t(dqkv), ops.split_planes_t(x), _stack3(gq[0]), accumulate=True,
+                               tile=ops._wgrad_tile(3 * hid, hid))
+                ops.colsum(dqkv, out=_stack3(gq[3]), accumulate=True)
+                ops.plane_gemm(ops.split_planes(dqkv), ops.weight_planes(_stack3(wq), True), dx, accumulate=True, tile=ops._dense_tile(ntok, hid))
+            else:
+                ops.linear_wgrad(dqkv, x, _stack3(gq[0]), accumulate=True)
+                ops.colsum(dqkv, out=_stack3(gq[3]), accumulate=True)
+                ops.linear_dgrad(dqkv, _stack3(wq), out=dx, accumulate=True)
             for t in (rq, rk, rv, rbq, rbk, rbv):
                 wgrad_done(t)
             return (dx, None, None, None, None, None, None, dwo, dbo, dg1, db1, dwi, dbi, dwo2, dbo2, dg2, db2, None, None, None, None, None)

@@ -35,6 +35,21 @@ class GemmDesc(C.Structure):
                 ("stats", c_vp), ("stats_slots", c_int), ("bf16", c_int)]
 
 
+class PlaneGroup(C.Structure):
+    _fields_ = [("A", c_vp), ("B", c_vp), ("C", c_vp), ("a_plane", c_ll), ("lda", c_ll), ("b_plane", c_ll), ("ldb", c_ll), ("ldc", c_ll),
+                ("M", c_int), ("N", c_int), ("tiles_m", c_int), ("tiles_n", c_int)]
+
+
+class PlaneGemmDesc(C.Structure):
+    _fields_ = [("M", c_int), ("N", c_int), ("K", c_int),
+                ("A", c_vp), ("a_plane", c_ll), ("lda", c_ll),
+                ("B", c_vp), ("b_plane", c_ll), ("ldb", c_ll),
+                ("C", c_vp), ("ldc", c_ll), ("C2", c_vp), ("bias", c_vp),
+                ("Cp", c_vp), ("c_plane", c_ll), ("ldp", c_ll),
+                ("epi", c_int), ("alpha", c_f), ("accumulate", c_int), ("splitk", c_int), ("tile", c_int), ("trans", c_int),
+                ("ngroups", c_int), ("grp", PlaneGroup * 4)]
+
+
 OP_DENSE_K, OP_DENSE_R, OP_CONV_K, OP_CONV_R, OP_WT_R = 0, 1, 2, 3, 4
 EPI_NONE, EPI_RELU, EPI_GELU_DUAL = 0, 1, 2
 
@@ -46,6 +61,10 @@ SIGNATURES = {
     "vbg_timer_create": (c_int, [c_vp]),
     "vbg_timer_destroy": (c_int, [c_vp]),
     "vbg_timer_elapsed_ms": (c_int, [c_vp, c_vp, c_vp]),
+    "vbg_plane_gemm": (c_int, [C.POINTER(PlaneGemmDesc), c_vp]),
+    "vbg_plane_gemm_timed": (c_int, [C.POINTER(PlaneGemmDesc), c_vp, c_vp, c_vp]),
+    "vbg_split_planes": (c_int, [c_vp, c_ll, c_int, c_int, c_vp, c_int, c_ll, c_int, c_vp]),
+    "vbg_split_planes_t": (c_int, [c_vp, c_ll, c_int, c_int, c_vp, c_int, c_ll, c_vp]),
     "vbg_colsum": (c_int, [c_vp, c_ll, c_int, c_int, c_vp, c_int, c_vp]),
     "vbg_im2col": (c_int, [c_vp, c_int, c_int, c_int, c_int, c_int, c_int, c_int, c_int, c_int, c_vp, c_vp]),
     "vbg_normalize_resize": (c_int, [c_vp, c_int, c_int, c_int, c_int, C.POINTER(c_f), C.POINTER(c_f), c_vp, c_int, c_int, c_int, c_vp]),

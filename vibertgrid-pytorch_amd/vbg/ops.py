@@ -8,7 +8,7 @@ import os
 import torch
 
 from .lib import (EPI_GELU_DUAL, EPI_NONE, EPI_RELU, OP_CONV_K, OP_CONV_R, OP_DENSE_K, OP_DENSE_R, OP_WT_R, ConvGeo,
-                  GemmDesc, check, lib)
+                  GemmDesc, PlaneGemmDesc, check, lib)
 
 f32 = torch.float32
 i32 = torch.int32
@@ -95,6 +95,159 @@ def gemm_raw(M, N, K, A, lda, a_kind, B, ldb, b_kind, Cout, ldc, *, bias=None, e
         prof.add(2.0 * M * N * K, e0, e1)
         return
     check(lib.vbg_gemm(C.byref(d), _stream()), "vbg_gemm")
+
+
+# ----------------------------------------------------------------------------------------------
+# plane operands: a tensor split ONCE into three bf16 planes [3][rows][ld] (csrc/gemm_planes.hip)
+# ----------------------------------------------------------------------------------------------
+class Planes:
+    """bf16 planes of a [rows, cols] fp32 matrix (K-contiguous along cols): `buf` int16 [3, rows, ld], ld = cols rounded up to 32"""
+    __slots__ = ("buf", "rows", "cols", "ld")
+
+    def __init__(self, buf, rows, cols, ld):
+        self.buf, self.rows, self.cols, self.ld = buf, rows, cols, ld
+
+    @property
+    def plane(self):
+        return self.rows * self.ld
+
+
+def _ld32(n):
+    return (int(n) + 31) // 32 * 32
+
+
+def planes_empty(rows, cols, device):
+    ld = _ld32(cols)
+    return Planes(torch.empty((3, rows, ld), device=device, dtype=torch.int16), int(rows), int(cols), ld)
+
+
+def split_planes(x, relu=False, out=None):
+    """x [rows, cols] fp32 (last dim contiguous) -> Planes of x (rows = GEMM rows, cols = reduction index)"""
+    assert x.dim() == 2 and x.stride(1) == 1 and x.dtype == f32
+    rows, cols = x.shape
+    o = out if out is not None else planes_empty(rows, cols, x.device)
+    check(lib.vbg_split_planes(P(x), x.stride(0), rows, cols, P(o.buf), o.ld, o.plane, int(relu), _stream()), "vbg_split_planes")
+    return o
+
+
+def split_planes_t(x, out=None):
+    """x [rows, cols] fp32 -> Planes of x^T ([cols, rows]: the reduction index becomes x's row index)"""
+    assert x.dim() == 2 and x.stride(1) == 1 and x.dtype == f32
+    rows, cols = x.shape
+    o = out if out is not None else planes_empty(cols, rows, x.device)
+    check(lib.vbg_split_planes_t(P(x), x.stride(0), rows, cols, P(o.buf), o.ld, o.plane, _stream()), "vbg_split_planes_t")
+    return o
+
+
+def plane_gemm(a: Planes, b: Planes, out=None, *, bias=None, epi=EPI_NONE, C2=None, accumulate=False, splitk=1, alpha=1.0, tile=0,
+               out_planes=None, ldc=None, trans=False):
+    """out[M, N] (+)= alpha * a[M, K] b[N, K]^T (+ bias).  out_planes: Planes [M, N] that receive the split of the stored value.
+    trans: out[Ma, Nb] (+)= alpha * a[K, Ma]^T b[K, Nb] (the operands' ROWS are the reduction index: weight gradients)."""
+    d = PlaneGemmDesc()
+    if trans:
+        assert a.rows == b.rows, (a.rows, b.rows)
+        d.M, d.N, d.K, d.trans = a.cols, b.cols, a.rows, 1
+    else:
+        assert a.cols == b.cols, (a.cols, b.cols)
+        d.M, d.N, d.K = a.rows, b.rows, _ld32(a.cols)
+    d.A, d.a_plane, d.lda = a.buf.data_ptr(), a.plane, a.ld
+    d.B, d.b_plane, d.ldb = b.buf.data_ptr(), b.plane, b.ld
+    if out is not None:
+        d.C, d.ldc = out.data_ptr(), int(ldc if ldc is not None else out.stride(-2))
+    else:
+        d.ldc = (d.N + 3) // 4 * 4
+    d.C2 = None if C2 is None else C2.data_ptr()
+    d.bias = None if bias is None else bias.data_ptr()
+    if out_planes is not None:
+        d.Cp, d.c_plane, d.ldp = out_planes.buf.data_ptr(), out_planes.plane, out_planes.ld
+    d.epi, d.alpha, d.accumulate, d.splitk, d.tile = epi, float(alpha), int(bool(accumulate)), int(splitk), int(tile)
+    prof = _GEMM_PROF
+    if prof is not None and not trans and prof.match(OP_DENSE_K, OP_DENSE_K, False):
+        e0, e1 = prof.events()
+        check(lib.vbg_plane_gemm_timed(C.byref(d), _stream(), e0, e1), "vbg_plane_gemm_timed")
+        prof.add(2.0 * d.M * d.N * (a.rows if trans else a.cols), e0, e1)
+        return out
+    check(lib.vbg_plane_gemm(C.byref(d), _stream()), "vbg_plane_gemm")
+    return out
+
+
+def plane_gemm_grouped(problems, *, trans=True, accumulate=True, tile=0, alpha=1.0):
+    """several independent plane products of ONE reduction length in one launch: problems = [(a: Planes, b: Planes, out), ...]
+    (trans: out[a.cols, b.cols] (+)= a^T b, the weight gradients of a layer)"""
+    assert 1 <= len(problems) <= 4
+    d = PlaneGemmDesc()
+    d.ngroups, d.trans, d.accumulate, d.tile, d.alpha, d.splitk = len(problems), int(trans), int(bool(accumulate)), int(tile), float(alpha), 1
+    k = None
+    for i, (a, b, out) in enumerate(problems):
+        g = d.grp[i]
+        g.A, g.a_plane, g.lda = a.buf.data_ptr(), a.plane, a.ld
+        g.B, g.b_plane, g.ldb = b.buf.data_ptr(), b.plane, b.ld
+        g.C, g.ldc = out.data_ptr(), out.stride(-2)
+        if trans:
+            assert a.rows == b.rows
+            g.M, g.N, kk = a.cols, b.cols, a.rows
+        else:
+            assert a.cols == b.cols
+            g.M, g.N, kk = a.rows, b.rows, _ld32(a.cols)
+        assert k is None or k == kk, "grouped products share the reduction length"
+        k = kk
+    d.K = k
+    check(lib.vbg_plane_gemm(C.byref(d), _stream()), "vbg_plane_gemm (grouped)")
+
+
+_PLANES = [True]
+_W_EPOCH = [0]
+_WCACHE = {}          # (data_ptr, shape, transposed) -> ((epoch, version), Planes); insertion ordered, oldest evicted
+_WCACHE_MAX = 400
+
+
+def set_planes(on: bool):
+    """dense linear products from pre-split bf16 planes (csrc/gemm_planes.hip) instead of the in-kernel split of vbg_gemm"""
+    _PLANES[0] = bool(on)
+
+
+def planes_enabled() -> bool:
+    return _PLANES[0] and _SPLIT3[0] and not _AMP[0]
+
+
+def bump_weight_epoch():
+    """parameters were changed by something torch's version counters do not see (the fused optimizer kernels): cached weight
+    planes are stale"""
+    _W_EPOCH[0] += 1
+
+
+def weight_planes(w, transposed=False) -> Planes:
+    """planes of a 2-D weight [N, K] (transposed: of w^T, the B operand of the data-gradient product), split once per weight
+    version: the optimizer step bumps the epoch, in-place torch ops bump `_version`"""
+    assert w.dim() == 2 and w.stride(1) == 1 and w.stride(0) == w.shape[1]
+    key = (w.data_ptr(), tuple(w.shape), bool(transposed))
+    tag = (_W_EPOCH[0], w._version)
+    hit = _WCACHE.get(key)
+    if hit is not None and hit[0] == tag:
+        return hit[1]
+    with torch.no_grad():
+        pl = split_planes_t(w.detach(), out=hit[1] if hit is not None else None) if transposed else \
+            split_planes(w.detach(), out=hit[1] if hit is not None else None)
+    _WCACHE.pop(key, None)
+    _WCACHE[key] = (tag, pl)
+    while len(_WCACHE) > _WCACHE_MAX:
+        _WCACHE.pop(next(iter(_WCACHE)))
+    return pl
+
+
+def _dense_tile(M, N, wide=False):
+    """tile of a forward / data-gradient plane product [M, N]: the 8-wave 128 x 128 tile (2 waves per SIMD) once it fills the
+    chip, 256 x 128 for the widest outputs (fewer, fuller rounds), 64 x 64 for small problems (tests, single documents)"""
+    t128 = ((M + 127) // 128) * ((N + 127) // 128)
+    if t128 < 100:
+        return 64064
+    return 256128 if (wide and M >= 2048) else 128129
+
+
+def _wgrad_tile(N, K):
+    """tile of a weight-gradient plane product dW[N, K]: no split-K (float atomics run at the L2's atomic rate, ~17 us per pass
+    over a 3072 x 768 gradient); the 8-wave 128 x 128 tile from 100 tiles on, 64 x 64 below"""
+    return 128129 if ((N + 127) // 128) * ((K + 127) // 128) >= 100 else 64064
 
 
 class GemmProfiler:

@@ -192,6 +192,7 @@ class FusedSGD(_FlatOptimizer):
         ops.sgd_step(self.group.pflat, self.group.gflat, self.mom, float(g["lr"]), float(g["momentum"]), float(g["weight_decay"]),
                      self.steps == 0, self.grad_scale)
         self.steps += 1
+        ops.bump_weight_epoch()
 
 
 class FusedAdamW(_FlatOptimizer):
@@ -211,6 +212,7 @@ class FusedAdamW(_FlatOptimizer):
         self.steps += 1
         ops.adamw_step(self.group.pflat, self.group.gflat, self.m, self.v, float(g["lr"]), float(g["betas"][0]), float(g["betas"][1]),
                        float(g["eps"]), float(g["weight_decay"]), self.steps, self.grad_scale)
+        ops.bump_weight_epoch()
 
 
 def clip_grad_norm_(optimizers, max_norm: float, norm_scale: float = 1.0) -> float:
