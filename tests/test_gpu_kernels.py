@@ -876,3 +876,109 @@ def test_crf_vs_oracle(ops, ntag, lens):
         sc, p = O.crf_viterbi(em[off[k]:off[k + 1]], trans, start, stop)
         assert path[off[k]:off[k + 1]].cpu().tolist() == p
         assert abs(float(score[k]) - float(sc)) <= 1e-4 * max(1.0, abs(float(sc)))
+
+
+# ----------------------------------------------------------------------------------------------
+# plane GEMM (csrc/gemm_planes.hip): split kernels, NT / TN / grouped products, epilogues
+# ----------------------------------------------------------------------------------------------
+def _bf16_planes_ref(x):
+    """exact three-way truncation split in torch: (hi, mid, lo) as int16 bit patterns"""
+    def top16(t):
+        return (t.view(torch.int32) & -65536).view(torch.float32)
+    h = top16(x)
+    r1 = x - h
+    m = top16(r1)
+    r2 = r1 - m
+    bits = lambda t: (t.view(torch.int32) >> 16).to(torch.int16)
+    return bits(h), bits(m), bits(r2), h, m, r2
+
+
+def test_split_planes_exact_and_transposed():
+    from vbg import ops
+    dev = torch.device("cuda")
+    g = torch.Generator().manual_seed(3)
+    for rows, cols in ((5, 7), (64, 96), (130, 770), (1000, 264)):
+        x = (torch.randn(rows, cols, generator=g) * torch.exp2(torch.randint(-20, 20, (rows, cols), generator=g).float())).to(dev)
+        h, m, l, hf, mf, lf = _bf16_planes_ref(x)
+        assert torch.equal(hf + mf + lf, x)                                   # the three pieces are exact: x = hi + mid + lo
+        p = ops.split_planes(x)
+        assert p.ld % 32 == 0 and p.ld >= cols and tuple(p.buf.shape) == (3, rows, p.ld)
+        for q, ref in enumerate((h, m, l)):
+            assert torch.equal(p.buf[q, :, :cols], ref)
+            assert int(p.buf[q, :, cols:].abs().max() if p.ld > cols else 0) == 0     # zero padding of the reduction tail
+        pt = ops.split_planes_t(x)
+        assert tuple(pt.buf.shape) == (3, cols, (rows + 31) // 32 * 32)
+        for q, ref in enumerate((h, m, l)):
+            assert torch.equal(pt.buf[q, :, :rows], ref.t())
+        pr = ops.split_planes(x, relu=True)
+        assert torch.equal(pr.buf[0, :, :cols], _bf16_planes_ref(x.clamp(min=0))[0])
+
+
+@pytest.mark.parametrize("tile", [0, 64064, 128064, 128128, 128129, 128130, 256128])
+def test_plane_gemm_nt_vs_fp64(tile):
+    from vbg import ops
+    from vbg.lib import EPI_GELU_DUAL, EPI_RELU
+    dev = torch.device("cuda")
+    g = torch.Generator().manual_seed(tile + 1)
+    for (M, N, K) in ((300, 264, 96), (129, 128, 32), (1000, 772, 800), (257, 512, 3072)):
+        a = (torch.randn(M, K, generator=g) * torch.exp2(torch.randint(-8, 8, (M, 1), generator=g).float())).to(dev)
+        b = (torch.randn(N, K, generator=g) / K ** 0.5).to(dev)
+        bias = torch.randn(N, generator=g).to(dev)
+        ref = a.double() @ b.double().t() + bias.double()
+        scale = float((a.double().abs() @ b.double().abs().t()).max())
+        pa, pb = ops.split_planes(a), ops.split_planes(b)
+        out = torch.full((M, N), 7.0, device=dev)
+        ops.plane_gemm(pa, pb, out, bias=bias, tile=tile)
+        assert float((out.double() - ref).abs().max()) <= 2e-6 * scale, (M, N, K)
+        # ReLU epilogue, GELU dual + planes of the stored value, accumulate, split-K with atomics
+        o2 = torch.empty(M, N, device=dev)
+        ops.plane_gemm(pa, pb, o2, bias=bias, epi=EPI_RELU, tile=tile)
+        assert float((o2.double() - ref.clamp(min=0)).abs().max()) <= 2e-6 * scale
+        h, gl, pg = torch.empty(M, N, device=dev), torch.empty(M, N, device=dev), ops.planes_empty(M, N, dev)
+        ops.plane_gemm(pa, pb, h, bias=bias, epi=EPI_GELU_DUAL, C2=gl, out_planes=pg, tile=tile)
+        assert torch.equal(h, out)
+        assert float((gl.double() - torch.nn.functional.gelu(out.double())).abs().max()) <= 1e-5 * max(1.0, float(out.abs().max()))
+        assert torch.equal(pg.buf[:, :, :N], ops.split_planes(gl).buf[:, :, :N])
+        acc = torch.ones(M, N, device=dev)
+        ops.plane_gemm(pa, pb, acc, accumulate=True, tile=tile)
+        assert float((acc.double() - 1 - (ref - bias.double())).abs().max()) <= 2e-6 * scale
+        acc = torch.ones(M, N, device=dev)
+        ops.plane_gemm(pa, pb, acc, accumulate=True, splitk=3, tile=tile)
+        assert float((acc.double() - 1 - (ref - bias.double())).abs().max()) <= 2e-6 * scale
+        # same pieces, same products as the in-kernel split form of vbg_gemm: agreement to summation order
+        old = ops.linear_fwd(a, b, bias)
+        assert float((old - out).abs().max()) <= 1e-6 * scale
+
+
+def test_plane_gemm_tn_and_grouped_vs_fp64():
+    """weight-gradient form: dW = dY^T X straight from the untransposed planes (LDS transpose reads), ragged sizes, reduction
+    lengths that are not a multiple of the k-tile, and the grouped launch"""
+    from vbg import ops
+    dev = torch.device("cuda")
+    g = torch.Generator().manual_seed(11)
+    probs, refs = [], []
+    for (Mt, N1, N2) in ((77, 128, 128), (1000, 264, 136), (4100, 768, 96), (515, 40, 2304)):
+        dy = (torch.randn(Mt, N1, generator=g) * torch.exp2(torch.randint(-6, 6, (Mt, 1), generator=g).float())).to(dev)
+        x = torch.randn(Mt, N2, generator=g).to(dev)
+        ref = dy.double().t() @ x.double()
+        scale = float((dy.double().abs().t() @ x.double().abs()).max())
+        pdy, px = ops.split_planes(dy), ops.split_planes(x)
+        for tile in (128129, 128130):
+            out = torch.full((N1, N2), 3.0, device=dev)
+            ops.plane_gemm(pdy, px, out, trans=True, tile=tile)
+            assert float((out.double() - ref).abs().max()) <= 2e-6 * scale, (Mt, N1, N2, tile)
+        acc = torch.ones(N1, N2, device=dev)
+        ops.plane_gemm(pdy, px, acc, trans=True, accumulate=True)
+        assert float((acc.double() - 1 - ref).abs().max()) <= 2e-6 * scale
+        # transposed planes + the NT kernel give the same numbers
+        o3 = torch.empty(N1, N2, device=dev)
+        ops.plane_gemm(ops.split_planes_t(dy), ops.split_planes_t(x), o3)
+        assert float((o3.double() - ref).abs().max()) <= 2e-6 * scale
+    Mt = 1031
+    for (N1, N2) in ((768, 256), (256, 768), (96, 96), (320, 64)):
+        dy, x = torch.randn(Mt, N1, generator=g).to(dev), torch.randn(Mt, N2, generator=g).to(dev)
+        probs.append((ops.split_planes(dy), ops.split_planes(x), torch.ones(N1, N2, device=dev)))
+        refs.append(dy.double().t() @ x.double())
+    ops.plane_gemm_grouped(probs, trans=True, accumulate=True)
+    for (_, _, out), ref in zip(probs, refs):
+        assert float((out.double() - 1 - ref).abs().max()) <= 2e-6 * float(ref.abs().max()) * 30

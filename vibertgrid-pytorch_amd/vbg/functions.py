@@ -515,9 +515,15 @@ class BertLayerFn(torch.autograd.Function):
         dev = x.device
         qkv = torch.empty((ntok, 3 * hid), device=dev, dtype=f32)
         fused_qkv = _back_to_back(wq, wk, wv) and _back_to_back(bq, bk, bv)
-        planes = ops.planes_enabled() and fused_qkv and hid % 32 == 0 and wi.shape[0] % 32 == 0
+        planes = ops.planes_enabled() and hid % 32 == 0 and wi.shape[0] % 32 == 0
+        px = pctx = px1 = pg = None
         if planes:                 # operands split into bf16 planes once (csrc/gemm_planes.hip), weights once per optimizer step
-            ops.plane_gemm(ops.split_planes(x), ops.weight_planes(_stack3(wq)), qkv, bias=_stack3(bq), tile=ops._dense_tile(ntok, 3 * hid))
+            px = ops.split_planes(x)
+            if fused_qkv:
+                ops.plane_gemm(px, ops.weight_planes(wq, view=_stack3(wq), also=(wk, wv)), qkv, bias=_stack3(bq), tile=ops._dense_tile(ntok, 3 * hid))
+            else:              # parameters not laid out back to back (no flat buffers): one product per projection, same kernel
+                for j, (w, b) in enumerate(((wq, bq), (wk, bk), (wv, bv))):
+                    ops.plane_gemm(px, ops.weight_planes(w), qkv[:, j * hid:(j + 1) * hid], bias=b, tile=ops._dense_tile(ntok, hid))
         elif fused_qkv:            # one [ntok,hid] x [3*hid,hid]^T GEMM over the stacked projections
             ops.linear_fwd(x, _stack3(wq), _stack3(bq), out=qkv)
         else:
@@ -533,14 +539,17 @@ class BertLayerFn(torch.autograd.Function):
         ops.gemm_raw(0, 0, 0, P, meta.ld, OP_DENSE_K, qkv, 3 * hid, OP_DENSE_R, ctxv, hid, grp=meta.t_pv, ngroups=meta.ngroups,
                      grp_max=(meta.maxlen, dh), b_ptr_off=2 * hid, a_relu_scale=1.0 / (1.0 - p))
         if planes:
-            ao = ops.plane_gemm(ops.split_planes(ctxv), ops.weight_planes(wo), torch.empty((ntok, hid), device=dev, dtype=f32), bias=bo, tile=ops._dense_tile(ntok, hid))
+            pctx = ops.split_planes(ctxv)
+            ao = ops.plane_gemm(pctx, ops.weight_planes(wo), torch.empty((ntok, hid), device=dev, dtype=f32), bias=bo, tile=ops._dense_tile(ntok, hid))
             x1, xh1, rs1 = ops.dropout_add_ln_fwd(ao, x, g1, b1, eps, p, seed, sid + 1)
             inter = wi.shape[0]
-            h, g = torch.empty((ntok, inter), device=dev, dtype=f32), torch.empty((ntok, inter), device=dev, dtype=f32)
-            pg = ops.planes_empty(ntok, inter, dev)          # gelu(h) leaves the FFN1 epilogue as planes: the A operand of FFN2
-            ops.plane_gemm(ops.split_planes(x1), ops.weight_planes(wi), h, bias=bi, epi=EPI_GELU_DUAL, C2=g, out_planes=pg,
-                           tile=ops._dense_tile(ntok, inter, True))
+            h = torch.empty((ntok, inter), device=dev, dtype=f32)
+            # gelu(h) leaves the FFN1 epilogue as planes only (the A operand of FFN2 and, untransposed, of its weight gradient)
+            pg = ops.planes_empty(ntok, inter, dev)
+            px1 = ops.split_planes(x1)
+            ops.plane_gemm(px1, ops.weight_planes(wi), h, bias=bi, epi=EPI_GELU_DUAL, out_planes=pg, tile=ops._dense_tile(ntok, inter, True))
             fo = ops.plane_gemm(pg, ops.weight_planes(wo2), torch.empty((ntok, hid), device=dev, dtype=f32), bias=bo2, tile=ops._dense_tile(ntok, hid))
+            g = None
         else:
             ao = ops.linear_fwd(ctxv, wo, bo)
             x1, xh1, rs1 = ops.dropout_add_ln_fwd(ao, x, g1, b1, eps, p, seed, sid + 1)
@@ -551,11 +560,99 @@ class BertLayerFn(torch.autograd.Function):
         ctx.planes = planes
         ctx.w_refs = (wq, wk, wv, wo, wi, wo2)
         ctx.b_refs = (bq, bk, bv, bo, bi, bo2, g1, b1, g2, b2)
-        ctx.save_for_backward(x, wq, wk, wv, wo, g1, wi, wo2, g2, qkv, P, ctxv, xh1, rs1, x1, h, g, xh2, rs2)
+        if planes:
+            # backward needs the activations only as GEMM operands: their planes stand in for x / ctx / x1 / gelu(h)
+            ctx.pl_shape = (ntok, hid, wi.shape[0])
+            ctx.save_for_backward(wq, wk, wv, wo, g1, wi, wo2, g2, qkv, P, xh1, rs1, h, xh2, rs2, px.buf, pctx.buf, px1.buf, pg.buf)
+        else:
+            ctx.save_for_backward(x, wq, wk, wv, wo, g1, wi, wo2, g2, qkv, P, ctxv, xh1, rs1, x1, h, g, xh2, rs2)
         return y
 
     @staticmethod
+    def _backward_planes(ctx, dy):
+        """backward of the plane path: every dy is split once (the A operand of its data-gradient product) and the four weight
+        gradients of the layer run as ONE grouped TN launch from the untransposed planes of dy and of the saved activations"""
+        (wq, wk, wv, wo, g1, wi, wo2, g2, qkv, P, xh1, rs1, h, xh2, rs2, bx, bctx, bx1, bg) = ctx.saved_tensors
+        meta = ctx.meta
+        eps, p, seed, sid = ctx.cfg
+        ntok, hid, inter = ctx.pl_shape
+        H, dh = meta.heads, meta.dh
+        dev = qkv.device
+        mk = lambda buf, cols: ops.Planes(buf, ntok, cols, buf.shape[2])
+        px, pctx, px1, pg = mk(bx, hid), mk(bctx, hid), mk(bx1, hid), mk(bg, inter)
+        rbq, rbk, rbv, rbo, rbi, rbo2, rg1, rb1, rg2, rb2 = ctx.b_refs
+        rq, rk, rv, ro, ri, ro2 = ctx.w_refs
+        dg2, db2, sunk2 = _affine_dest(rg2, rb2)
+        dfo, dx1 = ops.dropout_add_ln_bwd(_c(dy), xh2, rs2, g2, p, seed, sid + 2, dg2, db2)
+        dg2, db2 = _affine_done(rg2, rb2, dg2, db2, sunk2)
+        pdfo = ops.split_planes(dfo)
+        dbo2 = _bias_grad(rbo2, dfo)
+        dh_ = ops.plane_gemm(pdfo, ops.weight_planes(ro2, True, view=wo2), torch.empty_like(h), tile=ops._dense_tile(ntok, inter, True))
+        ops.gelu_bwd_(h, dh_)
+        pdh = ops.split_planes(dh_)
+        dbi = _bias_grad(rbi, dh_)
+        ops.plane_gemm(pdh, ops.weight_planes(ri, True, view=wi), dx1, accumulate=True, tile=ops._dense_tile(ntok, hid))
+        dg1, db1, sunk1 = _affine_dest(rg1, rb1)
+        dao, dx = ops.dropout_add_ln_bwd(dx1, xh1, rs1, g1, p, seed, sid + 1, dg1, db1)
+        dg1, db1 = _affine_done(rg1, rb1, dg1, db1, sunk1)
+        pdao = ops.split_planes(dao)
+        dbo = _bias_grad(rbo, dao)
+        dctx = ops.plane_gemm(pdao, ops.weight_planes(ro, True, view=wo), torch.empty((ntok, hid), device=dev, dtype=f32), tile=ops._dense_tile(ntok, hid))
+        dP = torch.empty_like(P)
+        ops.gemm_raw(0, 0, 0, dctx, hid, OP_DENSE_K, qkv, 3 * hid, OP_DENSE_K, dP, meta.ld, grp=meta.t_dp, ngroups=meta.ngroups,
+                     grp_max=(meta.maxlen, meta.maxlen), b_ptr_off=2 * hid, bk=16 if dh <= 128 else 0, tile=64064 if dh <= 128 else 0)
+        dqkv = torch.empty_like(qkv)
+        ops.gemm_raw(0, 0, 0, P, meta.ld, OP_DENSE_R, dctx, hid, OP_DENSE_R, dqkv, 3 * hid, grp=meta.t_dv, ngroups=meta.ngroups,
+                     grp_max=(meta.maxlen, dh), c_ptr_off=2 * hid, a_relu_scale=1.0 / (1.0 - p))
+        ops.softmax_bwd(P, dP, meta.soff, meta.lens, meta.ldp, meta.ngroups, H, meta.maxlen, 1.0 / (dh ** 0.5), p)
+        ops.gemm_raw(0, 0, 0, dP, meta.ld, OP_DENSE_K, qkv, 3 * hid, OP_DENSE_R, dqkv, 3 * hid, grp=meta.t_dq, ngroups=meta.ngroups,
+                     grp_max=(meta.maxlen, dh), b_ptr_off=hid)
+        ops.gemm_raw(0, 0, 0, dP, meta.ld, OP_DENSE_R, qkv, 3 * hid, OP_DENSE_R, dqkv, 3 * hid, grp=meta.t_dk, ngroups=meta.ngroups,
+                     grp_max=(meta.maxlen, dh), c_ptr_off=hid)
+        pdqkv = ops.split_planes(dqkv)
+        stacked = _back_to_back(wq, wk, wv)
+        if stacked:
+            ops.plane_gemm(pdqkv, ops.weight_planes(rq, True, view=_stack3(wq), also=(rk, rv)), dx, accumulate=True, tile=ops._dense_tile(ntok, hid))
+        else:
+            for j, (w, wr) in enumerate(((wq, rq), (wk, rk), (wv, rv))):
+                ops.plane_gemm(pdqkv.col_block(j * hid, hid), ops.weight_planes(wr, True, view=w), dx, accumulate=True, tile=ops._dense_tile(ntok, hid))
+        # ---- the four weight gradients: one grouped TN launch (432 tiles at bert-base: two rounds on 256 CUs instead of four
+        #      launches of 36-144 tiles each) ------------------------------------------------------------------------------
+        gq = [wgrad_dest(t) for t in (rq, rk, rv, rbq, rbk, rbv)]
+        qkv_sunk = stacked and all(t is not None for t in gq) and _back_to_back(*gq[:3]) and _back_to_back(*gq[3:])
+        dw_qkv = _stack3(gq[0]) if qkv_sunk else torch.zeros((3 * hid, hid), device=dev, dtype=f32)
+        dests, fresh = [], []
+        for wp in (ro2, ri, ro):
+            d_ = wgrad_dest(wp)
+            fresh.append(d_ is None)
+            dests.append(d_ if d_ is not None else torch.zeros_like(wp))
+        ops.plane_gemm_grouped([(pdfo, pg, dests[0]), (pdh, px1, dests[1]), (pdao, pctx, dests[2]), (pdqkv, px, dw_qkv)], trans=True, accumulate=True)
+        for wp, fr in zip((ro2, ri, ro), fresh):
+            if not fr:
+                wgrad_done(wp)
+        dwo2, dwi, dwo = (dests[i] if fresh[i] else None for i in range(3))
+        if qkv_sunk:
+            ops.colsum(dqkv, out=_stack3(gq[3]), accumulate=True)
+            for t in (rq, rk, rv, rbq, rbk, rbv):
+                wgrad_done(t)
+            return (dx, None, None, None, None, None, None, dwo, dbo, dg1, db1, dwi, dbi, dwo2, dbo2, dg2, db2, None, None, None, None, None)
+        dws, dbs = [], []
+        for j, (wr, br) in enumerate(((rq, rbq), (rk, rbk), (rv, rbv))):
+            dj = dw_qkv[j * hid:(j + 1) * hid]
+            dst = wgrad_dest(wr)
+            if dst is not None:            # sunk but not stacked: add the block into the parameter's own gradient view
+                dst.add_(dj)
+                wgrad_done(wr)
+                dj = None
+            dws.append(dj)
+            dbs.append(_bias_grad(br, dqkv[:, j * hid:(j + 1) * hid]))
+        return (dx, dws[0], dbs[0], dws[1], dbs[1], dws[2], dbs[2], dwo, dbo, dg1, db1, dwi, dbi, dwo2, dbo2,
+                dg2, db2, None, None, None, None, None)
+
+    @staticmethod
     def backward(ctx, dy):
+        if ctx.planes:
+            return BertLayerFn._backward_planes(ctx, dy)
         (x, wq, wk, wv, wo, g1, wi, wo2, g2, qkv, P, ctxv, xh1, rs1, x1, h, g, xh2, rs2) = ctx.saved_tensors
         meta = ctx.meta
         eps, p, seed, sid = ctx.cfg
@@ -568,36 +665,20 @@ class BertLayerFn(torch.autograd.Function):
         dg2, db2 = _affine_done(rg2, rb2, dg2, db2, sunk2)
         # FFN
         rq, rk, rv, ro, ri, ro2 = ctx.w_refs
-        planes = ctx.planes
-        if planes:
-            dwo2 = _plane_wgrad(ro2, dfo, g)
-            dbo2 = _bias_grad(rbo2, dfo)
-            dh_ = ops.plane_gemm(ops.split_planes(dfo), ops.weight_planes(wo2, True), torch.empty_like(h),
-                                 tile=ops._dense_tile(ntok, h.shape[1], True))
-            ops.gelu_bwd_(h, dh_)
-            dwi = _plane_wgrad(ri, dh_, x1)
-            dbi = _bias_grad(rbi, dh_)
-            ops.plane_gemm(ops.split_planes(dh_), ops.weight_planes(wi, True), dx1, accumulate=True, tile=ops._dense_tile(ntok, hid))
-        else:
-            dwo2 = _linear_wgrad(ro2, dfo, g)
-            dbo2 = _bias_grad(rbo2, dfo)
-            dh_ = ops.linear_dgrad(dfo, wo2)
-            ops.gelu_bwd_(h, dh_)
-            dwi = _linear_wgrad(ri, dh_, x1)
-            dbi = _bias_grad(rbi, dh_)
-            ops.linear_dgrad(dh_, wi, out=dx1, accumulate=True)
+        dwo2 = _linear_wgrad(ro2, dfo, g)
+        dbo2 = _bias_grad(rbo2, dfo)
+        dh_ = ops.linear_dgrad(dfo, wo2)
+        ops.gelu_bwd_(h, dh_)
+        dwi = _linear_wgrad(ri, dh_, x1)
+        dbi = _bias_grad(rbi, dh_)
+        ops.linear_dgrad(dh_, wi, out=dx1, accumulate=True)
         # LN1
         dg1, db1, sunk1 = _affine_dest(rg1, rb1)
         dao, dx = ops.dropout_add_ln_bwd(dx1, xh1, rs1, g1, p, seed, sid + 1, dg1, db1)
         dg1, db1 = _affine_done(rg1, rb1, dg1, db1, sunk1)
-        if planes:
-            dwo = _plane_wgrad(ro, dao, ctxv)
-            dbo = _bias_grad(rbo, dao)
-            dctx = ops.plane_gemm(ops.split_planes(dao), ops.weight_planes(wo, True), torch.empty_like(ctxv), tile=ops._dense_tile(ntok, hid))
-        else:
-            dwo = _linear_wgrad(ro, dao, ctxv)
-            dbo = _bias_grad(rbo, dao)
-            dctx = ops.linear_dgrad(dao, wo)
+        dwo = _linear_wgrad(ro, dao, ctxv)
+        dbo = _bias_grad(rbo, dao)
+        dctx = ops.linear_dgrad(dao, wo)
         # attention backward (grouped GEMMs + row softmax backward)
         dP = torch.empty_like(P)
         ops.gemm_raw(0, 0, 0, dctx, hid, OP_DENSE_K, qkv, 3 * hid, OP_DENSE_K, dP, meta.ld, grp=meta.t_dp, ngroups=meta.ngroups,
@@ -613,15 +694,9 @@ class BertLayerFn(torch.autograd.Function):
         # QKV projections
         gq = [wgrad_dest(t) for t in (rq, rk, rv, rbq, rbk, rbv)]
         if (all(t is not None for t in gq) and _back_to_back(wq, wk, wv) and _back_to_back(*gq[:3]) and _back_to_back(*gq[3:])):
-            if planes:
-                ops.plane_gemm(ops.split_planes_t(dqkv), ops.split_planes_t(x), _stack3(gq[0]), accumulate=True,
-                               tile=ops._wgrad_tile(3 * hid, hid))
-                ops.colsum(dqkv, out=_stack3(gq[3]), accumulate=True)
-                ops.plane_gemm(ops.split_planes(dqkv), ops.weight_planes(_stack3(wq), True), dx, accumulate=True, tile=ops._dense_tile(ntok, hid))
-            else:
-                ops.linear_wgrad(dqkv, x, _stack3(gq[0]), accumulate=True)
-                ops.colsum(dqkv, out=_stack3(gq[3]), accumulate=True)
-                ops.linear_dgrad(dqkv, _stack3(wq), out=dx, accumulate=True)
+            ops.linear_wgrad(dqkv, x, _stack3(gq[0]), accumulate=True)
+            ops.colsum(dqkv, out=_stack3(gq[3]), accumulate=True)
+            ops.linear_dgrad(dqkv, _stack3(wq), out=dx, accumulate=True)
             for t in (rq, rk, rv, rbq, rbk, rbv):
                 wgrad_done(t)
             return (dx, None, None, None, None, None, None, dwo, dbo, dg1, db1, dwi, dbi, dwo2, dbo2, dg2, db2, None, None, None, None, None)

@@ -109,7 +109,12 @@ class Planes:
 
     @property
     def plane(self):
-        return self.rows * self.ld
+        return self.buf.stride(0)
+
+    def col_block(self, c0, ncols):
+        """the planes of columns [c0, c0 + ncols) as an operand of their own (same rows, row stride and plane stride)"""
+        assert c0 % 8 == 0 and c0 + ncols <= self.ld
+        return Planes(self.buf[:, :, c0:c0 + ncols], self.rows, int(ncols), self.ld)
 
 
 def _ld32(n):
@@ -197,8 +202,6 @@ def plane_gemm_grouped(problems, *, trans=True, accumulate=True, tile=0, alpha=1
 
 _PLANES = [True]
 _W_EPOCH = [0]
-_WCACHE = {}          # (data_ptr, shape, transposed) -> ((epoch, version), Planes); insertion ordered, oldest evicted
-_WCACHE_MAX = 400
 
 
 def set_planes(on: bool):
@@ -216,22 +219,23 @@ def bump_weight_epoch():
     _W_EPOCH[0] += 1
 
 
-def weight_planes(w, transposed=False) -> Planes:
+def weight_planes(owner, transposed=False, view=None, also=()) -> Planes:
     """planes of a 2-D weight [N, K] (transposed: of w^T, the B operand of the data-gradient product), split once per weight
-    version: the optimizer step bumps the epoch, in-place torch ops bump `_version`"""
+    version.  The cache lives ON the parameter object `owner` (it dies with it: a recycled device address can never serve another
+    model's planes); `view`: the matrix to split when it is not `owner` itself (the stacked q/k/v view that starts at `owner`).
+    Stale when the optimizer kernels ran (epoch), torch updated the tensor in place (`_version`) or it moved (data_ptr)."""
+    w = owner if view is None else view
     assert w.dim() == 2 and w.stride(1) == 1 and w.stride(0) == w.shape[1]
-    key = (w.data_ptr(), tuple(w.shape), bool(transposed))
-    tag = (_W_EPOCH[0], w._version)
-    hit = _WCACHE.get(key)
+    cache = owner.__dict__.setdefault("_vbg_wplanes", {})
+    key = (tuple(w.shape), bool(transposed))
+    tag = (_W_EPOCH[0], owner._version, w.data_ptr()) + tuple(t._version for t in also)      # `also`: the other tensors a stacked view covers
+    hit = cache.get(key)
     if hit is not None and hit[0] == tag:
         return hit[1]
     with torch.no_grad():
-        pl = split_planes_t(w.detach(), out=hit[1] if hit is not None else None) if transposed else \
-            split_planes(w.detach(), out=hit[1] if hit is not None else None)
-    _WCACHE.pop(key, None)
-    _WCACHE[key] = (tag, pl)
-    while len(_WCACHE) > _WCACHE_MAX:
-        _WCACHE.pop(next(iter(_WCACHE)))
+        buf = hit[1] if hit is not None else None
+        pl = split_planes_t(w.detach(), out=buf) if transposed else split_planes(w.detach(), out=buf)
+    cache[key] = (tag, pl)
     return pl
 
 
