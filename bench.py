@@ -87,32 +87,43 @@ def build_model(tmp, backbone="resnet_34_fpn_pretrained", layers=12, vocab=VOCAB
 
 
 def cpu_baseline(threads):
-    """The CPU oracle (oracle/vbg_oracle.py: the pinned restatement of the reference's step) timed on this box's
-    host cores on a bounded sample: 4 cfg2-shaped documents, one forward+backward+optimizer step."""
+    """The CPU oracle (oracle/vbg_oracle.py: the pinned restatement of the reference's step, SURVEY.md §8d) timed on this box's
+    host cores on a bounded sample: batches of 2 cfg2-shaped documents, 1 warm-up step + 3 timed steps of forward + backward +
+    SGD / AdamW updates.  `cores` = the box's logical cores, `threads` = what torch was given (more than 16 only adds
+    oversubscription for these op sizes)."""
     sys.path.insert(0, os.path.join(ROOT, "oracle"))
     import vbg_oracle as O
     torch.set_num_threads(threads)
     cfg = O.NetCfg(num_classes=NCLS, backbone="resnet_34_fpn_pretrained", bert=O.BertCfg(layers=12, dropout=0.1))
     sd = O.synth_state_dict(O.state_shapes(cfg, vocab=VOCAB, dup_bert=False))
     sd = {k: (v.requires_grad_(True) if v.is_floating_point() and "running" not in k else v) for k, v in sd.items()}
-    nd = 4
+    nd, warm, steps = 2, 1, 3
     batch = synthetic_batch(nd, 512, 512, 512, 128, NCLS, VOCAB, 4321)
-    random.seed(0)
-    t0 = time.time()
-    loss = O.forward(sd, cfg, *batch, training=True)[0]
-    loss.backward()
-    with torch.no_grad():
-        for k, v in sd.items():
-            if v.grad is None:
-                continue
-            if "bert_model" in k:
-                p, m, vv = O.adamw_step(v, v.grad, torch.zeros_like(v), torch.zeros_like(v), 1, 5e-5, 0.9, 0.999, 1e-8, 0.01)
-            else:
-                p, m = O.sgd_step(v, v.grad, None, 0.005, 0.9, 0.005)
-            v.copy_(p)
-    dt = time.time() - t0
-    return {"value": round(nd / dt, 5), "unit": "docs/sec", "cores": threads, "kind": "port",
-            "sample": f"{nd} documents (cfg2 shape: 512x512, T=512, S=128, r34+bert-base), 1 step fwd+bwd+opt, {dt:.1f} s, torch CPU fp32"}
+    state = {}
+    times = []
+    for it in range(warm + steps):
+        random.seed(it)
+        t0 = time.time()
+        loss = O.forward(sd, cfg, *batch, training=True)[0]
+        loss.backward()
+        with torch.no_grad():
+            for k, v in sd.items():
+                if v.grad is None:
+                    continue
+                if "bert_model" in k:
+                    m, vv = state.get(k, (torch.zeros_like(v), torch.zeros_like(v)))
+                    p, m, vv = O.adamw_step(v, v.grad, m, vv, it + 1, 5e-5, 0.9, 0.999, 1e-8, 0.01)
+                    state[k] = (m, vv)
+                else:
+                    p, m = O.sgd_step(v, v.grad, state.get(k), 0.005, 0.9, 0.005)
+                    state[k] = m
+                v.copy_(p)
+                v.grad = None
+        times.append(time.time() - t0)
+    dt = sum(times[warm:])
+    return {"value": round(nd * steps / dt, 5), "unit": "docs/sec", "cores": os.cpu_count() or 1, "threads": threads, "kind": "port",
+            "sample": f"{steps} timed steps (after {warm} warm-up) of {nd} documents each (cfg2 shape: 512x512, T=512, S=128, r34+bert-base), "
+                      f"fwd+bwd+SGD/AdamW, {dt:.1f} s, torch CPU fp32"}
 
 
 def main():
@@ -131,8 +142,9 @@ def main():
     ap.add_argument("--shape", default="cfg2", choices=["cfg2", "cfg4", "cfg5"],
                     help="cfg2 (default, the BASELINE metric's configuration); cfg4 / cfg5: the other §8 shapes as exploratory runs "
                          "(char-level S=T=512, 12 classes, vocab 21128 / 1024x1024 images), reported under config.workload")
-    ap.add_argument("--h2d", action="store_true", help="include the packed pinned H2D transfer of the batch in every step "
-                    "(PCIe-inclusive rate quoted in DESIGN.md; never the headline value)")
+    ap.add_argument("--h2d", action="store_true", help="make the headline the PCIe-inclusive step (packed pinned H2D transfer of the batch "
+                    "inside every step: SURVEY.md §8d's step body); the default run reports that rate beside the HBM-resident headline")
+    ap.add_argument("--no-h2d-leg", action="store_true", help="skip the PCIe-inclusive leg of the default run")
     args = ap.parse_args()
 
     world = int(os.environ.get("WORLD_SIZE", "1"))
@@ -177,10 +189,9 @@ def main():
     mv = lambda ts: tuple(t.to(dev) for t in ts)
     dbatch = (mv(batch[0]), mv(batch[1]), mv(batch[2]), mv(batch[3]), batch[4].to(dev), batch[5].to(dev))
 
-    packed = None
-    if args.h2d:
-        from vbg.batch import PackedBatch
-        packed = PackedBatch.pack(*batch)
+    from vbg.batch import PackedBatch
+    packed_src = PackedBatch.pack(*batch)
+    use_h2d = [bool(args.h2d)]
 
     amp_on = [bool(args.amp)]
     if args.fp32_mfma:
@@ -189,7 +200,7 @@ def main():
     def step():
         # `amp: True` = the reference's autocast region around the model call (pipeline/train_val_utils.py:264)
         with torch.autocast("cuda", dtype=torch.bfloat16, enabled=amp_on[0]):
-            loss = net(*(packed.to(dev) if packed is not None else dbatch))
+            loss = net(*(packed_src.to(dev) if use_h2d[0] else dbatch))
         val = loss.item()
         opt_cnn.zero_grad()
         opt_bert.zero_grad()
@@ -224,6 +235,32 @@ def main():
         dist.all_reduce(t, op=dist.ReduceOp.MAX)
         dt = float(t.item())
     launches, flops, ms = prof.summary()
+    def timed_leg(n_warm=2):
+        for _ in range(n_warm):
+            step()
+        if world > 1:
+            dist.barrier()
+        torch.cuda.synchronize()
+        t1 = time.perf_counter()
+        for _ in range(args.steps):
+            lv = step()
+        if world > 1:
+            dist.barrier()
+        torch.cuda.synchronize()
+        d = time.perf_counter() - t1
+        if world > 1:
+            tt = torch.tensor([d], device=dev, dtype=torch.float64)
+            dist.all_reduce(tt, op=dist.ReduceOp.MAX)
+            d = float(tt.item())
+        return d, lv
+
+    h2d_leg = None
+    if not args.h2d and not args.no_h2d_leg:      # the same steps with the batch uploaded inside every step (SURVEY §8d step body)
+        use_h2d[0] = True
+        hdt, _ = timed_leg()
+        use_h2d[0] = False
+        h2d_leg = {"value": round(B * world * args.steps / hdt, 3), "unit": "docs/sec", "ms_per_step": round(1e3 * hdt / args.steps, 3),
+                   "bytes_per_step": packed_src.nbytes(), "how": "one pinned packed buffer, one asynchronous H2D copy per step (vbg/batch.py)"}
     amp_leg = None
     if not args.amp and not args.no_amp_leg:      # the same steps with `amp: True` (reported beside the fp32 headline, never as it)
         amp_on[0] = True
@@ -278,11 +315,14 @@ def main():
         ranks_in_sync = bool(torch.equal(lo, hi))
     # HBM-side bytes per launch of the same kernel: rocprofv3 PMC passes of this command (cannot be collected in-process),
     # summarised in profiles/ by the round that produced them; null when the file is absent
-    traffic = None
-    tf = os.path.join(os.path.dirname(os.path.abspath(__file__)), "profiles", "r01_gemm_hbm_traffic.json")
-    if os.path.exists(tf):
-        with open(tf) as fh:
-            traffic = round(float(json.load(fh)["bytes_per_launch"]), 0)
+    traffic, traffic_src = None, None
+    for rnd in ("r02", "r01"):
+        tf = os.path.join(os.path.dirname(os.path.abspath(__file__)), "profiles", f"{rnd}_gemm_hbm_traffic.json")
+        if os.path.exists(tf):
+            with open(tf) as fh:
+                traffic = round(float(json.load(fh)["bytes_per_launch"]), 0)
+            traffic_src = f"profiles/{rnd}_gemm_hbm_traffic.json: rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE passes of this command (counters cannot be read in-process), not this run"
+            break
 
     if rank == 0:
         docs = B * world * args.steps
@@ -302,18 +342,20 @@ def main():
                                     "512x512, T=512 tokens, S=128 segments, batch 8/GPU, fwd+bwd+SGD/AdamW, dropout 0.1, simp classifier")
                        if args.shape == "cfg2" else f"EXPLORATORY {args.shape}: {shape}, T=512, batch {B}/GPU (not the BASELINE metric's configuration)",
                        "global_batch": B * world, "seq_len": 512, "parallelism": f"dp{world}" + ("+syncbn" if sync_bn else ""),
-                       "last_loss": round(float(last), 4), **({"ranks_in_sync": ranks_in_sync} if ranks_in_sync is not None else {}), **({"h2d_in_step": packed.nbytes()} if packed is not None else {})},
+                       "last_loss": round(float(last), 4), **({"ranks_in_sync": ranks_in_sync} if ranks_in_sync is not None else {}), **({"h2d_in_step": packed_src.nbytes()} if args.h2d else {})},
             "step_mfma_frac": round(value / world * {"cfg2": F_STEP_GF, "cfg4": 862.4, "cfg5": 1715.3}[args.shape] / 1e3 / PEAK_F32_TF, 4),
             # the dense NT GEMM runs as the fp32-grade split form: every product is six bf16 MFMA piece products, so the kernel's
             # matrix-core roofline in algorithmic (fp32-equivalent) flops is the bf16 peak / 6; `mfma_rate` is what the pipe executes
             "roofline": {"bound": "mfma",
                          "kernel": ("vbg::gemm_kernel<*,*,*,DENSE_K,DENSE_K,*,1> (bf16 MFMA NT GEMM, amp; every ungrouped launch)" if args.amp else
                                     "vbg::gemm_kernel<*,*,*,DENSE_K,DENSE_K,*,0> (fp32 MFMA NT GEMM; every ungrouped launch)" if args.fp32_mfma else
-                                    "vbg::gemm_kernel<*,*,*,DENSE_K,DENSE_K,*,3> (fp32-grade NT GEMM as 6 bf16 MFMA piece products: BERT linears, 1x1 convs; every ungrouped launch)"),
+                                    "vbg::plane_gemm_kernel<*,*,*,*,*,false> + vbg::gemm_kernel<*,*,*,DENSE_K,DENSE_K,*,3> (fp32-grade NT GEMM as 6 bf16 MFMA piece products: the BERT linears from pre-split bf16 planes, 1x1 convs / heads with the in-kernel split; every ungrouped launch)"),
                          "achieved": round(ach, 2), "peak": round(form_peak, 1), "unit": "TFLOP/s", "frac": round(ach / form_peak, 4),
-                         "traffic": traffic, "launches": launches, "avg_us": round(1e3 * ms / max(launches, 1), 2),
+                         "traffic": traffic, "traffic_source": traffic_src, "launches": launches, "avg_us": round(1e3 * ms / max(launches, 1), 2),
                          "mfma_rate": round(ach * form_products, 1), "vs_fp32_mfma_peak": round(ach / PEAK_F32_TF, 4)},
         }
+        if h2d_leg is not None:
+            out["h2d_inclusive"] = h2d_leg
         if amp_leg is not None:
             out["amp"] = amp_leg
             if fp32_leg is not None:
