@@ -135,9 +135,10 @@ typedef struct vbg_plane_gemm_desc {
 int vbg_plane_gemm(const vbg_plane_gemm_desc* desc, void* stream);
 int vbg_plane_gemm_timed(const vbg_plane_gemm_desc* desc, void* stream, void* start_event, void* stop_event);
 /* x [rows][cols] fp32 (row stride ldx) -> planes [3][rows][ldp] (plane stride `plane` elements), columns cols..ldp-1 zero;
- * relu != 0: the pieces of max(x, 0) */
+ * relu != 0: the pieces of max(x, 0); colsum_accum != NULL: colsum_accum[c] += sum_r x[r][c] in the same pass (the bias gradient
+ * of a linear layer: torch's autograd `grad_output.sum(0)` for F.linear) */
 int vbg_split_planes(const float* x, long long ldx, int rows, int cols, unsigned short* out, int ldp, long long plane, int relu,
-                     void* stream);
+                     float* colsum_accum, void* stream);
 /* x [rows][cols] fp32 -> TRANSPOSED planes [3][cols][ldp], ldp >= rows (multiple of 32), entries rows..ldp-1 zero */
 int vbg_split_planes_t(const float* x, long long ldx, int rows, int cols, unsigned short* out, int ldp, long long plane,
                        void* stream);

@@ -897,7 +897,7 @@ def test_split_planes_exact_and_transposed():
     from vbg import ops
     dev = torch.device("cuda")
     g = torch.Generator().manual_seed(3)
-    for rows, cols in ((5, 7), (64, 96), (130, 770), (1000, 264)):
+    for rows, cols in ((5, 7), (64, 96), (130, 770), (1000, 264), (4128, 2304)):
         x = (torch.randn(rows, cols, generator=g) * torch.exp2(torch.randint(-20, 20, (rows, cols), generator=g).float())).to(dev)
         h, m, l, hf, mf, lf = _bf16_planes_ref(x)
         assert torch.equal(hf + mf + lf, x)                                   # the three pieces are exact: x = hi + mid + lo
@@ -912,6 +912,12 @@ def test_split_planes_exact_and_transposed():
             assert torch.equal(pt.buf[q, :, :rows], ref.t())
         pr = ops.split_planes(x, relu=True)
         assert torch.equal(pr.buf[0, :, :cols], _bf16_planes_ref(x.clamp(min=0))[0])
+        # column sums riding on the split pass (bias gradients): same planes, sums within fp32 summation noise
+        xs = torch.randn(rows, cols, generator=g).to(dev)
+        cs = torch.full((cols,), 2.0, device=dev)
+        pc = ops.split_planes(xs, colsum_out=cs)
+        assert torch.equal(pc.buf, ops.split_planes(xs).buf)
+        assert torch.allclose(cs.double() - 2.0, xs.double().sum(0), rtol=1e-5, atol=1e-5 * rows ** 0.5)
 
 
 @pytest.mark.parametrize("tile", [0, 64064, 128064, 128128, 128129, 128130, 256128])
@@ -982,3 +988,20 @@ def test_plane_gemm_tn_and_grouped_vs_fp64():
     ops.plane_gemm_grouped(probs, trans=True, accumulate=True)
     for (_, _, out), ref in zip(probs, refs):
         assert float((out.double() - 1 - ref).abs().max()) <= 2e-6 * float(ref.abs().max()) * 30
+
+
+def test_ce_label_out_of_range_is_nan_not_oob():
+    """a label >= ncls (misconfigured num_classes) yields a NaN loss and no out-of-bounds access; in-range elements are untouched"""
+    from vbg import ops
+    dev = torch.device("cuda")
+    x = torch.randn(16, 5, device=dev)
+    lab = torch.tensor([0, 1, 2, 3, 4, 5, -1, 2] * 2, dtype=torch.int32, device=dev)
+    elem = torch.arange(16, dtype=torch.int32, device=dev)
+    loss = ops.ce_fwd(x, elem, lab, 16, None, 0, 0, 0)
+    bad = (lab < 0) | (lab >= 5)
+    assert torch.isnan(loss[bad]).all() and torch.isfinite(loss[~bad]).all()
+    ref = torch.nn.functional.cross_entropy(x[~bad], lab[~bad].long(), reduction="none")
+    assert torch.allclose(loss[~bad], ref, rtol=1e-5, atol=1e-6)
+    dl = torch.zeros_like(x)
+    ops.ce_bwd(x, elem, lab, 16, None, torch.ones(1, device=dev), 1.0, 0, 0, 0, dl)
+    assert torch.isfinite(dl).all() and float(dl[bad].abs().max()) == 0.0

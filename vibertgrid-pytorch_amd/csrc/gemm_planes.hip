@@ -398,12 +398,20 @@ __device__ __forceinline__ void pg_split3(float x, unsigned short& h, unsigned s
 }
 
 // x [rows][cols] fp32 (row stride ldx) -> planes [3][rows][ldp] bf16, columns cols..ldp-1 zero.  One thread = 8 columns.
+// colsum != nullptr: colsum[c] += sum_r x[r][c] rides along (the bias gradient of a linear layer is the column sum of the same dy
+// whose planes feed its data- and weight-gradient products).  The host then launches a thread count that is a multiple of the
+// 8-column chunks per row, so a thread keeps ONE chunk for all its rows: 8 register partials, one LDS reduction per block, one
+// global atomic per column and block (<= 288 blocks: same-address atomics serialise at ~0.1 us each).
 __global__ __launch_bounds__(256) void split_planes_kernel(const float* __restrict__ x, long long ldx, int rows, int cols,
-                                                            unsigned short* __restrict__ out, int ldp, long long plane, int relu) {
+                                                            unsigned short* __restrict__ out, int ldp, long long plane, int relu,
+                                                            float* colsum) {
+    extern __shared__ float sh_cols[];
     const int cpr = ldp / 8;
     const long long n = (long long)rows * cpr;
     const long long stride = (long long)gridDim.x * blockDim.x;
-    for (long long i = (long long)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += stride) {
+    float cs[8] = {0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f};
+    const long long i0 = (long long)blockIdx.x * blockDim.x + threadIdx.x;
+    for (long long i = i0; i < n; i += stride) {
         const int r = (int)(i / cpr), c = (int)(i % cpr) * 8;
         float e[8];
         if (c + 8 <= cols && ((ldx & 3) == 0) && ((((uintptr_t)x) & 15) == 0)) {
@@ -416,7 +424,10 @@ __global__ __launch_bounds__(256) void split_planes_kernel(const float* __restri
         }
         unsigned short h[8], m[8], l[8];
 #pragma unroll
-        for (int t = 0; t < 8; ++t) pg_split3(relu ? fmaxf(e[t], 0.f) : e[t], h[t], m[t], l[t]);
+        for (int t = 0; t < 8; ++t) {
+            cs[t] += e[t];
+            pg_split3(relu ? fmaxf(e[t], 0.f) : e[t], h[t], m[t], l[t]);
+        }
         unsigned short* o = out + (long long)r * ldp + c;
         auto pack = [](const unsigned short* s) {
             return make_uint4(s[0] | ((unsigned)s[1] << 16), s[2] | ((unsigned)s[3] << 16), s[4] | ((unsigned)s[5] << 16), s[6] | ((unsigned)s[7] << 16));
@@ -424,6 +435,20 @@ __global__ __launch_bounds__(256) void split_planes_kernel(const float* __restri
         *reinterpret_cast<uint4*>(o) = pack(h);
         *reinterpret_cast<uint4*>(o + plane) = pack(m);
         *reinterpret_cast<uint4*>(o + 2 * plane) = pack(l);
+    }
+    if (colsum) {                                        // (uniform)
+        for (int c = threadIdx.x; c < ldp; c += blockDim.x) sh_cols[c] = 0.f;
+        __syncthreads();
+        if (i0 < n) {
+            const int c = (int)(i0 % cpr) * 8;           // the chunk this thread kept (stride % cpr == 0)
+#pragma unroll
+            for (int t = 0; t < 8; ++t) atomicAdd(&sh_cols[c + t], cs[t]);
+        }
+        __syncthreads();
+        for (int c = threadIdx.x; c < cols; c += blockDim.x) {
+            const float v = sh_cols[c];
+            if (v != 0.f) unsafeAtomicAdd(colsum + c, v);
+        }
     }
 }
 
@@ -549,14 +574,31 @@ extern "C" int vbg_plane_gemm_timed(const vbg_plane_gemm_desc* desc, void* strea
 }
 
 extern "C" int vbg_split_planes(const float* x, long long ldx, int rows, int cols, unsigned short* out, int ldp, long long plane,
-                                int relu, void* stream) {
+                                int relu, float* colsum_accum, void* stream) {
     VBG_CHECK_ARG(rows >= 0 && cols >= 0 && ldp % 32 == 0 && ldp >= cols && plane >= (long long)rows * ldp && plane % 8 == 0);
     if (rows == 0 || cols == 0) return VBG_OK;
     VBG_CHECK_ARG(x && out && ((uintptr_t)out & 15) == 0);
     const long long n = (long long)rows * (ldp / 8);
     long long g = (n + 255) / 256;
-    if (g > 256 * 16) g = 256 * 16;
-    VBG_LAUNCH(split_planes_kernel, dim3((unsigned)g), dim3(256), 0, (hipStream_t)stream, x, ldx, rows, cols, out, ldp, plane, relu);
+    size_t lds = 0;
+    if (colsum_accum) {
+        VBG_CHECK_ARG(relu == 0 && ldp * 4 <= 64 * 1024);
+        // thread count = a multiple of the chunks per row (every thread keeps one 8-column chunk), ~288 blocks at most
+        const long long cpr = ldp / 8;
+        long long a = cpr, b = 256;
+        while (b) { const long long t = a % b; a = b; b = t; }
+        const long long unit = cpr / a;                  // blocks per multiple of cpr threads
+        long long k = 288 / unit;
+        if (k < 1) k = 1;
+        const long long need = (g + unit - 1) / unit;
+        if (k > need) k = need;
+        g = k * unit;
+        lds = (size_t)ldp * 4;
+    } else if (g > 256 * 16) {
+        g = 256 * 16;
+    }
+    VBG_LAUNCH(split_planes_kernel, dim3((unsigned)g), dim3(256), lds, (hipStream_t)stream, x, ldx, rows, cols, out, ldp, plane, relu,
+               colsum_accum);
     VBG_LAUNCH_RET();
 }
 

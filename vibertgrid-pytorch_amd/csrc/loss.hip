@@ -29,8 +29,6 @@ __device__ __forceinline__ long long ce_row(long long e, int up_shift, int H, in
     return (b * (H >> up_shift) + (y >> up_shift)) * (W >> up_shift) + (x >> up_shift);
 }
 
-constexpr int CE_MAXC = 32;
-
 __global__ void ce_fwd_kernel(const float* __restrict__ logits, long long ld, int ncls, const int* __restrict__ elem,
                               const int* __restrict__ labels, long long n, const float* __restrict__ weight, int up_shift,
                               int H, int W, float* __restrict__ loss) {
@@ -38,6 +36,9 @@ __global__ void ce_fwd_kernel(const float* __restrict__ logits, long long ld, in
     for (long long i = (long long)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += stride) {
         const long long e = elem ? elem[i] : i;
         const int t = labels[e];
+        // a label outside [0, ncls) (num_classes / tag_to_idx misconfiguration) must not index logits or weights: the loss
+        // becomes NaN -- visible to the caller like torch's device assert -- and backward skips the element
+        if ((unsigned)t >= (unsigned)ncls) { loss[i] = __int_as_float(0x7fc00000); continue; }
         const float* x = logits + ce_row(e, up_shift, H, W) * ld;
         float mx = x[0];
         for (int c = 1; c < ncls; ++c) mx = fmaxf(mx, x[c]);
@@ -56,6 +57,7 @@ __global__ void ce_bwd_kernel(const float* __restrict__ logits, long long ld, in
     for (long long i = (long long)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += stride) {
         const long long e = elem ? elem[i] : i;
         const int t = labels[e];
+        if ((unsigned)t >= (unsigned)ncls) continue;
         const long long row = ce_row(e, up_shift, H, W);
         const float* x = logits + row * ld;
         float mx = x[0];

@@ -160,7 +160,9 @@ class BERTgridGenerator(nn.Module):
         pa = float(cfg.attention_probs_dropout_prob) if self.training else 0.0
         assert abs(p - pa) < 1e-12 or not self.training, "hidden and attention dropout rates must match"
         self._step_seed += 1
-        seed = self._step_seed * 0x9E3779B1 + (torch.initial_seed() & 0xFFFFFFFF)
+        # per step, per rank (data-parallel ranks seeded alike must not share dropout masks) and per torch seed
+        rank = torch.distributed.get_rank() if (torch.distributed.is_available() and torch.distributed.is_initialized()) else 0
+        seed = self._step_seed * 0x9E3779B1 + (torch.initial_seed() & 0xFFFFFFFF) + rank * 0x85EBCA6B
         eps = float(cfg.layer_norm_eps)
         x = Fn.BertEmbedFn.apply(emb.word_embeddings.weight, emb.position_embeddings.weight, emb.token_type_embeddings.weight,
                                  emb.LayerNorm.weight, emb.LayerNorm.bias, ids, pos, eps, p, seed, 1000)

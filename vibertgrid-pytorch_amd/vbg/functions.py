@@ -95,6 +95,16 @@ def _linear_wgrad(w_param, dy, x):
     return dw
 
 
+def _split_with_bias_grad(b_param, dy2d):
+    """(planes of dy, bias gradient): the column sums ride on the split pass when the bias gradient is sunk into the flat buffer"""
+    dst = wgrad_dest(b_param)
+    if dst is not None:
+        pl = ops.split_planes(dy2d, colsum_out=dst)
+        wgrad_done(b_param)
+        return pl, None
+    return ops.split_planes(dy2d), ops.colsum(dy2d)
+
+
 def _plane_wgrad(w_param, dy, x):
     """dW = dy^T x from transposed planes (both operands K-contiguous along the token index); into the flat gradient buffer when
     the parameter is sunk (returns None), else a fresh tensor"""
@@ -585,18 +595,15 @@ class BertLayerFn(torch.autograd.Function):
         dg2, db2, sunk2 = _affine_dest(rg2, rb2)
         dfo, dx1 = ops.dropout_add_ln_bwd(_c(dy), xh2, rs2, g2, p, seed, sid + 2, dg2, db2)
         dg2, db2 = _affine_done(rg2, rb2, dg2, db2, sunk2)
-        pdfo = ops.split_planes(dfo)
-        dbo2 = _bias_grad(rbo2, dfo)
+        pdfo, dbo2 = _split_with_bias_grad(rbo2, dfo)
         dh_ = ops.plane_gemm(pdfo, ops.weight_planes(ro2, True, view=wo2), torch.empty_like(h), tile=ops._dense_tile(ntok, inter, True))
         ops.gelu_bwd_(h, dh_)
-        pdh = ops.split_planes(dh_)
-        dbi = _bias_grad(rbi, dh_)
+        pdh, dbi = _split_with_bias_grad(rbi, dh_)
         ops.plane_gemm(pdh, ops.weight_planes(ri, True, view=wi), dx1, accumulate=True, tile=ops._dense_tile(ntok, hid))
         dg1, db1, sunk1 = _affine_dest(rg1, rb1)
         dao, dx = ops.dropout_add_ln_bwd(dx1, xh1, rs1, g1, p, seed, sid + 1, dg1, db1)
         dg1, db1 = _affine_done(rg1, rb1, dg1, db1, sunk1)
-        pdao = ops.split_planes(dao)
-        dbo = _bias_grad(rbo, dao)
+        pdao, dbo = _split_with_bias_grad(rbo, dao)
         dctx = ops.plane_gemm(pdao, ops.weight_planes(ro, True, view=wo), torch.empty((ntok, hid), device=dev, dtype=f32), tile=ops._dense_tile(ntok, hid))
         dP = torch.empty_like(P)
         ops.gemm_raw(0, 0, 0, dctx, hid, OP_DENSE_K, qkv, 3 * hid, OP_DENSE_K, dP, meta.ld, grp=meta.t_dp, ngroups=meta.ngroups,
@@ -609,8 +616,10 @@ class BertLayerFn(torch.autograd.Function):
                      grp_max=(meta.maxlen, dh), b_ptr_off=hid)
         ops.gemm_raw(0, 0, 0, dP, meta.ld, OP_DENSE_R, qkv, 3 * hid, OP_DENSE_R, dqkv, 3 * hid, grp=meta.t_dk, ngroups=meta.ngroups,
                      grp_max=(meta.maxlen, dh), c_ptr_off=hid)
-        pdqkv = ops.split_planes(dqkv)
         stacked = _back_to_back(wq, wk, wv)
+        gq = [wgrad_dest(t) for t in (rq, rk, rv, rbq, rbk, rbv)]
+        qkv_sunk = stacked and all(t is not None for t in gq) and _back_to_back(*gq[:3]) and _back_to_back(*gq[3:])
+        pdqkv = ops.split_planes(dqkv, colsum_out=_stack3(gq[3]) if qkv_sunk else None)
         if stacked:
             ops.plane_gemm(pdqkv, ops.weight_planes(rq, True, view=_stack3(wq), also=(rk, rv)), dx, accumulate=True, tile=ops._dense_tile(ntok, hid))
         else:
@@ -618,8 +627,6 @@ class BertLayerFn(torch.autograd.Function):
                 ops.plane_gemm(pdqkv.col_block(j * hid, hid), ops.weight_planes(wr, True, view=w), dx, accumulate=True, tile=ops._dense_tile(ntok, hid))
         # ---- the four weight gradients: one grouped TN launch (432 tiles at bert-base: two rounds on 256 CUs instead of four
         #      launches of 36-144 tiles each) ------------------------------------------------------------------------------
-        gq = [wgrad_dest(t) for t in (rq, rk, rv, rbq, rbk, rbv)]
-        qkv_sunk = stacked and all(t is not None for t in gq) and _back_to_back(*gq[:3]) and _back_to_back(*gq[3:])
         dw_qkv = _stack3(gq[0]) if qkv_sunk else torch.zeros((3 * hid, hid), device=dev, dtype=f32)
         dests, fresh = [], []
         for wp in (ro2, ri, ro):
@@ -632,7 +639,6 @@ class BertLayerFn(torch.autograd.Function):
                 wgrad_done(wp)
         dwo2, dwi, dwo = (dests[i] if fresh[i] else None for i in range(3))
         if qkv_sunk:
-            ops.colsum(dqkv, out=_stack3(gq[3]), accumulate=True)
             for t in (rq, rk, rv, rbq, rbk, rbv):
                 wgrad_done(t)
             return (dx, None, None, None, None, None, None, dwo, dbo, dg1, db1, dwi, dbi, dwo2, dbo2, dg2, db2, None, None, None, None, None)
@@ -774,3 +780,35 @@ class SelectedCEFn(torch.autograd.Function):
         g = _c(dout).to(f32).view(1)
         ops.ce_bwd(logits2d, elem, labels, n, weight, g, scale, up_shift, H, W, dl)
         return dl, None, None, None, None, None, None, None
+
+
+# ----------------------------------------------------------------------------------------------
+# The arithmetic form (amp latch, split / fp32 precision) a Function's FORWARD ran with is the one its BACKWARD runs with:
+# both are recorded on ctx and re-established around backward, so an eval / inference forward of this or another model between
+# a training forward and its backward (or a second model under a different autocast setting) cannot switch the backward's
+# products to another form.
+# ----------------------------------------------------------------------------------------------
+def _pin_arithmetic(cls):
+    fwd, bwd = cls.forward, cls.backward
+
+    def forward(ctx, *a, **k):
+        ctx._vbg_form = (ops.amp_enabled(), ops.precision())
+        return fwd(ctx, *a, **k)
+
+    def backward(ctx, *g):
+        amp, prec = ctx._vbg_form
+        prev_amp, prev_prec = ops.amp_enabled(), ops.precision()
+        ops.set_amp(amp)
+        ops.set_precision(prec)
+        try:
+            return bwd(ctx, *g)
+        finally:
+            ops.set_amp(prev_amp)
+            ops.set_precision(prev_prec)
+
+    cls.forward, cls.backward = staticmethod(forward), staticmethod(backward)
+
+
+for _name, _obj in list(globals().items()):
+    if isinstance(_obj, type) and issubclass(_obj, torch.autograd.Function) and _obj is not torch.autograd.Function:
+        _pin_arithmetic(_obj)

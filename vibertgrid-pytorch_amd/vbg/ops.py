@@ -126,12 +126,13 @@ def planes_empty(rows, cols, device):
     return Planes(torch.empty((3, rows, ld), device=device, dtype=torch.int16), int(rows), int(cols), ld)
 
 
-def split_planes(x, relu=False, out=None):
-    """x [rows, cols] fp32 (last dim contiguous) -> Planes of x (rows = GEMM rows, cols = reduction index)"""
+def split_planes(x, relu=False, out=None, colsum_out=None):
+    """x [rows, cols] fp32 (last dim contiguous) -> Planes of x (rows = GEMM rows, cols = reduction index).
+    colsum_out [cols] fp32: += the column sums of x in the same pass (bias gradients)."""
     assert x.dim() == 2 and x.stride(1) == 1 and x.dtype == f32
     rows, cols = x.shape
     o = out if out is not None else planes_empty(rows, cols, x.device)
-    check(lib.vbg_split_planes(P(x), x.stride(0), rows, cols, P(o.buf), o.ld, o.plane, int(relu), _stream()), "vbg_split_planes")
+    check(lib.vbg_split_planes(P(x), x.stride(0), rows, cols, P(o.buf), o.ld, o.plane, int(relu), P(colsum_out), _stream()), "vbg_split_planes")
     return o
 
 
