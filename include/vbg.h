@@ -142,6 +142,12 @@ int vbg_split_planes(const float* x, long long ldx, int rows, int cols, unsigned
 /* x [rows][cols] fp32 -> TRANSPOSED planes [3][cols][ldp], ldp >= rows (multiple of 32), entries rows..ldp-1 zero */
 int vbg_split_planes_t(const float* x, long long ldx, int rows, int cols, unsigned short* out, int ldp, long long plane,
                        void* stream);
+/* many matrices of one fp32 buffer in one launch: tbl_dev = device int64 [njobs][6] = {source offset (elements), rows, cols,
+ * destination offset (elements), ldp (multiple of 32, >= rows), index of the job's first 64 x 64 tile}; job j writes the planes of
+ * its matrix TRANSPOSED ([3][cols][ldp]) at dst + offset, plane stride `plane` for all jobs.  (The W^T planes of every weight of a
+ * flat parameter buffer, refreshed once per optimizer step.) */
+int vbg_split_planes_t_batched(const float* src, unsigned short* dst, const long long* tbl_dev, int njobs, int total_tiles,
+                               long long plane, void* stream);
 
 /* column sums: out[n] (+)= sum_m x[m*ld + n]   (bias gradients) */
 int vbg_colsum(const float* x, long long ld, int M, int N, float* out, int accumulate, void* stream);

@@ -494,6 +494,53 @@ __global__ __launch_bounds__(256) void split_planes_t_kernel(const float* __rest
     }
 }
 
+// batched transposing split: job j = matrix [rows_j][cols_j] fp32 at src + soff_j -> transposed planes [3][cols_j][ldp_j] at
+// dst + doff_j (plane stride `plane` elements for every job: one flat plane buffer), tiles of 64 x 64; tbl = int64 [njobs][6]:
+// soff, rows, cols, doff, ldp, first tile.  The weights of a whole flat parameter buffer in ONE launch (their W^T planes are the
+// B operands of the data-gradient products), refreshed once per optimizer step.
+__global__ __launch_bounds__(256) void split_planes_t_batched_kernel(const float* __restrict__ src, unsigned short* __restrict__ dst,
+                                                                      const long long* __restrict__ tbl, int njobs, long long plane) {
+    __shared__ float t[64][65];
+    int j = 0;
+    while (j + 1 < njobs && (long long)blockIdx.x >= tbl[(j + 1) * 6 + 5]) ++j;
+    const long long* e = tbl + j * 6;
+    const float* x = src + e[0];
+    const int rows = (int)e[1], cols = (int)e[2], ldp = (int)e[4];
+    unsigned short* out = dst + e[3];
+    const int local = (int)(blockIdx.x - e[5]);
+    const int tr = (ldp + 63) / 64;
+    const int r0 = (local % tr) * 64, c0 = (local / tr) * 64;
+    const int tid = threadIdx.x;
+    const long long ldx = cols;
+#pragma unroll
+    for (int i = 0; i < 4; ++i) {
+        const int f = tid + i * 256, r = f / 16, c = (f % 16) * 4;
+        float v[4] = {0.f, 0.f, 0.f, 0.f};
+        if (r0 + r < rows) {
+#pragma unroll
+            for (int q = 0; q < 4; ++q)
+                if (c0 + c + q < cols) v[q] = x[(long long)(r0 + r) * ldx + c0 + c + q];
+        }
+        t[r][c] = v[0]; t[r][c + 1] = v[1]; t[r][c + 2] = v[2]; t[r][c + 3] = v[3];
+    }
+    __syncthreads();
+#pragma unroll
+    for (int i = 0; i < 2; ++i) {
+        const int f = tid + i * 256, c = f / 8, rg = (f % 8) * 8;
+        if (c0 + c >= cols || r0 + rg >= ldp) continue;
+        unsigned short h[8], m[8], l[8];
+#pragma unroll
+        for (int q = 0; q < 8; ++q) pg_split3(t[rg + q][c], h[q], m[q], l[q]);
+        unsigned short* o = out + (long long)(c0 + c) * ldp + r0 + rg;
+        auto pack = [](const unsigned short* s) {
+            return make_uint4(s[0] | ((unsigned)s[1] << 16), s[2] | ((unsigned)s[3] << 16), s[4] | ((unsigned)s[5] << 16), s[6] | ((unsigned)s[7] << 16));
+        };
+        *reinterpret_cast<uint4*>(o) = pack(h);
+        *reinterpret_cast<uint4*>(o + plane) = pack(m);
+        *reinterpret_cast<uint4*>(o + 2 * plane) = pack(l);
+    }
+}
+
 template <int BM, int BN, int WGM, int WGN, int NST, bool TRANS = false>
 static void pg_launch(const vbg_plane_gemm_desc& d, hipStream_t s, hipEvent_t e0, hipEvent_t e1) {
     dim3 g(cdiv(d.M, BM), cdiv(d.N, BN), d.splitk);
@@ -608,5 +655,14 @@ extern "C" int vbg_split_planes_t(const float* x, long long ldx, int rows, int c
     if (rows == 0 || cols == 0) return VBG_OK;
     VBG_CHECK_ARG(x && out && ((uintptr_t)out & 15) == 0);
     VBG_LAUNCH(split_planes_t_kernel, dim3(cdiv(ldp, 64), cdiv(cols, 64)), dim3(256), 0, (hipStream_t)stream, x, ldx, rows, cols, out, ldp, plane);
+    VBG_LAUNCH_RET();
+}
+
+extern "C" int vbg_split_planes_t_batched(const float* src, unsigned short* dst, const long long* tbl_dev, int njobs, int total_tiles,
+                                          long long plane, void* stream) {
+    VBG_CHECK_ARG(njobs >= 0 && total_tiles >= 0);
+    if (njobs == 0 || total_tiles == 0) return VBG_OK;
+    VBG_CHECK_ARG(src && dst && tbl_dev && ((uintptr_t)dst & 15) == 0 && plane % 8 == 0);
+    VBG_LAUNCH(split_planes_t_batched_kernel, dim3(total_tiles), dim3(256), 0, (hipStream_t)stream, src, dst, tbl_dev, njobs, plane);
     VBG_LAUNCH_RET();
 }

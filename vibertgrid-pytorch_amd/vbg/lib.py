@@ -65,6 +65,7 @@ SIGNATURES = {
     "vbg_plane_gemm_timed": (c_int, [C.POINTER(PlaneGemmDesc), c_vp, c_vp, c_vp]),
     "vbg_split_planes": (c_int, [c_vp, c_ll, c_int, c_int, c_vp, c_int, c_ll, c_int, c_vp, c_vp]),
     "vbg_split_planes_t": (c_int, [c_vp, c_ll, c_int, c_int, c_vp, c_int, c_ll, c_vp]),
+    "vbg_split_planes_t_batched": (c_int, [c_vp, c_vp, c_vp, c_int, c_int, c_ll, c_vp]),
     "vbg_colsum": (c_int, [c_vp, c_ll, c_int, c_int, c_vp, c_int, c_vp]),
     "vbg_im2col": (c_int, [c_vp, c_int, c_int, c_int, c_int, c_int, c_int, c_int, c_int, c_int, c_vp, c_vp]),
     "vbg_normalize_resize": (c_int, [c_vp, c_int, c_int, c_int, c_int, C.POINTER(c_f), C.POINTER(c_f), c_vp, c_int, c_int, c_int, c_vp]),

@@ -136,6 +136,12 @@ def split_planes(x, relu=False, out=None, colsum_out=None):
     return o
 
 
+def split_planes_t_batched(src_flat, dst_planes, tbl_dev, njobs, total_tiles):
+    """transposed planes of many matrices of one fp32 buffer in one launch (table layout: include/vbg.h)"""
+    check(lib.vbg_split_planes_t_batched(P(src_flat), P(dst_planes), P(tbl_dev), int(njobs), int(total_tiles), dst_planes.stride(0), _stream()),
+          "vbg_split_planes_t_batched")
+
+
 def split_planes_t(x, out=None):
     """x [rows, cols] fp32 -> Planes of x^T ([cols, rows]: the reduction index becomes x's row index)"""
     assert x.dim() == 2 and x.stride(1) == 1 and x.dtype == f32
@@ -227,6 +233,15 @@ def weight_planes(owner, transposed=False, view=None, also=()) -> Planes:
     Stale when the optimizer kernels ran (epoch), torch updated the tensor in place (`_version`) or it moved (data_ptr)."""
     w = owner if view is None else view
     assert w.dim() == 2 and w.stride(1) == 1 and w.stride(0) == w.shape[1]
+    flat = getattr(owner, "_vbg_flat", None)
+    if flat is not None and flat[0].pflat.data_ptr() + 4 * flat[1] == w.data_ptr():
+        # the parameter lives in a flat buffer (vbg/optim.FlatGroup): its planes are a view of the buffer's plane image, which one
+        # launch per optimizer step refreshes for all weights
+        g, off = flat
+        ver = (owner._version,) + tuple(t._version for t in also)
+        pl = g.planes_t_of(off, w.shape[0], w.shape[1], ver) if transposed else g.planes_of(off, w.shape[0], w.shape[1], ver)
+        if pl is not None:
+            return pl
     cache = owner.__dict__.setdefault("_vbg_wplanes", {})
     key = (tuple(w.shape), bool(transposed))
     tag = (_W_EPOCH[0], owner._version, w.data_ptr()) + tuple(t._version for t in also)      # `also`: the other tensors a stacked view covers

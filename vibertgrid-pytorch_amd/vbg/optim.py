@@ -73,12 +73,13 @@ class FlatGroup:
         self.names = [n for n, _ in named]
         self.params = [p for _, p in named]
         sizes = [p.numel() for p in self.params]
-        # 16-byte aligned slots so float4 kernels and vector GEMM loads stay legal on every view
+        # 32-byte aligned slots: float4 kernels / vector GEMM loads stay legal on every view, and the same offsets address the
+        # bf16 plane image of the buffer 16-byte aligned (LDS-DMA rows)
         self.offsets, o = [], 0
         for s in sizes:
             self.offsets.append(o)
-            o += (s + 3) // 4 * 4
-        self.total = o
+            o += (s + 7) // 8 * 8
+        self.total = (o + 31) // 32 * 32
         self.pflat = torch.zeros((self.total,), device=device, dtype=torch.float32)
         self.gflat = torch.zeros((self.total,), device=device, dtype=torch.float32)
         for p, off in zip(self.params, self.offsets):
@@ -87,12 +88,75 @@ class FlatGroup:
             p.data = v
             p.grad = _phys_view(self.gflat, off, p.data)
             p._vbg_sunk = True               # weight-gradient GEMMs accumulate straight into this view
+            p._vbg_flat = (self, off)
+        # bf16 planes of the whole buffer (csrc/gemm_planes.hip operands), refreshed at most once per parameter version: the plain
+        # image [3][total] in ONE elementwise launch, the transposed images of the matrices that asked for one in ONE batched launch
+        self._planes = None
+        self._planes_tag = None
+        self._t_jobs = {}                    # (offset, rows, cols) -> (slot offset, ld)
+        self._t_buf = None
+        self._t_tbl = None
+        self._t_tag = None
+        self._ver = {}
 
     def zero_grad(self):
         self.gflat.zero_()
         for p, off in zip(self.params, self.offsets):       # re-attach if something set grads to None
             if p.grad is None or p.grad.data_ptr() != self.gflat.data_ptr() + 4 * off:
                 p.grad = _phys_view(self.gflat, off, p.data)
+
+    def _tag(self):
+        return (ops._W_EPOCH[0], self.pflat._version)
+
+    def _stale(self, which: str, off: int, ver) -> bool:
+        """refresh needed?  The optimizer kernels bump the epoch; torch in-place updates of a parameter (load_state_dict, tests) bump
+        that parameter's own version counter, which is checked per request against the version seen at the last refresh."""
+        seen = self._ver.setdefault(which, {})
+        if (self._planes_tag if which == "p" else self._t_tag) != self._tag() or seen.get(off, ver) != ver:
+            seen.clear()
+            seen[off] = ver
+            return True
+        seen[off] = ver
+        return False
+
+    def planes_of(self, off: int, rows: int, cols: int, ver=0):
+        """plane operand of the matrix [rows, cols] stored at element offset `off` of the parameter buffer (None if its layout does not
+        allow it)"""
+        if cols % 32 or off % 8:
+            return None
+        if self._planes is None:
+            self._planes = torch.empty((3, self.total), device=self.pflat.device, dtype=torch.int16)
+        if self._stale("p", off, ver):
+            with torch.no_grad():
+                ops.split_planes(self.pflat.detach().view(-1, 32), out=ops.Planes(self._planes.view(3, -1, 32), self.total // 32, 32, 32))
+            self._planes_tag = self._tag()
+        return ops.Planes(self._planes[:, off:off + rows * cols].view(3, rows, cols), rows, cols, cols)
+
+    def planes_t_of(self, off: int, rows: int, cols: int, ver=0):
+        """plane operand of the TRANSPOSE of that matrix ([cols, rows], reduction over rows)"""
+        if off % 8:
+            return None
+        key = (off, rows, cols)
+        if key not in self._t_jobs:
+            ld = (rows + 31) // 32 * 32
+            slot = sum(c * l for (_, _, c), (_, l) in self._t_jobs.items())
+            self._t_jobs[key] = (slot, ld)
+            self._t_tbl = None
+        if self._t_tbl is None:
+            tot = sum(c * l for (_, _, c), (_, l) in self._t_jobs.items())
+            self._t_buf = torch.empty((3, (tot + 7) // 8 * 8), device=self.pflat.device, dtype=torch.int16)
+            rows_, first = [], 0
+            for (o, r, c), (slot, ld) in self._t_jobs.items():
+                rows_.append([o, r, c, slot, ld, first])
+                first += ((ld + 63) // 64) * ((c + 63) // 64)
+            self._t_tiles = first
+            self._t_tbl = torch.tensor(rows_, dtype=torch.int64).to(self.pflat.device)
+            self._t_tag = None
+        if self._stale("t", off, ver):
+            ops.split_planes_t_batched(self.pflat, self._t_buf, self._t_tbl, len(self._t_jobs), self._t_tiles)
+            self._t_tag = self._tag()
+        slot, ld = self._t_jobs[key]
+        return ops.Planes(self._t_buf[:, slot:slot + cols * ld].view(3, cols, ld), cols, rows, ld)
 
     def view(self, flat: torch.Tensor, i: int) -> torch.Tensor:
         """parameter i's slice of another flat buffer of this layout (optimizer state), shaped / laid out like the parameter"""
