@@ -1,9 +1,11 @@
 #!/usr/bin/env python3
-"""Summarise the rocprofv3 runs of gpurun_out/ into the committed profiles/ (round-1 names).
+"""Summarise the rocprofv3 runs of gpurun_out/ into the committed profiles/ (names carry the round tag).
 
 expects: gpurun_out/prof_e (kernel-trace + stats of `bench.py --steps 10 --warmup 3`), gpurun_out/pmc_f / pmc_w (FETCH_SIZE / WRITE_SIZE
 passes of `bench.py --steps 3 --warmup 1`), gpurun_out/gemm_shapes.txt, gpurun_out/bench_line.json"""
 import collections, csv, json, os, re, shutil, subprocess, sys
+TAG = sys.argv[1] if len(sys.argv) > 1 else "r02"          # round tag of the output names
+NSTEP = int(sys.argv[2]) if len(sys.argv) > 2 else 13       # steps in the kernel trace of prof_e (bench.py --steps 10 --warmup 3 --no-h2d-leg)
 R = os.path.dirname(os.path.dirname(os.path.abspath(__file__))) + "/"
 G = R + "gpurun_out/"
 
@@ -37,16 +39,16 @@ tot_f = sum(2 * v[1] * 1024 for v in f.values()) / 4
 tot_w = sum(v[1] * 1024 for v in w.values()) / 4
 lines.append(f"# all GEMM launches: fetch {tot_f / 1e9:.1f} GB + write {tot_w / 1e9:.1f} GB per step (before the XCD-aware block->tile map: fetch 112.7 GB per step)")
 lines.append(f"# ungrouped dense NT GEMM (A0 B0; the launches bench.py's roofline times): {n / 4:.0f} launches/step, fetch {nf / n / 1e6:.1f} MB + write {nw / n / 1e6:.1f} MB per launch")
-open(R + 'profiles/r01_gemm_hbm_traffic.txt', 'w').write("\n".join(lines) + "\n")
+open(R + 'profiles/' + TAG + '_gemm_hbm_traffic.txt', 'w').write("\n".join(lines) + "\n")
 json.dump({"kernel": "vbg::gemm_kernel<*,*,*,DENSE_K,DENSE_K> (every ungrouped dense NT launch of one bench step: the launches bench.py times)",
            "launches_per_step": n / 4, "fetch_bytes_per_launch": nf / n, "write_bytes_per_launch": nw / n, "bytes_per_launch": (nf + nw) / n,
-           "source": "profiles/r01_gemm_hbm_traffic.txt (rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE, separate passes; FETCH_SIZE x2 gfx950 correction; L2 misses incl. Infinity-Cache hits)"},
-          open(R + 'profiles/r01_gemm_hbm_traffic.json', 'w'), indent=1)
+           "source": "profiles/' + TAG + '_gemm_hbm_traffic.txt (rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE, separate passes; FETCH_SIZE x2 gfx950 correction; L2 misses incl. Infinity-Cache hits)"},
+          open(R + 'profiles/' + TAG + '_gemm_hbm_traffic.json', 'w'), indent=1)
 print(lines[-2]); print(lines[-1])
-shutil.copy(G + 'prof_e/e_kernel_stats.csv', R + 'profiles/r01_bench_kernel_stats.csv')
-shutil.copy(G + 'prof_e/e_domain_stats.csv', R + 'profiles/r01_bench_domain_stats.csv')
-shutil.copy(G + 'gemm_shapes.txt', R + 'profiles/r01_gemm_shapes.txt')
-shutil.copy(G + 'bench_line.json', R + 'profiles/r01_bench_line.json')
+shutil.copy(G + 'prof_e/e_kernel_stats.csv', R + 'profiles/' + TAG + '_bench_kernel_stats.csv')
+shutil.copy(G + 'prof_e/e_domain_stats.csv', R + 'profiles/' + TAG + '_bench_domain_stats.csv')
+shutil.copy(G + 'gemm_shapes.txt', R + 'profiles/' + TAG + '_gemm_shapes.txt')
+shutil.copy(G + 'bench_line.json', R + 'profiles/' + TAG + '_bench_line.json')
 # ---- MFMA utilisation per instantiation (gpurun_out/pmc_m: SQ_VALU_MFMA_BUSY_CYCLES ... GRBM_GUI_ACTIVE pass of `bench.py --steps 3 --warmup 1`)
 if os.path.exists(G + 'pmc_m/m_counter_collection.csv'):
     disp = collections.OrderedDict()
@@ -77,17 +79,17 @@ if os.path.exists(G + 'pmc_m/m_counter_collection.csv'):
         out.append(f"{k[0]}x{k[1]}x{k[2]},{names[k[3]]},{names[k[4]]},{k[5]},prec{k[6]},{a_['n'] / 4:.1f},{a_['ns'] / 4 / 1e6:.3f},{clk:.2f},{a_['SQ_VALU_MFMA_BUSY_CYCLES'] / cap:.3f},"
                    f"{a_['SQ_WAIT_ANY'] / wc:.3f},{a_['SQ_WAIT_INST_ANY'] / wc:.3f},{a_['SQ_ACTIVE_INST_ANY'] / wc:.3f},{a_['SQ_LDS_BANK_CONFLICT']:.0f}")
     out.append(f"# all GEMM / conv kernels of the step: MFMA pipe busy {tb / tc:.3f} of the time they run")
-    open(R + 'profiles/r01_gemm_mfma_util.txt', 'w').write("\n".join(out) + "\n")
+    open(R + 'profiles/' + TAG + '_gemm_mfma_util.txt', 'w').write("\n".join(out) + "\n")
     print(out[-1])
-tab = subprocess.run([sys.executable, R + 'tools/hbm_table.py', G + 'prof_e/e_kernel_trace.csv', '13'], capture_output=True, text=True).stdout
-open(R + 'profiles/r01_hbm_kernels.txt', 'w').write("# tools/hbm_table.py over the kernel trace of `bench.py --steps 10 --warmup 3` (13 steps): achieved HBM-side bandwidth of the\n"
+tab = subprocess.run([sys.executable, R + 'tools/hbm_table.py', G + 'prof_e/e_kernel_trace.csv', str(NSTEP)], capture_output=True, text=True).stdout
+open(R + 'profiles/' + TAG + '_hbm_kernels.txt', 'w').write("# tools/hbm_table.py over the kernel trace of `bench.py --steps 10 --warmup 3` (13 steps): achieved HBM-side bandwidth of the\n"
                                                     "# streaming kernels = algorithmic bytes per step (cfg2 shapes, fp32, every tensor read / written once) / kernel time per step\n" + tab)
 print(tab)
-rows = list(csv.DictReader(open(R + 'profiles/r01_bench_kernel_stats.csv')))
-tot = sum(float(r['TotalDurationNs']) for r in rows) / 13 / 1e6
+rows = list(csv.DictReader(open(R + 'profiles/' + TAG + '_bench_kernel_stats.csv')))
+tot = sum(float(r['TotalDurationNs']) for r in rows) / NSTEP / 1e6
 cat = collections.OrderedDict()
 for r in rows:
-    nme, v = r['Name'], float(r['TotalDurationNs']) / 13 / 1e6
+    nme, v = r['Name'], float(r['TotalDurationNs']) / NSTEP / 1e6
     if 'gemm_kernel' in nme:
         m = re.search(r'256, (\d), (\d)', nme)
         key = {('0', '0'): 'dense NT (fwd, 1x1)', ('0', '1'): 'dense NN (dgrad)', ('1', '1'): 'dense TN (wgrad)', ('2', '0'): 'conv fwd', ('2', '4'): 'conv dgrad', ('1', '3'): 'conv wgrad'}[m.groups()]
@@ -102,5 +104,5 @@ for k, v in cat.items():
     print(f"{k:22s} {v:6.2f} ms {100 * v / tot:5.1f} %")
 for r in rows:
     if 'gemm_kernel' in r['Name'] and ', 0, 0, ' in r['Name']:
-        print(r['Name'][:64], int(r['Calls']) // 13, round(float(r['AverageNs']) / 1e3, 1))
-print(open(R + 'profiles/r01_bench_line.json').read()[:2000])
+        print(r['Name'][:64], int(r['Calls']) // NSTEP, round(float(r['AverageNs']) / 1e3, 1))
+print(open(R + 'profiles/' + TAG + '_bench_line.json').read()[:2000])
