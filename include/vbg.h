@@ -149,6 +149,43 @@ int vbg_split_planes_t(const float* x, long long ldx, int rows, int cols, unsign
 int vbg_split_planes_t_batched(const float* src, unsigned short* dst, const long long* tbl_dev, int njobs, int total_tiles,
                                long long plane, void* stream);
 
+/* ------------------------------------------------------------------------------------------
+ * Fused self-attention on packed variable-length sequences (head width 64), fp32-grade on the bf16 matrix cores; no [L, L]
+ * score / probability block is ever written.  Replaces transformers' BertSelfAttention inside BertModel
+ * (model/BERTgrid_generator.py:134): softmax(Q K^T * scale) -> dropout -> P V, and its autograd.
+ * Q, K, V are columns [0, hid), [hid, 2 hid), [2 hid, 3 hid) (hid = heads * 64) of the plane tensor `qkv` [3][ntok][qkv_ld]
+ * (vbg_plane_gemm's Cp output); dO (backward) is a plane tensor [3][ntok][do_ld].  Sequence s owns token rows
+ * [seq_row0[s], seq_row0[s] + seq_len[s]); tasks = int32 [ntasks][2] = (sequence, 128-row block) pairs; grid = ntasks x heads.
+ *   mode FWD: out = O [ntok][ldo] (columns head * 64 ..); lse [2][heads][ntok_pad]: [0][head][pad_off[s] + row] = maximum m of the scaled
+ *             scores of the row, [1][..] = 1 / sum exp(x - m) (the two numbers the row was normalised with; the backward modes read them);
+ *   mode DQ : out = dqkv [ntok][ldo]: columns [0, hid) <- dQ; REPLACES delta (from vbg_attn_delta: rowsum(dO o O)) by the rows' own
+ *             sum_k P_k dP_k and corrects dQ for the difference with kbar;
+ *   mode DKV: columns [hid, 3 hid) <- dK, dV; run it after DQ.
+ * delta: fp32 [heads][ntok_pad]; pad_off[s] a multiple of 32 with room for roundup(seq_len, 32) rows, rows past a
+ * sequence's length ZERO (delta from vbg_attn_delta).  Dropout: mask_q / mask_k from vbg_attn_mask (NULL = none), keep_scale =
+ * 65536 / (65536 - vbg_attn_drop_thr16(p)); mask_off[s] = first word of sequence s (heads * roundup(len,32) * ceil(len/32) words). */
+enum { VBG_ATTN_FWD = 0, VBG_ATTN_DQ = 1, VBG_ATTN_DKV = 2 };
+typedef struct vbg_attn_desc {
+    int mode, heads, ntasks;
+    const int* tasks; const int* seq_len; const int* seq_row0; const int* pad_off; long long ntok_pad;
+    const unsigned short* qkv; long long qkv_plane, qkv_ld;
+    const unsigned short* dO; long long do_plane, do_ld;
+    float* out; long long ldo;
+    float* lse; float* delta;
+    float* kbar; long long ldk;     /* [ntok][ldk]: FWD writes sum_k P_k K_k (bf16 precision; NULL = skip), DQ reads it */
+    const unsigned* mask_q; const unsigned* mask_k; const long long* mask_off;
+    float scale, keep_scale;
+} vbg_attn_desc;
+int vbg_attn(const vbg_attn_desc* desc, void* stream);
+/* delta[head * ntok_pad + tok_pad[t]] = sum_d dO[t][head*64 + d] * O[t][head*64 + d] (row sums of P o dP of the softmax backward) */
+int vbg_attn_delta(const float* dO, const float* O, long long ld, int ntok, int heads, const int* tok_pad, long long ntok_pad,
+                   float* delta, void* stream);
+/* dropout keeps of one layer and step, both orientations (torch.nn.Dropout(attention_probs_dropout_prob) on the probabilities):
+ * keep <=> a 16-bit slice of the counter hash >= thr16 = round(p * 65536), i.e. drop rate thr16 / 65536 */
+unsigned vbg_attn_drop_thr16(float drop_p);
+int vbg_attn_mask(const int* seq_len, const long long* mask_off, int nseq, int heads, int maxlen, float drop_p,
+                  unsigned long long seed, unsigned long long stream_id, unsigned* mask_q, unsigned* mask_k, void* stream);
+
 /* column sums: out[n] (+)= sum_m x[m*ld + n]   (bias gradients) */
 int vbg_colsum(const float* x, long long ld, int M, int N, float* out, int accumulate, void* stream);
 

@@ -103,6 +103,23 @@ def attention_tables(seq_len: np.ndarray, heads: int, dh: int, hidden: int):
     return t, soff, int(blk.sum()), maxlen, ld
 
 
+def flash_tables(seq_len: np.ndarray, heads: int):
+    """Host tables of the fused attention kernels (csrc/attn.hip; layouts in include/vbg.h `vbg_attn_desc`): first token row of
+    each sequence, its offset in the 32-row padded statistics buffers, the padded index of every token, the first dropout-mask word
+    of each sequence, and the (sequence, 128-row block) task list, longest sequences first."""
+    nseq = seq_len.shape[0]
+    row0 = np.concatenate([[0], np.cumsum(seq_len)[:-1]]).astype(np.int64) if nseq else np.zeros(0, np.int64)
+    lpad = (seq_len + 31) // 32 * 32
+    pad_off = np.concatenate([[0], np.cumsum(lpad)[:-1]]).astype(np.int64) if nseq else np.zeros(0, np.int64)
+    ntok_pad = int(lpad.sum())
+    tok_pad = np.concatenate([pad_off[s] + np.arange(seq_len[s]) for s in range(nseq)]).astype(np.int64) if nseq else np.zeros(0, np.int64)
+    words = heads * lpad * (lpad // 32)
+    mask_off = np.concatenate([[0], np.cumsum(words)[:-1]]).astype(np.int64) if nseq else np.zeros(0, np.int64)
+    order = np.argsort(-seq_len, kind="stable")
+    tasks = np.asarray([(s, b) for s in order for b in range((int(seq_len[s]) + 127) // 128)], np.int64).reshape(-1, 2)
+    return row0, pad_off, ntok_pad, tok_pad, mask_off, int(words.sum()), tasks
+
+
 class BERTgridGenerator(nn.Module):
     """generate BERTgrid with the given OCR results (same API as the reference class)."""
 
@@ -134,8 +151,10 @@ class BERTgridGenerator(nn.Module):
         meta.ntok, meta.nseq, meta.heads, meta.dh, meta.maxlen, meta.ld, meta.s_elems = pk.ntok, len(pk.seq_len), heads, dh, maxlen, ld, s_elems
         meta.ngroups = len(pk.seq_len) * heads
         # one H2D for all index tables
+        row0, pad_off, ntok_pad, tok_pad, mask_off, mask_words, tasks = flash_tables(pk.seq_len, heads)
         blob = np.concatenate([pk.ids.astype(np.int64), pk.pos.astype(np.int64), soff.astype(np.int64), pk.seq_len,
-                               np.full(len(pk.seq_len), ld, np.int64)] + [tabs[k].reshape(-1) for k in ("qk", "pv", "dp", "dv", "dq")])
+                               np.full(len(pk.seq_len), ld, np.int64)] + [tabs[k].reshape(-1) for k in ("qk", "pv", "dp", "dv", "dq")]
+                              + [mask_off, row0, pad_off, tok_pad, tasks.reshape(-1)])
         d = torch.from_numpy(blob).to(dev, non_blocking=False)
         o = 0
 
@@ -153,6 +172,11 @@ class BERTgridGenerator(nn.Module):
         G8 = meta.ngroups * 8
         meta.t_qk, meta.t_pv, meta.t_dp, meta.t_dv, meta.t_dq = (take(G8).contiguous() for _ in range(5))
         meta.t_dk = meta.t_dq
+        meta.mask_off = take(meta.nseq).contiguous()
+        i32 = take(2 * meta.nseq + pk.ntok + tasks.size).int()          # (one conversion launch for all int32 tables)
+        meta.seq_row0, meta.pad_off = i32[:meta.nseq], i32[meta.nseq:2 * meta.nseq]
+        meta.tok_pad, meta.tasks = i32[2 * meta.nseq:2 * meta.nseq + pk.ntok], i32[2 * meta.nseq + pk.ntok:]
+        meta.ntok_pad, meta.mask_words, meta.ntasks = ntok_pad, mask_words, int(tasks.shape[0])
 
         m = self.model
         emb = m.embeddings

@@ -7,7 +7,7 @@ import torch
 import torch.distributed as dist
 
 from . import ops
-from .lib import EPI_GELU_DUAL, EPI_NONE, EPI_RELU, OP_DENSE_K, OP_DENSE_R
+from .lib import ATTN_DKV, ATTN_DQ, ATTN_FWD, EPI_GELU_DUAL, EPI_NONE, EPI_RELU, OP_DENSE_K, OP_DENSE_R
 
 f32 = torch.float32
 
@@ -510,7 +510,7 @@ class AttnMeta:
     """Host-built description of the packed variable-length sequences of one batch (see
     model/BERTgrid_generator.py in this package): device tables for the grouped attention GEMMs."""
     __slots__ = ("ntok", "nseq", "heads", "dh", "maxlen", "ld", "s_elems", "soff", "lens", "ldp", "t_qk", "t_pv", "t_dp", "t_dv",
-                 "t_dq", "t_dk", "ngroups")
+                 "t_dq", "t_dk", "ngroups", "mask_off", "seq_row0", "pad_off", "tok_pad", "tasks", "ntok_pad", "mask_words", "ntasks")
 
 
 class BertLayerFn(torch.autograd.Function):
@@ -523,31 +523,44 @@ class BertLayerFn(torch.autograd.Function):
         ntok, hid = x.shape
         H, dh = meta.heads, meta.dh
         dev = x.device
-        qkv = torch.empty((ntok, 3 * hid), device=dev, dtype=f32)
         fused_qkv = _back_to_back(wq, wk, wv) and _back_to_back(bq, bk, bv)
         planes = ops.planes_enabled() and hid % 32 == 0 and wi.shape[0] % 32 == 0
-        px = pctx = px1 = pg = None
+        flash = planes and dh == 64 and ops.flash_enabled()
+        px = pctx = px1 = pg = pqkv = qkv = P = lse = masks = kbar = None
+        if not flash:
+            qkv = torch.empty((ntok, 3 * hid), device=dev, dtype=f32)
+        else:                      # q, k, v leave the projection as planes only: the fused attention kernels' operands
+            pqkv = ops.planes_empty(ntok, 3 * hid, dev)
         if planes:                 # operands split into bf16 planes once (csrc/gemm_planes.hip), weights once per optimizer step
             px = ops.split_planes(x)
             if fused_qkv:
-                ops.plane_gemm(px, ops.weight_planes(wq, view=_stack3(wq), also=(wk, wv)), qkv, bias=_stack3(bq), tile=ops._dense_tile(ntok, 3 * hid))
+                ops.plane_gemm(px, ops.weight_planes(wq, view=_stack3(wq), also=(wk, wv)), qkv, bias=_stack3(bq), out_planes=pqkv,
+                               tile=ops._dense_tile(ntok, 3 * hid))
             else:              # parameters not laid out back to back (no flat buffers): one product per projection, same kernel
                 for j, (w, b) in enumerate(((wq, bq), (wk, bk), (wv, bv))):
-                    ops.plane_gemm(px, ops.weight_planes(w), qkv[:, j * hid:(j + 1) * hid], bias=b, tile=ops._dense_tile(ntok, hid))
+                    ops.plane_gemm(px, ops.weight_planes(w), None if flash else qkv[:, j * hid:(j + 1) * hid], bias=b,
+                                   out_planes=pqkv.col_block(j * hid, hid) if flash else None, tile=ops._dense_tile(ntok, hid))
         elif fused_qkv:            # one [ntok,hid] x [3*hid,hid]^T GEMM over the stacked projections
             ops.linear_fwd(x, _stack3(wq), _stack3(bq), out=qkv)
         else:
             for j, (w, b) in enumerate(((wq, bq), (wk, bk), (wv, bv))):
                 ops.gemm_raw(ntok, hid, hid, x, hid, OP_DENSE_K, w, hid, OP_DENSE_K, qkv, 3 * hid, bias=b, c_ptr_off=j * hid)
-        # scores -> probabilities (in place), grouped over (sequence, head)
-        P = torch.empty((meta.s_elems,), device=dev, dtype=f32)
-        ops.gemm_raw(0, 0, 0, qkv, 3 * hid, OP_DENSE_K, qkv, 3 * hid, OP_DENSE_K, P, meta.ld, grp=meta.t_qk, ngroups=meta.ngroups,
-                     grp_max=(meta.maxlen, meta.maxlen), b_ptr_off=hid, bk=16 if dh <= 128 else 0, tile=64064 if dh <= 128 else 0)
         sid = layer * 8
-        ops.softmax_fwd(P, meta.soff, meta.lens, meta.ldp, meta.ngroups, H, meta.maxlen, 1.0 / (dh ** 0.5), p, seed, sid + 0)
         ctxv = torch.empty((ntok, hid), device=dev, dtype=f32)
-        ops.gemm_raw(0, 0, 0, P, meta.ld, OP_DENSE_K, qkv, 3 * hid, OP_DENSE_R, ctxv, hid, grp=meta.t_pv, ngroups=meta.ngroups,
-                     grp_max=(meta.maxlen, dh), b_ptr_off=2 * hid, a_relu_scale=1.0 / (1.0 - p))
+        if flash:
+            # fused attention (csrc/attn.hip): scores, softmax, dropout and P V in one pass, nothing of size L x L is stored
+            lse = torch.zeros((2, H, meta.ntok_pad), device=dev, dtype=f32)            # row statistics (m, 1 / l)
+            masks = ops.attn_mask(meta, p, seed, sid + 0) if p > 0 else None
+            kbar = torch.empty((ntok, hid), device=dev, dtype=f32) if any(ctx.needs_input_grad) else None
+            ops.attn(meta, ATTN_FWD, pqkv, None, ctxv, lse, None, masks, 1.0 / (dh ** 0.5), p, kbar=kbar)
+        else:
+            # scores -> probabilities (in place), grouped over (sequence, head)
+            P = torch.empty((meta.s_elems,), device=dev, dtype=f32)
+            ops.gemm_raw(0, 0, 0, qkv, 3 * hid, OP_DENSE_K, qkv, 3 * hid, OP_DENSE_K, P, meta.ld, grp=meta.t_qk, ngroups=meta.ngroups,
+                         grp_max=(meta.maxlen, meta.maxlen), b_ptr_off=hid, bk=16 if dh <= 128 else 0, tile=64064 if dh <= 128 else 0)
+            ops.softmax_fwd(P, meta.soff, meta.lens, meta.ldp, meta.ngroups, H, meta.maxlen, 1.0 / (dh ** 0.5), p, seed, sid + 0)
+            ops.gemm_raw(0, 0, 0, P, meta.ld, OP_DENSE_K, qkv, 3 * hid, OP_DENSE_R, ctxv, hid, grp=meta.t_pv, ngroups=meta.ngroups,
+                         grp_max=(meta.maxlen, dh), b_ptr_off=2 * hid, a_relu_scale=1.0 / (1.0 - p))
         if planes:
             pctx = ops.split_planes(ctxv)
             ao = ops.plane_gemm(pctx, ops.weight_planes(wo), torch.empty((ntok, hid), device=dev, dtype=f32), bias=bo, tile=ops._dense_tile(ntok, hid))
@@ -567,13 +580,17 @@ class BertLayerFn(torch.autograd.Function):
             fo = ops.linear_fwd(g, wo2, bo2)
         y, xh2, rs2 = ops.dropout_add_ln_fwd(fo, x1, g2, b2, eps, p, seed, sid + 2)
         ctx.meta, ctx.cfg = meta, (eps, p, seed, sid)
-        ctx.planes = planes
+        ctx.planes, ctx.flash = planes, flash
         ctx.w_refs = (wq, wk, wv, wo, wi, wo2)
         ctx.b_refs = (bq, bk, bv, bo, bi, bo2, g1, b1, g2, b2)
         if planes:
             # backward needs the activations only as GEMM operands: their planes stand in for x / ctx / x1 / gelu(h)
             ctx.pl_shape = (ntok, hid, wi.shape[0])
-            ctx.save_for_backward(wq, wk, wv, wo, g1, wi, wo2, g2, qkv, P, xh1, rs1, h, xh2, rs2, px.buf, pctx.buf, px1.buf, pg.buf)
+            if flash:
+                ctx.masks = masks
+                ctx.save_for_backward(wq, wk, wv, wo, g1, wi, wo2, g2, pqkv.buf, ctxv, xh1, rs1, h, xh2, rs2, px.buf, pctx.buf, px1.buf, pg.buf, lse, kbar)
+            else:
+                ctx.save_for_backward(wq, wk, wv, wo, g1, wi, wo2, g2, qkv, P, xh1, rs1, h, xh2, rs2, px.buf, pctx.buf, px1.buf, pg.buf)
         else:
             ctx.save_for_backward(x, wq, wk, wv, wo, g1, wi, wo2, g2, qkv, P, ctxv, xh1, rs1, x1, h, g, xh2, rs2)
         return y
@@ -582,12 +599,16 @@ class BertLayerFn(torch.autograd.Function):
     def _backward_planes(ctx, dy):
         """backward of the plane path: every dy is split once (the A operand of its data-gradient product) and the four weight
         gradients of the layer run as ONE grouped TN launch from the untransposed planes of dy and of the saved activations"""
-        (wq, wk, wv, wo, g1, wi, wo2, g2, qkv, P, xh1, rs1, h, xh2, rs2, bx, bctx, bx1, bg) = ctx.saved_tensors
+        flash = ctx.flash
+        if flash:
+            (wq, wk, wv, wo, g1, wi, wo2, g2, bqkv, ctxv, xh1, rs1, h, xh2, rs2, bx, bctx, bx1, bg, lse, kbar) = ctx.saved_tensors
+        else:
+            (wq, wk, wv, wo, g1, wi, wo2, g2, qkv, P, xh1, rs1, h, xh2, rs2, bx, bctx, bx1, bg) = ctx.saved_tensors
         meta = ctx.meta
         eps, p, seed, sid = ctx.cfg
         ntok, hid, inter = ctx.pl_shape
         H, dh = meta.heads, meta.dh
-        dev = qkv.device
+        dev = h.device
         mk = lambda buf, cols: ops.Planes(buf, ntok, cols, buf.shape[2])
         px, pctx, px1, pg = mk(bx, hid), mk(bctx, hid), mk(bx1, hid), mk(bg, inter)
         rbq, rbk, rbv, rbo, rbi, rbo2, rg1, rb1, rg2, rb2 = ctx.b_refs
@@ -604,18 +625,30 @@ class BertLayerFn(torch.autograd.Function):
         dao, dx = ops.dropout_add_ln_bwd(dx1, xh1, rs1, g1, p, seed, sid + 1, dg1, db1)
         dg1, db1 = _affine_done(rg1, rb1, dg1, db1, sunk1)
         pdao, dbo = _split_with_bias_grad(rbo, dao)
-        dctx = ops.plane_gemm(pdao, ops.weight_planes(ro, True, view=wo), torch.empty((ntok, hid), device=dev, dtype=f32), tile=ops._dense_tile(ntok, hid))
-        dP = torch.empty_like(P)
-        ops.gemm_raw(0, 0, 0, dctx, hid, OP_DENSE_K, qkv, 3 * hid, OP_DENSE_K, dP, meta.ld, grp=meta.t_dp, ngroups=meta.ngroups,
-                     grp_max=(meta.maxlen, meta.maxlen), b_ptr_off=2 * hid, bk=16 if dh <= 128 else 0, tile=64064 if dh <= 128 else 0)
-        dqkv = torch.empty_like(qkv)
-        ops.gemm_raw(0, 0, 0, P, meta.ld, OP_DENSE_R, dctx, hid, OP_DENSE_R, dqkv, 3 * hid, grp=meta.t_dv, ngroups=meta.ngroups,
-                     grp_max=(meta.maxlen, dh), c_ptr_off=2 * hid, a_relu_scale=1.0 / (1.0 - p))
-        ops.softmax_bwd(P, dP, meta.soff, meta.lens, meta.ldp, meta.ngroups, H, meta.maxlen, 1.0 / (dh ** 0.5), p)
-        ops.gemm_raw(0, 0, 0, dP, meta.ld, OP_DENSE_K, qkv, 3 * hid, OP_DENSE_R, dqkv, 3 * hid, grp=meta.t_dq, ngroups=meta.ngroups,
-                     grp_max=(meta.maxlen, dh), b_ptr_off=hid)
-        ops.gemm_raw(0, 0, 0, dP, meta.ld, OP_DENSE_R, qkv, 3 * hid, OP_DENSE_R, dqkv, 3 * hid, grp=meta.t_dk, ngroups=meta.ngroups,
-                     grp_max=(meta.maxlen, dh), c_ptr_off=hid)
+        pdctx = ops.planes_empty(ntok, hid, dev) if flash else None
+        dctx = ops.plane_gemm(pdao, ops.weight_planes(ro, True, view=wo), torch.empty((ntok, hid), device=dev, dtype=f32), out_planes=pdctx,
+                              tile=ops._dense_tile(ntok, hid))
+        if flash:
+            # fused attention backward: delta = rowsum(dO o O), then dQ (queries stationary) and dK / dV (keys stationary), each
+            # recomputing its score tile from the q / k / v planes and the saved log-sum-exp
+            pqkv = ops.Planes(bqkv, ntok, 3 * hid, bqkv.shape[2])
+            delta = ops.attn_delta(dctx, ctxv, meta, torch.zeros_like(lse[0]))
+            dqkv = torch.empty((ntok, 3 * hid), device=dev, dtype=f32)
+            sc = 1.0 / (dh ** 0.5)
+            ops.attn(meta, ATTN_DQ, pqkv, pdctx, dqkv, lse, delta, ctx.masks, sc, p, kbar=kbar)
+            ops.attn(meta, ATTN_DKV, pqkv, pdctx, dqkv, lse, delta, ctx.masks, sc, p)
+        else:
+            dP = torch.empty_like(P)
+            ops.gemm_raw(0, 0, 0, dctx, hid, OP_DENSE_K, qkv, 3 * hid, OP_DENSE_K, dP, meta.ld, grp=meta.t_dp, ngroups=meta.ngroups,
+                         grp_max=(meta.maxlen, meta.maxlen), b_ptr_off=2 * hid, bk=16 if dh <= 128 else 0, tile=64064 if dh <= 128 else 0)
+            dqkv = torch.empty_like(qkv)
+            ops.gemm_raw(0, 0, 0, P, meta.ld, OP_DENSE_R, dctx, hid, OP_DENSE_R, dqkv, 3 * hid, grp=meta.t_dv, ngroups=meta.ngroups,
+                         grp_max=(meta.maxlen, dh), c_ptr_off=2 * hid, a_relu_scale=1.0 / (1.0 - p))
+            ops.softmax_bwd(P, dP, meta.soff, meta.lens, meta.ldp, meta.ngroups, H, meta.maxlen, 1.0 / (dh ** 0.5), p)
+            ops.gemm_raw(0, 0, 0, dP, meta.ld, OP_DENSE_K, qkv, 3 * hid, OP_DENSE_R, dqkv, 3 * hid, grp=meta.t_dq, ngroups=meta.ngroups,
+                         grp_max=(meta.maxlen, dh), b_ptr_off=hid)
+            ops.gemm_raw(0, 0, 0, dP, meta.ld, OP_DENSE_R, qkv, 3 * hid, OP_DENSE_R, dqkv, 3 * hid, grp=meta.t_dk, ngroups=meta.ngroups,
+                         grp_max=(meta.maxlen, dh), c_ptr_off=hid)
         stacked = _back_to_back(wq, wk, wv)
         gq = [wgrad_dest(t) for t in (rq, rk, rv, rbq, rbk, rbv)]
         qkv_sunk = stacked and all(t is not None for t in gq) and _back_to_back(*gq[:3]) and _back_to_back(*gq[3:])

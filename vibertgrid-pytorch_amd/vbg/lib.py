@@ -50,6 +50,17 @@ class PlaneGemmDesc(C.Structure):
                 ("ngroups", c_int), ("grp", PlaneGroup * 4)]
 
 
+class AttnDesc(C.Structure):
+    _fields_ = [("mode", c_int), ("heads", c_int), ("ntasks", c_int),
+                ("tasks", c_vp), ("seq_len", c_vp), ("seq_row0", c_vp), ("pad_off", c_vp), ("ntok_pad", c_ll),
+                ("qkv", c_vp), ("qkv_plane", c_ll), ("qkv_ld", c_ll),
+                ("dO", c_vp), ("do_plane", c_ll), ("do_ld", c_ll),
+                ("out", c_vp), ("ldo", c_ll), ("lse", c_vp), ("delta", c_vp), ("kbar", c_vp), ("ldk", c_ll),
+                ("mask_q", c_vp), ("mask_k", c_vp), ("mask_off", c_vp),
+                ("scale", c_f), ("keep_scale", c_f)]
+
+
+ATTN_FWD, ATTN_DQ, ATTN_DKV = 0, 1, 2
 OP_DENSE_K, OP_DENSE_R, OP_CONV_K, OP_CONV_R, OP_WT_R = 0, 1, 2, 3, 4
 EPI_NONE, EPI_RELU, EPI_GELU_DUAL = 0, 1, 2
 
@@ -66,6 +77,10 @@ SIGNATURES = {
     "vbg_split_planes": (c_int, [c_vp, c_ll, c_int, c_int, c_vp, c_int, c_ll, c_int, c_vp, c_vp]),
     "vbg_split_planes_t": (c_int, [c_vp, c_ll, c_int, c_int, c_vp, c_int, c_ll, c_vp]),
     "vbg_split_planes_t_batched": (c_int, [c_vp, c_vp, c_vp, c_int, c_int, c_ll, c_vp]),
+    "vbg_attn": (c_int, [C.POINTER(AttnDesc), c_vp]),
+    "vbg_attn_delta": (c_int, [c_vp, c_vp, c_ll, c_int, c_int, c_vp, c_ll, c_vp, c_vp]),
+    "vbg_attn_drop_thr16": (C.c_uint, [c_f]),
+    "vbg_attn_mask": (c_int, [c_vp, c_vp, c_int, c_int, c_int, c_f, c_ull, c_ull, c_vp, c_vp, c_vp]),
     "vbg_colsum": (c_int, [c_vp, c_ll, c_int, c_int, c_vp, c_int, c_vp]),
     "vbg_im2col": (c_int, [c_vp, c_int, c_int, c_int, c_int, c_int, c_int, c_int, c_int, c_int, c_vp, c_vp]),
     "vbg_normalize_resize": (c_int, [c_vp, c_int, c_int, c_int, c_int, C.POINTER(c_f), C.POINTER(c_f), c_vp, c_int, c_int, c_int, c_vp]),

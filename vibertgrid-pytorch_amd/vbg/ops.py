@@ -8,7 +8,7 @@ import os
 import torch
 
 from .lib import (EPI_GELU_DUAL, EPI_NONE, EPI_RELU, OP_CONV_K, OP_CONV_R, OP_DENSE_K, OP_DENSE_R, OP_WT_R, ConvGeo,
-                  GemmDesc, PlaneGemmDesc, check, lib)
+                  AttnDesc, GemmDesc, PlaneGemmDesc, check, lib)
 
 f32 = torch.float32
 i32 = torch.int32
@@ -218,6 +218,18 @@ def set_planes(on: bool):
 
 def planes_enabled() -> bool:
     return _PLANES[0] and _SPLIT3[0] and not _AMP[0]
+
+
+_FLASH = [os.environ.get("VBG_FLASH", "1") != "0"]
+
+
+def set_flash(on: bool):
+    """fused attention kernels (csrc/attn.hip) for the plane path with 64-wide heads; off = grouped score GEMMs + row softmax"""
+    _FLASH[0] = bool(on)
+
+
+def flash_enabled() -> bool:
+    return _FLASH[0]
 
 
 def bump_weight_epoch():
@@ -568,6 +580,54 @@ def softmax_fwd(s, off, lens, ldp, ngroups, heads, maxlen, scale, p, seed, sid):
 
 def softmax_bwd(pbuf, dp, off, lens, ldp, ngroups, heads, maxlen, scale, p):
     check(lib.vbg_softmax_bwd(P(pbuf), P(dp), P(off), P(lens), P(ldp), ngroups, heads, maxlen, scale, p, _stream()), "vbg_softmax_bwd")
+
+
+# ----------------------------------------------------------------------------------------------
+# fused attention (csrc/attn.hip): no [L, L] block is written; meta = vbg.functions.AttnMeta with the flash tables
+# ----------------------------------------------------------------------------------------------
+def attn_keep_scale(p):
+    """1 / (1 - p') with p' = the 16-bit quantised drop rate the mask kernel realises (thr16 / 65536)"""
+    thr = int(lib.vbg_attn_drop_thr16(float(p)))
+    return 65536.0 / (65536.0 - thr)
+
+
+def attn_mask(meta, p, seed, sid):
+    """dropout keeps of one layer and step in both orientations -> (mask_q, mask_k) uint32 words"""
+    dev = meta.lens.device
+    mq = torch.empty((meta.mask_words,), device=dev, dtype=i32)
+    mk = torch.empty((meta.mask_words,), device=dev, dtype=i32)
+    check(lib.vbg_attn_mask(P(meta.lens), P(meta.mask_off), meta.nseq, meta.heads, meta.maxlen, float(p), seed, sid, P(mq), P(mk), _stream()),
+          "vbg_attn_mask")
+    return mq, mk
+
+
+def attn(meta, mode, qkv: Planes, dO, out, lse, delta, masks, scale, p, kbar=None):
+    """one fused attention pass (mode: lib.ATTN_FWD / ATTN_DQ / ATTN_DKV) over all (sequence, head) pairs of the packed batch"""
+    d = AttnDesc()
+    d.mode, d.heads, d.ntasks = int(mode), meta.heads, meta.ntasks
+    d.tasks, d.seq_len, d.seq_row0, d.pad_off, d.ntok_pad = P(meta.tasks), P(meta.lens), P(meta.seq_row0), P(meta.pad_off), meta.ntok_pad
+    d.qkv, d.qkv_plane, d.qkv_ld = qkv.buf.data_ptr(), qkv.plane, qkv.ld
+    if dO is not None:
+        d.dO, d.do_plane, d.do_ld = dO.buf.data_ptr(), dO.plane, dO.ld
+    d.out, d.ldo = out.data_ptr(), out.stride(0)
+    d.lse = lse.data_ptr()
+    d.delta = None if delta is None else delta.data_ptr()
+    if kbar is not None:
+        d.kbar, d.ldk = kbar.data_ptr(), kbar.stride(0)
+    if masks is not None:
+        d.mask_q, d.mask_k, d.mask_off = masks[0].data_ptr(), masks[1].data_ptr(), meta.mask_off.data_ptr()
+        d.keep_scale = attn_keep_scale(p)
+    else:
+        d.keep_scale = 1.0
+    d.scale = float(scale)
+    check(lib.vbg_attn(C.byref(d), _stream()), "vbg_attn")
+    return out
+
+
+def attn_delta(dO, O, meta, delta):
+    ntok = dO.shape[0]
+    check(lib.vbg_attn_delta(P(dO), P(O), dO.stride(0), ntok, meta.heads, P(meta.tok_pad), meta.ntok_pad, P(delta), _stream()), "vbg_attn_delta")
+    return delta
 
 
 def row_softmax(x):
