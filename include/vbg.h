@@ -131,6 +131,13 @@ typedef struct vbg_plane_gemm_desc {
        gradients of an encoder layer: 432 tiles in 2 rounds instead of 4 launches of <= 144 tiles on 256 CUs).  No bias / epilogue. */
     int ngroups;
     vbg_plane_group grp[VBG_PLANE_MAX_GROUPS];
+    /* optional stream-K tail (NT products on the 8-wave 128 x 128 tiles, no split-K, not grouped): sk_blocks = number of CUs,
+       sk_ws = fp32 workspace of sk_blocks * 2 * 128 * 128 elements, sk_cnt = int32 [sk_blocks] that is ZERO on entry (and left
+       zero).  The whole rounds of tiles run one block per tile; the k-tile sequence of the last, partly filled round is cut into
+       sk_blocks equal ranges whose partial tiles are summed (in block order: deterministic) by the last block to finish each tile.
+       The workspace must not be shared by launches that may run concurrently.  NULL = plain rounds. */
+    float* sk_ws; int* sk_cnt; int sk_blocks;
+    int sk_full, sk_tiles_m, sk_tiles_n;                         /* filled by the library */
 } vbg_plane_gemm_desc;
 int vbg_plane_gemm(const vbg_plane_gemm_desc* desc, void* stream);
 int vbg_plane_gemm_timed(const vbg_plane_gemm_desc* desc, void* stream, void* start_event, void* stop_event);

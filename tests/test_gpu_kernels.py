@@ -1005,3 +1005,50 @@ def test_ce_label_out_of_range_is_nan_not_oob():
     dl = torch.zeros_like(x)
     ops.ce_bwd(x, elem, lab, 16, None, torch.ones(1, device=dev), 1.0, 0, 0, 0, dl)
     assert torch.isfinite(dl).all() and float(dl[bad].abs().max()) == 0.0
+
+
+@pytest.mark.parametrize("tile", [128129, 128130])
+def test_plane_gemm_streamk_tail(tile):
+    """stream-K tail of the NT plane product (the last, partly filled round of tiles is cut along k over all CUs and summed by the
+    last block to finish each tile): fp32-grade against fp64, bit-identical to itself run to run (slabs are summed in block
+    order), every epilogue, and the plain-rounds kernel as the second opinion"""
+    from vbg import ops
+    from vbg.lib import EPI_GELU_DUAL
+    dev = torch.device("cuda")
+    g = torch.Generator().manual_seed(tile)
+    ops.set_streamk(True)
+    for (M, N, K) in ((4128, 768, 768), (4128, 2304, 768), (4128, 768, 3072), (4128, 3072, 768), (2100, 1536, 1056)):
+        a = (torch.randn(M, K, generator=g) * torch.exp2(torch.randint(-8, 8, (M, 1), generator=g).float())).to(dev)
+        b = (torch.randn(N, K, generator=g) / K ** 0.5).to(dev)
+        bias = torch.randn(N, generator=g).to(dev)
+        ref = a.double() @ b.double().t() + bias.double()
+        scale = float((a.double().abs() @ b.double().abs().t()).max())
+        pa, pb = ops.split_planes(a), ops.split_planes(b)
+        outs = []
+        for rep in range(3):
+            out = torch.full((M, N), 7.0, device=dev)
+            ops.plane_gemm(pa, pb, out, bias=bias, tile=tile)
+            outs.append(out)
+        assert float((outs[0].double() - ref).abs().max()) <= 2e-6 * scale, (M, N, K)
+        assert torch.equal(outs[0], outs[1]) and torch.equal(outs[0], outs[2])
+        ops.set_streamk(False)
+        try:
+            plain = torch.empty(M, N, device=dev)
+            ops.plane_gemm(pa, pb, plain, bias=bias, tile=tile)
+        finally:
+            ops.set_streamk(True)
+        assert float((plain - outs[0]).abs().max()) <= 1e-6 * scale
+        h, gl, pg = torch.empty(M, N, device=dev), torch.empty(M, N, device=dev), ops.planes_empty(M, N, dev)
+        ops.plane_gemm(pa, pb, h, bias=bias, epi=EPI_GELU_DUAL, C2=gl, out_planes=pg, tile=tile)
+        assert torch.equal(h, outs[0])
+        assert torch.equal(pg.buf[:, :, :N], ops.split_planes(gl).buf[:, :, :N])
+        only_planes = ops.planes_empty(M, N, dev)
+        ops.plane_gemm(pa, pb, None, bias=bias, out_planes=only_planes, tile=tile)
+        assert torch.equal(only_planes.buf[:, :, :N], ops.split_planes(outs[0]).buf[:, :, :N])
+        acc = torch.ones(M, N, device=dev)
+        ops.plane_gemm(pa, pb, acc, accumulate=True, tile=tile)
+        assert float((acc.double() - 1 - (ref - bias.double())).abs().max()) <= 2e-6 * scale
+    # the tile counters are left zero for the next launch
+    _, cnt, _ = ops._sk_workspace(dev)
+    ops.set_streamk(False)
+    assert int(cnt.abs().sum()) == 0

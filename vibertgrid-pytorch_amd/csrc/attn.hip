@@ -226,6 +226,21 @@ __global__ __launch_bounds__(256) void attn_kernel(const vbg_attn_desc p) {
     unsigned mword = 0xffffffffu;
     if constexpr (DROP) mword = (active && own0 + lr < nt * 32) ? mrow[0] : 0u;
 
+    float nst[3][16];                            // DKV: (m, 1 / l, delta) of the NEXT streamed tile's queries
+    auto load_stats = [&](int t) {
+        if constexpr (DKV) {
+#pragma unroll
+            for (int j = 0; j < 4; ++j) {
+                const float4 a = *reinterpret_cast<const float4*>(p.lse + lsoff + t * 32 + 8 * j + 4 * lh);
+                const float4 c = *reinterpret_cast<const float4*>(p.lse + lsplane + lsoff + t * 32 + 8 * j + 4 * lh);
+                const float4 b = *reinterpret_cast<const float4*>(p.delta + lsoff + t * 32 + 8 * j + 4 * lh);
+                nst[0][4 * j] = a.x; nst[0][4 * j + 1] = a.y; nst[0][4 * j + 2] = a.z; nst[0][4 * j + 3] = a.w;
+                nst[1][4 * j] = c.x; nst[1][4 * j + 1] = c.y; nst[1][4 * j + 2] = c.z; nst[1][4 * j + 3] = c.w;
+                nst[2][4 * j] = b.x; nst[2][4 * j + 1] = b.y; nst[2][4 * j + 2] = b.z; nst[2][4 * j + 3] = b.w;
+            }
+        }
+    };
+    load_stats(0);
     issue(0, 0);
     asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
     __builtin_amdgcn_s_barrier();
@@ -235,6 +250,14 @@ __global__ __launch_bounds__(256) void attn_kernel(const vbg_attn_desc p) {
         if (t + 1 < nt) issue(stage ^ 1, t + 1);
         unsigned mnext = 0xffffffffu;
         if constexpr (DROP) mnext = (active && t + 1 < nt && own0 + lr < nt * 32) ? mrow[t + 1] : 0u;
+        float cst[3][16];
+        if constexpr (DKV) {
+#pragma unroll
+            for (int a = 0; a < 3; ++a)
+#pragma unroll
+                for (int r = 0; r < 16; ++r) cst[a][r] = nst[a][r];
+            if (t + 1 < nt) load_stats(t + 1);
+        }
         if (active) {
             const unsigned char* im0 = smem + stage * AT_STAGE;
             const unsigned char* im1 = im0 + AT_OP;
@@ -306,17 +329,11 @@ __global__ __launch_bounds__(256) void attn_kernel(const vbg_attn_desc p) {
                     at_split16(ds, bp);
                     tprod(im0, bp, acc0);                                  // dQ^T += K^T dS^T
                 } else {
-                    // statistics of the streamed queries: register r = query 8 (r >> 2) + 4 lh + (r & 3) of the tile
+                    // statistics of the streamed queries: register r = query 8 (r >> 2) + 4 lh + (r & 3) of the tile (loaded an
+                    // iteration ahead: a use of a fresh global load in here would drain the tile DMA in flight)
                     float lq[16], iq[16], dq[16];
 #pragma unroll
-                    for (int j = 0; j < 4; ++j) {
-                        const float4 a = *reinterpret_cast<const float4*>(p.lse + lsoff + t * 32 + 8 * j + 4 * lh);
-                        const float4 c = *reinterpret_cast<const float4*>(p.lse + lsplane + lsoff + t * 32 + 8 * j + 4 * lh);
-                        const float4 b = *reinterpret_cast<const float4*>(p.delta + lsoff + t * 32 + 8 * j + 4 * lh);
-                        lq[4 * j] = a.x; lq[4 * j + 1] = a.y; lq[4 * j + 2] = a.z; lq[4 * j + 3] = a.w;
-                        iq[4 * j] = c.x; iq[4 * j + 1] = c.y; iq[4 * j + 2] = c.z; iq[4 * j + 3] = c.w;
-                        dq[4 * j] = b.x; dq[4 * j + 1] = b.y; dq[4 * j + 2] = b.z; dq[4 * j + 3] = b.w;
-                    }
+                    for (int r = 0; r < 16; ++r) { lq[r] = cst[0][r]; iq[r] = cst[1][r]; dq[r] = cst[2][r]; }
 #pragma unroll
                     for (int r = 0; r < 16; ++r) {
                         const float pv = __expf(s[r] * scale - lq[r]) * iq[r];

@@ -388,6 +388,294 @@ __global__ __launch_bounds__(WGM * WGN * 64) void plane_gemm_kernel(const vbg_pl
     }
 }
 
+// ---- stream-K form of the NT product ------------------------------------------------------------------------------------------
+// One block per CU holds a 128 x 128 tile's stages, so a product runs in ROUNDS of 256 tiles and the BERT shapes end in a
+// round that is a quarter full (4128 x 768: 198 tiles, 4128 x 2304: 594 = 2.32 rounds, 4128 x 3072: 792 = 3.09 rounds).  Here the
+// first `sk_full` tiles (whole rounds) run one block per tile as above; the k-tile sequence of the remaining tiles is cut into
+// `sk_blocks` equal contiguous ranges, one per block.  A range touches one or two tiles; for each it writes its partial 128 x 128
+// sums to a slab (write-through stores), draws a ticket on the tile's counter, and the block that draws the last ticket adds the
+// slabs of all contributors IN BLOCK ORDER (its own included: the result does not depend on who arrives last) and runs the
+// epilogue.  No block ever waits for another.  MEASURED (MI355X, cfg2 BERT shapes): slower than the plain rounds -- the two 64 KB slab
+// publications per block and the slab reads of the reducers cost 20-50 us per launch against the <= 25 us an evenly filled chip
+// would save (4128x2304x768: 112 vs 100 us, 4128x768x3072: 139 vs 110 us) -- so the library uses it only on request (sk_ws != NULL).  Ordering: sc1 (write-through) slab stores, every wave drains its stores, barrier,
+// relaxed agent-scope ticket; the last arriver issues ONE agent-scope acquire before it reads the slabs.
+template <int BM, int BN, int WGM, int WGN>
+__global__ __launch_bounds__(WGM * WGN * 64) void plane_gemm_sk_kernel(const vbg_plane_gemm_desc p) {
+    constexpr int NW = WGM * WGN, NT = NW * 64, NST = 3;
+    constexpr int BK = 32;
+    constexpr int WM = BM / WGM, WN = BN / WGN, TM = WM / 32, TN = WN / 32;
+    constexpr int PA = BM * 64, PB = BN * 64;
+    constexpr int STAGE = 3 * (PA + PB);
+    constexpr int NIA = 3 * BM / 16 / NW, NIB = 3 * BN / 16 / NW;
+    constexpr int CTS = BN + 4;
+    constexpr int CBYTES = BM * CTS * 4;
+    constexpr int SMEM = (NST * STAGE > CBYTES + 16) ? NST * STAGE : CBYTES + 16;
+    __shared__ __attribute__((aligned(1024))) unsigned char smem[SMEM];          // (the ONE LDS object of the kernel)
+
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    const int M = p.M, N = p.N;
+    const long long a_plane = p.a_plane, b_plane = p.b_plane, lda = p.lda, ldb = p.ldb;
+    const int nkt = (p.K + BK - 1) / BK;
+    const unsigned gx = p.sk_tiles_m, gy = p.sk_tiles_n;
+    const unsigned full = p.sk_full, nsk = p.sk_blocks, ntiles_all = gx * gy, rtiles = ntiles_all - full;
+    const unsigned lin = blockIdx.x;
+    // units of this block: ONE whole tile (lin < full, XCD-aware order over the whole-round tiles) or a k-range of the tail tiles
+    unsigned seg_tile[2];
+    int seg_k0[2], seg_k1[2], nseg;
+    const bool sk = lin >= full;
+    const unsigned skb = lin - full;
+    const long long units = (long long)rtiles * nkt;
+    auto ub = [&](unsigned b) { return (long long)b * units / nsk; };             // first unit of tail block b
+    if (!sk) {
+        constexpr unsigned XCDS = 8;
+        const unsigned xcd = lin % XCDS, local = lin / XCDS;
+        const unsigned per_xcd = (full + XCDS - 1) / XCDS, tall = (full % XCDS) ? (full % XCDS) : XCDS;
+        seg_tile[0] = xcd < tall ? xcd * per_xcd + local : tall * per_xcd + (xcd - tall) * (per_xcd - 1) + local;
+        seg_k0[0] = 0; seg_k1[0] = nkt; nseg = 1;
+    } else {
+        const long long u0 = ub(skb), u1 = ub(skb + 1);
+        nseg = 0;
+        long long u = u0;
+        while (u < u1 && nseg < 2) {
+            const unsigned t = (unsigned)(u / nkt);
+            const int k0 = (int)(u - (long long)t * nkt);
+            const int k1 = (int)min((long long)nkt, k0 + (u1 - u));
+            seg_tile[nseg] = full + t; seg_k0[nseg] = k0; seg_k1[nseg] = k1; ++nseg;
+            u += k1 - k0;
+        }
+    }
+
+    const int wm = wave / WGN, wn = wave % WGN;
+    const int lr = lane & 31, lk = lane >> 5;
+    const int sw = (lr >> 2) & 3;
+    const int fo0 = lr * 64 + (((0 + lk) ^ sw) << 4), fo1 = lr * 64 + (((2 + lk) ^ sw) << 4);
+    typedef __attribute__((address_space(3))) void* lds_ptr;
+    constexpr unsigned XCD_GROUP = 8;
+
+    for (int sg = 0; sg < nseg; ++sg) {
+        const unsigned rem = seg_tile[sg];
+        const unsigned band = XCD_GROUP * gy, bid = rem / band, first = bid * XCD_GROUP;
+        const unsigned bm = min(gx - first, XCD_GROUP), inb = rem - bid * band;
+        const unsigned tile_m = first + inb % bm, tile_n = inb / bm;
+        const int m0 = (int)tile_m * BM, n0 = (int)tile_n * BN;
+        const int kt0 = seg_k0[sg], kt1 = seg_k1[sg];
+        const int ntiles = kt1 - kt0;
+        const bool partial = ntiles < nkt;
+
+        unsigned avo[NIA], bvo[NIB];
+        int alds[NIA], blds[NIB];
+        {
+            const int lrow = lane >> 2;
+            const int lchunk = (lane & 3) ^ ((lane >> 4) & 3);
+#pragma unroll
+            for (int i = 0; i < NIA; ++i) {
+                const int u = wave + NW * i, q = u / (BM / 16), rb = u % (BM / 16);
+                const int r = rb * 16 + lrow;
+                avo[i] = (m0 + r < M) ? (unsigned)(((long long)q * a_plane + (long long)r * lda) * 2 + lchunk * 16) : PG_INVALID;
+                alds[i] = __builtin_amdgcn_readfirstlane(q * PA + rb * 1024);
+            }
+#pragma unroll
+            for (int i = 0; i < NIB; ++i) {
+                const int u = wave + NW * i, q = u / (BN / 16), rb = u % (BN / 16);
+                const int r = rb * 16 + lrow;
+                bvo[i] = (n0 + r < N) ? (unsigned)(((long long)q * b_plane + (long long)r * ldb) * 2 + lchunk * 16) : PG_INVALID;
+                blds[i] = __builtin_amdgcn_readfirstlane(3 * PA + q * PB + rb * 1024);
+            }
+        }
+        const unsigned short* abase = p.A + (long long)m0 * lda + (long long)kt0 * BK;
+        const unsigned short* bbase = p.B + (long long)n0 * ldb + (long long)kt0 * BK;
+        auto issue = [&](int stage, unsigned inv) {
+            unsigned char* sb = smem + stage * STAGE;
+            const __amdgpu_buffer_rsrc_t ra = pg_rsrc(abase), rb = pg_rsrc(bbase);
+#pragma unroll
+            for (int i = 0; i < NIA; ++i)
+                __builtin_amdgcn_raw_ptr_buffer_load_lds(ra, (lds_ptr)(sb + alds[i]), 16, (int)(avo[i] | inv), 0, 0, 0);
+#pragma unroll
+            for (int i = 0; i < NIB; ++i)
+                __builtin_amdgcn_raw_ptr_buffer_load_lds(rb, (lds_ptr)(sb + blds[i]), 16, (int)(bvo[i] | inv), 0, 0, 0);
+            abase += BK;
+            bbase += BK;
+        };
+        f32x16 acc[TM][TN];
+#pragma unroll
+        for (int i = 0; i < TM; ++i)
+#pragma unroll
+            for (int j = 0; j < TN; ++j)
+#pragma unroll
+                for (int r = 0; r < 16; ++r) acc[i][j][r] = 0.f;
+        pg_u32x4 fa0[3][TM], fb0[3][TN], fa1[3][TM], fb1[3][TN];
+        auto read_frags = [&](int stage, int fo, pg_u32x4 (&fa)[3][TM], pg_u32x4 (&fb)[3][TN]) {
+            const unsigned char* as = smem + stage * STAGE + (wm * WM) * 64 + fo;
+            const unsigned char* bs = smem + stage * STAGE + 3 * PA + (wn * WN) * 64 + fo;
+#pragma unroll
+            for (int q = 0; q < 3; ++q) {
+#pragma unroll
+                for (int i = 0; i < TM; ++i) fa[q][i] = *reinterpret_cast<const pg_u32x4*>(as + q * PA + i * 32 * 64);
+#pragma unroll
+                for (int j = 0; j < TN; ++j) fb[q][j] = *reinterpret_cast<const pg_u32x4*>(bs + q * PB + j * 32 * 64);
+            }
+        };
+        auto mma = [&](const pg_u32x4 (&fa)[3][TM], const pg_u32x4 (&fb)[3][TN]) {
+            constexpr int qa[6] = {2, 0, 1, 1, 0, 0}, qb[6] = {0, 2, 1, 0, 1, 0};
+#pragma unroll
+            for (int t = 0; t < 6; ++t)
+#pragma unroll
+                for (int i = 0; i < TM; ++i)
+#pragma unroll
+                    for (int j = 0; j < TN; ++j)
+                        acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(__builtin_bit_cast(pg_bf16x8, fa[qa[t]][i]),
+                                                                            __builtin_bit_cast(pg_bf16x8, fb[qb[t]][j]), acc[i][j], 0, 0, 0);
+        };
+        constexpr int NIW = NIA + NIB;
+        constexpr int NMMA = 6 * TM * TN, NRD = 3 * (TM + TN);
+        issue(0, 0u);
+        issue(1, ntiles > 1 ? 0u : PG_INVALID);
+        asm volatile("s_waitcnt vmcnt(%0)" ::"n"(NIW) : "memory");
+        __builtin_amdgcn_s_barrier();
+        auto settle0 = [&]() {
+#pragma unroll
+            for (int q = 0; q < 3; ++q) {
+#pragma unroll
+                for (int i = 0; i < TM; ++i) asm volatile("" ::"v"(fa0[q][i]));
+#pragma unroll
+                for (int j = 0; j < TN; ++j) asm volatile("" ::"v"(fb0[q][j]));
+            }
+        };
+        read_frags(0, fo0, fa0, fb0);
+        settle0();
+        int cur = 0;
+        for (int t = 0; t < ntiles; ++t) {
+            const int nxt = (cur + 1 == NST) ? 0 : cur + 1;
+            const int nn = (nxt + 1 == NST) ? 0 : nxt + 1;
+            __builtin_amdgcn_sched_barrier(0);
+            issue(nn, t + NST - 1 < ntiles ? 0u : PG_INVALID);
+            read_frags(cur, fo1, fa1, fb1);
+            mma(fa0, fb0);
+#pragma unroll
+            for (int g = 0; g < NMMA; ++g) {
+                __builtin_amdgcn_sched_group_barrier(0x008, 1, 0);
+                if (g < NRD) __builtin_amdgcn_sched_group_barrier(0x100, 1, 0);
+                if (g < NIW) { __builtin_amdgcn_sched_group_barrier(0x004, 2, 0); __builtin_amdgcn_sched_group_barrier(0x020, 1, 0); }
+            }
+            __builtin_amdgcn_sched_barrier(0);
+            asm volatile("s_waitcnt vmcnt(%0) lgkmcnt(0)" ::"n"(NIW) : "memory");
+            __builtin_amdgcn_s_barrier();
+            __builtin_amdgcn_sched_barrier(0);
+            read_frags(nxt, fo0, fa0, fb0);
+            mma(fa1, fb1);
+#pragma unroll
+            for (int g = 0; g < NMMA; ++g) {
+                __builtin_amdgcn_sched_group_barrier(0x008, 1, 0);
+                if (g < NRD) __builtin_amdgcn_sched_group_barrier(0x100, 1, 0);
+            }
+            __builtin_amdgcn_sched_barrier(0);
+            settle0();
+            cur = nxt;
+        }
+        __syncthreads();                               // (drains the DMA queue: the output tile is staged over the operand stages)
+
+        const float alpha = p.alpha;
+        float* const Ct = reinterpret_cast<float*>(smem);
+        int* const flag = reinterpret_cast<int*>(smem + CBYTES);
+#pragma unroll
+        for (int j = 0; j < TN; ++j)
+#pragma unroll
+            for (int i = 0; i < TM; ++i)
+#pragma unroll
+                for (int r = 0; r < 16; ++r)
+                    Ct[(wm * WM + i * 32 + (r & 3) + 8 * (r >> 2) + 4 * lk) * CTS + wn * WN + j * 32 + lr] = acc[i][j][r] * alpha;
+        __syncthreads();
+        constexpr int QN = BN / 4;
+        // contributors of this tail tile: the tail blocks whose unit range meets the tile's (consecutive block indices)
+        unsigned c_first = 0, c_last = 0, first_slot = 0;
+        if (partial) {
+            const unsigned tt = rem - full;
+            const long long t0 = (long long)tt * nkt, t1 = t0 + nkt;
+            // the block that holds unit u is ceil((u + 1) nsk / units) - 1
+            c_first = (unsigned)(((t0 + 1) * nsk + units - 1) / units - 1);
+            c_last = (unsigned)((t1 * nsk + units - 1) / units - 1);
+            first_slot = (ub(c_first) == t0) ? 0u : 1u;          // only the first contributor can have started in the previous tile
+            // slab of block b for this tile: slot 0 if the tile holds b's first unit, else slot 1
+            float* slab = p.sk_ws + ((size_t)skb * 2 + (sg ? 1 : 0)) * (size_t)(BM * BN);
+            const __amdgpu_buffer_rsrc_t rs = __builtin_amdgcn_make_buffer_rsrc(slab, 0, BM * BN * 4, 0x00020000);
+#pragma unroll
+            for (int q = 0; q < BM * QN / NT; ++q) {
+                const int idx = tid + q * NT;
+                const int row = idx / QN, c = (idx % QN) * 4;
+                const pg_u32x4 v = *reinterpret_cast<const pg_u32x4*>(&Ct[row * CTS + c]);
+                __builtin_amdgcn_raw_buffer_store_b128(v, rs, (row * BN + c) * 4, 0, 16 /* sc1: write-through */);
+            }
+            asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+            __syncthreads();
+            if (tid == 0) *flag = __hip_atomic_fetch_add(p.sk_cnt + tt, 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+            __syncthreads();
+            const bool last = *flag == (int)(c_last - c_first);
+            if (!last) { __syncthreads(); continue; }                 // (uniform) somebody else finishes this tile
+            if (tid == 0) {
+                __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "agent");
+                __hip_atomic_store(p.sk_cnt + tt, 0, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);      // ready for the next launch
+            }
+            __syncthreads();
+        }
+        const float* bias = p.bias;
+        const int epi = p.epi, accumulate = p.accumulate;
+        const long long ldc = p.ldc;
+        float* const C = p.C;
+        float* const C2 = p.C2;
+        unsigned short* const Cp = p.Cp;
+#pragma unroll
+        for (int q = 0; q < BM * QN / NT; ++q) {
+            const int idx = tid + q * NT;
+            const int row = idx / QN, c = (idx % QN) * 4;
+            const int gm = m0 + row, gn = n0 + c;
+            if (gm >= M || gn >= N) continue;
+            float4 v;
+            if (partial) {
+                v = make_float4(0.f, 0.f, 0.f, 0.f);
+                for (unsigned b = c_first; b <= c_last; ++b) {
+                    const unsigned slot = (b == c_first) ? first_slot : 0u;
+                    const float4 o = *reinterpret_cast<const float4*>(p.sk_ws + ((size_t)b * 2 + slot) * (size_t)(BM * BN) + row * BN + c);
+                    v.x += o.x; v.y += o.y; v.z += o.z; v.w += o.w;
+                }
+            } else {
+                v = *reinterpret_cast<const float4*>(&Ct[row * CTS + c]);
+            }
+            if (bias) {
+                const float4 b = *reinterpret_cast<const float4*>(bias + gn);
+                v.x += b.x; v.y += b.y; v.z += b.z; v.w += b.w;
+            }
+            float* cp = C + (long long)gm * ldc + gn;
+            if (accumulate) {
+                const float4 o = *reinterpret_cast<const float4*>(cp);
+                v.x += o.x; v.y += o.y; v.z += o.z; v.w += o.w;
+            }
+            if (epi == VBG_EPI_RELU) v = make_float4(fmaxf(v.x, 0.f), fmaxf(v.y, 0.f), fmaxf(v.z, 0.f), fmaxf(v.w, 0.f));
+            if (C) *reinterpret_cast<float4*>(cp) = v;
+            if (epi == VBG_EPI_GELU_DUAL) {
+                v = make_float4(gelu_erf(v.x), gelu_erf(v.y), gelu_erf(v.z), gelu_erf(v.w));
+                if (C2) *reinterpret_cast<float4*>(C2 + (long long)gm * ldc + gn) = v;
+            }
+            if (Cp) {
+                const float e[4] = {v.x, v.y, v.z, v.w};
+                unsigned short h[4], m[4], l[4];
+#pragma unroll
+                for (int t = 0; t < 4; ++t) {
+                    const unsigned u = __float_as_uint(e[t]);
+                    const float r1 = e[t] - __uint_as_float(u & 0xffff0000u);
+                    const unsigned u1 = __float_as_uint(r1);
+                    const float r2 = r1 - __uint_as_float(u1 & 0xffff0000u);
+                    h[t] = (unsigned short)(u >> 16); m[t] = (unsigned short)(u1 >> 16); l[t] = (unsigned short)(__float_as_uint(r2) >> 16);
+                }
+                unsigned short* o = Cp + (long long)gm * p.ldp + gn;
+                *reinterpret_cast<uint2*>(o) = make_uint2(h[0] | ((unsigned)h[1] << 16), h[2] | ((unsigned)h[3] << 16));
+                *reinterpret_cast<uint2*>(o + p.c_plane) = make_uint2(m[0] | ((unsigned)m[1] << 16), m[2] | ((unsigned)m[3] << 16));
+                *reinterpret_cast<uint2*>(o + 2 * p.c_plane) = make_uint2(l[0] | ((unsigned)l[1] << 16), l[2] | ((unsigned)l[3] << 16));
+            }
+        }
+        __syncthreads();                               // the next segment's DMA overwrites the staged tile
+    }
+}
+
 // exact three-way split of one float: top 16 bits, top 16 bits of the (exact) remainder, the (exact, <= 8 bit) rest
 __device__ __forceinline__ void pg_split3(float x, unsigned short& h, unsigned short& m, unsigned short& l) {
     const unsigned u = __float_as_uint(x);
@@ -602,6 +890,27 @@ static int plane_gemm_dispatch(const vbg_plane_gemm_desc* desc, void* stream, vo
     if (tile == 0) {
         const long t128 = (long)cdiv(d.M, 128) * cdiv(d.N, 128) * d.splitk;
         tile = (t128 >= 200 && d.N >= 128) ? 128128 : 64064;
+    }
+    if ((tile == 128129 || tile == 128130) && d.sk_ws && d.sk_cnt && d.sk_blocks >= 8 && d.splitk == 1) {
+        // stream-K tail when the last round of 128 x 128 tiles would leave a good part of the chip idle
+        const int tm = cdiv(d.M, 128), tn = cdiv(d.N, 128), nkt = d.K / 32;
+        const long T = (long)tm * tn, ncu = d.sk_blocks;
+        const long full = T / ncu * ncu, r = T - full;
+        if (r > 0 && r * 100 <= ncu * 85 && r * nkt >= 4 * ncu) {
+            VBG_CHECK_ARG(((uintptr_t)d.sk_ws & 15) == 0);
+            d.sk_full = (int)full; d.sk_tiles_m = tm; d.sk_tiles_n = tn;
+            const dim3 g((unsigned)(full + ncu));
+            (void)hipGetLastError();
+            hipEvent_t ev0 = (hipEvent_t)e0, ev1 = (hipEvent_t)e1;
+            if (tile == 128129) {
+                if (ev0 && ev1) hipExtLaunchKernelGGL((plane_gemm_sk_kernel<128, 128, 4, 2>), g, dim3(512), 0, s, ev0, ev1, 0, d);
+                else hipLaunchKernelGGL((plane_gemm_sk_kernel<128, 128, 4, 2>), g, dim3(512), 0, s, d);
+            } else {
+                if (ev0 && ev1) hipExtLaunchKernelGGL((plane_gemm_sk_kernel<128, 128, 2, 4>), g, dim3(512), 0, s, ev0, ev1, 0, d);
+                else hipLaunchKernelGGL((plane_gemm_sk_kernel<128, 128, 2, 4>), g, dim3(512), 0, s, d);
+            }
+            VBG_LAUNCH_RET();
+        }
     }
     if (tile == 256128) pg_launch<256, 128, 4, 2, 2>(d, s, (hipEvent_t)e0, (hipEvent_t)e1);
     else if (tile == 128128) pg_launch<128, 128, 2, 2, 3>(d, s, (hipEvent_t)e0, (hipEvent_t)e1);

@@ -173,6 +173,9 @@ def plane_gemm(a: Planes, b: Planes, out=None, *, bias=None, epi=EPI_NONE, C2=No
     if out_planes is not None:
         d.Cp, d.c_plane, d.ldp = out_planes.buf.data_ptr(), out_planes.plane, out_planes.ld
     d.epi, d.alpha, d.accumulate, d.splitk, d.tile = epi, float(alpha), int(bool(accumulate)), int(splitk), int(tile)
+    if _STREAMK[0] and not trans and splitk == 1 and tile in (128129, 128130):
+        ws, cnt, ncu = _sk_workspace(a.buf.device)
+        d.sk_ws, d.sk_cnt, d.sk_blocks = ws.data_ptr(), cnt.data_ptr(), ncu
     prof = _GEMM_PROF
     if prof is not None and not trans and prof.match(OP_DENSE_K, OP_DENSE_K, False):
         e0, e1 = prof.events()
@@ -181,6 +184,27 @@ def plane_gemm(a: Planes, b: Planes, out=None, *, bias=None, epi=EPI_NONE, C2=No
         return out
     check(lib.vbg_plane_gemm(C.byref(d), _stream()), "vbg_plane_gemm")
     return out
+
+
+_STREAMK = [os.environ.get("VBG_STREAMK", "0") != "0"]          # off: measured slower than the plain rounds at the BERT shapes (csrc/gemm_planes.hip)
+_SK_WS = {}
+
+
+def set_streamk(on: bool):
+    """stream-K tail of the NT plane products (csrc/gemm_planes.hip plane_gemm_sk_kernel)"""
+    _STREAMK[0] = bool(on)
+
+
+def _sk_workspace(device):
+    """(slabs, zeroed tile counters, CU count) of the stream-K tail: one set per (device, stream) -- launches on one stream are
+    ordered, launches on different streams must not share slabs"""
+    key = (device.index, torch.cuda.current_stream().cuda_stream)
+    w = _SK_WS.get(key)
+    if w is None:
+        ncu = torch.cuda.get_device_properties(device).multi_processor_count
+        w = (torch.empty((ncu * 2 * 128 * 128,), device=device, dtype=f32), torch.zeros((ncu,), device=device, dtype=i32), ncu)
+        _SK_WS[key] = w
+    return w
 
 
 def plane_gemm_grouped(problems, *, trans=True, accumulate=True, tile=0, alpha=1.0):
