@@ -179,6 +179,7 @@ typedef struct vbg_attn_desc {
     const unsigned short* dO; long long do_plane, do_ld;
     float* out; long long ldo;
     float* lse; float* delta;
+    unsigned short* out_planes; long long op_plane, op_ld;   /* FWD, optional: the three bf16 planes [3][ntok][op_ld] of O */
     float* kbar; long long ldk;     /* [ntok][ldk]: FWD writes sum_k P_k K_k (bf16 precision; NULL = skip), DQ reads it */
     const unsigned* mask_q; const unsigned* mask_k; const long long* mask_off;
     float scale, keep_scale;
@@ -227,6 +228,12 @@ int vbg_embed_ln_bwd(const float* dout, const float* xhat, const float* rstd, co
 int vbg_dropout_add_ln_fwd(const float* x, const float* res, int rows, int hidden, const float* gamma,
                            const float* beta, float eps, float drop_p, unsigned long long seed,
                            unsigned long long stream_id, float* y, float* xhat, float* rstd, void* stream);
+/* the same, and y's three bf16 planes [3][rows][ldp] (plane stride `plane`; ldp == hidden leaves no padding columns to zero, a wider
+ * ldp expects them zero already) -- the A operand of the plane GEMM that consumes y: saves the separate split pass */
+int vbg_dropout_add_ln_fwd_planes(const float* x, const float* res, int rows, int hidden, const float* gamma,
+                                  const float* beta, float eps, float drop_p, unsigned long long seed,
+                                  unsigned long long stream_id, float* y, float* xhat, float* rstd, unsigned short* y_planes, int ldp,
+                                  long long plane, void* stream);
 /* dx (to the dense output), dres, dgamma/dbeta +=.  `slots_ws` (optional): fp32 [vbg_ln_slots()][2][hidden] workspace that is ZERO
  * on entry and left zero on exit; with it the per-block column sums are spread over the slot rows and folded by a second tiny
  * launch (same-address atomics serialise: ~500 blocks per column at cfg2), without it they go straight into dgamma/dbeta */

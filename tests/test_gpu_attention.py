@@ -51,7 +51,9 @@ def _run(seq_len, heads, p, seed=0):
     O = torch.zeros(ntok, hid, device=dev)
     lse = torch.zeros(2, heads, meta.ntok_pad, device=dev)
     kbar = torch.zeros(ntok, hid, device=dev)
-    ops.attn(meta, ATTN_FWD, pq, None, O, lse, None, masks, scale, p, kbar=kbar)
+    opl = ops.planes_empty(ntok, hid, dev)
+    ops.attn(meta, ATTN_FWD, pq, None, O, lse, None, masks, scale, p, kbar=kbar, out_planes=opl)
+    assert torch.equal(opl.buf, ops.split_planes(O).buf), "planes of O written by the forward kernel != split(O)"
     delta = ops.attn_delta(dO.to(dev), O, meta, torch.zeros_like(lse[0]))
     dqkv = torch.full((ntok, 3 * hid), float("nan"), device=dev)
     ops.attn(meta, ATTN_DQ, pq, pdo, dqkv, lse, delta, masks, scale, p, kbar=kbar)

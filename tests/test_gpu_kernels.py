@@ -239,6 +239,9 @@ def test_dropout_add_ln(ops, rows, Hd):
     y.backward(gy)
     d = dev()
     yo, xhat, rstd = ops.dropout_add_ln_fwd(x.detach().to(d), r.detach().to(d), gam.detach().to(d), bet.detach().to(d), 1e-12, 0.0, 1, 0)
+    ypl = ops.planes_empty(rows, Hd, d)
+    y2, _, _ = ops.dropout_add_ln_fwd(x.detach().to(d), r.detach().to(d), gam.detach().to(d), bet.detach().to(d), 1e-12, 0.0, 1, 0, out_planes=ypl)
+    assert torch.equal(y2, yo) and torch.equal(ypl.buf, ops.split_planes(yo).buf)          # planes written by the LayerNorm pass == split(y)
     assert close(yo, y, 1e-4, 1e-5)
     dg, db = torch.zeros(Hd, device=d), torch.zeros(Hd, device=d)
     dx, dres = ops.dropout_add_ln_bwd(gy.to(d), xhat, rstd, gam.detach().to(d), 0.0, 1, 0, dg, db)

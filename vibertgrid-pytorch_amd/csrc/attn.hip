@@ -376,6 +376,28 @@ __global__ __launch_bounds__(256) void attn_kernel(const vbg_attn_desc p) {
         const float lt = l_run + __shfl_xor(l_run, 32, 64);
         const float il = 1.0f / lt;
         store(acc0, il, head * 64, p.out);
+        if (p.out_planes) {                           // exact three-way split of the stored values, 4 bf16 (8 bytes) per plane and quad
+            unsigned short* pr0 = p.out_planes + (long long)(row0 + own0 + lr) * p.op_ld + head * 64;
+#pragma unroll
+            for (int db = 0; db < 2; ++db)
+#pragma unroll
+                for (int j = 0; j < 4; ++j) {
+                    unsigned h[4], m[4], l[4];
+#pragma unroll
+                    for (int i = 0; i < 4; ++i) {
+                        const float e = acc0[db][4 * j + i] * il;
+                        const unsigned u = __float_as_uint(e);
+                        const float r1 = e - __uint_as_float(u & 0xffff0000u);
+                        const unsigned u1 = __float_as_uint(r1);
+                        const float r2 = r1 - __uint_as_float(u1 & 0xffff0000u);
+                        h[i] = u >> 16; m[i] = u1 >> 16; l[i] = __float_as_uint(r2) >> 16;
+                    }
+                    unsigned short* o = pr0 + db * 32 + 8 * j + 4 * lh;
+                    *reinterpret_cast<uint2*>(o) = make_uint2(h[0] | (h[1] << 16), h[2] | (h[3] << 16));
+                    *reinterpret_cast<uint2*>(o + p.op_plane) = make_uint2(m[0] | (m[1] << 16), m[2] | (m[3] << 16));
+                    *reinterpret_cast<uint2*>(o + 2 * p.op_plane) = make_uint2(l[0] | (l[1] << 16), l[2] | (l[3] << 16));
+                }
+        }
         if (want_kbar) store(acc1, il, head * 64, p.kbar + krow - orow);
         if (lh == 0) { p.lse[lsoff + own0 + lr] = m_run; p.lse[lsplane + lsoff + own0 + lr] = il; }
     } else if constexpr (DQ) {
@@ -458,6 +480,7 @@ extern "C" int vbg_attn(const vbg_attn_desc* desc, void* stream) {
     VBG_CHECK_ARG(d.tasks && d.seq_len && d.seq_row0 && d.pad_off && d.qkv && d.out && d.lse);
     VBG_CHECK_ARG(d.qkv_ld % 8 == 0 && ((uintptr_t)d.qkv & 15) == 0 && d.qkv_plane % 8 == 0 && 6 * d.qkv_plane < 0x7fffffffll);
     VBG_CHECK_ARG(((uintptr_t)d.kbar & 15) == 0 && d.ldk % 4 == 0);
+    if (d.out_planes) VBG_CHECK_ARG(d.mode == VBG_ATTN_FWD && ((uintptr_t)d.out_planes & 7) == 0 && d.op_ld % 4 == 0 && d.op_plane % 4 == 0);
     VBG_CHECK_ARG(d.ldo % 4 == 0 && ((uintptr_t)d.out & 15) == 0 && d.ntok_pad % 32 == 0 && ((uintptr_t)d.lse & 15) == 0);
     if (d.mode != VBG_ATTN_FWD) {
         VBG_CHECK_ARG(d.dO && d.delta && d.do_ld % 8 == 0 && ((uintptr_t)d.dO & 15) == 0 && d.do_plane % 8 == 0 && 6 * d.do_plane < 0x7fffffffll);

@@ -145,7 +145,8 @@ __device__ __forceinline__ float4 drop4(float4 v, uint32_t thr, float ks, uint64
 __global__ __launch_bounds__(256) void dropout_add_ln_fwd_kernel(
     const float* __restrict__ x, const float* __restrict__ res, int rows, int hidden, const float* __restrict__ gamma,
     const float* __restrict__ beta, float eps, uint32_t drop_thr, float keep_scale, uint64_t seed, uint64_t sid,
-    float* __restrict__ y, float* __restrict__ xhat_out, float* __restrict__ rstd_out) {
+    float* __restrict__ y, float* __restrict__ xhat_out, float* __restrict__ rstd_out,
+    unsigned short* __restrict__ ypl, int ldp, long long plane) {
     const int lane = threadIdx.x & 63;
     const int t = blockIdx.x * 4 + (threadIdx.x >> 6);
     if (t >= rows) return;
@@ -183,6 +184,22 @@ __global__ __launch_bounds__(256) void dropout_add_ln_fwd_kernel(
             o.x = xh.x * g.x + b.x; o.y = xh.y * g.y + b.y; o.z = xh.z * g.z + b.z; o.w = xh.w * g.w + b.w;
             *reinterpret_cast<float4*>(y + base + c) = o;
             *reinterpret_cast<float4*>(xhat_out + base + c) = xh;
+            if (ypl) {                                // the bf16 planes of y (the A operand of the next plane GEMM), exact 3-way split
+                const float e[4] = {o.x, o.y, o.z, o.w};
+                unsigned short h[4], m[4], l[4];
+#pragma unroll
+                for (int i = 0; i < 4; ++i) {
+                    const unsigned u = __float_as_uint(e[i]);
+                    const float r1 = e[i] - __uint_as_float(u & 0xffff0000u);
+                    const unsigned u1 = __float_as_uint(r1);
+                    const float r2 = r1 - __uint_as_float(u1 & 0xffff0000u);
+                    h[i] = (unsigned short)(u >> 16); m[i] = (unsigned short)(u1 >> 16); l[i] = (unsigned short)(__float_as_uint(r2) >> 16);
+                }
+                unsigned short* op = ypl + (long long)t * ldp + c;
+                *reinterpret_cast<uint2*>(op) = make_uint2(h[0] | ((unsigned)h[1] << 16), h[2] | ((unsigned)h[3] << 16));
+                *reinterpret_cast<uint2*>(op + plane) = make_uint2(m[0] | ((unsigned)m[1] << 16), m[2] | ((unsigned)m[3] << 16));
+                *reinterpret_cast<uint2*>(op + 2 * plane) = make_uint2(l[0] | ((unsigned)l[1] << 16), l[2] | ((unsigned)l[3] << 16));
+            }
         }
     if (lane == 0) rstd_out[t] = rstd;
 }
@@ -482,7 +499,21 @@ extern "C" int vbg_dropout_add_ln_fwd(const float* x, const float* res, int rows
     VBG_CHECK_ARG(((uintptr_t)x | (uintptr_t)res | (uintptr_t)gamma | (uintptr_t)beta | (uintptr_t)y | (uintptr_t)xhat) % 16 == 0);
     if (rows <= 0) return VBG_OK;
     VBG_LAUNCH(dropout_add_ln_fwd_kernel, dim3(cdiv(rows, 4)), dim3(256), 0, (hipStream_t)stream, x, res, rows, hidden,
-               gamma, beta, eps, drop_threshold(drop_p), 1.0f / (1.0f - drop_p), seed, sid, y, xhat, rstd);
+               gamma, beta, eps, drop_threshold(drop_p), 1.0f / (1.0f - drop_p), seed, sid, y, xhat, rstd, (unsigned short*)nullptr, 0, 0ll);
+    VBG_LAUNCH_RET();
+}
+
+extern "C" int vbg_dropout_add_ln_fwd_planes(const float* x, const float* res, int rows, int hidden, const float* gamma,
+                                             const float* beta, float eps, float drop_p, unsigned long long seed,
+                                             unsigned long long sid, float* y, float* xhat, float* rstd, unsigned short* y_planes, int ldp,
+                                             long long plane, void* stream) {
+    VBG_CHECK_ARG(x && res && gamma && beta && y && xhat && rstd && y_planes);
+    VBG_CHECK_ARG(hidden > 0 && hidden % 256 == 0 && hidden <= 256 * LN_V && drop_p >= 0.f && drop_p < 1.f);
+    VBG_CHECK_ARG(((uintptr_t)x | (uintptr_t)res | (uintptr_t)gamma | (uintptr_t)beta | (uintptr_t)y | (uintptr_t)xhat) % 16 == 0);
+    VBG_CHECK_ARG(ldp % 4 == 0 && ldp >= hidden && plane % 4 == 0 && plane >= (long long)rows * ldp && ((uintptr_t)y_planes & 7) == 0);
+    if (rows <= 0) return VBG_OK;
+    VBG_LAUNCH(dropout_add_ln_fwd_kernel, dim3(cdiv(rows, 4)), dim3(256), 0, (hipStream_t)stream, x, res, rows, hidden,
+               gamma, beta, eps, drop_threshold(drop_p), 1.0f / (1.0f - drop_p), seed, sid, y, xhat, rstd, y_planes, ldp, plane);
     VBG_LAUNCH_RET();
 }
 

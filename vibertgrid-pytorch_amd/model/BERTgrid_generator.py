@@ -190,9 +190,10 @@ class BERTgridGenerator(nn.Module):
         eps = float(cfg.layer_norm_eps)
         x = Fn.BertEmbedFn.apply(emb.word_embeddings.weight, emb.position_embeddings.weight, emb.token_type_embeddings.weight,
                                  emb.LayerNorm.weight, emb.LayerNorm.bias, ids, pos, eps, p, seed, 1000)
+        xpl = None                       # bf16 planes of x, handed from each layer's closing LayerNorm to the next layer's first product
         for li, layer in enumerate(m.encoder.layer):
             a, o_, it, ou = layer.attention.self, layer.attention.output, layer.intermediate, layer.output
-            x = Fn.BertLayerFn.apply(x, a.query.weight, a.query.bias, a.key.weight, a.key.bias, a.value.weight, a.value.bias,
+            x, xpl = Fn.BertLayerFn.apply(x, xpl, a.query.weight, a.query.bias, a.key.weight, a.key.bias, a.value.weight, a.value.bias,
                                      o_.dense.weight, o_.dense.bias, o_.LayerNorm.weight, o_.LayerNorm.bias,
                                      it.dense.weight, it.dense.bias, ou.dense.weight, ou.dense.bias, ou.LayerNorm.weight,
                                      ou.LayerNorm.bias, meta, eps, p, seed, li)

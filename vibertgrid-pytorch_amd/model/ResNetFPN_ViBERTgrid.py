@@ -25,9 +25,29 @@ def _cl(module: nn.Module):
     return module
 
 
+class bn_tick_scope:
+    """Inside the scope the `num_batches_tracked += 1` of every training-mode BatchNorm (torch.nn.BatchNorm2d.forward) is collected
+    and applied by ONE multi-tensor launch on exit instead of one tiny launch per layer (40 at resnet34 + heads)."""
+    _pending = None
+
+    def __enter__(self):
+        self._outer = bn_tick_scope._pending
+        bn_tick_scope._pending = []
+        return self
+
+    def __exit__(self, *exc):
+        ticks, bn_tick_scope._pending = bn_tick_scope._pending, self._outer
+        if ticks:
+            torch._foreach_add_(ticks, 1)
+        return False
+
+
 def conv_bn(x, conv: nn.Conv2d, bn: nn.Module, res=None, relu=True):
     if bn.training and bn.track_running_stats and bn.num_batches_tracked is not None:
-        bn.num_batches_tracked.add_(1)
+        if bn_tick_scope._pending is not None:
+            bn_tick_scope._pending.append(bn.num_batches_tracked)
+        else:
+            bn.num_batches_tracked.add_(1)
     return Fn.ConvBnFn.apply(x, conv.weight, bn.weight, bn.bias, bn.running_mean, bn.running_var, res, conv.stride[0],
                              conv.padding[0], relu, bn.training, bn.momentum, bn.eps, isinstance(bn, nn.SyncBatchNorm))
 

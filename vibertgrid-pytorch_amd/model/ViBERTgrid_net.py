@@ -22,7 +22,7 @@ from model.BERTgrid_generator import BERTgridGenerator
 from model.field_type_classification_head import (CRFFieldTypeClassification, FieldTypeClassification, LateFusion,
                                                    SimplifiedFieldTypeClassification)
 from model.grid_roi_align import GridROIAlign
-from model.ResNetFPN_ViBERTgrid import resnet_18_D_fpn, resnet_18_fpn, resnet_34_D_fpn, resnet_34_fpn
+from model.ResNetFPN_ViBERTgrid import bn_tick_scope, resnet_18_D_fpn, resnet_18_fpn, resnet_34_D_fpn, resnet_34_fpn
 from model.semantic_segmentation_head import SemanticSegmentationClassifier, SimplifiedSemanticSegmentationClassifier
 from vbg import ops
 from pipeline.custom_loss import PendingCounts, resolve_plans  # noqa: F401
@@ -215,6 +215,10 @@ class ViBERTgridNet(nn.Module):
 
     def forward(self, image: Tuple[torch.Tensor], seg_indices: Tuple[torch.Tensor], segment_classes: Tuple[torch.Tensor],
                 coors: torch.Tensor, corpus: torch.Tensor, mask: torch.Tensor):
+        with bn_tick_scope():          # the BatchNorm step counters of the whole forward advance in one launch
+            return self._forward(image, seg_indices, segment_classes, coors, corpus, mask)
+
+    def _forward(self, image, seg_indices, segment_classes, coors, corpus, mask):
         # `amp: True`: the caller wraps this call in torch.cuda.amp.autocast (reference pipeline/train_val_utils.py:264); the
         # matrix products of this forward AND of its backward then run on the bf16 matrix cores (see vbg.ops.set_amp)
         ops.set_amp(torch.is_autocast_enabled("cuda"))

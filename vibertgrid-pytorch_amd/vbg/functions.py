@@ -518,7 +518,9 @@ class BertLayerFn(torch.autograd.Function):
     out-proj + dropout + residual LN, FFN(GELU erf) + dropout + residual LN)."""
 
     @staticmethod
-    def forward(ctx, x, wq, bq, wk, bk, wv, bv, wo, bo, g1, b1, wi, bi, wo2, bo2, g2, b2, meta, eps, p, seed, layer):
+    def forward(ctx, x, xpl, wq, bq, wk, bk, wv, bv, wo, bo, g1, b1, wi, bi, wo2, bo2, g2, b2, meta, eps, p, seed, layer):
+        """xpl: the bf16 planes of x ([3, ntok, hidden] int16) when the producer already wrote them, else None.  Returns (y, planes of y
+        or None): the LayerNorm that ends the layer splits its output for the next layer's first product."""
         x = _c(x)
         ntok, hid = x.shape
         H, dh = meta.heads, meta.dh
@@ -532,7 +534,7 @@ class BertLayerFn(torch.autograd.Function):
         else:                      # q, k, v leave the projection as planes only: the fused attention kernels' operands
             pqkv = ops.planes_empty(ntok, 3 * hid, dev)
         if planes:                 # operands split into bf16 planes once (csrc/gemm_planes.hip), weights once per optimizer step
-            px = ops.split_planes(x)
+            px = ops.Planes(xpl, ntok, hid, xpl.shape[2]) if xpl is not None else ops.split_planes(x)
             if fused_qkv:
                 ops.plane_gemm(px, ops.weight_planes(wq, view=_stack3(wq), also=(wk, wv)), qkv, bias=_stack3(bq), out_planes=pqkv,
                                tile=ops._dense_tile(ntok, 3 * hid))
@@ -552,7 +554,8 @@ class BertLayerFn(torch.autograd.Function):
             lse = torch.zeros((2, H, meta.ntok_pad), device=dev, dtype=f32)            # row statistics (m, 1 / l)
             masks = ops.attn_mask(meta, p, seed, sid + 0) if p > 0 else None
             kbar = torch.empty((ntok, hid), device=dev, dtype=f32) if any(ctx.needs_input_grad) else None
-            ops.attn(meta, ATTN_FWD, pqkv, None, ctxv, lse, None, masks, 1.0 / (dh ** 0.5), p, kbar=kbar)
+            pctx = ops.planes_empty(ntok, hid, dev)
+            ops.attn(meta, ATTN_FWD, pqkv, None, ctxv, lse, None, masks, 1.0 / (dh ** 0.5), p, kbar=kbar, out_planes=pctx)
         else:
             # scores -> probabilities (in place), grouped over (sequence, head)
             P = torch.empty((meta.s_elems,), device=dev, dtype=f32)
@@ -561,15 +564,17 @@ class BertLayerFn(torch.autograd.Function):
             ops.softmax_fwd(P, meta.soff, meta.lens, meta.ldp, meta.ngroups, H, meta.maxlen, 1.0 / (dh ** 0.5), p, seed, sid + 0)
             ops.gemm_raw(0, 0, 0, P, meta.ld, OP_DENSE_K, qkv, 3 * hid, OP_DENSE_R, ctxv, hid, grp=meta.t_pv, ngroups=meta.ngroups,
                          grp_max=(meta.maxlen, dh), b_ptr_off=2 * hid, a_relu_scale=1.0 / (1.0 - p))
+        py = None
         if planes:
-            pctx = ops.split_planes(ctxv)
+            if pctx is None:
+                pctx = ops.split_planes(ctxv)
             ao = ops.plane_gemm(pctx, ops.weight_planes(wo), torch.empty((ntok, hid), device=dev, dtype=f32), bias=bo, tile=ops._dense_tile(ntok, hid))
-            x1, xh1, rs1 = ops.dropout_add_ln_fwd(ao, x, g1, b1, eps, p, seed, sid + 1)
+            px1 = ops.planes_empty(ntok, hid, dev)
+            x1, xh1, rs1 = ops.dropout_add_ln_fwd(ao, x, g1, b1, eps, p, seed, sid + 1, out_planes=px1)
             inter = wi.shape[0]
             h = torch.empty((ntok, inter), device=dev, dtype=f32)
             # gelu(h) leaves the FFN1 epilogue as planes only (the A operand of FFN2 and, untransposed, of its weight gradient)
             pg = ops.planes_empty(ntok, inter, dev)
-            px1 = ops.split_planes(x1)
             ops.plane_gemm(px1, ops.weight_planes(wi), h, bias=bi, epi=EPI_GELU_DUAL, out_planes=pg, tile=ops._dense_tile(ntok, inter, True))
             fo = ops.plane_gemm(pg, ops.weight_planes(wo2), torch.empty((ntok, hid), device=dev, dtype=f32), bias=bo2, tile=ops._dense_tile(ntok, hid))
             g = None
@@ -578,7 +583,9 @@ class BertLayerFn(torch.autograd.Function):
             x1, xh1, rs1 = ops.dropout_add_ln_fwd(ao, x, g1, b1, eps, p, seed, sid + 1)
             h, g = ops.linear_fwd(x1, wi, bi, EPI_GELU_DUAL)
             fo = ops.linear_fwd(g, wo2, bo2)
-        y, xh2, rs2 = ops.dropout_add_ln_fwd(fo, x1, g2, b2, eps, p, seed, sid + 2)
+        if planes:
+            py = ops.planes_empty(ntok, hid, dev)
+        y, xh2, rs2 = ops.dropout_add_ln_fwd(fo, x1, g2, b2, eps, p, seed, sid + 2, out_planes=py)
         ctx.meta, ctx.cfg = meta, (eps, p, seed, sid)
         ctx.planes, ctx.flash = planes, flash
         ctx.w_refs = (wq, wk, wv, wo, wi, wo2)
@@ -593,7 +600,10 @@ class BertLayerFn(torch.autograd.Function):
                 ctx.save_for_backward(wq, wk, wv, wo, g1, wi, wo2, g2, qkv, P, xh1, rs1, h, xh2, rs2, px.buf, pctx.buf, px1.buf, pg.buf)
         else:
             ctx.save_for_backward(x, wq, wk, wv, wo, g1, wi, wo2, g2, qkv, P, ctxv, xh1, rs1, x1, h, g, xh2, rs2)
-        return y
+        if py is None:
+            return y, None
+        ctx.mark_non_differentiable(py.buf)
+        return y, py.buf
 
     @staticmethod
     def _backward_planes(ctx, dy):
@@ -674,7 +684,7 @@ class BertLayerFn(torch.autograd.Function):
         if qkv_sunk:
             for t in (rq, rk, rv, rbq, rbk, rbv):
                 wgrad_done(t)
-            return (dx, None, None, None, None, None, None, dwo, dbo, dg1, db1, dwi, dbi, dwo2, dbo2, dg2, db2, None, None, None, None, None)
+            return (dx, None, None, None, None, None, None, None, dwo, dbo, dg1, db1, dwi, dbi, dwo2, dbo2, dg2, db2, None, None, None, None, None)
         dws, dbs = [], []
         for j, (wr, br) in enumerate(((rq, rbq), (rk, rbk), (rv, rbv))):
             dj = dw_qkv[j * hid:(j + 1) * hid]
@@ -685,11 +695,11 @@ class BertLayerFn(torch.autograd.Function):
                 dj = None
             dws.append(dj)
             dbs.append(_bias_grad(br, dqkv[:, j * hid:(j + 1) * hid]))
-        return (dx, dws[0], dbs[0], dws[1], dbs[1], dws[2], dbs[2], dwo, dbo, dg1, db1, dwi, dbi, dwo2, dbo2,
+        return (dx, None, dws[0], dbs[0], dws[1], dbs[1], dws[2], dbs[2], dwo, dbo, dg1, db1, dwi, dbi, dwo2, dbo2,
                 dg2, db2, None, None, None, None, None)
 
     @staticmethod
-    def backward(ctx, dy):
+    def backward(ctx, dy, _dplanes=None):
         if ctx.planes:
             return BertLayerFn._backward_planes(ctx, dy)
         (x, wq, wk, wv, wo, g1, wi, wo2, g2, qkv, P, ctxv, xh1, rs1, x1, h, g, xh2, rs2) = ctx.saved_tensors
@@ -738,14 +748,14 @@ class BertLayerFn(torch.autograd.Function):
             ops.linear_dgrad(dqkv, _stack3(wq), out=dx, accumulate=True)
             for t in (rq, rk, rv, rbq, rbk, rbv):
                 wgrad_done(t)
-            return (dx, None, None, None, None, None, None, dwo, dbo, dg1, db1, dwi, dbi, dwo2, dbo2, dg2, db2, None, None, None, None, None)
+            return (dx, None, None, None, None, None, None, None, dwo, dbo, dg1, db1, dwi, dbi, dwo2, dbo2, dg2, db2, None, None, None, None, None)
         dws, dbs = [], []
         for j, (w, wr, br) in enumerate(((wq, rq, rbq), (wk, rk, rbk), (wv, rv, rbv))):
             dj = dqkv[:, j * hid:(j + 1) * hid]
             dws.append(_linear_wgrad(wr, dj, x))
             dbs.append(_bias_grad(br, dj))
             ops.linear_dgrad(dj, w, out=dx, accumulate=True)
-        return (dx, dws[0], dbs[0], dws[1], dbs[1], dws[2], dbs[2], dwo, dbo, dg1, db1, dwi, dbi, dwo2, dbo2,
+        return (dx, None, dws[0], dbs[0], dws[1], dbs[1], dws[2], dbs[2], dwo, dbo, dg1, db1, dwi, dbi, dwo2, dbo2,
                 dg2, db2, None, None, None, None, None)
 
 

@@ -56,7 +56,7 @@ class AttnDesc(C.Structure):
                 ("tasks", c_vp), ("seq_len", c_vp), ("seq_row0", c_vp), ("pad_off", c_vp), ("ntok_pad", c_ll),
                 ("qkv", c_vp), ("qkv_plane", c_ll), ("qkv_ld", c_ll),
                 ("dO", c_vp), ("do_plane", c_ll), ("do_ld", c_ll),
-                ("out", c_vp), ("ldo", c_ll), ("lse", c_vp), ("delta", c_vp), ("kbar", c_vp), ("ldk", c_ll),
+                ("out", c_vp), ("ldo", c_ll), ("lse", c_vp), ("delta", c_vp), ("out_planes", c_vp), ("op_plane", c_ll), ("op_ld", c_ll), ("kbar", c_vp), ("ldk", c_ll),
                 ("mask_q", c_vp), ("mask_k", c_vp), ("mask_off", c_vp),
                 ("scale", c_f), ("keep_scale", c_f)]
 
@@ -89,6 +89,7 @@ SIGNATURES = {
     "vbg_embed_ln_fwd": (c_int, [c_vp, c_vp, c_int, c_int, c_vp, c_vp, c_vp, c_vp, c_vp, c_f, c_f, c_ull, c_ull, c_vp, c_vp, c_vp, c_vp]),
     "vbg_embed_ln_bwd": (c_int, [c_vp, c_vp, c_vp, c_vp, c_vp, c_int, c_int, c_vp, c_f, c_ull, c_ull, c_vp, c_vp, c_vp, c_vp, c_vp, c_vp]),
     "vbg_dropout_add_ln_fwd": (c_int, [c_vp, c_vp, c_int, c_int, c_vp, c_vp, c_f, c_f, c_ull, c_ull, c_vp, c_vp, c_vp, c_vp]),
+    "vbg_dropout_add_ln_fwd_planes": (c_int, [c_vp, c_vp, c_int, c_int, c_vp, c_vp, c_f, c_f, c_ull, c_ull, c_vp, c_vp, c_vp, c_vp, c_int, c_ll, c_vp]),
     "vbg_ln_slots": (c_int, []),
     "vbg_dropout_add_ln_bwd": (c_int, [c_vp, c_vp, c_vp, c_int, c_int, c_vp, c_f, c_ull, c_ull, c_vp, c_vp, c_vp, c_vp, c_vp, c_vp]),
     "vbg_softmax_fwd": (c_int, [c_vp, c_vp, c_vp, c_vp, c_int, c_int, c_int, c_f, c_f, c_ull, c_ull, c_vp]),

@@ -566,11 +566,17 @@ def embed_ln_bwd(dout, xhat, rstd, ids, pos_ids, gamma, p, seed, sid, dword, dpo
                                P(dpos), P(dtype0), P(dgamma), P(dbeta), _stream()), "vbg_embed_ln_bwd")
 
 
-def dropout_add_ln_fwd(x, res, gamma, beta, eps, p, seed, sid):
+def dropout_add_ln_fwd(x, res, gamma, beta, eps, p, seed, sid, out_planes=None):
+    """out_planes: Planes [rows, hidden] that receive the split of y in the same pass (ld == hidden: no padding columns)"""
     rows, hidden = x.shape
     y = torch.empty_like(x)
     xhat = torch.empty_like(x)
     rstd = torch.empty((rows,), device=x.device, dtype=f32)
+    if out_planes is not None:
+        assert out_planes.ld == hidden and out_planes.rows == rows
+        check(lib.vbg_dropout_add_ln_fwd_planes(P(x), P(res), rows, hidden, P(gamma), P(beta), eps, p, seed, sid, P(y), P(xhat), P(rstd),
+                                                P(out_planes.buf), out_planes.ld, out_planes.plane, _stream()), "vbg_dropout_add_ln_fwd_planes")
+        return y, xhat, rstd
     check(lib.vbg_dropout_add_ln_fwd(P(x), P(res), rows, hidden, P(gamma), P(beta), eps, p, seed, sid, P(y), P(xhat), P(rstd),
                                      _stream()), "vbg_dropout_add_ln_fwd")
     return y, xhat, rstd
@@ -625,7 +631,7 @@ def attn_mask(meta, p, seed, sid):
     return mq, mk
 
 
-def attn(meta, mode, qkv: Planes, dO, out, lse, delta, masks, scale, p, kbar=None):
+def attn(meta, mode, qkv: Planes, dO, out, lse, delta, masks, scale, p, kbar=None, out_planes=None):
     """one fused attention pass (mode: lib.ATTN_FWD / ATTN_DQ / ATTN_DKV) over all (sequence, head) pairs of the packed batch"""
     d = AttnDesc()
     d.mode, d.heads, d.ntasks = int(mode), meta.heads, meta.ntasks
@@ -638,6 +644,8 @@ def attn(meta, mode, qkv: Planes, dO, out, lse, delta, masks, scale, p, kbar=Non
     d.delta = None if delta is None else delta.data_ptr()
     if kbar is not None:
         d.kbar, d.ldk = kbar.data_ptr(), kbar.stride(0)
+    if out_planes is not None:            # FWD: the planes of O ride along (the A operand of the output projection)
+        d.out_planes, d.op_plane, d.op_ld = out_planes.buf.data_ptr(), out_planes.plane, out_planes.ld
     if masks is not None:
         d.mask_q, d.mask_k, d.mask_off = masks[0].data_ptr(), masks[1].data_ptr(), meta.mask_off.data_ptr()
         d.keep_scale = attn_keep_scale(p)
