@@ -146,6 +146,10 @@ int vbg_plane_gemm_timed(const vbg_plane_gemm_desc* desc, void* stream, void* st
  * of a linear layer: torch's autograd `grad_output.sum(0)` for F.linear) */
 int vbg_split_planes(const float* x, long long ldx, int rows, int cols, unsigned short* out, int ldp, long long plane, int relu,
                      float* colsum_accum, void* stream);
+/* the planes (and column sums) of dg * gelu'(h): the backward of the GELU between the two FFN products (transformers
+ * BertIntermediate, erf form) fused into the split of its result -- dL/dh is only ever used as a plane operand */
+int vbg_split_planes_gelu_bwd(const float* dg, const float* h, long long ldx, int rows, int cols, unsigned short* out, int ldp,
+                              long long plane, float* colsum_accum, void* stream);
 /* x [rows][cols] fp32 -> TRANSPOSED planes [3][cols][ldp], ldp >= rows (multiple of 32), entries rows..ldp-1 zero */
 int vbg_split_planes_t(const float* x, long long ldx, int rows, int cols, unsigned short* out, int ldp, long long plane,
                        void* stream);
@@ -241,6 +245,13 @@ int vbg_ln_slots(void);
 int vbg_dropout_add_ln_bwd(const float* dy, const float* xhat, const float* rstd, int rows, int hidden,
                            const float* gamma, float drop_p, unsigned long long seed, unsigned long long stream_id,
                            float* dx, float* dres, float* dgamma, float* dbeta, float* slots_ws, void* stream);
+/* the same with dx delivered as bf16 planes [3][rows][ldp] (not as fp32) and its column sums added into dbias_accum[hidden]: dx is the
+ * gradient of the dense output in front of the LayerNorm, which is only ever a plane operand of that layer's gradient products, and
+ * its column sums are that layer's bias gradient.  slots3_ws: fp32 [vbg_ln_slots()][3][hidden], zero on entry, left zero. */
+int vbg_dropout_add_ln_bwd_planes(const float* dy, const float* xhat, const float* rstd, int rows, int hidden,
+                                  const float* gamma, float drop_p, unsigned long long seed, unsigned long long stream_id,
+                                  unsigned short* dx_planes, int ldp, long long plane, float* dres, float* dgamma, float* dbeta,
+                                  float* dbias_accum, float* slots3_ws, void* stream);
 /* attention probabilities, in place on the grouped score buffer: for group g (= seq*heads + head)
  * rows L=len[g/heads], row stride ldp[g/heads], block offset off[g]; P = softmax(S*scale);
  * dropped entries are stored NEGATED (sign bit = dropped), kept entries unscaled; pad columns = 0. */

@@ -263,6 +263,14 @@ def test_dropout_add_ln(ops, rows, Hd):
     assert abs(rate - (1 - p)) < 0.01
     dx, dres = ops.dropout_add_ln_bwd(torch.ones_like(yo), xhat, rstd, gam1, p, 123, 7, dg, db)
     assert torch.equal((dx != 0), (dres != 0) & (keep > 0)) or float(((dx != 0).float() - keep).abs().mean()) < 1e-3
+    # planes form of the backward: dx as bf16 planes (== split(dx) bit for bit), its column sums into the bias gradient, same dres
+    dg2, db2, dbias = torch.zeros(Hd, device=d), torch.zeros(Hd, device=d), torch.full((Hd,), 3.0, device=d)
+    gy2 = rnd(rows, Hd, seed=55).to(d)
+    dx_ref, dres_ref = ops.dropout_add_ln_bwd(gy2, xhat, rstd, gam1, p, 123, 7, torch.zeros(Hd, device=d), torch.zeros(Hd, device=d))
+    pdx, dres2 = ops.dropout_add_ln_bwd_planes(gy2, xhat, rstd, gam1, p, 123, 7, dg2, db2, dbias)
+    assert torch.equal(dres2, dres_ref) and torch.equal(pdx.buf, ops.split_planes(dx_ref).buf)
+    assert torch.allclose(dbias.double() - 3.0, dx_ref.double().sum(0), rtol=1e-4, atol=1e-4 * rows ** 0.5)
+    assert all(float(w.abs().max()) == 0.0 for w in ops._LN_WS3.values())
 
 
 def test_softmax(ops):
@@ -1055,3 +1063,19 @@ def test_plane_gemm_streamk_tail(tile):
     _, cnt, _ = ops._sk_workspace(dev)
     ops.set_streamk(False)
     assert int(cnt.abs().sum()) == 0
+
+
+def test_split_planes_gelu_bwd_fused():
+    """GELU backward fused into the split of its result == gelu_bwd followed by split (+ column sums), bit for bit"""
+    from vbg import ops
+    dev = torch.device("cuda")
+    g = torch.Generator().manual_seed(5)
+    for rows, cols in ((517, 3072), (64, 96), (1000, 776)):
+        h = (torch.randn(rows, cols, generator=g) * 2).to(dev)
+        dg = torch.randn(rows, cols, generator=g).to(dev)
+        cs = torch.full((cols,), 2.0, device=dev)
+        fused = ops.split_planes_gelu_bwd(dg, h, colsum_out=cs)
+        ref = dg.clone()
+        ops.gelu_bwd_(h, ref)
+        assert torch.equal(fused.buf[:, :, :cols], ops.split_planes(ref).buf[:, :, :cols])
+        assert torch.allclose(cs.double() - 2.0, ref.double().sum(0), rtol=1e-5, atol=1e-5 * rows ** 0.5)

@@ -692,7 +692,7 @@ __device__ __forceinline__ void pg_split3(float x, unsigned short& h, unsigned s
 // global atomic per column and block (<= 288 blocks: same-address atomics serialise at ~0.1 us each).
 __global__ __launch_bounds__(256) void split_planes_kernel(const float* __restrict__ x, long long ldx, int rows, int cols,
                                                             unsigned short* __restrict__ out, int ldp, long long plane, int relu,
-                                                            float* colsum) {
+                                                            float* colsum, const float* __restrict__ gelu_h) {
     extern __shared__ float sh_cols[];
     const int cpr = ldp / 8;
     const long long n = (long long)rows * cpr;
@@ -709,6 +709,11 @@ __global__ __launch_bounds__(256) void split_planes_kernel(const float* __restri
         } else {
 #pragma unroll
             for (int t = 0; t < 8; ++t) e[t] = (c + t < cols) ? x[(long long)r * ldx + c + t] : 0.f;
+        }
+        if (gelu_h) {                                    // x is dL/d gelu(h): split dL/dh = x * gelu'(h) (same layout as x)
+#pragma unroll
+            for (int t = 0; t < 8; ++t)
+                if (c + t < cols) e[t] *= gelu_erf_grad(gelu_h[(long long)r * ldx + c + t]);
         }
         unsigned short h[8], m[8], l[8];
 #pragma unroll
@@ -954,7 +959,35 @@ extern "C" int vbg_split_planes(const float* x, long long ldx, int rows, int col
         g = 256 * 16;
     }
     VBG_LAUNCH(split_planes_kernel, dim3((unsigned)g), dim3(256), lds, (hipStream_t)stream, x, ldx, rows, cols, out, ldp, plane, relu,
-               colsum_accum);
+               colsum_accum, (const float*)nullptr);
+    VBG_LAUNCH_RET();
+}
+
+extern "C" int vbg_split_planes_gelu_bwd(const float* dg, const float* h, long long ldx, int rows, int cols, unsigned short* out, int ldp,
+                                         long long plane, float* colsum_accum, void* stream) {
+    VBG_CHECK_ARG(rows >= 0 && cols >= 0 && ldp % 32 == 0 && ldp >= cols && plane >= (long long)rows * ldp && plane % 8 == 0);
+    if (rows == 0 || cols == 0) return VBG_OK;
+    VBG_CHECK_ARG(dg && h && out && ((uintptr_t)out & 15) == 0);
+    const long long n = (long long)rows * (ldp / 8);
+    long long g = (n + 255) / 256;
+    size_t lds = 0;
+    if (colsum_accum) {
+        VBG_CHECK_ARG(ldp * 4 <= 64 * 1024);
+        const long long cpr = ldp / 8;
+        long long a = cpr, b = 256;
+        while (b) { const long long t = a % b; a = b; b = t; }
+        const long long unit = cpr / a;
+        long long k = 288 / unit;
+        if (k < 1) k = 1;
+        const long long need = (g + unit - 1) / unit;
+        if (k > need) k = need;
+        g = k * unit;
+        lds = (size_t)ldp * 4;
+    } else if (g > 256 * 16) {
+        g = 256 * 16;
+    }
+    VBG_LAUNCH(split_planes_kernel, dim3((unsigned)g), dim3(256), lds, (hipStream_t)stream, dg, ldx, rows, cols, out, ldp, plane, 0,
+               colsum_accum, h);
     VBG_LAUNCH_RET();
 }
 

@@ -204,16 +204,22 @@ __global__ __launch_bounds__(256) void dropout_add_ln_fwd_kernel(
     if (lane == 0) rstd_out[t] = rstd;
 }
 
+// PL: dx (the gradient of the dense output in front of this LayerNorm) leaves as bf16 planes [3][rows][ldp] instead of fp32 -- it is
+// only ever a plane operand of that layer's data- and weight-gradient products -- and its column sums (the dense layer's bias
+// gradient) ride along in a third slot array; slots are then [LN_SLOTS][3][hidden] and mandatory.
+template <bool PL>
 __global__ __launch_bounds__(256) void dropout_add_ln_bwd_kernel(
     const float* __restrict__ dy, const float* __restrict__ xhat, const float* __restrict__ rstd, int rows, int hidden,
     const float* __restrict__ gamma, uint32_t drop_thr, float keep_scale, uint64_t seed, uint64_t sid,
-    float* __restrict__ dx, float* __restrict__ dres, float* dgamma, float* dbeta, float* slots) {
+    float* __restrict__ dx, float* __restrict__ dres, float* dgamma, float* dbeta, float* slots,
+    unsigned short* __restrict__ dxp, int ldp, long long plane) {
     const int lane = threadIdx.x & 63;
     const int nv = hidden >> 8;
     const int t0 = (blockIdx.x * 4 + (threadIdx.x >> 6)) * LN_WROWS;
-    float4 gam[LN_V], ag[LN_V], ab[LN_V];
+    float4 gam[LN_V], ag[LN_V], ab[LN_V], ac[LN_V];
 #pragma unroll
     for (int j = 0; j < LN_V; ++j) {
+        ac[j] = make_float4(0.f, 0.f, 0.f, 0.f);
         ag[j] = ab[j] = make_float4(0.f, 0.f, 0.f, 0.f);
         gam[j] = (j < nv) ? *reinterpret_cast<const float4*>(gamma + (lane + 64 * j) * 4) : ag[j];
     }
@@ -243,11 +249,31 @@ __global__ __launch_bounds__(256) void dropout_add_ln_bwd_kernel(
                 dz.x = rs * (g[j].x * gam[j].x - m1 - xh[j].x * m2); dz.y = rs * (g[j].y * gam[j].y - m1 - xh[j].y * m2);
                 dz.z = rs * (g[j].z * gam[j].z - m1 - xh[j].z * m2); dz.w = rs * (g[j].w * gam[j].w - m1 - xh[j].w * m2);
                 *reinterpret_cast<float4*>(dres + base + c) = dz;
-                *reinterpret_cast<float4*>(dx + base + c) = drop4(dz, drop_thr, keep_scale, seed, sid, (uint64_t)base + c);
+                const float4 dd = drop4(dz, drop_thr, keep_scale, seed, sid, (uint64_t)base + c);
+                if constexpr (!PL) {
+                    *reinterpret_cast<float4*>(dx + base + c) = dd;
+                } else {
+                    ac[j].x += dd.x; ac[j].y += dd.y; ac[j].z += dd.z; ac[j].w += dd.w;
+                    const float e[4] = {dd.x, dd.y, dd.z, dd.w};
+                    unsigned short h[4], m[4], l[4];
+#pragma unroll
+                    for (int i = 0; i < 4; ++i) {
+                        const unsigned u = __float_as_uint(e[i]);
+                        const float r1 = e[i] - __uint_as_float(u & 0xffff0000u);
+                        const unsigned u1 = __float_as_uint(r1);
+                        const float r2 = r1 - __uint_as_float(u1 & 0xffff0000u);
+                        h[i] = (unsigned short)(u >> 16); m[i] = (unsigned short)(u1 >> 16); l[i] = (unsigned short)(__float_as_uint(r2) >> 16);
+                    }
+                    unsigned short* op = dxp + (long long)t * ldp + c;
+                    *reinterpret_cast<uint2*>(op) = make_uint2(h[0] | ((unsigned)h[1] << 16), h[2] | ((unsigned)h[3] << 16));
+                    *reinterpret_cast<uint2*>(op + plane) = make_uint2(m[0] | ((unsigned)m[1] << 16), m[2] | ((unsigned)m[3] << 16));
+                    *reinterpret_cast<uint2*>(op + 2 * plane) = make_uint2(l[0] | ((unsigned)l[1] << 16), l[2] | ((unsigned)l[3] << 16));
+                }
             }
     }
     // cross-wave reduction of the column partials through LDS, then ONE atomic per column per block
-    __shared__ float red[2][4][256 * LN_V];
+    constexpr int NA = PL ? 3 : 2;
+    __shared__ float red[NA][4][256 * LN_V];
     const int w = threadIdx.x >> 6;
 #pragma unroll
     for (int j = 0; j < LN_V; ++j)
@@ -255,29 +281,32 @@ __global__ __launch_bounds__(256) void dropout_add_ln_bwd_kernel(
             const int c = (lane + 64 * j) * 4;
             *reinterpret_cast<float4*>(&red[0][w][c]) = ag[j];
             *reinterpret_cast<float4*>(&red[1][w][c]) = ab[j];
+            if constexpr (PL) *reinterpret_cast<float4*>(&red[2][w][c]) = ac[j];
         }
     __syncthreads();
     // same-address atomics serialise (~516 blocks at cfg2): with a slot workspace the block sums land in one of LN_SLOTS slot
     // rows and ln_fold_kernel adds the slots into dgamma / dbeta (and clears them for the next call)
-    float* dg = slots ? slots + (size_t)(blockIdx.x % LN_SLOTS) * 2 * hidden : dgamma;
+    float* dg = slots ? slots + (size_t)(blockIdx.x % LN_SLOTS) * NA * hidden : dgamma;
     float* db = slots ? dg + hidden : dbeta;
     for (int c = threadIdx.x; c < hidden; c += 256) {
         unsafeAtomicAdd(dg + c, (red[0][0][c] + red[0][1][c]) + (red[0][2][c] + red[0][3][c]));
         unsafeAtomicAdd(db + c, (red[1][0][c] + red[1][1][c]) + (red[1][2][c] + red[1][3][c]));
+        if constexpr (PL) unsafeAtomicAdd(dg + 2 * hidden + c, (red[2][0][c] + red[2][1][c]) + (red[2][2][c] + red[2][3][c]));
     }
 }
 
-__global__ void ln_fold_kernel(float* __restrict__ slots, int hidden, float* dgamma, float* dbeta) {
+// folds the slot rows ([LN_SLOTS][na][hidden]) into dgamma / dbeta (/ dbias) and clears them
+__global__ void ln_fold_kernel(float* __restrict__ slots, int hidden, int na, float* dgamma, float* dbeta, float* dbias) {
     const int c = blockIdx.x * blockDim.x + threadIdx.x;
-    if (c >= 2 * hidden) return;
+    if (c >= na * hidden) return;
     float v[4] = {0.f, 0.f, 0.f, 0.f};
 #pragma unroll 2
     for (int s = 0; s < LN_SLOTS; s += 4) {
 #pragma unroll
-        for (int j = 0; j < 4; ++j) { v[j] += slots[(size_t)(s + j) * 2 * hidden + c]; slots[(size_t)(s + j) * 2 * hidden + c] = 0.f; }
+        for (int j = 0; j < 4; ++j) { v[j] += slots[(size_t)(s + j) * na * hidden + c]; slots[(size_t)(s + j) * na * hidden + c] = 0.f; }
     }
     const float t = (v[0] + v[1]) + (v[2] + v[3]);
-    if (c < hidden) dgamma[c] += t; else dbeta[c - hidden] += t;
+    if (c < hidden) dgamma[c] += t; else if (c < 2 * hidden) dbeta[c - hidden] += t; else dbias[c - 2 * hidden] += t;
 }
 
 // ------------------------------------------------------------------------------------------
@@ -524,9 +553,27 @@ extern "C" int vbg_dropout_add_ln_bwd(const float* dy, const float* xhat, const 
     VBG_CHECK_ARG(hidden > 0 && hidden % 256 == 0 && hidden <= 256 * LN_V && drop_p >= 0.f && drop_p < 1.f);
     VBG_CHECK_ARG(((uintptr_t)dy | (uintptr_t)xhat | (uintptr_t)gamma | (uintptr_t)dx | (uintptr_t)dres) % 16 == 0);
     if (rows <= 0) return VBG_OK;
-    VBG_LAUNCH(dropout_add_ln_bwd_kernel, dim3(cdiv(rows, 4 * LN_WROWS)), dim3(256), 0, (hipStream_t)stream, dy, xhat, rstd, rows,
-               hidden, gamma, drop_threshold(drop_p), 1.0f / (1.0f - drop_p), seed, sid, dx, dres, dgamma, dbeta, slots_ws);
-    if (slots_ws) VBG_LAUNCH(ln_fold_kernel, dim3(cdiv(2 * hidden, 256)), dim3(256), 0, (hipStream_t)stream, slots_ws, hidden, dgamma, dbeta);
+    VBG_LAUNCH(dropout_add_ln_bwd_kernel<false>, dim3(cdiv(rows, 4 * LN_WROWS)), dim3(256), 0, (hipStream_t)stream, dy, xhat, rstd, rows,
+               hidden, gamma, drop_threshold(drop_p), 1.0f / (1.0f - drop_p), seed, sid, dx, dres, dgamma, dbeta, slots_ws,
+               (unsigned short*)nullptr, 0, 0ll);
+    if (slots_ws) VBG_LAUNCH(ln_fold_kernel, dim3(cdiv(2 * hidden, 256)), dim3(256), 0, (hipStream_t)stream, slots_ws, hidden, 2, dgamma, dbeta,
+                             (float*)nullptr);
+    VBG_LAUNCH_RET();
+}
+
+extern "C" int vbg_dropout_add_ln_bwd_planes(const float* dy, const float* xhat, const float* rstd, int rows, int hidden,
+                                             const float* gamma, float drop_p, unsigned long long seed, unsigned long long sid,
+                                             unsigned short* dx_planes, int ldp, long long plane, float* dres, float* dgamma, float* dbeta,
+                                             float* dbias_accum, float* slots3_ws, void* stream) {
+    VBG_CHECK_ARG(dy && xhat && rstd && gamma && dx_planes && dres && dgamma && dbeta && dbias_accum && slots3_ws);
+    VBG_CHECK_ARG(hidden > 0 && hidden % 256 == 0 && hidden <= 256 * LN_V && drop_p >= 0.f && drop_p < 1.f);
+    VBG_CHECK_ARG(((uintptr_t)dy | (uintptr_t)xhat | (uintptr_t)gamma | (uintptr_t)dres) % 16 == 0);
+    VBG_CHECK_ARG(ldp % 4 == 0 && ldp >= hidden && plane % 4 == 0 && plane >= (long long)rows * ldp && ((uintptr_t)dx_planes & 7) == 0);
+    if (rows <= 0) return VBG_OK;
+    VBG_LAUNCH(dropout_add_ln_bwd_kernel<true>, dim3(cdiv(rows, 4 * LN_WROWS)), dim3(256), 0, (hipStream_t)stream, dy, xhat, rstd, rows,
+               hidden, gamma, drop_threshold(drop_p), 1.0f / (1.0f - drop_p), seed, sid, (float*)nullptr, dres, dgamma, dbeta, slots3_ws,
+               dx_planes, ldp, plane);
+    VBG_LAUNCH(ln_fold_kernel, dim3(cdiv(3 * hidden, 256)), dim3(256), 0, (hipStream_t)stream, slots3_ws, hidden, 3, dgamma, dbeta, dbias_accum);
     VBG_LAUNCH_RET();
 }
 

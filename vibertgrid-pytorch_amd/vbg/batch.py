@@ -69,3 +69,31 @@ def packed_collate(collate_fn):
     def fn(samples):
         return PackedBatch.pack(*collate_fn(samples))
     return fn
+
+
+class AsyncScalar:
+    """`loss.item()` without draining the stream (pipeline/train_val_utils.py:270 reads the loss value between forward and
+    backward, which parks the GPU until the host has started to enqueue the backward pass).  The value is copied to pinned host
+    memory on a side stream that waits only for the kernels enqueued so far; `get()` blocks on that copy alone, so the caller can
+    enqueue the backward pass first and read the value afterwards -- same number, no bubble."""
+    _side = {}
+
+    def __init__(self, t: torch.Tensor):
+        dev = t.device
+        side = AsyncScalar._side.get(dev.index)
+        if side is None:
+            side = AsyncScalar._side[dev.index] = torch.cuda.Stream(device=dev)
+        self.host = torch.empty(t.shape, dtype=t.dtype, pin_memory=True)
+        ready = torch.cuda.Event()
+        ready.record(torch.cuda.current_stream(dev))
+        src = t.detach()
+        with torch.cuda.stream(side):
+            side.wait_event(ready)
+            self.host.copy_(src, non_blocking=True)
+            src.record_stream(side)
+            self.done = torch.cuda.Event()
+            self.done.record(side)
+
+    def get(self) -> float:
+        self.done.synchronize()
+        return float(self.host.reshape(-1)[0])

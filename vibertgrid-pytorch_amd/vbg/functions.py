@@ -624,17 +624,37 @@ class BertLayerFn(torch.autograd.Function):
         rbq, rbk, rbv, rbo, rbi, rbo2, rg1, rb1, rg2, rb2 = ctx.b_refs
         rq, rk, rv, ro, ri, ro2 = ctx.w_refs
         dg2, db2, sunk2 = _affine_dest(rg2, rb2)
-        dfo, dx1 = ops.dropout_add_ln_bwd(_c(dy), xh2, rs2, g2, p, seed, sid + 2, dg2, db2)
-        dg2, db2 = _affine_done(rg2, rb2, dg2, db2, sunk2)
-        pdfo, dbo2 = _split_with_bias_grad(rbo2, dfo)
+        dst = wgrad_dest(rbo2)
+        if dst is not None and hid % 32 == 0:     # dx leaves the LayerNorm backward as planes, its column sums as the bias gradient
+            pdfo, dx1 = ops.dropout_add_ln_bwd_planes(_c(dy), xh2, rs2, g2, p, seed, sid + 2, dg2, db2, dst)
+            wgrad_done(rbo2)
+            dbo2 = None
+            dg2, db2 = _affine_done(rg2, rb2, dg2, db2, sunk2)
+        else:
+            dfo, dx1 = ops.dropout_add_ln_bwd(_c(dy), xh2, rs2, g2, p, seed, sid + 2, dg2, db2)
+            dg2, db2 = _affine_done(rg2, rb2, dg2, db2, sunk2)
+            pdfo, dbo2 = _split_with_bias_grad(rbo2, dfo)
         dh_ = ops.plane_gemm(pdfo, ops.weight_planes(ro2, True, view=wo2), torch.empty_like(h), tile=ops._dense_tile(ntok, inter, True))
-        ops.gelu_bwd_(h, dh_)
-        pdh, dbi = _split_with_bias_grad(rbi, dh_)
+        # GELU backward rides on the split of its result (dL/dh is only used as a plane operand); the bias gradient = its column sums
+        dst_bi = wgrad_dest(rbi)
+        if dst_bi is not None:
+            pdh, dbi = ops.split_planes_gelu_bwd(dh_, h, colsum_out=dst_bi), None
+            wgrad_done(rbi)
+        else:
+            ops.gelu_bwd_(h, dh_)
+            pdh, dbi = ops.split_planes(dh_), ops.colsum(dh_)
         ops.plane_gemm(pdh, ops.weight_planes(ri, True, view=wi), dx1, accumulate=True, tile=ops._dense_tile(ntok, hid))
         dg1, db1, sunk1 = _affine_dest(rg1, rb1)
-        dao, dx = ops.dropout_add_ln_bwd(dx1, xh1, rs1, g1, p, seed, sid + 1, dg1, db1)
-        dg1, db1 = _affine_done(rg1, rb1, dg1, db1, sunk1)
-        pdao, dbo = _split_with_bias_grad(rbo, dao)
+        dst = wgrad_dest(rbo)
+        if dst is not None and hid % 32 == 0:
+            pdao, dx = ops.dropout_add_ln_bwd_planes(dx1, xh1, rs1, g1, p, seed, sid + 1, dg1, db1, dst)
+            wgrad_done(rbo)
+            dbo = None
+            dg1, db1 = _affine_done(rg1, rb1, dg1, db1, sunk1)
+        else:
+            dao, dx = ops.dropout_add_ln_bwd(dx1, xh1, rs1, g1, p, seed, sid + 1, dg1, db1)
+            dg1, db1 = _affine_done(rg1, rb1, dg1, db1, sunk1)
+            pdao, dbo = _split_with_bias_grad(rbo, dao)
         pdctx = ops.planes_empty(ntok, hid, dev) if flash else None
         dctx = ops.plane_gemm(pdao, ops.weight_planes(ro, True, view=wo), torch.empty((ntok, hid), device=dev, dtype=f32), out_planes=pdctx,
                               tile=ops._dense_tile(ntok, hid))

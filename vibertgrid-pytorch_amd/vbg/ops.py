@@ -136,6 +136,16 @@ def split_planes(x, relu=False, out=None, colsum_out=None):
     return o
 
 
+def split_planes_gelu_bwd(dg, h, colsum_out=None):
+    """Planes of dg * gelu'(h) (+ their column sums into colsum_out): GELU backward fused into the split of its result"""
+    assert dg.shape == h.shape and dg.stride() == h.stride() and dg.stride(1) == 1
+    rows, cols = dg.shape
+    o = planes_empty(rows, cols, dg.device)
+    check(lib.vbg_split_planes_gelu_bwd(P(dg), P(h), dg.stride(0), rows, cols, P(o.buf), o.ld, o.plane, P(colsum_out), _stream()),
+          "vbg_split_planes_gelu_bwd")
+    return o
+
+
 def split_planes_t_batched(src_flat, dst_planes, tbl_dev, njobs, total_tiles):
     """transposed planes of many matrices of one fp32 buffer in one launch (table layout: include/vbg.h)"""
     check(lib.vbg_split_planes_t_batched(P(src_flat), P(dst_planes), P(tbl_dev), int(njobs), int(total_tiles), dst_planes.stride(0), _stream()),
@@ -592,6 +602,25 @@ def _ln_workspace(device, hidden):
     if ws is None:
         ws = _LN_WS[key] = torch.zeros((int(lib.vbg_ln_slots()) * 2 * hidden,), device=device, dtype=f32)
     return ws
+
+
+_LN_WS3 = {}
+
+
+def dropout_add_ln_bwd_planes(dy, xhat, rstd, gamma, p, seed, sid, dgamma, dbeta, dbias):
+    """LayerNorm backward with dx as planes (-> Planes, dres) and dbias += column sums of dx in the same pass"""
+    rows, hidden = xhat.shape
+    dev = xhat.device
+    key = (dev, hidden, torch.cuda.current_stream(dev).cuda_stream)
+    ws = _LN_WS3.get(key)
+    if ws is None:
+        ws = _LN_WS3[key] = torch.zeros((int(lib.vbg_ln_slots()) * 3 * hidden,), device=dev, dtype=f32)
+    pdx = planes_empty(rows, hidden, dev)
+    assert pdx.ld == hidden
+    dres = torch.empty_like(xhat)
+    check(lib.vbg_dropout_add_ln_bwd_planes(P(dy), P(xhat), P(rstd), rows, hidden, P(gamma), p, seed, sid, P(pdx.buf), pdx.ld, pdx.plane, P(dres),
+                                            P(dgamma), P(dbeta), P(dbias), P(ws), _stream()), "vbg_dropout_add_ln_bwd_planes")
+    return pdx, dres
 
 
 def dropout_add_ln_bwd(dy, xhat, rstd, gamma, p, seed, sid, dgamma, dbeta):
