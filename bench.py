@@ -343,7 +343,7 @@ def main():
             "dtype": "bf16" if args.amp else "f32", "data": "synthetic",
             "arithmetic": ("bf16 MFMA products of fp32 tensors, f32 accumulate" if args.amp else
                            "f32 MFMA for every product" if args.fp32_mfma else
-                           "fp32-grade: exact 3-way bf16 split of every operand, 6 bf16 MFMA piece products per product, f32 accumulate (attention products and the short-reduction conv weight gradients on the f32 MFMA)"),
+                           "fp32-grade: exact 3-way bf16 split of every operand, 6 bf16 MFMA piece products per product, f32 accumulate, fused attention included (only the short-reduction conv weight gradients and the unaligned stem run on the f32 MFMA)"),
             "config": {"workload": ("SROIE line-level cfg2: resnet_34_fpn_pretrained + bert-base-uncased (12L, vocab 30522, random init), "
                                     "512x512, T=512 tokens, S=128 segments, batch 8/GPU, fwd+bwd+SGD/AdamW, dropout 0.1, simp classifier")
                        if args.shape == "cfg2" else f"EXPLORATORY {args.shape}: {shape}, T=512, batch {B}/GPU (not the BASELINE metric's configuration)",

@@ -40,7 +40,8 @@ enum {
     VBG_OP_CONV_R = 3,  /* B only: k = output pixel, col = (tap, ci) gathered from NHWC source      */
     VBG_OP_WT_R = 4     /* B only: conv weight [Cout][taps][Cin] read as k = (tap, co), col = ci    */
 };
-enum { VBG_EPI_NONE = 0, VBG_EPI_RELU = 1, VBG_EPI_GELU_DUAL = 2 /* C = x, C2 = gelu_erf(x) */ };
+enum { VBG_EPI_NONE = 0, VBG_EPI_RELU = 1, VBG_EPI_GELU_DUAL = 2 /* C = x, C2 = gelu_erf(x) */,
+       VBG_EPI_MUL_GELU_GRAD = 3 /* vbg_plane_gemm only: C = x * gelu_erf'(C2), C2 = h is an INPUT (GELU backward in the data-gradient product) */ };
 
 typedef struct vbg_conv_geo {
     int Hs, Ws, Cs;      /* gather-source tensor [*, Hs, Ws, Cs] (X for fwd/wgrad, dY for dgrad)   */
@@ -146,10 +147,6 @@ int vbg_plane_gemm_timed(const vbg_plane_gemm_desc* desc, void* stream, void* st
  * of a linear layer: torch's autograd `grad_output.sum(0)` for F.linear) */
 int vbg_split_planes(const float* x, long long ldx, int rows, int cols, unsigned short* out, int ldp, long long plane, int relu,
                      float* colsum_accum, void* stream);
-/* the planes (and column sums) of dg * gelu'(h): the backward of the GELU between the two FFN products (transformers
- * BertIntermediate, erf form) fused into the split of its result -- dL/dh is only ever used as a plane operand */
-int vbg_split_planes_gelu_bwd(const float* dg, const float* h, long long ldx, int rows, int cols, unsigned short* out, int ldp,
-                              long long plane, float* colsum_accum, void* stream);
 /* x [rows][cols] fp32 -> TRANSPOSED planes [3][cols][ldp], ldp >= rows (multiple of 32), entries rows..ldp-1 zero */
 int vbg_split_planes_t(const float* x, long long ldx, int rows, int cols, unsigned short* out, int ldp, long long plane,
                        void* stream);

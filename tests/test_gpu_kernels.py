@@ -956,6 +956,14 @@ def test_plane_gemm_nt_vs_fp64(tile):
         assert torch.equal(h, out)
         assert float((gl.double() - torch.nn.functional.gelu(out.double())).abs().max()) <= 1e-5 * max(1.0, float(out.abs().max()))
         assert torch.equal(pg.buf[:, :, :N], ops.split_planes(gl).buf[:, :, :N])
+        # GELU backward in the epilogue: stored value = product * gelu'(h), h an input in C2 (== vbg_gelu_bwd on the plain product)
+        from vbg.lib import EPI_MUL_GELU_GRAD
+        hh = (torch.randn(M, N, generator=g) * 2).to(dev)
+        dh = torch.empty(M, N, device=dev)
+        ops.plane_gemm(pa, pb, dh, bias=bias, epi=EPI_MUL_GELU_GRAD, C2=hh, tile=tile)
+        want = out.clone()
+        ops.gelu_bwd_(hh, want)
+        assert torch.equal(dh, want)
         acc = torch.ones(M, N, device=dev)
         ops.plane_gemm(pa, pb, acc, accumulate=True, tile=tile)
         assert float((acc.double() - 1 - (ref - bias.double())).abs().max()) <= 2e-6 * scale
@@ -1064,18 +1072,3 @@ def test_plane_gemm_streamk_tail(tile):
     ops.set_streamk(False)
     assert int(cnt.abs().sum()) == 0
 
-
-def test_split_planes_gelu_bwd_fused():
-    """GELU backward fused into the split of its result == gelu_bwd followed by split (+ column sums), bit for bit"""
-    from vbg import ops
-    dev = torch.device("cuda")
-    g = torch.Generator().manual_seed(5)
-    for rows, cols in ((517, 3072), (64, 96), (1000, 776)):
-        h = (torch.randn(rows, cols, generator=g) * 2).to(dev)
-        dg = torch.randn(rows, cols, generator=g).to(dev)
-        cs = torch.full((cols,), 2.0, device=dev)
-        fused = ops.split_planes_gelu_bwd(dg, h, colsum_out=cs)
-        ref = dg.clone()
-        ops.gelu_bwd_(h, ref)
-        assert torch.equal(fused.buf[:, :, :cols], ops.split_planes(ref).buf[:, :, :cols])
-        assert torch.allclose(cs.double() - 2.0, ref.double().sum(0), rtol=1e-5, atol=1e-5 * rows ** 0.5)

@@ -1,11 +1,14 @@
+# every rocprofv3 collection the committed profiles/ are made from, on one box:  gpurun -- bash tools/collect_profiles.sh ; python tools/make_profiles.py r02
 cd /tmp && export TMPDIR=/tmp && cd $GRAFT_REPO_ROOT
-B="python bench.py --steps 3 --warmup 1 --no-cpu-baseline --no-amp-leg"
-timeout 600 python bench.py --steps 20 --warmup 5 2>gpurun_out/bench_line.err | grep "^{" > gpurun_out/bench_line.json
-timeout 600 rocprofv3 --kernel-trace --stats --output-format csv -d gpurun_out/prof_e -o e -- python bench.py --steps 10 --warmup 3 --no-cpu-baseline --no-amp-leg > gpurun_out/prof_e.log 2>&1
-timeout 600 rocprofv3 --kernel-trace --stats --output-format csv -d gpurun_out/prof_amp -o amp -- python bench.py --amp --steps 10 --warmup 3 --no-cpu-baseline > gpurun_out/prof_amp.log 2>&1
+B="python bench.py --steps 3 --warmup 1 --no-cpu-baseline --no-amp-leg --no-h2d-leg"
+timeout 900 python bench.py --steps 20 --warmup 5 2>gpurun_out/bench_line.err | grep "^{" > gpurun_out/bench_line.json
+timeout 600 rocprofv3 --kernel-trace --stats --output-format csv -d gpurun_out/prof_e -o e -- python bench.py --steps 10 --warmup 3 --no-cpu-baseline --no-amp-leg --no-h2d-leg > gpurun_out/prof_e.log 2>&1
+timeout 600 rocprofv3 --kernel-trace --stats --output-format csv -d gpurun_out/prof_amp -o amp -- python bench.py --amp --steps 10 --warmup 3 --no-cpu-baseline --no-h2d-leg > gpurun_out/prof_amp.log 2>&1
 timeout 600 rocprofv3 --kernel-trace --pmc FETCH_SIZE --output-format csv -d gpurun_out/pmc_f -o f -- $B > gpurun_out/pmc_f.log 2>&1
 timeout 600 rocprofv3 --kernel-trace --pmc WRITE_SIZE --output-format csv -d gpurun_out/pmc_w -o w -- $B > gpurun_out/pmc_w.log 2>&1
 timeout 600 rocprofv3 --kernel-trace --pmc SQ_VALU_MFMA_BUSY_CYCLES SQ_WAVE_CYCLES SQ_WAIT_ANY SQ_WAIT_INST_ANY SQ_ACTIVE_INST_ANY SQ_LDS_BANK_CONFLICT GRBM_GUI_ACTIVE --output-format csv -d gpurun_out/pmc_m -o m -- $B > gpurun_out/pmc_m.log 2>&1
 timeout 600 python tools/gemm_bench.py > gpurun_out/gemm_shapes.txt 2>&1
 timeout 600 python tools/gemm_bench.py --amp > gpurun_out/gemm_shapes_amp.txt 2>&1
-rm -f gpurun_out/prof_e/e_kernel_trace.csv.keep; ls -la gpurun_out/prof_e gpurun_out/pmc_f gpurun_out/pmc_m | head -30; cut -c1-400 gpurun_out/bench_line.json
+timeout 600 python tools/plane_gemm_bench.py > gpurun_out/plane_gemm_shapes.txt 2>&1
+rm -f gpurun_out/prof_amp/amp_kernel_trace.csv
+ls -la gpurun_out/prof_e gpurun_out/pmc_f gpurun_out/pmc_m | head -30; cut -c1-400 gpurun_out/bench_line.json

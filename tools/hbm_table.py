@@ -31,8 +31,10 @@ bytes_per_step = {
     "bn_bwd_apply_kernel": sum(act(m, c) * (3 + a + r) for m, c, r, a in bn),
     "softmax_fwd_kernel": 12 * 2 * s_elems * f4,
     "softmax_bwd_kernel": 12 * 3 * s_elems * f4,
-    "dropout_add_ln_fwd_kernel": 24 * 4 * tok,
-    "dropout_add_ln_bwd_kernel": 24 * 4 * tok,
+    # LayerNorm forward: reads x, res; writes y, xhat and the bf16 planes of y (6 B / element)
+    "dropout_add_ln_fwd_kernel": 24 * (4 * tok + NTOK * HID * 6),
+    # LayerNorm backward (planes form): reads dy, xhat; writes dres and the planes of dx
+    "dropout_add_ln_bwd_kernel": 24 * (3 * tok + NTOK * HID * 6),
     "gelu_bwd_kernel": 12 * 3 * NTOK * 3072 * f4,
     "adamw_kernel": 28 * 108.9e6,
     "sgd_kernel": 20 * 41.8e6,
@@ -40,6 +42,7 @@ bytes_per_step = {
     "maxpool_fwd_kernel": act(B * 256 * 256, 64) + 2 * act(B * 128 * 128, 64),
     "maxpool_bwd_kernel": 2 * act(B * 128 * 128, 64) + act(B * 256 * 256, 64),
     "roi_align_fwd_kernel": NSEG * 49 * 256 * f4 + act(B * 128 * 128, 256),
+    "roi_align_bwd_sep_kernel": NSEG * 49 * 256 * f4 + act(B * 128 * 128, 256),
     "roi_align_bwd_kernel": NSEG * 49 * 256 * f4 + act(B * 128 * 128, 256),
     "grid_scatter_nhwc_kernel": act(B * 64 * 64, HID) + NSEG * HID * f4,
     "grid_scatter_bwd_kernel": act(B * 64 * 64, HID) + NSEG * HID * f4,
@@ -48,6 +51,16 @@ bytes_per_step = {
     "seg_reduce_fwd_kernel": 4096 * HID * f4 + NSEG * HID * f4,
     "seg_reduce_bwd_kernel": 4096 * HID * f4 + NSEG * HID * f4,
     "colsum": 12 * (NTOK * 2304 + 3 * NTOK * 768 + NTOK * 3072) * f4,
+    # plane splits per layer: x (layer 0 only), dqkv [ntok, 2304] + column sums, and dL/dh [ntok, 3072] with the GELU backward fused
+    # (reads dg and h): fp32 in, 6 B / element out
+    "split_planes_kernel": 12 * (NTOK * 2304 * 10 + NTOK * 3072 * 14) + NTOK * HID * 10,
+    # fused attention: q / k / v planes (6 B / element) in, O + planes + Kbar out (forward); planes of q, k, v, dO in, dq (dk, dv) out;
+    # K / V (Q / dO) are re-streamed once per 128-row block of the other side: 4 blocks at L = 512 (algorithmic = one pass)
+    "attn_kernel<0": 12 * (NTOK * 2304 * 6 + NTOK * HID * (4 + 6 + 4)),
+    "attn_kernel<1": 12 * (NTOK * 2304 * 6 + NTOK * HID * (6 + 4 + 4)),
+    "attn_kernel<2": 12 * (NTOK * 2304 * 6 + NTOK * HID * (6 + 8)),
+    "attn_mask_kernel": 12 * 2 * 12 * 8 * 512 * 16 * 4,
+    "attn_delta_kernel": 12 * 2 * tok,
 }
 
 

@@ -364,6 +364,10 @@ __global__ __launch_bounds__(WGM * WGN * 64) void plane_gemm_kernel(const vbg_pl
             v.x += o.x; v.y += o.y; v.z += o.z; v.w += o.w;
         }
         if (epi == VBG_EPI_RELU) v = make_float4(fmaxf(v.x, 0.f), fmaxf(v.y, 0.f), fmaxf(v.z, 0.f), fmaxf(v.w, 0.f));
+        if (epi == VBG_EPI_MUL_GELU_GRAD) {          // C2 = h (input): the product is dL/d gelu(h), the stored value dL/dh
+            const float4 hv = *reinterpret_cast<const float4*>(C2 + (long long)gm * ldc + gn);
+            v.x *= gelu_erf_grad(hv.x); v.y *= gelu_erf_grad(hv.y); v.z *= gelu_erf_grad(hv.z); v.w *= gelu_erf_grad(hv.w);
+        }
         if (C) *reinterpret_cast<float4*>(cp) = v;
         if (epi == VBG_EPI_GELU_DUAL) {
             v = make_float4(gelu_erf(v.x), gelu_erf(v.y), gelu_erf(v.z), gelu_erf(v.w));
@@ -692,7 +696,7 @@ __device__ __forceinline__ void pg_split3(float x, unsigned short& h, unsigned s
 // global atomic per column and block (<= 288 blocks: same-address atomics serialise at ~0.1 us each).
 __global__ __launch_bounds__(256) void split_planes_kernel(const float* __restrict__ x, long long ldx, int rows, int cols,
                                                             unsigned short* __restrict__ out, int ldp, long long plane, int relu,
-                                                            float* colsum, const float* __restrict__ gelu_h) {
+                                                            float* colsum) {
     extern __shared__ float sh_cols[];
     const int cpr = ldp / 8;
     const long long n = (long long)rows * cpr;
@@ -709,11 +713,6 @@ __global__ __launch_bounds__(256) void split_planes_kernel(const float* __restri
         } else {
 #pragma unroll
             for (int t = 0; t < 8; ++t) e[t] = (c + t < cols) ? x[(long long)r * ldx + c + t] : 0.f;
-        }
-        if (gelu_h) {                                    // x is dL/d gelu(h): split dL/dh = x * gelu'(h) (same layout as x)
-#pragma unroll
-            for (int t = 0; t < 8; ++t)
-                if (c + t < cols) e[t] *= gelu_erf_grad(gelu_h[(long long)r * ldx + c + t]);
         }
         unsigned short h[8], m[8], l[8];
 #pragma unroll
@@ -883,6 +882,7 @@ static int plane_gemm_dispatch(const vbg_plane_gemm_desc* desc, void* stream, vo
     if (d.splitk > 1) VBG_CHECK_ARG(d.accumulate == 1 && d.C);
     if (d.accumulate) VBG_CHECK_ARG(d.epi == VBG_EPI_NONE && d.Cp == nullptr);
     if (d.epi == VBG_EPI_GELU_DUAL) VBG_CHECK_ARG(d.C2 != nullptr || d.Cp != nullptr);
+    if (d.epi == VBG_EPI_MUL_GELU_GRAD) VBG_CHECK_ARG(d.C2 != nullptr && d.ngroups == 0 && !d.trans && !(d.sk_ws && d.sk_cnt));
     if (d.Cp) VBG_CHECK_ARG(d.ldp % 8 == 0 && d.ldp >= d.N && ((uintptr_t)d.Cp & 7) == 0 && d.c_plane % 4 == 0);
     if (d.M == 0 || d.N == 0) return VBG_OK;
     hipStream_t s = (hipStream_t)stream;
@@ -959,35 +959,7 @@ extern "C" int vbg_split_planes(const float* x, long long ldx, int rows, int col
         g = 256 * 16;
     }
     VBG_LAUNCH(split_planes_kernel, dim3((unsigned)g), dim3(256), lds, (hipStream_t)stream, x, ldx, rows, cols, out, ldp, plane, relu,
-               colsum_accum, (const float*)nullptr);
-    VBG_LAUNCH_RET();
-}
-
-extern "C" int vbg_split_planes_gelu_bwd(const float* dg, const float* h, long long ldx, int rows, int cols, unsigned short* out, int ldp,
-                                         long long plane, float* colsum_accum, void* stream) {
-    VBG_CHECK_ARG(rows >= 0 && cols >= 0 && ldp % 32 == 0 && ldp >= cols && plane >= (long long)rows * ldp && plane % 8 == 0);
-    if (rows == 0 || cols == 0) return VBG_OK;
-    VBG_CHECK_ARG(dg && h && out && ((uintptr_t)out & 15) == 0);
-    const long long n = (long long)rows * (ldp / 8);
-    long long g = (n + 255) / 256;
-    size_t lds = 0;
-    if (colsum_accum) {
-        VBG_CHECK_ARG(ldp * 4 <= 64 * 1024);
-        const long long cpr = ldp / 8;
-        long long a = cpr, b = 256;
-        while (b) { const long long t = a % b; a = b; b = t; }
-        const long long unit = cpr / a;
-        long long k = 288 / unit;
-        if (k < 1) k = 1;
-        const long long need = (g + unit - 1) / unit;
-        if (k > need) k = need;
-        g = k * unit;
-        lds = (size_t)ldp * 4;
-    } else if (g > 256 * 16) {
-        g = 256 * 16;
-    }
-    VBG_LAUNCH(split_planes_kernel, dim3((unsigned)g), dim3(256), lds, (hipStream_t)stream, dg, ldx, rows, cols, out, ldp, plane, 0,
-               colsum_accum, h);
+               colsum_accum);
     VBG_LAUNCH_RET();
 }
 

@@ -177,6 +177,8 @@ class BERTgridGenerator(nn.Module):
         meta.seq_row0, meta.pad_off = i32[:meta.nseq], i32[meta.nseq:2 * meta.nseq]
         meta.tok_pad, meta.tasks = i32[2 * meta.nseq:2 * meta.nseq + pk.ntok], i32[2 * meta.nseq + pk.ntok:]
         meta.ntok_pad, meta.mask_words, meta.ntasks = ntok_pad, mask_words, int(tasks.shape[0])
+        # softmax statistics / delta of every layer's fused attention (padding rows must read zero): one zero fill per step
+        meta.stat_pool = torch.zeros((len(self.model.encoder.layer), 3, heads, ntok_pad), device=dev, dtype=torch.float32)
 
         m = self.model
         emb = m.embeddings

@@ -7,7 +7,7 @@ import torch
 import torch.distributed as dist
 
 from . import ops
-from .lib import ATTN_DKV, ATTN_DQ, ATTN_FWD, EPI_GELU_DUAL, EPI_NONE, EPI_RELU, OP_DENSE_K, OP_DENSE_R
+from .lib import ATTN_DKV, ATTN_DQ, ATTN_FWD, EPI_GELU_DUAL, EPI_MUL_GELU_GRAD, EPI_NONE, EPI_RELU, OP_DENSE_K, OP_DENSE_R
 
 f32 = torch.float32
 
@@ -510,7 +510,7 @@ class AttnMeta:
     """Host-built description of the packed variable-length sequences of one batch (see
     model/BERTgrid_generator.py in this package): device tables for the grouped attention GEMMs."""
     __slots__ = ("ntok", "nseq", "heads", "dh", "maxlen", "ld", "s_elems", "soff", "lens", "ldp", "t_qk", "t_pv", "t_dp", "t_dv",
-                 "t_dq", "t_dk", "ngroups", "mask_off", "seq_row0", "pad_off", "tok_pad", "tasks", "ntok_pad", "mask_words", "ntasks")
+                 "t_dq", "t_dk", "ngroups", "mask_off", "seq_row0", "pad_off", "tok_pad", "tasks", "ntok_pad", "mask_words", "ntasks", "stat_pool")
 
 
 class BertLayerFn(torch.autograd.Function):
@@ -551,7 +551,11 @@ class BertLayerFn(torch.autograd.Function):
         ctxv = torch.empty((ntok, hid), device=dev, dtype=f32)
         if flash:
             # fused attention (csrc/attn.hip): scores, softmax, dropout and P V in one pass, nothing of size L x L is stored
-            lse = torch.zeros((2, H, meta.ntok_pad), device=dev, dtype=f32)            # row statistics (m, 1 / l)
+            # row statistics (m, 1 / l) and, in backward, delta: zero in the padding rows; one zeroed pool per step for all layers
+            pool = getattr(meta, "stat_pool", None)
+            st = pool[layer] if pool is not None and layer < pool.shape[0] else torch.zeros((3, H, meta.ntok_pad), device=dev, dtype=f32)
+            lse = st[:2]
+            ctx.delta_buf = st[2]
             masks = ops.attn_mask(meta, p, seed, sid + 0) if p > 0 else None
             kbar = torch.empty((ntok, hid), device=dev, dtype=f32) if any(ctx.needs_input_grad) else None
             pctx = ops.planes_empty(ntok, hid, dev)
@@ -634,15 +638,10 @@ class BertLayerFn(torch.autograd.Function):
             dfo, dx1 = ops.dropout_add_ln_bwd(_c(dy), xh2, rs2, g2, p, seed, sid + 2, dg2, db2)
             dg2, db2 = _affine_done(rg2, rb2, dg2, db2, sunk2)
             pdfo, dbo2 = _split_with_bias_grad(rbo2, dfo)
-        dh_ = ops.plane_gemm(pdfo, ops.weight_planes(ro2, True, view=wo2), torch.empty_like(h), tile=ops._dense_tile(ntok, inter, True))
-        # GELU backward rides on the split of its result (dL/dh is only used as a plane operand); the bias gradient = its column sums
-        dst_bi = wgrad_dest(rbi)
-        if dst_bi is not None:
-            pdh, dbi = ops.split_planes_gelu_bwd(dh_, h, colsum_out=dst_bi), None
-            wgrad_done(rbi)
-        else:
-            ops.gelu_bwd_(h, dh_)
-            pdh, dbi = ops.split_planes(dh_), ops.colsum(dh_)
+        # dL/dh = (dfo Wo2) o gelu'(h): the GELU backward rides in the product's epilogue
+        dh_ = ops.plane_gemm(pdfo, ops.weight_planes(ro2, True, view=wo2), torch.empty_like(h), epi=EPI_MUL_GELU_GRAD, C2=h,
+                             tile=ops._dense_tile(ntok, inter, True))
+        pdh, dbi = _split_with_bias_grad(rbi, dh_)
         ops.plane_gemm(pdh, ops.weight_planes(ri, True, view=wi), dx1, accumulate=True, tile=ops._dense_tile(ntok, hid))
         dg1, db1, sunk1 = _affine_dest(rg1, rb1)
         dst = wgrad_dest(rbo)
@@ -662,7 +661,7 @@ class BertLayerFn(torch.autograd.Function):
             # fused attention backward: delta = rowsum(dO o O), then dQ (queries stationary) and dK / dV (keys stationary), each
             # recomputing its score tile from the q / k / v planes and the saved log-sum-exp
             pqkv = ops.Planes(bqkv, ntok, 3 * hid, bqkv.shape[2])
-            delta = ops.attn_delta(dctx, ctxv, meta, torch.zeros_like(lse[0]))
+            delta = ops.attn_delta(dctx, ctxv, meta, ctx.delta_buf)
             dqkv = torch.empty((ntok, 3 * hid), device=dev, dtype=f32)
             sc = 1.0 / (dh ** 0.5)
             ops.attn(meta, ATTN_DQ, pqkv, pdctx, dqkv, lse, delta, ctx.masks, sc, p, kbar=kbar)

@@ -63,7 +63,7 @@ class AttnDesc(C.Structure):
 
 ATTN_FWD, ATTN_DQ, ATTN_DKV = 0, 1, 2
 OP_DENSE_K, OP_DENSE_R, OP_CONV_K, OP_CONV_R, OP_WT_R = 0, 1, 2, 3, 4
-EPI_NONE, EPI_RELU, EPI_GELU_DUAL = 0, 1, 2
+EPI_NONE, EPI_RELU, EPI_GELU_DUAL, EPI_MUL_GELU_GRAD = 0, 1, 2, 3
 
 # name -> (restype, argtypes); must list EVERY symbol include/vbg.h declares (tests check this)
 SIGNATURES = {
@@ -76,7 +76,6 @@ SIGNATURES = {
     "vbg_plane_gemm": (c_int, [C.POINTER(PlaneGemmDesc), c_vp]),
     "vbg_plane_gemm_timed": (c_int, [C.POINTER(PlaneGemmDesc), c_vp, c_vp, c_vp]),
     "vbg_split_planes": (c_int, [c_vp, c_ll, c_int, c_int, c_vp, c_int, c_ll, c_int, c_vp, c_vp]),
-    "vbg_split_planes_gelu_bwd": (c_int, [c_vp, c_vp, c_ll, c_int, c_int, c_vp, c_int, c_ll, c_vp, c_vp]),
     "vbg_split_planes_t": (c_int, [c_vp, c_ll, c_int, c_int, c_vp, c_int, c_ll, c_vp]),
     "vbg_split_planes_t_batched": (c_int, [c_vp, c_vp, c_vp, c_int, c_int, c_ll, c_vp]),
     "vbg_attn": (c_int, [C.POINTER(AttnDesc), c_vp]),

@@ -136,16 +136,6 @@ def split_planes(x, relu=False, out=None, colsum_out=None):
     return o
 
 
-def split_planes_gelu_bwd(dg, h, colsum_out=None):
-    """Planes of dg * gelu'(h) (+ their column sums into colsum_out): GELU backward fused into the split of its result"""
-    assert dg.shape == h.shape and dg.stride() == h.stride() and dg.stride(1) == 1
-    rows, cols = dg.shape
-    o = planes_empty(rows, cols, dg.device)
-    check(lib.vbg_split_planes_gelu_bwd(P(dg), P(h), dg.stride(0), rows, cols, P(o.buf), o.ld, o.plane, P(colsum_out), _stream()),
-          "vbg_split_planes_gelu_bwd")
-    return o
-
-
 def split_planes_t_batched(src_flat, dst_planes, tbl_dev, njobs, total_tiles):
     """transposed planes of many matrices of one fp32 buffer in one launch (table layout: include/vbg.h)"""
     check(lib.vbg_split_planes_t_batched(P(src_flat), P(dst_planes), P(tbl_dev), int(njobs), int(total_tiles), dst_planes.stride(0), _stream()),
