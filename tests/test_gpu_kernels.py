@@ -1072,3 +1072,37 @@ def test_plane_gemm_streamk_tail(tile):
     ops.set_streamk(False)
     assert int(cnt.abs().sum()) == 0
 
+
+
+def test_plane_gemm_256_tile():
+    """256 x 256 tile form of the NT plane product (16-deep k-tiles, 32-byte LDS rows): fp32-grade vs fp64 and every epilogue"""
+    from vbg import ops
+    from vbg.lib import EPI_GELU_DUAL, EPI_MUL_GELU_GRAD
+    dev = torch.device("cuda")
+    g = torch.Generator().manual_seed(256)
+    for (M, N, K) in ((4128, 2304, 768), (1000, 772, 800), (257, 512, 3072), (300, 264, 96), (256, 256, 32)):
+        a = (torch.randn(M, K, generator=g) * torch.exp2(torch.randint(-8, 8, (M, 1), generator=g).float())).to(dev)
+        b = (torch.randn(N, K, generator=g) / K ** 0.5).to(dev)
+        bias = torch.randn(N, generator=g).to(dev)
+        ref = a.double() @ b.double().t() + bias.double()
+        scale = float((a.double().abs() @ b.double().abs().t()).max())
+        pa, pb = ops.split_planes(a), ops.split_planes(b)
+        out = torch.full((M, N), 7.0, device=dev)
+        ops.plane_gemm(pa, pb, out, bias=bias, tile=256256)
+        assert float((out.double() - ref).abs().max()) <= 2e-6 * scale, (M, N, K)
+        other = torch.empty(M, N, device=dev)
+        ops.plane_gemm(pa, pb, other, bias=bias, tile=128129)
+        assert float((other - out).abs().max()) <= 1e-6 * scale
+        h, gl, pg = torch.empty(M, N, device=dev), torch.empty(M, N, device=dev), ops.planes_empty(M, N, dev)
+        ops.plane_gemm(pa, pb, h, bias=bias, epi=EPI_GELU_DUAL, C2=gl, out_planes=pg, tile=256256)
+        assert torch.equal(h, out)
+        assert torch.equal(pg.buf[:, :, :N], ops.split_planes(gl).buf[:, :, :N])
+        only = ops.planes_empty(M, N, dev)
+        ops.plane_gemm(pa, pb, None, bias=bias, out_planes=only, tile=256256)
+        assert torch.equal(only.buf[:, :, :N], ops.split_planes(out).buf[:, :, :N])
+        hh = (torch.randn(M, N, generator=g) * 2).to(dev)
+        dh = torch.empty(M, N, device=dev)
+        ops.plane_gemm(pa, pb, dh, bias=bias, epi=EPI_MUL_GELU_GRAD, C2=hh, tile=256256)
+        want = out.clone()
+        ops.gelu_bwd_(hh, want)
+        assert torch.equal(dh, want)

@@ -392,6 +392,198 @@ __global__ __launch_bounds__(WGM * WGN * 64) void plane_gemm_kernel(const vbg_pl
     }
 }
 
+__device__ __forceinline__ void pg_split3(float x, unsigned short& h, unsigned short& m, unsigned short& l);
+
+// ---- 256 x 256 tile form of the NT product -----------------------------------------------------------------------------------------
+// Every matrix kernel of this library levels off where its CUs ingest ~12-13 bytes per clock from L2 / fabric (the 128 x 128 plane
+// tile needs 31 B / clk / CU at full matrix rate -> 0.38-0.40 MFMA utilisation measured, the 256 x 128 tile 23 B -> 0.49, the fp32
+// operands of gemm.hip's 128 x 128 x 16 tile 21 B -> 0.56-0.60): the lever is products per byte moved.  A 256 x 256 tile halves the
+// bytes per product again (16 B / clk / CU at full rate).  Its stages only fit as 16-deep k-tiles (3 planes x 512 rows x 32 B =
+// 48 KB, three of them in flight); 8 waves as 2 x 4, a wave owns 128 x 64 (eight 32 x 32 accumulators), one k-step = 48 MFMAs per
+// barrier.  LDS image [plane][row][32 B], the two 16-byte halves of a row swapped where (row >> 3) & 1 (on the DMA's source
+// address), which spreads the ds_read_b128 fragment reads of 32-byte rows over all banks.  The output tile is staged through LDS in
+// four passes of 64 rows.  Used where the tile count still fills the chip's CUs reasonably (N >= 2304 at M = 4128).
+__global__ __launch_bounds__(512) void plane_gemm_256_kernel(const vbg_plane_gemm_desc p) {
+    constexpr int BM = 256, BN = 256, WGN = 4, NW = 8, NT = 512, NST = 3, BK = 16;
+    constexpr int WM = 128, WN = 64, TM = 4, TN = 2;
+    constexpr int PA = BM * 32, PB = BN * 32;                  // bytes of one plane of a stage (32 B per row)
+    constexpr int STAGE = 3 * (PA + PB);
+    constexpr int NIA = 3, NIB = 3;                            // DMA instructions per wave and stage (1 KiB = 32 rows x 32 B each)
+    constexpr int CTS = BN + 4;
+    constexpr int SMEM = NST * STAGE;
+    static_assert(64 * CTS * 4 <= SMEM, "epilogue pass fits");
+    __shared__ __attribute__((aligned(1024))) unsigned char smem[SMEM];          // (the ONE LDS object of the kernel)
+
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    const int M = p.M, N = p.N;
+    const long long a_plane = p.a_plane, b_plane = p.b_plane, lda = p.lda, ldb = p.ldb;
+    // XCD-aware block -> tile map (as above)
+    constexpr unsigned XCDS = 8, XCD_GROUP = 8;
+    const unsigned gx = gridDim.x, gy = gridDim.y;
+    const unsigned lin = blockIdx.x + gridDim.x * blockIdx.y;
+    const unsigned total = gx * gy;
+    const unsigned xcd = lin % XCDS, local = lin / XCDS;
+    const unsigned per_xcd = (total + XCDS - 1) / XCDS, tall = (total % XCDS) ? (total % XCDS) : XCDS;
+    const unsigned rem = xcd < tall ? xcd * per_xcd + local : tall * per_xcd + (xcd - tall) * (per_xcd - 1) + local;
+    const unsigned band = XCD_GROUP * gy, bid = rem / band, first = bid * XCD_GROUP;
+    const unsigned bm = min(gx - first, XCD_GROUP), inb = rem - bid * band;
+    const unsigned tile_m = first + inb % bm, tile_n = inb / bm;
+    const int m0 = (int)tile_m * BM, n0 = (int)tile_n * BN;
+    if (m0 >= M || n0 >= N) return;
+    const int ntiles = p.K / BK;
+
+    // DMA: unit (plane q, 32-row block rb) of an operand; lane l -> row rb*32 + l/2, physical half l%2 <- logical half (l%2) ^ (row>>3 & 1)
+    unsigned avo[NIA], bvo[NIB];
+    int alds[NIA], blds[NIB];
+    {
+        const int lrow = lane >> 1;
+#pragma unroll
+        for (int i = 0; i < NIA; ++i) {
+            const int u = wave + NW * i, q = u / 8, rb = u % 8;
+            const int r = rb * 32 + lrow;
+            const int half = (lane & 1) ^ ((r >> 3) & 1);
+            avo[i] = (m0 + r < M) ? (unsigned)(((long long)q * a_plane + (long long)r * lda) * 2 + half * 16) : PG_INVALID;
+            alds[i] = __builtin_amdgcn_readfirstlane(q * PA + rb * 1024);
+        }
+#pragma unroll
+        for (int i = 0; i < NIB; ++i) {
+            const int u = wave + NW * i, q = u / 8, rb = u % 8;
+            const int r = rb * 32 + lrow;
+            const int half = (lane & 1) ^ ((r >> 3) & 1);
+            bvo[i] = (n0 + r < N) ? (unsigned)(((long long)q * b_plane + (long long)r * ldb) * 2 + half * 16) : PG_INVALID;
+            blds[i] = __builtin_amdgcn_readfirstlane(3 * PA + q * PB + rb * 1024);
+        }
+    }
+    const unsigned short* abase = p.A + (long long)m0 * lda;
+    const unsigned short* bbase = p.B + (long long)n0 * ldb;
+    typedef __attribute__((address_space(3))) void* lds_ptr;
+    auto issue = [&](int stage, unsigned inv) {
+        unsigned char* sb = smem + stage * STAGE;
+        const __amdgpu_buffer_rsrc_t ra = pg_rsrc(abase), rb = pg_rsrc(bbase);
+#pragma unroll
+        for (int i = 0; i < NIA; ++i)
+            __builtin_amdgcn_raw_ptr_buffer_load_lds(ra, (lds_ptr)(sb + alds[i]), 16, (int)(avo[i] | inv), 0, 0, 0);
+#pragma unroll
+        for (int i = 0; i < NIB; ++i)
+            __builtin_amdgcn_raw_ptr_buffer_load_lds(rb, (lds_ptr)(sb + blds[i]), 16, (int)(bvo[i] | inv), 0, 0, 0);
+        abase += BK;
+        bbase += BK;
+    };
+
+    const int wm = wave / WGN, wn = wave % WGN;
+    const int lr = lane & 31, lk = lane >> 5;
+    // fragment: row lr of a 32-row block (block bases are multiples of 32 rows, so (row >> 3) & 1 == (lr >> 3) & 1), logical half lk
+    const int fo = lr * 32 + ((lk ^ ((lr >> 3) & 1)) << 4);
+    f32x16 acc[TM][TN];
+#pragma unroll
+    for (int i = 0; i < TM; ++i)
+#pragma unroll
+        for (int j = 0; j < TN; ++j)
+#pragma unroll
+            for (int r = 0; r < 16; ++r) acc[i][j][r] = 0.f;
+    pg_u32x4 fa[3][TM], fb[3][TN];
+    auto read_frags = [&](int stage) {
+        const unsigned char* as = smem + stage * STAGE + (wm * WM) * 32 + fo;
+        const unsigned char* bs = smem + stage * STAGE + 3 * PA + (wn * WN) * 32 + fo;
+        // (in the order the piece products need them: lo / hi first)
+        constexpr int order[3] = {2, 0, 1};
+#pragma unroll
+        for (int o = 0; o < 3; ++o) {
+            const int q = order[o];
+#pragma unroll
+            for (int i = 0; i < TM; ++i) fa[q][i] = *reinterpret_cast<const pg_u32x4*>(as + q * PA + i * 32 * 32);
+#pragma unroll
+            for (int j = 0; j < TN; ++j) fb[q][j] = *reinterpret_cast<const pg_u32x4*>(bs + q * PB + j * 32 * 32);
+        }
+    };
+    auto mma = [&]() {
+        constexpr int qa[6] = {2, 0, 1, 1, 0, 0}, qb[6] = {0, 2, 1, 0, 1, 0};
+#pragma unroll
+        for (int t = 0; t < 6; ++t)
+#pragma unroll
+            for (int i = 0; i < TM; ++i)
+#pragma unroll
+                for (int j = 0; j < TN; ++j)
+                    acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(__builtin_bit_cast(pg_bf16x8, fa[qa[t]][i]),
+                                                                        __builtin_bit_cast(pg_bf16x8, fb[qb[t]][j]), acc[i][j], 0, 0, 0);
+    };
+    constexpr int NIW = NIA + NIB;
+    issue(0, 0u);
+    issue(1, ntiles > 1 ? 0u : PG_INVALID);
+    asm volatile("s_waitcnt vmcnt(%0)" ::"n"(NIW) : "memory");
+    __builtin_amdgcn_s_barrier();
+    int cur = 0;
+    for (int t = 0; t < ntiles; ++t) {
+        const int nxt = (cur + 1 == NST) ? 0 : cur + 1;
+        const int nn = (nxt + 1 == NST) ? 0 : nxt + 1;
+        issue(nn, t + 2 < ntiles ? 0u : PG_INVALID);         // (stage of tile t - 1: every wave read it before the last barrier)
+        read_frags(cur);
+        mma();
+        asm volatile("s_waitcnt vmcnt(%0) lgkmcnt(0)" ::"n"(NIW) : "memory");      // tile t + 1 landed; tile t + 2 stays in flight
+        __builtin_amdgcn_s_barrier();
+        cur = nxt;
+    }
+    __syncthreads();                               // (drains the DMA queue: the output tile is staged over the operand stages)
+
+    // ---- epilogue: four passes of 64 rows through LDS, float4 row pieces ------------------------------------------------------
+    const float* bias = p.bias;
+    const int epi = p.epi;
+    const float alpha = p.alpha;
+    const long long ldc = p.ldc;
+    float* const C = p.C;
+    float* const C2 = p.C2;
+    unsigned short* const Cp = p.Cp;
+    float* const Ct = reinterpret_cast<float*>(smem);
+    constexpr int QN = BN / 4;
+#pragma unroll
+    for (int ps = 0; ps < 4; ++ps) {
+        if (wm == (ps >> 1)) {
+#pragma unroll
+            for (int ii = 0; ii < 2; ++ii)
+#pragma unroll
+                for (int j = 0; j < TN; ++j)
+#pragma unroll
+                    for (int r = 0; r < 16; ++r)
+                        Ct[(ii * 32 + (r & 3) + 8 * (r >> 2) + 4 * lk) * CTS + wn * WN + j * 32 + lr] = acc[2 * (ps & 1) + ii][j][r] * alpha;
+        }
+        __syncthreads();
+#pragma unroll
+        for (int q = 0; q < 64 * QN / NT; ++q) {
+            const int idx = tid + q * NT;
+            const int row = idx / QN, c = (idx % QN) * 4;
+            const int gm = m0 + ps * 64 + row, gn = n0 + c;
+            if (gm >= M || gn >= N) continue;
+            float4 v = *reinterpret_cast<const float4*>(&Ct[row * CTS + c]);
+            if (bias) {
+                const float4 b = *reinterpret_cast<const float4*>(bias + gn);
+                v.x += b.x; v.y += b.y; v.z += b.z; v.w += b.w;
+            }
+            float* cp = C + (long long)gm * ldc + gn;
+            if (epi == VBG_EPI_RELU) v = make_float4(fmaxf(v.x, 0.f), fmaxf(v.y, 0.f), fmaxf(v.z, 0.f), fmaxf(v.w, 0.f));
+            if (epi == VBG_EPI_MUL_GELU_GRAD) {
+                const float4 hv = *reinterpret_cast<const float4*>(C2 + (long long)gm * ldc + gn);
+                v.x *= gelu_erf_grad(hv.x); v.y *= gelu_erf_grad(hv.y); v.z *= gelu_erf_grad(hv.z); v.w *= gelu_erf_grad(hv.w);
+            }
+            if (C) *reinterpret_cast<float4*>(cp) = v;
+            if (epi == VBG_EPI_GELU_DUAL) {
+                v = make_float4(gelu_erf(v.x), gelu_erf(v.y), gelu_erf(v.z), gelu_erf(v.w));
+                if (C2) *reinterpret_cast<float4*>(C2 + (long long)gm * ldc + gn) = v;
+            }
+            if (Cp) {
+                const float e[4] = {v.x, v.y, v.z, v.w};
+                unsigned short h[4], m[4], l[4];
+#pragma unroll
+                for (int t = 0; t < 4; ++t) pg_split3(e[t], h[t], m[t], l[t]);
+                unsigned short* o = Cp + (long long)gm * p.ldp + gn;
+                *reinterpret_cast<uint2*>(o) = make_uint2(h[0] | ((unsigned)h[1] << 16), h[2] | ((unsigned)h[3] << 16));
+                *reinterpret_cast<uint2*>(o + p.c_plane) = make_uint2(m[0] | ((unsigned)m[1] << 16), m[2] | ((unsigned)m[3] << 16));
+                *reinterpret_cast<uint2*>(o + 2 * p.c_plane) = make_uint2(l[0] | ((unsigned)l[1] << 16), l[2] | ((unsigned)l[3] << 16));
+            }
+        }
+        __syncthreads();
+    }
+}
+
 // ---- stream-K form of the NT product ------------------------------------------------------------------------------------------
 // One block per CU holds a 128 x 128 tile's stages, so a product runs in ROUNDS of 256 tiles and the BERT shapes end in a
 // round that is a quarter full (4128 x 768: 198 tiles, 4128 x 2304: 594 = 2.32 rounds, 4128 x 3072: 792 = 3.09 rounds).  Here the
@@ -916,6 +1108,15 @@ static int plane_gemm_dispatch(const vbg_plane_gemm_desc* desc, void* stream, vo
             }
             VBG_LAUNCH_RET();
         }
+    }
+    if (tile == 256256) {
+        VBG_CHECK_ARG(d.splitk == 1 && !d.accumulate && d.K % 16 == 0);
+        const dim3 g(cdiv(d.M, 256), cdiv(d.N, 256));
+        (void)hipGetLastError();
+        hipEvent_t ev0 = (hipEvent_t)e0, ev1 = (hipEvent_t)e1;
+        if (ev0 && ev1) hipExtLaunchKernelGGL(plane_gemm_256_kernel, g, dim3(512), 0, s, ev0, ev1, 0, d);
+        else hipLaunchKernelGGL(plane_gemm_256_kernel, g, dim3(512), 0, s, d);
+        VBG_LAUNCH_RET();
     }
     if (tile == 256128) pg_launch<256, 128, 4, 2, 2>(d, s, (hipEvent_t)e0, (hipEvent_t)e1);
     else if (tile == 128128) pg_launch<128, 128, 2, 2, 3>(d, s, (hipEvent_t)e0, (hipEvent_t)e1);
