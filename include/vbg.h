@@ -122,7 +122,7 @@ typedef struct vbg_plane_gemm_desc {
     unsigned short* Cp; long long c_plane; long long ldp;
     int epi; float alpha; int accumulate;                         /* C += result (atomics only if splitk > 1) */
     int splitk;                                                   /* >1 requires accumulate */
-    int tile;                                                     /* 0 auto; 256128 / 128128 / 128129 / 128130 / 128064 / 64064 */
+    int tile;                                                     /* 0 auto; 256256 / 256128 / 128128 / 128129 / 128130 / 128064 / 64064 */
     /* trans != 0 ("TN"): C[M,N] (+)= alpha * sum_k A[k,M] * B[k,N] -- the reduction index is the operands' ROW index: A planes
        [3][K][lda], B planes [3][K][ldb], lda / ldb multiples of 32 (zero padded), K any length.  The weight gradient dW = dY^T X
        straight from the planes of dY and X that the data-gradient / forward products already use (LDS transpose reads). */
