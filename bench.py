@@ -160,6 +160,7 @@ def main():
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
         # VBG_DIST_BACKEND=gloo lets two ranks share ONE GPU for functional validation of the N>1 path
         dist.init_process_group(os.environ.get("VBG_DIST_BACKEND", "nccl"), rank=rank, world_size=world)
+        cpu_pg = dist.new_group(backend="gloo")      # host-side agreement on per-step decisions (gradient clipping)
     assert world == args.gpus, f"--gpus {args.gpus} but WORLD_SIZE={world} (launch with torch.distributed.run)"
 
     from vbg import ops
@@ -210,9 +211,26 @@ def main():
         opt_bert.zero_grad()
         loss.backward()
         reducer.finish()
+        if world > 1 and os.environ.get("VBG_SYNC_DEBUG"):
+            named = cnn + bert
+            gs = torch.stack([p.grad.detach().double().sum() for _, p in named])
+            lo3, hi3 = gs.clone(), gs.clone()
+            dist.all_reduce(lo3, op=dist.ReduceOp.MIN)
+            dist.all_reduce(hi3, op=dist.ReduceOp.MAX)
+            badg = (lo3 != hi3).nonzero().flatten().tolist()
+            if rank == 0:
+                print(f"[sync check] gradients after finish(): {len(badg)} differ; first {[named[i][0] for i in badg[:6]]}", file=sys.stderr, flush=True)
         if not args.sync_loss:
             val = val.get()
-        if val > 10:
+        clip = val > 10
+        if world > 1:
+            # the reference decides on the LOCAL loss (pipeline/train_val_utils.py:280-281); ranks that decide differently scale the same
+            # all-reduced gradient differently and their parameters drift apart.  Agree on the decision (any rank over the threshold)
+            # through a host-side gloo group: the GPU queue is not touched.
+            cf = torch.tensor([1.0 if clip else 0.0])
+            dist.all_reduce(cf, op=dist.ReduceOp.MAX, group=cpu_pg)
+            clip = bool(cf.item() > 0)
+        if clip:
             clip_grad_norm_(opts, 2.0, 1.0 / world)
         opt_cnn.step()
         opt_bert.step()
@@ -319,6 +337,16 @@ def main():
         dist.all_reduce(lo, op=dist.ReduceOp.MIN)
         dist.all_reduce(hi, op=dist.ReduceOp.MAX)
         ranks_in_sync = bool(torch.equal(lo, hi))
+        if not ranks_in_sync or os.environ.get("VBG_SYNC_DEBUG"):
+            # which parameters differ between ranks (per-parameter checksums, MIN / MAX over ranks)
+            named = cnn + bert
+            sums = torch.stack([p.detach().double().sum() for _, p in named] + [p.detach().double().abs().sum() for _, p in named])
+            lo2, hi2 = sums.clone(), sums.clone()
+            dist.all_reduce(lo2, op=dist.ReduceOp.MIN)
+            dist.all_reduce(hi2, op=dist.ReduceOp.MAX)
+            bad = ((lo2 != hi2)[:len(named)] | (lo2 != hi2)[len(named):]).nonzero().flatten().tolist()
+            if rank == 0:
+                print(f"[sync check] {len(bad)} of {len(named)} parameters differ between ranks; first: {[named[i][0] for i in bad[:12]]}", file=sys.stderr, flush=True)
     # HBM-side bytes per launch of the same kernel: rocprofv3 PMC passes of this command (cannot be collected in-process),
     # summarised in profiles/ by the round that produced them; null when the file is absent
     traffic, traffic_src = None, None

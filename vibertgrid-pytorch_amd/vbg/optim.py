@@ -26,6 +26,8 @@ import torch
 import torch.distributed as dist
 
 from . import functions as Fn
+import os
+
 from . import ops
 
 STATIC_UNUSED = ("pooler.", "resnet.fc.")
@@ -343,7 +345,18 @@ class FlatReducer:
         self.buckets.append([view, len(members), len(members)])
         for p in members:
             self.bucket_of[id(p)] = idx
-            p.register_post_accumulate_grad_hook(lambda _p, idx=idx: self._ready(idx))       # autograd-accumulated gradients
+            p.register_post_accumulate_grad_hook(lambda _p, idx=idx: self._hook_ready(_p, idx))       # autograd-accumulated gradients
+
+    def _hook_ready(self, p, idx):
+        """post-accumulate hook of parameter p.  torch runs these hooks for a parameter whose autograd node handed it no gradient
+        as well (every sunk parameter: its Function wrote the gradient into the flat buffer itself, reported it through
+        `_param_ready` and returned None), so a parameter is counted ONCE per step whichever way it reports first -- counting both
+        let a bucket reach zero when only half of its members were complete, and the bucket's all-reduce then raced the kernels
+        that were still writing the rest (the last bucket lost: ranks drifted apart in the stem's parameters)."""
+        if id(p) in self._reported:
+            return
+        self._reported.add(id(p))
+        self._ready(idx)
 
     def _param_ready(self, p):
         """a sunk gradient is complete (each sunk parameter feeds exactly one autograd node per step in this model;
@@ -359,6 +372,7 @@ class FlatReducer:
     def _ready(self, idx):
         b = self.buckets[idx]
         b[2] -= 1
+        assert b[2] >= 0, "a gradient was reported twice: the bucket would be reduced before it is complete"
         if b[2] != 0:
             return
         self._observed.append(idx)
