@@ -988,7 +988,7 @@ def test_plane_gemm_tn_and_grouped_vs_fp64():
         ref = dy.double().t() @ x.double()
         scale = float((dy.double().abs().t() @ x.double().abs()).max())
         pdy, px = ops.split_planes(dy), ops.split_planes(x)
-        for tile in (128129, 128130):
+        for tile in (128129, 128130, 256128):
             out = torch.full((N1, N2), 3.0, device=dev)
             ops.plane_gemm(pdy, px, out, trans=True, tile=tile)
             assert float((out.double() - ref).abs().max()) <= 2e-6 * scale, (Mt, N1, N2, tile)
@@ -1005,6 +1005,12 @@ def test_plane_gemm_tn_and_grouped_vs_fp64():
         probs.append((ops.split_planes(dy), ops.split_planes(x), torch.ones(N1, N2, device=dev)))
         refs.append(dy.double().t() @ x.double())
     ops.plane_gemm_grouped(probs, trans=True, accumulate=True)
+    for (_, _, out), ref in zip(probs, refs):
+        assert float((out.double() - 1 - ref).abs().max()) <= 2e-6 * float(ref.abs().max()) * 30
+    # the 256 x 128 tile form of the grouped launch (512-byte LDS rows for the A operand)
+    for (_, _, out) in probs:
+        out.fill_(1.0)
+    ops.plane_gemm_grouped(probs, trans=True, accumulate=True, tile=256128)
     for (_, _, out), ref in zip(probs, refs):
         assert float((out.double() - 1 - ref).abs().max()) <= 2e-6 * float(ref.abs().max()) * 30
 

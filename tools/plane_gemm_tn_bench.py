@@ -17,7 +17,7 @@ for (Mt, N1, N2) in ((4128, 3072, 768), (4128, 768, 3072), (4128, 2304, 768), (4
     pdy, px = ops.split_planes(dy), ops.split_planes(x)
     out = torch.zeros(N1, N2, device=dev)
     row = [f"dW {N1}x{N2} over {Mt}:"]
-    for tile in (128129, 128130):
+    for tile in (128129, 128130, 256128):
         out.zero_()
         ops.plane_gemm(pdy, px, out, trans=True, tile=tile)
         err = float((out.double() - ref).abs().max()) / scale
@@ -42,6 +42,11 @@ for (N1, N2) in shapes:
 ops.plane_gemm_grouped(probs)
 for (a, b, out), ref in zip(probs, refs):
     print("grouped err", float((out.double() - ref).abs().max() / ref.abs().max()))
-t = timed(lambda: ops.plane_gemm_grouped(probs))
 fl = sum(2.0 * Mt * a * b for a, b in shapes)
-print(f"grouped 4 wgrads: {t:.1f} us {fl / t * 1e-6:.0f} TF")
+for tile in (0, 256128):
+    for (_, _, out) in probs:
+        out.zero_()
+    ops.plane_gemm_grouped(probs, tile=tile)
+    errs = [float((out.double() - ref).abs().max() / ref.abs().max()) for (a, b, out), ref in zip(probs, refs)]
+    t = timed(lambda: ops.plane_gemm_grouped(probs, tile=tile))
+    print(f"grouped 4 wgrads tile {tile}: {t:.1f} us {fl / t * 1e-6:.0f} TF, errs {errs}")

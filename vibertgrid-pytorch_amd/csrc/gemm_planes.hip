@@ -41,7 +41,7 @@ typedef __attribute__((address_space(3))) pg_v4s* pg_lds_v4s;
 //   Rows past the reduction length fall off the per-plane buffer descriptors and read 0.
 template <int BM, int BN, int WGM, int WGN, int NST, bool TRANS>
 __global__ __launch_bounds__(WGM * WGN * 64) void plane_gemm_kernel(const vbg_plane_gemm_desc p) {
-    static_assert(!TRANS || (BM == 128 && BN == 128), "TN: 128-column operand tiles (256-byte LDS rows)");
+    static_assert(!TRANS || ((BM == 128 || BM == 256) && BN == 128), "TN: 128- or 256-column A tiles, 128-column B tiles");
     constexpr int NW = WGM * WGN, NT = NW * 64;
     constexpr int BK = 32;
     constexpr int WM = BM / WGM, WN = BN / WGN, TM = WM / 32, TN = WN / 32;
@@ -120,22 +120,26 @@ __global__ __launch_bounds__(WGM * WGN * 64) void plane_gemm_kernel(const vbg_pl
         abase = pA + (long long)m0 * lda + (long long)kt0 * BK;
         bbase = pB + (long long)n0 * ldb + (long long)kt0 * BK;
     } else {
-        // unit (plane q, 4-row block rb): lane l fills LDS bytes [16 l, +16) of the unit's 1 KiB = k-row rb*4 + l/16, physical
-        // 16-byte piece l%16, from logical 64-byte chunk (piece / 4) ^ (row & 3)
-        const int lrow = lane >> 4, piece = lane & 15;
-        const int lcol = ((((piece >> 2) ^ (lrow & 3)) << 2) + (piece & 3)) * 8;          // source column (elements)
+        // a k-row of an operand tile is RS = 2 * columns bytes (256 or 512); a 1 KiB DMA unit = 1024 / RS rows: lane l fills LDS bytes
+        // [16 l, +16) of the unit = k-row rb * RPU + l / PPR, physical 16-byte piece l % PPR, from logical 64-byte chunk
+        // (piece / 4) ^ (row & 3) (XOR on the two low bits of the chunk index)
+        constexpr int PPRA = BM / 8, PPRB = BN / 8, RPUA = 64 / PPRA, RPUB = 64 / PPRB, UPA = 32 / RPUA, UPB = 32 / RPUB;
         const int mpad = (M + 31) / 32 * 32, npad = (N + 31) / 32 * 32;                   // (plane rows are zero padded to 32)
 #pragma unroll
         for (int i = 0; i < NIA; ++i) {
-            const int u = wave + NW * i, rb = u % 8;
-            avo[i] = (m0 + lcol < mpad) ? (unsigned)(((long long)(rb * 4 + lrow) * lda + lcol) * 2) : PG_INVALID;
-            alds[i] = __builtin_amdgcn_readfirstlane((u / 8) * PA + rb * 1024);
+            const int u = wave + NW * i, rb = u % UPA;
+            const int lrow = lane / PPRA, piece = lane % PPRA, row = rb * RPUA + lrow;
+            const int lcol = (((((piece >> 2) ^ (row & 3))) << 2) + (piece & 3)) * 8;     // source column (elements)
+            avo[i] = (m0 + lcol < mpad) ? (unsigned)(((long long)row * lda + lcol) * 2) : PG_INVALID;
+            alds[i] = __builtin_amdgcn_readfirstlane((u / UPA) * PA + rb * 1024);
         }
 #pragma unroll
         for (int i = 0; i < NIB; ++i) {
-            const int u = wave + NW * i, rb = u % 8;
-            bvo[i] = (n0 + lcol < npad) ? (unsigned)(((long long)(rb * 4 + lrow) * ldb + lcol) * 2) : PG_INVALID;
-            blds[i] = __builtin_amdgcn_readfirstlane(3 * PA + (u / 8) * PB + rb * 1024);
+            const int u = wave + NW * i, rb = u % UPB;
+            const int lrow = lane / PPRB, piece = lane % PPRB, row = rb * RPUB + lrow;
+            const int lcol = (((((piece >> 2) ^ (row & 3))) << 2) + (piece & 3)) * 8;
+            bvo[i] = (n0 + lcol < npad) ? (unsigned)(((long long)row * ldb + lcol) * 2) : PG_INVALID;
+            blds[i] = __builtin_amdgcn_readfirstlane(3 * PA + (u / UPB) * PB + rb * 1024);
         }
         abase = pA + (long long)kt0 * BK * lda + m0;
         bbase = pB + (long long)kt0 * BK * ldb + n0;
@@ -158,18 +162,22 @@ __global__ __launch_bounds__(WGM * WGN * 64) void plane_gemm_kernel(const vbg_pl
             abase += BK;
             bbase += BK;
         } else {
-            // one descriptor per plane, ending behind the last row of the reduction (NIA == NIB == 3: unit i of a wave = plane i)
-            static_assert(NIA == 3 && NIB == 3, "TN: 8 waves, one plane per DMA instruction of a wave");
+            // one descriptor per plane, ending behind the last row of the reduction (the plane of unit i of a wave is a compile-time
+            // constant: units are dealt to the waves plane by plane)
+            constexpr int UPA = 32 / (64 / (BM / 8)), UPB = 32 / (64 / (BN / 8));
+            static_assert(UPA % NW == 0 && UPB % NW == 0, "TN: a plane's DMA units divide over the waves");
             const int na = (int)(a_rem < 0 ? 0 : (a_rem > 0x7fffffffll ? 0x7fffffffll : a_rem));
             const int nb = (int)(b_rem < 0 ? 0 : (b_rem > 0x7fffffffll ? 0x7fffffffll : b_rem));
 #pragma unroll
-            for (int i = 0; i < 3; ++i) {
-                const __amdgpu_buffer_rsrc_t ra = __builtin_amdgcn_make_buffer_rsrc(const_cast<unsigned short*>(abase + i * a_plane), 0, na, 0x00020000);
+            for (int i = 0; i < NIA; ++i) {
+                const int q = (NW * i) / UPA;
+                const __amdgpu_buffer_rsrc_t ra = __builtin_amdgcn_make_buffer_rsrc(const_cast<unsigned short*>(abase + q * a_plane), 0, na, 0x00020000);
                 __builtin_amdgcn_raw_ptr_buffer_load_lds(ra, (lds_ptr)(sb + alds[i]), 16, (int)(avo[i] | inv), 0, 0, 0);
             }
 #pragma unroll
-            for (int i = 0; i < 3; ++i) {
-                const __amdgpu_buffer_rsrc_t rb = __builtin_amdgcn_make_buffer_rsrc(const_cast<unsigned short*>(bbase + i * b_plane), 0, nb, 0x00020000);
+            for (int i = 0; i < NIB; ++i) {
+                const int q = (NW * i) / UPB;
+                const __amdgpu_buffer_rsrc_t rb = __builtin_amdgcn_make_buffer_rsrc(const_cast<unsigned short*>(bbase + q * b_plane), 0, nb, 0x00020000);
                 __builtin_amdgcn_raw_ptr_buffer_load_lds(rb, (lds_ptr)(sb + blds[i]), 16, (int)(bvo[i] | inv), 0, 0, 0);
             }
             abase += (long long)BK * lda;
@@ -184,14 +192,16 @@ __global__ __launch_bounds__(WGM * WGN * 64) void plane_gemm_kernel(const vbg_pl
     const int lr = lane & 31, lk = lane >> 5;
     const int sw = (lr >> 2) & 3;
     // byte offset of lane's 16-byte fragment of k-step s inside a 32-row fragment block: row lr, logical chunk 2 s + lk
-    const int fo0 = TRANS ? 0 : lr * 64 + (((0 + lk) ^ sw) << 4), fo1 = TRANS ? 4096 : lr * 64 + (((2 + lk) ^ sw) << 4);
+    // (TRANS: k-step 1 starts 16 k-rows further: 16 * RS bytes, applied per operand in read_frags)
+    const int fo0 = TRANS ? 0 : lr * 64 + (((0 + lk) ^ sw) << 4), fo1 = TRANS ? 16 : lr * 64 + (((2 + lk) ^ sw) << 4);
     // TRANS: byte offset of this lane's tr-read address inside a plane tile for fragment block i (32 columns), k-step 0, half 0
     const int i16 = lane & 15, tg = (lane >> 4) & 1;
     int ta[TM], tb[TN];
+    constexpr int RSA = BM * 2, RSB = BN * 2;                      // bytes of a k-row of the A / B tile image
 #pragma unroll
-    for (int i = 0; i < TM; ++i) ta[i] = (8 * lk + (i16 >> 2)) * 256 + (((wm * TM + i) ^ (i16 >> 2)) << 6) + (16 * tg + 4 * (i16 & 3)) * 2;
+    for (int i = 0; i < TM; ++i) ta[i] = (8 * lk + (i16 >> 2)) * RSA + (((wm * TM + i) ^ (i16 >> 2)) << 6) + (16 * tg + 4 * (i16 & 3)) * 2;
 #pragma unroll
-    for (int j = 0; j < TN; ++j) tb[j] = (8 * lk + (i16 >> 2)) * 256 + (((wn * TN + j) ^ (i16 >> 2)) << 6) + (16 * tg + 4 * (i16 & 3)) * 2;
+    for (int j = 0; j < TN; ++j) tb[j] = (8 * lk + (i16 >> 2)) * RSB + (((wn * TN + j) ^ (i16 >> 2)) << 6) + (16 * tg + 4 * (i16 & 3)) * 2;
     f32x16 acc[TM][TN];
 #pragma unroll
     for (int i = 0; i < TM; ++i)
@@ -204,20 +214,20 @@ __global__ __launch_bounds__(WGM * WGN * 64) void plane_gemm_kernel(const vbg_pl
     auto read_frags = [&](int stage, int fo, pg_u32x4 (&fa)[3][TM], pg_u32x4 (&fb)[3][TN]) {
         if constexpr (TRANS) {
             typedef __attribute__((address_space(3))) unsigned char* lds_bytes;
-            lds_bytes as = (lds_bytes)(smem + stage * STAGE + fo), bs = (lds_bytes)(smem + stage * STAGE + 3 * PA + fo);
+            lds_bytes as = (lds_bytes)(smem + stage * STAGE + fo * RSA), bs = (lds_bytes)(smem + stage * STAGE + 3 * PA + fo * RSB);
 #pragma unroll
             for (int q = 0; q < 3; ++q) {
 #pragma unroll
                 for (int i = 0; i < TM; ++i) {
                     const pg_v4s lo = __builtin_amdgcn_ds_read_tr16_b64_v4i16((pg_lds_v4s)(as + q * PA + ta[i]));
-                    const pg_v4s hi = __builtin_amdgcn_ds_read_tr16_b64_v4i16((pg_lds_v4s)(as + q * PA + ta[i] + 1024));
+                    const pg_v4s hi = __builtin_amdgcn_ds_read_tr16_b64_v4i16((pg_lds_v4s)(as + q * PA + ta[i] + 4 * RSA));
                     const uint2 l2 = __builtin_bit_cast(uint2, lo), h2 = __builtin_bit_cast(uint2, hi);
                     fa[q][i] = pg_u32x4{l2.x, l2.y, h2.x, h2.y};
                 }
 #pragma unroll
                 for (int j = 0; j < TN; ++j) {
                     const pg_v4s lo = __builtin_amdgcn_ds_read_tr16_b64_v4i16((pg_lds_v4s)(bs + q * PB + tb[j]));
-                    const pg_v4s hi = __builtin_amdgcn_ds_read_tr16_b64_v4i16((pg_lds_v4s)(bs + q * PB + tb[j] + 1024));
+                    const pg_v4s hi = __builtin_amdgcn_ds_read_tr16_b64_v4i16((pg_lds_v4s)(bs + q * PB + tb[j] + 4 * RSB));
                     const uint2 l2 = __builtin_bit_cast(uint2, lo), h2 = __builtin_bit_cast(uint2, hi);
                     fb[q][j] = pg_u32x4{l2.x, l2.y, h2.x, h2.y};
                 }
@@ -1054,7 +1064,7 @@ static int plane_gemm_dispatch(const vbg_plane_gemm_desc* desc, void* stream, vo
             if (d.trans) VBG_CHECK_ARG(g.lda % 32 == 0 && g.ldb % 32 == 0 && g.lda >= g.M && g.ldb >= g.N);
             else VBG_CHECK_ARG(g.lda % 8 == 0 && g.ldb % 8 == 0 && g.lda >= d.K && g.ldb >= d.K);
             VBG_CHECK_ARG(2 * g.a_plane * 2 + 256 * g.lda * 2 < 0x7fffffffll && 2 * g.b_plane * 2 + 256 * g.ldb * 2 < 0x7fffffffll);
-            const int bm = (d.trans || d.tile != 64064) ? 128 : 64, bn = bm;
+            const int bn = (d.trans || d.tile != 64064) ? 128 : 64, bm = (d.trans && d.tile == 256128) ? 256 : bn;
             g.tiles_m = (g.M + bm - 1) / bm;
             g.tiles_n = (g.N + bn - 1) / bn;
         }
@@ -1080,7 +1090,8 @@ static int plane_gemm_dispatch(const vbg_plane_gemm_desc* desc, void* stream, vo
     hipStream_t s = (hipStream_t)stream;
     int tile = d.tile;
     if (d.trans) {
-        if (tile == 128130) pg_launch<128, 128, 2, 4, 3, true>(d, s, (hipEvent_t)e0, (hipEvent_t)e1);
+        if (tile == 256128) pg_launch<256, 128, 4, 2, 2, true>(d, s, (hipEvent_t)e0, (hipEvent_t)e1);
+        else if (tile == 128130) pg_launch<128, 128, 2, 4, 3, true>(d, s, (hipEvent_t)e0, (hipEvent_t)e1);
         else pg_launch<128, 128, 4, 2, 3, true>(d, s, (hipEvent_t)e0, (hipEvent_t)e1);
         VBG_LAUNCH_RET();
     }

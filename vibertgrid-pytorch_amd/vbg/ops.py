@@ -211,6 +211,12 @@ def plane_gemm_grouped(problems, *, trans=True, accumulate=True, tile=0, alpha=1
     """several independent plane products of ONE reduction length in one launch: problems = [(a: Planes, b: Planes, out), ...]
     (trans: out[a.cols, b.cols] (+)= a^T b, the weight gradients of a layer)"""
     assert 1 <= len(problems) <= 4
+    if trans and tile == 0:
+        # 256 x 128 output tiles move a third fewer operand bytes per product (csrc/gemm_planes.hip: the kernels are bound by what a CU
+        # ingests); worth it once they still cover most of the chip (the four weight gradients of a bert-base layer: 216 tiles)
+        t256 = sum(((a.cols + 255) // 256) * ((b.cols + 127) // 128) for a, b, _ in problems)
+        if t256 >= 0.6 * torch.cuda.get_device_properties(problems[0][2].device).multi_processor_count:
+            tile = 256128
     d = PlaneGemmDesc()
     d.ngroups, d.trans, d.accumulate, d.tile, d.alpha, d.splitk = len(problems), int(trans), int(bool(accumulate)), int(tile), float(alpha), 1
     k = None
