@@ -174,7 +174,7 @@ int vbg_split_planes_t_batched(const float* src, unsigned short* dst, const long
  * 65536 / (65536 - vbg_attn_drop_thr16(p)); mask_off[s] = first word of sequence s (heads * roundup(len,32) * ceil(len/32) words). */
 enum { VBG_ATTN_FWD = 0, VBG_ATTN_DQ = 1, VBG_ATTN_DKV = 2 };
 typedef struct vbg_attn_desc {
-    int mode, heads, ntasks;
+    int mode, heads, ntasks, max_len;                 /* max_len: longest sequence (<= 512: BERT windows) */
     const int* tasks; const int* seq_len; const int* seq_row0; const int* pad_off; long long ntok_pad;
     const unsigned short* qkv; long long qkv_plane, qkv_ld;
     const unsigned short* dO; long long do_plane, do_ld;

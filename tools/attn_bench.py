@@ -1,0 +1,35 @@
+#!/usr/bin/env python3
+"""Time the three fused-attention kernels at the cfg2 shape (8 sequences of 512 + 8 of 4 tokens, 12 heads, dropout 0.1)."""
+import os, sys
+import numpy as np
+import torch
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+sys.path.insert(0, os.path.join(ROOT, "vibertgrid-pytorch_amd")); sys.path.insert(0, os.path.join(ROOT, "tests")); sys.path.insert(0, os.path.join(ROOT, "tools"))
+from vbg import ops  # noqa: E402
+from vbg.lib import ATTN_DKV, ATTN_DQ, ATTN_FWD  # noqa: E402
+from plane_gemm_bench import timed  # noqa: E402
+from test_gpu_attention import _meta  # noqa: E402
+dev = torch.device("cuda")
+heads = 12
+meta, *_ = _meta([512] * 8 + [4] * 8, heads)
+hid, ntok = heads * 64, meta.ntok
+g = torch.Generator().manual_seed(0)
+pq = ops.split_planes(torch.randn(ntok, 3 * hid, generator=g).to(dev))
+pdo = ops.split_planes(torch.randn(ntok, hid, generator=g).to(dev))
+for p in (0.1, 0.0):
+    masks = ops.attn_mask(meta, p, 1, 2) if p > 0 else None
+    O, kbar = torch.zeros(ntok, hid, device=dev), torch.zeros(ntok, hid, device=dev)
+    lse = torch.zeros(2, heads, meta.ntok_pad, device=dev)
+    opl = ops.planes_empty(ntok, hid, dev)
+    dqkv = torch.zeros(ntok, 3 * hid, device=dev)
+    f = lambda: ops.attn(meta, ATTN_FWD, pq, None, O, lse, None, masks, 0.125, p, kbar=kbar, out_planes=opl)
+    f()
+    delta = ops.attn_delta(torch.randn(ntok, hid, device=dev), O, meta, torch.zeros_like(lse[0]))
+    d0 = delta.clone()
+    def dq():
+        delta.copy_(d0)
+        ops.attn(meta, ATTN_DQ, pq, pdo, dqkv, lse, delta, masks, 0.125, p, kbar=kbar)
+    dkv = lambda: ops.attn(meta, ATTN_DKV, pq, pdo, dqkv, lse, delta, masks, 0.125, p)
+    tf, tq, tk = timed(f), timed(dq), timed(dkv)
+    fl = 8 * heads * 4.0 * 512 * 512 * 64
+    print(f"dropout {p}: FWD {tf:6.1f} us ({fl / tf * 1e-6:5.1f} TF)  DQ {tq:6.1f} us ({1.5 * fl / tq * 1e-6:5.1f} TF executed)  DKV {tk:6.1f} us ({2 * fl / tk * 1e-6:5.1f} TF executed)")

@@ -64,7 +64,11 @@ template <int MODE, bool DROP>
 __global__ __launch_bounds__(256) void attn_kernel(const vbg_attn_desc p) {
     constexpr bool FWD = MODE == VBG_ATTN_FWD, DQ = MODE == VBG_ATTN_DQ, DKV = MODE == VBG_ATTN_DKV;
     constexpr int NS = FWD ? 1 : 2;                                   // stationary operands
-    __shared__ __attribute__((aligned(1024))) unsigned char smem[2 * AT_STAGE];          // (the ONE LDS object of the kernel)
+    // behind the two tile stages: the dropout keep words of the workgroup's own rows (128 rows x 16 tiles) and, DKV, the statistics
+    // (m, 1 / l, delta) of every query of the sequence (3 x 512 floats) -- staged ONCE, so that the tile loop issues no ordinary
+    // global load (hipcc waits vmcnt(0) for any such load while LDS-DMA is in flight: it drained the tile pipeline every iteration)
+    constexpr int AT_MASK_OFF = 2 * AT_STAGE, AT_STAT_OFF = AT_MASK_OFF + 128 * 16 * 4, AT_SMEM = AT_STAT_OFF + (DKV ? 3 * 512 * 4 : 0);
+    __shared__ __attribute__((aligned(1024))) unsigned char smem[AT_SMEM];          // (the ONE LDS object of the kernel)
 
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
     const int lr = lane & 31, lh = lane >> 5;
@@ -221,42 +225,39 @@ __global__ __launch_bounds__(256) void attn_kernel(const vbg_attn_desc p) {
     const bool want_kbar = FWD && p.kbar != nullptr;
     float dsum = 0.f;                            // DQ: this half-wave's part of sum_k P_k dP_k of the own query
     // dropout keep words of the own row: FWD / DQ bit = key of the streamed 32-key block, DKV bit = query of the 32-query block
-    const unsigned* mrow = nullptr;
-    if constexpr (DROP) mrow = (DKV ? p.mask_k : p.mask_q) + mbase + (long long)(own0 + lr) * nt;
-    unsigned mword = 0xffffffffu;
-    if constexpr (DROP) mword = (active && own0 + lr < nt * 32) ? mrow[0] : 0u;
-
-    float nst[3][16];                            // DKV: (m, 1 / l, delta) of the NEXT streamed tile's queries
-    auto load_stats = [&](int t) {
-        if constexpr (DKV) {
-#pragma unroll
-            for (int j = 0; j < 4; ++j) {
-                const float4 a = *reinterpret_cast<const float4*>(p.lse + lsoff + t * 32 + 8 * j + 4 * lh);
-                const float4 c = *reinterpret_cast<const float4*>(p.lse + lsplane + lsoff + t * 32 + 8 * j + 4 * lh);
-                const float4 b = *reinterpret_cast<const float4*>(p.delta + lsoff + t * 32 + 8 * j + 4 * lh);
-                nst[0][4 * j] = a.x; nst[0][4 * j + 1] = a.y; nst[0][4 * j + 2] = a.z; nst[0][4 * j + 3] = a.w;
-                nst[1][4 * j] = c.x; nst[1][4 * j + 1] = c.y; nst[1][4 * j + 2] = c.z; nst[1][4 * j + 3] = c.w;
-                nst[2][4 * j] = b.x; nst[2][4 * j + 1] = b.y; nst[2][4 * j + 2] = b.z; nst[2][4 * j + 3] = b.w;
-            }
+    unsigned* const mlds = reinterpret_cast<unsigned*>(smem + AT_MASK_OFF) + (wave * 32 + lr) * 16;
+    if constexpr (DROP) {
+        if (active && lh == 0 && own0 + lr < nt * 32) {
+            const unsigned* mrow = (DKV ? p.mask_k : p.mask_q) + mbase + (long long)(own0 + lr) * nt;
+            for (int t = 0; t < nt; ++t) mlds[t] = mrow[t];
         }
-    };
-    load_stats(0);
+    }
+    float* const slds = reinterpret_cast<float*>(smem + AT_STAT_OFF);
+    if constexpr (DKV) {
+        for (int i = tid; i < nt * 32; i += 256) {
+            slds[i] = p.lse[lsoff + i];
+            slds[512 + i] = p.lse[lsplane + lsoff + i];
+            slds[1024 + i] = p.delta[lsoff + i];
+        }
+    }
+    unsigned mword = 0xffffffffu;
     issue(0, 0);
-    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+    asm volatile("s_waitcnt vmcnt(0) lgkmcnt(0)" ::: "memory");
     __builtin_amdgcn_s_barrier();
 
     for (int t = 0; t < nt; ++t) {
         const int stage = t & 1;
         if (t + 1 < nt) issue(stage ^ 1, t + 1);
-        unsigned mnext = 0xffffffffu;
-        if constexpr (DROP) mnext = (active && t + 1 < nt && own0 + lr < nt * 32) ? mrow[t + 1] : 0u;
+        if constexpr (DROP) mword = mlds[t];                               // (rows past the padded length are never stored)
         float cst[3][16];
         if constexpr (DKV) {
 #pragma unroll
             for (int a = 0; a < 3; ++a)
 #pragma unroll
-                for (int r = 0; r < 16; ++r) cst[a][r] = nst[a][r];
-            if (t + 1 < nt) load_stats(t + 1);
+                for (int j = 0; j < 4; ++j) {
+                    const float4 v = *reinterpret_cast<const float4*>(slds + a * 512 + t * 32 + 8 * j + 4 * lh);
+                    cst[a][4 * j] = v.x; cst[a][4 * j + 1] = v.y; cst[a][4 * j + 2] = v.z; cst[a][4 * j + 3] = v.w;
+                }
         }
         if (active) {
             const unsigned char* im0 = smem + stage * AT_STAGE;
@@ -314,12 +315,22 @@ __global__ __launch_bounds__(256) void attn_kernel(const vbg_attn_desc p) {
                 f32x16 dp;
 #pragma unroll
                 for (int r = 0; r < 16; ++r) dp[r] = 0.f;
-                sprod(im1, st[1], dp);
                 float pr[16], ds[16];
                 if constexpr (DQ) {
+                    // the probabilities only need S: their VALU work is issued into the gaps of the dP product's MFMAs
+                    __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+                    for (int r = 0; r < 16; ++r) pr[r] = __expf(s[r] * scale - m_own) * il_own;
+                    sprod(im1, st[1], dp);
+#pragma unroll
+                    for (int g = 0; g < 24; ++g) {
+                        __builtin_amdgcn_sched_group_barrier(0x008, 1, 0);
+                        if (g < 12) __builtin_amdgcn_sched_group_barrier(0x100, 1, 0);
+                        __builtin_amdgcn_sched_group_barrier(0x002, 3, 0);
+                    }
+                    __builtin_amdgcn_sched_barrier(0);
 #pragma unroll
                     for (int r = 0; r < 16; ++r) {
-                        pr[r] = __expf(s[r] * scale - m_own) * il_own;
                         float g = dp[r];
                         if constexpr (DROP) g = ((mw >> ((r & 3) + 8 * (r >> 2))) & 1u) ? g * keep_scale : 0.f;
                         ds[r] = pr[r] * (g - del_own);
@@ -331,30 +342,46 @@ __global__ __launch_bounds__(256) void attn_kernel(const vbg_attn_desc p) {
                 } else {
                     // statistics of the streamed queries: register r = query 8 (r >> 2) + 4 lh + (r & 3) of the tile (loaded an
                     // iteration ahead: a use of a fresh global load in here would drain the tile DMA in flight)
-                    float lq[16], iq[16], dq[16];
-#pragma unroll
-                    for (int r = 0; r < 16; ++r) { lq[r] = cst[0][r]; iq[r] = cst[1][r]; dq[r] = cst[2][r]; }
+                    // Phase A: P, its dropped / scaled form and the split of that only need S -> issued into the gaps of the dP product.
+                    float pv[16];
+                    at_u32x4 bpv[3][2], bpk[3][2];
+                    __builtin_amdgcn_sched_barrier(0);
 #pragma unroll
                     for (int r = 0; r < 16; ++r) {
-                        const float pv = __expf(s[r] * scale - lq[r]) * iq[r];
-                        float g = dp[r], pd = pv;
-                        if constexpr (DROP) {
-                            const bool keep = (mw >> ((r & 3) + 8 * (r >> 2))) & 1u;
-                            g = keep ? g * keep_scale : 0.f;
-                            pd = keep ? pv * keep_scale : 0.f;
-                        }
+                        pv[r] = __expf(s[r] * scale - cst[0][r]) * cst[1][r];
+                        float pd = pv[r];
+                        if constexpr (DROP) pd = ((mw >> ((r & 3) + 8 * (r >> 2))) & 1u) ? pv[r] * keep_scale : 0.f;
                         pr[r] = pd;
-                        ds[r] = pv * (g - dq[r]);
                     }
-                    at_u32x4 bp[3][2];
-                    at_split16(pr, bp);
-                    tprod(im1, bp, acc1);                                  // dV^T += dO^T Pd
-                    at_split16(ds, bp);
-                    tprod(im0, bp, acc0);                                  // dK^T += Q^T dS
+                    at_split16(pr, bpv);
+                    sprod(im1, st[1], dp);
+#pragma unroll
+                    for (int g = 0; g < 24; ++g) {
+                        __builtin_amdgcn_sched_group_barrier(0x008, 1, 0);
+                        if (g < 12) __builtin_amdgcn_sched_group_barrier(0x100, 1, 0);
+                        __builtin_amdgcn_sched_group_barrier(0x002, 8, 0);
+                    }
+                    __builtin_amdgcn_sched_barrier(0);
+                    // Phase B: dS and its split need dP -> issued into the gaps of the dV product
+#pragma unroll
+                    for (int r = 0; r < 16; ++r) {
+                        float g = dp[r];
+                        if constexpr (DROP) g = ((mw >> ((r & 3) + 8 * (r >> 2))) & 1u) ? g * keep_scale : 0.f;
+                        ds[r] = pv[r] * (g - cst[2][r]);
+                    }
+                    at_split16(ds, bpk);
+                    tprod(im1, bpv, acc1);                                 // dV^T += dO^T Pd
+#pragma unroll
+                    for (int g = 0; g < 24; ++g) {
+                        __builtin_amdgcn_sched_group_barrier(0x008, 1, 0);
+                        __builtin_amdgcn_sched_group_barrier(0x100, 1, 0);
+                        __builtin_amdgcn_sched_group_barrier(0x002, 7, 0);
+                    }
+                    __builtin_amdgcn_sched_barrier(0);
+                    tprod(im0, bpk, acc0);                                 // dK^T += Q^T dS
                 }
             }
         }
-        mword = mnext;
         asm volatile("s_waitcnt vmcnt(0) lgkmcnt(0)" ::: "memory");
         __builtin_amdgcn_s_barrier();
     }
@@ -487,6 +514,7 @@ extern "C" int vbg_attn(const vbg_attn_desc* desc, void* stream) {
         VBG_CHECK_ARG(((uintptr_t)d.delta & 15) == 0);
         if (d.mode == VBG_ATTN_DQ) VBG_CHECK_ARG(d.kbar != nullptr);
     }
+    VBG_CHECK_ARG(d.max_len >= 1 && d.max_len <= 512);          // (16 tiles of 32 rows: the size of the staged mask / statistic tables)
     const bool drop = d.mask_q != nullptr;
     if (drop) VBG_CHECK_ARG(d.mask_k && d.mask_off && d.keep_scale >= 1.0f);
     hipStream_t s = (hipStream_t)stream;

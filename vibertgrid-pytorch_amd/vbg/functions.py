@@ -527,7 +527,7 @@ class BertLayerFn(torch.autograd.Function):
         dev = x.device
         fused_qkv = _back_to_back(wq, wk, wv) and _back_to_back(bq, bk, bv)
         planes = ops.planes_enabled() and hid % 32 == 0 and wi.shape[0] % 32 == 0
-        flash = planes and dh == 64 and ops.flash_enabled()
+        flash = planes and dh == 64 and meta.maxlen <= 512 and ops.flash_enabled()
         px = pctx = px1 = pg = pqkv = qkv = P = lse = masks = kbar = None
         if not flash:
             qkv = torch.empty((ntok, 3 * hid), device=dev, dtype=f32)

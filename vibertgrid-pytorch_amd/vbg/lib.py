@@ -52,7 +52,7 @@ class PlaneGemmDesc(C.Structure):
 
 
 class AttnDesc(C.Structure):
-    _fields_ = [("mode", c_int), ("heads", c_int), ("ntasks", c_int),
+    _fields_ = [("mode", c_int), ("heads", c_int), ("ntasks", c_int), ("max_len", c_int),
                 ("tasks", c_vp), ("seq_len", c_vp), ("seq_row0", c_vp), ("pad_off", c_vp), ("ntok_pad", c_ll),
                 ("qkv", c_vp), ("qkv_plane", c_ll), ("qkv_ld", c_ll),
                 ("dO", c_vp), ("do_plane", c_ll), ("do_ld", c_ll),

@@ -659,7 +659,7 @@ def attn_mask(meta, p, seed, sid):
 def attn(meta, mode, qkv: Planes, dO, out, lse, delta, masks, scale, p, kbar=None, out_planes=None):
     """one fused attention pass (mode: lib.ATTN_FWD / ATTN_DQ / ATTN_DKV) over all (sequence, head) pairs of the packed batch"""
     d = AttnDesc()
-    d.mode, d.heads, d.ntasks = int(mode), meta.heads, meta.ntasks
+    d.mode, d.heads, d.ntasks, d.max_len = int(mode), meta.heads, meta.ntasks, meta.maxlen
     d.tasks, d.seq_len, d.seq_row0, d.pad_off, d.ntok_pad = P(meta.tasks), P(meta.lens), P(meta.seq_row0), P(meta.pad_off), meta.ntok_pad
     d.qkv, d.qkv_plane, d.qkv_ld = qkv.buf.data_ptr(), qkv.plane, qkv.ld
     if dO is not None:
