@@ -207,6 +207,68 @@ __global__ __launch_bounds__(256) void attn_kernel(const vbg_attn_desc p) {
             }
     };
 
+    // The same two products with element-wise work woven in by hand: `work(pi)` (pi = 0..7: the register pair 2 pi, 2 pi + 1 of the
+    // D layout) is issued behind every third MFMA, fenced so that the compiler keeps the order -- a 32 x 32 x 16 MFMA holds the matrix
+    // pipe for 32 clocks, ~25 VALU instructions of a pair fit behind three of them.  (hipcc's own schedule puts the ~200 VALU
+    // instructions of a tile in one block between the products; with one wave per SIMD nothing then overlaps the matrix pipe.)
+    // Fragments are read one group ahead.
+    auto sprod_woven = [&](const unsigned char* img, const at_u32x4 (&sb)[3][4], f32x16& acc, auto&& work) {
+        at_u32x4 fa[2][3];
+#pragma unroll
+        for (int q = 0; q < 3; ++q) fa[0][q] = *reinterpret_cast<const at_u32x4*>(img + q * AT_PL + fra[0]);
+#pragma unroll
+        for (int ks = 0; ks < 4; ++ks) {
+            if (ks + 1 < 4) {
+#pragma unroll
+                for (int q = 0; q < 3; ++q) fa[(ks + 1) & 1][q] = *reinterpret_cast<const at_u32x4*>(img + q * AT_PL + fra[ks + 1]);
+            }
+#pragma unroll
+            for (int hf = 0; hf < 2; ++hf) {
+#pragma unroll
+                for (int t = 3 * hf; t < 3 * hf + 3; ++t) acc = AT_MFMA(fa[ks & 1][qa[t]], sb[qb[t]][ks], acc);
+                __builtin_amdgcn_sched_barrier(0);
+                work(2 * ks + hf);
+                __builtin_amdgcn_sched_barrier(0);
+            }
+        }
+    };
+    auto tprod_woven = [&](const unsigned char* img, const at_u32x4 (&bp)[3][2], f32x16 (&acc)[2], auto&& work) {
+        typedef __attribute__((address_space(3))) unsigned char* lds_bytes;
+        lds_bytes im = (lds_bytes)img;
+        at_u32x4 fa[2][3];
+        auto rd = [&](int g, at_u32x4 (&f)[3]) {                       // group g = 2 ks + db
+            const int ks = g >> 1, db = g & 1;
+#pragma unroll
+            for (int q = 0; q < 3; ++q) {
+                const at_v4s lo = __builtin_amdgcn_ds_read_tr16_b64_v4i16((at_lds_v4s)(im + q * AT_PL + ks * 2048 + tra[0][db]));
+                const at_v4s hi = __builtin_amdgcn_ds_read_tr16_b64_v4i16((at_lds_v4s)(im + q * AT_PL + ks * 2048 + tra[1][db]));
+                const uint2 l2 = __builtin_bit_cast(uint2, lo), h2 = __builtin_bit_cast(uint2, hi);
+                f[q] = at_u32x4{l2.x, l2.y, h2.x, h2.y};
+            }
+        };
+        rd(0, fa[0]);
+#pragma unroll
+        for (int g = 0; g < 4; ++g) {
+            if (g + 1 < 4) rd(g + 1, fa[(g + 1) & 1]);
+#pragma unroll
+            for (int hf = 0; hf < 2; ++hf) {
+#pragma unroll
+                for (int t = 3 * hf; t < 3 * hf + 3; ++t) acc[g & 1] = AT_MFMA(fa[g & 1][qa[t]], bp[qb[t]][g >> 1], acc[g & 1]);
+                __builtin_amdgcn_sched_barrier(0);
+                work(2 * g + hf);
+                __builtin_amdgcn_sched_barrier(0);
+            }
+        }
+    };
+    // exact three-way split of the register pair (2 pi, 2 pi + 1) into its slot of the B-operand fragments (as at_split16)
+    auto split_pair = [&](float a, float b, int pi, at_u32x4 (&bp)[3][2]) {
+        const float ra = a - __uint_as_float(__float_as_uint(a) & 0xffff0000u), rb = b - __uint_as_float(__float_as_uint(b) & 0xffff0000u);
+        const float sa = ra - __uint_as_float(__float_as_uint(ra) & 0xffff0000u), sb2 = rb - __uint_as_float(__float_as_uint(rb) & 0xffff0000u);
+        bp[0][pi >> 2][pi & 3] = __builtin_amdgcn_perm(__float_as_uint(b), __float_as_uint(a), 0x07060302u);
+        bp[1][pi >> 2][pi & 3] = __builtin_amdgcn_perm(__float_as_uint(rb), __float_as_uint(ra), 0x07060302u);
+        bp[2][pi >> 2][pi & 3] = __builtin_amdgcn_perm(__float_as_uint(sb2), __float_as_uint(sa), 0x07060302u);
+    };
+
     f32x16 acc0[2], acc1[2];                     // FWD: O^T, Kbar^T; DQ: dQ^T; DKV: dK^T (acc0), dV^T (acc1)
 #pragma unroll
     for (int db = 0; db < 2; ++db)
@@ -317,18 +379,9 @@ __global__ __launch_bounds__(256) void attn_kernel(const vbg_attn_desc p) {
                 for (int r = 0; r < 16; ++r) dp[r] = 0.f;
                 float pr[16], ds[16];
                 if constexpr (DQ) {
-                    // the probabilities only need S: their VALU work is issued into the gaps of the dP product's MFMAs
-                    __builtin_amdgcn_sched_barrier(0);
 #pragma unroll
                     for (int r = 0; r < 16; ++r) pr[r] = __expf(s[r] * scale - m_own) * il_own;
                     sprod(im1, st[1], dp);
-#pragma unroll
-                    for (int g = 0; g < 24; ++g) {
-                        __builtin_amdgcn_sched_group_barrier(0x008, 1, 0);
-                        if (g < 12) __builtin_amdgcn_sched_group_barrier(0x100, 1, 0);
-                        __builtin_amdgcn_sched_group_barrier(0x002, 3, 0);
-                    }
-                    __builtin_amdgcn_sched_barrier(0);
 #pragma unroll
                     for (int r = 0; r < 16; ++r) {
                         float g = dp[r];
@@ -342,42 +395,31 @@ __global__ __launch_bounds__(256) void attn_kernel(const vbg_attn_desc p) {
                 } else {
                     // statistics of the streamed queries: register r = query 8 (r >> 2) + 4 lh + (r & 3) of the tile (loaded an
                     // iteration ahead: a use of a fresh global load in here would drain the tile DMA in flight)
-                    // Phase A: P, its dropped / scaled form and the split of that only need S -> issued into the gaps of the dP product.
+                    // Phase A: P, its dropped / scaled form and the split of that only need S -> woven into the dP product.
                     float pv[16];
                     at_u32x4 bpv[3][2], bpk[3][2];
-                    __builtin_amdgcn_sched_barrier(0);
+                    sprod_woven(im1, st[1], dp, [&](int pi) {
 #pragma unroll
-                    for (int r = 0; r < 16; ++r) {
-                        pv[r] = __expf(s[r] * scale - cst[0][r]) * cst[1][r];
-                        float pd = pv[r];
-                        if constexpr (DROP) pd = ((mw >> ((r & 3) + 8 * (r >> 2))) & 1u) ? pv[r] * keep_scale : 0.f;
-                        pr[r] = pd;
-                    }
-                    at_split16(pr, bpv);
-                    sprod(im1, st[1], dp);
+                        for (int e = 0; e < 2; ++e) {
+                            const int r = 2 * pi + e;
+                            pv[r] = __expf(s[r] * scale - cst[0][r]) * cst[1][r];
+                            float pd = pv[r];
+                            if constexpr (DROP) pd = ((mw >> ((r & 3) + 8 * (r >> 2))) & 1u) ? pv[r] * keep_scale : 0.f;
+                            pr[r] = pd;
+                        }
+                        split_pair(pr[2 * pi], pr[2 * pi + 1], pi, bpv);
+                    });
+                    // Phase B: dS and its split need dP -> woven into the dV product
+                    tprod_woven(im1, bpv, acc1, [&](int pi) {                                 // dV^T += dO^T Pd
 #pragma unroll
-                    for (int g = 0; g < 24; ++g) {
-                        __builtin_amdgcn_sched_group_barrier(0x008, 1, 0);
-                        if (g < 12) __builtin_amdgcn_sched_group_barrier(0x100, 1, 0);
-                        __builtin_amdgcn_sched_group_barrier(0x002, 8, 0);
-                    }
-                    __builtin_amdgcn_sched_barrier(0);
-                    // Phase B: dS and its split need dP -> issued into the gaps of the dV product
-#pragma unroll
-                    for (int r = 0; r < 16; ++r) {
-                        float g = dp[r];
-                        if constexpr (DROP) g = ((mw >> ((r & 3) + 8 * (r >> 2))) & 1u) ? g * keep_scale : 0.f;
-                        ds[r] = pv[r] * (g - cst[2][r]);
-                    }
-                    at_split16(ds, bpk);
-                    tprod(im1, bpv, acc1);                                 // dV^T += dO^T Pd
-#pragma unroll
-                    for (int g = 0; g < 24; ++g) {
-                        __builtin_amdgcn_sched_group_barrier(0x008, 1, 0);
-                        __builtin_amdgcn_sched_group_barrier(0x100, 1, 0);
-                        __builtin_amdgcn_sched_group_barrier(0x002, 7, 0);
-                    }
-                    __builtin_amdgcn_sched_barrier(0);
+                        for (int e = 0; e < 2; ++e) {
+                            const int r = 2 * pi + e;
+                            float g = dp[r];
+                            if constexpr (DROP) g = ((mw >> ((r & 3) + 8 * (r >> 2))) & 1u) ? g * keep_scale : 0.f;
+                            ds[r] = pv[r] * (g - cst[2][r]);
+                        }
+                        split_pair(ds[2 * pi], ds[2 * pi + 1], pi, bpk);
+                    });
                     tprod(im0, bpk, acc0);                                 // dK^T += Q^T dS
                 }
             }
