@@ -61,7 +61,7 @@ __device__ __forceinline__ void at_split16(const float (&x)[16], at_u32x4 (&bp)[
 #define AT_MFMA(a, b, c) __builtin_amdgcn_mfma_f32_32x32x16_bf16(__builtin_bit_cast(at_bf16x8, a), __builtin_bit_cast(at_bf16x8, b), c, 0, 0, 0)
 
 template <int MODE, bool DROP>
-__global__ __launch_bounds__(256) void attn_kernel(const vbg_attn_desc p) {
+__global__ __launch_bounds__(256, 2) void attn_kernel(const vbg_attn_desc p) {
     constexpr bool FWD = MODE == VBG_ATTN_FWD, DQ = MODE == VBG_ATTN_DQ, DKV = MODE == VBG_ATTN_DKV;
     constexpr int NS = FWD ? 1 : 2;                                   // stationary operands
     // behind the two tile stages: the dropout keep words of the workgroup's own rows (128 rows x 16 tiles) and, DKV, the statistics
@@ -311,16 +311,8 @@ __global__ __launch_bounds__(256) void attn_kernel(const vbg_attn_desc p) {
         const int stage = t & 1;
         if (t + 1 < nt) issue(stage ^ 1, t + 1);
         if constexpr (DROP) mword = mlds[t];                               // (rows past the padded length are never stored)
-        float cst[3][16];
-        if constexpr (DKV) {
-#pragma unroll
-            for (int a = 0; a < 3; ++a)
-#pragma unroll
-                for (int j = 0; j < 4; ++j) {
-                    const float4 v = *reinterpret_cast<const float4*>(slds + a * 512 + t * 32 + 8 * j + 4 * lh);
-                    cst[a][4 * j] = v.x; cst[a][4 * j + 1] = v.y; cst[a][4 * j + 2] = v.z; cst[a][4 * j + 3] = v.w;
-                }
-        }
+        // (DKV: the statistics of the streamed queries are read from LDS where they are used -- 48 registers less)
+        const float* const stile = slds + t * 32 + 4 * lh;
         if (active) {
             const unsigned char* im0 = smem + stage * AT_STAGE;
             const unsigned char* im1 = im0 + AT_OP;
@@ -399,26 +391,31 @@ __global__ __launch_bounds__(256) void attn_kernel(const vbg_attn_desc p) {
                     float pv[16];
                     at_u32x4 bpv[3][2], bpk[3][2];
                     sprod_woven(im1, st[1], dp, [&](int pi) {
+                        // registers 2 pi, 2 pi + 1 = queries 8 (pi >> 1) + 2 (pi & 1) (+ 1) of this half-wave's rows
+                        const float2 mq = *reinterpret_cast<const float2*>(stile + 8 * (pi >> 1) + 2 * (pi & 1));
+                        const float2 iq = *reinterpret_cast<const float2*>(stile + 512 + 8 * (pi >> 1) + 2 * (pi & 1));
+                        float pd[2];
 #pragma unroll
                         for (int e = 0; e < 2; ++e) {
                             const int r = 2 * pi + e;
-                            pv[r] = __expf(s[r] * scale - cst[0][r]) * cst[1][r];
-                            float pd = pv[r];
-                            if constexpr (DROP) pd = ((mw >> ((r & 3) + 8 * (r >> 2))) & 1u) ? pv[r] * keep_scale : 0.f;
-                            pr[r] = pd;
+                            pv[r] = __expf(s[r] * scale - (e ? mq.y : mq.x)) * (e ? iq.y : iq.x);
+                            pd[e] = pv[r];
+                            if constexpr (DROP) pd[e] = ((mw >> ((r & 3) + 8 * (r >> 2))) & 1u) ? pv[r] * keep_scale : 0.f;
                         }
-                        split_pair(pr[2 * pi], pr[2 * pi + 1], pi, bpv);
+                        split_pair(pd[0], pd[1], pi, bpv);
                     });
                     // Phase B: dS and its split need dP -> woven into the dV product
                     tprod_woven(im1, bpv, acc1, [&](int pi) {                                 // dV^T += dO^T Pd
+                        const float2 dq = *reinterpret_cast<const float2*>(stile + 1024 + 8 * (pi >> 1) + 2 * (pi & 1));
+                        float dsv[2];
 #pragma unroll
                         for (int e = 0; e < 2; ++e) {
                             const int r = 2 * pi + e;
                             float g = dp[r];
                             if constexpr (DROP) g = ((mw >> ((r & 3) + 8 * (r >> 2))) & 1u) ? g * keep_scale : 0.f;
-                            ds[r] = pv[r] * (g - cst[2][r]);
+                            dsv[e] = pv[r] * (g - (e ? dq.y : dq.x));
                         }
-                        split_pair(ds[2 * pi], ds[2 * pi + 1], pi, bpk);
+                        split_pair(dsv[0], dsv[1], pi, bpk);
                     });
                     tprod(im0, bpk, acc0);                                 // dK^T += Q^T dS
                 }
