@@ -160,7 +160,13 @@ def main():
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
         # VBG_DIST_BACKEND=gloo lets two ranks share ONE GPU for functional validation of the N>1 path
         dist.init_process_group(os.environ.get("VBG_DIST_BACKEND", "nccl"), rank=rank, world_size=world)
-        cpu_pg = dist.new_group(backend="gloo")      # host-side agreement on per-step decisions (gradient clipping)
+        # host-side agreement on per-step decisions (gradient clipping): a gloo group over the loopback interface (single node)
+        os.environ.setdefault("GLOO_SOCKET_IFNAME", "lo")
+        try:
+            cpu_pg = dist.new_group(backend="gloo")
+        except Exception as e:          # no host-side group: every rank decides on its own loss, like the reference loop
+            cpu_pg = None
+            print(f"[bench] gloo side group unavailable ({type(e).__name__}: {e}); clipping decided per rank", file=sys.stderr, flush=True)
     assert world == args.gpus, f"--gpus {args.gpus} but WORLD_SIZE={world} (launch with torch.distributed.run)"
 
     from vbg import ops
@@ -223,7 +229,7 @@ def main():
         if not args.sync_loss:
             val = val.get()
         clip = val > 10
-        if world > 1:
+        if world > 1 and cpu_pg is not None:
             # the reference decides on the LOCAL loss (pipeline/train_val_utils.py:280-281); ranks that decide differently scale the same
             # all-reduced gradient differently and their parameters drift apart.  Agree on the decision (any rank over the threshold)
             # through a host-side gloo group: the GPU queue is not touched.
