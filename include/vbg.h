@@ -166,11 +166,11 @@ int vbg_split_planes_t_batched(const float* src, unsigned short* dst, const long
  * [seq_row0[s], seq_row0[s] + seq_len[s]); tasks = int32 [ntasks][2] = (sequence, 128-row block) pairs; grid = ntasks x heads.
  *   mode FWD: out = O [ntok][ldo] (columns head * 64 ..); lse [2][heads][ntok_pad]: [0][head][pad_off[s] + row] = maximum m of the scaled
  *             scores of the row, [1][..] = 1 / sum exp(x - m) (the two numbers the row was normalised with; the backward modes read them);
- *   mode DQ : out = dqkv [ntok][ldo]: columns [0, hid) <- dQ; REPLACES delta (from vbg_attn_delta: rowsum(dO o O)) by the rows' own
- *             sum_k P_k dP_k and corrects dQ for the difference with kbar;
+ *   mode DQ : out = dqkv [ntok][ldo]: columns [0, hid) <- dQ; forms delta = rowsum(dO o O) from the dO planes and `o`, WRITES the rows' own
+ *             sum_k P_k dP_k into `delta` (zero in the padding rows on entry) and corrects dQ for the difference with kbar;
  *   mode DKV: columns [hid, 3 hid) <- dK, dV; run it after DQ.
  * delta: fp32 [heads][ntok_pad]; pad_off[s] a multiple of 32 with room for roundup(seq_len, 32) rows, rows past a
- * sequence's length ZERO (delta from vbg_attn_delta).  Dropout: mask_q / mask_k from vbg_attn_mask (NULL = none), keep_scale =
+ * sequence's length ZERO.  Dropout: mask_q / mask_k from vbg_attn_mask (NULL = none), keep_scale =
  * 65536 / (65536 - vbg_attn_drop_thr16(p)); mask_off[s] = first word of sequence s (heads * roundup(len,32) * ceil(len/32) words). */
 enum { VBG_ATTN_FWD = 0, VBG_ATTN_DQ = 1, VBG_ATTN_DKV = 2 };
 typedef struct vbg_attn_desc {
@@ -182,13 +182,11 @@ typedef struct vbg_attn_desc {
     float* lse; float* delta;
     unsigned short* out_planes; long long op_plane, op_ld;   /* FWD, optional: the three bf16 planes [3][ntok][op_ld] of O */
     float* kbar; long long ldk;     /* [ntok][ldk]: FWD writes sum_k P_k K_k (bf16 precision; NULL = skip), DQ reads it */
+    const float* o;                 /* DQ: the forward's O as fp32 [ntok][ldk] (delta = rowsum(dO o O) is formed in the kernel) */
     const unsigned* mask_q; const unsigned* mask_k; const long long* mask_off;
     float scale, keep_scale;
 } vbg_attn_desc;
 int vbg_attn(const vbg_attn_desc* desc, void* stream);
-/* delta[head * ntok_pad + tok_pad[t]] = sum_d dO[t][head*64 + d] * O[t][head*64 + d] (row sums of P o dP of the softmax backward) */
-int vbg_attn_delta(const float* dO, const float* O, long long ld, int ntok, int heads, const int* tok_pad, long long ntok_pad,
-                   float* delta, void* stream);
 /* dropout keeps of one layer and step, both orientations (torch.nn.Dropout(attention_probs_dropout_prob) on the probabilities):
  * keep <=> a 16-bit slice of the counter hash >= thr16 = round(p * 65536), i.e. drop rate thr16 / 65536 */
 unsigned vbg_attn_drop_thr16(float drop_p);

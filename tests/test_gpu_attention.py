@@ -54,9 +54,9 @@ def _run(seq_len, heads, p, seed=0):
     opl = ops.planes_empty(ntok, hid, dev)
     ops.attn(meta, ATTN_FWD, pq, None, O, lse, None, masks, scale, p, kbar=kbar, out_planes=opl)
     assert torch.equal(opl.buf, ops.split_planes(O).buf), "planes of O written by the forward kernel != split(O)"
-    delta = ops.attn_delta(dO.to(dev), O, meta, torch.zeros_like(lse[0]))
+    delta = torch.zeros_like(lse[0])
     dqkv = torch.full((ntok, 3 * hid), float("nan"), device=dev)
-    ops.attn(meta, ATTN_DQ, pq, pdo, dqkv, lse, delta, masks, scale, p, kbar=kbar)
+    ops.attn(meta, ATTN_DQ, pq, pdo, dqkv, lse, delta, masks, scale, p, kbar=kbar, o=O)
     ops.attn(meta, ATTN_DKV, pq, pdo, dqkv, lse, delta, masks, scale, p)
     torch.cuda.synchronize()
     # ---- reference: fp64, per (sequence, head) --------------------------------------------------------------------

@@ -24,11 +24,8 @@ for p in (0.1, 0.0):
     dqkv = torch.zeros(ntok, 3 * hid, device=dev)
     f = lambda: ops.attn(meta, ATTN_FWD, pq, None, O, lse, None, masks, 0.125, p, kbar=kbar, out_planes=opl)
     f()
-    delta = ops.attn_delta(torch.randn(ntok, hid, device=dev), O, meta, torch.zeros_like(lse[0]))
-    d0 = delta.clone()
-    def dq():
-        delta.copy_(d0)
-        ops.attn(meta, ATTN_DQ, pq, pdo, dqkv, lse, delta, masks, 0.125, p, kbar=kbar)
+    delta = torch.zeros_like(lse[0])
+    dq = lambda: ops.attn(meta, ATTN_DQ, pq, pdo, dqkv, lse, delta, masks, 0.125, p, kbar=kbar, o=O)
     dkv = lambda: ops.attn(meta, ATTN_DKV, pq, pdo, dqkv, lse, delta, masks, 0.125, p)
     tf, tq, tk = timed(f), timed(dq), timed(dkv)
     fl = 8 * heads * 4.0 * 512 * 512 * 64

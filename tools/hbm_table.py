@@ -60,7 +60,6 @@ bytes_per_step = {
     "attn_kernel<1": 12 * (NTOK * 2304 * 6 + NTOK * HID * (6 + 4 + 4)),
     "attn_kernel<2": 12 * (NTOK * 2304 * 6 + NTOK * HID * (6 + 8)),
     "attn_mask_kernel": 12 * 2 * 12 * 8 * 512 * 16 * 4,
-    "attn_delta_kernel": 12 * 2 * tok,
 }
 
 

@@ -11,7 +11,8 @@
 // rows (LDS-DMA, two stages):
 //   FWD : own = queries, stream = (K, V).  S^T = K Q^T (lane = query, registers = keys: the softmax statistics are lane-local),
 //         online softmax, O^T += V^T Pd^T (V^T fragments by ds_read_b64_tr_b16).  Writes O and the row statistics (m, 1 / l).
-//   DQ  : own = queries, stream = (K, V).  P^T = exp(S^T - m) / l, dP^T = V dO^T, dS^T = P^T o (dP^T - delta), dQ^T += K^T dS^T.
+//   DQ  : own = queries, stream = (K, V).  delta = rowsum(dO o O) in the prologue; P^T = exp(S^T - m) / l, dP^T = V dO^T,
+//         dS^T = P^T o (dP^T - delta), dQ^T += K^T dS^T; writes the rows' own sum P dP as the delta of the DKV pass.
 //   DKV : own = keys,    stream = (Q, dO). P = exp(S - m) / l (lane = key, registers = queries), dP = dO V^T,
 //         dV^T += dO^T Pd, dK^T += Q^T dS.
 // (Two backward kernels recompute S and dP once each instead of exchanging dS through LDS or accumulating dQ with atomics: seven
@@ -281,7 +282,27 @@ __global__ __launch_bounds__(256, 2) void attn_kernel(const vbg_attn_desc p) {
     const long long lsplane = (long long)p.heads * p.ntok_pad;
     float m_own = 0.f, il_own = 0.f, del_own = 0.f;          // DQ: per own query
     if constexpr (DQ) {
-        if (own0 + lr < L) { m_own = p.lse[lsoff + own0 + lr]; il_own = p.lse[lsplane + lsoff + own0 + lr]; del_own = p.delta[lsoff + own0 + lr]; }
+        if (own0 + lr < L) {
+            m_own = p.lse[lsoff + own0 + lr];
+            il_own = p.lse[lsplane + lsoff + own0 + lr];
+            // delta = sum_d dO[q][d] O[q][d] of this head: dO is rebuilt exactly from its three planes (the stationary fragments: this
+            // lane holds columns 16 ks + 8 lh .. + 7 of its row), O is read as fp32; the two half-waves of a row add up below
+            const float* orow = p.o + (long long)(row0 + own0 + lr) * p.ldk + head * 64 + 8 * lh;
+#pragma unroll
+            for (int ks = 0; ks < 4; ++ks) {
+                const float4 o0 = *reinterpret_cast<const float4*>(orow + 16 * ks), o1 = *reinterpret_cast<const float4*>(orow + 16 * ks + 4);
+                const float ov[8] = {o0.x, o0.y, o0.z, o0.w, o1.x, o1.y, o1.z, o1.w};
+#pragma unroll
+                for (int j = 0; j < 4; ++j) {
+                    const unsigned h = st[1][0][ks][j], m = st[1][1][ks][j], l = st[1][2][ks][j];
+                    const float lo_e = (__uint_as_float(h << 16) + __uint_as_float(m << 16)) + __uint_as_float(l << 16);
+                    const float hi_e = (__uint_as_float(h & 0xffff0000u) + __uint_as_float(m & 0xffff0000u)) + __uint_as_float(l & 0xffff0000u);
+                    del_own = fmaf(lo_e, ov[2 * j], del_own);
+                    del_own = fmaf(hi_e, ov[2 * j + 1], del_own);
+                }
+            }
+        }
+        del_own += __shfl_xor(del_own, 32, 64);
     }
     const float scale = p.scale, keep_scale = p.keep_scale;
     const bool want_kbar = FWD && p.kbar != nullptr;
@@ -488,18 +509,6 @@ __global__ __launch_bounds__(256, 2) void attn_kernel(const vbg_attn_desc p) {
     }
 }
 
-// delta[head][pad(tok)] = sum_d dO[tok][head*64 + d] * O[tok][head*64 + d]  (= sum_k P dP of the softmax backward); one wave per token
-__global__ __launch_bounds__(256) void attn_delta_kernel(const float* __restrict__ dO, const float* __restrict__ O, long long ld, int ntok,
-                                                         int heads, const int* __restrict__ tok_pad, long long ntok_pad, float* __restrict__ delta) {
-    const int tok = blockIdx.x * 4 + (threadIdx.x >> 6), lane = threadIdx.x & 63;
-    if (tok >= ntok) return;
-    const int pp = tok_pad[tok];
-    for (int h = 0; h < heads; ++h) {
-        const float v = wave_sum(dO[(long long)tok * ld + h * 64 + lane] * O[(long long)tok * ld + h * 64 + lane]);
-        if (lane == 0) delta[(long long)h * ntok_pad + pp] = v;
-    }
-}
-
 // dropout keeps of one layer: for group g = (seq, head), query q, 32-key block kb: mask_q[off + q * nkb + kb] bit j = keep of key
 // 32 kb + j; the same bits transposed: mask_k[off + key * nkb + qb] bit i = keep of query 32 qb + i.  A wave = one 32-query block x
 // two 32-key blocks; draws are 16-bit slices of the counter hash (rng_u32's 64-bit state), keep <=> draw >= thr16.
@@ -551,7 +560,7 @@ extern "C" int vbg_attn(const vbg_attn_desc* desc, void* stream) {
     if (d.mode != VBG_ATTN_FWD) {
         VBG_CHECK_ARG(d.dO && d.delta && d.do_ld % 8 == 0 && ((uintptr_t)d.dO & 15) == 0 && d.do_plane % 8 == 0 && 6 * d.do_plane < 0x7fffffffll);
         VBG_CHECK_ARG(((uintptr_t)d.delta & 15) == 0);
-        if (d.mode == VBG_ATTN_DQ) VBG_CHECK_ARG(d.kbar != nullptr);
+        if (d.mode == VBG_ATTN_DQ) VBG_CHECK_ARG(d.kbar != nullptr && d.o != nullptr && ((uintptr_t)d.o & 15) == 0);
     }
     VBG_CHECK_ARG(d.max_len >= 1 && d.max_len <= 512);          // (16 tiles of 32 rows: the size of the staged mask / statistic tables)
     const bool drop = d.mask_q != nullptr;
@@ -568,15 +577,6 @@ extern "C" int vbg_attn(const vbg_attn_desc* desc, void* stream) {
     else if (d.mode == VBG_ATTN_DQ) AT_GO(VBG_ATTN_DQ);
     else AT_GO(VBG_ATTN_DKV);
 #undef AT_GO
-    VBG_LAUNCH_RET();
-}
-
-extern "C" int vbg_attn_delta(const float* dO, const float* O, long long ld, int ntok, int heads, const int* tok_pad, long long ntok_pad,
-                              float* delta, void* stream) {
-    VBG_CHECK_ARG(ntok >= 0 && heads > 0);
-    if (ntok == 0) return VBG_OK;
-    VBG_CHECK_ARG(dO && O && tok_pad && delta && ld >= (long long)heads * 64);
-    VBG_LAUNCH(attn_delta_kernel, dim3(cdiv(ntok, 4)), dim3(256), 0, (hipStream_t)stream, dO, O, ld, ntok, heads, tok_pad, ntok_pad, delta);
     VBG_LAUNCH_RET();
 }
 

@@ -607,6 +607,7 @@ class BertLayerFn(torch.autograd.Function):
         if py is None:
             return y, None
         ctx.mark_non_differentiable(py.buf)
+        ctx.set_materialize_grads(False)       # (no zero tensor for the planes output's gradient slot: 19 MB fill per layer)
         return y, py.buf
 
     @staticmethod
@@ -661,10 +662,10 @@ class BertLayerFn(torch.autograd.Function):
             # fused attention backward: delta = rowsum(dO o O), then dQ (queries stationary) and dK / dV (keys stationary), each
             # recomputing its score tile from the q / k / v planes and the saved log-sum-exp
             pqkv = ops.Planes(bqkv, ntok, 3 * hid, bqkv.shape[2])
-            delta = ops.attn_delta(dctx, ctxv, meta, ctx.delta_buf)
+            delta = ctx.delta_buf                      # zero in the padding rows; the DQ pass fills it
             dqkv = torch.empty((ntok, 3 * hid), device=dev, dtype=f32)
             sc = 1.0 / (dh ** 0.5)
-            ops.attn(meta, ATTN_DQ, pqkv, pdctx, dqkv, lse, delta, ctx.masks, sc, p, kbar=kbar)
+            ops.attn(meta, ATTN_DQ, pqkv, pdctx, dqkv, lse, delta, ctx.masks, sc, p, kbar=kbar, o=ctxv)
             ops.attn(meta, ATTN_DKV, pqkv, pdctx, dqkv, lse, delta, ctx.masks, sc, p)
         else:
             dP = torch.empty_like(P)

@@ -56,7 +56,7 @@ class AttnDesc(C.Structure):
                 ("tasks", c_vp), ("seq_len", c_vp), ("seq_row0", c_vp), ("pad_off", c_vp), ("ntok_pad", c_ll),
                 ("qkv", c_vp), ("qkv_plane", c_ll), ("qkv_ld", c_ll),
                 ("dO", c_vp), ("do_plane", c_ll), ("do_ld", c_ll),
-                ("out", c_vp), ("ldo", c_ll), ("lse", c_vp), ("delta", c_vp), ("out_planes", c_vp), ("op_plane", c_ll), ("op_ld", c_ll), ("kbar", c_vp), ("ldk", c_ll),
+                ("out", c_vp), ("ldo", c_ll), ("lse", c_vp), ("delta", c_vp), ("out_planes", c_vp), ("op_plane", c_ll), ("op_ld", c_ll), ("kbar", c_vp), ("ldk", c_ll), ("o", c_vp),
                 ("mask_q", c_vp), ("mask_k", c_vp), ("mask_off", c_vp),
                 ("scale", c_f), ("keep_scale", c_f)]
 
@@ -79,7 +79,6 @@ SIGNATURES = {
     "vbg_split_planes_t": (c_int, [c_vp, c_ll, c_int, c_int, c_vp, c_int, c_ll, c_vp]),
     "vbg_split_planes_t_batched": (c_int, [c_vp, c_vp, c_vp, c_int, c_int, c_ll, c_vp]),
     "vbg_attn": (c_int, [C.POINTER(AttnDesc), c_vp]),
-    "vbg_attn_delta": (c_int, [c_vp, c_vp, c_ll, c_int, c_int, c_vp, c_ll, c_vp, c_vp]),
     "vbg_attn_drop_thr16": (C.c_uint, [c_f]),
     "vbg_attn_mask": (c_int, [c_vp, c_vp, c_int, c_int, c_int, c_f, c_ull, c_ull, c_vp, c_vp, c_vp]),
     "vbg_colsum": (c_int, [c_vp, c_ll, c_int, c_int, c_vp, c_int, c_vp]),

@@ -656,7 +656,7 @@ def attn_mask(meta, p, seed, sid):
     return mq, mk
 
 
-def attn(meta, mode, qkv: Planes, dO, out, lse, delta, masks, scale, p, kbar=None, out_planes=None):
+def attn(meta, mode, qkv: Planes, dO, out, lse, delta, masks, scale, p, kbar=None, out_planes=None, o=None):
     """one fused attention pass (mode: lib.ATTN_FWD / ATTN_DQ / ATTN_DKV) over all (sequence, head) pairs of the packed batch"""
     d = AttnDesc()
     d.mode, d.heads, d.ntasks, d.max_len = int(mode), meta.heads, meta.ntasks, meta.maxlen
@@ -669,6 +669,9 @@ def attn(meta, mode, qkv: Planes, dO, out, lse, delta, masks, scale, p, kbar=Non
     d.delta = None if delta is None else delta.data_ptr()
     if kbar is not None:
         d.kbar, d.ldk = kbar.data_ptr(), kbar.stride(0)
+    if o is not None:                     # DQ: the forward's O (same row stride as kbar)
+        assert kbar is not None and o.stride(0) == kbar.stride(0)
+        d.o = o.data_ptr()
     if out_planes is not None:            # FWD: the planes of O ride along (the A operand of the output projection)
         d.out_planes, d.op_plane, d.op_ld = out_planes.buf.data_ptr(), out_planes.plane, out_planes.ld
     if masks is not None:
@@ -679,12 +682,6 @@ def attn(meta, mode, qkv: Planes, dO, out, lse, delta, masks, scale, p, kbar=Non
     d.scale = float(scale)
     check(lib.vbg_attn(C.byref(d), _stream()), "vbg_attn")
     return out
-
-
-def attn_delta(dO, O, meta, delta):
-    ntok = dO.shape[0]
-    check(lib.vbg_attn_delta(P(dO), P(O), dO.stride(0), ntok, meta.heads, P(meta.tok_pad), meta.ntok_pad, P(delta), _stream()), "vbg_attn_delta")
-    return delta
 
 
 def row_softmax(x):
