@@ -139,6 +139,9 @@ typedef struct vbg_plane_gemm_desc {
        The workspace must not be shared by launches that may run concurrently.  NULL = plain rounds. */
     float* sk_ws; int* sk_cnt; int sk_blocks;
     int sk_full, sk_tiles_m, sk_tiles_n;                         /* filled by the library */
+    /* optional: colsum[n] += sum_m (stored value)[m][n] (atomics, one per column and row tile): the bias gradient of the layer whose
+       output gradient this product produces (NT, no split-K / groups / accumulate / GELU-dual / stream-K / 256256 tile) */
+    float* colsum;
 } vbg_plane_gemm_desc;
 int vbg_plane_gemm(const vbg_plane_gemm_desc* desc, void* stream);
 int vbg_plane_gemm_timed(const vbg_plane_gemm_desc* desc, void* stream, void* start_event, void* stop_event);

@@ -956,6 +956,13 @@ def test_plane_gemm_nt_vs_fp64(tile):
         assert torch.equal(h, out)
         assert float((gl.double() - torch.nn.functional.gelu(out.double())).abs().max()) <= 1e-5 * max(1.0, float(out.abs().max()))
         assert torch.equal(pg.buf[:, :, :N], ops.split_planes(gl).buf[:, :, :N])
+        # column sums of the stored values ride in the epilogue (a bias gradient): planes only, no fp32 output
+        if tile != 256256:
+            cs = torch.full((N,), 2.0, device=dev)
+            pl = ops.planes_empty(M, N, dev)
+            ops.plane_gemm(pa, pb, None, bias=bias, out_planes=pl, colsum_out=cs, tile=tile)
+            assert torch.equal(pl.buf[:, :, :N], ops.split_planes(out).buf[:, :, :N])
+            assert torch.allclose(cs.double() - 2.0, out.double().sum(0), rtol=1e-5, atol=2e-6 * scale * M ** 0.5)
         # GELU backward in the epilogue: stored value = product * gelu'(h), h an input in C2 (== vbg_gelu_bwd on the plain product)
         from vbg.lib import EPI_MUL_GELU_GRAD
         hh = (torch.randn(M, N, generator=g) * 2).to(dev)

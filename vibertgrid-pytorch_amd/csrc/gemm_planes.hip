@@ -379,6 +379,7 @@ __global__ __launch_bounds__(WGM * WGN * 64) void plane_gemm_kernel(const vbg_pl
             v.x *= gelu_erf_grad(hv.x); v.y *= gelu_erf_grad(hv.y); v.z *= gelu_erf_grad(hv.z); v.w *= gelu_erf_grad(hv.w);
         }
         if (C) *reinterpret_cast<float4*>(cp) = v;
+        if (p.colsum) *reinterpret_cast<float4*>(&Ct[row * CTS + c]) = v;      // (the stored value goes back for the column sums below)
         if (epi == VBG_EPI_GELU_DUAL) {
             v = make_float4(gelu_erf(v.x), gelu_erf(v.y), gelu_erf(v.z), gelu_erf(v.w));
             if (C2) *reinterpret_cast<float4*>(C2 + (long long)gm * ldc + gn) = v;
@@ -398,6 +399,17 @@ __global__ __launch_bounds__(WGM * WGN * 64) void plane_gemm_kernel(const vbg_pl
             *reinterpret_cast<uint2*>(o) = make_uint2(h[0] | ((unsigned)h[1] << 16), h[2] | ((unsigned)h[3] << 16));
             *reinterpret_cast<uint2*>(o + p.c_plane) = make_uint2(m[0] | ((unsigned)m[1] << 16), m[2] | ((unsigned)m[3] << 16));
             *reinterpret_cast<uint2*>(o + 2 * p.c_plane) = make_uint2(l[0] | ((unsigned)l[1] << 16), l[2] | ((unsigned)l[3] << 16));
+        }
+    }
+    // optional column sums of the stored values (the bias gradient of the layer whose dL/d(output) this product produces): one thread
+    // per column of the staged tile, one atomic per column and row tile (rows past M hold zeros: their operand rows were read as zeros)
+    if (p.colsum) {                                   // (uniform)
+        __syncthreads();
+        if (tid < BN && n0 + tid < N) {
+            float cs = 0.f;
+            const int rows = min(BM, M - m0);
+            for (int r = 0; r < rows; ++r) cs += Ct[r * CTS + tid];
+            unsafeAtomicAdd(p.colsum + n0 + tid, cs);
         }
     }
 }
@@ -1083,6 +1095,7 @@ static int plane_gemm_dispatch(const vbg_plane_gemm_desc* desc, void* stream, vo
     if (d.splitk < 1) d.splitk = 1;
     if (d.splitk > 1) VBG_CHECK_ARG(d.accumulate == 1 && d.C);
     if (d.accumulate) VBG_CHECK_ARG(d.epi == VBG_EPI_NONE && d.Cp == nullptr);
+    if (d.colsum) VBG_CHECK_ARG(d.splitk == 1 && d.ngroups == 0 && !d.trans && !d.accumulate && d.epi != VBG_EPI_GELU_DUAL && d.tile != 256256 && !(d.sk_ws && d.sk_cnt));
     if (d.epi == VBG_EPI_GELU_DUAL) VBG_CHECK_ARG(d.C2 != nullptr || d.Cp != nullptr);
     if (d.epi == VBG_EPI_MUL_GELU_GRAD) VBG_CHECK_ARG(d.C2 != nullptr && d.ngroups == 0 && !d.trans && !(d.sk_ws && d.sk_cnt));
     if (d.Cp) VBG_CHECK_ARG(d.ldp % 8 == 0 && d.ldp >= d.N && ((uintptr_t)d.Cp & 7) == 0 && d.c_plane % 4 == 0);

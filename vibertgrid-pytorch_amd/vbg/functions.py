@@ -640,9 +640,18 @@ class BertLayerFn(torch.autograd.Function):
             dg2, db2 = _affine_done(rg2, rb2, dg2, db2, sunk2)
             pdfo, dbo2 = _split_with_bias_grad(rbo2, dfo)
         # dL/dh = (dfo Wo2) o gelu'(h): the GELU backward rides in the product's epilogue
-        dh_ = ops.plane_gemm(pdfo, ops.weight_planes(ro2, True, view=wo2), torch.empty_like(h), epi=EPI_MUL_GELU_GRAD, C2=h,
-                             tile=ops._dense_tile(ntok, inter, True))
-        pdh, dbi = _split_with_bias_grad(rbi, dh_)
+        dst_bi = wgrad_dest(rbi)
+        if dst_bi is not None:
+            # ... and dL/dh leaves as planes only (it is only ever a plane operand), its column sums go into the bias gradient
+            pdh = ops.planes_empty(ntok, inter, dev)
+            ops.plane_gemm(pdfo, ops.weight_planes(ro2, True, view=wo2), None, epi=EPI_MUL_GELU_GRAD, C2=h, out_planes=pdh, colsum_out=dst_bi,
+                           tile=ops._dense_tile(ntok, inter, True))
+            wgrad_done(rbi)
+            dbi = None
+        else:
+            dh_ = ops.plane_gemm(pdfo, ops.weight_planes(ro2, True, view=wo2), torch.empty_like(h), epi=EPI_MUL_GELU_GRAD, C2=h,
+                                 tile=ops._dense_tile(ntok, inter, True))
+            pdh, dbi = _split_with_bias_grad(rbi, dh_)
         ops.plane_gemm(pdh, ops.weight_planes(ri, True, view=wi), dx1, accumulate=True, tile=ops._dense_tile(ntok, hid))
         dg1, db1, sunk1 = _affine_dest(rg1, rb1)
         dst = wgrad_dest(rbo)

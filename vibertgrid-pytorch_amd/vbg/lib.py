@@ -48,7 +48,8 @@ class PlaneGemmDesc(C.Structure):
                 ("Cp", c_vp), ("c_plane", c_ll), ("ldp", c_ll),
                 ("epi", c_int), ("alpha", c_f), ("accumulate", c_int), ("splitk", c_int), ("tile", c_int), ("trans", c_int),
                 ("ngroups", c_int), ("grp", PlaneGroup * 4),
-                ("sk_ws", c_vp), ("sk_cnt", c_vp), ("sk_blocks", c_int), ("sk_full", c_int), ("sk_tiles_m", c_int), ("sk_tiles_n", c_int)]
+                ("sk_ws", c_vp), ("sk_cnt", c_vp), ("sk_blocks", c_int), ("sk_full", c_int), ("sk_tiles_m", c_int), ("sk_tiles_n", c_int),
+                ("colsum", c_vp)]
 
 
 class AttnDesc(C.Structure):

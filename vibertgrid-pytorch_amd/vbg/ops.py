@@ -152,7 +152,7 @@ def split_planes_t(x, out=None):
 
 
 def plane_gemm(a: Planes, b: Planes, out=None, *, bias=None, epi=EPI_NONE, C2=None, accumulate=False, splitk=1, alpha=1.0, tile=0,
-               out_planes=None, ldc=None, trans=False):
+               out_planes=None, ldc=None, trans=False, colsum_out=None):
     """out[M, N] (+)= alpha * a[M, K] b[N, K]^T (+ bias).  out_planes: Planes [M, N] that receive the split of the stored value.
     trans: out[Ma, Nb] (+)= alpha * a[K, Ma]^T b[K, Nb] (the operands' ROWS are the reduction index: weight gradients)."""
     d = PlaneGemmDesc()
@@ -173,7 +173,9 @@ def plane_gemm(a: Planes, b: Planes, out=None, *, bias=None, epi=EPI_NONE, C2=No
     if out_planes is not None:
         d.Cp, d.c_plane, d.ldp = out_planes.buf.data_ptr(), out_planes.plane, out_planes.ld
     d.epi, d.alpha, d.accumulate, d.splitk, d.tile = epi, float(alpha), int(bool(accumulate)), int(splitk), int(tile)
-    if _STREAMK[0] and not trans and splitk == 1 and tile in (128129, 128130):
+    if colsum_out is not None:             # += column sums of the stored values (a bias gradient)
+        d.colsum = colsum_out.data_ptr()
+    if _STREAMK[0] and colsum_out is None and not trans and splitk == 1 and tile in (128129, 128130):
         ws, cnt, ncu = _sk_workspace(a.buf.device)
         d.sk_ws, d.sk_cnt, d.sk_blocks = ws.data_ptr(), cnt.data_ptr(), ncu
     prof = _GEMM_PROF
