@@ -192,6 +192,63 @@ def test_conv(ops, Cin, Cout, k, stride, pad, H, W):
     assert close(dw.permute(0, 3, 1, 2), w.grad, 1e-4, 2e-3)
 
 
+@pytest.mark.parametrize("B,H,W,Cs,N", [(2, 8, 128, 32, 128), (3, 4, 64, 48, 136), (2, 8, 32, 16, 256), (1, 128, 128, 64, 128)])
+def test_conv3x3_row_reuse(ops, B, H, W, Cs, N):
+    """csrc/conv3.hip (activation rows shared by the three horizontal taps) against fp64 torch conv2d: forward with bias and fused
+    BatchNorm statistics, accumulate, the input gradient through the turned filter; and against the generic implicit GEMM (same
+    piece products, other tap order: equal to fp32 rounding)."""
+    x = rnd(B, Cs, H, W, seed=60).requires_grad_(True)
+    w = (rnd(N, Cs, 3, 3, seed=61) / math.sqrt(Cs * 9)).requires_grad_(True)
+    b = rnd(N, seed=62)
+    y = F.conv2d(x.double(), w.double(), b.double(), 1, 1)
+    gy = rnd(*y.shape, seed=63)
+    y.backward(gy.double())
+    xh = x.detach().permute(0, 2, 3, 1).contiguous().to(dev())
+    wh = w.detach().permute(0, 2, 3, 1).contiguous().to(dev())
+    bh = b.to(dev())
+    stats = torch.zeros(ops.bn_slots() * 2 * N, device=dev(), dtype=torch.float64)
+    yh = ops.conv3x3(xh, wh, bh, stats=stats)
+    ref = y.float().permute(0, 2, 3, 1)
+    assert close(yh, ref, 2e-5, 2e-6)
+    st = stats.view(-1, 2, N).sum(0).cpu()
+    y2 = y.detach().permute(0, 2, 3, 1).reshape(-1, N)
+    assert torch.allclose(st[0], y2.sum(0), rtol=1e-5, atol=1e-4) and torch.allclose(st[1], (y2 * y2).sum(0), rtol=1e-5, atol=1e-4)
+    # generic kernel, same arithmetic form
+    ops.set_conv3(False)
+    try:
+        yg = ops.conv2d_fwd(xh, wh, 1, 1, bh)
+    finally:
+        ops.set_conv3(True)
+    assert close(yh, yg, 1e-5, 1e-5)
+    # accumulate
+    acc = yh.clone()
+    ops.conv3x3(xh, wh, None, out=acc, accumulate=True)
+    assert close(acc, 2 * ref - b.view(1, 1, 1, N), 2e-5, 1e-5)
+    # input gradient: the same kernel over dy with the turned filter
+    if N % 16 == 0 and Cs % 4 == 0:
+        gyh = gy.permute(0, 2, 3, 1).contiguous().to(dev())
+        wf = ops.conv3x3_wflip(wh)
+        assert torch.equal(wf.cpu(), w.detach().permute(1, 2, 3, 0).flip(1, 2).contiguous())
+        dx = ops.conv3x3(gyh, wf)
+        assert close(dx.permute(0, 3, 1, 2), x.grad.float(), 2e-5, 2e-6)
+
+
+def test_conv3x3_dispatch(ops):
+    """conv2d_fwd / conv2d_dgrad take the row-reuse kernel for a wide trunk shape and agree with the generic path"""
+    B, H, W, C = 2, 128, 128, 128
+    assert ops.conv3_ok(B, H, W, C, C, 3, 3, 1, 1) and not ops.conv3_ok(B, H, W, C, C, 3, 3, 2, 1) and not ops.conv3_ok(B, 16, 16, C, C, 3, 3, 1, 1)
+    xh = rnd(B, H, W, C, seed=64).to(dev())
+    wh = (rnd(C, 3, 3, C, seed=65) / 34).to(dev())
+    gy = rnd(B, H, W, C, seed=66).to(dev())
+    y1, dx1 = ops.conv2d_fwd(xh, wh, 1, 1), ops.conv2d_dgrad(gy, wh, tuple(xh.shape), 1, 1)
+    ops.set_conv3(False)
+    try:
+        y0, dx0 = ops.conv2d_fwd(xh, wh, 1, 1), ops.conv2d_dgrad(gy, wh, tuple(xh.shape), 1, 1)
+    finally:
+        ops.set_conv3(True)
+    assert close(y1, y0, 1e-5, 1e-5) and close(dx1, dx0, 1e-5, 1e-5)
+
+
 def test_stem_im2col(ops):
     B, H, W = 2, 20, 18
     x = rnd(B, 3, H, W, seed=33)

@@ -1,0 +1,32 @@
+#!/usr/bin/env python3
+"""Row-reuse 3x3 convolution (csrc/conv3.hip) against the generic implicit GEMM (csrc/gemm.hip) on the wide cfg2 shapes.
+   python tools/conv3_bench.py"""
+import os
+import sys
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+sys.path.insert(0, os.path.join(ROOT, "vibertgrid-pytorch_amd"))
+sys.path.insert(0, os.path.join(ROOT, "tools"))
+import torch
+
+from gemm_bench import report, timeit
+from vbg import ops
+
+dev = torch.device("cuda")
+for (B, H, W, Ci, Co) in [(8, 128, 128, 256, 256), (8, 128, 128, 128, 128), (8, 64, 64, 128, 128), (8, 64, 64, 256, 256), (16, 128, 128, 256, 256)]:
+    x = torch.randn(B, H, W, Ci, device=dev)
+    w = torch.randn(Co, 3, 3, Ci, device=dev) / (3 * Ci ** 0.5)
+    dy = torch.randn(B, H, W, Co, device=dev)
+    fl = 2.0 * B * H * W * Ci * Co * 9
+    tag = f"B{B} {H}x{W} {Ci}->{Co}"
+    for on in (False, True):
+        ops.set_conv3(on)
+        name = "conv3 " if on else "generic"
+        report(f"{name} fwd   {tag}", fl, timeit(lambda: ops.conv2d_fwd(x, w, 1, 1)))
+        report(f"{name} dgrad {tag}", fl, timeit(lambda: ops.conv2d_dgrad(dy, w, tuple(x.shape), 1, 1)))
+    ops.set_conv3(True)
+    y1 = ops.conv2d_fwd(x, w, 1, 1)
+    ops.set_conv3(False)
+    y0 = ops.conv2d_fwd(x, w, 1, 1)
+    ops.set_conv3(True)
+    print("   max |conv3 - generic| =", float((y1 - y0).abs().max()), " max |y| =", float(y0.abs().max()), flush=True)

@@ -24,6 +24,7 @@ from model.field_type_classification_head import (CRFFieldTypeClassification, Fi
 from model.grid_roi_align import GridROIAlign
 from model.ResNetFPN_ViBERTgrid import bn_tick_scope, resnet_18_D_fpn, resnet_18_fpn, resnet_34_D_fpn, resnet_34_fpn
 from model.semantic_segmentation_head import SemanticSegmentationClassifier, SimplifiedSemanticSegmentationClassifier
+from vbg import functions as Fn
 from vbg import ops
 from pipeline.custom_loss import PendingCounts, resolve_plans  # noqa: F401
 from pipeline.transform import GeneralizedViBERTgridTransform, ImageList  # noqa: F401  (ImageList re-exported like the reference)
@@ -196,8 +197,21 @@ class ViBERTgridNet(nn.Module):
         gen = self.BERTgrid_generator
         # the part of the CNN in front of the early fusion does not need the grid: enqueue it first, so the host-side packing of
         # the token windows / index tables of the encoder runs behind ~3 ms of device work instead of an idle device
-        pre = self.backbone.stage1(batch)
-        emb_cat, counts = gen._segment_embeddings(corpus, mask, seg_indices)
+        if ops.overlap_enabled() and batch.is_cuda:
+            # ... and the encoder goes on the side stream (vbg/ops.py): its workgroups and the CNN's fill each other's idle CUs.
+            # autograd runs every backward node on the stream of its forward, so the encoder's backward overlaps the backward of
+            # the CNN in front of the early fusion the same way; JoinSideFn brings the two streams together at the end of backward
+            main, side = torch.cuda.current_stream(batch.device), ops.side_stream(batch.device)
+            side.wait_stream(main)              # inputs / parameters written on the caller's stream so far
+            pre = self.backbone.stage1(batch)
+            with torch.cuda.stream(side):
+                emb_cat, counts = gen._segment_embeddings(corpus, mask, seg_indices)
+            main.wait_stream(side)
+            emb_cat.record_stream(main)
+            emb_cat = Fn.JoinSideFn.apply(emb_cat)
+        else:
+            pre = self.backbone.stage1(batch)
+            emb_cat, counts = gen._segment_embeddings(corpus, mask, seg_indices)
         boxes, box_off, box_doc = packed
         assert emb_cat.shape[0] == boxes.shape[0], "number of segment embeddings and boxes mismatch"
         grid = gen._scatter((H, W), emb_cat, boxes, box_off, box_doc, B, 0)

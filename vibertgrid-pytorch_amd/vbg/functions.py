@@ -705,7 +705,22 @@ class BertLayerFn(torch.autograd.Function):
             d_ = wgrad_dest(wp)
             fresh.append(d_ is None)
             dests.append(d_ if d_ is not None else torch.zeros_like(wp))
-        ops.plane_gemm_grouped([(pdfo, pg, dests[0]), (pdh, px1, dests[1]), (pdao, pctx, dests[2]), (pdqkv, px, dw_qkv)], trans=True, accumulate=True)
+        jobs = [(pdfo, pg, dests[0]), (pdh, px1, dests[1]), (pdao, pctx, dests[2]), (pdqkv, px, dw_qkv)]
+        if qkv_sunk and not any(fresh) and ops.wgrad_stream_enabled():
+            # every destination is a flat gradient buffer nothing else in this backward touches: the launch goes on the
+            # weight-gradient stream and shares the chip with the backward of the layer below.  The operands stay reserved for
+            # that stream when this node releases them; JoinSideFn's callback / FlatReducer's staging stream wait for it.
+            cur, ws = torch.cuda.current_stream(dev), ops.side_stream(dev, "wgrad")
+            ws.wait_stream(cur)
+            with torch.cuda.stream(ws):
+                ops.plane_gemm_grouped(jobs, trans=True, accumulate=True)
+                for a_, b_, _ in jobs:
+                    a_.buf.record_stream(ws)
+                    b_.buf.record_stream(ws)
+                for t in (ro2, ri, ro, rq, rk, rv, rbq, rbk, rbv):
+                    wgrad_done(t)
+            return (dx, None, None, None, None, None, None, None, None, dbo, dg1, db1, None, dbi, None, dbo2, dg2, db2, None, None, None, None, None)
+        ops.plane_gemm_grouped(jobs, trans=True, accumulate=True)
         for wp, fr in zip((ro2, ri, ro), fresh):
             if not fr:
                 wgrad_done(wp)
@@ -786,6 +801,32 @@ class BertLayerFn(torch.autograd.Function):
             ops.linear_dgrad(dj, w, out=dx, accumulate=True)
         return (dx, None, dws[0], dbs[0], dws[1], dbs[1], dws[2], dbs[2], dwo, dbo, dg1, db1, dwi, dbi, dwo2, dbo2,
                 dg2, db2, None, None, None, None, None)
+
+
+class JoinSideFn(torch.autograd.Function):
+    """Identity on a tensor that was produced on the side stream (vbg/ops.side_stream) and is consumed on the caller's stream.
+    Forward: nothing (the caller has already made its stream wait).  Backward: the gradient passes through unchanged -- the
+    autograd engine hands it to the producer's node on the side stream with its own event -- and a callback is queued that makes
+    the stream `backward()` was called on wait for the side stream once the whole graph has run: gradients that the side
+    stream's nodes wrote straight into the flat gradient buffers (sunk parameters: no AccumulateGrad node the engine could
+    synchronise on) are complete for whatever the caller enqueues next (clipping, optimizer steps, all-reduce)."""
+
+    @staticmethod
+    def forward(ctx, x):
+        ctx.dev = x.device
+        return x.view_as(x)
+
+    @staticmethod
+    def backward(ctx, dy):
+        dev = ctx.dev
+
+        def join():
+            cur = torch.cuda.current_stream(dev)
+            for s in ops.side_streams():
+                if s.device == dev:
+                    cur.wait_stream(s)
+        torch.autograd.Variable._execution_engine.queue_callback(join)
+        return dy
 
 
 class GatherRowsFn(torch.autograd.Function):

@@ -18,6 +18,49 @@ def _stream():
     return C.c_void_p(torch.cuda.current_stream().cuda_stream)
 
 
+# ----------------------------------------------------------------------------------------------
+# Second compute stream.  The text encoder and the part of the CNN in front of the early fusion are independent, forward and
+# backward; enqueued on two HIP streams the workgroups of one fill the CUs the other leaves idle (a 198-tile plane product
+# covers 0.77 of the chip, a grouped weight-gradient launch 0.84).  `VBG_OVERLAP=0` puts everything back on one stream.
+# ----------------------------------------------------------------------------------------------
+_OVERLAP = [os.environ.get("VBG_OVERLAP", "0") != "0"]
+_SIDE = {}
+
+
+def overlap_enabled() -> bool:
+    return _OVERLAP[0]
+
+
+def set_overlap(on: bool):
+    _OVERLAP[0] = bool(on)
+
+
+_WGRAD_STREAM = [os.environ.get("VBG_WGRAD_STREAM", "1") != "0"]
+
+
+def wgrad_stream_enabled() -> bool:
+    """the grouped weight-gradient launch of an encoder layer goes on its own stream (it depends on nothing the rest of the
+    backward waits for): its 216 tiles and the next layer's data-gradient products share the chip"""
+    return _OVERLAP[0] and _WGRAD_STREAM[0]
+
+
+def side_stream(device, name: str = "side") -> "torch.cuda.Stream":
+    """the side stream `name` of `device` (created on first use)"""
+    idx = torch.device(device).index
+    if idx is None:
+        idx = torch.cuda.current_device()
+    s = _SIDE.get((idx, name))
+    if s is None:
+        s = _SIDE[(idx, name)] = torch.cuda.Stream(device=idx)
+    return s
+
+
+def side_streams():
+    """every side stream created so far: whoever consumes results of the whole backward on another stream (the gradient
+    all-reduce, vbg/optim.FlatReducer) waits for these as well"""
+    return list(_SIDE.values())
+
+
 def P(t):
     if t is None:
         return None
@@ -484,6 +527,42 @@ def fuse_stats_ok(M, N, K):
     return N % 4 == 0 and not (tiles <= 384 and (K + 31) // 32 >= 48)
 
 
+_CONV3 = [os.environ.get("VBG_CONV3", "1") != "0"]
+
+
+def set_conv3(on: bool):
+    """row-reuse kernel (csrc/conv3.hip) for the wide 3x3 / s1 / p1 convolutions; off = the generic implicit GEMM of csrc/gemm.hip"""
+    _CONV3[0] = bool(on)
+
+
+def conv3_ok(B, H, W, Cs, N, kh, kw, stride, pad) -> bool:
+    """shapes the row-reuse kernel takes: whole image rows per 128-pixel tile, full 128-wide column tiles and enough of them to
+    fill the chip (the small late-stage convolutions stay on the 64 x 64 tiles of the generic kernel); default split form only"""
+    return (_CONV3[0] and _SPLIT3[0] and not _AMP[0] and kh == 3 and kw == 3 and stride == 1 and pad == 1 and W in (32, 64, 128)
+            and (H * W) % 128 == 0 and Cs % 16 == 0 and N % 128 == 0 and H * W * Cs < (1 << 29)
+            and (B * H * W // 128) * (N // 128) >= 240)
+
+
+def conv3x3(x, w_ohwi, bias=None, out=None, stats=None, accumulate=False):
+    """y (+)= conv3x3(x NHWC, w [N,3,3,Cs]), stride 1, pad 1 (csrc/conv3.hip)"""
+    B, H, W, Cs = x.shape
+    N = w_ohwi.shape[0]
+    if out is None:
+        assert not accumulate
+        out = torch.empty((B, H, W, N), device=x.device, dtype=f32)
+    check(lib.vbg_conv3x3(P(x), P(w_ohwi), P(bias), P(out), P(stats), bn_slots() if stats is not None else 0, B, H, W, Cs, N,
+                          int(accumulate), _stream()), "vbg_conv3x3")
+    return out
+
+
+def conv3x3_wflip(w_ohwi):
+    """[Cout,3,3,Cin] -> [Cin,3,3,Cout] turned by 180 degrees: the filter of the input gradient"""
+    Cout, _, _, Cin = w_ohwi.shape
+    out = torch.empty((Cin, 3, 3, Cout), device=w_ohwi.device, dtype=f32)
+    check(lib.vbg_conv3x3_wflip(P(w_ohwi), Cout, Cin, P(out), _stream()), "vbg_conv3x3_wflip")
+    return out
+
+
 def conv2d_fwd(x, w_ohwi, stride, pad, bias=None, out=None, stats=None):
     """x NHWC [B,H,W,Cin] contiguous; w_ohwi [Cout,kh,kw,Cin] contiguous -> y NHWC [B,Ho,Wo,Cout]."""
     _chk_f32(x, w_ohwi, bias)
@@ -494,6 +573,8 @@ def conv2d_fwd(x, w_ohwi, stride, pad, bias=None, out=None, stats=None):
     if out is None:
         out = torch.empty((B, Ho, Wo, Cout), device=x.device, dtype=f32)
     M, K = B * Ho * Wo, kh * kw * Cin
+    if conv3_ok(B, H, W, Cin, Cout, kh, kw, stride, pad):
+        return conv3x3(x, w_ohwi, bias, out, stats)
     if kh == 1 and kw == 1 and stride == 1 and pad == 0:
         gemm_raw(M, Cout, K, x, Cin, OP_DENSE_K, w_ohwi, K, OP_DENSE_K, out, Cout, bias=bias, stats=stats)
     else:
@@ -516,6 +597,9 @@ def conv2d_dgrad(dy, w_ohwi, x_shape, stride, pad, out=None, accumulate=False):
         assert not accumulate
         out = torch.empty(x_shape, device=dy.device, dtype=f32)
     M = B * H * W
+    if conv3_ok(B, H, W, Cout, Cin, kh, kw, stride, pad):
+        # the input gradient of a 3x3 / s1 / p1 convolution is the same convolution of dy with the turned, channel-swapped filter
+        return conv3x3(dy, conv3x3_wflip(w_ohwi), None, out, None, accumulate)
     if kh == 1 and kw == 1 and stride == 1 and pad == 0:
         gemm_raw(M, Cin, Cout, dy, Cout, OP_DENSE_K, w_ohwi, Cin, OP_DENSE_R, out, Cin, accumulate=accumulate, splitk=_BWD_SPLIT)
     else:

@@ -319,6 +319,8 @@ class FlatReducer:
         self._observed = []        # completion order seen in the current step
         self._complete = set()
         self._next = 0             # position in `order` of the next bucket to issue
+        self._stage = None         # stream the collectives are issued from
+        self._streams = set()      # compute streams gradients were reported from in this step
         if not self.enabled:
             return
         if sync_bn_group == "new":
@@ -367,10 +369,26 @@ class FlatReducer:
             self._ready(idx)
 
     def _issue(self, idx):
-        self.handles.append(dist.all_reduce(self.buckets[idx][0], group=self.pg, async_op=True))
+        buf = self.buckets[idx][0]
+        if not buf.is_cuda:
+            self.handles.append(dist.all_reduce(buf, group=self.pg, async_op=True))
+            return
+        # gradients are written on more than one compute stream (the encoder's backward runs on vbg.ops.side_stream): the
+        # collective is issued from a staging stream that waits for every stream a gradient was reported from and for the side
+        # streams -- the reporting stream itself is not held up
+        dev = buf.device
+        if self._stage is None:
+            self._stage = torch.cuda.Stream(device=dev)
+        self._streams.add(torch.cuda.current_stream(dev))
+        for s in list(self._streams) + [t for t in ops.side_streams() if t.device == dev]:
+            self._stage.wait_stream(s)
+        with torch.cuda.stream(self._stage):
+            self.handles.append(dist.all_reduce(buf, group=self.pg, async_op=True))
 
     def _ready(self, idx):
         b = self.buckets[idx]
+        if b[0].is_cuda:
+            self._streams.add(torch.cuda.current_stream(b[0].device))
         b[2] -= 1
         assert b[2] >= 0, "a gradient was reported twice: the bucket would be reduced before it is complete"
         if b[2] != 0:
@@ -403,4 +421,5 @@ class FlatReducer:
         for b in self.buckets:
             b[2] = b[1]
         self._reported.clear()
+        self._streams.clear()
         self._observed, self._complete, self._next = [], set(), 0
