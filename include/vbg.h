@@ -210,6 +210,15 @@ int vbg_conv3x3(const float* x, const float* w, const float* bias, float* y, dou
  * same convolution of dy */
 int vbg_conv3x3_wflip(const float* w, int Cout, int Cin, float* out, void* stream);
 
+/* weight gradient of that convolution: dw[Cout,3,3,Cs] += sum over pixels dy[B,H,W,Cout]^T * shifted x[B,H,W,Cs] (csrc/conv3.hip:
+ * operands stay [pixel][channel] in LDS, fragments through transposing LDS reads, one load + split of x serves all nine taps).
+ * The pixel range is cut into vbg_conv3x3_wgrad_strips(...) strips; slab = [strips][Cout,3,3,Cs] scratch -> each strip stores its
+ * partial result plainly and a second launch adds them into dw in a fixed order (deterministic); slab = NULL -> float atomics.
+ * Replaces the weight gradient autograd forms for torch.nn.Conv2d(k=3, s=1, p=1).  Requires W % 16 == 0, Cs % 32 == 0 and
+ * Cout % 128 == 0 (or Cout % 64 == 0 and Cs % 64 == 0). */
+int vbg_conv3x3_wgrad_strips(int B, int H, int W, int Cs, int Cout);
+int vbg_conv3x3_wgrad(const float* dy, const float* x, float* dw, float* slab, int B, int H, int W, int Cs, int Cout, void* stream);
+
 /* stem im2col: NHWC [B,H,W,C] -> [B*Ho*Wo, Kpad] with k = (dy*kw+dx)*C + c, zero padded to Kpad */
 int vbg_im2col(const float* x, int B, int H, int W, int C, int kh, int kw, int stride, int pad, int Kpad,
                float* out, void* stream);

@@ -209,7 +209,8 @@ def test_conv3x3_row_reuse(ops, B, H, W, Cs, N):
     stats = torch.zeros(ops.bn_slots() * 2 * N, device=dev(), dtype=torch.float64)
     yh = ops.conv3x3(xh, wh, bh, stats=stats)
     ref = y.float().permute(0, 2, 3, 1)
-    assert close(yh, ref, 2e-5, 2e-6)
+    tol = 3e-6 * float(ref.abs().max())          # fp32-grade: errors scale with the summed magnitudes, not with the element
+    assert close(yh, ref, 2e-5, tol)
     st = stats.view(-1, 2, N).sum(0).cpu()
     y2 = y.detach().permute(0, 2, 3, 1).reshape(-1, N)
     assert torch.allclose(st[0], y2.sum(0), rtol=1e-5, atol=1e-4) and torch.allclose(st[1], (y2 * y2).sum(0), rtol=1e-5, atol=1e-4)
@@ -219,18 +220,41 @@ def test_conv3x3_row_reuse(ops, B, H, W, Cs, N):
         yg = ops.conv2d_fwd(xh, wh, 1, 1, bh)
     finally:
         ops.set_conv3(True)
-    assert close(yh, yg, 1e-5, 1e-5)
+    assert close(yh, yg, 1e-5, 2 * tol)
     # accumulate
     acc = yh.clone()
     ops.conv3x3(xh, wh, None, out=acc, accumulate=True)
-    assert close(acc, 2 * ref - b.view(1, 1, 1, N), 2e-5, 1e-5)
+    assert close(acc, 2 * ref - b.view(1, 1, 1, N), 2e-5, 2 * tol)
     # input gradient: the same kernel over dy with the turned filter
     if N % 16 == 0 and Cs % 4 == 0:
         gyh = gy.permute(0, 2, 3, 1).contiguous().to(dev())
         wf = ops.conv3x3_wflip(wh)
         assert torch.equal(wf.cpu(), w.detach().permute(1, 2, 3, 0).flip(1, 2).contiguous())
         dx = ops.conv3x3(gyh, wf)
-        assert close(dx.permute(0, 3, 1, 2), x.grad.float(), 2e-5, 2e-6)
+        assert close(dx.permute(0, 3, 1, 2), x.grad.float(), 2e-5, 3e-6 * float(x.grad.abs().max()))
+
+
+@pytest.mark.parametrize("B,H,W,Cs,Cout", [(2, 8, 32, 32, 128), (3, 4, 16, 64, 64), (1, 16, 64, 96, 256), (2, 5, 48, 64, 192)])
+@pytest.mark.parametrize("slabs", [True, False])
+def test_conv3x3_wgrad(ops, B, H, W, Cs, Cout, slabs):
+    """csrc/conv3.hip weight gradient (transposing LDS reads, X loaded once for nine taps) against fp64 autograd; accumulates into dw;
+    the slab form is run-to-run bit-identical"""
+    x = rnd(B, Cs, H, W, seed=70)
+    w = (rnd(Cout, Cs, 3, 3, seed=71) / math.sqrt(Cs * 9)).double().requires_grad_(True)
+    gy = rnd(B, Cout, H, W, seed=72)
+    F.conv2d(x.double(), w, None, 1, 1).backward(gy.double())
+    xh = x.permute(0, 2, 3, 1).contiguous().to(dev())
+    gyh = gy.permute(0, 2, 3, 1).contiguous().to(dev())
+    init = rnd(Cout, 3, 3, Cs, seed=73)
+    dw = init.clone().to(dev())
+    ops.conv3x3_wgrad(gyh, xh, dw, slabs=slabs)
+    ref = w.grad.permute(0, 2, 3, 1).float() + init
+    scale = float(w.grad.abs().max())
+    assert float((dw.cpu() - ref).abs().max()) <= 3e-6 * scale + 1e-6
+    if slabs:
+        dw2 = init.clone().to(dev())
+        ops.conv3x3_wgrad(gyh, xh, dw2, slabs=True)
+        assert torch.equal(dw, dw2)
 
 
 def test_conv3x3_dispatch(ops):

@@ -13,7 +13,7 @@ from gemm_bench import report, timeit
 from vbg import ops
 
 dev = torch.device("cuda")
-for (B, H, W, Ci, Co) in [(8, 128, 128, 256, 256), (8, 128, 128, 128, 128), (8, 64, 64, 128, 128), (8, 64, 64, 256, 256), (16, 128, 128, 256, 256)]:
+for (B, H, W, Ci, Co) in [(8, 128, 128, 256, 256), (8, 128, 128, 128, 128), (8, 64, 64, 128, 128), (8, 64, 64, 256, 256), (8, 32, 32, 256, 256), (8, 16, 16, 512, 512), (8, 128, 128, 64, 64)]:
     x = torch.randn(B, H, W, Ci, device=dev)
     w = torch.randn(Co, 3, 3, Ci, device=dev) / (3 * Ci ** 0.5)
     dy = torch.randn(B, H, W, Co, device=dev)
@@ -24,6 +24,10 @@ for (B, H, W, Ci, Co) in [(8, 128, 128, 256, 256), (8, 128, 128, 128, 128), (8, 
         name = "conv3 " if on else "generic"
         report(f"{name} fwd   {tag}", fl, timeit(lambda: ops.conv2d_fwd(x, w, 1, 1)))
         report(f"{name} dgrad {tag}", fl, timeit(lambda: ops.conv2d_dgrad(dy, w, tuple(x.shape), 1, 1)))
+        dw = torch.zeros_like(w)
+        report(f"{name} wgrad {tag}", fl, timeit(lambda: ops.conv2d_wgrad(dy, x, dw, 1, 1)))
+        if on:
+            report(f"{name} wgrad (atomics) {tag}", fl, timeit(lambda: ops.conv3x3_wgrad(dy, x, dw, slabs=False)))
     ops.set_conv3(True)
     y1 = ops.conv2d_fwd(x, w, 1, 1)
     ops.set_conv3(False)

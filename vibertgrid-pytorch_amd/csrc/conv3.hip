@@ -315,7 +315,227 @@ __global__ void conv3_wflip_kernel(const float* __restrict__ w, int Cout, int Ci
     }
 }
 
+
+// ------------------------------------------------------------------------------------------------------------------------------
+// Weight gradient of the same convolution: dW[co][kh][kw][ci] += sum_p dY[p][co] * X[p + (kh-1) W + (kw-1)][ci].
+// The reduction index is the pixel, i.e. the ROW index of both NHWC operands.  A k-tile is a chunk of 16 consecutive pixels of one
+// image row; its dY rows [16][CO] and the X pixels the nine taps touch ([3 rows][18 pixels][CI], borders read 0) are split once
+// and stored as they lie in memory ([pixel][channel] bf16, three planes).  The MFMA fragments -- 8 consecutive pixels of one channel --
+// come out of that image through ds_read_b64_tr_b16 (a 16-lane group reads a [4 pixels][16 channels] block and receives it
+// transposed), so nothing is transposed on the way into LDS, and a filter tap is a ROW offset (kh * 18 + kw) of the X image: one
+// load and one split of X serve all nine taps, the dY fragments of a k-tile serve 54 MFMAs.  Per product the kernel moves 0.025 B
+// from L2 (generic CONV_R gather of gemm.hip: 0.0625 B) and splits a quarter of the elements.  A workgroup owns a [CO x 9 x CI]
+// block of dW (CO x CI = 128 x 32 or 64 x 64: 144 accumulator registers) and a strip of pixel chunks; strips meet in float atomics.
+// Row strides of the LDS images are 2 * channels + 32 bytes: the four pixel rows of a transposing read land on disjoint banks.
+// ------------------------------------------------------------------------------------------------------------------------------
+struct conv3w_args {
+    const float* dY;       // [B, H, W, Cout]
+    const float* X;        // [B, H, W, Cs]
+    float* dW;             // [Cout, 3, 3, Cs], accumulated into with float atomics (slab == null) ...
+    float* slab;           // ... or [strips][Cout, 3, 3, Cs]: every strip stores its partial block plainly, conv3_wgrad_reduce_kernel adds them up
+    int H, W, Cs, Cout;
+    int nchunks, per;      // 16-pixel chunks in total / per strip
+};
+
+typedef short c3_v4s __attribute__((ext_vector_type(4)));
+typedef __attribute__((address_space(3))) c3_v4s* c3_lds_v4s;
+typedef __attribute__((address_space(3))) unsigned char* c3_lds_bytes;
+
+template <int WCO>
+__global__ __launch_bounds__(256, 2) void conv3x3_wgrad_kernel(const conv3w_args p) {
+    constexpr int NT = 256, WCI = 4 / WCO, CO = 32 * WCO, CI = 32 * WCI;
+    constexpr int RSA = CO * 2 + 32, RSB = CI * 2 + 32;        // bytes of a pixel row of the dY / X image
+    constexpr int PA = 16 * RSA, PB = 54 * RSB;                // one plane
+    constexpr int STAGE = 3 * (PA + PB);
+    constexpr int QA = CO / 4, QB = CI / 4;                    // float4 per pixel
+    constexpr int NDA = 16 * QA / NT, NXB = 54 * QB, NDB = (NXB + NT - 1) / NT;
+    static_assert(16 * QA % NT == 0, "dY chunk divides over the threads");
+    __shared__ __attribute__((aligned(16))) unsigned char smem[2 * STAGE];
+
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    const int H = p.H, W = p.W, Cs = p.Cs, Cout = p.Cout;
+    const int co0 = blockIdx.z * CO, ci0 = blockIdx.y * CI;
+    const int c0 = blockIdx.x * p.per, c1 = min(p.nchunks, c0 + p.per);
+    if (c0 >= c1) return;
+
+    // ---- loader: per-thread constants, per-chunk scalars -------------------------------------------------------------------
+    unsigned avo[NDA], bvo[NDB];
+    int alds[NDA], blds[NDB], b_r3[NDB], b_px[NDB];
+#pragma unroll
+    for (int i = 0; i < NDA; ++i) {
+        const int e = tid + i * NT, px = e / QA, c4 = e % QA;
+        avo[i] = (unsigned)((px * Cout + co0 + 4 * c4) * 4);
+        alds[i] = px * RSA + c4 * 8;
+    }
+#pragma unroll
+    for (int i = 0; i < NDB; ++i) {
+        const int e = tid + i * NT;
+        const int r3 = e / (18 * QB), rem = e - r3 * (18 * QB), px = rem / QB, c4 = rem % QB;
+        const bool ok = e < NXB;
+        b_r3[i] = ok ? r3 : 1000000;                           // (never inside the image)
+        b_px[i] = px;
+        bvo[i] = (unsigned)(((r3 * W + px) * Cs + ci0 + 4 * c4) * 4);
+        blds[i] = ok ? (r3 * 18 + px) * RSB + c4 * 8 : 0;
+    }
+    // chunk c = pixels [16 c, 16 c + 16) of the flattened [B, H, W] index: (image n, row y, first column x0) walk in scalars
+    int pix = c0 * 16;
+    int n = pix / (H * W);
+    int y = (pix - n * H * W) / W;
+    int x0 = pix - (n * H + y) * W;
+    float4 ra[NDA], rb[NDB];
+    auto load_chunk = [&](unsigned inv) {
+        const __amdgpu_buffer_rsrc_t rA = c3_rsrc(p.dY + (long long)pix * Cout);
+#pragma unroll
+        for (int i = 0; i < NDA; ++i) ra[i] = c3_load(rA, avo[i] | inv);
+        // descriptor base: pixel (y - 1, x0 - 1) of image n (lanes whose pixel lies outside the image carry the invalid offset)
+        const __amdgpu_buffer_rsrc_t rB = c3_rsrc(p.X + ((long long)(n * H + y - 1) * W + (x0 - 1)) * Cs);
+#pragma unroll
+        for (int i = 0; i < NDB; ++i) {
+            const bool ok = (unsigned)(y + b_r3[i] - 1) < (unsigned)H && (unsigned)(x0 + b_px[i] - 1) < (unsigned)W;
+            rb[i] = c3_load(rB, ok ? (bvo[i] | inv) : C3_INVALID);
+        }
+        pix += 16; x0 += 16;
+        if (x0 >= W) { x0 = 0; if (++y >= H) { y = 0; ++n; } }
+    };
+    auto store3 = [&](unsigned char* dst, int PL, const float4& v) {
+        uint2 h, m, l;
+        c3_split3(v.x, v.y, h.x, m.x, l.x);
+        c3_split3(v.z, v.w, h.y, m.y, l.y);
+        *reinterpret_cast<uint2*>(dst) = h;
+        *reinterpret_cast<uint2*>(dst + PL) = m;
+        *reinterpret_cast<uint2*>(dst + 2 * PL) = l;
+    };
+    auto store_chunk = [&](int stage) {
+        unsigned char* sa = smem + stage * STAGE;
+        unsigned char* sb = sa + 3 * PA;
+#pragma unroll
+        for (int i = 0; i < NDA; ++i) store3(sa + alds[i], PA, ra[i]);
+#pragma unroll
+        for (int i = 0; i < NDB; ++i)
+            if (NXB % NT == 0 || i + 1 < NDB || tid + i * NT < NXB) store3(sb + blds[i], PB, rb[i]);
+    };
+
+    // ---- fragments -----------------------------------------------------------------------------------------------------------
+    const int wco = wave / WCI, wci = wave % WCI;
+    const int lr = lane & 31, lk = lane >> 5;
+    const int i16 = lane & 15, tg = (lane >> 4) & 1;
+    const int ta = (8 * lk + (i16 >> 2)) * RSA + (32 * wco + 16 * tg + 4 * (i16 & 3)) * 2;
+    const int tb = (8 * lk + (i16 >> 2)) * RSB + (32 * wci + 16 * tg + 4 * (i16 & 3)) * 2;
+    f32x16 acc[9];
+#pragma unroll
+    for (int t = 0; t < 9; ++t)
+#pragma unroll
+        for (int r = 0; r < 16; ++r) acc[t][r] = 0.f;
+    auto frag = [&](c3_lds_bytes base, int RS) {
+        const c3_v4s lo = __builtin_amdgcn_ds_read_tr16_b64_v4i16((c3_lds_v4s)(base));
+        const c3_v4s hi = __builtin_amdgcn_ds_read_tr16_b64_v4i16((c3_lds_v4s)(base + 4 * RS));
+        const uint2 l2 = __builtin_bit_cast(uint2, lo), h2 = __builtin_bit_cast(uint2, hi);
+        return c3_u32x4{l2.x, l2.y, h2.x, h2.y};
+    };
+
+    load_chunk(0u);
+    store_chunk(0);
+    __syncthreads();
+    const int nch = c1 - c0;
+    for (int it = 0; it < nch; ++it) {
+        const int stage = it & 1;
+        load_chunk(it + 1 < nch ? 0u : C3_INVALID);             // (past the strip: every lane reads 0, no traffic; stored into the idle stage)
+        __builtin_amdgcn_sched_barrier(0);
+        c3_lds_bytes as = (c3_lds_bytes)(smem + stage * STAGE) + ta;
+        c3_lds_bytes bs = (c3_lds_bytes)(smem + stage * STAGE + 3 * PA) + tb;
+        c3_u32x4 fa[3];
+#pragma unroll
+        for (int q = 0; q < 3; ++q) fa[q] = frag(as + q * PA, RSA);
+        constexpr int qa[6] = {2, 0, 1, 1, 0, 0}, qb[6] = {0, 2, 1, 0, 1, 0};
+#pragma unroll
+        for (int tap = 0; tap < 9; ++tap) {
+            c3_u32x4 fb[3];
+#pragma unroll
+            for (int q = 0; q < 3; ++q) fb[q] = frag(bs + q * PB + ((tap / 3) * 18 + tap % 3) * RSB, RSB);
+#pragma unroll
+            for (int t = 0; t < 6; ++t)
+                acc[tap] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(__builtin_bit_cast(c3_bf16x8, fa[qa[t]]), __builtin_bit_cast(c3_bf16x8, fb[qb[t]]),
+                                                                   acc[tap], 0, 0, 0);
+        }
+        store_chunk(stage ^ 1);
+        __syncthreads();
+    }
+    // ---- epilogue (lanes = 32 consecutive ci: 128-byte rows): the strip's partial block goes to its slab as plain stores (float
+    //      atomics run at the L2's atomic rate: ~70 us for the 9.4 M partials of a 256 x 256 filter), or straight into dW ---------
+    if (p.slab) {
+        float* const out = p.slab + (long long)blockIdx.x * Cout * 9 * Cs;
+#pragma unroll
+        for (int tap = 0; tap < 9; ++tap)
+#pragma unroll
+            for (int r = 0; r < 16; ++r) {
+                const int co = co0 + 32 * wco + (r & 3) + 8 * (r >> 2) + 4 * lk;
+                out[((long long)co * 9 + tap) * Cs + ci0 + 32 * wci + lr] = acc[tap][r];
+            }
+        return;
+    }
+#pragma unroll
+    for (int tap = 0; tap < 9; ++tap)
+#pragma unroll
+        for (int r = 0; r < 16; ++r) {
+            const int co = co0 + 32 * wco + (r & 3) + 8 * (r >> 2) + 4 * lk;
+            unsafeAtomicAdd(p.dW + ((long long)co * 9 + tap) * Cs + ci0 + 32 * wci + lr, acc[tap][r]);
+        }
+}
+
+// dW[i] += sum over the strips' slabs (fixed order: deterministic)
+__global__ void conv3_wgrad_reduce_kernel(const float4* __restrict__ slab, int nsplit, long long n4, float4* __restrict__ dW) {
+    const long long i = blockIdx.x * (long long)blockDim.x + threadIdx.x;
+    if (i >= n4) return;
+    float4 s = dW[i];
+    for (int k = 0; k < nsplit; ++k) {
+        const float4 v = slab[k * n4 + i];
+        s.x += v.x; s.y += v.y; s.z += v.z; s.w += v.w;
+    }
+    dW[i] = s;
+}
+
 }  // namespace vbg
+
+extern "C" int vbg_conv3x3_wgrad_strips(int B, int H, int W, int Cs, int Cout) {
+    const long long nchunks = (long long)B * H * W / 16;
+    const bool wide = Cout % 128 == 0;
+    const long long tiles = wide ? (long long)(Cout / 128) * (Cs / 32) : (long long)(Cout / 64) * (Cs / 64);
+    if (tiles <= 0 || nchunks <= 0) return 0;
+    long long nsplit = (512 + tiles - 1) / tiles;              // two workgroups per CU
+    const long long cap = (96ll << 20) / ((long long)Cout * 9 * Cs * 4);       // at most 96 MB of slabs
+    if (nsplit > cap) nsplit = cap < 1 ? 1 : cap;
+    if (nsplit > nchunks / 8) nsplit = nchunks / 8 < 1 ? 1 : nchunks / 8;      // at least 8 k-tiles per strip
+    const long long per = (nchunks + nsplit - 1) / nsplit;
+    return (int)((nchunks + per - 1) / per);
+}
+
+extern "C" int vbg_conv3x3_wgrad(const float* dy, const float* x, float* dw, float* slab, int B, int H, int W, int Cs, int Cout, void* stream) {
+    VBG_CHECK_ARG(dy && x && dw && B > 0 && H > 0 && W >= 16 && W % 16 == 0);
+    VBG_CHECK_ARG(Cs % 32 == 0 && Cout % 64 == 0);
+    VBG_CHECK_ARG((((uintptr_t)x) & 15) == 0 && (((uintptr_t)dy) & 15) == 0);
+    VBG_CHECK_ARG((long long)(3 * W + 18) * Cs < (1ll << 28) && (long long)16 * Cout < (1ll << 28));
+    const long long M = (long long)B * H * W;
+    VBG_CHECK_ARG(M < (1ll << 31));
+    vbg::conv3w_args a;
+    a.dY = dy; a.X = x; a.dW = dw; a.slab = slab; a.H = H; a.W = W; a.Cs = Cs; a.Cout = Cout;
+    a.nchunks = (int)(M / 16);
+    const bool wide = Cout % 128 == 0;                         // [128 co x 32 ci] blocks, else [64 co x 64 ci]
+    VBG_CHECK_ARG(wide || Cs % 64 == 0);
+    const int nsplit = vbg_conv3x3_wgrad_strips(B, H, W, Cs, Cout);
+    VBG_CHECK_ARG(nsplit >= 1 && (!slab || (((uintptr_t)slab) & 15) == 0) && (((uintptr_t)dw) & 15) == 0);
+    a.per = (a.nchunks + nsplit - 1) / nsplit;
+    if (wide) {
+        VBG_LAUNCH(vbg::conv3x3_wgrad_kernel<4>, dim3(nsplit, Cs / 32, Cout / 128), dim3(256), 0, (hipStream_t)stream, a);
+    } else {
+        VBG_LAUNCH(vbg::conv3x3_wgrad_kernel<2>, dim3(nsplit, Cs / 64, Cout / 64), dim3(256), 0, (hipStream_t)stream, a);
+    }
+    if (slab) {
+        const long long n4 = (long long)Cout * 9 * Cs / 4;
+        hipLaunchKernelGGL(vbg::conv3_wgrad_reduce_kernel, dim3((unsigned)((n4 + 255) / 256)), dim3(256), 0, (hipStream_t)stream,
+                           reinterpret_cast<const float4*>(slab), nsplit, n4, reinterpret_cast<float4*>(dw));
+    }
+    VBG_LAUNCH_RET();
+}
 
 extern "C" int vbg_conv3x3(const float* x, const float* w, const float* bias, float* y, double* stats, int stats_slots, int B, int H,
                            int W, int Cs, int N, int accumulate, void* stream) {

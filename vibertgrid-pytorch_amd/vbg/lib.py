@@ -85,6 +85,8 @@ SIGNATURES = {
     "vbg_colsum": (c_int, [c_vp, c_ll, c_int, c_int, c_vp, c_int, c_vp]),
     "vbg_conv3x3": (c_int, [c_vp, c_vp, c_vp, c_vp, c_vp, c_int, c_int, c_int, c_int, c_int, c_int, c_int, c_vp]),
     "vbg_conv3x3_wflip": (c_int, [c_vp, c_int, c_int, c_vp, c_vp]),
+    "vbg_conv3x3_wgrad_strips": (c_int, [c_int, c_int, c_int, c_int, c_int]),
+    "vbg_conv3x3_wgrad": (c_int, [c_vp, c_vp, c_vp, c_vp, c_int, c_int, c_int, c_int, c_int, c_vp]),
     "vbg_im2col": (c_int, [c_vp, c_int, c_int, c_int, c_int, c_int, c_int, c_int, c_int, c_int, c_vp, c_vp]),
     "vbg_normalize_resize": (c_int, [c_vp, c_int, c_int, c_int, c_int, C.POINTER(c_f), C.POINTER(c_f), c_vp, c_int, c_int, c_int, c_vp]),
     "vbg_rescale_boxes": (c_int, [c_vp, c_int, c_f, c_f, c_vp, c_vp]),

@@ -563,6 +563,30 @@ def conv3x3_wflip(w_ohwi):
     return out
 
 
+def conv3w_ok(B, H, W, Cs, Cout, kh, kw, stride, pad) -> bool:
+    """shapes the row-reuse weight-gradient kernel takes (csrc/conv3.hip): default split form, strips of at least 32 k-tiles"""
+    if not (_CONV3[0] and _SPLIT3[0] and not _AMP[0] and kh == 3 and kw == 3 and stride == 1 and pad == 1 and W % 16 == 0
+            and Cs % 32 == 0 and Cout % 128 == 0 and (3 * W + 18) * Cs < (1 << 28)):       # (64-wide filters: the generic kernel is faster)
+        return False
+    strips = int(lib.vbg_conv3x3_wgrad_strips(B, H, W, Cs, Cout))
+    return strips >= 1 and (B * H * W // 16) // strips >= _CONV3W_MIN[0]
+
+
+_CONV3W_MIN = [int(os.environ.get("VBG_CONV3W_MIN", "32"))]
+
+
+def conv3x3_wgrad(dy, x, dw_ohwi, slabs=True):
+    """dw += conv3x3 weight gradient (stride 1, pad 1); slabs: deterministic strip reduction through scratch, else float atomics"""
+    B, H, W, Cs = x.shape
+    Cout = dy.shape[3]
+    slab = None
+    if slabs:
+        strips = int(lib.vbg_conv3x3_wgrad_strips(B, H, W, Cs, Cout))
+        slab = torch.empty((strips, dw_ohwi.numel()), device=x.device, dtype=f32)
+    check(lib.vbg_conv3x3_wgrad(P(dy), P(x), P(dw_ohwi), P(slab), B, H, W, Cs, Cout, _stream()), "vbg_conv3x3_wgrad")
+    return dw_ohwi
+
+
 def conv2d_fwd(x, w_ohwi, stride, pad, bias=None, out=None, stats=None):
     """x NHWC [B,H,W,Cin] contiguous; w_ohwi [Cout,kh,kw,Cin] contiguous -> y NHWC [B,Ho,Wo,Cout]."""
     _chk_f32(x, w_ohwi, bias)
@@ -617,6 +641,10 @@ def conv2d_wgrad(dy, x, dw_ohwi, stride, pad, accumulate=True):
     _, Ho, Wo, _ = dy.shape
     assert dy.is_contiguous() and x.is_contiguous() and dw_ohwi.is_contiguous()
     Mpix, Kc = B * Ho * Wo, kh * kw * Cin
+    if conv3w_ok(B, H, W, Cin, Cout, kh, kw, stride, pad):
+        if not accumulate:
+            dw_ohwi.zero_()
+        return conv3x3_wgrad(dy, x, dw_ohwi)
     sk = _pick_splitk(Cout, Kc, Mpix)
     if not accumulate and sk > 1:
         dw_ohwi.zero_()
