@@ -16,6 +16,7 @@
 // roles swapped: vbg_conv3x3_wflip writes that filter (2.4 MB at 256 x 256) and the backward calls this kernel again.
 #include "vbg_common.h"
 #include <type_traits>
+#include <stdlib.h>
 #include "../../include/vbg.h"
 
 namespace vbg {
@@ -501,8 +502,15 @@ extern "C" int vbg_conv3x3_wgrad_strips(int B, int H, int W, int Cs, int Cout) {
     const bool wide = Cout % 128 == 0;
     const long long tiles = wide ? (long long)(Cout / 128) * (Cs / 32) : (long long)(Cout / 64) * (Cs / 64);
     if (tiles <= 0 || nchunks <= 0) return 0;
-    long long nsplit = (512 + tiles - 1) / tiles;              // two workgroups per CU
-    const long long cap = (96ll << 20) / ((long long)Cout * 9 * Cs * 4);       // at most 96 MB of slabs
+    // workgroups: whole rounds of the chip -- two per CU when a strip then still holds >= 256 k-tiles (the wide convolutions at
+    // 1/4 resolution: 717 vs 767 us), else one per CU (fewer, longer strips and half the slab traffic: 72 vs 87 us at 128 x 128
+    // channels, 64 x 64 pixels); measured with tools/conv3w_sweep.py.  VBG_CONV3W_BLOCKS / VBG_CONV3W_SLAB_MB override (tuning).
+    static const long long blocks_env = getenv("VBG_CONV3W_BLOCKS") ? atoll(getenv("VBG_CONV3W_BLOCKS")) : 0;
+    static const long long slab_mb = getenv("VBG_CONV3W_SLAB_MB") ? atoll(getenv("VBG_CONV3W_SLAB_MB")) : 96;
+    long long blocks = blocks_env;
+    if (blocks <= 0) blocks = (nchunks / ((512 + tiles - 1) / tiles) >= 256) ? 512 : 256;
+    long long nsplit = (blocks + tiles - 1) / tiles;
+    const long long cap = (slab_mb << 20) / ((long long)Cout * 9 * Cs * 4);    // bound on the slab scratch
     if (nsplit > cap) nsplit = cap < 1 ? 1 : cap;
     if (nsplit > nchunks / 8) nsplit = nchunks / 8 < 1 ? 1 : nchunks / 8;      // at least 8 k-tiles per strip
     const long long per = (nchunks + nsplit - 1) / nsplit;

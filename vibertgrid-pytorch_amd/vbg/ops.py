@@ -564,7 +564,7 @@ def conv3x3_wflip(w_ohwi):
 
 
 def conv3w_ok(B, H, W, Cs, Cout, kh, kw, stride, pad) -> bool:
-    """shapes the row-reuse weight-gradient kernel takes (csrc/conv3.hip): default split form, strips of at least 32 k-tiles"""
+    """shapes the row-reuse weight-gradient kernel takes (csrc/conv3.hip): default split form, strips of at least 8 k-tiles"""
     if not (_CONV3[0] and _SPLIT3[0] and not _AMP[0] and kh == 3 and kw == 3 and stride == 1 and pad == 1 and W % 16 == 0
             and Cs % 32 == 0 and Cout % 128 == 0 and (3 * W + 18) * Cs < (1 << 28)):       # (64-wide filters: the generic kernel is faster)
         return False
@@ -572,7 +572,7 @@ def conv3w_ok(B, H, W, Cs, Cout, kh, kw, stride, pad) -> bool:
     return strips >= 1 and (B * H * W // 16) // strips >= _CONV3W_MIN[0]
 
 
-_CONV3W_MIN = [int(os.environ.get("VBG_CONV3W_MIN", "32"))]
+_CONV3W_MIN = [int(os.environ.get("VBG_CONV3W_MIN", "8"))]
 
 
 def conv3x3_wgrad(dy, x, dw_ohwi, slabs=True):
