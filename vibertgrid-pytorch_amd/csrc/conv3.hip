@@ -327,7 +327,7 @@ __global__ void conv3_wflip_kernel(const float* __restrict__ w, int Cout, int Ci
 // load and one split of X serve all nine taps, the dY fragments of a k-tile serve 54 MFMAs.  Per product the kernel moves 0.025 B
 // from L2 (generic CONV_R gather of gemm.hip: 0.0625 B) and splits a quarter of the elements.  A workgroup owns a [CO x 9 x CI]
 // block of dW (CO x CI = 128 x 32 or 64 x 64: 144 accumulator registers) and a strip of pixel chunks; strips meet in float atomics.
-// Row strides of the LDS images are 2 * channels + 32 bytes: the four pixel rows of a transposing read land on disjoint banks.
+// Row strides of the LDS images are odd multiples of 64 bytes: the four pixel rows of a transposing read land on disjoint banks.
 // ------------------------------------------------------------------------------------------------------------------------------
 struct conv3w_args {
     const float* dY;       // [B, H, W, Cout]
@@ -345,7 +345,9 @@ typedef __attribute__((address_space(3))) unsigned char* c3_lds_bytes;
 template <int WCO>
 __global__ __launch_bounds__(256, 2) void conv3x3_wgrad_kernel(const conv3w_args p) {
     constexpr int NT = 256, WCI = 4 / WCO, CO = 32 * WCO, CI = 32 * WCI;
-    constexpr int RSA = CO * 2 + 32, RSB = CI * 2 + 32;        // bytes of a pixel row of the dY / X image
+    // bytes of a pixel row of the dY / X image: an odd multiple of 64 B (16 banks), so that the four consecutive pixel rows a
+    // transposing read touches -- 32 bytes each for either 16-channel half -- lie on eight disjoint 8-bank groups
+    constexpr int RSA = CO * 2 + 64, RSB = CI == 32 ? 64 : CI * 2 + 64;
     constexpr int PA = 16 * RSA, PB = 54 * RSB;                // one plane
     constexpr int STAGE = 3 * (PA + PB);
     constexpr int QA = CO / 4, QB = CI / 4;                    // float4 per pixel
