@@ -10,5 +10,9 @@ timeout 600 rocprofv3 --kernel-trace --pmc SQ_VALU_MFMA_BUSY_CYCLES SQ_WAVE_CYCL
 timeout 600 python tools/gemm_bench.py > gpurun_out/gemm_shapes.txt 2>&1
 timeout 600 python tools/gemm_bench.py --amp > gpurun_out/gemm_shapes_amp.txt 2>&1
 timeout 600 python tools/plane_gemm_bench.py > gpurun_out/plane_gemm_shapes.txt 2>&1
+timeout 600 python tools/conv3_bench.py 2>&1 | grep -v amdgpu.ids > gpurun_out/conv3_shapes.txt
 rm -f gpurun_out/prof_amp/amp_kernel_trace.csv
 ls -la gpurun_out/prof_e gpurun_out/pmc_f gpurun_out/pmc_m | head -30; cut -c1-400 gpurun_out/bench_line.json
+# exploratory shapes and legs of the same build
+for s in cfg4 cfg5; do timeout 600 python bench.py --shape $s --steps 6 --warmup 2 --no-cpu-baseline --no-h2d-leg 2>/dev/null | grep "^{" > gpurun_out/bench_$s.json; done
+timeout 300 python tools/infer_latency.py > gpurun_out/infer_latency.txt 2>&1

@@ -13,7 +13,7 @@ NPMC = int(sys.argv[3]) if len(sys.argv) > 3 else 4
 R = os.path.dirname(os.path.dirname(os.path.abspath(__file__))) + "/"
 G = R + "gpurun_out/"
 P = R + "profiles/" + TAG + "_"
-MATRIX = ("gemm_kernel", "attn_kernel<")          # kernels that run on the matrix cores
+MATRIX = ("gemm_kernel", "attn_kernel<", "conv3x3_kernel", "conv3x3_wgrad_kernel")          # kernels that run on the matrix cores
 
 
 def short(name):
@@ -70,7 +70,7 @@ if os.path.exists(G + "pmc_f/f_counter_collection.csv") and os.path.exists(G + "
 shutil.copy(G + "prof_e/e_kernel_stats.csv", P + "bench_kernel_stats.csv")
 shutil.copy(G + "prof_e/e_domain_stats.csv", P + "bench_domain_stats.csv")
 for src, dst in (("gemm_shapes.txt", "gemm_shapes.txt"), ("bench_line.json", "bench_line.json"), ("plane_gemm_shapes.txt", "plane_gemm_shapes.txt"),
-                 ("gemm_shapes_amp.txt", "gemm_shapes_amp.txt")):
+                 ("gemm_shapes_amp.txt", "gemm_shapes_amp.txt"), ("conv3_shapes.txt", "conv3_shapes.txt")):
     if os.path.exists(G + src):
         shutil.copy(G + src, P + dst)
 if os.path.exists(G + "prof_amp/amp_kernel_stats.csv"):
@@ -95,7 +95,7 @@ if os.path.exists(G + "pmc_m/m_counter_collection.csv"):
            "# mfma_util = SQ_VALU_MFMA_BUSY_CYCLES / (kernel time * clock * 1024 SIMDs), clock = GRBM_GUI_ACTIVE / time / 8 XCDs;",
            "# wait/active columns are fractions of SQ_WAVE_CYCLES.  gemm_kernel<BM, BN, BK, 256, A-kind, B-kind, vec, form>: kinds 0 DENSE_K, 1 DENSE_R, 2 CONV_K,",
            "# 3 CONV_R, 4 WT_R; form 0 = fp32 MFMA, 3 = in-kernel bf16x3 split.  plane_gemm_kernel<BM, BN, waves M, waves N, stages, TN>: pre-split planes.",
-           "# attn_kernel<mode, dropout>: 0 forward, 1 dQ, 2 dK/dV.",
+           "# attn_kernel<mode, dropout>: 0 forward, 1 dQ, 2 dK/dV.  conv3x3_kernel<pixels per tile> / conv3x3_wgrad_kernel<waves along the filters>: csrc/conv3.hip.",
            "kernel,launches_per_step,ms_per_step,clock_GHz,mfma_util,wait_any,wait_inst_any,active_inst_any,lds_bank_conflict_Mcycles"]
     tb = tc = 0
     for k, a_ in sorted(ag.items(), key=lambda kv: -kv[1]["ns"]):
@@ -123,6 +123,8 @@ cat = collections.OrderedDict()
 for r in rows:
     nme, v = r["Name"], float(r["TotalDurationNs"]) / NSTEP / 1e6
     if "plane_gemm_kernel" in nme: key = "plane GEMM TN (dense wgrad)" if "true>(" in nme else "plane GEMM NT (dense fwd / dgrad)"
+    elif "conv3x3_wgrad" in nme or "conv3_wgrad_reduce" in nme: key = "conv wgrad, row-reuse kernel (conv3.hip)"
+    elif "conv3x3_kernel" in nme or "conv3_wflip" in nme: key = "conv fwd + dgrad, row-reuse kernel (conv3.hip)"
     elif "gemm_kernel" in nme:
         m = re.search(r"256, (\d), (\d)", nme)
         key = {("0", "0"): "dense NT in-kernel split (1x1, heads, stem)", ("0", "1"): "dense NN (dgrad)", ("1", "1"): "dense TN (wgrad)", ("2", "0"): "conv fwd",

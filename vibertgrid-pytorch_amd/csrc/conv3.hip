@@ -64,13 +64,17 @@ struct c3_pipe {
     }
 };
 
+// BM = 128 pixels per tile, or 64 for the late stages whose pixel count would leave half the chip without a 128-pixel tile
+template <int BM>
 __global__ __launch_bounds__(256, 2) void conv3x3_kernel(const conv3_args p) {
-    constexpr int BM = 128, BN = 128, NT = 256, SKH = 24;
-    constexpr int AROWS = BM + 8;                              // + a zero pixel on either side of each of up to 4 image rows
+    constexpr int BN = 128, NT = 256, SKH = 24;
+    constexpr int NAI = BM * 4 / NT;                           // activation float4s per thread and super-tile
+    constexpr int TM = BM / 64;                                // 32-row fragments per wave (waves 2 x 2: BM / 2 pixels x 64 filters each)
+    constexpr int AROWS = BM + BM / 8;                         // + a zero pixel on either side of each image row (W >= 16)
     constexpr int PA = AROWS * SKH / 2, PB = BN * SKH / 2;     // one bf16 plane (dwords)
     constexpr int ASZ = 3 * PA, BSZ = 3 * PB;
     constexpr int CTS = BN + 4;
-    constexpr int SMEM = 2 * (ASZ + BSZ);                      // 76 KB: two workgroups per CU
+    constexpr int SMEM = 2 * (ASZ + BSZ);                      // 76 KB at BM = 128: two workgroups per CU
     static_assert(BM * CTS <= SMEM, "staged output tile");
     __shared__ __attribute__((aligned(16))) unsigned smem[SMEM];
     unsigned* const As = smem;
@@ -97,32 +101,36 @@ __global__ __launch_bounds__(256, 2) void conv3x3_kernel(const conv3_args p) {
     const int nb = m0 / HW, p0 = m0 - nb * HW;                 // the tile lies inside one image (H*W % 128 == 0)
     const float* const a_img = p.X + (long long)nb * HW * Cs;
     const int kc = (tid & 3) * 4;                              // this thread's 4 channels of a 16-channel chunk
-    int a_y[2], a_x[2], a_lrow[2];
-    unsigned avo[2], bvo[2];
+    int a_y[NAI], a_x[NAI], a_lrow[NAI];
+    unsigned avo[NAI], bvo[2];
 #pragma unroll
-    for (int i = 0; i < 2; ++i) {
+    for (int i = 0; i < NAI; ++i) {
         const int r = (tid + i * NT) >> 2;
         const int pix = p0 + r;
         a_x[i] = pix & (W - 1);
         a_y[i] = pix >> wsh;
         a_lrow[i] = r + 1 + 2 * (r >> wsh);
+    }
+#pragma unroll
+    for (int i = 0; i < 2; ++i) {
+        const int r = (tid + i * NT) >> 2;
         bvo[i] = (n0 + r < N) ? (unsigned)((r * K + kc) * 4) : C3_INVALID;
     }
     auto set_a = [&](int kh) {
 #pragma unroll
-        for (int i = 0; i < 2; ++i) {
+        for (int i = 0; i < NAI; ++i) {
             const int sy = a_y[i] + kh - 1;
             avo[i] = ((unsigned)sy < (unsigned)H) ? (unsigned)(((sy * W + a_x[i]) * Cs + kc) * 4) : C3_INVALID;
         }
     };
     const float* const wbase = p.Wt + (long long)n0 * K;
-    float4 ra[2], rb[2];
+    float4 ra[NAI], rb[2];
     int a_kh = 0, a_c0 = 0;                    // next activation super-tile (filter row, channel chunk) to load
     int b_kh = 0, b_c0 = 0, b_kw = 0;          // next weight tile to load: order (kh, chunk, kw)
     auto load_a = [&]() {
         const __amdgpu_buffer_rsrc_t r = c3_rsrc(a_img + a_c0);
-        ra[0] = c3_load(r, avo[0]);
-        ra[1] = c3_load(r, avo[1]);
+#pragma unroll
+        for (int i = 0; i < NAI; ++i) ra[i] = c3_load(r, avo[i]);
         a_c0 += 16;
         if (a_c0 >= Cs) { a_c0 = 0; ++a_kh; set_a(a_kh); }
     };
@@ -145,8 +153,8 @@ __global__ __launch_bounds__(256, 2) void conv3x3_kernel(const conv3_args p) {
         *reinterpret_cast<uint2*>(&dst[o + 2 * PL]) = l;
     };
     auto store_a = [&](int buf) {
-        store4(As + buf * ASZ, PA, a_lrow[0], ra[0]);
-        store4(As + buf * ASZ, PA, a_lrow[1], ra[1]);
+#pragma unroll
+        for (int i = 0; i < NAI; ++i) store4(As + buf * ASZ, PA, a_lrow[i], ra[i]);
     };
     auto store_b = [&](int buf) {
         store4(Bs + buf * BSZ, PB, tid >> 2, rb[0]);
@@ -157,18 +165,18 @@ __global__ __launch_bounds__(256, 2) void conv3x3_kernel(const conv3_args p) {
     const int lane = tid & 63, wave = tid >> 6;
     const int wm = wave >> 1, wn = wave & 1;
     const int lr = lane & 31, lk = lane >> 5;
-    f32x16 acc[2][2];
+    f32x16 acc[TM][2];
 #pragma unroll
-    for (int i = 0; i < 2; ++i)
+    for (int i = 0; i < TM; ++i)
 #pragma unroll
         for (int j = 0; j < 2; ++j)
 #pragma unroll
             for (int r = 0; r < 16; ++r) acc[i][j][r] = 0.f;
-    int arow[2];
+    int arow[TM];
 #pragma unroll
-    for (int i = 0; i < 2; ++i) {
-        const int r0 = wm * 64 + i * 32;
-        arow[i] = r0 + lr + 2 * (r0 >> wsh);                  // LDS row of pixel x - 1 (tap kw adds kw)
+    for (int i = 0; i < TM; ++i) {
+        const int r = wm * (BM / 2) + i * 32 + lr;
+        arow[i] = r + 2 * (r >> wsh);                         // LDS row of pixel x - 1 (tap kw adds kw)
     }
     const int brow = wn * 64 + lr;
 
@@ -180,11 +188,11 @@ __global__ __launch_bounds__(256, 2) void conv3x3_kernel(const conv3_args p) {
         constexpr bool LOADA = decltype(loada_tag)::value, MORE = decltype(more_tag)::value;
         const c3_u32x4* as = reinterpret_cast<const c3_u32x4*>(As + abuf * ASZ);
         const c3_u32x4* bs = reinterpret_cast<const c3_u32x4*>(Bs + bbuf * BSZ);
-        c3_u32x4 fa[3][2], fb[3][2];
+        c3_u32x4 fa[3][TM], fb[3][2];
 #pragma unroll
         for (int q = 0; q < 3; ++q) {
 #pragma unroll
-            for (int i = 0; i < 2; ++i) fa[q][i] = as[q * (PA / 4) + (arow[i] + kw) * (SKH / 8) + lk];
+            for (int i = 0; i < TM; ++i) fa[q][i] = as[q * (PA / 4) + (arow[i] + kw) * (SKH / 8) + lk];
 #pragma unroll
             for (int j = 0; j < 2; ++j) fb[q][j] = bs[q * (PB / 4) + (brow + j * 32) * (SKH / 8) + lk];
         }
@@ -198,7 +206,7 @@ __global__ __launch_bounds__(256, 2) void conv3x3_kernel(const conv3_args p) {
 #pragma unroll
             for (int t = decltype(t0_tag)::value; t < decltype(t1_tag)::value; ++t)
 #pragma unroll
-                for (int i = 0; i < 2; ++i)
+                for (int i = 0; i < TM; ++i)
 #pragma unroll
                     for (int n = 0; n < 2; ++n)
                         acc[i][n] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(__builtin_bit_cast(c3_bf16x8, fa[qa[t]][i]),
@@ -213,8 +221,8 @@ __global__ __launch_bounds__(256, 2) void conv3x3_kernel(const conv3_args p) {
             mma_range(ih{}, i1{});
             store_b(bbuf ^ 1);
             if constexpr (LOADA) store_a(abuf ^ 1);
-            constexpr int NL = LOADA ? 4 : 2;
-            c3_pipe<0, 16, NL * 22, NL * 3>::run();
+            constexpr int NL = LOADA ? 2 + NAI : 2;
+            c3_pipe<0, 8 * TM, NL * 22, NL * 3>::run();
             __builtin_amdgcn_sched_barrier(0);
             __syncthreads();
         } else {
@@ -254,10 +262,10 @@ __global__ __launch_bounds__(256, 2) void conv3x3_kernel(const conv3_args p) {
 #pragma unroll
     for (int j = 0; j < 2; ++j)
 #pragma unroll
-        for (int i = 0; i < 2; ++i)
+        for (int i = 0; i < TM; ++i)
 #pragma unroll
             for (int r = 0; r < 16; ++r)
-                Ct[(wm * 64 + i * 32 + (r & 3) + 8 * (r >> 2) + 4 * lk) * CTS + wn * 64 + j * 32 + lr] = acc[i][j][r];
+                Ct[(wm * (BM / 2) + i * 32 + (r & 3) + 8 * (r >> 2) + 4 * lk) * CTS + wn * 64 + j * 32 + lr] = acc[i][j][r];
     __syncthreads();
     constexpr int QN = BN / 4;
     float4 cs = make_float4(0.f, 0.f, 0.f, 0.f), cq = cs;
@@ -550,19 +558,24 @@ extern "C" int vbg_conv3x3_wgrad(const float* dy, const float* x, float* dw, flo
 extern "C" int vbg_conv3x3(const float* x, const float* w, const float* bias, float* y, double* stats, int stats_slots, int B, int H,
                            int W, int Cs, int N, int accumulate, void* stream) {
     VBG_CHECK_ARG(x && w && y && B > 0 && H > 0);
-    VBG_CHECK_ARG(W == 32 || W == 64 || W == 128);
-    VBG_CHECK_ARG(((long long)H * W) % 128 == 0 && (long long)H * W * Cs < (1ll << 29));
+    VBG_CHECK_ARG(W == 16 || W == 32 || W == 64 || W == 128);
+    VBG_CHECK_ARG(((long long)H * W) % 64 == 0 && (long long)H * W * Cs < (1ll << 29));
     VBG_CHECK_ARG(Cs >= 16 && Cs % 16 == 0 && N >= 4 && N % 4 == 0);
     VBG_CHECK_ARG((((uintptr_t)x) & 15) == 0 && (((uintptr_t)w) & 15) == 0 && (((uintptr_t)y) & 15) == 0);
     VBG_CHECK_ARG(!stats || (stats_slots >= 1 && !accumulate));
     vbg::conv3_args a;
     a.X = x; a.Wt = w; a.bias = bias; a.Y = y; a.stats = stats; a.stats_slots = stats_slots;
-    a.H = H; a.W = W; a.wsh = W == 32 ? 5 : (W == 64 ? 6 : 7); a.Cs = Cs; a.N = N;
+    a.H = H; a.W = W; a.wsh = W == 16 ? 4 : (W == 32 ? 5 : (W == 64 ? 6 : 7)); a.Cs = Cs; a.N = N;
     const long long M = (long long)B * H * W;
     VBG_CHECK_ARG(M < (1ll << 31));
     a.M = (int)M; a.accumulate = accumulate;
-    dim3 g((unsigned)(M / 128), (unsigned)vbg::cdiv(N, 128), 1);
-    VBG_LAUNCH(vbg::conv3x3_kernel, g, dim3(256), 0, (hipStream_t)stream, a);
+    // 128-pixel tiles once they fill the chip (or the image does not divide into 64-pixel tiles any better), else 64-pixel tiles
+    const long long t128 = (M / 128) * vbg::cdiv(N, 128);
+    if (((long long)H * W) % 128 == 0 && (t128 >= 240 || W == 128)) {
+        VBG_LAUNCH(vbg::conv3x3_kernel<128>, dim3((unsigned)(M / 128), (unsigned)vbg::cdiv(N, 128), 1), dim3(256), 0, (hipStream_t)stream, a);
+    } else {
+        VBG_LAUNCH(vbg::conv3x3_kernel<64>, dim3((unsigned)(M / 64), (unsigned)vbg::cdiv(N, 128), 1), dim3(256), 0, (hipStream_t)stream, a);
+    }
     VBG_LAUNCH_RET();
 }
 

@@ -535,12 +535,17 @@ def set_conv3(on: bool):
     _CONV3[0] = bool(on)
 
 
+_CONV3_MIN_TILES = [int(os.environ.get("VBG_CONV3_MIN_TILES", "480"))]
+
+
 def conv3_ok(B, H, W, Cs, N, kh, kw, stride, pad) -> bool:
-    """shapes the row-reuse kernel takes: whole image rows per 128-pixel tile, full 128-wide column tiles and enough of them to
-    fill the chip (the small late-stage convolutions stay on the 64 x 64 tiles of the generic kernel); default split form only"""
-    return (_CONV3[0] and _SPLIT3[0] and not _AMP[0] and kh == 3 and kw == 3 and stride == 1 and pad == 1 and W in (32, 64, 128)
-            and (H * W) % 128 == 0 and Cs % 16 == 0 and N % 128 == 0 and H * W * Cs < (1 << 29)
-            and (B * H * W // 128) * (N // 128) >= 240)
+    """shapes the row-reuse kernel takes: whole image rows per pixel tile, full 128-wide column tiles and at least 480 64-pixel tiles
+    (= 240 of the 128-pixel tiles the kernel then uses).  Below that the kernel would run 64-pixel tiles, one 4-wave workgroup per CU:
+    measured level with the generic 64 x 64 tiles (70 vs 72 us forward at 256 channels, 32 x 32 pixels) and behind them once the filter
+    has to be turned for the input gradient (84 vs 74 us) -- the late stages stay on the generic kernel; default split form only"""
+    return (_CONV3[0] and _SPLIT3[0] and not _AMP[0] and kh == 3 and kw == 3 and stride == 1 and pad == 1 and W in (16, 32, 64, 128)
+            and (H * W) % 64 == 0 and Cs % 16 == 0 and N % 128 == 0 and H * W * Cs < (1 << 29)
+            and (B * H * W // 64) * (N // 128) >= _CONV3_MIN_TILES[0])
 
 
 def conv3x3(x, w_ohwi, bias=None, out=None, stats=None, accumulate=False):
