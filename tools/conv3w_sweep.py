@@ -13,7 +13,7 @@ from vbg import lib, ops
 
 dev = torch.device("cuda")
 out = []
-for (B, H, W, Ci, Co) in [(8, 128, 128, 256, 256), (8, 128, 128, 128, 128), (8, 64, 64, 128, 128), (8, 32, 32, 256, 256), (8, 16, 16, 512, 512)]:
+for (B, H, W, Ci, Co) in [(8, 128, 128, 64, 64), (8, 128, 128, 256, 256), (8, 128, 128, 128, 128), (8, 64, 64, 128, 128), (8, 32, 32, 256, 256), (8, 16, 16, 512, 512)]:
     x = torch.randn(B, H, W, Ci, device=dev)
     dy = torch.randn(B, H, W, Co, device=dev)
     dw = torch.zeros(Co, 3, 3, Ci, device=dev)
