@@ -901,8 +901,35 @@ class SelectedCEFn(torch.autograd.Function):
 # a training forward and its backward (or a second model under a different autocast setting) cannot switch the backward's
 # products to another form.
 # ----------------------------------------------------------------------------------------------
+class _NoGradCtx:
+    """stand-in for the autograd context when grad mode is off (inference / validation): nothing is saved, nothing needs a gradient"""
+    needs_input_grad = (False,) * 64
+
+    def save_for_backward(self, *tensors):
+        pass
+
+    def mark_non_differentiable(self, *tensors):
+        pass
+
+    def mark_dirty(self, *tensors):
+        pass
+
+    def set_materialize_grads(self, value):
+        pass
+
+
 def _pin_arithmetic(cls):
     fwd, bwd = cls.forward, cls.backward
+    graph_apply = cls.apply
+
+    def apply(*args):
+        # grad mode off: the forward runs directly -- torch.autograd.Function.apply costs ~15 us of host time per call (72 calls in a
+        # single-document inference, which is host-bound) and would record nothing
+        if not torch.is_grad_enabled():
+            return fwd(_NoGradCtx(), *args)
+        return graph_apply(*args)
+
+    cls.apply = staticmethod(apply)
 
     def forward(ctx, *a, **k):
         ctx._vbg_form = (ops.amp_enabled(), ops.precision())
