@@ -320,7 +320,7 @@ class FlatReducer:
         self._complete = set()
         self._next = 0             # position in `order` of the next bucket to issue
         self._stage = None         # stream the collectives are issued from
-        self._streams = set()      # compute streams gradients were reported from in this step
+        self._streams = {}         # raw handle -> torch stream: compute streams gradients were reported from in this step
         if not self.enabled:
             return
         if sync_bn_group == "new":
@@ -368,6 +368,13 @@ class FlatReducer:
             self._reported.add(id(p))
             self._ready(idx)
 
+    def _note_stream(self, dev):
+        """remember the stream a gradient was reported from (hundreds of reports per step: the raw handle is two C calls, the torch
+        stream object is only built for a handle not seen yet in this step)"""
+        raw = ops.raw_stream(dev)
+        if raw not in self._streams:
+            self._streams[raw] = torch.cuda.current_stream(dev)
+
     def _issue(self, idx):
         buf = self.buckets[idx][0]
         if not buf.is_cuda:
@@ -379,8 +386,8 @@ class FlatReducer:
         dev = buf.device
         if self._stage is None:
             self._stage = torch.cuda.Stream(device=dev)
-        self._streams.add(torch.cuda.current_stream(dev))
-        for s in list(self._streams) + [t for t in ops.side_streams() if t.device == dev]:
+        self._note_stream(dev)
+        for s in list(self._streams.values()) + [t for t in ops.side_streams() if t.device == dev]:
             self._stage.wait_stream(s)
         with torch.cuda.stream(self._stage):
             self.handles.append(dist.all_reduce(buf, group=self.pg, async_op=True))
@@ -388,7 +395,7 @@ class FlatReducer:
     def _ready(self, idx):
         b = self.buckets[idx]
         if b[0].is_cuda:
-            self._streams.add(torch.cuda.current_stream(b[0].device))
+            self._note_stream(b[0].device)
         b[2] -= 1
         assert b[2] >= 0, "a gradient was reported twice: the bucket would be reduced before it is complete"
         if b[2] != 0:
