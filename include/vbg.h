@@ -203,7 +203,7 @@ int vbg_colsum(const float* x, long long ld, int M, int N, float* out, int accum
  * (csrc/conv3.hip): y[B,H,W,N] (+)= conv(x[B,H,W,Cs], w[N,3,3,Cs]) (+ bias); stats: BatchNorm slot workspace [slots][2][N] fp64 that
  * receives the per-channel sum / sum of squares of y (not with accumulate).  Replaces torch.nn.Conv2d(k=3, s=1, p=1) forward
  * (model/ResNetFPN_ViBERTgrid.py:478-508, 612-648; model/semantic_segmentation_head.py) and, with the filter written by
- * vbg_conv3x3_wflip, its input gradient.  Requires W in {32, 64, 128}, H*W % 128 == 0, Cs % 16 == 0, N % 4 == 0. */
+ * vbg_conv3x3_wflip, its input gradient.  Requires W a power of two >= 16, H*W % 64 == 0, Cs % 16 == 0, N % 4 == 0. */
 int vbg_conv3x3(const float* x, const float* w, const float* bias, float* y, double* stats, int stats_slots, int B, int H, int W,
                 int Cs, int N, int accumulate, void* stream);
 /* out[ci][2-kh][2-kw][co] = w[co][kh][kw][ci]: the filter with which the input gradient of a 3x3 / s1 / p1 convolution is the

@@ -194,7 +194,9 @@ def test_conv(ops, Cin, Cout, k, stride, pad, H, W):
 
 @pytest.mark.parametrize("B,H,W,Cs,N", [(2, 8, 128, 32, 128), (3, 4, 64, 48, 136), (2, 8, 32, 16, 256), (1, 128, 128, 64, 128),
                                         # 64-pixel tiles (few pixels): two / four image rows per tile
-                                        (3, 6, 32, 32, 128), (2, 12, 16, 32, 256), (8, 32, 32, 64, 256)])
+                                        (3, 6, 32, 32, 128), (2, 12, 16, 32, 256), (8, 32, 32, 64, 256),
+                                        # rows wider than a tile: the neighbouring pixels are fetched into the halo rows
+                                        (2, 5, 256, 32, 128), (1, 3, 512, 16, 132)])
 def test_conv3x3_row_reuse(ops, B, H, W, Cs, N):
     """csrc/conv3.hip (activation rows shared by the three horizontal taps) against fp64 torch conv2d: forward with bias and fused
     BatchNorm statistics, accumulate, the input gradient through the turned filter; and against the generic implicit GEMM (same

@@ -4,7 +4,7 @@
 // model/semantic_segmentation_head.py conv stacks, torch.nn.Conv2d(k=3, s=1, p=1)), the generic implicit GEMM of gemm.hip, whose
 // k-loop fetches and splits the 128 x 16 activation tile once per filter tap: nine times per (row of taps x channel chunk).  Every
 // matrix kernel of this library levels off where a CU ingests ~12.5 B / clk from L2, so the lever is bytes per
-// product.  Here an output tile is 128 consecutive pixels = whole image rows (W in {32, 64, 128}); for a filter row kh and a chunk
+// product.  Here an output tile is 128 consecutive pixels = whole image rows (W <= 128) or a piece of one row; for a filter row kh and a chunk
 // of 16 input channels the source row y + kh - 1 is loaded and split ONCE into an LDS image that carries one zero pixel on either
 // side of each image row, and the three taps kw = 0, 1, 2 read their MFMA fragments from it at row offsets 0, 1, 2 (a uniform
 // shift keeps the bank pattern of the [row][16 + 8] bf16 layout).  Activation traffic and split work per tap drop to a third;
@@ -116,12 +116,20 @@ __global__ __launch_bounds__(256, 2) void conv3x3_kernel(const conv3_args p) {
         const int r = (tid + i * NT) >> 2;
         bvo[i] = (n0 + r < N) ? (unsigned)((r * K + kc) * 4) : C3_INVALID;
     }
+    // image rows wider than the tile (W = 256, 512, ...: the tile is a piece of ONE row): the pixels left and right of it are real
+    // pixels, not padding -- eight lanes fetch them per super-tile into the two halo rows of the LDS image
+    const bool wide = W > BM;
+    const int h_side = (tid >> 2) & 1, h_x = (p0 & (W - 1)) + (h_side ? BM : -1), h_y = p0 >> wsh, h_row = h_side ? BM + 1 : 0;
+    unsigned hvo = C3_INVALID;
+    float4 rh = make_float4(0.f, 0.f, 0.f, 0.f);
     auto set_a = [&](int kh) {
 #pragma unroll
         for (int i = 0; i < NAI; ++i) {
             const int sy = a_y[i] + kh - 1;
             avo[i] = ((unsigned)sy < (unsigned)H) ? (unsigned)(((sy * W + a_x[i]) * Cs + kc) * 4) : C3_INVALID;
         }
+        const int sy = h_y + kh - 1;
+        hvo = (wide && tid < 8 && (unsigned)sy < (unsigned)H && (unsigned)h_x < (unsigned)W) ? (unsigned)(((sy * W + h_x) * Cs + kc) * 4) : C3_INVALID;
     };
     const float* const wbase = p.Wt + (long long)n0 * K;
     float4 ra[NAI], rb[2];
@@ -131,6 +139,7 @@ __global__ __launch_bounds__(256, 2) void conv3x3_kernel(const conv3_args p) {
         const __amdgpu_buffer_rsrc_t r = c3_rsrc(a_img + a_c0);
 #pragma unroll
         for (int i = 0; i < NAI; ++i) ra[i] = c3_load(r, avo[i]);
+        if (wide) rh = c3_load(r, hvo);
         a_c0 += 16;
         if (a_c0 >= Cs) { a_c0 = 0; ++a_kh; set_a(a_kh); }
     };
@@ -155,6 +164,7 @@ __global__ __launch_bounds__(256, 2) void conv3x3_kernel(const conv3_args p) {
     auto store_a = [&](int buf) {
 #pragma unroll
         for (int i = 0; i < NAI; ++i) store4(As + buf * ASZ, PA, a_lrow[i], ra[i]);
+        if (wide && tid < 8) store4(As + buf * ASZ, PA, h_row, rh);
     };
     auto store_b = [&](int buf) {
         store4(Bs + buf * BSZ, PB, tid >> 2, rb[0]);
@@ -558,20 +568,20 @@ extern "C" int vbg_conv3x3_wgrad(const float* dy, const float* x, float* dw, flo
 extern "C" int vbg_conv3x3(const float* x, const float* w, const float* bias, float* y, double* stats, int stats_slots, int B, int H,
                            int W, int Cs, int N, int accumulate, void* stream) {
     VBG_CHECK_ARG(x && w && y && B > 0 && H > 0);
-    VBG_CHECK_ARG(W == 16 || W == 32 || W == 64 || W == 128);
+    VBG_CHECK_ARG(W >= 16 && W <= 4096 && (W & (W - 1)) == 0);
     VBG_CHECK_ARG(((long long)H * W) % 64 == 0 && (long long)H * W * Cs < (1ll << 29));
     VBG_CHECK_ARG(Cs >= 16 && Cs % 16 == 0 && N >= 4 && N % 4 == 0);
     VBG_CHECK_ARG((((uintptr_t)x) & 15) == 0 && (((uintptr_t)w) & 15) == 0 && (((uintptr_t)y) & 15) == 0);
     VBG_CHECK_ARG(!stats || (stats_slots >= 1 && !accumulate));
     vbg::conv3_args a;
     a.X = x; a.Wt = w; a.bias = bias; a.Y = y; a.stats = stats; a.stats_slots = stats_slots;
-    a.H = H; a.W = W; a.wsh = W == 16 ? 4 : (W == 32 ? 5 : (W == 64 ? 6 : 7)); a.Cs = Cs; a.N = N;
+    a.H = H; a.W = W; a.wsh = 31 - __builtin_clz((unsigned)W); a.Cs = Cs; a.N = N;
     const long long M = (long long)B * H * W;
     VBG_CHECK_ARG(M < (1ll << 31));
     a.M = (int)M; a.accumulate = accumulate;
     // 128-pixel tiles once they fill the chip (or the image does not divide into 64-pixel tiles any better), else 64-pixel tiles
     const long long t128 = (M / 128) * vbg::cdiv(N, 128);
-    if (((long long)H * W) % 128 == 0 && (t128 >= 240 || W == 128)) {
+    if (((long long)H * W) % 128 == 0 && (t128 >= 240 || W >= 128)) {
         VBG_LAUNCH(vbg::conv3x3_kernel<128>, dim3((unsigned)(M / 128), (unsigned)vbg::cdiv(N, 128), 1), dim3(256), 0, (hipStream_t)stream, a);
     } else {
         VBG_LAUNCH(vbg::conv3x3_kernel<64>, dim3((unsigned)(M / 64), (unsigned)vbg::cdiv(N, 128), 1), dim3(256), 0, (hipStream_t)stream, a);

@@ -551,7 +551,7 @@ def conv3_ok(B, H, W, Cs, N, kh, kw, stride, pad) -> bool:
     (= 240 of the 128-pixel tiles the kernel then uses).  Below that the kernel would run 64-pixel tiles, one 4-wave workgroup per CU:
     measured level with the generic 64 x 64 tiles (70 vs 72 us forward at 256 channels, 32 x 32 pixels) and behind them once the filter
     has to be turned for the input gradient (84 vs 74 us) -- the late stages stay on the generic kernel; default split form only"""
-    return (_CONV3[0] and _SPLIT3[0] and not _AMP[0] and kh == 3 and kw == 3 and stride == 1 and pad == 1 and W in (16, 32, 64, 128)
+    return (_CONV3[0] and _SPLIT3[0] and not _AMP[0] and kh == 3 and kw == 3 and stride == 1 and pad == 1 and W in (16, 32, 64, 128, 256, 512, 1024)
             and (H * W) % 64 == 0 and Cs % 16 == 0 and N % 128 == 0 and H * W * Cs < (1 << 29)
             and (B * H * W // 64) * (N // 128) >= _CONV3_MIN_TILES[0])
 
