@@ -32,6 +32,25 @@ def test_argument_errors_do_not_need_a_gpu():
     assert L.lib.vbg_sgd_step(None, None, None, 0, 0.1, 0.9, 0.0, 1, 1.0, None) == 0      # n == 0 is a no-op
 
 
+def test_conv3_host_logic_without_a_gpu():
+    """csrc/conv3.hip entry points: shapes outside the kernels' geometry are argument errors (no launch), and the strip count of the
+    weight gradient gives whole rounds of workgroups with at least 8 k-tiles per strip on the cfg2 shapes"""
+    from vbg import lib as L
+    f = L.lib.vbg_conv3x3
+    assert f(None, None, None, None, None, 0, 1, 16, 128, 16, 128, 0, None) == -1            # null operands
+    strips = L.lib.vbg_conv3x3_wgrad_strips
+    for (B, H, W, Cs, Cout, blocks) in [(8, 128, 128, 256, 256, 512), (8, 128, 128, 128, 128, 256), (8, 64, 64, 128, 128, 256),
+                                        (8, 32, 32, 256, 256, 256), (8, 16, 16, 512, 512, 256)]:
+        s = strips(B, H, W, Cs, Cout)
+        tiles = (Cout // 128) * (Cs // 32)
+        nchunks = B * H * W // 16
+        assert s >= 1 and s * tiles == blocks, (B, H, W, Cs, Cout, s)
+        assert nchunks // s >= 8
+    assert strips(1, 4, 16, 32, 128) == 1                                                    # 4 chunks: one strip
+    assert L.lib.vbg_conv3x3_wgrad(None, None, None, None, 1, 16, 16, 32, 128, None) == -1
+    assert L.lib.vbg_conv3x3_wflip(None, 1, 1, None, None) == -1
+
+
 def test_gemm_desc_layout_matches_header():
     import ctypes as C
     from vbg.lib import GemmDesc, ConvGeo
