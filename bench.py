@@ -240,8 +240,9 @@ def main():
             clip_grad_norm_(opts, 2.0, 1.0 / world)
         opt_cnn.step()
         opt_bert.step()
-        if world > 1:
-            dist.barrier()
+        # (no per-step barrier: like the reference's DDP loop, ranks meet in the gradient all-reduce -- and here in the host-side
+        #  clipping decision --; a barrier would drain the GPU queue every step and take away the host's run-ahead.  The timed region
+        #  itself is bracketed by barrier + synchronize.)
         return val
 
     for _ in range(args.warmup):
