@@ -284,6 +284,21 @@ class ConvFn(torch.autograd.Function):
         return dx, dw, db, None, None
 
 
+def _frozen_invstd(running_var, eps):
+    """1 / sqrt(running_var + eps) of a BatchNorm that uses its frozen statistics (eval mode), computed once per version of the buffer:
+    two tiny torch launches per layer and call otherwise -- 76 of the ~210 launches of a single-document inference.  The cache lives on
+    the buffer object and is keyed by its version counter (load_state_dict), the library's own update counter (the training kernels
+    write the running statistics behind torch's back), its address and eps."""
+    tag = (running_var._version, ops.bn_epoch(), running_var.data_ptr(), float(eps))
+    hit = running_var.__dict__.get("_vbg_invstd")
+    if hit is not None and hit[0] == tag:
+        return hit[1]
+    with torch.no_grad():
+        inv = torch.rsqrt(running_var + eps)
+    running_var.__dict__["_vbg_invstd"] = (tag, inv)
+    return inv
+
+
 class ConvBnFn(torch.autograd.Function):
     """conv (bias-free) -> BatchNorm2d (batch statistics in training, SyncBN-able) -> (+ residual) -> ReLU."""
 
@@ -310,7 +325,7 @@ class ConvBnFn(torch.autograd.Function):
             else:
                 mean, invstd = ops.bn_finalize(stats, C, ops.bn_slots(), count, eps, momentum, running_mean, running_var)
         else:
-            mean, invstd, count, count_dev = running_mean, torch.rsqrt(running_var + eps), float(M), None
+            mean, invstd, count, count_dev = running_mean, _frozen_invstd(running_var, eps), float(M), None
         r2 = None if res is None else _c(res).view(-1, C)
         y = ops.bn_apply(z2, r2, mean, invstd, gamma, beta, relu).view(z.shape)
         ctx.cfg = (stride, pad, relu, training, count, res is not None, sync)

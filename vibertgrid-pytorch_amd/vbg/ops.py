@@ -929,7 +929,17 @@ def bn_finalize(stats, C_, nslots, count, eps, momentum, running_mean, running_v
     invstd = torch.empty_like(mean)
     check(lib.vbg_bn_finalize(P(stats), int(nslots), int(nslots > 1), float(count), P(count_dev), C_, eps, momentum, P(mean), P(invstd),
                               P(running_mean), P(running_var), _stream()), "vbg_bn_finalize")
+    if running_var is not None:
+        _BN_EPOCH[0] += 1              # the kernel wrote the running statistics behind torch's version counters
     return mean, invstd
+
+
+_BN_EPOCH = [0]
+
+
+def bn_epoch() -> int:
+    """bumped whenever a kernel of this library updated BatchNorm running statistics in place (caches derived from them are stale)"""
+    return _BN_EPOCH[0]
 
 
 def bn_apply(x2d, res2d, mean, invstd, gamma, beta, relu, out=None):
