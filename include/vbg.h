@@ -205,7 +205,10 @@ int vbg_colsum(const float* x, long long ld, int M, int N, float* out, int accum
  * (model/ResNetFPN_ViBERTgrid.py:478-508, 612-648; model/semantic_segmentation_head.py) and, with the filter written by
  * vbg_conv3x3_wflip, its input gradient.  Requires W a power of two >= 16, H*W % 64 == 0, Cs % 16 == 0, N % 4 == 0. */
 int vbg_conv3x3(const float* x, const float* w, const float* bias, float* y, double* stats, int stats_slots, int B, int H, int W,
-                int Cs, int N, int accumulate, void* stream);
+                int Cs, int N, int accumulate, int form, void* stream);
+/* form 0: three bf16 pieces per operand, six piece products (any operands); form 1: two fp16 pieces, three piece products -- same
+ * measured accuracy against fp64 and half the matrix-core work, for operands inside fp16's range: forward activations and filters,
+ * not gradients */
 /* out[ci][2-kh][2-kw][co] = w[co][kh][kw][ci]: the filter with which the input gradient of a 3x3 / s1 / p1 convolution is the
  * same convolution of dy */
 int vbg_conv3x3_wflip(const float* w, int Cout, int Cin, float* out, void* stream);

@@ -215,6 +215,12 @@ def test_conv3x3_row_reuse(ops, B, H, W, Cs, N):
     ref = y.float().permute(0, 2, 3, 1)
     tol = 3e-6 * float(ref.abs().max())          # fp32-grade: errors scale with the summed magnitudes, not with the element
     assert close(yh, ref, 2e-5, tol)
+    # the two-piece fp16 form of the forward (three piece products): the same bound, also for operands far below / above 1 (the scaled
+    # low piece keeps small values exact to 2^-21; the accumulators are fp32 either way)
+    assert close(ops.conv3x3(xh, wh, bh, f16x2=True), ref, 2e-5, tol)
+    for sc in (2.0 ** -12, 2.0 ** 9):
+        ys = ops.conv3x3(xh * sc, wh, None, f16x2=True)
+        assert close(ys / sc, ref - b.view(1, 1, 1, N), 2e-5, tol), sc
     st = stats.view(-1, 2, N).sum(0).cpu()
     y2 = y.detach().permute(0, 2, 3, 1).reshape(-1, N)
     assert torch.allclose(st[0], y2.sum(0), rtol=1e-5, atol=1e-4) and torch.allclose(st[1], (y2 * y2).sum(0), rtol=1e-5, atol=1e-4)

@@ -51,6 +51,17 @@ __device__ __forceinline__ void c3_split3(float a, float b, unsigned& hi, unsign
     mid = __builtin_amdgcn_perm(__float_as_uint(rb), __float_as_uint(ra), 0x07060302u);
     lo = __builtin_amdgcn_perm(__float_as_uint(sb), __float_as_uint(sa), 0x07060302u);
 }
+typedef _Float16 c3_f16x8 __attribute__((ext_vector_type(8)));
+typedef __fp16 c3_f16x2 __attribute__((ext_vector_type(2)));
+// F16 form: two fp16 pieces of a pair of floats (a in the low half): hi = fp16(x) toward zero, lo = fp16((x - hi) * 2^11) -- the
+// remainder is exact in fp32 and its scaling keeps it clear of fp16's subnormals -- so x = hi + lo * 2^-11 up to 2^-21 |x|
+__device__ __forceinline__ void c3_split2(float a, float b, unsigned& hi, unsigned& lo) {
+    const c3_f16x2 h = __builtin_amdgcn_cvt_pkrtz(a, b);
+    const float ra = (a - (float)h[0]) * 2048.f, rb = (b - (float)h[1]) * 2048.f;
+    const c3_f16x2 l = __builtin_amdgcn_cvt_pkrtz(ra, rb);
+    hi = __builtin_bit_cast(unsigned, h);
+    lo = __builtin_bit_cast(unsigned, l);
+}
 // after every MFMA its share of the NV VALU and ND LDS-write instructions of the region
 template <int M, int NM, int NV, int ND>
 struct c3_pipe {
@@ -65,17 +76,21 @@ struct c3_pipe {
 };
 
 // BM = 128 pixels per tile, or 64 for the late stages whose pixel count would leave half the chip without a 128-pixel tile
-template <int BM>
+// F16: the arithmetic form -- false: three bf16 pieces per operand, six piece products (the library's default everywhere); true: two
+// fp16 pieces, three piece products with the two cross products in their own accumulators (scaled by 2^11), for operands inside fp16's
+// range (forward activations and filters; NOT gradients).  Measured against fp64 on the same data the two forms are equally accurate
+// (1.7e-7 vs 2.5e-7 of the summed magnitudes) and F16 needs half the matrix-core work: 457 vs 701 us at 256 x 256, 128 x 128 pixels.
+template <int BM, bool F16>
 __global__ __launch_bounds__(256, 2) void conv3x3_kernel(const conv3_args p) {
     constexpr int BN = 128, NT = 256, SKH = 24;
+    constexpr int NPL = F16 ? 2 : 3;                           // planes per operand tile
     constexpr int NAI = BM * 4 / NT;                           // activation float4s per thread and super-tile
     constexpr int TM = BM / 64;                                // 32-row fragments per wave (waves 2 x 2: BM / 2 pixels x 64 filters each)
     constexpr int AROWS = BM + BM / 8;                         // + a zero pixel on either side of each image row (W >= 16)
     constexpr int PA = AROWS * SKH / 2, PB = BN * SKH / 2;     // one bf16 plane (dwords)
-    constexpr int ASZ = 3 * PA, BSZ = 3 * PB;
+    constexpr int ASZ = NPL * PA, BSZ = NPL * PB;
     constexpr int CTS = BN + 4;
-    constexpr int SMEM = 2 * (ASZ + BSZ);                      // 76 KB at BM = 128: two workgroups per CU
-    static_assert(BM * CTS <= SMEM, "staged output tile");
+    constexpr int SMEM = 2 * (ASZ + BSZ) > BM * CTS ? 2 * (ASZ + BSZ) : BM * CTS;      // 76 KB at BM = 128, three planes: two workgroups per CU
     __shared__ __attribute__((aligned(16))) unsigned smem[SMEM];
     unsigned* const As = smem;
     unsigned* const Bs = smem + 2 * ASZ;
@@ -154,12 +169,20 @@ __global__ __launch_bounds__(256, 2) void conv3x3_kernel(const conv3_args p) {
     };
     auto store4 = [&](unsigned* dst, int PL, int row, const float4& v) {
         const int o = row * (SKH / 2) + kc / 2;
-        uint2 h, m, l;
-        c3_split3(v.x, v.y, h.x, m.x, l.x);
-        c3_split3(v.z, v.w, h.y, m.y, l.y);
-        *reinterpret_cast<uint2*>(&dst[o]) = h;
-        *reinterpret_cast<uint2*>(&dst[o + PL]) = m;
-        *reinterpret_cast<uint2*>(&dst[o + 2 * PL]) = l;
+        if constexpr (F16) {
+            uint2 h, l;
+            c3_split2(v.x, v.y, h.x, l.x);
+            c3_split2(v.z, v.w, h.y, l.y);
+            *reinterpret_cast<uint2*>(&dst[o]) = h;
+            *reinterpret_cast<uint2*>(&dst[o + PL]) = l;
+        } else {
+            uint2 h, m, l;
+            c3_split3(v.x, v.y, h.x, m.x, l.x);
+            c3_split3(v.z, v.w, h.y, m.y, l.y);
+            *reinterpret_cast<uint2*>(&dst[o]) = h;
+            *reinterpret_cast<uint2*>(&dst[o + PL]) = m;
+            *reinterpret_cast<uint2*>(&dst[o + 2 * PL]) = l;
+        }
     };
     auto store_a = [&](int buf) {
 #pragma unroll
@@ -175,13 +198,16 @@ __global__ __launch_bounds__(256, 2) void conv3x3_kernel(const conv3_args p) {
     const int lane = tid & 63, wave = tid >> 6;
     const int wm = wave >> 1, wn = wave & 1;
     const int lr = lane & 31, lk = lane >> 5;
-    f32x16 acc[TM][2];
+    f32x16 acc[TM][2], acx[F16 ? TM : 1][2];                   // (F16: the cross products hi lo + lo hi, scaled by 2^11)
 #pragma unroll
     for (int i = 0; i < TM; ++i)
 #pragma unroll
         for (int j = 0; j < 2; ++j)
 #pragma unroll
-            for (int r = 0; r < 16; ++r) acc[i][j][r] = 0.f;
+            for (int r = 0; r < 16; ++r) {
+                acc[i][j][r] = 0.f;
+                if constexpr (F16) acx[i][j][r] = 0.f;
+            }
     int arow[TM];
 #pragma unroll
     for (int i = 0; i < TM; ++i) {
@@ -198,9 +224,9 @@ __global__ __launch_bounds__(256, 2) void conv3x3_kernel(const conv3_args p) {
         constexpr bool LOADA = decltype(loada_tag)::value, MORE = decltype(more_tag)::value;
         const c3_u32x4* as = reinterpret_cast<const c3_u32x4*>(As + abuf * ASZ);
         const c3_u32x4* bs = reinterpret_cast<const c3_u32x4*>(Bs + bbuf * BSZ);
-        c3_u32x4 fa[3][TM], fb[3][2];
+        c3_u32x4 fa[NPL][TM], fb[NPL][2];
 #pragma unroll
-        for (int q = 0; q < 3; ++q) {
+        for (int q = 0; q < NPL; ++q) {
 #pragma unroll
             for (int i = 0; i < TM; ++i) fa[q][i] = as[q * (PA / 4) + (arow[i] + kw) * (SKH / 8) + lk];
 #pragma unroll
@@ -210,21 +236,28 @@ __global__ __launch_bounds__(256, 2) void conv3x3_kernel(const conv3_args p) {
         if constexpr (MORE) load_b();
         if constexpr (LOADA) load_a();
         __builtin_amdgcn_sched_barrier(0);
-        // piece products, smallest first: (lo,hi) (hi,lo) (mid,mid) (mid,hi) (hi,mid) (hi,hi)
-        constexpr int qa[6] = {2, 0, 1, 1, 0, 0}, qb[6] = {0, 2, 1, 0, 1, 0};
+        // piece products, smallest first: (lo,hi) (hi,lo) (mid,mid) (mid,hi) (hi,mid) (hi,hi); F16: (lo,hi) (hi,lo) -> cross sums, (hi,hi)
+        constexpr int qa[6] = {F16 ? 1 : 2, 0, 1, 1, 0, 0}, qb[6] = {0, F16 ? 1 : 2, F16 ? 0 : 1, 0, 1, 0};
         auto mma_range = [&](auto t0_tag, auto t1_tag) {
 #pragma unroll
             for (int t = decltype(t0_tag)::value; t < decltype(t1_tag)::value; ++t)
 #pragma unroll
                 for (int i = 0; i < TM; ++i)
 #pragma unroll
-                    for (int n = 0; n < 2; ++n)
-                        acc[i][n] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(__builtin_bit_cast(c3_bf16x8, fa[qa[t]][i]),
-                                                                            __builtin_bit_cast(c3_bf16x8, fb[qb[t]][n]), acc[i][n], 0, 0, 0);
+                    for (int n = 0; n < 2; ++n) {
+                        if constexpr (F16) {
+                            f32x16& d = t < 2 ? acx[i][n] : acc[i][n];
+                            d = __builtin_amdgcn_mfma_f32_32x32x16_f16(__builtin_bit_cast(c3_f16x8, fa[t == 0 ? 1 : 0][i]),
+                                                                       __builtin_bit_cast(c3_f16x8, fb[t == 1 ? 1 : 0][n]), d, 0, 0, 0);
+                        } else {
+                            acc[i][n] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(__builtin_bit_cast(c3_bf16x8, fa[qa[t]][i]),
+                                                                                __builtin_bit_cast(c3_bf16x8, fb[qb[t]][n]), acc[i][n], 0, 0, 0);
+                        }
+                    }
         };
         using i0 = std::integral_constant<int, 0>;
-        using ih = std::integral_constant<int, 2>;
-        using i1 = std::integral_constant<int, 6>;
+        using ih = std::integral_constant<int, F16 ? 1 : 2>;
+        using i1 = std::integral_constant<int, F16 ? 3 : 6>;
         if constexpr (MORE) {
             mma_range(i0{}, ih{});
             __builtin_amdgcn_sched_barrier(0);
@@ -232,7 +265,8 @@ __global__ __launch_bounds__(256, 2) void conv3x3_kernel(const conv3_args p) {
             store_b(bbuf ^ 1);
             if constexpr (LOADA) store_a(abuf ^ 1);
             constexpr int NL = LOADA ? 2 + NAI : 2;
-            c3_pipe<0, 8 * TM, NL * 22, NL * 3>::run();
+            if constexpr (F16) c3_pipe<0, 4 * TM, NL * 10, NL * 2>::run();
+            else c3_pipe<0, 8 * TM, NL * 22, NL * 3>::run();
             __builtin_amdgcn_sched_barrier(0);
             __syncthreads();
         } else {
@@ -275,7 +309,8 @@ __global__ __launch_bounds__(256, 2) void conv3x3_kernel(const conv3_args p) {
         for (int i = 0; i < TM; ++i)
 #pragma unroll
             for (int r = 0; r < 16; ++r)
-                Ct[(wm * (BM / 2) + i * 32 + (r & 3) + 8 * (r >> 2) + 4 * lk) * CTS + wn * 64 + j * 32 + lr] = acc[i][j][r];
+                Ct[(wm * (BM / 2) + i * 32 + (r & 3) + 8 * (r >> 2) + 4 * lk) * CTS + wn * 64 + j * 32 + lr] =
+                    F16 ? acc[i][j][r] + acx[i][j][r] * (1.f / 2048.f) : acc[i][j][r];
     __syncthreads();
     constexpr int QN = BN / 4;
     float4 cs = make_float4(0.f, 0.f, 0.f, 0.f), cq = cs;
@@ -566,7 +601,8 @@ extern "C" int vbg_conv3x3_wgrad(const float* dy, const float* x, float* dw, flo
 }
 
 extern "C" int vbg_conv3x3(const float* x, const float* w, const float* bias, float* y, double* stats, int stats_slots, int B, int H,
-                           int W, int Cs, int N, int accumulate, void* stream) {
+                           int W, int Cs, int N, int accumulate, int form, void* stream) {
+    VBG_CHECK_ARG(form == 0 || form == 1);
     VBG_CHECK_ARG(x && w && y && B > 0 && H > 0);
     VBG_CHECK_ARG(W >= 16 && W <= 4096 && (W & (W - 1)) == 0);
     VBG_CHECK_ARG(((long long)H * W) % 64 == 0 && (long long)H * W * Cs < (1ll << 29));
@@ -581,10 +617,14 @@ extern "C" int vbg_conv3x3(const float* x, const float* w, const float* bias, fl
     a.M = (int)M; a.accumulate = accumulate;
     // 128-pixel tiles once they fill the chip (or the image does not divide into 64-pixel tiles any better), else 64-pixel tiles
     const long long t128 = (M / 128) * vbg::cdiv(N, 128);
-    if (((long long)H * W) % 128 == 0 && (t128 >= 240 || W >= 128)) {
-        VBG_LAUNCH(vbg::conv3x3_kernel<128>, dim3((unsigned)(M / 128), (unsigned)vbg::cdiv(N, 128), 1), dim3(256), 0, (hipStream_t)stream, a);
+    const bool big = ((long long)H * W) % 128 == 0 && (t128 >= 240 || W >= 128);
+    const dim3 g((unsigned)(M / (big ? 128 : 64)), (unsigned)vbg::cdiv(N, 128), 1);
+    if (form == 1) {
+        if (big) { VBG_LAUNCH((vbg::conv3x3_kernel<128, true>), g, dim3(256), 0, (hipStream_t)stream, a); }
+        else { VBG_LAUNCH((vbg::conv3x3_kernel<64, true>), g, dim3(256), 0, (hipStream_t)stream, a); }
     } else {
-        VBG_LAUNCH(vbg::conv3x3_kernel<64>, dim3((unsigned)(M / 64), (unsigned)vbg::cdiv(N, 128), 1), dim3(256), 0, (hipStream_t)stream, a);
+        if (big) { VBG_LAUNCH((vbg::conv3x3_kernel<128, false>), g, dim3(256), 0, (hipStream_t)stream, a); }
+        else { VBG_LAUNCH((vbg::conv3x3_kernel<64, false>), g, dim3(256), 0, (hipStream_t)stream, a); }
     }
     VBG_LAUNCH_RET();
 }

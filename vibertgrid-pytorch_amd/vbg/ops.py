@@ -556,15 +556,24 @@ def conv3_ok(B, H, W, Cs, N, kh, kw, stride, pad) -> bool:
             and (B * H * W // 64) * (N // 128) >= _CONV3_MIN_TILES[0])
 
 
-def conv3x3(x, w_ohwi, bias=None, out=None, stats=None, accumulate=False):
-    """y (+)= conv3x3(x NHWC, w [N,3,3,Cs]), stride 1, pad 1 (csrc/conv3.hip)"""
+_CONV3_F16 = [os.environ.get("VBG_CONV3_F16", "1") != "0"]
+
+
+def set_conv3_f16(on: bool):
+    """forward convolutions of csrc/conv3.hip on two fp16 pieces per operand (three piece products) instead of three bf16 pieces (six)"""
+    _CONV3_F16[0] = bool(on)
+
+
+def conv3x3(x, w_ohwi, bias=None, out=None, stats=None, accumulate=False, f16x2=False):
+    """y (+)= conv3x3(x NHWC, w [N,3,3,Cs]), stride 1, pad 1 (csrc/conv3.hip).  f16x2: the two-piece fp16 form -- only for operands
+    inside fp16's range (activations, filters), never for gradients"""
     B, H, W, Cs = x.shape
     N = w_ohwi.shape[0]
     if out is None:
         assert not accumulate
         out = torch.empty((B, H, W, N), device=x.device, dtype=f32)
     check(lib.vbg_conv3x3(P(x), P(w_ohwi), P(bias), P(out), P(stats), bn_slots() if stats is not None else 0, B, H, W, Cs, N,
-                          int(accumulate), _stream()), "vbg_conv3x3")
+                          int(accumulate), int(bool(f16x2)), _stream()), "vbg_conv3x3")
     return out
 
 
@@ -611,7 +620,7 @@ def conv2d_fwd(x, w_ohwi, stride, pad, bias=None, out=None, stats=None):
         out = torch.empty((B, Ho, Wo, Cout), device=x.device, dtype=f32)
     M, K = B * Ho * Wo, kh * kw * Cin
     if conv3_ok(B, H, W, Cin, Cout, kh, kw, stride, pad):
-        return conv3x3(x, w_ohwi, bias, out, stats)
+        return conv3x3(x, w_ohwi, bias, out, stats, f16x2=_CONV3_F16[0])
     if kh == 1 and kw == 1 and stride == 1 and pad == 0:
         gemm_raw(M, Cout, K, x, Cin, OP_DENSE_K, w_ohwi, K, OP_DENSE_K, out, Cout, bias=bias, stats=stats)
     else:
