@@ -82,7 +82,9 @@ def _worker(rank, world, port, tmp):
     dev = torch.device("cuda", 0)
     dist.init_process_group("gloo", rank=rank, world_size=world)
     from test_gpu_model import to_dev
+    from vbg import ops
     from vbg.optim import FlatReducer, FusedAdamW, FusedSGD, split_parameters
+    ops.set_conv3(False)        # (see the single-process half of the test: one kernel family on both sides)
     net = _build(os.path.join(tmp, f"rank{rank}"), sync_bn=True).to(dev).train()
     assert any(isinstance(m, torch.nn.SyncBatchNorm) for m in net.modules())
     cnn, bert = split_parameters(net)
@@ -126,12 +128,19 @@ def test_two_ranks_syncbn_equals_one_process(tmp_path):
     # the gradients after the exchange are the same tensor on both ranks
     for k in r0["grads"]:
         assert torch.equal(r0["grads"][k], r1["grads"][k]), k
-    # (i) one process, both documents, plain BatchNorm
+    # (i) one process, both documents, plain BatchNorm.  The row-reuse convolution kernels are chosen by problem size, so one document
+    # per rank and two documents in one process would run different kernel families (equal to ~3e-7, which this fixture's batch
+    # statistics over a handful of samples amplify a thousandfold): both sides use the generic kernels -- the test is about the exchange
+    from vbg import ops
     dev = torch.device("cuda")
     net = _build(os.path.join(tmp, "single"), sync_bn=False).to(dev).train()
     random.seed(5)
-    loss = net(*to_dev(_docs(), dev))
-    loss.backward()
+    ops.set_conv3(False)
+    try:
+        loss = net(*to_dev(_docs(), dev))
+        loss.backward()
+    finally:
+        ops.set_conv3(True)
     avg_loss = 0.5 * (r0["loss"] + r1["loss"])
     print("loss single", float(loss.detach()), "mean of ranks", avg_loss)
     assert abs(float(loss.detach()) - avg_loss) <= 1e-5 * abs(avg_loss)

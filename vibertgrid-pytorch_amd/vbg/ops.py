@@ -544,16 +544,18 @@ def set_conv3(on: bool):
 
 
 _CONV3_MIN_TILES = [int(os.environ.get("VBG_CONV3_MIN_TILES", "480"))]
+# the forward in its two-piece fp16 form also wins on 64-pixel tiles once they cover the chip (256 channels at 32 x 32 pixels: 59 vs 74 us)
+_CONV3_MIN_TILES_FWD = [int(os.environ.get("VBG_CONV3_MIN_TILES_FWD", "256"))]
 
 
-def conv3_ok(B, H, W, Cs, N, kh, kw, stride, pad) -> bool:
+def conv3_ok(B, H, W, Cs, N, kh, kw, stride, pad, fwd=False) -> bool:
     """shapes the row-reuse kernel takes: whole image rows per pixel tile, full 128-wide column tiles and at least 480 64-pixel tiles
     (= 240 of the 128-pixel tiles the kernel then uses).  Below that the kernel would run 64-pixel tiles, one 4-wave workgroup per CU:
     measured level with the generic 64 x 64 tiles (70 vs 72 us forward at 256 channels, 32 x 32 pixels) and behind them once the filter
     has to be turned for the input gradient (84 vs 74 us) -- the late stages stay on the generic kernel; default split form only"""
     return (_CONV3[0] and _SPLIT3[0] and not _AMP[0] and kh == 3 and kw == 3 and stride == 1 and pad == 1 and W in (16, 32, 64, 128, 256, 512, 1024)
             and (H * W) % 64 == 0 and Cs % 16 == 0 and N % 128 == 0 and H * W * Cs < (1 << 29)
-            and (B * H * W // 64) * (N // 128) >= _CONV3_MIN_TILES[0])
+            and (B * H * W // 64) * (N // 128) >= (_CONV3_MIN_TILES_FWD[0] if fwd and _CONV3_F16[0] else _CONV3_MIN_TILES[0]))
 
 
 _CONV3_F16 = [os.environ.get("VBG_CONV3_F16", "1") != "0"]
@@ -619,7 +621,7 @@ def conv2d_fwd(x, w_ohwi, stride, pad, bias=None, out=None, stats=None):
     if out is None:
         out = torch.empty((B, Ho, Wo, Cout), device=x.device, dtype=f32)
     M, K = B * Ho * Wo, kh * kw * Cin
-    if conv3_ok(B, H, W, Cin, Cout, kh, kw, stride, pad):
+    if conv3_ok(B, H, W, Cin, Cout, kh, kw, stride, pad, fwd=True):
         return conv3x3(x, w_ohwi, bias, out, stats, f16x2=_CONV3_F16[0])
     if kh == 1 and kw == 1 and stride == 1 and pad == 0:
         gemm_raw(M, Cout, K, x, Cin, OP_DENSE_K, w_ohwi, K, OP_DENSE_K, out, Cout, bias=bias, stats=stats)
