@@ -378,9 +378,9 @@ def main():
             "dtype": "bf16" if args.amp else "f32", "data": "synthetic",
             "arithmetic": ("bf16 MFMA products of fp32 tensors, f32 accumulate" if args.amp else
                            "f32 MFMA for every product" if args.fp32_mfma else
-                           "fp32-grade: exact 3-way bf16 split of every operand, 6 bf16 MFMA piece products per product, f32 accumulate, fused attention included (only the short-reduction conv weight gradients and the unaligned stem run on the f32 MFMA)"),
+                           "fp32-grade: exact 3-way bf16 split of every operand, 6 bf16 MFMA piece products per product, f32 accumulate, fused attention included; the forward of the wide 3x3 convolutions as 2 fp16 pieces per operand / 3 piece products (same measured error against fp64); the 64-filter and strided conv weight gradients and the unaligned stem on the f32 MFMA"),
             "config": {"workload": ("SROIE line-level cfg2: resnet_34_fpn_pretrained + bert-base-uncased (12L, vocab 30522, random init), "
-                                    "512x512, T=512 tokens, S=128 segments, batch 8/GPU, fwd+bwd+SGD/AdamW, dropout 0.1, simp classifier")
+                                    f"512x512, T=512 tokens, S=128 segments, batch {B}/GPU, fwd+bwd+SGD/AdamW, dropout 0.1, simp classifier")
                        if args.shape == "cfg2" else f"EXPLORATORY {args.shape}: {shape}, T=512, batch {B}/GPU (not the BASELINE metric's configuration)",
                        "global_batch": B * world, "seq_len": 512, "parallelism": f"dp{world}" + ("+syncbn" if sync_bn else ""),
                        "last_loss": round(float(last), 4), **({"ranks_in_sync": ranks_in_sync} if ranks_in_sync is not None else {}), **({"h2d_in_step": packed_src.nbytes()} if args.h2d else {})},
