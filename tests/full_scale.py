@@ -35,6 +35,11 @@ CASES["cfg2p"] = dict(CASES["cfg2"], plain=True)
 # gradients by 3-5e-4 instead of 6e-3 (measured, tests/golden/make_golden.py::gen_full), which lets EVERY parameter gradient of
 # the full-size model be held to 1e-3.
 CASES["cfg2e"] = dict(CASES["cfg2"], plain=True, bn_frozen=True)
+# the same "every parameter gradient at 1e-3" setup for the other two model families: the char-level / 12-class / own-layout
+# resnet-34 model of configs[3] and the RoBERTa (position offset, one token type, eps 1e-5) / 1024 x 1024 (wide-row convolution
+# paths) model of configs[4]
+CASES["cfg4e"] = dict(CASES["cfg4"], plain=True, bn_frozen=True)
+CASES["cfg5e"] = dict(CASES["cfg5"], plain=True, bn_frozen=True)
 # parameters whose gradients are stored as strided samples (the norms of ALL parameter gradients are stored too)
 GRAD_PICK = ["bert_model.embeddings.word_embeddings.weight", "bert_model.encoder.layer.0.attention.self.query.weight",
              "bert_model.encoder.layer.5.intermediate.dense.weight", "bert_model.encoder.layer.11.output.dense.weight",

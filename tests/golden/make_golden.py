@@ -739,6 +739,22 @@ def gen_full(V, tmp, name):
             vals.append(float((a.double() - b).norm() / (a.double().norm() + 1e-30)))
         out["ulpnoise_keys"], out["ulpnoise_vals"] = np.array(keys), np.array(vals)
         print(name, "1-ulp gradient noise: median", float(np.median(vals)), "max", float(np.max(vals)))
+        # ... and of the eval-mode outputs: the same one-ulp move of the weights on the freshly reloaded state (the train steps
+        # above moved the BatchNorm running statistics), sampled like pred_mask / pred_ss / pred above
+        net.zero_grad()
+        load_synth(net)
+        gen = torch.Generator().manual_seed(1)
+        with torch.no_grad():
+            for k, p in net.named_parameters():
+                if not k.startswith("BERTgrid_generator."):
+                    p.mul_(1 + 1.2e-7 * torch.randn(p.shape, generator=gen))
+        net.eval()
+        random.seed(7)
+        with torch.no_grad():
+            _, pm1, ps1, _, pred1 = net(imgs, segs, classes, coors, corpus, mask)
+        out.update(pred_1ulp=pred1, pred_mask_1ulp=pm1[:, :, 5::16, 3::16], pred_ss_1ulp=ps1[:, :, 5::16, 3::16])
+        for nm, a, b in (("pred_mask", pm, pm1), ("pred_ss", ps, ps1), ("pred", pred, pred1)):
+            print(name, nm, "1-ulp output noise: max abs", float((a - b).abs().max()), "of max |ref|", float(a.abs().max()))
     out["keys"] = np.array(list(shapes_of(net).keys()))
     out["key_shapes"] = np.array([str(v) for v in shapes_of(net).values()])
     npz(f"full_{name}.npz", **out)
@@ -758,7 +774,7 @@ def main():
     import pipeline.custom_loss as L
     import pipeline.transform as T
 
-    which = sys.argv[1:] or ["transform", "windows", "aggregate", "scatter", "losses", "labels", "bert", "backbone", "backbone_d", "e2e", "e2e_roberta", "losses_bce", "e2e_modes", "e2e_amp", "full_cfg2", "full_cfg4", "full_cfg5", "full_cfg2p", "full_cfg2e"]
+    which = sys.argv[1:] or ["transform", "windows", "aggregate", "scatter", "losses", "labels", "bert", "backbone", "backbone_d", "e2e", "e2e_roberta", "losses_bce", "e2e_modes", "e2e_amp", "full_cfg2", "full_cfg4", "full_cfg5", "full_cfg2p", "full_cfg2e", "full_cfg4e", "full_cfg5e"]
     if "transform" in which:
         gen_transform(T)
     if "windows" in which:
@@ -787,7 +803,7 @@ def main():
         gen_e2e_modes(V, tmp)
     if "e2e_amp" in which:
         gen_e2e_amp(V, tmp)
-    for name in ("cfg2", "cfg4", "cfg5", "cfg2p", "cfg2e"):
+    for name in ("cfg2", "cfg4", "cfg5", "cfg2p", "cfg2e", "cfg4e", "cfg5e"):
         if "full_" + name in which:
             gen_full(V, tmp, name)
 

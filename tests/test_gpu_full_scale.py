@@ -86,8 +86,23 @@ def _check_eval(g, c, net, dbatch, name, loss_tol):
     # north_star: logits within 1e-4 rel of the reference
     assert torch.allclose(pred.cpu(), ref, rtol=1e-4, atol=1e-5)
     assert pm.shape == (2, 3, c["img"], c["img"]) and ps.shape == (2, c["ncls"], c["img"], c["img"])
-    assert torch.allclose(pm.cpu()[:, :, 5::16, 3::16], T(g["pred_mask"]), rtol=1e-3, atol=2e-4)
-    assert torch.allclose(ps.cpu()[:, :, 5::16, 3::16], T(g["pred_ss"]), rtol=1e-3, atol=2e-4)
+    # segmentation logits (model/semantic_segmentation_head.py:66-78): 1e-4 of the tensor's largest logit in the max norm and 1e-4
+    # relative L2 -- element-wise relative error is meaningless where a logit crosses zero.  Where the fixture carries the
+    # reference's OWN change of these tensors under a one-ulp move of its weights (`*_1ulp`, plain-loss cases), that floor is
+    # printed beside the achieved error and the gate is max(1e-4, 3 x floor).
+    for nm, mine in (("pred_mask", pm), ("pred_ss", ps)):
+        ref_t = T(g[nm]).double()
+        a = mine.cpu()[:, :, 5::16, 3::16].double()
+        emax = float((a - ref_t).abs().max() / ref_t.abs().max())
+        el2 = float((a - ref_t).norm() / ref_t.norm())
+        floor_max = floor_l2 = 0.0
+        if nm + "_1ulp" in g.files:
+            n_t = T(g[nm + "_1ulp"]).double()
+            floor_max = float((n_t - ref_t).abs().max() / ref_t.abs().max())
+            floor_l2 = float((n_t - ref_t).norm() / ref_t.norm())
+        print(f"{name}: {nm} max-norm rel error {emax:.2e} (reference one-ulp floor {floor_max:.2e}), rel-L2 {el2:.2e} (floor {floor_l2:.2e}), max |logit| {float(ref_t.abs().max()):.3f}")
+        assert emax <= max(1e-4, 3.0 * floor_max), (nm, emax, floor_max)
+        assert el2 <= max(1e-4, 3.0 * floor_l2), (nm, el2, floor_l2)
     rl = float(np.asarray(g["eval_loss"]).reshape(-1)[0])
     print(f"{name}: eval loss {float(loss):.7f} reference {rl:.7f}")
     assert abs(float(loss) - rl) <= loss_tol * abs(rl)
@@ -155,10 +170,11 @@ def test_full_scale_vs_reference_golden(golden, tmp_path, name):
     assert torch.allclose(sdn[bnk + ".running_var"].cpu(), T(g["bn_rv"]), rtol=1e-4, atol=1e-6)
 
 
-@pytest.mark.parametrize("name", ["cfg2p", "cfg2e"])
+@pytest.mark.parametrize("name", ["cfg2p", "cfg2e", "cfg4e", "cfg5e"])
 def test_full_scale_every_gradient_vs_reference(golden, tmp_path, name):
     """The cfg2 model with the constructor's DEFAULT losses (plain mean cross entropies: smooth in the weights), train-mode
-    BatchNorm (cfg2p) and frozen BatchNorm (cfg2e): loss and EVERY parameter gradient against the reference's autograd.
+    BatchNorm (cfg2p) and frozen BatchNorm (cfg2e), and the configs[3] / configs[4] models (char-level 12-class own-layout resnet;
+    RoBERTa + 1024 x 1024) with frozen BatchNorm (cfg4e / cfg5e): loss and EVERY parameter gradient against the reference's autograd.
     The fixture also carries the reference's own gradient change under a one-ulp perturbation of its weights (`ulpnoise_*`):
     the rounding-error floor of this model.  cfg2e: every gradient within 1e-3 relative L2.  cfg2p (batch statistics couple
     every pixel; the reference moves by 6e-3 under one ulp): within 3x the reference's own one-ulp change (floor 1e-4: bias gradients are fp32 sums of 5e5 terms)."""

@@ -244,7 +244,9 @@ def test_conv3x3_row_reuse(ops, B, H, W, Cs, N):
         assert close(dx.permute(0, 3, 1, 2), x.grad.float(), 2e-5, 3e-6 * float(x.grad.abs().max()))
 
 
-@pytest.mark.parametrize("B,H,W,Cs,Cout", [(2, 8, 32, 32, 128), (3, 4, 16, 64, 64), (1, 16, 64, 96, 256), (2, 5, 48, 64, 192)])
+@pytest.mark.parametrize("B,H,W,Cs,Cout", [(2, 8, 32, 32, 128), (3, 4, 16, 64, 64), (1, 16, 64, 96, 256), (2, 5, 48, 64, 192),
+                                           # image rows of 128 / 256 pixels (cfg2's 128 x 128 and cfg5's 256 x 256 maps): 8 / 16 k-tiles per row
+                                           (2, 6, 128, 64, 128), (1, 5, 256, 32, 128), (2, 3, 256, 64, 256)])
 @pytest.mark.parametrize("slabs", [True, False])
 def test_conv3x3_wgrad(ops, B, H, W, Cs, Cout, slabs):
     """csrc/conv3.hip weight gradient (transposing LDS reads, X loaded once for nine taps) against fp64 autograd; accumulates into dw;
