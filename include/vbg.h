@@ -198,6 +198,10 @@ int vbg_attn_mask(const int* seq_len, const long long* mask_off, int nseq, int h
 
 /* column sums: out[n] (+)= sum_m x[m*ld + n]   (bias gradients) */
 int vbg_colsum(const float* x, long long ld, int M, int N, float* out, int accumulate, void* stream);
+/* the same with every partial sum in fp64 (ws: N doubles of caller scratch, overwritten): bias gradients of the 1x1 segmentation
+ * classifiers (model/semantic_segmentation_head.py:66-78: torch's pairwise sum over ~1e6 pixel terms that cancel to 1e-3 of their
+ * running magnitude) and every other bias gradient that does not ride on a split pass */
+int vbg_colsum_f64(const float* x, long long ld, int M, int N, float* out, int accumulate, double* ws, void* stream);
 
 /* 3x3 / stride 1 / pad 1 convolution, NHWC, fp32-grade split form, activation rows reused across the three horizontal taps
  * (csrc/conv3.hip): y[B,H,W,N] (+)= conv(x[B,H,W,Cs], w[N,3,3,Cs]) (+ bias); stats: BatchNorm slot workspace [slots][2][N] fp64 that

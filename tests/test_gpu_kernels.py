@@ -900,6 +900,23 @@ def test_colsum(ops, M, N, ld):
     assert close(acc, (ref + 1).float(), 1e-5, 1e-4 * math.sqrt(M))
 
 
+@pytest.mark.parametrize("M,N", [(131072, 3), (131072, 5), (200000, 12), (70000, 4), (50000, 40)])
+def test_colsum_cancelling_columns(ops, M, N):
+    """the bias gradient of a 1x1 segmentation classifier (model/semantic_segmentation_head.py:66-78): per-pixel terms whose partial sums
+    run to ~1e3 x the final value (page regions of one label).  The fp64 column sums reproduce the exactly rounded result; the fp32
+    atomics of vbg_colsum do not (that is what failed the cfg4e / cfg5e bias gradients at 1.3e-3 / 1.8e-3)."""
+    g = torch.Generator().manual_seed(900 + N)
+    x = torch.rand(M, N, generator=g) * 1e-5
+    x[M // 2:] -= x[: M - M // 2].flip(0) * (1.0 - 1e-3)          # second half cancels the first to 1e-3
+    ref = x.double().sum(0)
+    out = ops.colsum(x.to(dev()))
+    rel = float(((out.cpu().double() - ref).abs() / ref.abs()).max())
+    assert rel < 2e-7, rel
+    acc = torch.full((N,), 0.5, device=dev())
+    ops.colsum(x.to(dev()), out=acc, accumulate=True)
+    assert torch.equal(acc.cpu(), (ref + 0.5).float())
+
+
 # ------------------------------------------------------------------------------------------
 # classifier_mode full / crf: row subsets, BCE losses, linear-chain CRF
 # ------------------------------------------------------------------------------------------

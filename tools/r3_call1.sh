@@ -9,3 +9,8 @@ python $R/tools/pmc_summary.py plane_gemm $(find $R/gpurun_out/pg_pmc_c_$T -name
 done
 cat $R/gpurun_out/pair_probe.txt | tail -120
 cat $R/gpurun_out/pg_pmc_c_*.txt
+cd $R
+timeout 900 python -m pytest tests -m gpu -x -q 2>&1 | tail -15 > gpurun_out/call1_pytest.txt
+cat gpurun_out/call1_pytest.txt
+timeout 600 python bench.py --steps 20 --warmup 5 > gpurun_out/call1_bench.json 2> gpurun_out/call1_bench.err
+tail -c 3000 gpurun_out/call1_bench.json

@@ -470,6 +470,54 @@ __global__ __launch_bounds__(256) void colsum_vec_kernel(const float* __restrict
     }
 }
 
+// fp64 column sums.  A bias gradient such as that of the 1x1 segmentation classifiers (model/semantic_segmentation_head.py:66-78) is
+// the sum of ~1e5..1e6 per-pixel terms (p - onehot) / N whose partial sums wander to 1e3 x the final value (page regions of one label):
+// fp32 accumulation across blocks leaves 1e-3 relative error there (the reference's torch.sum is pairwise).  Here every thread, block
+// and the cross-block stage accumulate in double: ws[n] (fp64, one per column) takes one double atomic per block and column, and
+// colsum_f64_finish_kernel rounds ONCE to fp32.
+// small N (contiguous rows of <= NMAX floats): a thread owns whole rows (a wave reads 64 consecutive rows = one contiguous piece)
+template <int NMAX>
+__global__ __launch_bounds__(256) void colsum_f64_rows_kernel(const float* __restrict__ x, long long ld, int M, int N, double* ws) {
+    __shared__ double sh[4][NMAX];
+    double acc[NMAX];
+#pragma unroll
+    for (int c = 0; c < NMAX; ++c) acc[c] = 0.0;
+    const long long stride = (long long)gridDim.x * blockDim.x;
+    for (long long r = (long long)blockIdx.x * blockDim.x + threadIdx.x; r < M; r += stride) {
+        const float* row = x + r * ld;
+#pragma unroll
+        for (int c = 0; c < NMAX; ++c)
+            if (c < N) acc[c] += (double)row[c];
+    }
+    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+#pragma unroll
+    for (int c = 0; c < NMAX; ++c) {
+        double v = acc[c];
+#pragma unroll
+        for (int o = 32; o > 0; o >>= 1) v += __shfl_xor(v, o, 64);
+        if (lane == 0) sh[wave][c] = v;
+    }
+    __syncthreads();
+    if (threadIdx.x < N) unsafeAtomicAdd(ws + threadIdx.x, sh[0][threadIdx.x] + sh[1][threadIdx.x] + sh[2][threadIdx.x] + sh[3][threadIdx.x]);
+}
+// general N: block = 64 columns x 4 row lanes over a row range
+__global__ __launch_bounds__(256) void colsum_f64_kernel(const float* __restrict__ x, long long ld, int M, int N, int rows_per_block, double* ws) {
+    __shared__ double sh[4][64];
+    const int c = blockIdx.x * 64 + (threadIdx.x & 63);
+    const int rl = threadIdx.x >> 6;
+    const int r0 = blockIdx.y * rows_per_block, r1 = min(M, r0 + rows_per_block);
+    double s = 0.0;
+    if (c < N)
+        for (int r = r0 + rl; r < r1; r += 4) s += (double)x[(long long)r * ld + c];
+    sh[rl][threadIdx.x & 63] = s;
+    __syncthreads();
+    if (rl == 0 && c < N) unsafeAtomicAdd(ws + c, sh[0][threadIdx.x] + sh[1][threadIdx.x] + sh[2][threadIdx.x] + sh[3][threadIdx.x]);
+}
+__global__ void colsum_f64_finish_kernel(const double* __restrict__ ws, int N, float* out, int accumulate) {
+    const int c = blockIdx.x * blockDim.x + threadIdx.x;
+    if (c < N) out[c] = accumulate ? (float)((double)out[c] + ws[c]) : (float)ws[c];
+}
+
 // plain row softmax for the returned class probabilities ([rows, cols], cols small)
 __global__ void row_softmax_kernel(const float* __restrict__ x, int rows, int cols, float* __restrict__ y) {
     const int r = blockIdx.x * blockDim.x + threadIdx.x;
@@ -646,6 +694,29 @@ extern "C" int vbg_colsum(const float* x, long long ld, int M, int N, float* out
     } else {
         VBG_LAUNCH(colsum_kernel, dim3(cdiv(N, 64), cdiv(M, 256)), dim3(256), 0, s, x, ld, M, N, out);
     }
+    VBG_LAUNCH_RET();
+}
+
+extern "C" int vbg_colsum_f64(const float* x, long long ld, int M, int N, float* out, int accumulate, double* ws, void* stream) {
+    VBG_CHECK_ARG(x && out && ws && M >= 0 && N >= 0 && ld >= N);
+    if (N == 0) return VBG_OK;
+    hipStream_t s = (hipStream_t)stream;
+    hipError_t e = hipMemsetAsync(ws, 0, sizeof(double) * (size_t)N, s);
+    if (e != hipSuccess) return (int)e;
+    if (M > 0) {
+        const int blocks = (int)((M + 1023) / 1024 < 128 ? (M + 1023) / 1024 : 128);     // >= 4 rows per thread, <= 128 double atomics per column
+        if (N <= 4) VBG_LAUNCH(colsum_f64_rows_kernel<4>, dim3(blocks), dim3(256), 0, s, x, ld, M, N, ws);
+        else if (N <= 8) VBG_LAUNCH(colsum_f64_rows_kernel<8>, dim3(blocks), dim3(256), 0, s, x, ld, M, N, ws);
+        else if (N <= 16) VBG_LAUNCH(colsum_f64_rows_kernel<16>, dim3(blocks), dim3(256), 0, s, x, ld, M, N, ws);
+        else {
+            const int CG = cdiv(N, 64);
+            long long rpb = cdiv((long long)M * CG, 192);
+            if (rpb < 16) rpb = 16;
+            rpb = cdiv(rpb, 4) * 4;
+            VBG_LAUNCH(colsum_f64_kernel, dim3(CG, cdiv(M, rpb)), dim3(256), 0, s, x, ld, M, N, (int)rpb, ws);
+        }
+    }
+    VBG_LAUNCH(colsum_f64_finish_kernel, dim3(cdiv(N, 256)), dim3(256), 0, s, ws, N, out, accumulate);
     VBG_LAUNCH_RET();
 }
 

@@ -83,6 +83,7 @@ SIGNATURES = {
     "vbg_attn_drop_thr16": (C.c_uint, [c_f]),
     "vbg_attn_mask": (c_int, [c_vp, c_vp, c_int, c_int, c_int, c_f, c_ull, c_ull, c_vp, c_vp, c_vp]),
     "vbg_colsum": (c_int, [c_vp, c_ll, c_int, c_int, c_vp, c_int, c_vp]),
+    "vbg_colsum_f64": (c_int, [c_vp, c_ll, c_int, c_int, c_vp, c_int, c_vp, c_vp]),
     "vbg_conv3x3": (c_int, [c_vp, c_vp, c_vp, c_vp, c_vp, c_int, c_int, c_int, c_int, c_int, c_int, c_int, c_int, c_vp]),
     "vbg_conv3x3_wflip": (c_int, [c_vp, c_int, c_int, c_vp, c_vp]),
     "vbg_conv3x3_wgrad_strips": (c_int, [c_int, c_int, c_int, c_int, c_int]),

@@ -514,8 +514,21 @@ def colsum(x, out=None, accumulate=False):
     if out is None:
         out = torch.empty((N,), device=x.device, dtype=f32)
         accumulate = False
+    if _COLSUM_F64[0]:
+        key = (x.device, raw_stream(x.device))
+        ws = _COLSUM_WS.get(key)
+        if ws is None or ws.numel() < N:
+            ws = _COLSUM_WS[key] = torch.empty((max(N, 4096),), device=x.device, dtype=torch.float64)
+        check(lib.vbg_colsum_f64(P(x), x.stride(0), M, N, P(out), int(accumulate), P(ws), _stream()), "vbg_colsum_f64")
+        return out
     check(lib.vbg_colsum(P(x), x.stride(0), M, N, P(out), int(accumulate), _stream()), "vbg_colsum")
     return out
+
+
+# bias gradients that do not ride on a split pass are summed in fp64 (csrc/rowops.hip colsum_f64_*: the 1x1 segmentation classifiers'
+# bias gradients cancel to 1e-3 of their running partial sums); VBG_COLSUM_F64=0 restores the fp32 atomics
+_COLSUM_F64 = [os.environ.get("VBG_COLSUM_F64", "1") != "0"]
+_COLSUM_WS = {}
 
 
 def conv_geo(Hs, Ws, Cs, Hr, Wr, kh, kw, stride, pad, dgrad=0):
