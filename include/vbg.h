@@ -209,10 +209,15 @@ int vbg_colsum_f64(const float* x, long long ld, int M, int N, float* out, int a
  * (model/ResNetFPN_ViBERTgrid.py:478-508, 612-648; model/semantic_segmentation_head.py) and, with the filter written by
  * vbg_conv3x3_wflip, its input gradient.  Requires W a power of two >= 16, H*W % 64 == 0, Cs % 16 == 0, N % 4 == 0. */
 int vbg_conv3x3(const float* x, const float* w, const float* bias, float* y, double* stats, int stats_slots, int B, int H, int W,
-                int Cs, int N, int accumulate, int form, void* stream);
-/* form 0: three bf16 pieces per operand, six piece products (any operands); form 1: two fp16 pieces, three piece products -- same
- * measured accuracy against fp64 and half the matrix-core work, for operands inside fp16's range: forward activations and filters,
- * not gradients */
+                int Cs, int N, int accumulate, int form, const unsigned* x_amax, void* stream);
+/* form 0: three bf16 pieces per operand, six piece products (any operands); form 1: two fp16 pieces (round to nearest), three piece
+ * products -- same measured accuracy against fp64 and half the matrix-core work, for operands inside fp16's range; a magnitude of
+ * 65520 or more becomes inf, never a silently clipped value.  x_amax (form 1, optional): device word holding the bit pattern of
+ * max |x| (vbg_amax, or the amax output of vbg_bn_bwd_apply): x is multiplied by the power of two that brings that maximum to
+ * [2^13, 2^14) on its way into the kernel and the result by its inverse (exact), which puts a GRADIENT operand inside fp16's range:
+ * the input gradient of the convolution in form 1. */
+/* amax[0] = max(amax[0], bit pattern of max |x[i]|) (non-negative floats order like their bit patterns); the caller zeroes amax */
+int vbg_amax(const float* x, long long n, unsigned* amax, void* stream);
 /* out[ci][2-kh][2-kw][co] = w[co][kh][kw][ci]: the filter with which the input gradient of a 3x3 / s1 / p1 convolution is the
  * same convolution of dy */
 int vbg_conv3x3_wflip(const float* w, int Cout, int Cin, float* out, void* stream);
@@ -346,7 +351,8 @@ int vbg_bn_bwd_reduce(const float* dy, const float* y, const float* x, long long
 int vbg_bn_bwd_apply(const float* dy, const float* y, const float* x, long long M, int C, const float* mean,
                      const float* invstd, const float* gamma, const double* sums, double count, const double* count_dev,
                      int relu, float* dx,
-                     float* dres, float* dgamma_accum, float* dbeta_accum, void* stream);
+                     float* dres, float* dgamma_accum, float* dbeta_accum, unsigned* dx_amax, void* stream);
+/* dx_amax (optional): receives the bit pattern of max |dx| (overwritten) -- the scale of the fp16-form products that consume dx */
 /* fold `nslots` slot rows: folded[0..2C) = sum over slots (optional output), and (optional) the BatchNorm affine
    gradients from these LOCAL sums: dbeta += (float)folded[0..C), dgamma += (float)folded[C..2C)  (call before a SyncBN
    all-reduce of `folded`; torch.nn.SyncBatchNorm leaves weight/bias gradients per-rank for DDP to average,

@@ -220,7 +220,18 @@ def _every_gradient(g, c, net, dbatch, name):
             continue
         # (position embeddings: the smallest gradient of the model, norm 0.011 against 5.5 for the token-type row that sums the same
         #  per-token gradients; 1.2e-3 on the split form, 4e-4 with every product on the fp32 pipe, reference one-ulp noise 7e-5)
-        tol = (2e-3 if "position_embeddings" in k else 1e-3) if c.get("bn_frozen") else max(3.0 * noise[k], 1e-4)
+        # frozen BatchNorm: 1e-3, or 5 x the reference's OWN change of this gradient under a one-ulp move of its weights where that is
+        # larger (cfg4e backbone.conv_4_x.1.conv_1.weight: the reference moves 3.6e-4, four times its neighbours; 5.8e-4 here with every
+        # product on the fp32 pipe, 1.65e-3 on the split form)
+        tol = max(2e-3 if "position_embeddings" in k else 1e-3, 5.0 * noise[k]) if c.get("bn_frozen") else max(3.0 * noise[k], 1e-4)
+        if k.endswith(("conv_3_1.bias", "conv_3_2.bias")) and f"grad::{k}" in g.files:
+            # the bias gradients of the two 1x1 segmentation classifiers sum to ZERO over the classes (softmax - onehot does, pixel by
+            # pixel).  Here they do to 1e-9; the reference's fp32 sum over 1e6 pixels does not (cfg5e: 1.7e-3 of the largest entry):
+            # its own violation of the identity bounds what agreement with it can mean
+            ref_b = np.asarray(g[f"grad::{k}"], dtype=np.float64).reshape(-1)
+            mine_b = named[k].grad.detach().double().cpu().numpy().reshape(-1)
+            assert abs(mine_b.sum()) <= 1e-6 * np.abs(mine_b).max(), (k, mine_b.sum())
+            tol = max(tol, 2.0 * abs(ref_b.sum()) / np.linalg.norm(ref_b))
         if v > tol:
             bad.append((k, v, tol))
     assert not bad, bad[:10]

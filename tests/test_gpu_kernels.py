@@ -242,6 +242,16 @@ def test_conv3x3_row_reuse(ops, B, H, W, Cs, N):
         assert torch.equal(wf.cpu(), w.detach().permute(1, 2, 3, 0).flip(1, 2).contiguous())
         dx = ops.conv3x3(gyh, wf)
         assert close(dx.permute(0, 3, 1, 2), x.grad.float(), 2e-5, 3e-6 * float(x.grad.abs().max()))
+        # ... in the two-piece fp16 form, dy at the magnitudes gradients really have (1e-9 ... 1e+6 x the test's): the kernel scales dy
+        # by the power of two derived from its largest magnitude (vbg_amax) and the result back -- the same bound at every scale
+        for sc in (1.0, 2.0 ** -30, 2.0 ** -20, 2.0 ** 20):
+            g = gyh * sc
+            am = ops.amax(g)
+            assert int(am.item()) == int((g.abs().max()).view(torch.int32).item())
+            dxs = ops.conv3x3(g, wf, f16x2=True, x_amax=am)
+            assert close(dxs.permute(0, 3, 1, 2) / sc, x.grad.float(), 2e-5, 3e-6 * float(x.grad.abs().max())), sc
+        # without the scale a large operand is visible as inf / nan, never clipped
+        assert not bool(torch.isfinite(ops.conv3x3(gyh * 1e6, wf, f16x2=True)).all())
 
 
 @pytest.mark.parametrize("B,H,W,Cs,Cout", [(2, 8, 32, 32, 128), (3, 4, 16, 64, 64), (1, 16, 64, 96, 256), (2, 5, 48, 64, 192),
@@ -563,8 +573,10 @@ def test_batchnorm(ops, relu, res, shape):
     slots = ops.bn_bwd_reduce(g2, yo, x2, mean, invstd, relu)
     dg, db = torch.zeros(C_, device=d), torch.zeros(C_, device=d)
     sums = ops.bn_param_grad(slots, C_, dg, db)
-    dx, dres = ops.bn_bwd_apply(g2, yo, x2, mean, invstd, gam.detach().to(d), sums, x2.shape[0], relu, res, None, None)
+    slot = torch.full((1,), 12345, device=d, dtype=torch.int32)            # (overwritten, not max-ed into)
+    dx, dres = ops.bn_bwd_apply(g2, yo, x2, mean, invstd, gam.detach().to(d), sums, x2.shape[0], relu, res, None, None, dx_amax=slot)
     assert close(dx, x.grad.permute(0, 2, 3, 1).reshape(-1, C_), 1e-3, 1e-5)
+    assert int(slot.item()) == int(dx.abs().max().view(torch.int32).item())       # the bit pattern of max |dx| rides on the kernel
     assert close(dg, gam.grad, 1e-3, 1e-4) and close(db, bet.grad, 1e-3, 1e-4)
     if res:
         assert close(dres, r.grad.permute(0, 2, 3, 1).reshape(-1, C_), 1e-5, 1e-6)

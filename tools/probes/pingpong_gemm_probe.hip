@@ -30,9 +30,11 @@ __device__ __forceinline__ __amdgpu_buffer_rsrc_t pg_rsrc(const void* base) {
     return __builtin_amdgcn_make_buffer_rsrc(const_cast<void*>(base), 0, (int)0x80000000u, 0x00020000);
 }
 
-template <int BM, int BN, int WGM, int WGN, int SCHED, int GSEL>
+// WIDE = 1: what-if (results are garbage): every DMA instruction reads 8 rows x 128 B instead of 16 rows x 64 B -- same LDS bytes and
+// instruction count, half the L2 requests
+template <int BM, int BN, int WGM, int WGN, int SCHED, int GSEL, int WIDE = 0>
 __global__ __launch_bounds__(WGM * WGN * 64) void pp_gemm_kernel(const desc p) {
-    constexpr int NW = WGM * WGN, NT = NW * 64, NST = 3;
+    constexpr int NW = WGM * WGN, NT = NW * 64, NST = (SCHED == 3) ? 2 : 3;
     constexpr int BK = 32, NP = 3;
     constexpr int WM = BM / WGM, WN = BN / WGN, TM = WM / 32, TN = WN / 32;
     constexpr int PA = BM * 64, PB = BN * 64;
@@ -68,8 +70,8 @@ __global__ __launch_bounds__(WGM * WGN * 64) void pp_gemm_kernel(const desc p) {
     unsigned avo[NIA], bvo[NIB];
     int alds[NIA], blds[NIB];
     {
-        const int lrow = lane >> 2;
-        const int lchunk = (lane & 3) ^ ((lane >> 4) & 3);
+        const int lrow = WIDE ? (lane >> 3) : (lane >> 2);
+        const int lchunk = WIDE ? (lane & 7) : ((lane & 3) ^ ((lane >> 4) & 3));
 #pragma unroll
         for (int i = 0; i < NIA; ++i) {
             const int u = wave + NW * i, q = u / (BM / 16), rb = u % (BM / 16);
@@ -193,8 +195,12 @@ __global__ __launch_bounds__(WGM * WGN * 64) void pp_gemm_kernel(const desc p) {
         // ---- ping-pong: group 1 runs one barrier interval behind group 0 ----------------------------------------------------------
         const int grp = (GSEL == 0) ? (wave / (NW / 2)) : (wave & 1);
         issue(0, 0u);
-        issue(1, ntiles > 1 ? 0u : PG_INVALID);
-        asm volatile("s_waitcnt vmcnt(%0)" ::"n"(NIW) : "memory");
+        if constexpr (SCHED == 3) {
+            asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+        } else {
+            issue(1, ntiles > 1 ? 0u : PG_INVALID);
+            asm volatile("s_waitcnt vmcnt(%0)" ::"n"(NIW) : "memory");
+        }
         __builtin_amdgcn_s_barrier();                       // tile 0 landed (every wave's share)
         if (grp) __builtin_amdgcn_s_barrier();              // the followers start one interval late
         int cur = 0;
@@ -217,6 +223,32 @@ __global__ __launch_bounds__(WGM * WGN * 64) void pp_gemm_kernel(const desc p) {
                 __builtin_amdgcn_s_setprio(1);
                 mma(fa0, fb0);
                 mma(fa1, fb1);
+                __builtin_amdgcn_s_setprio(0);
+                __builtin_amdgcn_sched_barrier(0);
+                __builtin_amdgcn_s_barrier();
+            } else if constexpr (SCHED == 3) {
+                // two stages: the whole of tile t + 1 is issued in the first LOAD interval of tile t (its stage held tile t - 1, whose
+                // last readers finished an interval ago) and waited for at the end of the second one
+                __builtin_amdgcn_sched_barrier(0);
+                issue(nxt, t + 1 < ntiles ? 0u : PG_INVALID);
+                read_frags(cur, fo0, fa0, fb0);
+                __builtin_amdgcn_sched_barrier(0);
+                asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+                __builtin_amdgcn_s_barrier();
+                __builtin_amdgcn_sched_barrier(0);
+                __builtin_amdgcn_s_setprio(1);
+                mma(fa0, fb0);
+                __builtin_amdgcn_s_setprio(0);
+                __builtin_amdgcn_sched_barrier(0);
+                __builtin_amdgcn_s_barrier();
+                __builtin_amdgcn_sched_barrier(0);
+                read_frags(cur, fo1, fa0, fb0);
+                __builtin_amdgcn_sched_barrier(0);
+                asm volatile("s_waitcnt vmcnt(0) lgkmcnt(0)" ::: "memory");
+                __builtin_amdgcn_s_barrier();
+                __builtin_amdgcn_sched_barrier(0);
+                __builtin_amdgcn_s_setprio(1);
+                mma(fa0, fb0);
                 __builtin_amdgcn_s_setprio(0);
                 __builtin_amdgcn_sched_barrier(0);
                 __builtin_amdgcn_s_barrier();
@@ -283,15 +315,15 @@ static float bf_f(unsigned short h) { unsigned u = (unsigned)h << 16; float f; m
 
 struct Problem { const char* name; int M, N, K; };
 
-template <int BM, int BN, int WGM, int WGN, int SCHED, int GSEL>
+template <int BM, int BN, int WGM, int WGN, int SCHED, int GSEL, int WIDE = 0>
 static float run(const desc& d, int iters) {
     dim3 g((d.M + BM - 1) / BM, (d.N + BN - 1) / BN);
     hipEvent_t e0, e1;
     CK(hipEventCreate(&e0)); CK(hipEventCreate(&e1));
-    for (int i = 0; i < 3; ++i) hipLaunchKernelGGL((pp_gemm_kernel<BM, BN, WGM, WGN, SCHED, GSEL>), g, dim3(WGM * WGN * 64), 0, 0, d);
+    for (int i = 0; i < 3; ++i) hipLaunchKernelGGL((pp_gemm_kernel<BM, BN, WGM, WGN, SCHED, GSEL, WIDE>), g, dim3(WGM * WGN * 64), 0, 0, d);
     CK(hipDeviceSynchronize());
     CK(hipEventRecord(e0));
-    for (int i = 0; i < iters; ++i) hipLaunchKernelGGL((pp_gemm_kernel<BM, BN, WGM, WGN, SCHED, GSEL>), g, dim3(WGM * WGN * 64), 0, 0, d);
+    for (int i = 0; i < iters; ++i) hipLaunchKernelGGL((pp_gemm_kernel<BM, BN, WGM, WGN, SCHED, GSEL, WIDE>), g, dim3(WGM * WGN * 64), 0, 0, d);
     CK(hipEventRecord(e1));
     CK(hipEventSynchronize(e1));
     CK(hipGetLastError());
@@ -357,16 +389,16 @@ int main(int argc, char** argv) {
         };
         const double fl = 2.0 * M * N * K;
         printf("%s %dx%dx%d\n", pr.name, M, N, K);
-#define RUNCFG(BM, BN, WGM, WGN, SCHED, GSEL, REF)                                                                                 \
+#define RUNCFG(BM, BN, WGM, WGN, SCHED, GSEL, REF, WIDE)                                                                                \
         {                                                                                                                          \
             CK(hipMemset(dC, 0, (size_t)M * N * 4));                                                                               \
             d.simd_map = printed_map ? nullptr : dmap;                                                                            \
-            const float t3 = run<BM, BN, WGM, WGN, SCHED, GSEL>(d, iters);                                                         \
-            const double err = check(REF);                                                                                         \
+            const float t3 = run<BM, BN, WGM, WGN, SCHED, GSEL, WIDE>(d, iters);                                                        \
+            const double err = WIDE ? -1.0 : check(REF);                                                                                        \
             const long tiles = (long)((M + BM - 1) / BM) * ((N + BN - 1) / BN);                                                    \
             const double rounds = (double)((tiles + 255) / 256);                                                                   \
-            printf("  %3dx%3d w%dx%d sched %d gsel %d: %7.1f us %6.1f TF (err %.1e) | per full round of tiles: MFMA-busy %.2f @2.4GHz | tiles %ld\n", \
-                   BM, BN, WGM, WGN, SCHED, GSEL, t3, fl / t3 * 1e-6, err,                                                         \
+            printf("  %3dx%3d w%dx%d sched %d gsel %d wide %d: %7.1f us %6.1f TF (err %.1e) | per full round of tiles: MFMA-busy %.2f @2.4GHz | tiles %ld\n", \
+                   BM, BN, WGM, WGN, SCHED, GSEL, WIDE, t3, fl / t3 * 1e-6, err,                                                         \
                    (double)(K / 16) * 6 * (BM / 32) * (BN / 32) * 32 / 4 * rounds / (t3 * 2400.0), tiles);                         \
             fflush(stdout);                                                                                                        \
             if (!printed_map) {                                                                                                    \
@@ -380,14 +412,14 @@ int main(int argc, char** argv) {
                 printed_map = true;                                                                                                \
             }                                                                                                                      \
         }
-        RUNCFG(128, 128, 2, 4, 0, 0, true)
-        RUNCFG(128, 128, 2, 4, 1, 0, false)
-        RUNCFG(128, 128, 2, 4, 1, 1, false)
-        RUNCFG(128, 128, 2, 4, 2, 0, false)
-        RUNCFG(128, 128, 2, 4, 2, 1, false)
-        RUNCFG(128, 128, 4, 2, 0, 0, false)
-        RUNCFG(128, 128, 4, 2, 1, 0, false)
-        RUNCFG(128, 128, 4, 2, 2, 0, false)
+        RUNCFG(128, 128, 2, 4, 0, 0, true, 0)
+        RUNCFG(128, 128, 2, 4, 1, 0, false, 0)
+        RUNCFG(128, 128, 2, 4, 2, 0, false, 0)
+        RUNCFG(128, 128, 2, 4, 0, 0, false, 1)
+        RUNCFG(128, 128, 2, 4, 1, 0, false, 1)
+        RUNCFG(128, 128, 2, 4, 2, 0, false, 1)
+        RUNCFG(256, 128, 4, 2, 3, 0, false, 0)
+        RUNCFG(256, 128, 4, 2, 3, 0, false, 1)
         CK(hipFree(dA)); CK(hipFree(dB)); CK(hipFree(dC)); CK(hipFree(dC0));
     }
     return 0;

@@ -34,6 +34,7 @@ struct conv3_args {
     int stats_slots;
     int H, W, wsh, Cs, N, M;
     int accumulate;
+    const unsigned* a_amax; // F16 form: bits of max |X| (a device word written by the producer of X), or null: X is used as it is
 };
 
 __device__ __forceinline__ __amdgpu_buffer_rsrc_t c3_rsrc(const float* base) {
@@ -53,14 +54,25 @@ __device__ __forceinline__ void c3_split3(float a, float b, unsigned& hi, unsign
 }
 typedef _Float16 c3_f16x8 __attribute__((ext_vector_type(8)));
 typedef __fp16 c3_f16x2 __attribute__((ext_vector_type(2)));
-// F16 form: two fp16 pieces of a pair of floats (a in the low half): hi = fp16(x) toward zero, lo = fp16((x - hi) * 2^11) -- the
-// remainder is exact in fp32 and its scaling keeps it clear of fp16's subnormals -- so x = hi + lo * 2^-11 up to 2^-21 |x|
+// F16 form: two fp16 pieces of a pair of floats (a in the low half): hi = fp16(x), lo = fp16((x - hi) * 2^11), both rounded to
+// nearest -- the remainder is exact in fp32 and its scaling keeps it clear of fp16's subnormals -- so x = hi + lo * 2^-11 up to
+// 2^-23 |x| (11 + 1 + 11 bits: the remainder carries a sign).  |x| >= 65520 becomes inf (and the products NaN / inf): an operand
+// outside fp16's range is visible, never silently clipped.
 __device__ __forceinline__ void c3_split2(float a, float b, unsigned& hi, unsigned& lo) {
-    const c3_f16x2 h = __builtin_amdgcn_cvt_pkrtz(a, b);
-    const float ra = (a - (float)h[0]) * 2048.f, rb = (b - (float)h[1]) * 2048.f;
-    const c3_f16x2 l = __builtin_amdgcn_cvt_pkrtz(ra, rb);
+    typedef float f32x2_t __attribute__((ext_vector_type(2)));
+    typedef _Float16 f16x2_t __attribute__((ext_vector_type(2)));
+    const f32x2_t v = {a, b};
+    const f16x2_t h = __builtin_convertvector(v, f16x2_t);                        // v_cvt_pk_f16_f32: round to nearest even
+    const f16x2_t l = __builtin_convertvector((v - __builtin_convertvector(h, f32x2_t)) * 2048.f, f16x2_t);
     hi = __builtin_bit_cast(unsigned, h);
     lo = __builtin_bit_cast(unsigned, l);
+}
+// power-of-two scale that brings a tensor whose largest magnitude has the bit pattern `amax_bits` to [2^13, 2^14): (scale, 1 / scale).
+// Exact in fp32 (the scaled operand's pieces see the same significand bits); amax = 0 or below 2^-100: no scaling.
+__device__ __forceinline__ float2 c3_pow2_scale(unsigned amax_bits) {
+    const int e = (int)((amax_bits >> 23) & 0xffu);            // biased exponent of amax
+    if (e < 27 || e > 240) return make_float2(1.f, 1.f);
+    return make_float2(__uint_as_float((unsigned)(267 - e) << 23), __uint_as_float((unsigned)(e - 13) << 23));
 }
 // after every MFMA its share of the NV VALU and ND LDS-write instructions of the region
 template <int M, int NM, int NV, int ND>
@@ -96,6 +108,10 @@ __global__ __launch_bounds__(256, 2) void conv3x3_kernel(const conv3_args p) {
     unsigned* const Bs = smem + 2 * ASZ;
 
     const int tid = threadIdx.x;
+    // F16 form on an operand outside fp16's range (a gradient): X is multiplied by a power of two derived from its largest magnitude
+    // on the way into LDS and the result by the inverse -- exact, and the pieces then sit in the middle of fp16's range
+    float2 a_sc = make_float2(1.f, 1.f);
+    if constexpr (F16) { if (p.a_amax) a_sc = c3_pow2_scale(__builtin_amdgcn_readfirstlane(p.a_amax[0])); }
     // XCD-aware block -> tile map (same as gemm.hip: XCD k owns the k-th eighth of the tile sequence, bands of 8 row tiles)
     constexpr unsigned XCDS = 8, XCD_GROUP = 8;
     const unsigned gx = gridDim.x, gy = gridDim.y;
@@ -184,10 +200,11 @@ __global__ __launch_bounds__(256, 2) void conv3x3_kernel(const conv3_args p) {
             *reinterpret_cast<uint2*>(&dst[o + 2 * PL]) = l;
         }
     };
+    auto scaled = [&](const float4& v) { return make_float4(v.x * a_sc.x, v.y * a_sc.x, v.z * a_sc.x, v.w * a_sc.x); };
     auto store_a = [&](int buf) {
 #pragma unroll
-        for (int i = 0; i < NAI; ++i) store4(As + buf * ASZ, PA, a_lrow[i], ra[i]);
-        if (wide && tid < 8) store4(As + buf * ASZ, PA, h_row, rh);
+        for (int i = 0; i < NAI; ++i) store4(As + buf * ASZ, PA, a_lrow[i], F16 ? scaled(ra[i]) : ra[i]);
+        if (wide && tid < 8) store4(As + buf * ASZ, PA, h_row, F16 ? scaled(rh) : rh);
     };
     auto store_b = [&](int buf) {
         store4(Bs + buf * BSZ, PB, tid >> 2, rb[0]);
@@ -310,7 +327,7 @@ __global__ __launch_bounds__(256, 2) void conv3x3_kernel(const conv3_args p) {
 #pragma unroll
             for (int r = 0; r < 16; ++r)
                 Ct[(wm * (BM / 2) + i * 32 + (r & 3) + 8 * (r >> 2) + 4 * lk) * CTS + wn * 64 + j * 32 + lr] =
-                    F16 ? acc[i][j][r] + acx[i][j][r] * (1.f / 2048.f) : acc[i][j][r];
+                    F16 ? (acc[i][j][r] + acx[i][j][r] * (1.f / 2048.f)) * a_sc.y : acc[i][j][r];
     __syncthreads();
     constexpr int QN = BN / 4;
     float4 cs = make_float4(0.f, 0.f, 0.f, 0.f), cq = cs;
@@ -601,8 +618,9 @@ extern "C" int vbg_conv3x3_wgrad(const float* dy, const float* x, float* dw, flo
 }
 
 extern "C" int vbg_conv3x3(const float* x, const float* w, const float* bias, float* y, double* stats, int stats_slots, int B, int H,
-                           int W, int Cs, int N, int accumulate, int form, void* stream) {
+                           int W, int Cs, int N, int accumulate, int form, const unsigned* x_amax, void* stream) {
     VBG_CHECK_ARG(form == 0 || form == 1);
+    VBG_CHECK_ARG(!x_amax || form == 1);
     VBG_CHECK_ARG(x && w && y && B > 0 && H > 0);
     VBG_CHECK_ARG(W >= 16 && W <= 4096 && (W & (W - 1)) == 0);
     VBG_CHECK_ARG(((long long)H * W) % 64 == 0 && (long long)H * W * Cs < (1ll << 29));
@@ -614,7 +632,7 @@ extern "C" int vbg_conv3x3(const float* x, const float* w, const float* bias, fl
     a.H = H; a.W = W; a.wsh = 31 - __builtin_clz((unsigned)W); a.Cs = Cs; a.N = N;
     const long long M = (long long)B * H * W;
     VBG_CHECK_ARG(M < (1ll << 31));
-    a.M = (int)M; a.accumulate = accumulate;
+    a.M = (int)M; a.accumulate = accumulate; a.a_amax = x_amax;
     // 128-pixel tiles once they fill the chip (or the image does not divide into 64-pixel tiles any better), else 64-pixel tiles
     const long long t128 = (M / 128) * vbg::cdiv(N, 128);
     const bool big = ((long long)H * W) % 128 == 0 && (t128 >= 240 || W >= 128);

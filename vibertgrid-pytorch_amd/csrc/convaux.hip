@@ -150,12 +150,29 @@ __global__ void bn_apply_kernel(const float* __restrict__ x, const float* __rest
     }
 }
 
+// block-wide max of non-negative floats into a device word holding a bit pattern (non-negative floats order like their bits).  One
+// atomic per block at most, and none when the word already holds a larger value (same-address atomics serialise at ~10 ns each:
+// 8192 wave-level atomics cost ~100 us, measured)
+__device__ __forceinline__ void amax_publish(float mx, unsigned* amax) {
+    __shared__ float amax_sh[16];
+#pragma unroll
+    for (int o = 32; o > 0; o >>= 1) mx = fmaxf(mx, __shfl_xor(mx, o, 64));
+    if ((threadIdx.x & 63) == 0) amax_sh[threadIdx.x >> 6] = mx;
+    __syncthreads();
+    if (threadIdx.x == 0) {
+        for (int w = 1; w < (int)(blockDim.x >> 6); ++w) mx = fmaxf(mx, amax_sh[w]);
+        const unsigned bits = __float_as_uint(mx);
+        if (bits > __hip_atomic_load(amax, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT)) atomicMax(amax, bits);
+    }
+}
+
 __global__ void bn_bwd_apply_kernel(const float* __restrict__ dy, const float* __restrict__ y, const float* __restrict__ x,
                                     long long M, int C4, int C, const float* __restrict__ mean, const float* __restrict__ invstd,
                                     const float* __restrict__ gamma, const double* __restrict__ sums, double count,
                                     const double* __restrict__ count_dev, int relu, float* __restrict__ dx,
-                                    float* __restrict__ dres) {
+                                    float* __restrict__ dres, unsigned* amax) {
     if (count_dev) count = count_dev[0];
+    float mx = 0.f;
     const float icnt = (float)(1.0 / count);
     const long long total = M * C4;
     const long long stride = (long long)gridDim.x * blockDim.x;
@@ -176,7 +193,21 @@ __global__ void bn_bwd_apply_kernel(const float* __restrict__ dy, const float* _
         o.w = ga.w * is.w * (g.w - (float)sums[c + 3] * icnt - (xv.w - mu.w) * is.w * ((float)sums[C + c + 3] * icnt));
         reinterpret_cast<float4*>(dx)[i] = o;
         if (dres) reinterpret_cast<float4*>(dres)[i] = g;
+        mx = fmaxf(fmaxf(mx, fmaxf(fabsf(o.x), fabsf(o.y))), fmaxf(fabsf(o.z), fabsf(o.w)));
     }
+    if (amax) amax_publish(mx, amax);                            // (uniform)
+}
+
+// amax[0] = max(amax[0], bits of max |x|)
+__global__ __launch_bounds__(256) void amax_kernel(const float* __restrict__ x, long long n, unsigned* amax) {
+    const long long n4 = n / 4, stride = (long long)gridDim.x * blockDim.x;
+    float mx = 0.f;
+    for (long long i = (long long)blockIdx.x * blockDim.x + threadIdx.x; i < n4; i += stride) {
+        const float4 v = reinterpret_cast<const float4*>(x)[i];
+        mx = fmaxf(fmaxf(mx, fmaxf(fabsf(v.x), fabsf(v.y))), fmaxf(fabsf(v.z), fabsf(v.w)));
+    }
+    if (blockIdx.x == 0 && threadIdx.x < (int)(n - n4 * 4)) mx = fmaxf(mx, fabsf(x[n4 * 4 + threadIdx.x]));
+    amax_publish(mx, amax);
 }
 
 __global__ void bn_param_grad_kernel(double* __restrict__ slots, int nslots, int clear, int C, double* __restrict__ folded, float* dgamma,
@@ -478,14 +509,26 @@ extern "C" int vbg_bn_bwd_reduce(const float* dy, const float* y, const float* x
 extern "C" int vbg_bn_bwd_apply(const float* dy, const float* y, const float* x, long long M, int C, const float* mean,
                                 const float* invstd, const float* gamma, const double* sums, double count,
                                 const double* count_dev, int relu, float* dx, float* dres, float* dgamma_accum,
-                                float* dbeta_accum, void* stream) {
+                                float* dbeta_accum, unsigned* dx_amax, void* stream) {
     VBG_CHECK_ARG(dy && x && mean && invstd && gamma && sums && dx && M >= 0 && C > 0 && (count > 0 || count_dev) && (!relu || y));
     VBG_CHECK_ARG(C % 4 == 0 && ALIGNED16(dy) && ALIGNED16(x) && ALIGNED16(dx) && ALIGNED16(mean) && ALIGNED16(invstd) &&
                   ALIGNED16(gamma) && (!relu || ALIGNED16(y)) && (!dres || ALIGNED16(dres)));
+    if (dx_amax) {
+        hipError_t e = hipMemsetAsync(dx_amax, 0, sizeof(unsigned), S_);
+        if (e != hipSuccess) return (int)e;
+    }
     if (M > 0) VBG_LAUNCH(bn_bwd_apply_kernel, dim3(ew_grid(M * (C / 4), 256)), dim3(256), 0, S_, dy, y, x, M, C / 4, C, mean, invstd,
-                          gamma, sums, count, count_dev, relu, dx, dres);
+                          gamma, sums, count, count_dev, relu, dx, dres, dx_amax);
     if (dgamma_accum && dbeta_accum)
         VBG_LAUNCH(bn_param_grad_kernel, dim3(cdiv(C, 256)), dim3(256), 0, S_, const_cast<double*>(sums), 1, 0, C, (double*)nullptr, dgamma_accum, dbeta_accum);
+    VBG_LAUNCH_RET();
+}
+
+extern "C" int vbg_amax(const float* x, long long n, unsigned* amax, void* stream) {
+    VBG_CHECK_ARG(n >= 0 && amax);
+    if (n == 0) return VBG_OK;
+    VBG_CHECK_ARG(x && ALIGNED16(x));
+    VBG_LAUNCH(amax_kernel, dim3(ew_grid((n + 3) / 4, 256 * 8)), dim3(256), 0, S_, x, n, amax);
     VBG_LAUNCH_RET();
 }
 

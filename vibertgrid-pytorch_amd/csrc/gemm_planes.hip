@@ -16,6 +16,7 @@
 // forward / dgrad / wgrad, the 1x1 convolutions of model/ResNetFPN_ViBERTgrid.py, the heads' MLPs.
 #include "vbg_common.h"
 #include <type_traits>
+#include <cstdlib>
 #include <hip/hip_ext.h>
 #include "../../include/vbg.h"
 
@@ -39,7 +40,7 @@ typedef __attribute__((address_space(3))) pg_v4s* pg_lds_v4s;
 //   two ds_read_b64_tr_b16: each 16-lane group reads a [4 k][16 col] block, lane i supplying the address of (k = i / 4, cols
 //   4 (i % 4)..+3) and receiving the 4 k of column i (lane semantics verified on the hardware, tools/probes/tr_probe.hip).
 //   Rows past the reduction length fall off the per-plane buffer descriptors and read 0.
-template <int BM, int BN, int WGM, int WGN, int NST, bool TRANS>
+template <int BM, int BN, int WGM, int WGN, int NST, bool TRANS, bool PP = true>
 __global__ __launch_bounds__(WGM * WGN * 64) void plane_gemm_kernel(const vbg_plane_gemm_desc p) {
     static_assert(!TRANS || ((BM == 128 || BM == 256) && BN == 128), "TN: 128- or 256-column A tiles, 128-column B tiles");
     constexpr int NW = WGM * WGN, NT = NW * 64;
@@ -149,18 +150,28 @@ __global__ __launch_bounds__(WGM * WGN * 64) void plane_gemm_kernel(const vbg_pl
     typedef __attribute__((address_space(3))) void* lds_ptr;
     // `inv` = PG_INVALID for a tile past the block's range: every lane's offset falls outside the descriptor, the DMA writes zeros
     // into a stage nobody reads and moves no memory -- the loop body stays branch free (one scheduling region per half iteration)
+    // (NT form, ping-pong schedule: the A and the B share of a tile are issued in different intervals)
+    auto issue_a = [&](int stage, unsigned inv) {
+        unsigned char* sb = smem + stage * STAGE;
+        const __amdgpu_buffer_rsrc_t ra = pg_rsrc(abase);
+#pragma unroll
+        for (int i = 0; i < NIA; ++i)
+            __builtin_amdgcn_raw_ptr_buffer_load_lds(ra, (lds_ptr)(sb + alds[i]), 16, (int)(avo[i] | inv), 0, 0, 0);
+        abase += BK;
+    };
+    auto issue_b = [&](int stage, unsigned inv) {
+        unsigned char* sb = smem + stage * STAGE;
+        const __amdgpu_buffer_rsrc_t rb = pg_rsrc(bbase);
+#pragma unroll
+        for (int i = 0; i < NIB; ++i)
+            __builtin_amdgcn_raw_ptr_buffer_load_lds(rb, (lds_ptr)(sb + blds[i]), 16, (int)(bvo[i] | inv), 0, 0, 0);
+        bbase += BK;
+    };
     auto issue = [&](int stage, unsigned inv) {
         unsigned char* sb = smem + stage * STAGE;
         if constexpr (!TRANS) {
-            const __amdgpu_buffer_rsrc_t ra = pg_rsrc(abase), rb = pg_rsrc(bbase);
-#pragma unroll
-            for (int i = 0; i < NIA; ++i)
-                __builtin_amdgcn_raw_ptr_buffer_load_lds(ra, (lds_ptr)(sb + alds[i]), 16, (int)(avo[i] | inv), 0, 0, 0);
-#pragma unroll
-            for (int i = 0; i < NIB; ++i)
-                __builtin_amdgcn_raw_ptr_buffer_load_lds(rb, (lds_ptr)(sb + blds[i]), 16, (int)(bvo[i] | inv), 0, 0, 0);
-            abase += BK;
-            bbase += BK;
+            issue_a(stage, inv);
+            issue_b(stage, inv);
         } else {
             // one descriptor per plane, ending behind the last row of the reduction (the plane of unit i of a wave is a compile-time
             // constant: units are dealt to the waves plane by plane)
@@ -266,6 +277,63 @@ __global__ __launch_bounds__(WGM * WGN * 64) void plane_gemm_kernel(const vbg_pl
     // during tile t, barrier at the end of the iteration.
     constexpr int NIW = NIA + NIB;
     constexpr int NMMA = 6 * TM * TN, NRD = (TRANS ? 6 : 3) * (TM + TN);
+    // ---- ping-pong schedule of the 8-wave NT tiles --------------------------------------------------------------------------
+    // Waves w and w + 4 of a workgroup share a SIMD (measured: tools/probes/pingpong_gemm_probe.hip prints HW_ID).  In lockstep both
+    // issue their DMA, read their fragments and then want the matrix pipe at the same moments: matrix-pipe busy 0.40-0.47 of a full
+    // round of tiles.  Here the waves form two groups (0-3 / 4-7: the two waves of every SIMD in different groups) that run ONE
+    // barrier interval apart: while a group issues the 12 MFMAs of a 16-deep k-step, its partners issue DMA and read the fragments of
+    // their next k-step.  Intervals of a tile t per group: L0 (DMA + fragments of k-step 0) | M0 | L1 (DMA + fragments of k-step 1)
+    // | M1, a barrier between any two.  Hazards (group 1 runs one interval behind group 0):
+    //   NST = 3: tile t + 2 is issued during tile t (A share in L0, B share in L1) into the stage of tile t - 1, whose last readers
+    //            (group 1's L1 of tile t - 1) finished one interval before group 0's L0 of tile t; every wave waits for its share of
+    //            tile t + 1 at the end of L1 (counted vmcnt: tile t + 2 stays in flight), two barriers before anybody reads it;
+    //   NST = 2: all of tile t + 1 is issued in L0 of tile t (same argument) and waited for at the end of L1.
+    // Every accumulator sees the same MFMAs in the same order as in the lockstep loop: results are bit-identical.
+    if constexpr (!TRANS && NW == 8 && PP) {
+        const int grp = wave >> 2;
+        issue(0, 0u);
+        if constexpr (NST == 3) {
+            issue(1, ntiles > 1 ? 0u : PG_INVALID);
+            asm volatile("s_waitcnt vmcnt(%0)" ::"n"(NIW) : "memory");
+        } else {
+            asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+        }
+        __builtin_amdgcn_s_barrier();                       // tile 0 has landed (every wave's share)
+        if (grp) __builtin_amdgcn_s_barrier();              // group 1 starts one interval late
+        int cur = 0;
+        for (int t = 0; t < ntiles; ++t) {
+            const int nxt = (cur + 1 == NST) ? 0 : cur + 1;
+            const int nn = (nxt + 1 == NST) ? 0 : nxt + 1;
+            const unsigned inv = (t + NST - 1 < ntiles) ? 0u : PG_INVALID;
+            __builtin_amdgcn_sched_barrier(0);
+            if constexpr (NST == 3) issue_a(nn, inv); else issue(nxt, inv);
+            read_frags(cur, fo0, fa0, fb0);
+            __builtin_amdgcn_sched_barrier(0);
+            asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+            __builtin_amdgcn_s_barrier();
+            __builtin_amdgcn_sched_barrier(0);
+            __builtin_amdgcn_s_setprio(1);
+            mma(fa0, fb0);
+            __builtin_amdgcn_s_setprio(0);
+            __builtin_amdgcn_sched_barrier(0);
+            __builtin_amdgcn_s_barrier();
+            __builtin_amdgcn_sched_barrier(0);
+            if constexpr (NST == 3) issue_b(nn, inv);
+            read_frags(cur, fo1, fa0, fb0);
+            __builtin_amdgcn_sched_barrier(0);
+            if constexpr (NST == 3) asm volatile("s_waitcnt vmcnt(%0) lgkmcnt(0)" ::"n"(NIW) : "memory");
+            else asm volatile("s_waitcnt vmcnt(0) lgkmcnt(0)" ::: "memory");
+            __builtin_amdgcn_s_barrier();
+            __builtin_amdgcn_sched_barrier(0);
+            __builtin_amdgcn_s_setprio(1);
+            mma(fa0, fb0);
+            __builtin_amdgcn_s_setprio(0);
+            __builtin_amdgcn_sched_barrier(0);
+            __builtin_amdgcn_s_barrier();
+            cur = nxt;
+        }
+        if (!grp) __builtin_amdgcn_s_barrier();             // group 0 waits for group 1's last interval
+    } else {
     issue(0, 0u);
     if constexpr (NST == 3) {
         issue(1, ntiles > 1 ? 0u : PG_INVALID);
@@ -329,6 +397,7 @@ __global__ __launch_bounds__(WGM * WGN * 64) void plane_gemm_kernel(const vbg_pl
         // in front of the next iteration's first MFMA, which would also wait for the set-1 reads issued just before it)
         settle0();
         cur = nxt;
+    }
     }
     __syncthreads();                               // every wave is done with the operand stages: the output tile is staged there
 
@@ -1047,6 +1116,12 @@ __global__ __launch_bounds__(256) void split_planes_t_batched_kernel(const float
     }
 }
 
+// VBG_PINGPONG=0: the lockstep k-loop of the 8-wave NT tiles (A/B measurements; results are bit-identical)
+static bool pg_pingpong() {
+    static const bool on = [] { const char* e = getenv("VBG_PINGPONG"); return !(e && e[0] == '0'); }();
+    return on;
+}
+
 template <int BM, int BN, int WGM, int WGN, int NST, bool TRANS = false>
 static void pg_launch(const vbg_plane_gemm_desc& d, hipStream_t s, hipEvent_t e0, hipEvent_t e1) {
     dim3 g(cdiv(d.M, BM), cdiv(d.N, BN), d.splitk);
@@ -1056,6 +1131,13 @@ static void pg_launch(const vbg_plane_gemm_desc& d, hipStream_t s, hipEvent_t e0
         g = dim3(total, 1, d.splitk);
     }
     (void)hipGetLastError();
+    if constexpr (!TRANS && WGM * WGN == 8) {
+        if (!pg_pingpong()) {
+            if (e0 && e1) hipExtLaunchKernelGGL((plane_gemm_kernel<BM, BN, WGM, WGN, NST, TRANS, false>), g, dim3(WGM * WGN * 64), 0, s, e0, e1, 0, d);
+            else hipLaunchKernelGGL((plane_gemm_kernel<BM, BN, WGM, WGN, NST, TRANS, false>), g, dim3(WGM * WGN * 64), 0, s, d);
+            return;
+        }
+    }
     if (e0 && e1) hipExtLaunchKernelGGL((plane_gemm_kernel<BM, BN, WGM, WGN, NST, TRANS>), g, dim3(WGM * WGN * 64), 0, s, e0, e1, 0, d);
     else hipLaunchKernelGGL((plane_gemm_kernel<BM, BN, WGM, WGN, NST, TRANS>), g, dim3(WGM * WGN * 64), 0, s, d);
 }

@@ -351,9 +351,14 @@ class ConvBnFn(torch.autograd.Function):
             sums = torch.zeros_like(sums)
         elif sync:
             dist.all_reduce(sums, group=SyncCtx.group)
-        dz2, dres2 = ops.bn_bwd_apply(dy2, y2, z2, mean, invstd, gamma, sums, count, relu, has_res, None, None, count_dev)
+        # the fp16-form products that consume dz (input gradient of a wide 3x3 convolution) scale it by its largest magnitude, which
+        # rides on the kernel that writes dz
+        B_, H_, W_, Cin_ = x.shape
+        want_amax = ctx.needs_input_grad[0] and ops.conv3_f16_bwd_ok(B_, H_, W_, C, Cin_, w4.shape[1], w4.shape[2], stride, pad)
+        dz_amax = ops.amax_slot(dy2.device) if want_amax else None
+        dz2, dres2 = ops.bn_bwd_apply(dy2, y2, z2, mean, invstd, gamma, sums, count, relu, has_res, None, None, count_dev, dx_amax=dz_amax)
         dz = dz2.view(z.shape)
-        dx = ops.conv2d_dgrad(dz, w4, tuple(x.shape), stride, pad) if ctx.needs_input_grad[0] else None
+        dx = ops.conv2d_dgrad(dz, w4, tuple(x.shape), stride, pad, dy_amax=dz_amax) if ctx.needs_input_grad[0] else None
         dw = _conv_wgrad_any(dz, x, col, tuple(w4.shape), stride, pad, ctx.w_ref)
         dres = dres2.view(z.shape) if has_res else None
         return dx, dw, dgamma, dbeta, None, None, dres, None, None, None, None, None, None, None

@@ -84,7 +84,8 @@ SIGNATURES = {
     "vbg_attn_mask": (c_int, [c_vp, c_vp, c_int, c_int, c_int, c_f, c_ull, c_ull, c_vp, c_vp, c_vp]),
     "vbg_colsum": (c_int, [c_vp, c_ll, c_int, c_int, c_vp, c_int, c_vp]),
     "vbg_colsum_f64": (c_int, [c_vp, c_ll, c_int, c_int, c_vp, c_int, c_vp, c_vp]),
-    "vbg_conv3x3": (c_int, [c_vp, c_vp, c_vp, c_vp, c_vp, c_int, c_int, c_int, c_int, c_int, c_int, c_int, c_int, c_vp]),
+    "vbg_conv3x3": (c_int, [c_vp, c_vp, c_vp, c_vp, c_vp, c_int, c_int, c_int, c_int, c_int, c_int, c_int, c_int, c_vp, c_vp]),
+    "vbg_amax": (c_int, [c_vp, c_ll, c_vp, c_vp]),
     "vbg_conv3x3_wflip": (c_int, [c_vp, c_int, c_int, c_vp, c_vp]),
     "vbg_conv3x3_wgrad_strips": (c_int, [c_int, c_int, c_int, c_int, c_int]),
     "vbg_conv3x3_wgrad": (c_int, [c_vp, c_vp, c_vp, c_vp, c_int, c_int, c_int, c_int, c_int, c_vp]),
@@ -116,7 +117,7 @@ SIGNATURES = {
     "vbg_bn_finalize": (c_int, [c_vp, c_int, c_int, c_d, c_vp, c_int, c_f, c_f, c_vp, c_vp, c_vp, c_vp, c_vp]),
     "vbg_bn_apply": (c_int, [c_vp, c_vp, c_ll, c_int, c_vp, c_vp, c_vp, c_vp, c_int, c_vp, c_vp]),
     "vbg_bn_bwd_reduce": (c_int, [c_vp, c_vp, c_vp, c_ll, c_int, c_vp, c_vp, c_int, c_vp, c_vp]),
-    "vbg_bn_bwd_apply": (c_int, [c_vp, c_vp, c_vp, c_ll, c_int, c_vp, c_vp, c_vp, c_vp, c_d, c_vp, c_int, c_vp, c_vp, c_vp, c_vp, c_vp]),
+    "vbg_bn_bwd_apply": (c_int, [c_vp, c_vp, c_vp, c_ll, c_int, c_vp, c_vp, c_vp, c_vp, c_d, c_vp, c_int, c_vp, c_vp, c_vp, c_vp, c_vp, c_vp]),
     "vbg_bn_param_grad": (c_int, [c_vp, c_int, c_int, c_int, c_vp, c_vp, c_vp, c_vp]),
     "vbg_maxpool3x3s2_fwd": (c_int, [c_vp, c_int, c_int, c_int, c_int, c_vp, c_vp, c_vp]),
     "vbg_maxpool3x3s2_bwd": (c_int, [c_vp, c_vp, c_int, c_int, c_int, c_int, c_int, c_int, c_vp, c_vp]),

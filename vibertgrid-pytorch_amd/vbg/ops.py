@@ -579,16 +579,30 @@ def set_conv3_f16(on: bool):
     _CONV3_F16[0] = bool(on)
 
 
-def conv3x3(x, w_ohwi, bias=None, out=None, stats=None, accumulate=False, f16x2=False):
-    """y (+)= conv3x3(x NHWC, w [N,3,3,Cs]), stride 1, pad 1 (csrc/conv3.hip).  f16x2: the two-piece fp16 form -- only for operands
-    inside fp16's range (activations, filters), never for gradients"""
+def amax_slot(device):
+    """a fresh device word for the bit pattern of a tensor's largest magnitude (vbg_amax / the amax output of bn_bwd_apply)"""
+    return torch.zeros((1,), device=device, dtype=torch.int32)
+
+
+def amax(x, slot=None):
+    """bit pattern of max |x| in a device word (no host sync): the scale of fp16-form products whose operand x is a gradient"""
+    slot = amax_slot(x.device) if slot is None else slot
+    check(lib.vbg_amax(P(x), x.numel(), P(slot), _stream()), "vbg_amax")
+    return slot
+
+
+def conv3x3(x, w_ohwi, bias=None, out=None, stats=None, accumulate=False, f16x2=False, x_amax=None):
+    """y (+)= conv3x3(x NHWC, w [N,3,3,Cs]), stride 1, pad 1 (csrc/conv3.hip).  f16x2: the two-piece fp16 form -- for operands inside
+    fp16's range (activations, filters); a gradient operand x needs x_amax (device word with the bits of max |x|): the kernel then
+    scales x by the power of two that centres it in fp16's range and the result back (exact)"""
     B, H, W, Cs = x.shape
     N = w_ohwi.shape[0]
     if out is None:
         assert not accumulate
         out = torch.empty((B, H, W, N), device=x.device, dtype=f32)
+    assert x_amax is None or f16x2
     check(lib.vbg_conv3x3(P(x), P(w_ohwi), P(bias), P(out), P(stats), bn_slots() if stats is not None else 0, B, H, W, Cs, N,
-                          int(accumulate), int(bool(f16x2)), _stream()), "vbg_conv3x3")
+                          int(accumulate), int(bool(f16x2)), P(x_amax), _stream()), "vbg_conv3x3")
     return out
 
 
@@ -647,8 +661,23 @@ def conv2d_fwd(x, w_ohwi, stride, pad, bias=None, out=None, stats=None):
 _BWD_SPLIT = 0          # backward products run with grad mode off; they are training-only, so the library may always split them
 
 
-def conv2d_dgrad(dy, w_ohwi, x_shape, stride, pad, out=None, accumulate=False):
-    """dx NHWC [B,H,W,Cin] (+)= conv_transpose(dy NHWC [B,Ho,Wo,Cout], w)."""
+_CONV3_F16_BWD = [os.environ.get("VBG_CONV3_F16_BWD", "1") != "0"]
+
+
+def set_conv3_f16_bwd(on: bool):
+    """input gradients of the wide 3x3 convolutions in the two-piece fp16 form, dy scaled by the power of two derived from its largest
+    magnitude (exact; csrc/conv3.hip); off: three bf16 pieces / six piece products"""
+    _CONV3_F16_BWD[0] = bool(on)
+
+
+def conv3_f16_bwd_ok(B, H, W, Cout, Cin, kh, kw, stride, pad) -> bool:
+    """will conv2d_dgrad of this convolution run the fp16 form (and want the largest magnitude of dy)?"""
+    return _CONV3_F16[0] and _CONV3_F16_BWD[0] and conv3_ok(B, H, W, Cout, Cin, kh, kw, stride, pad)
+
+
+def conv2d_dgrad(dy, w_ohwi, x_shape, stride, pad, out=None, accumulate=False, dy_amax=None):
+    """dx NHWC [B,H,W,Cin] (+)= conv_transpose(dy NHWC [B,Ho,Wo,Cout], w).  dy_amax: device word with the bits of max |dy| when the
+    producer of dy wrote one (bn_bwd_apply); otherwise the fp16 form takes it with one vbg_amax pass over dy"""
     _chk_f32(dy, w_ohwi)
     B, H, W, Cin = x_shape
     Cout, kh, kw, _ = w_ohwi.shape
@@ -660,6 +689,8 @@ def conv2d_dgrad(dy, w_ohwi, x_shape, stride, pad, out=None, accumulate=False):
     M = B * H * W
     if conv3_ok(B, H, W, Cout, Cin, kh, kw, stride, pad):
         # the input gradient of a 3x3 / s1 / p1 convolution is the same convolution of dy with the turned, channel-swapped filter
+        if _CONV3_F16[0] and _CONV3_F16_BWD[0]:
+            return conv3x3(dy, conv3x3_wflip(w_ohwi), None, out, None, accumulate, f16x2=True, x_amax=dy_amax if dy_amax is not None else amax(dy))
         return conv3x3(dy, conv3x3_wflip(w_ohwi), None, out, None, accumulate)
     if kh == 1 and kw == 1 and stride == 1 and pad == 0:
         gemm_raw(M, Cin, Cout, dy, Cout, OP_DENSE_K, w_ohwi, Cin, OP_DENSE_R, out, Cin, accumulate=accumulate, splitk=_BWD_SPLIT)
@@ -982,12 +1013,13 @@ def bn_bwd_reduce(dy, y, x, mean, invstd, relu):
     return sums
 
 
-def bn_bwd_apply(dy, y, x, mean, invstd, gamma, sums, count, relu, want_dres, dgamma, dbeta, count_dev=None):
+def bn_bwd_apply(dy, y, x, mean, invstd, gamma, sums, count, relu, want_dres, dgamma, dbeta, count_dev=None, dx_amax=None):
+    """dx_amax: int32 device word that receives the bit pattern of max |dx| (the scale of the fp16-form products that consume dx)"""
     M, C_ = x.shape
     dx = torch.empty_like(x)
     dres = torch.empty_like(x) if want_dres else None
     check(lib.vbg_bn_bwd_apply(P(dy), P(y), P(x), M, C_, P(mean), P(invstd), P(gamma), P(sums), float(count), P(count_dev), int(relu), P(dx), P(dres),
-                               P(dgamma), P(dbeta), _stream()), "vbg_bn_bwd_apply")
+                               P(dgamma), P(dbeta), P(dx_amax), _stream()), "vbg_bn_bwd_apply")
     return dx, dres
 
 
