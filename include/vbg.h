@@ -229,7 +229,11 @@ int vbg_conv3x3_wflip(const float* w, int Cout, int Cin, float* out, void* strea
  * Replaces the weight gradient autograd forms for torch.nn.Conv2d(k=3, s=1, p=1).  Requires W % 16 == 0, Cs % 32 == 0 and
  * Cout % 128 == 0 (or Cout % 64 == 0 and Cs % 64 == 0). */
 int vbg_conv3x3_wgrad_strips(int B, int H, int W, int Cs, int Cout);
-int vbg_conv3x3_wgrad(const float* dy, const float* x, float* dw, float* slab, int B, int H, int W, int Cs, int Cout, void* stream);
+int vbg_conv3x3_wgrad(const float* dy, const float* x, float* dw, float* slab, int B, int H, int W, int Cs, int Cout, int form,
+                      const unsigned* dy_amax, const unsigned* x_amax, void* stream);
+/* form 0: three bf16 pieces per operand, six piece products; form 1: two fp16 pieces, three piece products, both operands scaled by
+ * the powers of two that bring max |dy| and max |x| (bit patterns in the device words dy_amax / x_amax: vbg_amax, or the amax outputs
+ * of vbg_bn_bwd_apply / vbg_bn_apply) to [2^13, 2^14), the result scaled back: exact scaling, half the matrix-core work */
 
 /* stem im2col: NHWC [B,H,W,C] -> [B*Ho*Wo, Kpad] with k = (dy*kw+dx)*C + c, zero padded to Kpad */
 int vbg_im2col(const float* x, int B, int H, int W, int C, int kh, int kw, int stride, int pad, int Kpad,
@@ -342,7 +346,9 @@ int vbg_bn_finalize(double* stats, int nslots, int clear_slots, double count, co
                     float* mean, float* invstd, float* running_mean, float* running_var, void* stream);
 /* y = relu?( (x-mean)*invstd*gamma + beta (+ res) ) */
 int vbg_bn_apply(const float* x, const float* res, long long M, int C, const float* mean, const float* invstd,
-                 const float* gamma, const float* beta, int relu, float* y, void* stream);
+                 const float* gamma, const float* beta, int relu, float* y, unsigned* y_amax, void* stream);
+/* y_amax (optional): y_amax[0] = max(y_amax[0], bit pattern of max |y|) (the caller zeroes it): the scale of y as an operand of
+ * fp16-form products */
 /* backward reductions: slot[s][0..C) += sum(g), slot[s][C..2C) += sum(g*xhat), g = dy*(y>0 if relu) */
 int vbg_bn_bwd_reduce(const float* dy, const float* y, const float* x, long long M, int C, const float* mean,
                       const float* invstd, int relu, double* slots_accum, void* stream);
@@ -352,7 +358,8 @@ int vbg_bn_bwd_apply(const float* dy, const float* y, const float* x, long long 
                      const float* invstd, const float* gamma, const double* sums, double count, const double* count_dev,
                      int relu, float* dx,
                      float* dres, float* dgamma_accum, float* dbeta_accum, unsigned* dx_amax, void* stream);
-/* dx_amax (optional): receives the bit pattern of max |dx| (overwritten) -- the scale of the fp16-form products that consume dx */
+/* dx_amax (optional): dx_amax[0] = max(dx_amax[0], bit pattern of max |dx|) (the caller zeroes it) -- the scale of the fp16-form
+ * products that consume dx */
 /* fold `nslots` slot rows: folded[0..2C) = sum over slots (optional output), and (optional) the BatchNorm affine
    gradients from these LOCAL sums: dbeta += (float)folded[0..C), dgamma += (float)folded[C..2C)  (call before a SyncBN
    all-reduce of `folded`; torch.nn.SyncBatchNorm leaves weight/bias gradients per-rank for DDP to average,

@@ -47,7 +47,7 @@ def test_conv3_host_logic_without_a_gpu():
         assert s >= 1 and s * tiles == blocks, (B, H, W, Cs, Cout, s)
         assert nchunks // s >= 8
     assert strips(1, 4, 16, 32, 128) == 1                                                    # 4 chunks: one strip
-    assert L.lib.vbg_conv3x3_wgrad(None, None, None, None, 1, 16, 16, 32, 128, None) == -1
+    assert L.lib.vbg_conv3x3_wgrad(None, None, None, None, 1, 16, 16, 32, 128, 0, None, None, None) == -1
     assert L.lib.vbg_conv3x3_wflip(None, 1, 1, None, None) == -1
 
 

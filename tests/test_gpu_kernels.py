@@ -277,6 +277,21 @@ def test_conv3x3_wgrad(ops, B, H, W, Cs, Cout, slabs):
         dw2 = init.clone().to(dev())
         ops.conv3x3_wgrad(gyh, xh, dw2, slabs=True)
         assert torch.equal(dw, dw2)
+    # the two-piece fp16 form: both operands scaled by their largest magnitudes (exact powers of two), three piece products -- the
+    # same bound against fp64 at the magnitudes real gradients / activations have, far outside fp16's own range
+    for sy, sx in ((1.0, 1.0), (2.0 ** -30, 1.0), (2.0 ** -22, 2.0 ** 7), (2.0 ** 18, 2.0 ** -9)):
+        dwf = torch.zeros_like(init).to(dev())
+        ops.conv3x3_wgrad(gyh * sy, xh * sx, dwf, slabs=slabs, f16x2=True)
+        assert float((dwf.cpu() / (sy * sx) - (ref - init)).abs().max()) <= 3e-6 * scale, (sy, sx)
+    # an outlier 2^20 above the rest of dy: the small elements then sit below 2^-17 of the maximum and keep only their high piece
+    # exactly -- the error bound is absolute (2^-25 of the scaled range), still inside the fp32-grade bound of the whole sum
+    gyo = gyh.clone()
+    gyo[0, 0, 0, 0] = 2.0 ** 20
+    dwo = torch.zeros_like(init).to(dev())
+    ops.conv3x3_wgrad(gyo, xh, dwo, slabs=slabs, f16x2=True)
+    dwr = torch.zeros_like(init).to(dev())
+    ops.conv3x3_wgrad(gyo, xh, dwr, slabs=slabs)
+    assert float((dwo - dwr).abs().max()) <= 3e-6 * float(dwr.abs().max())
 
 
 def test_conv3x3_dispatch(ops):

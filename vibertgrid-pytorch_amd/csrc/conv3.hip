@@ -406,20 +406,28 @@ struct conv3w_args {
     float* slab;           // ... or [strips][Cout, 3, 3, Cs]: every strip stores its partial block plainly, conv3_wgrad_reduce_kernel adds them up
     int H, W, Cs, Cout;
     int nchunks, per;      // 16-pixel chunks in total / per strip
+    const unsigned* dy_amax;   // F16 form: bit patterns of max |dY| and max |X| (device words), the operands' power-of-two scales
+    const unsigned* x_amax;
 };
 
 typedef short c3_v4s __attribute__((ext_vector_type(4)));
 typedef __attribute__((address_space(3))) c3_v4s* c3_lds_v4s;
 typedef __attribute__((address_space(3))) unsigned char* c3_lds_bytes;
 
-template <int WCO>
+// F16: the arithmetic form -- false: three bf16 pieces per operand, six piece products; true: two fp16 pieces (hi = fp16(v s), lo =
+// fp16(v s - hi), round to nearest) of both operands after scaling each by the power of two s that brings its tensor's largest magnitude
+// to [2^13, 2^14) (exact), three piece products (lo hi, hi lo, hi hi) into the ONE accumulator of a tap (nine taps x two accumulators
+// would not fit the register file), the result scaled back in the epilogue.  Elements down to 2^-17 of the tensor's maximum keep 22
+// significant bits (lo is a normal fp16 there); below that the absolute error is <= 2^-25 (2^-39 of the maximum).
+template <int WCO, bool F16>
 __global__ __launch_bounds__(256, 2) void conv3x3_wgrad_kernel(const conv3w_args p) {
     constexpr int NT = 256, WCI = 4 / WCO, CO = 32 * WCO, CI = 32 * WCI;
+    constexpr int NPL = F16 ? 2 : 3;
     // bytes of a pixel row of the dY / X image: an odd multiple of 64 B (16 banks), so that the four consecutive pixel rows a
     // transposing read touches -- 32 bytes each for either 16-channel half -- lie on eight disjoint 8-bank groups
     constexpr int RSA = CO * 2 + 64, RSB = CI == 32 ? 64 : CI * 2 + 64;
     constexpr int PA = 16 * RSA, PB = 54 * RSB;                // one plane
-    constexpr int STAGE = 3 * (PA + PB);
+    constexpr int STAGE = NPL * (PA + PB);
     constexpr int QA = CO / 4, QB = CI / 4;                    // float4 per pixel
     constexpr int NDA = 16 * QA / NT, NXB = 54 * QB, NDB = (NXB + NT - 1) / NT;
     static_assert(16 * QA % NT == 0, "dY chunk divides over the threads");
@@ -430,6 +438,11 @@ __global__ __launch_bounds__(256, 2) void conv3x3_wgrad_kernel(const conv3w_args
     const int co0 = blockIdx.z * CO, ci0 = blockIdx.y * CI;
     const int c0 = blockIdx.x * p.per, c1 = min(p.nchunks, c0 + p.per);
     if (c0 >= c1) return;
+    float2 sc_a = make_float2(1.f, 1.f), sc_b = sc_a;
+    if constexpr (F16) {
+        sc_a = c3_pow2_scale(__builtin_amdgcn_readfirstlane(p.dy_amax[0]));
+        sc_b = c3_pow2_scale(__builtin_amdgcn_readfirstlane(p.x_amax[0]));
+    }
 
     // ---- loader: per-thread constants, per-chunk scalars -------------------------------------------------------------------
     unsigned avo[NDA], bvo[NDB];
@@ -478,14 +491,28 @@ __global__ __launch_bounds__(256, 2) void conv3x3_wgrad_kernel(const conv3w_args
         *reinterpret_cast<uint2*>(dst + PL) = m;
         *reinterpret_cast<uint2*>(dst + 2 * PL) = l;
     };
+    auto store2 = [&](unsigned char* dst, int PL, const float4& v, float sc) {
+        typedef float f32x2_t __attribute__((ext_vector_type(2)));
+        typedef _Float16 f16x2_t __attribute__((ext_vector_type(2)));
+        const f32x2_t v0 = {v.x * sc, v.y * sc}, v1 = {v.z * sc, v.w * sc};
+        const f16x2_t h0 = __builtin_convertvector(v0, f16x2_t), h1 = __builtin_convertvector(v1, f16x2_t);
+        const f16x2_t l0 = __builtin_convertvector(v0 - __builtin_convertvector(h0, f32x2_t), f16x2_t);
+        const f16x2_t l1 = __builtin_convertvector(v1 - __builtin_convertvector(h1, f32x2_t), f16x2_t);
+        *reinterpret_cast<uint2*>(dst) = make_uint2(__builtin_bit_cast(unsigned, h0), __builtin_bit_cast(unsigned, h1));
+        *reinterpret_cast<uint2*>(dst + PL) = make_uint2(__builtin_bit_cast(unsigned, l0), __builtin_bit_cast(unsigned, l1));
+    };
     auto store_chunk = [&](int stage) {
         unsigned char* sa = smem + stage * STAGE;
-        unsigned char* sb = sa + 3 * PA;
+        unsigned char* sb = sa + NPL * PA;
 #pragma unroll
-        for (int i = 0; i < NDA; ++i) store3(sa + alds[i], PA, ra[i]);
+        for (int i = 0; i < NDA; ++i) {
+            if constexpr (F16) store2(sa + alds[i], PA, ra[i], sc_a.x); else store3(sa + alds[i], PA, ra[i]);
+        }
 #pragma unroll
         for (int i = 0; i < NDB; ++i)
-            if (NXB % NT == 0 || i + 1 < NDB || tid + i * NT < NXB) store3(sb + blds[i], PB, rb[i]);
+            if (NXB % NT == 0 || i + 1 < NDB || tid + i * NT < NXB) {
+                if constexpr (F16) store2(sb + blds[i], PB, rb[i], sc_b.x); else store3(sb + blds[i], PB, rb[i]);
+            }
     };
 
     // ---- fragments -----------------------------------------------------------------------------------------------------------
@@ -515,26 +542,33 @@ __global__ __launch_bounds__(256, 2) void conv3x3_wgrad_kernel(const conv3w_args
         load_chunk(it + 1 < nch ? 0u : C3_INVALID);             // (past the strip: every lane reads 0, no traffic; stored into the idle stage)
         __builtin_amdgcn_sched_barrier(0);
         c3_lds_bytes as = (c3_lds_bytes)(smem + stage * STAGE) + ta;
-        c3_lds_bytes bs = (c3_lds_bytes)(smem + stage * STAGE + 3 * PA) + tb;
-        c3_u32x4 fa[3];
+        c3_lds_bytes bs = (c3_lds_bytes)(smem + stage * STAGE + NPL * PA) + tb;
+        c3_u32x4 fa[NPL];
 #pragma unroll
-        for (int q = 0; q < 3; ++q) fa[q] = frag(as + q * PA, RSA);
-        constexpr int qa[6] = {2, 0, 1, 1, 0, 0}, qb[6] = {0, 2, 1, 0, 1, 0};
+        for (int q = 0; q < NPL; ++q) fa[q] = frag(as + q * PA, RSA);
+        // piece products, smallest first; F16: (lo,hi) (hi,lo) (hi,hi)
+        constexpr int qa[6] = {F16 ? 1 : 2, 0, F16 ? 0 : 1, 1, 0, 0}, qb[6] = {0, F16 ? 1 : 2, F16 ? 0 : 1, 0, 1, 0};
 #pragma unroll
         for (int tap = 0; tap < 9; ++tap) {
-            c3_u32x4 fb[3];
+            c3_u32x4 fb[NPL];
 #pragma unroll
-            for (int q = 0; q < 3; ++q) fb[q] = frag(bs + q * PB + ((tap / 3) * 18 + tap % 3) * RSB, RSB);
+            for (int q = 0; q < NPL; ++q) fb[q] = frag(bs + q * PB + ((tap / 3) * 18 + tap % 3) * RSB, RSB);
 #pragma unroll
-            for (int t = 0; t < 6; ++t)
-                acc[tap] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(__builtin_bit_cast(c3_bf16x8, fa[qa[t]]), __builtin_bit_cast(c3_bf16x8, fb[qb[t]]),
-                                                                   acc[tap], 0, 0, 0);
+            for (int t = 0; t < (F16 ? 3 : 6); ++t) {
+                if constexpr (F16)
+                    acc[tap] = __builtin_amdgcn_mfma_f32_32x32x16_f16(__builtin_bit_cast(c3_f16x8, fa[qa[t]]), __builtin_bit_cast(c3_f16x8, fb[qb[t]]),
+                                                                      acc[tap], 0, 0, 0);
+                else
+                    acc[tap] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(__builtin_bit_cast(c3_bf16x8, fa[qa[t]]), __builtin_bit_cast(c3_bf16x8, fb[qb[t]]),
+                                                                       acc[tap], 0, 0, 0);
+            }
         }
         store_chunk(stage ^ 1);
         __syncthreads();
     }
     // ---- epilogue (lanes = 32 consecutive ci: 128-byte rows): the strip's partial block goes to its slab as plain stores (float
     //      atomics run at the L2's atomic rate: ~70 us for the 9.4 M partials of a 256 x 256 filter), or straight into dW ---------
+    const float unscale = sc_a.y * sc_b.y;                     // (1 in the bf16 form; a power of two: exact)
     if (p.slab) {
         float* const out = p.slab + (long long)blockIdx.x * Cout * 9 * Cs;
 #pragma unroll
@@ -542,7 +576,7 @@ __global__ __launch_bounds__(256, 2) void conv3x3_wgrad_kernel(const conv3w_args
 #pragma unroll
             for (int r = 0; r < 16; ++r) {
                 const int co = co0 + 32 * wco + (r & 3) + 8 * (r >> 2) + 4 * lk;
-                out[((long long)co * 9 + tap) * Cs + ci0 + 32 * wci + lr] = acc[tap][r];
+                out[((long long)co * 9 + tap) * Cs + ci0 + 32 * wci + lr] = F16 ? acc[tap][r] * unscale : acc[tap][r];
             }
         return;
     }
@@ -551,7 +585,7 @@ __global__ __launch_bounds__(256, 2) void conv3x3_wgrad_kernel(const conv3w_args
 #pragma unroll
         for (int r = 0; r < 16; ++r) {
             const int co = co0 + 32 * wco + (r & 3) + 8 * (r >> 2) + 4 * lk;
-            unsafeAtomicAdd(p.dW + ((long long)co * 9 + tap) * Cs + ci0 + 32 * wci + lr, acc[tap][r]);
+            unsafeAtomicAdd(p.dW + ((long long)co * 9 + tap) * Cs + ci0 + 32 * wci + lr, F16 ? acc[tap][r] * unscale : acc[tap][r]);
         }
 }
 
@@ -589,8 +623,10 @@ extern "C" int vbg_conv3x3_wgrad_strips(int B, int H, int W, int Cs, int Cout) {
     return (int)((nchunks + per - 1) / per);
 }
 
-extern "C" int vbg_conv3x3_wgrad(const float* dy, const float* x, float* dw, float* slab, int B, int H, int W, int Cs, int Cout, void* stream) {
+extern "C" int vbg_conv3x3_wgrad(const float* dy, const float* x, float* dw, float* slab, int B, int H, int W, int Cs, int Cout, int form,
+                                 const unsigned* dy_amax, const unsigned* x_amax, void* stream) {
     VBG_CHECK_ARG(dy && x && dw && B > 0 && H > 0 && W >= 16 && W % 16 == 0);
+    VBG_CHECK_ARG(form == 0 || (form == 1 && dy_amax && x_amax));
     VBG_CHECK_ARG(Cs % 32 == 0 && Cout % 64 == 0);
     VBG_CHECK_ARG((((uintptr_t)x) & 15) == 0 && (((uintptr_t)dy) & 15) == 0);
     VBG_CHECK_ARG((long long)(3 * W + 18) * Cs < (1ll << 28) && (long long)16 * Cout < (1ll << 28));
@@ -598,6 +634,7 @@ extern "C" int vbg_conv3x3_wgrad(const float* dy, const float* x, float* dw, flo
     VBG_CHECK_ARG(M < (1ll << 31));
     vbg::conv3w_args a;
     a.dY = dy; a.X = x; a.dW = dw; a.slab = slab; a.H = H; a.W = W; a.Cs = Cs; a.Cout = Cout;
+    a.dy_amax = dy_amax; a.x_amax = x_amax;
     a.nchunks = (int)(M / 16);
     const bool wide = Cout % 128 == 0;                         // [128 co x 32 ci] blocks, else [64 co x 64 ci]
     VBG_CHECK_ARG(wide || Cs % 64 == 0);
@@ -605,9 +642,11 @@ extern "C" int vbg_conv3x3_wgrad(const float* dy, const float* x, float* dw, flo
     VBG_CHECK_ARG(nsplit >= 1 && (!slab || (((uintptr_t)slab) & 15) == 0) && (((uintptr_t)dw) & 15) == 0);
     a.per = (a.nchunks + nsplit - 1) / nsplit;
     if (wide) {
-        VBG_LAUNCH(vbg::conv3x3_wgrad_kernel<4>, dim3(nsplit, Cs / 32, Cout / 128), dim3(256), 0, (hipStream_t)stream, a);
+        if (form == 1) { VBG_LAUNCH((vbg::conv3x3_wgrad_kernel<4, true>), dim3(nsplit, Cs / 32, Cout / 128), dim3(256), 0, (hipStream_t)stream, a); }
+        else { VBG_LAUNCH((vbg::conv3x3_wgrad_kernel<4, false>), dim3(nsplit, Cs / 32, Cout / 128), dim3(256), 0, (hipStream_t)stream, a); }
     } else {
-        VBG_LAUNCH(vbg::conv3x3_wgrad_kernel<2>, dim3(nsplit, Cs / 64, Cout / 64), dim3(256), 0, (hipStream_t)stream, a);
+        if (form == 1) { VBG_LAUNCH((vbg::conv3x3_wgrad_kernel<2, true>), dim3(nsplit, Cs / 64, Cout / 64), dim3(256), 0, (hipStream_t)stream, a); }
+        else { VBG_LAUNCH((vbg::conv3x3_wgrad_kernel<2, false>), dim3(nsplit, Cs / 64, Cout / 64), dim3(256), 0, (hipStream_t)stream, a); }
     }
     if (slab) {
         const long long n4 = (long long)Cout * 9 * Cs / 4;

@@ -125,12 +125,29 @@ __global__ void bn_finalize_kernel(double* __restrict__ stats, int nslots, int c
     }
 }
 
+// block-wide max of non-negative floats into a device word holding a bit pattern (non-negative floats order like their bits).  One
+// atomic per block at most, and none when the word already holds a larger value (same-address atomics serialise at ~10 ns each:
+// 8192 wave-level atomics cost ~100 us, measured)
+__device__ __forceinline__ void amax_publish(float mx, unsigned* amax) {
+    __shared__ float amax_sh[16];
+#pragma unroll
+    for (int o = 32; o > 0; o >>= 1) mx = fmaxf(mx, __shfl_xor(mx, o, 64));
+    if ((threadIdx.x & 63) == 0) amax_sh[threadIdx.x >> 6] = mx;
+    __syncthreads();
+    if (threadIdx.x == 0) {
+        for (int w = 1; w < (int)(blockDim.x >> 6); ++w) mx = fmaxf(mx, amax_sh[w]);
+        const unsigned bits = __float_as_uint(mx);
+        if (bits > __hip_atomic_load(amax, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT)) atomicMax(amax, bits);
+    }
+}
+
 __global__ void bn_apply_kernel(const float* __restrict__ x, const float* __restrict__ res, long long M, int C4,
                                 const float* __restrict__ mean, const float* __restrict__ invstd,
                                 const float* __restrict__ gamma, const float* __restrict__ beta, int relu,
-                                float* __restrict__ y) {
+                                float* __restrict__ y, unsigned* amax) {
     const long long total = M * C4;
     const long long stride = (long long)gridDim.x * blockDim.x;
+    float mx = 0.f;
     for (long long i = (long long)blockIdx.x * blockDim.x + threadIdx.x; i < total; i += stride) {
         const int c4 = (int)(i % C4);
         const float4 xv = reinterpret_cast<const float4*>(x)[i];
@@ -147,23 +164,9 @@ __global__ void bn_apply_kernel(const float* __restrict__ x, const float* __rest
         }
         if (relu) { o.x = fmaxf(o.x, 0.f); o.y = fmaxf(o.y, 0.f); o.z = fmaxf(o.z, 0.f); o.w = fmaxf(o.w, 0.f); }
         reinterpret_cast<float4*>(y)[i] = o;
+        mx = fmaxf(fmaxf(mx, fmaxf(fabsf(o.x), fabsf(o.y))), fmaxf(fabsf(o.z), fabsf(o.w)));
     }
-}
-
-// block-wide max of non-negative floats into a device word holding a bit pattern (non-negative floats order like their bits).  One
-// atomic per block at most, and none when the word already holds a larger value (same-address atomics serialise at ~10 ns each:
-// 8192 wave-level atomics cost ~100 us, measured)
-__device__ __forceinline__ void amax_publish(float mx, unsigned* amax) {
-    __shared__ float amax_sh[16];
-#pragma unroll
-    for (int o = 32; o > 0; o >>= 1) mx = fmaxf(mx, __shfl_xor(mx, o, 64));
-    if ((threadIdx.x & 63) == 0) amax_sh[threadIdx.x >> 6] = mx;
-    __syncthreads();
-    if (threadIdx.x == 0) {
-        for (int w = 1; w < (int)(blockDim.x >> 6); ++w) mx = fmaxf(mx, amax_sh[w]);
-        const unsigned bits = __float_as_uint(mx);
-        if (bits > __hip_atomic_load(amax, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT)) atomicMax(amax, bits);
-    }
+    if (amax) amax_publish(mx, amax);                            // (uniform)
 }
 
 __global__ void bn_bwd_apply_kernel(const float* __restrict__ dy, const float* __restrict__ y, const float* __restrict__ x,
@@ -484,13 +487,13 @@ extern "C" int vbg_bn_finalize(double* stats, int nslots, int clear_slots, doubl
 }
 
 extern "C" int vbg_bn_apply(const float* x, const float* res, long long M, int C, const float* mean, const float* invstd,
-                            const float* gamma, const float* beta, int relu, float* y, void* stream) {
+                            const float* gamma, const float* beta, int relu, float* y, unsigned* y_amax, void* stream) {
     VBG_CHECK_ARG(x && mean && invstd && gamma && beta && y && M >= 0 && C > 0 && C % 4 == 0);
     VBG_CHECK_ARG(ALIGNED16(x) && ALIGNED16(y) && ALIGNED16(mean) && ALIGNED16(invstd) && ALIGNED16(gamma) && ALIGNED16(beta) &&
                   (!res || ALIGNED16(res)));
     if (M == 0) return VBG_OK;
     VBG_LAUNCH(bn_apply_kernel, dim3(ew_grid(M * (C / 4), 256)), dim3(256), 0, S_, x, res, M, C / 4, mean, invstd, gamma,
-                       beta, relu, y);
+                       beta, relu, y, y_amax);
     VBG_LAUNCH_RET();
 }
 
@@ -513,10 +516,6 @@ extern "C" int vbg_bn_bwd_apply(const float* dy, const float* y, const float* x,
     VBG_CHECK_ARG(dy && x && mean && invstd && gamma && sums && dx && M >= 0 && C > 0 && (count > 0 || count_dev) && (!relu || y));
     VBG_CHECK_ARG(C % 4 == 0 && ALIGNED16(dy) && ALIGNED16(x) && ALIGNED16(dx) && ALIGNED16(mean) && ALIGNED16(invstd) &&
                   ALIGNED16(gamma) && (!relu || ALIGNED16(y)) && (!dres || ALIGNED16(dres)));
-    if (dx_amax) {
-        hipError_t e = hipMemsetAsync(dx_amax, 0, sizeof(unsigned), S_);
-        if (e != hipSuccess) return (int)e;
-    }
     if (M > 0) VBG_LAUNCH(bn_bwd_apply_kernel, dim3(ew_grid(M * (C / 4), 256)), dim3(256), 0, S_, dy, y, x, M, C / 4, C, mean, invstd,
                           gamma, sums, count, count_dev, relu, dx, dres, dx_amax);
     if (dgamma_accum && dbeta_accum)

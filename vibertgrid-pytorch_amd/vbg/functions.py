@@ -232,7 +232,7 @@ def _conv_any(x, w4, stride, pad, bias=None, want_stats=False):
     return ops.conv2d_fwd(x, w4, stride, pad, bias, stats=stats), None, stats
 
 
-def _conv_wgrad_any(dy, x, col, w4_shape, stride, pad, w_param=None):
+def _conv_wgrad_any(dy, x, col, w4_shape, stride, pad, w_param=None, dy_amax=None, x_amax=None):
     """-> OIHW-shaped gradient for autograd, or None when accumulated straight into the sunk flat gradient"""
     dst = wgrad_dest(w_param) if w_param is not None else None
     if dst is not None:
@@ -244,7 +244,7 @@ def _conv_wgrad_any(dy, x, col, w4_shape, stride, pad, w_param=None):
             sk = ops._pick_splitk(Cout, K, col.shape[0])
             ops.gemm_raw(Cout, K, col.shape[0], dy, Cout, OP_DENSE_R, col, col.shape[1], OP_DENSE_R, dw, K, accumulate=True, splitk=sk)
         else:
-            ops.conv2d_wgrad(dy, x, dw, stride, pad, accumulate=True)
+            ops.conv2d_wgrad(dy, x, dw, stride, pad, accumulate=True, dy_amax=dy_amax, x_amax=x_amax)
         wgrad_done(w_param)
         return None
     dw = torch.empty(w4_shape, device=dy.device, dtype=f32)
@@ -257,7 +257,7 @@ def _conv_wgrad_any(dy, x, col, w4_shape, stride, pad, w_param=None):
             dw.zero_()
         ops.gemm_raw(Cout, K, Mpix, dy, Cout, OP_DENSE_R, col, col.shape[1], OP_DENSE_R, dw, K, accumulate=sk > 1, splitk=sk)
     else:
-        ops.conv2d_wgrad(dy, x, dw, stride, pad, accumulate=False)
+        ops.conv2d_wgrad(dy, x, dw, stride, pad, accumulate=False, dy_amax=dy_amax, x_amax=x_amax)
     return oihw_grad_like(dw)
 
 
@@ -266,6 +266,7 @@ class ConvFn(torch.autograd.Function):
 
     @staticmethod
     def forward(ctx, x, w, b, stride, pad):
+        ctx.x_amax = getattr(x, "_vbg_amax", None)        # the producer's word with the bits of max |x| (see ConvBnFn), if any
         x = _c(x)
         w4 = ohwi(w)
         y, col, _ = _conv_any(x, w4, stride, pad, b)
@@ -278,8 +279,14 @@ class ConvFn(torch.autograd.Function):
     def backward(ctx, dy):
         x, w4, col = ctx.saved_tensors
         dy = _c(dy)
-        dx = ops.conv2d_dgrad(dy, w4, tuple(x.shape), ctx.stride, ctx.pad) if ctx.needs_input_grad[0] else None
-        dw = _conv_wgrad_any(dy, x, col, tuple(w4.shape), ctx.stride, ctx.pad, ctx.w_ref)
+        B_, H_, W_, Cin_ = x.shape
+        Cout_, kh, kw, _ = w4.shape
+        # fp16-form products of the wide 3x3 convolutions: ONE pass for the largest magnitude of dy serves both gradients
+        f16_d = ctx.needs_input_grad[0] and ops.conv3_f16_bwd_ok(B_, H_, W_, Cout_, Cin_, kh, kw, ctx.stride, ctx.pad)
+        f16_w = col is None and ops.conv3_f16_wgrad_ok(B_, H_, W_, Cin_, Cout_, kh, kw, ctx.stride, ctx.pad)
+        dy_amax = ops.amax(dy) if (f16_d or f16_w) else None
+        dx = ops.conv2d_dgrad(dy, w4, tuple(x.shape), ctx.stride, ctx.pad, dy_amax=dy_amax) if ctx.needs_input_grad[0] else None
+        dw = _conv_wgrad_any(dy, x, col, tuple(w4.shape), ctx.stride, ctx.pad, ctx.w_ref, dy_amax=dy_amax, x_amax=ctx.x_amax)
         db = _bias_grad(ctx.b_ref, dy.view(-1, dy.shape[-1])) if ctx.has_bias else None
         return dx, dw, db, None, None
 
@@ -304,6 +311,7 @@ class ConvBnFn(torch.autograd.Function):
 
     @staticmethod
     def forward(ctx, x, w, gamma, beta, running_mean, running_var, res, stride, pad, relu, training, momentum, eps, sync):
+        ctx.x_amax = getattr(x, "_vbg_amax", None)        # the producer's word with the bits of max |x|, if any
         x = _c(x)
         sync = bool(sync) and SyncCtx.active()
         w4 = ohwi(w)
@@ -327,7 +335,12 @@ class ConvBnFn(torch.autograd.Function):
         else:
             mean, invstd, count, count_dev = running_mean, _frozen_invstd(running_var, eps), float(M), None
         r2 = None if res is None else _c(res).view(-1, C)
-        y = ops.bn_apply(z2, r2, mean, invstd, gamma, beta, relu).view(z.shape)
+        # the largest magnitude of y rides on the kernel that writes it: the scale of y as an operand of the next convolution's
+        # fp16-form weight gradient (the tag travels on the tensor object; a consumer that does not find one takes a vbg_amax pass)
+        y_amax = ops.amax_slot(x.device) if (torch.is_grad_enabled() and ops.conv3_f16_bwd_enabled()) else None
+        y = ops.bn_apply(z2, r2, mean, invstd, gamma, beta, relu, y_amax=y_amax).view(z.shape)
+        if y_amax is not None:
+            y._vbg_amax = y_amax
         ctx.cfg = (stride, pad, relu, training, count, res is not None, sync)
         ctx.w_ref, ctx.affine = w, (gamma, beta)
         ctx.save_for_backward(x, w4, col, z, y if relu else None, mean, invstd, gamma, count_dev)
@@ -354,12 +367,13 @@ class ConvBnFn(torch.autograd.Function):
         # the fp16-form products that consume dz (input gradient of a wide 3x3 convolution) scale it by its largest magnitude, which
         # rides on the kernel that writes dz
         B_, H_, W_, Cin_ = x.shape
-        want_amax = ctx.needs_input_grad[0] and ops.conv3_f16_bwd_ok(B_, H_, W_, C, Cin_, w4.shape[1], w4.shape[2], stride, pad)
+        want_amax = (ctx.needs_input_grad[0] and ops.conv3_f16_bwd_ok(B_, H_, W_, C, Cin_, w4.shape[1], w4.shape[2], stride, pad)) or \
+            (col is None and ops.conv3_f16_wgrad_ok(B_, H_, W_, Cin_, C, w4.shape[1], w4.shape[2], stride, pad))
         dz_amax = ops.amax_slot(dy2.device) if want_amax else None
         dz2, dres2 = ops.bn_bwd_apply(dy2, y2, z2, mean, invstd, gamma, sums, count, relu, has_res, None, None, count_dev, dx_amax=dz_amax)
         dz = dz2.view(z.shape)
         dx = ops.conv2d_dgrad(dz, w4, tuple(x.shape), stride, pad, dy_amax=dz_amax) if ctx.needs_input_grad[0] else None
-        dw = _conv_wgrad_any(dz, x, col, tuple(w4.shape), stride, pad, ctx.w_ref)
+        dw = _conv_wgrad_any(dz, x, col, tuple(w4.shape), stride, pad, ctx.w_ref, dy_amax=dz_amax, x_amax=ctx.x_amax)
         dres = dres2.view(z.shape) if has_res else None
         return dx, dw, dgamma, dbeta, None, None, dres, None, None, None, None, None, None, None
 

@@ -88,7 +88,7 @@ SIGNATURES = {
     "vbg_amax": (c_int, [c_vp, c_ll, c_vp, c_vp]),
     "vbg_conv3x3_wflip": (c_int, [c_vp, c_int, c_int, c_vp, c_vp]),
     "vbg_conv3x3_wgrad_strips": (c_int, [c_int, c_int, c_int, c_int, c_int]),
-    "vbg_conv3x3_wgrad": (c_int, [c_vp, c_vp, c_vp, c_vp, c_int, c_int, c_int, c_int, c_int, c_vp]),
+    "vbg_conv3x3_wgrad": (c_int, [c_vp, c_vp, c_vp, c_vp, c_int, c_int, c_int, c_int, c_int, c_int, c_vp, c_vp, c_vp]),
     "vbg_im2col": (c_int, [c_vp, c_int, c_int, c_int, c_int, c_int, c_int, c_int, c_int, c_int, c_vp, c_vp]),
     "vbg_normalize_resize": (c_int, [c_vp, c_int, c_int, c_int, c_int, C.POINTER(c_f), C.POINTER(c_f), c_vp, c_int, c_int, c_int, c_vp]),
     "vbg_rescale_boxes": (c_int, [c_vp, c_int, c_f, c_f, c_vp, c_vp]),
@@ -115,7 +115,7 @@ SIGNATURES = {
     "vbg_bn_stats": (c_int, [c_vp, c_ll, c_int, c_vp, c_vp]),
     "vbg_bn_slots": (c_int, []),
     "vbg_bn_finalize": (c_int, [c_vp, c_int, c_int, c_d, c_vp, c_int, c_f, c_f, c_vp, c_vp, c_vp, c_vp, c_vp]),
-    "vbg_bn_apply": (c_int, [c_vp, c_vp, c_ll, c_int, c_vp, c_vp, c_vp, c_vp, c_int, c_vp, c_vp]),
+    "vbg_bn_apply": (c_int, [c_vp, c_vp, c_ll, c_int, c_vp, c_vp, c_vp, c_vp, c_int, c_vp, c_vp, c_vp]),
     "vbg_bn_bwd_reduce": (c_int, [c_vp, c_vp, c_vp, c_ll, c_int, c_vp, c_vp, c_int, c_vp, c_vp]),
     "vbg_bn_bwd_apply": (c_int, [c_vp, c_vp, c_vp, c_ll, c_int, c_vp, c_vp, c_vp, c_vp, c_d, c_vp, c_int, c_vp, c_vp, c_vp, c_vp, c_vp, c_vp]),
     "vbg_bn_param_grad": (c_int, [c_vp, c_int, c_int, c_int, c_vp, c_vp, c_vp, c_vp]),

@@ -579,9 +579,20 @@ def set_conv3_f16(on: bool):
     _CONV3_F16[0] = bool(on)
 
 
+_AMAX_POOL = {}
+
+
 def amax_slot(device):
-    """a fresh device word for the bit pattern of a tensor's largest magnitude (vbg_amax / the amax output of bn_bwd_apply)"""
-    return torch.zeros((1,), device=device, dtype=torch.int32)
+    """a fresh ZERO device word for the bit pattern of a tensor's largest magnitude (vbg_amax / the amax outputs of bn_apply and
+    bn_bwd_apply max INTO it).  Words come from a zero-filled pool of 1024 (one fill launch per 1024 slots); an exhausted pool is
+    replaced, never rewound, so a word saved for backward stays valid"""
+    key = (device.type, device.index)
+    ent = _AMAX_POOL.get(key)
+    if ent is None or ent[1] >= ent[0].numel():
+        ent = _AMAX_POOL[key] = [torch.zeros((1024,), device=device, dtype=torch.int32), 0]
+    i = ent[1]
+    ent[1] = i + 1
+    return ent[0][i:i + 1]
 
 
 def amax(x, slot=None):
@@ -626,15 +637,21 @@ def conv3w_ok(B, H, W, Cs, Cout, kh, kw, stride, pad) -> bool:
 _CONV3W_MIN = [int(os.environ.get("VBG_CONV3W_MIN", "8"))]
 
 
-def conv3x3_wgrad(dy, x, dw_ohwi, slabs=True):
-    """dw += conv3x3 weight gradient (stride 1, pad 1); slabs: deterministic strip reduction through scratch, else float atomics"""
+def conv3x3_wgrad(dy, x, dw_ohwi, slabs=True, f16x2=False, dy_amax=None, x_amax=None):
+    """dw += conv3x3 weight gradient (stride 1, pad 1); slabs: deterministic strip reduction through scratch, else float atomics.
+    f16x2: two fp16 pieces per operand / three piece products, both operands scaled by their largest magnitudes (device words
+    dy_amax / x_amax, taken with vbg_amax passes when the producers did not write them)"""
     B, H, W, Cs = x.shape
     Cout = dy.shape[3]
     slab = None
     if slabs:
         strips = int(lib.vbg_conv3x3_wgrad_strips(B, H, W, Cs, Cout))
         slab = torch.empty((strips, dw_ohwi.numel()), device=x.device, dtype=f32)
-    check(lib.vbg_conv3x3_wgrad(P(dy), P(x), P(dw_ohwi), P(slab), B, H, W, Cs, Cout, _stream()), "vbg_conv3x3_wgrad")
+    if f16x2:
+        dy_amax = amax(dy) if dy_amax is None else dy_amax
+        x_amax = amax(x) if x_amax is None else x_amax
+    check(lib.vbg_conv3x3_wgrad(P(dy), P(x), P(dw_ohwi), P(slab), B, H, W, Cs, Cout, int(bool(f16x2)), P(dy_amax), P(x_amax), _stream()),
+          "vbg_conv3x3_wgrad")
     return dw_ohwi
 
 
@@ -670,6 +687,10 @@ def set_conv3_f16_bwd(on: bool):
     _CONV3_F16_BWD[0] = bool(on)
 
 
+def conv3_f16_bwd_enabled() -> bool:
+    return _CONV3[0] and _SPLIT3[0] and not _AMP[0] and _CONV3_F16[0] and _CONV3_F16_BWD[0]
+
+
 def conv3_f16_bwd_ok(B, H, W, Cout, Cin, kh, kw, stride, pad) -> bool:
     """will conv2d_dgrad of this convolution run the fp16 form (and want the largest magnitude of dy)?"""
     return _CONV3_F16[0] and _CONV3_F16_BWD[0] and conv3_ok(B, H, W, Cout, Cin, kh, kw, stride, pad)
@@ -701,7 +722,12 @@ def conv2d_dgrad(dy, w_ohwi, x_shape, stride, pad, out=None, accumulate=False, d
     return out
 
 
-def conv2d_wgrad(dy, x, dw_ohwi, stride, pad, accumulate=True):
+def conv3_f16_wgrad_ok(B, H, W, Cin, Cout, kh, kw, stride, pad) -> bool:
+    """will conv2d_wgrad of this convolution run the fp16 form (and want the largest magnitudes of dy and x)?"""
+    return _CONV3_F16[0] and _CONV3_F16_BWD[0] and conv3w_ok(B, H, W, Cin, Cout, kh, kw, stride, pad)
+
+
+def conv2d_wgrad(dy, x, dw_ohwi, stride, pad, accumulate=True, dy_amax=None, x_amax=None):
     """dw [Cout,kh,kw,Cin] (+)= sum over pixels dy^T * im2col(x)."""
     _chk_f32(dy, x, dw_ohwi)
     B, H, W, Cin = x.shape
@@ -712,6 +738,8 @@ def conv2d_wgrad(dy, x, dw_ohwi, stride, pad, accumulate=True):
     if conv3w_ok(B, H, W, Cin, Cout, kh, kw, stride, pad):
         if not accumulate:
             dw_ohwi.zero_()
+        if _CONV3_F16[0] and _CONV3_F16_BWD[0]:
+            return conv3x3_wgrad(dy, x, dw_ohwi, f16x2=True, dy_amax=dy_amax, x_amax=x_amax)
         return conv3x3_wgrad(dy, x, dw_ohwi)
     sk = _pick_splitk(Cout, Kc, Mpix)
     if not accumulate and sk > 1:
@@ -997,11 +1025,12 @@ def bn_epoch() -> int:
     return _BN_EPOCH[0]
 
 
-def bn_apply(x2d, res2d, mean, invstd, gamma, beta, relu, out=None):
+def bn_apply(x2d, res2d, mean, invstd, gamma, beta, relu, out=None, y_amax=None):
+    """y_amax: zeroed int32 device word that receives the bit pattern of max |y|"""
     M, C_ = x2d.shape
     if out is None:
         out = torch.empty_like(x2d)
-    check(lib.vbg_bn_apply(P(x2d), P(res2d), M, C_, P(mean), P(invstd), P(gamma), P(beta), int(relu), P(out), _stream()), "vbg_bn_apply")
+    check(lib.vbg_bn_apply(P(x2d), P(res2d), M, C_, P(mean), P(invstd), P(gamma), P(beta), int(relu), P(out), P(y_amax), _stream()), "vbg_bn_apply")
     return out
 
 
@@ -1014,7 +1043,7 @@ def bn_bwd_reduce(dy, y, x, mean, invstd, relu):
 
 
 def bn_bwd_apply(dy, y, x, mean, invstd, gamma, sums, count, relu, want_dres, dgamma, dbeta, count_dev=None, dx_amax=None):
-    """dx_amax: int32 device word that receives the bit pattern of max |dx| (the scale of the fp16-form products that consume dx)"""
+    """dx_amax: zeroed int32 device word that receives the bit pattern of max |dx| (the scale of the fp16-form products that consume dx)"""
     M, C_ = x.shape
     dx = torch.empty_like(x)
     dres = torch.empty_like(x) if want_dres else None
