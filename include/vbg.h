@@ -142,6 +142,14 @@ typedef struct vbg_plane_gemm_desc {
     /* optional: colsum[n] += sum_m (stored value)[m][n] (atomics, one per column and row tile): the bias gradient of the layer whose
        output gradient this product produces (NT, no split-K / groups / accumulate / GELU-dual / stream-K / 256256 tile) */
     float* colsum;
+    /* form 1 (NT, tiles 128129 / 128130 / 256128, no split-K / groups): A and B are TWO fp16 planes [2][rows][ld] written by
+       vbg_split_planes_pair, a producer's pair output or Cq below: hi = fp16(x), lo' = fp16((x - hi) 2^11), round to nearest; three
+       piece products (hi hi, and lo' hi + hi lo' scaled by 2^-11 in the epilogue).  Half the matrix-core work and 4 instead of 6
+       operand bytes per element for operands inside fp16's range (the forward products: LayerNorm / GELU outputs and weights);
+       |x| >= 65520 becomes inf.  form 0: three bf16 planes, six piece products. */
+    int form;
+    /* optional: the stored value (after bias / GELU) also as fp16-pair planes [2][M][ldq] (plane stride q_plane elements) */
+    unsigned short* Cq; long long q_plane; long long ldq;
 } vbg_plane_gemm_desc;
 int vbg_plane_gemm(const vbg_plane_gemm_desc* desc, void* stream);
 int vbg_plane_gemm_timed(const vbg_plane_gemm_desc* desc, void* stream, void* start_event, void* stop_event);
@@ -153,6 +161,8 @@ int vbg_split_planes(const float* x, long long ldx, int rows, int cols, unsigned
 /* x [rows][cols] fp32 -> TRANSPOSED planes [3][cols][ldp], ldp >= rows (multiple of 32), entries rows..ldp-1 zero */
 int vbg_split_planes_t(const float* x, long long ldx, int rows, int cols, unsigned short* out, int ldp, long long plane,
                        void* stream);
+/* x [rows][cols] fp32 -> fp16-pair planes [2][rows][ldp] (hi, lo' as above; columns cols..ldp-1 zero): operands of form-1 products */
+int vbg_split_planes_pair(const float* x, long long ldx, int rows, int cols, unsigned short* out, int ldp, long long plane, void* stream);
 /* many matrices of one fp32 buffer in one launch: tbl_dev = device int64 [njobs][6] = {source offset (elements), rows, cols,
  * destination offset (elements), ldp (multiple of 32, >= rows), index of the job's first 64 x 64 tile}; job j writes the planes of
  * its matrix TRANSPOSED ([3][cols][ldp]) at dst + offset, plane stride `plane` for all jobs.  (The W^T planes of every weight of a
@@ -212,11 +222,16 @@ int vbg_conv3x3(const float* x, const float* w, const float* bias, float* y, dou
                 int Cs, int N, int accumulate, int form, const unsigned* x_amax, void* stream);
 /* form 0: three bf16 pieces per operand, six piece products (any operands); form 1: two fp16 pieces (round to nearest), three piece
  * products -- same measured accuracy against fp64 and half the matrix-core work, for operands inside fp16's range; a magnitude of
- * 65520 or more becomes inf, never a silently clipped value.  x_amax (form 1, optional): device word holding the bit pattern of
+ * 65520 or more becomes inf, never a silently clipped value.  x_amax (form 1, optional): amax slot (below) holding the bit pattern of
  * max |x| (vbg_amax, or the amax output of vbg_bn_bwd_apply): x is multiplied by the power of two that brings that maximum to
  * [2^13, 2^14) on its way into the kernel and the result by its inverse (exact), which puts a GRADIENT operand inside fp16's range:
  * the input gradient of the convolution in form 1. */
-/* amax[0] = max(amax[0], bit pattern of max |x[i]|) (non-negative floats order like their bit patterns); the caller zeroes amax */
+/* An "amax slot" is VBG_AMAX_WORDS = 64 device words VBG_AMAX_STRIDE = 32 words (128 bytes, one L2 line) apart -- 8 KB in all; its
+ * value -- the bit pattern of a tensor's largest magnitude (non-negative floats order like their bit patterns) -- is the max over the
+ * words.  Producers max INTO a slot (their blocks spread over the words: atomics on one L2 line serialise at ~10 ns each), the caller
+ * zeroes it; consumers reduce the 64 words with one wave.  vbg_amax: slot = max(slot, max |x[i]|). */
+#define VBG_AMAX_WORDS 64
+#define VBG_AMAX_STRIDE 32
 int vbg_amax(const float* x, long long n, unsigned* amax, void* stream);
 /* out[ci][2-kh][2-kw][co] = w[co][kh][kw][ci]: the filter with which the input gradient of a 3x3 / s1 / p1 convolution is the
  * same convolution of dy */
@@ -271,7 +286,8 @@ int vbg_dropout_add_ln_fwd(const float* x, const float* res, int rows, int hidde
 int vbg_dropout_add_ln_fwd_planes(const float* x, const float* res, int rows, int hidden, const float* gamma,
                                   const float* beta, float eps, float drop_p, unsigned long long seed,
                                   unsigned long long stream_id, float* y, float* xhat, float* rstd, unsigned short* y_planes, int ldp,
-                                  long long plane, void* stream);
+                                  long long plane, unsigned short* y_pair, int ldq, long long qplane, void* stream);
+/* (y_pair, optional: y also as fp16-pair planes [2][rows][ldq] -- the A operand of the form-1 forward products) */
 /* dx (to the dense output), dres, dgamma/dbeta +=.  `slots_ws` (optional): fp32 [vbg_ln_slots()][2][hidden] workspace that is ZERO
  * on entry and left zero on exit; with it the per-block column sums are spread over the slot rows and folded by a second tiny
  * launch (same-address atomics serialise: ~500 blocks per column at cfg2), without it they go straight into dgamma/dbeta */
@@ -347,7 +363,7 @@ int vbg_bn_finalize(double* stats, int nslots, int clear_slots, double count, co
 /* y = relu?( (x-mean)*invstd*gamma + beta (+ res) ) */
 int vbg_bn_apply(const float* x, const float* res, long long M, int C, const float* mean, const float* invstd,
                  const float* gamma, const float* beta, int relu, float* y, unsigned* y_amax, void* stream);
-/* y_amax (optional): y_amax[0] = max(y_amax[0], bit pattern of max |y|) (the caller zeroes it): the scale of y as an operand of
+/* y_amax (optional): amax slot (VBG_AMAX_WORDS words, zeroed by the caller) that receives the bit pattern of max |y|: the scale of y as an operand of
  * fp16-form products */
 /* backward reductions: slot[s][0..C) += sum(g), slot[s][C..2C) += sum(g*xhat), g = dy*(y>0 if relu) */
 int vbg_bn_bwd_reduce(const float* dy, const float* y, const float* x, long long M, int C, const float* mean,
@@ -358,7 +374,7 @@ int vbg_bn_bwd_apply(const float* dy, const float* y, const float* x, long long 
                      const float* invstd, const float* gamma, const double* sums, double count, const double* count_dev,
                      int relu, float* dx,
                      float* dres, float* dgamma_accum, float* dbeta_accum, unsigned* dx_amax, void* stream);
-/* dx_amax (optional): dx_amax[0] = max(dx_amax[0], bit pattern of max |dx|) (the caller zeroes it) -- the scale of the fp16-form
+/* dx_amax (optional): amax slot (VBG_AMAX_WORDS words, zeroed by the caller) that receives the bit pattern of max |dx| -- the scale of the fp16-form
  * products that consume dx */
 /* fold `nslots` slot rows: folded[0..2C) = sum over slots (optional output), and (optional) the BatchNorm affine
    gradients from these LOCAL sums: dbeta += (float)folded[0..C), dgamma += (float)folded[C..2C)  (call before a SyncBN

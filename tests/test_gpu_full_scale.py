@@ -59,6 +59,10 @@ def _setup(golden, tmp_path, name):
     batch = F.inputs(name)
     assert np.array_equal(np.array(F.checksums(batch)), g["checksums"]), "seeded inputs differ from the ones the reference saw"
     dev = torch.device("cuda")
+    from vbg import ops
+    # the forward BERT linears take the fp16-pair form from ~100 tiles of 128 x 128 on (batch 8); these tests run batch 2 and force
+    # it, so that the arithmetic held to the reference here is the arithmetic of the benchmark (VBG_PAIR=0: the six-product form)
+    ops.set_pair(os.environ.get("VBG_PAIR", "1") != "0", force=True)
     net = build_full(tmp_path, name)
     # state_dict inventory == the reference's, weights = the deterministic values the fixture was generated with
     ref_shapes = {str(k): str(v) for k, v in zip(g["keys"], g["key_shapes"])}

@@ -247,7 +247,7 @@ def test_conv3x3_row_reuse(ops, B, H, W, Cs, N):
         for sc in (1.0, 2.0 ** -30, 2.0 ** -20, 2.0 ** 20):
             g = gyh * sc
             am = ops.amax(g)
-            assert int(am.item()) == int((g.abs().max()).view(torch.int32).item())
+            assert int(am.max().item()) == int((g.abs().max()).view(torch.int32).item())
             dxs = ops.conv3x3(g, wf, f16x2=True, x_amax=am)
             assert close(dxs.permute(0, 3, 1, 2) / sc, x.grad.float(), 2e-5, 3e-6 * float(x.grad.abs().max())), sc
         # without the scale a large operand is visible as inf / nan, never clipped
@@ -588,10 +588,10 @@ def test_batchnorm(ops, relu, res, shape):
     slots = ops.bn_bwd_reduce(g2, yo, x2, mean, invstd, relu)
     dg, db = torch.zeros(C_, device=d), torch.zeros(C_, device=d)
     sums = ops.bn_param_grad(slots, C_, dg, db)
-    slot = torch.full((1,), 12345, device=d, dtype=torch.int32)            # (overwritten, not max-ed into)
+    slot = ops.amax_slot(d)
     dx, dres = ops.bn_bwd_apply(g2, yo, x2, mean, invstd, gam.detach().to(d), sums, x2.shape[0], relu, res, None, None, dx_amax=slot)
     assert close(dx, x.grad.permute(0, 2, 3, 1).reshape(-1, C_), 1e-3, 1e-5)
-    assert int(slot.item()) == int(dx.abs().max().view(torch.int32).item())       # the bit pattern of max |dx| rides on the kernel
+    assert int(slot.max().item()) == int(dx.abs().max().view(torch.int32).item())       # the bit pattern of max |dx| rides on the kernel
     assert close(dg, gam.grad, 1e-3, 1e-4) and close(db, bet.grad, 1e-3, 1e-4)
     if res:
         assert close(dres, r.grad.permute(0, 2, 3, 1).reshape(-1, C_), 1e-5, 1e-6)
@@ -1117,6 +1117,59 @@ def test_plane_gemm_nt_vs_fp64(tile):
         # same pieces, same products as the in-kernel split form of vbg_gemm: agreement to summation order
         old = ops.linear_fwd(a, b, bias)
         assert float((old - out).abs().max()) <= 1e-6 * scale
+
+
+@pytest.mark.parametrize("tile", [128129, 128130, 256128])
+def test_plane_gemm_pair_form_vs_fp64(tile):
+    """csrc/gemm_planes.hip FORM 1: operands as two fp16 planes (hi, lo' = (x - hi) 2^11, round to nearest), three piece products, the
+    cross products in their own accumulators.  Same bound against fp64 as the six-product bf16 form for operands anywhere inside
+    fp16's range (rows scaled by 2^-8 ... 2^8, and far smaller / larger whole operands); pair planes written by the split kernel, by
+    the GEMM epilogue (GELU output) and by the LayerNorm forward are bit-identical; an operand outside the range is inf, not clipped."""
+    from vbg import ops
+    from vbg.lib import EPI_GELU_DUAL
+    dev = torch.device("cuda")
+    g = torch.Generator().manual_seed(tile + 5)
+    for (M, N, K) in ((300, 264, 96), (1000, 772, 800), (257, 512, 3072), (4128, 768, 768)):
+        a = (torch.randn(M, K, generator=g) * torch.exp2(torch.randint(-8, 8, (M, 1), generator=g).float())).to(dev)
+        b = (torch.randn(N, K, generator=g) / K ** 0.5).to(dev)
+        bias = torch.randn(N, generator=g).to(dev)
+        ref = a.double() @ b.double().t() + bias.double()
+        scale = float((a.double().abs() @ b.double().abs().t()).max())
+        qa, qb = ops.split_planes_pair(a), ops.split_planes_pair(b)
+        # the pieces: hi = fp16(x) (round to nearest), lo' = fp16((x - hi) * 2048)
+        hi = a.half()
+        assert torch.equal(qa.buf[0, :, :K].view(torch.float16), hi)
+        assert torch.equal(qa.buf[1, :, :K].view(torch.float16), ((a - hi.float()) * 2048).half())
+        out = torch.full((M, N), 7.0, device=dev)
+        ops.plane_gemm(qa, qb, out, bias=bias, tile=tile, form=1)
+        assert float((out.double() - ref).abs().max()) <= 2e-6 * scale, (M, N, K)
+        # against the six-product form: both within fp32 summation noise of each other
+        o6 = torch.empty(M, N, device=dev)
+        ops.plane_gemm(ops.split_planes(a), ops.split_planes(b), o6, bias=bias, tile=tile)
+        assert float((o6 - out).abs().max()) <= 2e-6 * scale
+        # whole operands far from 1 (still inside fp16's range after the split: the scaled low piece keeps small values exact)
+        for sa, sb in ((2.0 ** -10, 2.0 ** 4), (2.0 ** 4, 2.0 ** -12)):
+            o = torch.empty(M, N, device=dev)
+            ops.plane_gemm(ops.split_planes_pair(a * sa), ops.split_planes_pair(b * sb), o, tile=tile, form=1)
+            assert float((o.double() / (sa * sb) - (ref - bias.double())).abs().max()) <= 2e-6 * scale, (sa, sb)
+        # GELU-dual epilogue: h fp32, gelu(h) as bf16 planes (the weight gradient's operand) AND as pair planes (the next product's)
+        h, gl = torch.empty(M, N, device=dev), torch.empty(M, N, device=dev)
+        pg, pq = ops.planes_empty(M, N, dev), ops.pair_empty(M, N, dev)
+        ops.plane_gemm(qa, qb, h, bias=bias, epi=EPI_GELU_DUAL, C2=gl, out_planes=pg, out_pair=pq, tile=tile, form=1)
+        assert torch.equal(h, out)
+        assert torch.equal(pg.buf[:, :, :N], ops.split_planes(gl).buf[:, :, :N])
+        assert torch.equal(pq.buf[:, :, :N], ops.split_planes_pair(gl).buf[:, :, :N])
+    # out of range: visible
+    big = torch.full((256, 64), 70000.0, device=dev)
+    o = torch.empty(256, 128, device=dev)
+    ops.plane_gemm(ops.split_planes_pair(big), ops.split_planes_pair(torch.ones(128, 64, device=dev)), o, tile=tile, form=1)
+    assert not bool(torch.isfinite(o).any())
+    # LayerNorm forward writes the pair planes of its output next to the bf16 planes
+    x, r = torch.randn(520, 768, generator=g).to(dev), torch.randn(520, 768, generator=g).to(dev)
+    gam, bet = (1 + 0.1 * torch.randn(768, generator=g)).to(dev), (0.1 * torch.randn(768, generator=g)).to(dev)
+    pl, pq = ops.planes_empty(520, 768, dev), ops.pair_empty(520, 768, dev)
+    y, _, _ = ops.dropout_add_ln_fwd(x, r, gam, bet, 1e-12, 0.0, 1, 2, out_planes=pl, out_pair=pq)
+    assert torch.equal(pl.buf, ops.split_planes(y).buf) and torch.equal(pq.buf, ops.split_planes_pair(y).buf)
 
 
 def test_plane_gemm_tn_and_grouped_vs_fp64():

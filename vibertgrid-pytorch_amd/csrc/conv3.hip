@@ -67,6 +67,13 @@ __device__ __forceinline__ void c3_split2(float a, float b, unsigned& hi, unsign
     hi = __builtin_bit_cast(unsigned, h);
     lo = __builtin_bit_cast(unsigned, l);
 }
+// the value of an amax slot (VBG_AMAX_WORDS = 64 words, see include/vbg.h): the max over its words, uniform across the wave
+__device__ __forceinline__ unsigned c3_amax_read(const unsigned* slot) {
+    unsigned v = slot[(threadIdx.x & (VBG_AMAX_WORDS - 1)) * VBG_AMAX_STRIDE];
+#pragma unroll
+    for (int o = 32; o > 0; o >>= 1) v = max(v, (unsigned)__shfl_xor((int)v, o, 64));
+    return __builtin_amdgcn_readfirstlane(v);
+}
 // power-of-two scale that brings a tensor whose largest magnitude has the bit pattern `amax_bits` to [2^13, 2^14): (scale, 1 / scale).
 // Exact in fp32 (the scaled operand's pieces see the same significand bits); amax = 0 or below 2^-100: no scaling.
 __device__ __forceinline__ float2 c3_pow2_scale(unsigned amax_bits) {
@@ -111,7 +118,7 @@ __global__ __launch_bounds__(256, 2) void conv3x3_kernel(const conv3_args p) {
     // F16 form on an operand outside fp16's range (a gradient): X is multiplied by a power of two derived from its largest magnitude
     // on the way into LDS and the result by the inverse -- exact, and the pieces then sit in the middle of fp16's range
     float2 a_sc = make_float2(1.f, 1.f);
-    if constexpr (F16) { if (p.a_amax) a_sc = c3_pow2_scale(__builtin_amdgcn_readfirstlane(p.a_amax[0])); }
+    if constexpr (F16) { if (p.a_amax) a_sc = c3_pow2_scale(c3_amax_read(p.a_amax)); }
     // XCD-aware block -> tile map (same as gemm.hip: XCD k owns the k-th eighth of the tile sequence, bands of 8 row tiles)
     constexpr unsigned XCDS = 8, XCD_GROUP = 8;
     const unsigned gx = gridDim.x, gy = gridDim.y;
@@ -440,8 +447,8 @@ __global__ __launch_bounds__(256, 2) void conv3x3_wgrad_kernel(const conv3w_args
     if (c0 >= c1) return;
     float2 sc_a = make_float2(1.f, 1.f), sc_b = sc_a;
     if constexpr (F16) {
-        sc_a = c3_pow2_scale(__builtin_amdgcn_readfirstlane(p.dy_amax[0]));
-        sc_b = c3_pow2_scale(__builtin_amdgcn_readfirstlane(p.x_amax[0]));
+        sc_a = c3_pow2_scale(c3_amax_read(p.dy_amax));
+        sc_b = c3_pow2_scale(c3_amax_read(p.x_amax));
     }
 
     // ---- loader: per-thread constants, per-chunk scalars -------------------------------------------------------------------

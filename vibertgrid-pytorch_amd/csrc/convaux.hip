@@ -125,9 +125,10 @@ __global__ void bn_finalize_kernel(double* __restrict__ stats, int nslots, int c
     }
 }
 
-// block-wide max of non-negative floats into a device word holding a bit pattern (non-negative floats order like their bits).  One
-// atomic per block at most, and none when the word already holds a larger value (same-address atomics serialise at ~10 ns each:
-// 8192 wave-level atomics cost ~100 us, measured)
+// block-wide max of non-negative floats into a device SLOT of VBG_AMAX_WORDS = 64 words holding bit patterns (non-negative floats order
+// like their bits); the slot's value is the max over its words, which lie 128 bytes apart.  A block publishes into word blockIdx % 64:
+// atomics on one L2 line serialise at ~10 ns each (2048 blocks on ONE word, or on 64 adjacent words: +16-19 us per launch, measured
+// in the step); 32 per line on 64 lines do not show.
 __device__ __forceinline__ void amax_publish(float mx, unsigned* amax) {
     __shared__ float amax_sh[16];
 #pragma unroll
@@ -137,7 +138,8 @@ __device__ __forceinline__ void amax_publish(float mx, unsigned* amax) {
     if (threadIdx.x == 0) {
         for (int w = 1; w < (int)(blockDim.x >> 6); ++w) mx = fmaxf(mx, amax_sh[w]);
         const unsigned bits = __float_as_uint(mx);
-        if (bits > __hip_atomic_load(amax, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT)) atomicMax(amax, bits);
+        unsigned* word = amax + (blockIdx.x & (VBG_AMAX_WORDS - 1)) * VBG_AMAX_STRIDE;
+        if (bits > __hip_atomic_load(word, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT)) atomicMax(word, bits);
     }
 }
 

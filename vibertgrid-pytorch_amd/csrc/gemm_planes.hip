@@ -30,6 +30,17 @@ __device__ __forceinline__ __amdgpu_buffer_rsrc_t pg_rsrc(const void* base) {
     return __builtin_amdgcn_make_buffer_rsrc(const_cast<void*>(base), 0, (int)0x80000000u, 0x00020000);
 }
 
+typedef _Float16 pg_f16x8 __attribute__((ext_vector_type(8)));
+// two fp16 pieces of a pair of floats (a in the low half), round to nearest: hi = fp16(x), lo' = fp16((x - hi) * 2^11)
+__device__ __forceinline__ void pg_split2(float a, float b, unsigned& hi, unsigned& lo) {
+    typedef float f32x2_t __attribute__((ext_vector_type(2)));
+    typedef _Float16 f16x2_t __attribute__((ext_vector_type(2)));
+    const f32x2_t v = {a, b};
+    const f16x2_t h = __builtin_convertvector(v, f16x2_t);
+    const f16x2_t l = __builtin_convertvector((v - __builtin_convertvector(h, f32x2_t)) * 2048.f, f16x2_t);
+    hi = __builtin_bit_cast(unsigned, h);
+    lo = __builtin_bit_cast(unsigned, l);
+}
 typedef short pg_v4s __attribute__((ext_vector_type(4)));
 typedef __attribute__((address_space(3))) pg_v4s* pg_lds_v4s;
 
@@ -40,16 +51,23 @@ typedef __attribute__((address_space(3))) pg_v4s* pg_lds_v4s;
 //   two ds_read_b64_tr_b16: each 16-lane group reads a [4 k][16 col] block, lane i supplying the address of (k = i / 4, cols
 //   4 (i % 4)..+3) and receiving the 4 k of column i (lane semantics verified on the hardware, tools/probes/tr_probe.hip).
 //   Rows past the reduction length fall off the per-plane buffer descriptors and read 0.
-template <int BM, int BN, int WGM, int WGN, int NST, bool TRANS, bool PP = true>
+// FORM = 0: three bf16 planes per operand, six piece products.  FORM = 1 (NT only): two fp16 planes per operand -- hi = fp16(x), lo' =
+// fp16((x - hi) 2^11), round to nearest: x = hi + lo' 2^-11 to 2^-23 |x| for 2^-14 <= |x| < 65520, absolute error <= 2^-36 below that,
+// inf from 65520 on -- and three piece products: hi hi into the main accumulators, lo' hi + hi lo' into a second set that the epilogue
+// scales by 2^-11.  Half the matrix-core work and 4 instead of 6 operand bytes per element, for operands inside fp16's range: the
+// forward products, whose operands are LayerNorm / GELU outputs and weights.
+template <int BM, int BN, int WGM, int WGN, int NST, bool TRANS, bool PP = true, int FORM = 0>
 __global__ __launch_bounds__(WGM * WGN * 64) void plane_gemm_kernel(const vbg_plane_gemm_desc p) {
     static_assert(!TRANS || ((BM == 128 || BM == 256) && BN == 128), "TN: 128- or 256-column A tiles, 128-column B tiles");
     constexpr int NW = WGM * WGN, NT = NW * 64;
     constexpr int BK = 32;
+    constexpr int NPL = FORM ? 2 : 3;                          // planes per operand
+    static_assert(FORM == 0 || (!TRANS && PP && NW == 8), "the fp16-pair form exists for the 8-wave ping-pong NT tiles");
     constexpr int WM = BM / WGM, WN = BN / WGN, TM = WM / 32, TN = WN / 32;
     constexpr int PA = BM * 64, PB = BN * 64;                  // bytes of one plane of a stage (64 B per row)
-    constexpr int STAGE = 3 * (PA + PB);
-    constexpr int NIA = 3 * BM / 16 / NW, NIB = 3 * BN / 16 / NW;      // DMA instructions per wave and stage
-    static_assert((3 * BM / 16) % NW == 0 && (3 * BN / 16) % NW == 0, "DMA units must divide over the waves");
+    constexpr int STAGE = NPL * (PA + PB);
+    constexpr int NIA = NPL * BM / 16 / NW, NIB = NPL * BN / 16 / NW;      // DMA instructions per wave and stage
+    static_assert((NPL * BM / 16) % NW == 0 && (NPL * BN / 16) % NW == 0, "DMA units must divide over the waves");
     static_assert(NST == 2 || NST == 3, "two or three LDS stages");
     constexpr int CTS = BN + 4;
     constexpr int SMEM = (NST * STAGE > BM * CTS * 4) ? NST * STAGE : BM * CTS * 4;
@@ -116,7 +134,7 @@ __global__ __launch_bounds__(WGM * WGN * 64) void plane_gemm_kernel(const vbg_pl
             const int u = wave + NW * i, q = u / (BN / 16), rb = u % (BN / 16);
             const int r = rb * 16 + lrow;
             bvo[i] = (n0 + r < N) ? (unsigned)(((long long)q * b_plane + (long long)r * ldb) * 2 + lchunk * 16) : PG_INVALID;
-            blds[i] = __builtin_amdgcn_readfirstlane(3 * PA + q * PB + rb * 1024);
+            blds[i] = __builtin_amdgcn_readfirstlane(NPL * PA + q * PB + rb * 1024);
         }
         abase = pA + (long long)m0 * lda + (long long)kt0 * BK;
         bbase = pB + (long long)n0 * ldb + (long long)kt0 * BK;
@@ -213,16 +231,19 @@ __global__ __launch_bounds__(WGM * WGN * 64) void plane_gemm_kernel(const vbg_pl
     for (int i = 0; i < TM; ++i) ta[i] = (8 * lk + (i16 >> 2)) * RSA + (((wm * TM + i) ^ (i16 >> 2)) << 6) + (16 * tg + 4 * (i16 & 3)) * 2;
 #pragma unroll
     for (int j = 0; j < TN; ++j) tb[j] = (8 * lk + (i16 >> 2)) * RSB + (((wn * TN + j) ^ (i16 >> 2)) << 6) + (16 * tg + 4 * (i16 & 3)) * 2;
-    f32x16 acc[TM][TN];
+    f32x16 acc[TM][TN], acx[FORM ? TM : 1][FORM ? TN : 1];         // (FORM 1: the cross products, scaled by 2^11)
 #pragma unroll
     for (int i = 0; i < TM; ++i)
 #pragma unroll
         for (int j = 0; j < TN; ++j)
 #pragma unroll
-            for (int r = 0; r < 16; ++r) acc[i][j][r] = 0.f;
+            for (int r = 0; r < 16; ++r) {
+                acc[i][j][r] = 0.f;
+                if constexpr (FORM) acx[i][j][r] = 0.f;
+            }
 
-    pg_u32x4 fa0[3][TM], fb0[3][TN], fa1[3][TM], fb1[3][TN];       // fragment sets of k-step 0 / 1 of a tile
-    auto read_frags = [&](int stage, int fo, pg_u32x4 (&fa)[3][TM], pg_u32x4 (&fb)[3][TN]) {
+    pg_u32x4 fa0[NPL][TM], fb0[NPL][TN], fa1[NPL][TM], fb1[NPL][TN];       // fragment sets of k-step 0 / 1 of a tile
+    auto read_frags = [&](int stage, int fo, pg_u32x4 (&fa)[NPL][TM], pg_u32x4 (&fb)[NPL][TN]) {
         if constexpr (TRANS) {
             typedef __attribute__((address_space(3))) unsigned char* lds_bytes;
             lds_bytes as = (lds_bytes)(smem + stage * STAGE + fo * RSA), bs = (lds_bytes)(smem + stage * STAGE + 3 * PA + fo * RSB);
@@ -246,26 +267,39 @@ __global__ __launch_bounds__(WGM * WGN * 64) void plane_gemm_kernel(const vbg_pl
             return;
         }
         const unsigned char* as = smem + stage * STAGE + (wm * WM) * 64 + fo;
-        const unsigned char* bs = smem + stage * STAGE + 3 * PA + (wn * WN) * 64 + fo;
+        const unsigned char* bs = smem + stage * STAGE + NPL * PA + (wn * WN) * 64 + fo;
 #pragma unroll
-        for (int q = 0; q < 3; ++q) {
+        for (int q = 0; q < NPL; ++q) {
 #pragma unroll
             for (int i = 0; i < TM; ++i) fa[q][i] = *reinterpret_cast<const pg_u32x4*>(as + q * PA + i * 32 * 64);
 #pragma unroll
             for (int j = 0; j < TN; ++j) fb[q][j] = *reinterpret_cast<const pg_u32x4*>(bs + q * PB + j * 32 * 64);
         }
     };
-    // piece products, smallest first: (lo,hi) (hi,lo) (mid,mid) (mid,hi) (hi,mid) (hi,hi)
-    auto mma = [&](const pg_u32x4 (&fa)[3][TM], const pg_u32x4 (&fb)[3][TN]) {
-        constexpr int qa[6] = {2, 0, 1, 1, 0, 0}, qb[6] = {0, 2, 1, 0, 1, 0};
+    // piece products, smallest first: (lo,hi) (hi,lo) (mid,mid) (mid,hi) (hi,mid) (hi,hi); FORM 1: (lo',hi) (hi,lo') -> cross sums, (hi,hi)
+    auto mma = [&](const pg_u32x4 (&fa)[NPL][TM], const pg_u32x4 (&fb)[NPL][TN]) {
+        if constexpr (FORM) {
 #pragma unroll
-        for (int t = 0; t < 6; ++t)
+            for (int t = 0; t < 3; ++t)
 #pragma unroll
-            for (int i = 0; i < TM; ++i)
+                for (int i = 0; i < TM; ++i)
 #pragma unroll
-                for (int j = 0; j < TN; ++j)
-                    acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(__builtin_bit_cast(pg_bf16x8, fa[qa[t]][i]),
-                                                                        __builtin_bit_cast(pg_bf16x8, fb[qb[t]][j]), acc[i][j], 0, 0, 0);
+                    for (int j = 0; j < TN; ++j) {
+                        f32x16& d = t < 2 ? acx[i][j] : acc[i][j];
+                        d = __builtin_amdgcn_mfma_f32_32x32x16_f16(__builtin_bit_cast(pg_f16x8, fa[t == 0 ? 1 : 0][i]),
+                                                                   __builtin_bit_cast(pg_f16x8, fb[t == 1 ? 1 : 0][j]), d, 0, 0, 0);
+                    }
+        } else {
+            constexpr int qa[6] = {2, 0, 1, 1, 0, 0}, qb[6] = {0, 2, 1, 0, 1, 0};
+#pragma unroll
+            for (int t = 0; t < 6; ++t)
+#pragma unroll
+                for (int i = 0; i < TM; ++i)
+#pragma unroll
+                    for (int j = 0; j < TN; ++j)
+                        acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(__builtin_bit_cast(pg_bf16x8, fa[qa[t]][i]),
+                                                                            __builtin_bit_cast(pg_bf16x8, fb[qb[t]][j]), acc[i][j], 0, 0, 0);
+        }
     };
 
     // ---- k loop ---------------------------------------------------------------------------------------------------------
@@ -276,7 +310,7 @@ __global__ __launch_bounds__(WGM * WGN * 64) void plane_gemm_kernel(const vbg_pl
     // is read -- no bubble after the barrier.  NST = 2 (the 8-wave tile, 2 waves per SIMD cover each other): tile t+1 travels
     // during tile t, barrier at the end of the iteration.
     constexpr int NIW = NIA + NIB;
-    constexpr int NMMA = 6 * TM * TN, NRD = (TRANS ? 6 : 3) * (TM + TN);
+    constexpr int NMMA = (FORM ? 3 : 6) * TM * TN, NRD = (TRANS ? 6 : NPL) * (TM + TN);
     // ---- ping-pong schedule of the 8-wave NT tiles --------------------------------------------------------------------------
     // Waves w and w + 4 of a workgroup share a SIMD (measured: tools/probes/pingpong_gemm_probe.hip prints HW_ID).  In lockstep both
     // issue their DMA, read their fragments and then want the matrix pipe at the same moments: matrix-pipe busy 0.40-0.47 of a full
@@ -344,7 +378,7 @@ __global__ __launch_bounds__(WGM * WGN * 64) void plane_gemm_kernel(const vbg_pl
     __builtin_amdgcn_s_barrier();
     auto settle0 = [&]() {
 #pragma unroll
-        for (int q = 0; q < 3; ++q) {
+        for (int q = 0; q < NPL; ++q) {
 #pragma unroll
             for (int i = 0; i < TM; ++i) asm volatile("" ::"v"(fa0[q][i]));
 #pragma unroll
@@ -417,11 +451,13 @@ __global__ __launch_bounds__(WGM * WGN * 64) void plane_gemm_kernel(const vbg_pl
         for (int i = 0; i < TM; ++i)
 #pragma unroll
             for (int r = 0; r < 16; ++r)
-                Ct[(wm * WM + i * 32 + (r & 3) + 8 * (r >> 2) + 4 * lk) * CTS + wn * WN + j * 32 + lr] = acc[i][j][r] * alpha;
+                Ct[(wm * WM + i * 32 + (r & 3) + 8 * (r >> 2) + 4 * lk) * CTS + wn * WN + j * 32 + lr] =
+                    (FORM ? acc[i][j][r] + acx[FORM ? i : 0][FORM ? j : 0][r] * (1.f / 2048.f) : acc[i][j][r]) * alpha;
     __syncthreads();
     constexpr int QN = BN / 4;
     // optional bf16 planes of the stored value (the A operand of the next product): [3][M][ldp], K-contiguous = along n here
     unsigned short* const Cp = p.Cp;
+    unsigned short* const Cq = p.Cq;                 // optional fp16-pair planes of the stored value [2][M][ldq]
 #pragma unroll
     for (int q = 0; q < BM * QN / NT; ++q) {
         const int idx = tid + q * NT;
@@ -468,6 +504,14 @@ __global__ __launch_bounds__(WGM * WGN * 64) void plane_gemm_kernel(const vbg_pl
             *reinterpret_cast<uint2*>(o) = make_uint2(h[0] | ((unsigned)h[1] << 16), h[2] | ((unsigned)h[3] << 16));
             *reinterpret_cast<uint2*>(o + p.c_plane) = make_uint2(m[0] | ((unsigned)m[1] << 16), m[2] | ((unsigned)m[3] << 16));
             *reinterpret_cast<uint2*>(o + 2 * p.c_plane) = make_uint2(l[0] | ((unsigned)l[1] << 16), l[2] | ((unsigned)l[3] << 16));
+        }
+        if (Cq) {
+            unsigned short* o = Cq + (long long)gm * p.ldq + gn;
+            uint2 h, l;
+            pg_split2(v.x, v.y, h.x, l.x);
+            pg_split2(v.z, v.w, h.y, l.y);
+            *reinterpret_cast<uint2*>(o) = h;
+            *reinterpret_cast<uint2*>(o + p.q_plane) = l;
         }
     }
     // optional column sums of the stored values (the bias gradient of the layer whose dL/d(output) this product produces): one thread
@@ -1027,6 +1071,32 @@ __global__ __launch_bounds__(256) void split_planes_kernel(const float* __restri
     }
 }
 
+// x [rows][cols] fp32 (row stride ldx) -> fp16-pair planes [2][rows][ldp], columns cols..ldp-1 zero.  One thread = 8 columns.
+__global__ __launch_bounds__(256) void split_planes_pair_kernel(const float* __restrict__ x, long long ldx, int rows, int cols,
+                                                                 unsigned short* __restrict__ out, int ldp, long long plane) {
+    const int cpr = ldp / 8;
+    const long long n = (long long)rows * cpr;
+    const long long stride = (long long)gridDim.x * blockDim.x;
+    const bool vec = ((ldx & 3) == 0) && ((((uintptr_t)x) & 15) == 0);
+    for (long long i = (long long)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += stride) {
+        const int r = (int)(i / cpr), c = (int)(i % cpr) * 8;
+        float e[8];
+        if (c + 8 <= cols && vec) {
+            const float4 a = *reinterpret_cast<const float4*>(x + (long long)r * ldx + c);
+            const float4 b = *reinterpret_cast<const float4*>(x + (long long)r * ldx + c + 4);
+            e[0] = a.x; e[1] = a.y; e[2] = a.z; e[3] = a.w; e[4] = b.x; e[5] = b.y; e[6] = b.z; e[7] = b.w;
+        } else {
+#pragma unroll
+            for (int t = 0; t < 8; ++t) e[t] = (c + t < cols) ? x[(long long)r * ldx + c + t] : 0.f;
+        }
+        uint4 h, l;
+        pg_split2(e[0], e[1], h.x, l.x); pg_split2(e[2], e[3], h.y, l.y); pg_split2(e[4], e[5], h.z, l.z); pg_split2(e[6], e[7], h.w, l.w);
+        unsigned short* o = out + (long long)r * ldp + c;
+        *reinterpret_cast<uint4*>(o) = h;
+        *reinterpret_cast<uint4*>(o + plane) = l;
+    }
+}
+
 // x [rows][cols] fp32 -> TRANSPOSED planes [3][cols][ldp] bf16 with ldp >= rows (multiple of 32), entries rows..ldp-1 zero:
 // out[q][c][r] = piece_q(x[r][c]).  64 x 64 tiles through LDS.
 __global__ __launch_bounds__(256) void split_planes_t_kernel(const float* __restrict__ x, long long ldx, int rows, int cols,
@@ -1122,6 +1192,14 @@ static bool pg_pingpong() {
     return on;
 }
 
+template <int BM, int BN, int WGM, int WGN, int NST>
+static void pg_launch_pair(const vbg_plane_gemm_desc& d, hipStream_t s, hipEvent_t e0, hipEvent_t e1) {
+    dim3 g(cdiv(d.M, BM), cdiv(d.N, BN), 1);
+    (void)hipGetLastError();
+    if (e0 && e1) hipExtLaunchKernelGGL((plane_gemm_kernel<BM, BN, WGM, WGN, NST, false, true, 1>), g, dim3(WGM * WGN * 64), 0, s, e0, e1, 0, d);
+    else hipLaunchKernelGGL((plane_gemm_kernel<BM, BN, WGM, WGN, NST, false, true, 1>), g, dim3(WGM * WGN * 64), 0, s, d);
+}
+
 template <int BM, int BN, int WGM, int WGN, int NST, bool TRANS = false>
 static void pg_launch(const vbg_plane_gemm_desc& d, hipStream_t s, hipEvent_t e0, hipEvent_t e1) {
     dim3 g(cdiv(d.M, BM), cdiv(d.N, BN), d.splitk);
@@ -1181,9 +1259,21 @@ static int plane_gemm_dispatch(const vbg_plane_gemm_desc* desc, void* stream, vo
     if (d.epi == VBG_EPI_GELU_DUAL) VBG_CHECK_ARG(d.C2 != nullptr || d.Cp != nullptr);
     if (d.epi == VBG_EPI_MUL_GELU_GRAD) VBG_CHECK_ARG(d.C2 != nullptr && d.ngroups == 0 && !d.trans && !(d.sk_ws && d.sk_cnt));
     if (d.Cp) VBG_CHECK_ARG(d.ldp % 8 == 0 && d.ldp >= d.N && ((uintptr_t)d.Cp & 7) == 0 && d.c_plane % 4 == 0);
+    if (d.Cq) VBG_CHECK_ARG(d.ldq % 8 == 0 && d.ldq >= d.N && ((uintptr_t)d.Cq & 7) == 0 && d.q_plane % 4 == 0 && !d.accumulate && d.ngroups == 0 &&
+                            !d.trans && d.tile != 256256 && !(d.sk_ws && d.sk_cnt));
     if (d.M == 0 || d.N == 0) return VBG_OK;
     hipStream_t s = (hipStream_t)stream;
     int tile = d.tile;
+    if (d.form == 1) {
+        // two fp16 planes per operand (csrc/gemm_planes.hip FORM 1): the 8-wave NT tiles only
+        VBG_CHECK_ARG(!d.trans && d.ngroups == 0 && d.splitk == 1 && !(d.sk_ws && d.sk_cnt));
+        if (tile == 256128) pg_launch_pair<256, 128, 4, 2, 2>(d, s, (hipEvent_t)e0, (hipEvent_t)e1);
+        else if (tile == 128130) pg_launch_pair<128, 128, 2, 4, 3>(d, s, (hipEvent_t)e0, (hipEvent_t)e1);
+        else if (tile == 128129 || tile == 0) pg_launch_pair<128, 128, 4, 2, 3>(d, s, (hipEvent_t)e0, (hipEvent_t)e1);
+        else return VBG_EARG;
+        VBG_LAUNCH_RET();
+    }
+    VBG_CHECK_ARG(d.form == 0);
     if (d.trans) {
         if (tile == 256128) pg_launch<256, 128, 4, 2, 2, true>(d, s, (hipEvent_t)e0, (hipEvent_t)e1);
         else if (tile == 128130) pg_launch<128, 128, 2, 4, 3, true>(d, s, (hipEvent_t)e0, (hipEvent_t)e1);
@@ -1267,6 +1357,17 @@ extern "C" int vbg_split_planes(const float* x, long long ldx, int rows, int col
     }
     VBG_LAUNCH(split_planes_kernel, dim3((unsigned)g), dim3(256), lds, (hipStream_t)stream, x, ldx, rows, cols, out, ldp, plane, relu,
                colsum_accum);
+    VBG_LAUNCH_RET();
+}
+
+extern "C" int vbg_split_planes_pair(const float* x, long long ldx, int rows, int cols, unsigned short* out, int ldp, long long plane,
+                                     void* stream) {
+    VBG_CHECK_ARG(rows >= 0 && cols >= 0 && ldp % 32 == 0 && ldp >= cols && plane >= (long long)rows * ldp && plane % 8 == 0);
+    if (rows == 0 || cols == 0) return VBG_OK;
+    VBG_CHECK_ARG(x && out && ((uintptr_t)out & 15) == 0);
+    long long g = ((long long)rows * (ldp / 8) + 255) / 256;
+    if (g > 256 * 16) g = 256 * 16;
+    VBG_LAUNCH(split_planes_pair_kernel, dim3((unsigned)g), dim3(256), 0, (hipStream_t)stream, x, ldx, rows, cols, out, ldp, plane);
     VBG_LAUNCH_RET();
 }
 

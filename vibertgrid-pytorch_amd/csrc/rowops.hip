@@ -146,7 +146,7 @@ __global__ __launch_bounds__(256) void dropout_add_ln_fwd_kernel(
     const float* __restrict__ x, const float* __restrict__ res, int rows, int hidden, const float* __restrict__ gamma,
     const float* __restrict__ beta, float eps, uint32_t drop_thr, float keep_scale, uint64_t seed, uint64_t sid,
     float* __restrict__ y, float* __restrict__ xhat_out, float* __restrict__ rstd_out,
-    unsigned short* __restrict__ ypl, int ldp, long long plane) {
+    unsigned short* __restrict__ ypl, int ldp, long long plane, unsigned short* __restrict__ yq, int ldq, long long qplane) {
     const int lane = threadIdx.x & 63;
     const int t = blockIdx.x * 4 + (threadIdx.x >> 6);
     if (t >= rows) return;
@@ -199,6 +199,17 @@ __global__ __launch_bounds__(256) void dropout_add_ln_fwd_kernel(
                 *reinterpret_cast<uint2*>(op) = make_uint2(h[0] | ((unsigned)h[1] << 16), h[2] | ((unsigned)h[3] << 16));
                 *reinterpret_cast<uint2*>(op + plane) = make_uint2(m[0] | ((unsigned)m[1] << 16), m[2] | ((unsigned)m[3] << 16));
                 *reinterpret_cast<uint2*>(op + 2 * plane) = make_uint2(l[0] | ((unsigned)l[1] << 16), l[2] | ((unsigned)l[3] << 16));
+            }
+            if (yq) {                                 // ... and its fp16-pair planes (the A operand of the form-1 forward products)
+                typedef float f32x2_t __attribute__((ext_vector_type(2)));
+                typedef _Float16 f16x2_t __attribute__((ext_vector_type(2)));
+                const f32x2_t v0 = {o.x, o.y}, v1 = {o.z, o.w};
+                const f16x2_t h0 = __builtin_convertvector(v0, f16x2_t), h1 = __builtin_convertvector(v1, f16x2_t);
+                const f16x2_t l0 = __builtin_convertvector((v0 - __builtin_convertvector(h0, f32x2_t)) * 2048.f, f16x2_t);
+                const f16x2_t l1 = __builtin_convertvector((v1 - __builtin_convertvector(h1, f32x2_t)) * 2048.f, f16x2_t);
+                unsigned short* oq = yq + (long long)t * ldq + c;
+                *reinterpret_cast<uint2*>(oq) = make_uint2(__builtin_bit_cast(unsigned, h0), __builtin_bit_cast(unsigned, h1));
+                *reinterpret_cast<uint2*>(oq + qplane) = make_uint2(__builtin_bit_cast(unsigned, l0), __builtin_bit_cast(unsigned, l1));
             }
         }
     if (lane == 0) rstd_out[t] = rstd;
@@ -576,21 +587,23 @@ extern "C" int vbg_dropout_add_ln_fwd(const float* x, const float* res, int rows
     VBG_CHECK_ARG(((uintptr_t)x | (uintptr_t)res | (uintptr_t)gamma | (uintptr_t)beta | (uintptr_t)y | (uintptr_t)xhat) % 16 == 0);
     if (rows <= 0) return VBG_OK;
     VBG_LAUNCH(dropout_add_ln_fwd_kernel, dim3(cdiv(rows, 4)), dim3(256), 0, (hipStream_t)stream, x, res, rows, hidden,
-               gamma, beta, eps, drop_threshold(drop_p), 1.0f / (1.0f - drop_p), seed, sid, y, xhat, rstd, (unsigned short*)nullptr, 0, 0ll);
+               gamma, beta, eps, drop_threshold(drop_p), 1.0f / (1.0f - drop_p), seed, sid, y, xhat, rstd, (unsigned short*)nullptr, 0, 0ll,
+               (unsigned short*)nullptr, 0, 0ll);
     VBG_LAUNCH_RET();
 }
 
 extern "C" int vbg_dropout_add_ln_fwd_planes(const float* x, const float* res, int rows, int hidden, const float* gamma,
                                              const float* beta, float eps, float drop_p, unsigned long long seed,
                                              unsigned long long sid, float* y, float* xhat, float* rstd, unsigned short* y_planes, int ldp,
-                                             long long plane, void* stream) {
+                                             long long plane, unsigned short* y_pair, int ldq, long long qplane, void* stream) {
     VBG_CHECK_ARG(x && res && gamma && beta && y && xhat && rstd && y_planes);
+    VBG_CHECK_ARG(!y_pair || (ldq % 4 == 0 && ldq >= hidden && qplane % 4 == 0 && qplane >= (long long)rows * ldq && ((uintptr_t)y_pair & 7) == 0));
     VBG_CHECK_ARG(hidden > 0 && hidden % 256 == 0 && hidden <= 256 * LN_V && drop_p >= 0.f && drop_p < 1.f);
     VBG_CHECK_ARG(((uintptr_t)x | (uintptr_t)res | (uintptr_t)gamma | (uintptr_t)beta | (uintptr_t)y | (uintptr_t)xhat) % 16 == 0);
     VBG_CHECK_ARG(ldp % 4 == 0 && ldp >= hidden && plane % 4 == 0 && plane >= (long long)rows * ldp && ((uintptr_t)y_planes & 7) == 0);
     if (rows <= 0) return VBG_OK;
     VBG_LAUNCH(dropout_add_ln_fwd_kernel, dim3(cdiv(rows, 4)), dim3(256), 0, (hipStream_t)stream, x, res, rows, hidden,
-               gamma, beta, eps, drop_threshold(drop_p), 1.0f / (1.0f - drop_p), seed, sid, y, xhat, rstd, y_planes, ldp, plane);
+               gamma, beta, eps, drop_threshold(drop_p), 1.0f / (1.0f - drop_p), seed, sid, y, xhat, rstd, y_planes, ldp, plane, y_pair, ldq, qplane);
     VBG_LAUNCH_RET();
 }
 

@@ -337,7 +337,8 @@ class ConvBnFn(torch.autograd.Function):
         r2 = None if res is None else _c(res).view(-1, C)
         # the largest magnitude of y rides on the kernel that writes it: the scale of y as an operand of the next convolution's
         # fp16-form weight gradient (the tag travels on the tensor object; a consumer that does not find one takes a vbg_amax pass)
-        y_amax = ops.amax_slot(x.device) if (torch.is_grad_enabled() and ops.conv3_f16_bwd_enabled()) else None
+        # (grad mode is off inside forward(): whether a backward will come is what ctx.needs_input_grad says)
+        y_amax = ops.amax_slot(x.device) if (any(ctx.needs_input_grad) and ops.conv3_f16_bwd_enabled()) else None
         y = ops.bn_apply(z2, r2, mean, invstd, gamma, beta, relu, y_amax=y_amax).view(z.shape)
         if y_amax is not None:
             y._vbg_amax = y_amax
@@ -567,9 +568,17 @@ class BertLayerFn(torch.autograd.Function):
             qkv = torch.empty((ntok, 3 * hid), device=dev, dtype=f32)
         else:                      # q, k, v leave the projection as planes only: the fused attention kernels' operands
             pqkv = ops.planes_empty(ntok, 3 * hid, dev)
+        # forward products whose operands are LayerNorm / GELU outputs and weights run on two fp16 pieces per operand (three piece
+        # products, csrc/gemm_planes.hip FORM 1) once the problem fills the 8-wave tiles; the pair planes of x arrive as an attribute of
+        # the previous layer's bf16 planes (written by its closing LayerNorm)
+        pair = planes and ops.pair_enabled() and ops.pair_tile(ntok, hid) != 0
+        xq = getattr(xpl, "_vbg_pair", None) if (pair and xpl is not None) else None
         if planes:                 # operands split into bf16 planes once (csrc/gemm_planes.hip), weights once per optimizer step
             px = ops.Planes(xpl, ntok, hid, xpl.shape[2]) if xpl is not None else ops.split_planes(x)
-            if fused_qkv:
+            if fused_qkv and xq is not None:
+                ops.plane_gemm(xq, ops.weight_planes(wq, view=_stack3(wq), also=(wk, wv), pair=True), qkv, bias=_stack3(bq), out_planes=pqkv,
+                               tile=ops.pair_tile(ntok, 3 * hid), form=1)
+            elif fused_qkv:
                 ops.plane_gemm(px, ops.weight_planes(wq, view=_stack3(wq), also=(wk, wv)), qkv, bias=_stack3(bq), out_planes=pqkv,
                                tile=ops._dense_tile(ntok, 3 * hid))
             else:              # parameters not laid out back to back (no flat buffers): one product per projection, same kernel
@@ -608,22 +617,33 @@ class BertLayerFn(torch.autograd.Function):
                 pctx = ops.split_planes(ctxv)
             ao = ops.plane_gemm(pctx, ops.weight_planes(wo), torch.empty((ntok, hid), device=dev, dtype=f32), bias=bo, tile=ops._dense_tile(ntok, hid))
             px1 = ops.planes_empty(ntok, hid, dev)
-            x1, xh1, rs1 = ops.dropout_add_ln_fwd(ao, x, g1, b1, eps, p, seed, sid + 1, out_planes=px1)
+            px1q = ops.pair_empty(ntok, hid, dev) if pair else None
+            x1, xh1, rs1 = ops.dropout_add_ln_fwd(ao, x, g1, b1, eps, p, seed, sid + 1, out_planes=px1, out_pair=px1q)
             inter = wi.shape[0]
             h = torch.empty((ntok, inter), device=dev, dtype=f32)
             # gelu(h) leaves the FFN1 epilogue as planes only (the A operand of FFN2 and, untransposed, of its weight gradient)
             pg = ops.planes_empty(ntok, inter, dev)
-            ops.plane_gemm(px1, ops.weight_planes(wi), h, bias=bi, epi=EPI_GELU_DUAL, out_planes=pg, tile=ops._dense_tile(ntok, inter, True))
-            fo = ops.plane_gemm(pg, ops.weight_planes(wo2), torch.empty((ntok, hid), device=dev, dtype=f32), bias=bo2, tile=ops._dense_tile(ntok, hid))
+            if pair:
+                pgq = ops.pair_empty(ntok, inter, dev)
+                ops.plane_gemm(px1q, ops.weight_planes(wi, pair=True), h, bias=bi, epi=EPI_GELU_DUAL, out_planes=pg, out_pair=pgq,
+                               tile=ops.pair_tile(ntok, inter, True), form=1)
+                fo = ops.plane_gemm(pgq, ops.weight_planes(wo2, pair=True), torch.empty((ntok, hid), device=dev, dtype=f32), bias=bo2,
+                                    tile=ops.pair_tile(ntok, hid), form=1)
+                del pgq, px1q
+            else:
+                ops.plane_gemm(px1, ops.weight_planes(wi), h, bias=bi, epi=EPI_GELU_DUAL, out_planes=pg, tile=ops._dense_tile(ntok, inter, True))
+                fo = ops.plane_gemm(pg, ops.weight_planes(wo2), torch.empty((ntok, hid), device=dev, dtype=f32), bias=bo2, tile=ops._dense_tile(ntok, hid))
             g = None
         else:
             ao = ops.linear_fwd(ctxv, wo, bo)
             x1, xh1, rs1 = ops.dropout_add_ln_fwd(ao, x, g1, b1, eps, p, seed, sid + 1)
             h, g = ops.linear_fwd(x1, wi, bi, EPI_GELU_DUAL)
             fo = ops.linear_fwd(g, wo2, bo2)
+        pyq = None
         if planes:
             py = ops.planes_empty(ntok, hid, dev)
-        y, xh2, rs2 = ops.dropout_add_ln_fwd(fo, x1, g2, b2, eps, p, seed, sid + 2, out_planes=py)
+            pyq = ops.pair_empty(ntok, hid, dev) if pair else None
+        y, xh2, rs2 = ops.dropout_add_ln_fwd(fo, x1, g2, b2, eps, p, seed, sid + 2, out_planes=py, out_pair=pyq)
         ctx.meta, ctx.cfg = meta, (eps, p, seed, sid)
         ctx.planes, ctx.flash = planes, flash
         ctx.w_refs = (wq, wk, wv, wo, wi, wo2)
@@ -642,6 +662,8 @@ class BertLayerFn(torch.autograd.Function):
             return y, None
         ctx.mark_non_differentiable(py.buf)
         ctx.set_materialize_grads(False)       # (no zero tensor for the planes output's gradient slot: 19 MB fill per layer)
+        if pyq is not None:
+            py.buf._vbg_pair = pyq             # (travels on the tensor object to the next layer's first product)
         return y, py.buf
 
     @staticmethod

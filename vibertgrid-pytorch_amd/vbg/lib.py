@@ -49,7 +49,7 @@ class PlaneGemmDesc(C.Structure):
                 ("epi", c_int), ("alpha", c_f), ("accumulate", c_int), ("splitk", c_int), ("tile", c_int), ("trans", c_int),
                 ("ngroups", c_int), ("grp", PlaneGroup * 4),
                 ("sk_ws", c_vp), ("sk_cnt", c_vp), ("sk_blocks", c_int), ("sk_full", c_int), ("sk_tiles_m", c_int), ("sk_tiles_n", c_int),
-                ("colsum", c_vp)]
+                ("colsum", c_vp), ("form", c_int), ("Cq", c_vp), ("q_plane", c_ll), ("ldq", c_ll)]
 
 
 class AttnDesc(C.Structure):
@@ -77,6 +77,7 @@ SIGNATURES = {
     "vbg_plane_gemm": (c_int, [C.POINTER(PlaneGemmDesc), c_vp]),
     "vbg_plane_gemm_timed": (c_int, [C.POINTER(PlaneGemmDesc), c_vp, c_vp, c_vp]),
     "vbg_split_planes": (c_int, [c_vp, c_ll, c_int, c_int, c_vp, c_int, c_ll, c_int, c_vp, c_vp]),
+    "vbg_split_planes_pair": (c_int, [c_vp, c_ll, c_int, c_int, c_vp, c_int, c_ll, c_vp]),
     "vbg_split_planes_t": (c_int, [c_vp, c_ll, c_int, c_int, c_vp, c_int, c_ll, c_vp]),
     "vbg_split_planes_t_batched": (c_int, [c_vp, c_vp, c_vp, c_int, c_int, c_ll, c_vp]),
     "vbg_attn": (c_int, [C.POINTER(AttnDesc), c_vp]),
@@ -95,7 +96,7 @@ SIGNATURES = {
     "vbg_embed_ln_fwd": (c_int, [c_vp, c_vp, c_int, c_int, c_vp, c_vp, c_vp, c_vp, c_vp, c_f, c_f, c_ull, c_ull, c_vp, c_vp, c_vp, c_vp]),
     "vbg_embed_ln_bwd": (c_int, [c_vp, c_vp, c_vp, c_vp, c_vp, c_int, c_int, c_vp, c_f, c_ull, c_ull, c_vp, c_vp, c_vp, c_vp, c_vp, c_vp]),
     "vbg_dropout_add_ln_fwd": (c_int, [c_vp, c_vp, c_int, c_int, c_vp, c_vp, c_f, c_f, c_ull, c_ull, c_vp, c_vp, c_vp, c_vp]),
-    "vbg_dropout_add_ln_fwd_planes": (c_int, [c_vp, c_vp, c_int, c_int, c_vp, c_vp, c_f, c_f, c_ull, c_ull, c_vp, c_vp, c_vp, c_vp, c_int, c_ll, c_vp]),
+    "vbg_dropout_add_ln_fwd_planes": (c_int, [c_vp, c_vp, c_int, c_int, c_vp, c_vp, c_f, c_f, c_ull, c_ull, c_vp, c_vp, c_vp, c_vp, c_int, c_ll, c_vp, c_int, c_ll, c_vp]),
     "vbg_ln_slots": (c_int, []),
     "vbg_dropout_add_ln_bwd": (c_int, [c_vp, c_vp, c_vp, c_int, c_int, c_vp, c_f, c_ull, c_ull, c_vp, c_vp, c_vp, c_vp, c_vp, c_vp]),
     "vbg_dropout_add_ln_bwd_planes": (c_int, [c_vp, c_vp, c_vp, c_int, c_int, c_vp, c_f, c_ull, c_ull, c_vp, c_int, c_ll, c_vp, c_vp, c_vp, c_vp, c_vp, c_vp]),

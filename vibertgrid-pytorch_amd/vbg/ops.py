@@ -187,6 +187,47 @@ def split_planes(x, relu=False, out=None, colsum_out=None):
     return o
 
 
+def pair_empty(rows, cols, device):
+    """fp16-pair planes [2][rows][ld] (hi = fp16(x), lo' = fp16((x - hi) * 2^11)) of a [rows, cols] matrix"""
+    ld = _ld32(cols)
+    return Planes(torch.empty((2, rows, ld), device=device, dtype=torch.int16), int(rows), int(cols), ld)
+
+
+def split_planes_pair(x, out=None):
+    """x [rows, cols] fp32 -> fp16-pair Planes (operands of plane_gemm(form=1))"""
+    assert x.dim() == 2 and x.stride(1) == 1 and x.dtype == f32
+    rows, cols = x.shape
+    o = out if out is not None else pair_empty(rows, cols, x.device)
+    check(lib.vbg_split_planes_pair(P(x), x.stride(0), rows, cols, P(o.buf), o.ld, o.plane, _stream()), "vbg_split_planes_pair")
+    return o
+
+
+_PAIR = [os.environ.get("VBG_PAIR", "1") != "0"]
+
+
+_PAIR_FORCE = [os.environ.get("VBG_PAIR_FORCE", "0") != "0"]
+
+
+def set_pair(on: bool, force: bool = False):
+    """forward BERT linears (QKV, FFN1, FFN2) on two fp16 pieces per operand / three piece products (csrc/gemm_planes.hip FORM 1)
+    instead of three bf16 pieces / six: operands are LayerNorm / GELU outputs and weights, inside fp16's range.  force: also for
+    problems too small to fill the 8-wave tiles the form exists for (parity tests at batch 2 run the arithmetic of batch 8)"""
+    _PAIR[0] = bool(on)
+    _PAIR_FORCE[0] = bool(force)
+
+
+def pair_enabled() -> bool:
+    return _PAIR[0] and _PLANES[0] and _SPLIT3[0] and not _AMP[0]
+
+
+def pair_tile(M, N, wide=False):
+    """tile of a form-1 product [M, N], or 0 when the problem is too small for the form (it then runs the bf16 form)"""
+    t = _dense_tile(M, N, wide)
+    if t == 64064:
+        return 128129 if _PAIR_FORCE[0] else 0
+    return t
+
+
 def split_planes_t_batched(src_flat, dst_planes, tbl_dev, njobs, total_tiles):
     """transposed planes of many matrices of one fp32 buffer in one launch (table layout: include/vbg.h)"""
     check(lib.vbg_split_planes_t_batched(P(src_flat), P(dst_planes), P(tbl_dev), int(njobs), int(total_tiles), dst_planes.stride(0), _stream()),
@@ -203,7 +244,7 @@ def split_planes_t(x, out=None):
 
 
 def plane_gemm(a: Planes, b: Planes, out=None, *, bias=None, epi=EPI_NONE, C2=None, accumulate=False, splitk=1, alpha=1.0, tile=0,
-               out_planes=None, ldc=None, trans=False, colsum_out=None):
+               out_planes=None, ldc=None, trans=False, colsum_out=None, form=0, out_pair=None):
     """out[M, N] (+)= alpha * a[M, K] b[N, K]^T (+ bias).  out_planes: Planes [M, N] that receive the split of the stored value.
     trans: out[Ma, Nb] (+)= alpha * a[K, Ma]^T b[K, Nb] (the operands' ROWS are the reduction index: weight gradients)."""
     d = PlaneGemmDesc()
@@ -224,6 +265,13 @@ def plane_gemm(a: Planes, b: Planes, out=None, *, bias=None, epi=EPI_NONE, C2=No
     if out_planes is not None:
         d.Cp, d.c_plane, d.ldp = out_planes.buf.data_ptr(), out_planes.plane, out_planes.ld
     d.epi, d.alpha, d.accumulate, d.splitk, d.tile = epi, float(alpha), int(bool(accumulate)), int(splitk), int(tile)
+    if form:                               # a, b: fp16-pair planes [2][rows][ld]
+        assert a.buf.shape[0] == 2 and b.buf.shape[0] == 2 and not trans
+        d.form = 1
+    else:
+        assert a.buf.shape[0] == 3 and b.buf.shape[0] == 3
+    if out_pair is not None:               # the stored value also as fp16-pair planes
+        d.Cq, d.q_plane, d.ldq = out_pair.buf.data_ptr(), out_pair.plane, out_pair.ld
     if colsum_out is not None:             # += column sums of the stored values (a bias gradient)
         d.colsum = colsum_out.data_ptr()
     if _STREAMK[0] and colsum_out is None and not trans and splitk == 1 and tile in (128129, 128130):
@@ -321,7 +369,7 @@ def bump_weight_epoch():
     _W_EPOCH[0] += 1
 
 
-def weight_planes(owner, transposed=False, view=None, also=()) -> Planes:
+def weight_planes(owner, transposed=False, view=None, also=(), pair=False) -> Planes:
     """planes of a 2-D weight [N, K] (transposed: of w^T, the B operand of the data-gradient product), split once per weight
     version.  The cache lives ON the parameter object `owner` (it dies with it: a recycled device address can never serve another
     model's planes); `view`: the matrix to split when it is not `owner` itself (the stacked q/k/v view that starts at `owner`).
@@ -334,18 +382,21 @@ def weight_planes(owner, transposed=False, view=None, also=()) -> Planes:
         # launch per optimizer step refreshes for all weights
         g, off = flat
         ver = (owner._version,) + tuple(t._version for t in also)
-        pl = g.planes_t_of(off, w.shape[0], w.shape[1], ver) if transposed else g.planes_of(off, w.shape[0], w.shape[1], ver)
+        if pair:
+            pl = g.pair_of(off, w.shape[0], w.shape[1], ver)
+        else:
+            pl = g.planes_t_of(off, w.shape[0], w.shape[1], ver) if transposed else g.planes_of(off, w.shape[0], w.shape[1], ver)
         if pl is not None:
             return pl
     cache = owner.__dict__.setdefault("_vbg_wplanes", {})
-    key = (tuple(w.shape), bool(transposed))
+    key = (tuple(w.shape), bool(transposed), bool(pair))
     tag = (_W_EPOCH[0], owner._version, w.data_ptr()) + tuple(t._version for t in also)      # `also`: the other tensors a stacked view covers
     hit = cache.get(key)
     if hit is not None and hit[0] == tag:
         return hit[1]
     with torch.no_grad():
         buf = hit[1] if hit is not None else None
-        pl = split_planes_t(w.detach(), out=buf) if transposed else split_planes(w.detach(), out=buf)
+        pl = split_planes_pair(w.detach(), out=buf) if pair else (split_planes_t(w.detach(), out=buf) if transposed else split_planes(w.detach(), out=buf))
     cache[key] = (tag, pl)
     return pl
 
@@ -568,10 +619,18 @@ def conv3_ok(B, H, W, Cs, N, kh, kw, stride, pad, fwd=False) -> bool:
     has to be turned for the input gradient (84 vs 74 us) -- the late stages stay on the generic kernel; default split form only"""
     return (_CONV3[0] and _SPLIT3[0] and not _AMP[0] and kh == 3 and kw == 3 and stride == 1 and pad == 1 and W in (16, 32, 64, 128, 256, 512, 1024)
             and (H * W) % 64 == 0 and Cs % 16 == 0 and N % 128 == 0 and H * W * Cs < (1 << 29)
-            and (B * H * W // 64) * (N // 128) >= (_CONV3_MIN_TILES_FWD[0] if fwd and _CONV3_F16[0] else _CONV3_MIN_TILES[0]))
+            and (B * H * W // 64) * (N // 128) >= (_CONV3_MIN_TILES_FWD[0] if fwd and _CONV3_F16[0] else _conv3_min_tiles_bwd()))
 
 
 _CONV3_F16 = [os.environ.get("VBG_CONV3_F16", "1") != "0"]
+_CONV3_MIN_TILES_BWD = [int(os.environ.get("VBG_CONV3_MIN_TILES_BWD", "0"))]
+
+
+def _conv3_min_tiles_bwd():
+    """64-pixel tiles an input gradient needs to take the row-reuse kernel (VBG_CONV3_MIN_TILES_BWD overrides)"""
+    if _CONV3_MIN_TILES_BWD[0] > 0:
+        return _CONV3_MIN_TILES_BWD[0]
+    return _CONV3_MIN_TILES[0]          # (the forward's 256 was A/B-ed in the step for the fp16-form input gradient: 190.97 vs 190.74 docs/s, no gain)
 
 
 def set_conv3_f16(on: bool):
@@ -582,21 +641,24 @@ def set_conv3_f16(on: bool):
 _AMAX_POOL = {}
 
 
+AMAX_WORDS, AMAX_STRIDE = 64, 32          # include/vbg.h VBG_AMAX_WORDS / VBG_AMAX_STRIDE
+
+
 def amax_slot(device):
-    """a fresh ZERO device word for the bit pattern of a tensor's largest magnitude (vbg_amax / the amax outputs of bn_apply and
-    bn_bwd_apply max INTO it).  Words come from a zero-filled pool of 1024 (one fill launch per 1024 slots); an exhausted pool is
-    replaced, never rewound, so a word saved for backward stays valid"""
+    """a fresh ZERO amax slot (64 int32 words 128 bytes apart whose max is the bit pattern of a tensor's largest magnitude: vbg_amax and
+    the amax outputs of bn_apply / bn_bwd_apply max INTO it).  Slots come from a zero-filled pool (one 2 MB fill launch per 256
+    slots); an exhausted pool is replaced, never rewound, so a slot saved for backward stays valid"""
     key = (device.type, device.index)
     ent = _AMAX_POOL.get(key)
-    if ent is None or ent[1] >= ent[0].numel():
-        ent = _AMAX_POOL[key] = [torch.zeros((1024,), device=device, dtype=torch.int32), 0]
+    if ent is None or ent[1] >= ent[0].shape[0]:
+        ent = _AMAX_POOL[key] = [torch.zeros((256, AMAX_WORDS * AMAX_STRIDE), device=device, dtype=torch.int32), 0]
     i = ent[1]
     ent[1] = i + 1
-    return ent[0][i:i + 1]
+    return ent[0][i]
 
 
 def amax(x, slot=None):
-    """bit pattern of max |x| in a device word (no host sync): the scale of fp16-form products whose operand x is a gradient"""
+    """bit pattern of max |x| in an amax slot (no host sync): the scale of fp16-form products whose operand x is a gradient"""
     slot = amax_slot(x.device) if slot is None else slot
     check(lib.vbg_amax(P(x), x.numel(), P(slot), _stream()), "vbg_amax")
     return slot
@@ -782,8 +844,9 @@ def embed_ln_bwd(dout, xhat, rstd, ids, pos_ids, gamma, p, seed, sid, dword, dpo
                                P(dpos), P(dtype0), P(dgamma), P(dbeta), _stream()), "vbg_embed_ln_bwd")
 
 
-def dropout_add_ln_fwd(x, res, gamma, beta, eps, p, seed, sid, out_planes=None):
-    """out_planes: Planes [rows, hidden] that receive the split of y in the same pass (ld == hidden: no padding columns)"""
+def dropout_add_ln_fwd(x, res, gamma, beta, eps, p, seed, sid, out_planes=None, out_pair=None):
+    """out_planes: Planes [rows, hidden] that receive the split of y in the same pass (ld == hidden: no padding columns); out_pair:
+    fp16-pair Planes of y as well (with out_planes)"""
     rows, hidden = x.shape
     y = torch.empty_like(x)
     xhat = torch.empty_like(x)
@@ -791,7 +854,9 @@ def dropout_add_ln_fwd(x, res, gamma, beta, eps, p, seed, sid, out_planes=None):
     if out_planes is not None:
         assert out_planes.ld == hidden and out_planes.rows == rows
         check(lib.vbg_dropout_add_ln_fwd_planes(P(x), P(res), rows, hidden, P(gamma), P(beta), eps, p, seed, sid, P(y), P(xhat), P(rstd),
-                                                P(out_planes.buf), out_planes.ld, out_planes.plane, _stream()), "vbg_dropout_add_ln_fwd_planes")
+                                                P(out_planes.buf), out_planes.ld, out_planes.plane,
+                                                P(out_pair.buf) if out_pair is not None else None, out_pair.ld if out_pair is not None else 0,
+                                                out_pair.plane if out_pair is not None else 0, _stream()), "vbg_dropout_add_ln_fwd_planes")
         return y, xhat, rstd
     check(lib.vbg_dropout_add_ln_fwd(P(x), P(res), rows, hidden, P(gamma), P(beta), eps, p, seed, sid, P(y), P(xhat), P(rstd),
                                      _stream()), "vbg_dropout_add_ln_fwd")

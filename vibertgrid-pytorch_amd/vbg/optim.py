@@ -95,6 +95,8 @@ class FlatGroup:
         # image [3][total] in ONE elementwise launch, the transposed images of the matrices that asked for one in ONE batched launch
         self._planes = None
         self._planes_tag = None
+        self._pair = None                    # fp16-pair image [2][total] (operands of the form-1 forward products)
+        self._pair_tag = None
         self._t_jobs = {}                    # (offset, rows, cols) -> (slot offset, ld)
         self._t_buf = None
         self._t_tbl = None
@@ -114,7 +116,7 @@ class FlatGroup:
         """refresh needed?  The optimizer kernels bump the epoch; torch in-place updates of a parameter (load_state_dict, tests) bump
         that parameter's own version counter, which is checked per request against the version seen at the last refresh."""
         seen = self._ver.setdefault(which, {})
-        if (self._planes_tag if which == "p" else self._t_tag) != self._tag() or seen.get(off, ver) != ver:
+        if {"p": self._planes_tag, "q": self._pair_tag, "t": self._t_tag}[which] != self._tag() or seen.get(off, ver) != ver:
             seen.clear()
             seen[off] = ver
             return True
@@ -133,6 +135,18 @@ class FlatGroup:
                 ops.split_planes(self.pflat.detach().view(-1, 32), out=ops.Planes(self._planes.view(3, -1, 32), self.total // 32, 32, 32))
             self._planes_tag = self._tag()
         return ops.Planes(self._planes[:, off:off + rows * cols].view(3, rows, cols), rows, cols, cols)
+
+    def pair_of(self, off: int, rows: int, cols: int, ver=0):
+        """the same matrix as an fp16-pair plane operand (csrc/gemm_planes.hip FORM 1): one launch per optimizer step for the whole buffer"""
+        if cols % 32 or off % 8:
+            return None
+        if self._pair is None:
+            self._pair = torch.empty((2, self.total), device=self.pflat.device, dtype=torch.int16)
+        if self._stale("q", off, ver):
+            with torch.no_grad():
+                ops.split_planes_pair(self.pflat.detach().view(-1, 32), out=ops.Planes(self._pair.view(2, -1, 32), self.total // 32, 32, 32))
+            self._pair_tag = self._tag()
+        return ops.Planes(self._pair[:, off:off + rows * cols].view(2, rows, cols), rows, cols, cols)
 
     def planes_t_of(self, off: int, rows: int, cols: int, ver=0):
         """plane operand of the TRANSPOSE of that matrix ([cols, rows], reduction over rows)"""
