@@ -6,6 +6,11 @@ bucket launches, FusedSGD / FusedAdamW with the 1/world scale.
 (i)  2 ranks x 1 document with SyncBN == 1 process x 2 documents: loss and every parameter gradient (the default plain mean
      losses, equal segment counts -> the global means are the averages of the per-rank means, so the identity is exact in math);
 (ii) after 3 optimizer steps both ranks hold bit-identical flat parameter buffers.
+Variants: the generic convolution kernels / the row-reuse kernels of csrc/conv3.hip on BOTH sides (their thresholds forced down, so
+that the slab-reduced weight gradients, the fp16-form products with their amax slots and the GRAD_READY reports of the product's
+default dispatch run under the reducer); resnet-34 + 12-layer BERT; SyncBatchNorm serialised against the buckets.
+(iii) SyncBatchNorm with UNEQUAL row counts per rank (the RoI-embedding BatchNorm normalises over N * 49 rows, N = the rank's segment
+     count: SURVEY.md "Variable-shape work") == one process over the concatenated rows, forward, statistics and every gradient.
 Needs a real MI355X."""
 import os
 import random
@@ -34,8 +39,25 @@ CFG = dict(num_classes=5, image_min_size=(256,), image_max_size=256, test_image_
            loss_aux_sample_list=None, num_hard_positive_aux=-1, num_hard_negative_aux=-1, ohem_random=False)
 
 
-def _cfg():
-    return O.NetCfg(bert=O.BertCfg(layers=2, dropout=0.0), **CFG)
+VARIANTS = {"generic": dict(conv3=False, backbone="resnet_18_fpn", layers=2, serialize=False),
+            "conv3": dict(conv3=True, backbone="resnet_18_fpn", layers=2, serialize=False),
+            "r34_bert12": dict(conv3=True, backbone="resnet_34_fpn", layers=12, serialize=True)}
+
+
+def _cfg(v="generic"):
+    c = dict(CFG)
+    c["backbone"] = VARIANTS[v]["backbone"]
+    return O.NetCfg(bert=O.BertCfg(layers=VARIANTS[v]["layers"], dropout=0.0), **c)
+
+
+def _dispatch(ops, v):
+    """one kernel family on both sides: the generic kernels, or the row-reuse kernels whatever the tile count (1 document per rank
+    and 2 documents in one process would otherwise fall on different sides of the thresholds)"""
+    if VARIANTS[v]["conv3"]:
+        ops.set_conv3(True)
+        ops._CONV3_MIN_TILES[0] = ops._CONV3_MIN_TILES_FWD[0] = ops._CONV3W_MIN[0] = 1
+    else:
+        ops.set_conv3(False)
 
 
 def _docs():
@@ -61,17 +83,17 @@ def _slice(batch, lo, hi):
     return imgs[lo:hi], segs[lo:hi], classes[lo:hi], coors[lo:hi], corpus[lo:hi], mask[lo:hi]
 
 
-def _build(tmp, sync_bn):
+def _build(tmp, sync_bn, v="generic"):
     from test_gpu_model import build_product, load_synth
-    cfg = _cfg()
-    net = build_product(tmp, "resnet_18_fpn", cfg)
+    cfg = _cfg(v)
+    net = build_product(tmp, VARIANTS[v]["backbone"], cfg, layers=VARIANTS[v]["layers"])
     load_synth(net, cfg, 1200)
     if sync_bn:
         net = torch.nn.SyncBatchNorm.convert_sync_batchnorm(net)
     return net
 
 
-def _worker(rank, world, port, tmp):
+def _worker(rank, world, port, tmp, v):
     import sys
     here = os.path.dirname(os.path.abspath(__file__))
     for p in (here, os.path.join(os.path.dirname(here), "oracle"), os.path.join(os.path.dirname(here), "vibertgrid-pytorch_amd")):
@@ -84,12 +106,12 @@ def _worker(rank, world, port, tmp):
     from test_gpu_model import to_dev
     from vbg import ops
     from vbg.optim import FlatReducer, FusedAdamW, FusedSGD, split_parameters
-    ops.set_conv3(False)        # (see the single-process half of the test: one kernel family on both sides)
-    net = _build(os.path.join(tmp, f"rank{rank}"), sync_bn=True).to(dev).train()
+    _dispatch(ops, v)           # (see the single-process half of the test: one kernel family on both sides)
+    net = _build(os.path.join(tmp, f"rank{rank}"), sync_bn=True, v=v).to(dev).train()
     assert any(isinstance(m, torch.nn.SyncBatchNorm) for m in net.modules())
     cnn, bert = split_parameters(net)
     opts = [FusedSGD(cnn, dev, lr=0.005, momentum=0.9, weight_decay=0.005), FusedAdamW(bert, dev, lr=5e-5, weight_decay=0.01)]
-    red = FlatReducer(opts)
+    red = FlatReducer(opts, serialize_syncbn=VARIANTS[v]["serialize"])
     dbatch = to_dev(_slice(_docs(), rank, rank + 1), dev)
     res = {}
     for step in range(3):
@@ -104,6 +126,9 @@ def _worker(rank, world, port, tmp):
             res["grads"] = {n: (p.grad.detach() / world).cpu().clone() for n, p in net.named_parameters()
                             if p.grad is not None and not n.startswith("BERTgrid_generator.")}
             res["rm"] = net.backbone.conv_1[1].running_mean.cpu().clone()
+            # the dispatch this variant is about really is what ran: layer 2 of the trunk (128 channels at 1/8 resolution) on one document
+            res["conv3"] = (ops.conv3w_ok(1, 32, 32, 128, 128, 3, 3, 1, 1), ops.conv3_ok(1, 32, 32, 128, 128, 3, 3, 1, 1, fwd=True),
+                            ops.conv3_ok(1, 32, 32, 128, 128, 3, 3, 1, 1))
         for o in opts:
             o.step()
     torch.cuda.synchronize()
@@ -115,12 +140,14 @@ def _worker(rank, world, port, tmp):
     dist.destroy_process_group()
 
 
-def test_two_ranks_syncbn_equals_one_process(tmp_path):
+@pytest.mark.parametrize("v", ["generic", "conv3", "r34_bert12"])
+def test_two_ranks_syncbn_equals_one_process(tmp_path, v):
     from test_gpu_model import to_dev
     tmp = str(tmp_path)
     port = _free_port()
-    mp.spawn(_worker, args=(2, port, tmp), nprocs=2, join=True)
+    mp.spawn(_worker, args=(2, port, tmp, v), nprocs=2, join=True)
     r0, r1 = (torch.load(os.path.join(tmp, f"res{r}.pt")) for r in range(2))
+    assert r0["conv3"] == ((True, True, True) if VARIANTS[v]["conv3"] else (False, False, False))
     # (ii) both ranks hold bit-identical parameters after 3 steps, and they launched their buckets in the same sequence
     assert r0["order"] == r1["order"] and sorted(r0["order"]) == list(range(r0["nbuckets"]))
     for a, b in zip(r0["pflat"], r1["pflat"]):
@@ -133,14 +160,16 @@ def test_two_ranks_syncbn_equals_one_process(tmp_path):
     # statistics over a handful of samples amplify a thousandfold): both sides use the generic kernels -- the test is about the exchange
     from vbg import ops
     dev = torch.device("cuda")
-    net = _build(os.path.join(tmp, "single"), sync_bn=False).to(dev).train()
+    net = _build(os.path.join(tmp, "single"), sync_bn=False, v=v).to(dev).train()
     random.seed(5)
-    ops.set_conv3(False)
+    saved = (ops._CONV3_MIN_TILES[0], ops._CONV3_MIN_TILES_FWD[0], ops._CONV3W_MIN[0])
+    _dispatch(ops, v)
     try:
         loss = net(*to_dev(_docs(), dev))
         loss.backward()
     finally:
         ops.set_conv3(True)
+        ops._CONV3_MIN_TILES[0], ops._CONV3_MIN_TILES_FWD[0], ops._CONV3W_MIN[0] = saved
     avg_loss = 0.5 * (r0["loss"] + r1["loss"])
     print("loss single", float(loss.detach()), "mean of ranks", avg_loss)
     assert abs(float(loss.detach()) - avg_loss) <= 1e-5 * abs(avg_loss)
@@ -155,4 +184,66 @@ def test_two_ranks_syncbn_equals_one_process(tmp_path):
         worst.append((float((a - b).norm() / (b.norm() + 1e-30)), n))
     worst.sort(reverse=True)
     print("2 ranks + SyncBN vs 1 process, rel-L2 of gradients, worst:", worst[:5], "median", worst[len(worst) // 2])
-    assert worst[0][0] < 1e-4, worst[:8]
+    # (12 layers: the query / key projections of the last layers carry the smallest gradients of the model -- 2.4e-4 there, median 9e-7)
+    assert worst[0][0] < (5e-4 if VARIANTS[v]["layers"] > 2 else 1e-4), worst[:8]
+
+
+# ---------------------------------------------------------------------------------------------------------------------------------
+# (iii) SyncBatchNorm over UNEQUAL row counts
+# ---------------------------------------------------------------------------------------------------------------------------------
+NROI = (8, 5)          # segments of the two ranks: the RoI-embedding BatchNorm sees 8 * 49 and 5 * 49 rows
+
+
+def _convbn_inputs():
+    g = torch.Generator().manual_seed(99)
+    xs = [torch.randn(n, 7, 7, 32, generator=g) for n in NROI]
+    gys = [torch.randn(n, 7, 7, 64, generator=g) for n in NROI]
+    w = torch.randn(64, 32, 3, 3, generator=g) / 17.0
+    gam, bet = 1 + 0.1 * torch.randn(64, generator=g), 0.1 * torch.randn(64, generator=g)
+    return xs, gys, w, gam, bet
+
+
+def _convbn_run(dev, x, gy, w, gam, bet, sync):
+    from vbg import functions as Fn
+    x = x.to(dev).requires_grad_(True)
+    w = w.to(dev).to(memory_format=torch.channels_last).requires_grad_(True)
+    gam, bet = gam.to(dev).requires_grad_(True), bet.to(dev).requires_grad_(True)
+    rm, rv = torch.zeros(64, device=dev), torch.ones(64, device=dev)
+    y = Fn.ConvBnFn.apply(x, w, gam, bet, rm, rv, None, 1, 1, True, True, 0.1, 1e-5, sync)
+    (y * gy.to(dev)).sum().backward()
+    return dict(y=y.detach().cpu(), dx=x.grad.cpu(), dw=w.grad.cpu().contiguous(), dg=gam.grad.cpu(), db=bet.grad.cpu(), rm=rm.cpu(), rv=rv.cpu())
+
+
+def _convbn_worker(rank, world, port, tmp):
+    import sys
+    here = os.path.dirname(os.path.abspath(__file__))
+    for p in (here, os.path.join(os.path.dirname(here), "oracle"), os.path.join(os.path.dirname(here), "vibertgrid-pytorch_amd")):
+        if p not in sys.path:
+            sys.path.insert(0, p)
+    os.environ.update(MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port))
+    torch.cuda.set_device(0)
+    dev = torch.device("cuda", 0)
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    xs, gys, w, gam, bet = _convbn_inputs()
+    res = _convbn_run(dev, xs[rank], gys[rank], w, gam, bet, True)
+    torch.save(res, os.path.join(tmp, f"cb{rank}.pt"))
+    dist.barrier()
+    dist.destroy_process_group()
+
+
+def test_syncbn_unequal_row_counts(tmp_path):
+    """two ranks with 8 and 5 RoIs (392 / 245 rows under the BatchNorm of late_fusion_net.ROI_embedding_net,
+    model/field_type_classification_head.py:64-75) == one process over all 13: the statistics are count-weighted, not rank-averaged"""
+    tmp = str(tmp_path)
+    port = _free_port()
+    mp.spawn(_convbn_worker, args=(2, port, tmp), nprocs=2, join=True)
+    r = [torch.load(os.path.join(tmp, f"cb{k}.pt")) for k in range(2)]
+    xs, gys, w, gam, bet = _convbn_inputs()
+    one = _convbn_run(torch.device("cuda"), torch.cat(xs), torch.cat(gys), w, gam, bet, False)
+    close = lambda a, b, tol=2e-5: float((a.double() - b.double()).abs().max()) <= tol * max(1.0, float(b.abs().max()))
+    assert close(torch.cat([r[0]["y"], r[1]["y"]]), one["y"])
+    assert close(torch.cat([r[0]["dx"], r[1]["dx"]]), one["dx"])
+    assert close(r[0]["dw"] + r[1]["dw"], one["dw"], 1e-4)          # (the gradient exchange would sum / average these)
+    assert close(r[0]["dg"] + r[1]["dg"], one["dg"], 1e-4) and close(r[0]["db"] + r[1]["db"], one["db"], 1e-4)
+    for k in range(2):                                             # every rank tracks the GLOBAL running statistics
+        assert close(r[k]["rm"], one["rm"]) and close(r[k]["rv"], one["rv"])

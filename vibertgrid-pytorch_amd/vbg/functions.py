@@ -74,12 +74,21 @@ def _affine_done(gamma_param, beta_param, dg, db, sunk):
 
 
 class SyncCtx:
-    """Process group for SyncBatchNorm statistics (train_SROIE.py:202-203 `convert_sync_batchnorm`)."""
+    """Process group for SyncBatchNorm statistics (train_SROIE.py:202-203 `convert_sync_batchnorm`).  `before`: optional hook run on
+    the compute stream in front of every SyncBatchNorm collective (vbg/optim.FlatReducer(serialize_syncbn=True) makes the stream wait
+    for the gradient buckets in flight on the staging stream, so that never two communicators have a collective in flight)."""
     group = None
+    before = None
 
     @classmethod
     def active(cls):
         return dist.is_available() and dist.is_initialized() and dist.get_world_size(cls.group) > 1
+
+    @classmethod
+    def all_reduce(cls, t):
+        if cls.before is not None:
+            cls.before()
+        dist.all_reduce(t, group=cls.group)
 
 
 # ----------------------------------------------------------------------------------------------
@@ -327,7 +336,7 @@ class ConvBnFn(torch.autograd.Function):
                 glob = torch.empty((2 * C + 1,), device=x.device, dtype=torch.float64)
                 ops.bn_fold(stats, C, out=glob)
                 glob[2 * C] = M
-                dist.all_reduce(glob, group=SyncCtx.group)
+                SyncCtx.all_reduce(glob)
                 count_dev = glob[2 * C:]                   # global row count stays on the device (no sync)
                 mean, invstd = ops.bn_finalize(glob, C, 1, count, eps, momentum, running_mean, running_var, count_dev)
             else:
@@ -364,7 +373,7 @@ class ConvBnFn(torch.autograd.Function):
             # terms of the input gradient vanish -> dz = gamma * invstd * dy (same kernel, zero sums); dgamma / dbeta as above
             sums = torch.zeros_like(sums)
         elif sync:
-            dist.all_reduce(sums, group=SyncCtx.group)
+            SyncCtx.all_reduce(sums)
         # the fp16-form products that consume dz (input gradient of a wide 3x3 convolution) scale it by its largest magnitude, which
         # rides on the kernel that writes dz
         B_, H_, W_, Cin_ = x.shape

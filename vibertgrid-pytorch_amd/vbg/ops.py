@@ -143,7 +143,7 @@ def gemm_raw(M, N, K, A, lda, a_kind, B, ldb, b_kind, Cout, ldc, *, bias=None, e
     if prof is not None and prof.match(a_kind, b_kind, grp is not None):
         e0, e1 = prof.events()
         check(lib.vbg_gemm_timed(C.byref(d), _stream(), e0, e1), "vbg_gemm_timed")
-        prof.add(2.0 * M * N * K, e0, e1)
+        prof.add(2.0 * M * N * K, e0, e1, 1 if (_AMP[0] or not _SPLIT3[0]) else 6)
         return
     check(lib.vbg_gemm(C.byref(d), _stream()), "vbg_gemm")
 
@@ -281,7 +281,7 @@ def plane_gemm(a: Planes, b: Planes, out=None, *, bias=None, epi=EPI_NONE, C2=No
     if prof is not None and not trans and prof.match(OP_DENSE_K, OP_DENSE_K, False):
         e0, e1 = prof.events()
         check(lib.vbg_plane_gemm_timed(C.byref(d), _stream(), e0, e1), "vbg_plane_gemm_timed")
-        prof.add(2.0 * d.M * d.N * (a.rows if trans else a.cols), e0, e1)
+        prof.add(2.0 * d.M * d.N * (a.rows if trans else a.cols), e0, e1, 3 if form else 6)
         return out
     check(lib.vbg_plane_gemm(C.byref(d), _stream()), "vbg_plane_gemm")
     return out
@@ -438,18 +438,21 @@ class GemmProfiler:
             out.append(h)
         return out
 
-    def add(self, flops, e0, e1):
-        self.records.append((flops, e0, e1))
+    def add(self, flops, e0, e1, products=6):
+        """products: MFMA piece products the launch executes per algorithmic product (6: three bf16 pieces per operand, 3: two fp16
+        pieces, 1: amp / the fp32 matrix pipe)"""
+        self.records.append((flops, e0, e1, products))
 
     def summary(self):
-        """-> (launches, total_flops, total_ms)  (call after a device sync); releases the events"""
+        """-> (launches, total algorithmic flops, total ms, total EXECUTED matrix-core flops)  (call after a device sync); releases
+        the events"""
         ms = 0.0
-        for _, e0, e1 in self.records:
+        for _, e0, e1, _ in self.records:
             v = C.c_float()
             check(lib.vbg_timer_elapsed_ms(e0, e1, C.byref(v)), "vbg_timer_elapsed_ms")
             ms += v.value
-        out = (len(self.records), sum(f for f, _, _ in self.records), ms)
-        for _, e0, e1 in self.records:
+        out = (len(self.records), sum(r[0] for r in self.records), ms, sum(r[0] * r[3] for r in self.records))
+        for _, e0, e1, _ in self.records:
             lib.vbg_timer_destroy(e0)
             lib.vbg_timer_destroy(e1)
         self.records = []

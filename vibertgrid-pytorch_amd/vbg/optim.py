@@ -20,14 +20,13 @@ pipeline/train_val_utils.py:272-284, designed for MI355X instead of translated:
   (`bert_model.pooler.*`, `backbone.resnet.fc.*`) are kept out of the buffers, which is what
   `find_unused_parameters=True` + "skip params with grad None" amounts to in the reference.
 """
+import os
 from typing import Dict, List, Sequence, Tuple
 
 import torch
 import torch.distributed as dist
 
 from . import functions as Fn
-import os
-
 from . import ops
 
 STATIC_UNUSED = ("pooler.", "resnet.fc.")
@@ -320,7 +319,7 @@ class FlatReducer:
     broadcast) -- from step 2 on the buckets fire during backward.  A rank whose graph skips a sub-module in some step simply
     issues the affected bucket (and everything behind it) from `finish()`; the sequence is unchanged."""
 
-    def __init__(self, optimizers, bucket_mb: float = 32.0, group=None, sync_bn_group="new"):
+    def __init__(self, optimizers, bucket_mb: float = 32.0, group=None, sync_bn_group="new", serialize_syncbn=None):
         self.enabled = dist.is_available() and dist.is_initialized() and dist.get_world_size(group) > 1
         self.pg = group
         self.optimizers = optimizers
@@ -337,12 +336,31 @@ class FlatReducer:
         self._streams = {}         # raw handle -> torch stream: compute streams gradients were reported from in this step
         if not self.enabled:
             return
+        # SyncBatchNorm statistics and gradient buckets.  The buckets follow ONE rank-agreed sequence, the SyncBatchNorm collectives
+        # the program order of forward / backward; how the two sequences INTERLEAVE is not rank-invariant once a rank's graph skips a
+        # sub-module (its bucket then fires from finish() instead of from a hook), so they cannot share a communicator in general:
+        #   sync_bn_group="new" (default, only with group=None -- dist.new_group is a collective over the DEFAULT group, every rank
+        #       must construct its reducer): an own communicator for the statistics.  torch documents concurrent collectives on two
+        #       NCCL communicators as unsafe when their kernels cannot co-reside; serialize_syncbn=True (VBG_SERIALIZE_SYNCBN=1) then
+        #       makes the compute stream wait for the buckets in flight before every SyncBatchNorm collective -- one communicator in
+        #       flight at any time, at the price of the overlap at those points;
+        #   sync_bn_group="default" (VBG_SYNCBN_GROUP=default): the statistics on the reducer's own group -- valid when every rank
+        #       runs the same graph every step (classifier_mode simp), nothing concurrent;
+        #   sync_bn_group=<ProcessGroup>: the caller's communicator (required with a sub-group).
         if sync_bn_group == "new":
-            # SyncBatchNorm statistics on their own communicator (collective call: every rank constructs its reducer)
-            ranks = list(range(dist.get_world_size())) if group is None else dist.get_process_group_ranks(group)
-            Fn.SyncCtx.group = dist.new_group(ranks=ranks)
+            sync_bn_group = os.environ.get("VBG_SYNCBN_GROUP", "new")
+        if sync_bn_group == "new":
+            if group is not None:
+                raise ValueError("FlatReducer(group=<sub-group>): pass sync_bn_group=<ProcessGroup> or 'default' -- dist.new_group is a "
+                                 "collective over the default group and would hang when only the sub-group's ranks call it")
+            Fn.SyncCtx.group = dist.new_group(ranks=list(range(dist.get_world_size())))
+        elif sync_bn_group == "default":
+            Fn.SyncCtx.group = group
         elif sync_bn_group is not None:
             Fn.SyncCtx.group = sync_bn_group
+        if serialize_syncbn is None:
+            serialize_syncbn = os.environ.get("VBG_SERIALIZE_SYNCBN", "0") != "0"
+        Fn.SyncCtx.before = self._wait_for_buckets if serialize_syncbn else None
         Fn.GRAD_READY[0] = self._param_ready      # sunk gradients (written by the wgrad kernels) report here
         cap = int(bucket_mb * (1 << 20) / 4)
         for o in optimizers:
@@ -405,6 +423,11 @@ class FlatReducer:
             self._stage.wait_stream(s)
         with torch.cuda.stream(self._stage):
             self.handles.append(dist.all_reduce(buf, group=self.pg, async_op=True))
+
+    def _wait_for_buckets(self):
+        """compute stream waits for the bucket collectives issued so far (serialize_syncbn)"""
+        if self._stage is not None:
+            torch.cuda.current_stream(self._stage.device).wait_stream(self._stage)
 
     def _ready(self, idx):
         b = self.buckets[idx]
