@@ -36,8 +36,10 @@ def _torch_opts(net):
 
 def _fused_opts(net, dev):
     from vbg.optim import FusedAdamW, FusedSGD, split_parameters
-    # unused=() keeps pooler / fc in the lists like the reference's optimizers do (their indices then line up in checkpoints)
-    cnn, bert = split_parameters(net, unused=())
+    # the DEFAULT split: pooler / fc stay out of the flat buffers (they never receive a gradient; torch skips them step by step), while
+    # the lists remember the reference's full parameter order, so checkpoint indices line up with torch.optim's (vbg.optim.NamedParams)
+    cnn, bert = split_parameters(net)
+    assert len(bert) < len(bert.ref_names)          # (the pooler is kept out, and still counted)
     return (FusedSGD(cnn, dev, lr=0.005, momentum=0.9, weight_decay=0.005),
             FusedAdamW(bert, dev, lr=5e-5, betas=(0.9, 0.999), eps=1e-8, weight_decay=0.01))
 

@@ -108,6 +108,14 @@ class FlatGroup:
             if p.grad is None or p.grad.data_ptr() != self.gflat.data_ptr() + 4 * off:
                 p.grad = _phys_view(self.gflat, off, p.data)
 
+    def invalidate(self):
+        """forget every cached plane image of the buffer.  The caches follow the optimizer kernels (weight epoch), torch in-place
+        updates (`_version` of the buffer and of the parameter asked for) and load_state_dict; a write through `param.data`
+        (`p.data.copy_(...)`, `p.data.mul_(...)`: EMA / weight-tying code) moves none of these counters -- call this, or
+        vbg.ops.bump_weight_epoch(), after such a write"""
+        self._planes_tag = self._pair_tag = self._t_tag = None
+        self._ver.clear()
+
     def _tag(self):
         return (ops._W_EPOCH[0], self.pflat._version)
 
@@ -178,14 +186,28 @@ class FlatGroup:
         return _phys_view(flat, self.offsets[i], self.params[i].data)
 
 
+class NamedParams(list):
+    """[(name, parameter)] that remembers the reference's FULL parameter list of the group (`ref_names`): torch optimizer checkpoints
+    key their state by index into that list (train_SROIE.py:215-221 keeps the never-used tensors in it), so the indices written and
+    read by _FlatOptimizer.state_dict / load_state_dict stay those of the reference's optimizer even though the unused tensors are
+    kept out of the flat buffers"""
+    ref_names: List[str] = None
+
+
 def split_parameters(model: torch.nn.Module, unused: Sequence[str] = STATIC_UNUSED):
     """(cnn_named, bert_named) exactly like train_SROIE.py:215-221, minus the tensors that never receive a gradient
-    (`unused`: name fragments; the reference keeps them in its optimizers, where `grad is None` makes every step skip them)."""
-    cnn, bert = [], []
+    (`unused`: name fragments; the reference keeps them in its optimizers, where `grad is None` makes every step skip them -- and
+    where they still occupy an index: see NamedParams)."""
+    cnn, bert = NamedParams(), NamedParams()
+    cnn.ref_names, bert.ref_names = [], []
     for name, p in model.named_parameters():
-        if not p.requires_grad or any(u in name for u in unused):
+        if not p.requires_grad:
             continue
-        (bert if "bert_model" in name else cnn).append((name, p))
+        dst = bert if "bert_model" in name else cnn
+        dst.ref_names.append(name)
+        if any(u in name for u in unused):
+            continue
+        dst.append((name, p))
     return cnn, bert
 
 
@@ -208,8 +230,12 @@ class _FlatOptimizer(torch.optim.Optimizer):
     _state_names: Tuple[str, ...] = ()
 
     def __init__(self, named, device, defaults: Dict):
+        ref = getattr(named, "ref_names", None)
         named = list(named)
         self.group = FlatGroup(named, device)
+        if ref is not None:                 # indices of the reference optimizer's full parameter list (unused tensors included)
+            assert set(n for n, _ in named) <= set(ref)
+            self.group.ref_names = list(ref)
         super().__init__([p for _, p in named], defaults)
         self.grad_scale = 1.0
         self.steps = 0
@@ -227,6 +253,8 @@ class _FlatOptimizer(torch.optim.Optimizer):
         state = {}
         if self.steps > 0:
             for ref_i, n in enumerate(g.ref_names):
+                if n not in pos:             # a tensor that never receives a gradient: torch keeps no state for it either
+                    continue
                 i = pos[n]
                 st = {k: g.view(flat, i).clone() for k, flat in self._flat_state().items()}
                 if "exp_avg" in st:
@@ -244,8 +272,15 @@ class _FlatOptimizer(torch.optim.Optimizer):
         for f in flats.values():
             f.zero_()
         self.steps = 0
+        n_ref = len(sd["param_groups"][0]["params"]) if sd.get("param_groups") else len(g.ref_names)
+        if n_ref != len(g.ref_names):
+            raise ValueError(f"optimizer checkpoint covers {n_ref} parameters, this optimizer's reference list has {len(g.ref_names)}: "
+                             "build the optimizer from split_parameters(model) so that the indices are the reference's")
         for ref_i, st in sd["state"].items():
-            i = pos[g.ref_names[int(ref_i)]]
+            n = g.ref_names[int(ref_i)]
+            if n not in pos:                 # state of a tensor kept out of the flat buffers (it never receives a gradient)
+                continue
+            i = pos[n]
             for k, flat in flats.items():
                 if k in st and st[k] is not None:
                     g.view(flat, i).copy_(st[k])
