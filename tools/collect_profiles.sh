@@ -1,4 +1,4 @@
-# every rocprofv3 collection the committed profiles/ are made from, on one box:  gpurun -- bash tools/collect_profiles.sh ; python tools/make_profiles.py r02
+# every rocprofv3 collection the committed profiles/ are made from, on one box:  gpurun -- bash tools/collect_profiles.sh ; python tools/make_profiles.py r03
 cd /tmp && export TMPDIR=/tmp && cd $GRAFT_REPO_ROOT
 B="python bench.py --steps 3 --warmup 1 --no-cpu-baseline --no-amp-leg --no-h2d-leg"
 timeout 900 python bench.py --steps 20 --warmup 5 2>gpurun_out/bench_line.err | grep "^{" > gpurun_out/bench_line.json
@@ -11,8 +11,10 @@ timeout 600 python tools/gemm_bench.py > gpurun_out/gemm_shapes.txt 2>&1
 timeout 600 python tools/gemm_bench.py --amp > gpurun_out/gemm_shapes_amp.txt 2>&1
 timeout 600 python tools/plane_gemm_bench.py > gpurun_out/plane_gemm_shapes.txt 2>&1
 timeout 600 python tools/conv3_bench.py 2>&1 | grep -v amdgpu.ids > gpurun_out/conv3_shapes.txt
+timeout 600 python tools/conv3_forms_bench.py 2>&1 | grep -v amdgpu.ids > gpurun_out/conv3_forms.txt
+timeout 300 python tools/attn_bench.py 2>&1 | grep -v amdgpu.ids > gpurun_out/attn_shapes.txt
 rm -f gpurun_out/prof_amp/amp_kernel_trace.csv
 ls -la gpurun_out/prof_e gpurun_out/pmc_f gpurun_out/pmc_m | head -30; cut -c1-400 gpurun_out/bench_line.json
 # exploratory shapes and legs of the same build
-for s in cfg4 cfg5; do timeout 600 python bench.py --shape $s --steps 6 --warmup 2 --no-cpu-baseline --no-h2d-leg 2>/dev/null | grep "^{" > gpurun_out/bench_$s.json; done
+for s in cfg3 cfg4 cfg5; do timeout 600 python bench.py --shape $s --steps 6 --warmup 2 --no-cpu-baseline --no-h2d-leg 2>/dev/null | grep "^{" > gpurun_out/bench_$s.json; done
 timeout 300 python tools/infer_latency.py > gpurun_out/infer_latency.txt 2>&1

@@ -1,15 +1,15 @@
 #!/usr/bin/env python3
 """Summarise the rocprofv3 runs of gpurun_out/ into the committed profiles/ (names carry the round tag).
 
-    python tools/make_profiles.py [r02] [steps in the kernel trace = 13] [steps in the PMC traces = 4]
+    python tools/make_profiles.py [r03] [steps in the kernel trace = 23] [steps in the PMC traces = 7]
 
 expects (tools/collect_profiles.sh): gpurun_out/prof_e (kernel-trace + stats of `bench.py --steps 10 --warmup 3 --no-h2d-leg`),
 gpurun_out/pmc_f / pmc_w (FETCH_SIZE / WRITE_SIZE passes of `bench.py --steps 3 --warmup 1 --no-h2d-leg`), gpurun_out/pmc_m (SQ / GRBM
 pass of the same command), gpurun_out/gemm_shapes.txt, gpurun_out/bench_line.json"""
 import collections, csv, json, os, re, shutil, subprocess, sys
-TAG = sys.argv[1] if len(sys.argv) > 1 else "r02"
-NSTEP = int(sys.argv[2]) if len(sys.argv) > 2 else 13
-NPMC = int(sys.argv[3]) if len(sys.argv) > 3 else 4
+TAG = sys.argv[1] if len(sys.argv) > 1 else "r03"
+NSTEP = int(sys.argv[2]) if len(sys.argv) > 2 else 23          # bench.py --steps 10 --warmup 3: 3 + 10 (headline) + 10 (roofline leg)
+NPMC = int(sys.argv[3]) if len(sys.argv) > 3 else 7            # bench.py --steps 3 --warmup 1: 1 + 3 + 3
 R = os.path.dirname(os.path.dirname(os.path.abspath(__file__))) + "/"
 G = R + "gpurun_out/"
 P = R + "profiles/" + TAG + "_"
@@ -24,8 +24,8 @@ def short(name):
 def is_roofline_launch(name, grid):
     """the launches bench.py's `roofline` times: every UNGROUPED dense NT product (plane_gemm NT, gemm_kernel DENSE_K x DENSE_K in the
     split form)"""
-    if "plane_gemm_kernel" in name:
-        return name.rstrip().endswith("false>(vbg_plane_gemm_desc)")
+    if "plane_gemm_kernel" in name:          # <BM, BN, waves M, waves N, stages, TN, ping-pong, form>: the NT launches
+        return re.search(r"plane_gemm_kernel<\d+, \d+, \d+, \d+, \d+, false", name) is not None
     m = re.search(r"gemm_kernel<(\d+), (\d+), (\d+), 256, (\d), (\d), (true|false), (\d)>", name)
     return bool(m) and m.group(4) == "0" and m.group(5) == "0" and not (m.group(7) == "0" and m.group(6) == "true")
 
@@ -94,8 +94,9 @@ if os.path.exists(G + "pmc_m/m_counter_collection.csv"):
            f"# over `python bench.py --steps 3 --warmup 1 --no-cpu-baseline --no-amp-leg --no-h2d-leg`, summed per matrix-core kernel instantiation over the {NPMC} steps.",
            "# mfma_util = SQ_VALU_MFMA_BUSY_CYCLES / (kernel time * clock * 1024 SIMDs), clock = GRBM_GUI_ACTIVE / time / 8 XCDs;",
            "# wait/active columns are fractions of SQ_WAVE_CYCLES.  gemm_kernel<BM, BN, BK, 256, A-kind, B-kind, vec, form>: kinds 0 DENSE_K, 1 DENSE_R, 2 CONV_K,",
-           "# 3 CONV_R, 4 WT_R; form 0 = fp32 MFMA, 3 = in-kernel bf16x3 split.  plane_gemm_kernel<BM, BN, waves M, waves N, stages, TN>: pre-split planes.",
-           "# attn_kernel<mode, dropout>: 0 forward, 1 dQ, 2 dK/dV.  conv3x3_kernel<pixels per tile> / conv3x3_wgrad_kernel<waves along the filters>: csrc/conv3.hip.",
+           "# 3 CONV_R, 4 WT_R; form 0 = fp32 MFMA, 3 = in-kernel bf16x3 split.  plane_gemm_kernel<BM, BN, waves M, waves N, stages, TN, ping-pong, form>: pre-split planes,",
+           "# form 0 = three bf16 planes / six piece products, 1 = two fp16 planes / three piece products (mfma_util counts BUSY cycles: half the products at equal time halve it).",
+           "# attn_kernel<mode, dropout>: 0 forward, 1 dQ, 2 dK/dV.  conv3x3_kernel<pixels per tile, fp16 form> / conv3x3_wgrad_kernel<waves along the filters, fp16 form>: csrc/conv3.hip.",
            "kernel,launches_per_step,ms_per_step,clock_GHz,mfma_util,wait_any,wait_inst_any,active_inst_any,lds_bank_conflict_Mcycles"]
     tb = tc = 0
     for k, a_ in sorted(ag.items(), key=lambda kv: -kv[1]["ns"]):
@@ -122,7 +123,10 @@ tot = sum(float(r["TotalDurationNs"]) for r in rows) / NSTEP / 1e6
 cat = collections.OrderedDict()
 for r in rows:
     nme, v = r["Name"], float(r["TotalDurationNs"]) / NSTEP / 1e6
-    if "plane_gemm_kernel" in nme: key = "plane GEMM TN (dense wgrad)" if "true>(" in nme else "plane GEMM NT (dense fwd / dgrad)"
+    if "plane_gemm_kernel" in nme:
+        tn = re.search(r"plane_gemm_kernel<\d+, \d+, \d+, \d+, \d+, true", nme) is not None
+        pair = re.search(r", 1>\(", nme) is not None
+        key = "plane GEMM TN (dense wgrad)" if tn else ("plane GEMM NT, fp16-pair form (forward QKV / FFN1 / FFN2)" if pair else "plane GEMM NT, bf16x3 form (dgrad, attention out)")
     elif "conv3x3_wgrad" in nme or "conv3_wgrad_reduce" in nme: key = "conv wgrad, row-reuse kernel (conv3.hip)"
     elif "conv3x3_kernel" in nme or "conv3_wflip" in nme: key = "conv fwd + dgrad, row-reuse kernel (conv3.hip)"
     elif "gemm_kernel" in nme:

@@ -354,7 +354,11 @@ class FlatReducer:
     broadcast) -- from step 2 on the buckets fire during backward.  A rank whose graph skips a sub-module in some step simply
     issues the affected bucket (and everything behind it) from `finish()`; the sequence is unchanged."""
 
-    def __init__(self, optimizers, bucket_mb: float = 32.0, group=None, sync_bn_group="new", serialize_syncbn=None):
+    def __init__(self, optimizers, bucket_mb: float = 32.0, group=None, sync_bn_group="new", serialize_syncbn=None, dry_run=False):
+        """dry_run (one process): same buckets, same hooks and the same launch sequence, but a bucket's "collective" is a timestamp on
+        the stream it would be issued from -- `timeline()` then tells when, inside backward, every bucket could have left
+        (tools/bucket_timeline.py)"""
+        self.dry = bool(dry_run)
         self.enabled = dist.is_available() and dist.is_initialized() and dist.get_world_size(group) > 1
         self.pg = group
         self.optimizers = optimizers
@@ -369,7 +373,10 @@ class FlatReducer:
         self._next = 0             # position in `order` of the next bucket to issue
         self._stage = None         # stream the collectives are issued from
         self._streams = {}         # raw handle -> torch stream: compute streams gradients were reported from in this step
-        if not self.enabled:
+        self._events = []          # dry run: (bucket, event) in issue order
+        if self.dry:
+            self.enabled = False
+        elif not self.enabled:
             return
         # SyncBatchNorm statistics and gradient buckets.  The buckets follow ONE rank-agreed sequence, the SyncBatchNorm collectives
         # the program order of forward / backward; how the two sequences INTERLEAVE is not rank-invariant once a rank's graph skips a
@@ -382,6 +389,8 @@ class FlatReducer:
         #   sync_bn_group="default" (VBG_SYNCBN_GROUP=default): the statistics on the reducer's own group -- valid when every rank
         #       runs the same graph every step (classifier_mode simp), nothing concurrent;
         #   sync_bn_group=<ProcessGroup>: the caller's communicator (required with a sub-group).
+        if self.dry:
+            sync_bn_group = None
         if sync_bn_group == "new":
             sync_bn_group = os.environ.get("VBG_SYNCBN_GROUP", "new")
         if sync_bn_group == "new":
@@ -395,11 +404,12 @@ class FlatReducer:
             Fn.SyncCtx.group = sync_bn_group
         if serialize_syncbn is None:
             serialize_syncbn = os.environ.get("VBG_SERIALIZE_SYNCBN", "0") != "0"
-        Fn.SyncCtx.before = self._wait_for_buckets if serialize_syncbn else None
+        Fn.SyncCtx.before = self._wait_for_buckets if (serialize_syncbn and not self.dry) else None
         Fn.GRAD_READY[0] = self._param_ready      # sunk gradients (written by the wgrad kernels) report here
         cap = int(bucket_mb * (1 << 20) / 4)
         for o in optimizers:
-            o.grad_scale = 1.0 / self.world
+            if not self.dry:
+                o.grad_scale = 1.0 / self.world
             g = o.group
             start, members = 0, []
             for i, (p, off) in enumerate(zip(g.params, g.offsets)):
@@ -444,6 +454,11 @@ class FlatReducer:
 
     def _issue(self, idx):
         buf = self.buckets[idx][0]
+        if self.dry:               # the moment this bucket's collective could start: everything reported so far has been enqueued
+            ev = torch.cuda.Event(enable_timing=True)
+            ev.record(torch.cuda.current_stream(buf.device))
+            self._events.append((idx, ev))
+            return
         if not buf.is_cuda:
             self.handles.append(dist.all_reduce(buf, group=self.pg, async_op=True))
             return
@@ -458,6 +473,12 @@ class FlatReducer:
             self._stage.wait_stream(s)
         with torch.cuda.stream(self._stage):
             self.handles.append(dist.all_reduce(buf, group=self.pg, async_op=True))
+
+    def timeline(self, start_event):
+        """dry run: [(bucket, MB, ms since start_event)] of the last step, in issue order; clears the record (call after a sync)"""
+        out = [(i, self.buckets[i][0].numel() * 4 / 1e6, start_event.elapsed_time(ev)) for i, ev in self._events]
+        self._events = []
+        return out
 
     def _wait_for_buckets(self):
         """compute stream waits for the bucket collectives issued so far (serialize_syncbn)"""
@@ -483,6 +504,18 @@ class FlatReducer:
     def finish(self):
         """issue what backward left over (in sequence), wait for every bucket (call after backward, before the optimizer
         steps), re-arm the counters"""
+        if self.dry:
+            if self.order is None:
+                self.order = self._observed + [i for i in range(len(self.buckets)) if i not in self._complete]
+            while self._next < len(self.order):
+                self._issue(self.order[self._next])
+                self._next += 1
+            for b in self.buckets:
+                b[2] = b[1]
+            self._reported.clear()
+            self._streams.clear()
+            self._observed, self._complete, self._next = [], set(), 0
+            return
         if not self.enabled:
             return
         if self.order is None:
