@@ -112,6 +112,7 @@ typedef struct vbg_plane_group {                                  /* one problem
     long long a_plane, lda, b_plane, ldb, ldc;
     int M, N;
     int tiles_m, tiles_n;                                         /* filled by the library */
+    const unsigned* a_amax;                                       /* form 1: amax slot whose power of two A was scaled by, or NULL */
 } vbg_plane_group;
 typedef struct vbg_plane_gemm_desc {
     int M, N, K;
@@ -150,6 +151,12 @@ typedef struct vbg_plane_gemm_desc {
     int form;
     /* optional: the stored value (after bias / GELU) also as fp16-pair planes [2][M][ldq] (plane stride q_plane elements) */
     unsigned short* Cq; long long q_plane; long long ldq;
+    /* form 1, optional: the A planes hold x * 2^e, e = the power of two that brings the value of this amax slot to [2^13, 2^14)
+       (vbg_split_planes_pair with the same slot): the product is scaled back by 2^-e -- a GRADIENT as the A operand.  With trans != 0
+       form 1 also covers the weight-gradient products (single and grouped: vbg_plane_group.a_amax per problem). */
+    const unsigned* a_amax;
+    /* optional (NT): amax slot that receives max |stored value| of this launch (zeroed by the caller) */
+    unsigned* c_amax;
 } vbg_plane_gemm_desc;
 int vbg_plane_gemm(const vbg_plane_gemm_desc* desc, void* stream);
 int vbg_plane_gemm_timed(const vbg_plane_gemm_desc* desc, void* stream, void* start_event, void* stop_event);
@@ -162,13 +169,19 @@ int vbg_split_planes(const float* x, long long ldx, int rows, int cols, unsigned
 int vbg_split_planes_t(const float* x, long long ldx, int rows, int cols, unsigned short* out, int ldp, long long plane,
                        void* stream);
 /* x [rows][cols] fp32 -> fp16-pair planes [2][rows][ldp] (hi, lo' as above; columns cols..ldp-1 zero): operands of form-1 products */
-int vbg_split_planes_pair(const float* x, long long ldx, int rows, int cols, unsigned short* out, int ldp, long long plane, void* stream);
+int vbg_split_planes_pair(const float* x, long long ldx, int rows, int cols, unsigned short* out, int ldp, long long plane,
+                          const unsigned* amax, float* colsum_accum, void* stream);
+/* amax (optional): x is multiplied by the power of two that brings the slot's value to [2^13, 2^14) first (gradient operands);
+ * colsum_accum (optional): colsum_accum[c] += sum_r x[r][c] of the unscaled values, as in vbg_split_planes */
 /* many matrices of one fp32 buffer in one launch: tbl_dev = device int64 [njobs][6] = {source offset (elements), rows, cols,
  * destination offset (elements), ldp (multiple of 32, >= rows), index of the job's first 64 x 64 tile}; job j writes the planes of
  * its matrix TRANSPOSED ([3][cols][ldp]) at dst + offset, plane stride `plane` for all jobs.  (The W^T planes of every weight of a
  * flat parameter buffer, refreshed once per optimizer step.) */
 int vbg_split_planes_t_batched(const float* src, unsigned short* dst, const long long* tbl_dev, int njobs, int total_tiles,
                                long long plane, void* stream);
+/* the same as fp16-pair planes [2][cols][ldp] per job (the W^T operands of the form-1 data-gradient products) */
+int vbg_split_planes_pair_t_batched(const float* src, unsigned short* dst, const long long* tbl_dev, int njobs, int total_tiles,
+                                    long long plane, void* stream);
 
 /* ------------------------------------------------------------------------------------------
  * Fused self-attention on packed variable-length sequences (head width 64), fp32-grade on the bf16 matrix cores; no [L, L]

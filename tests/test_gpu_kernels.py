@@ -1172,6 +1172,54 @@ def test_plane_gemm_pair_form_vs_fp64(tile):
     assert torch.equal(pl.buf, ops.split_planes(y).buf) and torch.equal(pq.buf, ops.split_planes_pair(y).buf)
 
 
+def test_plane_gemm_pair_form_gradients_vs_fp64():
+    """FORM 1 with a GRADIENT as the A operand: planes written scaled by the power of two of the tensor's largest magnitude (amax slot),
+    products scaled back -- the NT data gradient dX = dY W and the TN weight gradients dW = dY^T X, single and grouped, at gradient
+    magnitudes 2^-30 ... 2^20; the column sums of dY (bias gradient) ride on the scaled split unscaled."""
+    from vbg import ops
+    dev = torch.device("cuda")
+    g = torch.Generator().manual_seed(31)
+    M, N, K = 1000, 772 - 4, 96 * 3                      # tokens, out features, in features
+    x = (torch.randn(M, K, generator=g) * torch.exp2(torch.randint(-4, 4, (M, 1), generator=g).float())).to(dev)
+    w = (torch.randn(N, K, generator=g) / K ** 0.5).to(dev)
+    for sc in (1.0, 2.0 ** -30, 2.0 ** -21, 2.0 ** 20):
+        dy = (torch.randn(M, N, generator=g) * torch.exp2(torch.randint(-6, 6, (M, 1), generator=g).float())).to(dev) * sc
+        slot = ops.amax(dy)
+        cs = torch.zeros((N,), device=dev)
+        qdy = ops.split_planes_pair(dy, amax_slot_=slot, colsum_out=cs)
+        assert torch.allclose(cs.double() / sc, dy.double().sum(0) / sc, rtol=1e-5, atol=1e-4 * M ** 0.5)
+        # the stored planes are those of dy * 2^e with amax * 2^e in [2^13, 2^14)
+        e = 13 - int(torch.floor(torch.log2(dy.abs().max())).item())
+        assert torch.equal(qdy.buf[0, :, :N].view(torch.float16), (dy * 2.0 ** e).half())
+        # NT data gradient: dx = dy @ w   (B operand = planes of w^T)
+        qwt = ops.split_planes_pair(w.t().contiguous())
+        dx = torch.empty(M, K, device=dev)
+        ops.plane_gemm(qdy, qwt, dx, tile=128129, form=1, a_amax=slot)
+        ref = dy.double() @ w.double()
+        scale = float((dy.double().abs() @ w.double().abs()).max())
+        assert float((dx.double() - ref).abs().max()) <= 2e-6 * scale, sc
+        # ... with the largest magnitude of the stored values as a by-product
+        cam = ops.amax_slot(dev)
+        ops.plane_gemm(qdy, qwt, dx, tile=128129, form=1, a_amax=slot, c_amax=cam)
+        assert int(cam.max().item()) == int(dx.abs().max().view(torch.int32).item())
+        # TN weight gradient: dw = dy^T @ x, both tiles, accumulate, single and grouped (three problems, their own slots)
+        qx = ops.split_planes_pair(x)
+        refw = dy.double().t() @ x.double()
+        scw = float((dy.double().abs().t() @ x.double().abs()).max())
+        for tile in (128129, 256128):
+            dw = torch.full((N, K), sc, device=dev)
+            ops.plane_gemm(qdy, qx, dw, trans=True, accumulate=True, tile=tile, form=1, a_amax=slot)
+            assert float((dw.double() - sc - refw).abs().max()) <= 2e-6 * scw, (sc, tile)
+        dy2 = dy[:, :256].contiguous() * 4
+        slot2 = ops.amax(dy2)
+        qdy2 = ops.split_planes_pair(dy2, amax_slot_=slot2)
+        outs = [torch.zeros(N, K, device=dev), torch.zeros(256, K, device=dev), torch.zeros(N, K, device=dev)]
+        ops.plane_gemm_grouped([(qdy, qx, outs[0]), (qdy2, qx, outs[1]), (qdy, qx, outs[2])], trans=True, accumulate=True, form=1,
+                               a_amax=[slot, slot2, slot])
+        assert float((outs[0].double() - refw).abs().max()) <= 2e-6 * scw and torch.equal(outs[0], outs[2])
+        assert float((outs[1].double() - 4 * refw[:256]).abs().max()) <= 8e-6 * scw
+
+
 def test_plane_gemm_tn_and_grouped_vs_fp64():
     """weight-gradient form: dW = dY^T X straight from the untransposed planes (LDS transpose reads), ragged sizes, reduction
     lengths that are not a multiple of the k-tile, and the grouped launch"""

@@ -62,7 +62,7 @@ __global__ __launch_bounds__(WGM * WGN * 64) void plane_gemm_kernel(const vbg_pl
     constexpr int NW = WGM * WGN, NT = NW * 64;
     constexpr int BK = 32;
     constexpr int NPL = FORM ? 2 : 3;                          // planes per operand
-    static_assert(FORM == 0 || (!TRANS && PP && NW == 8), "the fp16-pair form exists for the 8-wave ping-pong NT tiles");
+    static_assert(FORM == 0 || (NW == 8 && (TRANS || PP)), "the fp16-pair form exists for the 8-wave tiles (NT: ping-pong loop)");
     constexpr int WM = BM / WGM, WN = BN / WGN, TM = WM / 32, TN = WN / 32;
     constexpr int PA = BM * 64, PB = BN * 64;                  // bytes of one plane of a stage (64 B per row)
     constexpr int STAGE = NPL * (PA + PB);
@@ -81,6 +81,7 @@ __global__ __launch_bounds__(WGM * WGN * 64) void plane_gemm_kernel(const vbg_pl
     float* pC = p.C;
     int M = p.M, N = p.N;
     long long a_plane = p.a_plane, b_plane = p.b_plane, lda = p.lda, ldb = p.ldb, ldc_ = p.ldc;
+    const unsigned* a_amax = p.a_amax;               // (FORM 1) the A operand was written scaled by the power of two of this slot
     // ---- XCD-aware block -> tile map (same scheme as gemm.hip): workgroup b runs on XCD b % 8; XCD k owns the k-th contiguous
     //      eighth of the tile sequence, and the sequence walks each problem's tile grid in bands of 8 row tiles ------------------
     constexpr unsigned XCDS = 8, XCD_GROUP = 8;
@@ -99,6 +100,7 @@ __global__ __launch_bounds__(WGM * WGN * 64) void plane_gemm_kernel(const vbg_pl
         pA = p.grp[g].A; pB = p.grp[g].B; pC = p.grp[g].C;
         M = p.grp[g].M; N = p.grp[g].N;
         a_plane = p.grp[g].a_plane; b_plane = p.grp[g].b_plane; lda = p.grp[g].lda; ldb = p.grp[g].ldb; ldc_ = p.grp[g].ldc;
+        a_amax = p.grp[g].a_amax;
         gx = p.grp[g].tiles_m; gy = p.grp[g].tiles_n;
     }
     const unsigned band = XCD_GROUP * gy, bid = rem / band, first = bid * XCD_GROUP;
@@ -158,7 +160,7 @@ __global__ __launch_bounds__(WGM * WGN * 64) void plane_gemm_kernel(const vbg_pl
             const int lrow = lane / PPRB, piece = lane % PPRB, row = rb * RPUB + lrow;
             const int lcol = (((((piece >> 2) ^ (row & 3))) << 2) + (piece & 3)) * 8;
             bvo[i] = (n0 + lcol < npad) ? (unsigned)(((long long)row * ldb + lcol) * 2) : PG_INVALID;
-            blds[i] = __builtin_amdgcn_readfirstlane(3 * PA + (u / UPB) * PB + rb * 1024);
+            blds[i] = __builtin_amdgcn_readfirstlane(NPL * PA + (u / UPB) * PB + rb * 1024);
         }
         abase = pA + (long long)kt0 * BK * lda + m0;
         bbase = pB + (long long)kt0 * BK * ldb + n0;
@@ -246,9 +248,9 @@ __global__ __launch_bounds__(WGM * WGN * 64) void plane_gemm_kernel(const vbg_pl
     auto read_frags = [&](int stage, int fo, pg_u32x4 (&fa)[NPL][TM], pg_u32x4 (&fb)[NPL][TN]) {
         if constexpr (TRANS) {
             typedef __attribute__((address_space(3))) unsigned char* lds_bytes;
-            lds_bytes as = (lds_bytes)(smem + stage * STAGE + fo * RSA), bs = (lds_bytes)(smem + stage * STAGE + 3 * PA + fo * RSB);
+            lds_bytes as = (lds_bytes)(smem + stage * STAGE + fo * RSA), bs = (lds_bytes)(smem + stage * STAGE + NPL * PA + fo * RSB);
 #pragma unroll
-            for (int q = 0; q < 3; ++q) {
+            for (int q = 0; q < NPL; ++q) {
 #pragma unroll
                 for (int i = 0; i < TM; ++i) {
                     const pg_v4s lo = __builtin_amdgcn_ds_read_tr16_b64_v4i16((pg_lds_v4s)(as + q * PA + ta[i]));
@@ -310,7 +312,7 @@ __global__ __launch_bounds__(WGM * WGN * 64) void plane_gemm_kernel(const vbg_pl
     // is read -- no bubble after the barrier.  NST = 2 (the 8-wave tile, 2 waves per SIMD cover each other): tile t+1 travels
     // during tile t, barrier at the end of the iteration.
     constexpr int NIW = NIA + NIB;
-    constexpr int NMMA = (FORM ? 3 : 6) * TM * TN, NRD = (TRANS ? 6 : NPL) * (TM + TN);
+    constexpr int NMMA = (FORM ? 3 : 6) * TM * TN, NRD = (TRANS ? 2 * NPL : NPL) * (TM + TN);
     // ---- ping-pong schedule of the 8-wave NT tiles --------------------------------------------------------------------------
     // Waves w and w + 4 of a workgroup share a SIMD (measured: tools/probes/pingpong_gemm_probe.hip prints HW_ID).  In lockstep both
     // issue their DMA, read their fragments and then want the matrix pipe at the same moments: matrix-pipe busy 0.40-0.47 of a full
@@ -440,7 +442,10 @@ __global__ __launch_bounds__(WGM * WGN * 64) void plane_gemm_kernel(const vbg_pl
     const bool add_bias = (bias != nullptr) && (split == 0);
     const int accumulate = p.accumulate, epi = p.epi;
     const bool atomic = accumulate && p.splitk > 1;
-    const float alpha = p.alpha;
+    // a gradient operand of the fp16-pair form was multiplied by a power of two when its planes were written (the power that brings
+    // the tensor's largest magnitude to [2^13, 2^14), vbg_split_planes_pair): the product is scaled back here -- exact
+    float alpha = p.alpha;
+    if constexpr (FORM) { if (a_amax) alpha *= vbg_pow2_scale(vbg_amax_read(a_amax)).y; }
     const long long ldc = ldc_;
     float* const C = pC;
     float* const C2 = p.C2;
@@ -458,6 +463,7 @@ __global__ __launch_bounds__(WGM * WGN * 64) void plane_gemm_kernel(const vbg_pl
     // optional bf16 planes of the stored value (the A operand of the next product): [3][M][ldp], K-contiguous = along n here
     unsigned short* const Cp = p.Cp;
     unsigned short* const Cq = p.Cq;                 // optional fp16-pair planes of the stored value [2][M][ldq]
+    float vmax = 0.f;                                // max |stored value| of this thread (p.c_amax)
 #pragma unroll
     for (int q = 0; q < BM * QN / NT; ++q) {
         const int idx = tid + q * NT;
@@ -484,6 +490,7 @@ __global__ __launch_bounds__(WGM * WGN * 64) void plane_gemm_kernel(const vbg_pl
             v.x *= gelu_erf_grad(hv.x); v.y *= gelu_erf_grad(hv.y); v.z *= gelu_erf_grad(hv.z); v.w *= gelu_erf_grad(hv.w);
         }
         if (C) *reinterpret_cast<float4*>(cp) = v;
+        vmax = fmaxf(fmaxf(vmax, fmaxf(fabsf(v.x), fabsf(v.y))), fmaxf(fabsf(v.z), fabsf(v.w)));
         if (p.colsum) *reinterpret_cast<float4*>(&Ct[row * CTS + c]) = v;      // (the stored value goes back for the column sums below)
         if (epi == VBG_EPI_GELU_DUAL) {
             v = make_float4(gelu_erf(v.x), gelu_erf(v.y), gelu_erf(v.z), gelu_erf(v.w));
@@ -513,6 +520,12 @@ __global__ __launch_bounds__(WGM * WGN * 64) void plane_gemm_kernel(const vbg_pl
             *reinterpret_cast<uint2*>(o) = h;
             *reinterpret_cast<uint2*>(o + p.q_plane) = l;
         }
+    }
+    // optional: the largest magnitude this launch stored (the scale of the fp16-pair planes a split pass makes of C next)
+    if (p.c_amax) {                                   // (uniform)
+        __syncthreads();
+        vbg_amax_publish(vmax, p.c_amax, Ct);
+        __syncthreads();
     }
     // optional column sums of the stored values (the bias gradient of the layer whose dL/d(output) this product produces): one thread
     // per column of the staged tile, one atomic per column and row tile (rows past M hold zeros: their operand rows were read as zeros)
@@ -1072,8 +1085,16 @@ __global__ __launch_bounds__(256) void split_planes_kernel(const float* __restri
 }
 
 // x [rows][cols] fp32 (row stride ldx) -> fp16-pair planes [2][rows][ldp], columns cols..ldp-1 zero.  One thread = 8 columns.
+// amax != nullptr: x is multiplied by the power of two that brings the slot's value (the tensor's largest magnitude) to [2^13, 2^14) --
+// a gradient operand; the consumer scales its product back (vbg_plane_gemm_desc.a_amax).  colsum as in split_planes_kernel (of the
+// UNSCALED values).
 __global__ __launch_bounds__(256) void split_planes_pair_kernel(const float* __restrict__ x, long long ldx, int rows, int cols,
-                                                                 unsigned short* __restrict__ out, int ldp, long long plane) {
+                                                                 unsigned short* __restrict__ out, int ldp, long long plane,
+                                                                 const unsigned* amax, float* colsum) {
+    extern __shared__ float sh_cols[];
+    const float sc = amax ? vbg_pow2_scale(vbg_amax_read(amax)).x : 1.f;
+    float cs[8] = {0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f};
+    const long long i0 = (long long)blockIdx.x * blockDim.x + threadIdx.x;
     const int cpr = ldp / 8;
     const long long n = (long long)rows * cpr;
     const long long stride = (long long)gridDim.x * blockDim.x;
@@ -1089,11 +1110,27 @@ __global__ __launch_bounds__(256) void split_planes_pair_kernel(const float* __r
 #pragma unroll
             for (int t = 0; t < 8; ++t) e[t] = (c + t < cols) ? x[(long long)r * ldx + c + t] : 0.f;
         }
+#pragma unroll
+        for (int t = 0; t < 8; ++t) { cs[t] += e[t]; e[t] *= sc; }
         uint4 h, l;
         pg_split2(e[0], e[1], h.x, l.x); pg_split2(e[2], e[3], h.y, l.y); pg_split2(e[4], e[5], h.z, l.z); pg_split2(e[6], e[7], h.w, l.w);
         unsigned short* o = out + (long long)r * ldp + c;
         *reinterpret_cast<uint4*>(o) = h;
         *reinterpret_cast<uint4*>(o + plane) = l;
+    }
+    if (colsum) {                                        // (uniform; the host launched a thread count that keeps a thread on ONE chunk)
+        for (int c = threadIdx.x; c < ldp; c += blockDim.x) sh_cols[c] = 0.f;
+        __syncthreads();
+        if (i0 < n) {
+            const int c = (int)(i0 % cpr) * 8;
+#pragma unroll
+            for (int t = 0; t < 8; ++t) atomicAdd(&sh_cols[c + t], cs[t]);
+        }
+        __syncthreads();
+        for (int c = threadIdx.x; c < cols; c += blockDim.x) {
+            const float v = sh_cols[c];
+            if (v != 0.f) unsafeAtomicAdd(colsum + c, v);
+        }
     }
 }
 
@@ -1143,6 +1180,7 @@ __global__ __launch_bounds__(256) void split_planes_t_kernel(const float* __rest
 // dst + doff_j (plane stride `plane` elements for every job: one flat plane buffer), tiles of 64 x 64; tbl = int64 [njobs][6]:
 // soff, rows, cols, doff, ldp, first tile.  The weights of a whole flat parameter buffer in ONE launch (their W^T planes are the
 // B operands of the data-gradient products), refreshed once per optimizer step.
+template <bool PAIR>
 __global__ __launch_bounds__(256) void split_planes_t_batched_kernel(const float* __restrict__ src, unsigned short* __restrict__ dst,
                                                                       const long long* __restrict__ tbl, int njobs, long long plane) {
     __shared__ float t[64][65];
@@ -1173,10 +1211,18 @@ __global__ __launch_bounds__(256) void split_planes_t_batched_kernel(const float
     for (int i = 0; i < 2; ++i) {
         const int f = tid + i * 256, c = f / 8, rg = (f % 8) * 8;
         if (c0 + c >= cols || r0 + rg >= ldp) continue;
+        unsigned short* o = out + (long long)(c0 + c) * ldp + r0 + rg;
+        if constexpr (PAIR) {                          // fp16-pair planes [2][cols][ldp] (the W^T operands of the form-1 data gradients)
+            uint4 h, l;
+            pg_split2(t[rg + 0][c], t[rg + 1][c], h.x, l.x); pg_split2(t[rg + 2][c], t[rg + 3][c], h.y, l.y);
+            pg_split2(t[rg + 4][c], t[rg + 5][c], h.z, l.z); pg_split2(t[rg + 6][c], t[rg + 7][c], h.w, l.w);
+            *reinterpret_cast<uint4*>(o) = h;
+            *reinterpret_cast<uint4*>(o + plane) = l;
+            continue;
+        }
         unsigned short h[8], m[8], l[8];
 #pragma unroll
         for (int q = 0; q < 8; ++q) pg_split3(t[rg + q][c], h[q], m[q], l[q]);
-        unsigned short* o = out + (long long)(c0 + c) * ldp + r0 + rg;
         auto pack = [](const unsigned short* s) {
             return make_uint4(s[0] | ((unsigned)s[1] << 16), s[2] | ((unsigned)s[3] << 16), s[4] | ((unsigned)s[5] << 16), s[6] | ((unsigned)s[7] << 16));
         };
@@ -1192,12 +1238,17 @@ static bool pg_pingpong() {
     return on;
 }
 
-template <int BM, int BN, int WGM, int WGN, int NST>
+template <int BM, int BN, int WGM, int WGN, int NST, bool TRANS = false>
 static void pg_launch_pair(const vbg_plane_gemm_desc& d, hipStream_t s, hipEvent_t e0, hipEvent_t e1) {
     dim3 g(cdiv(d.M, BM), cdiv(d.N, BN), 1);
+    if (d.ngroups > 0) {
+        int total = 0;
+        for (int i = 0; i < d.ngroups; ++i) total += d.grp[i].tiles_m * d.grp[i].tiles_n;
+        g = dim3(total, 1, 1);
+    }
     (void)hipGetLastError();
-    if (e0 && e1) hipExtLaunchKernelGGL((plane_gemm_kernel<BM, BN, WGM, WGN, NST, false, true, 1>), g, dim3(WGM * WGN * 64), 0, s, e0, e1, 0, d);
-    else hipLaunchKernelGGL((plane_gemm_kernel<BM, BN, WGM, WGN, NST, false, true, 1>), g, dim3(WGM * WGN * 64), 0, s, d);
+    if (e0 && e1) hipExtLaunchKernelGGL((plane_gemm_kernel<BM, BN, WGM, WGN, NST, TRANS, true, 1>), g, dim3(WGM * WGN * 64), 0, s, e0, e1, 0, d);
+    else hipLaunchKernelGGL((plane_gemm_kernel<BM, BN, WGM, WGN, NST, TRANS, true, 1>), g, dim3(WGM * WGN * 64), 0, s, d);
 }
 
 template <int BM, int BN, int WGM, int WGN, int NST, bool TRANS = false>
@@ -1265,8 +1316,13 @@ static int plane_gemm_dispatch(const vbg_plane_gemm_desc* desc, void* stream, vo
     hipStream_t s = (hipStream_t)stream;
     int tile = d.tile;
     if (d.form == 1) {
-        // two fp16 planes per operand (csrc/gemm_planes.hip FORM 1): the 8-wave NT tiles only
-        VBG_CHECK_ARG(!d.trans && d.ngroups == 0 && d.splitk == 1 && !(d.sk_ws && d.sk_cnt));
+        // two fp16 planes per operand (csrc/gemm_planes.hip FORM 1): the 8-wave tiles only
+        VBG_CHECK_ARG(d.splitk == 1 && !(d.sk_ws && d.sk_cnt) && (d.ngroups == 0 || d.trans));
+        if (d.trans) {
+            if (tile == 256128) pg_launch_pair<256, 128, 4, 2, 2, true>(d, s, (hipEvent_t)e0, (hipEvent_t)e1);
+            else pg_launch_pair<128, 128, 4, 2, 3, true>(d, s, (hipEvent_t)e0, (hipEvent_t)e1);
+            VBG_LAUNCH_RET();
+        }
         if (tile == 256128) pg_launch_pair<256, 128, 4, 2, 2>(d, s, (hipEvent_t)e0, (hipEvent_t)e1);
         else if (tile == 128130) pg_launch_pair<128, 128, 2, 4, 3>(d, s, (hipEvent_t)e0, (hipEvent_t)e1);
         else if (tile == 128129 || tile == 0) pg_launch_pair<128, 128, 4, 2, 3>(d, s, (hipEvent_t)e0, (hipEvent_t)e1);
@@ -1361,13 +1417,29 @@ extern "C" int vbg_split_planes(const float* x, long long ldx, int rows, int col
 }
 
 extern "C" int vbg_split_planes_pair(const float* x, long long ldx, int rows, int cols, unsigned short* out, int ldp, long long plane,
-                                     void* stream) {
+                                     const unsigned* amax, float* colsum_accum, void* stream) {
     VBG_CHECK_ARG(rows >= 0 && cols >= 0 && ldp % 32 == 0 && ldp >= cols && plane >= (long long)rows * ldp && plane % 8 == 0);
     if (rows == 0 || cols == 0) return VBG_OK;
     VBG_CHECK_ARG(x && out && ((uintptr_t)out & 15) == 0);
-    long long g = ((long long)rows * (ldp / 8) + 255) / 256;
-    if (g > 256 * 16) g = 256 * 16;
-    VBG_LAUNCH(split_planes_pair_kernel, dim3((unsigned)g), dim3(256), 0, (hipStream_t)stream, x, ldx, rows, cols, out, ldp, plane);
+    const long long n = (long long)rows * (ldp / 8);
+    long long g = (n + 255) / 256;
+    size_t lds = 0;
+    if (colsum_accum) {          // thread count = a multiple of the chunks per row (a thread keeps one 8-column chunk), <= ~288 blocks
+        VBG_CHECK_ARG(ldp * 4 <= 64 * 1024);
+        const long long cpr = ldp / 8;
+        long long a = cpr, b = 256;
+        while (b) { const long long t = a % b; a = b; b = t; }
+        const long long unit = cpr / a;
+        long long k = 288 / unit;
+        if (k < 1) k = 1;
+        const long long need = (g + unit - 1) / unit;
+        if (k > need) k = need;
+        g = k * unit;
+        lds = (size_t)ldp * 4;
+    } else if (g > 256 * 16) {
+        g = 256 * 16;
+    }
+    VBG_LAUNCH(split_planes_pair_kernel, dim3((unsigned)g), dim3(256), lds, (hipStream_t)stream, x, ldx, rows, cols, out, ldp, plane, amax, colsum_accum);
     VBG_LAUNCH_RET();
 }
 
@@ -1385,6 +1457,15 @@ extern "C" int vbg_split_planes_t_batched(const float* src, unsigned short* dst,
     VBG_CHECK_ARG(njobs >= 0 && total_tiles >= 0);
     if (njobs == 0 || total_tiles == 0) return VBG_OK;
     VBG_CHECK_ARG(src && dst && tbl_dev && ((uintptr_t)dst & 15) == 0 && plane % 8 == 0);
-    VBG_LAUNCH(split_planes_t_batched_kernel, dim3(total_tiles), dim3(256), 0, (hipStream_t)stream, src, dst, tbl_dev, njobs, plane);
+    VBG_LAUNCH(split_planes_t_batched_kernel<false>, dim3(total_tiles), dim3(256), 0, (hipStream_t)stream, src, dst, tbl_dev, njobs, plane);
+    VBG_LAUNCH_RET();
+}
+
+extern "C" int vbg_split_planes_pair_t_batched(const float* src, unsigned short* dst, const long long* tbl_dev, int njobs, int total_tiles,
+                                               long long plane, void* stream) {
+    VBG_CHECK_ARG(njobs >= 0 && total_tiles >= 0);
+    if (njobs == 0 || total_tiles == 0) return VBG_OK;
+    VBG_CHECK_ARG(src && dst && tbl_dev && ((uintptr_t)dst & 15) == 0 && plane % 8 == 0);
+    VBG_LAUNCH(split_planes_t_batched_kernel<true>, dim3(total_tiles), dim3(256), 0, (hipStream_t)stream, src, dst, tbl_dev, njobs, plane);
     VBG_LAUNCH_RET();
 }

@@ -80,3 +80,39 @@ __device__ __forceinline__ float gelu_erf_grad(float x) {
 }
 
 }  // namespace vbg
+
+// ---- amax slots (include/vbg.h VBG_AMAX_WORDS / VBG_AMAX_STRIDE) and the power-of-two scale derived from one ------------------------
+#if defined(__HIPCC__)
+#ifndef VBG_AMAX_WORDS
+#define VBG_AMAX_WORDS 64
+#define VBG_AMAX_STRIDE 32
+#endif
+// the value of an amax slot: the max over its 64 words, uniform across the wave (every wave of the caller may call it)
+__device__ __forceinline__ unsigned vbg_amax_read(const unsigned* slot) {
+    unsigned v = slot[(threadIdx.x & (VBG_AMAX_WORDS - 1)) * VBG_AMAX_STRIDE];
+#pragma unroll
+    for (int o = 32; o > 0; o >>= 1) v = max(v, (unsigned)__shfl_xor((int)v, o, 64));
+    return __builtin_amdgcn_readfirstlane(v);
+}
+// power-of-two scale that brings a tensor whose largest magnitude has the bit pattern `amax_bits` to [2^13, 2^14): (scale, 1 / scale).
+// Exact in fp32; amax = 0 or outside 2^-100 ... 2^113: no scaling.
+__device__ __forceinline__ float2 vbg_pow2_scale(unsigned amax_bits) {
+    const int e = (int)((amax_bits >> 23) & 0xffu);            // biased exponent of amax
+    if (e < 27 || e > 240) return make_float2(1.f, 1.f);
+    return make_float2(__uint_as_float((unsigned)(267 - e) << 23), __uint_as_float((unsigned)(e - 13) << 23));
+}
+// block-wide max of non-negative floats into an amax slot: one atomic per block at most, on the block's own word (L2 line)
+__device__ __forceinline__ void vbg_amax_publish(float mx, unsigned* amax, float* sh16) {
+#pragma unroll
+    for (int o = 32; o > 0; o >>= 1) mx = fmaxf(mx, __shfl_xor(mx, o, 64));
+    if ((threadIdx.x & 63) == 0) sh16[threadIdx.x >> 6] = mx;
+    __syncthreads();
+    if (threadIdx.x == 0) {
+        for (int w = 1; w < (int)(blockDim.x >> 6); ++w) mx = fmaxf(mx, sh16[w]);
+        const unsigned bits = __float_as_uint(mx);
+        const unsigned lin = blockIdx.x + gridDim.x * (blockIdx.y + gridDim.y * blockIdx.z);
+        unsigned* word = amax + (lin & (VBG_AMAX_WORDS - 1)) * VBG_AMAX_STRIDE;
+        if (bits > __hip_atomic_load(word, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT)) atomicMax(word, bits);
+    }
+}
+#endif

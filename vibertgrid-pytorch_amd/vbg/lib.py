@@ -37,7 +37,7 @@ class GemmDesc(C.Structure):
 
 class PlaneGroup(C.Structure):
     _fields_ = [("A", c_vp), ("B", c_vp), ("C", c_vp), ("a_plane", c_ll), ("lda", c_ll), ("b_plane", c_ll), ("ldb", c_ll), ("ldc", c_ll),
-                ("M", c_int), ("N", c_int), ("tiles_m", c_int), ("tiles_n", c_int)]
+                ("M", c_int), ("N", c_int), ("tiles_m", c_int), ("tiles_n", c_int), ("a_amax", c_vp)]
 
 
 class PlaneGemmDesc(C.Structure):
@@ -49,7 +49,7 @@ class PlaneGemmDesc(C.Structure):
                 ("epi", c_int), ("alpha", c_f), ("accumulate", c_int), ("splitk", c_int), ("tile", c_int), ("trans", c_int),
                 ("ngroups", c_int), ("grp", PlaneGroup * 4),
                 ("sk_ws", c_vp), ("sk_cnt", c_vp), ("sk_blocks", c_int), ("sk_full", c_int), ("sk_tiles_m", c_int), ("sk_tiles_n", c_int),
-                ("colsum", c_vp), ("form", c_int), ("Cq", c_vp), ("q_plane", c_ll), ("ldq", c_ll)]
+                ("colsum", c_vp), ("form", c_int), ("Cq", c_vp), ("q_plane", c_ll), ("ldq", c_ll), ("a_amax", c_vp), ("c_amax", c_vp)]
 
 
 class AttnDesc(C.Structure):
@@ -77,9 +77,10 @@ SIGNATURES = {
     "vbg_plane_gemm": (c_int, [C.POINTER(PlaneGemmDesc), c_vp]),
     "vbg_plane_gemm_timed": (c_int, [C.POINTER(PlaneGemmDesc), c_vp, c_vp, c_vp]),
     "vbg_split_planes": (c_int, [c_vp, c_ll, c_int, c_int, c_vp, c_int, c_ll, c_int, c_vp, c_vp]),
-    "vbg_split_planes_pair": (c_int, [c_vp, c_ll, c_int, c_int, c_vp, c_int, c_ll, c_vp]),
+    "vbg_split_planes_pair": (c_int, [c_vp, c_ll, c_int, c_int, c_vp, c_int, c_ll, c_vp, c_vp, c_vp]),
     "vbg_split_planes_t": (c_int, [c_vp, c_ll, c_int, c_int, c_vp, c_int, c_ll, c_vp]),
     "vbg_split_planes_t_batched": (c_int, [c_vp, c_vp, c_vp, c_int, c_int, c_ll, c_vp]),
+    "vbg_split_planes_pair_t_batched": (c_int, [c_vp, c_vp, c_vp, c_int, c_int, c_ll, c_vp]),
     "vbg_attn": (c_int, [C.POINTER(AttnDesc), c_vp]),
     "vbg_attn_drop_thr16": (C.c_uint, [c_f]),
     "vbg_attn_mask": (c_int, [c_vp, c_vp, c_int, c_int, c_int, c_f, c_ull, c_ull, c_vp, c_vp, c_vp]),

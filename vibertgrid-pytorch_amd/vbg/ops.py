@@ -193,12 +193,13 @@ def pair_empty(rows, cols, device):
     return Planes(torch.empty((2, rows, ld), device=device, dtype=torch.int16), int(rows), int(cols), ld)
 
 
-def split_planes_pair(x, out=None):
-    """x [rows, cols] fp32 -> fp16-pair Planes (operands of plane_gemm(form=1))"""
+def split_planes_pair(x, out=None, amax_slot_=None, colsum_out=None):
+    """x [rows, cols] fp32 -> fp16-pair Planes (operands of plane_gemm(form=1)).  amax_slot_: scale x by the power of two of that slot
+    first (a gradient operand; pass the same slot as plane_gemm(a_amax=...)); colsum_out [cols]: += column sums of x (bias gradients)"""
     assert x.dim() == 2 and x.stride(1) == 1 and x.dtype == f32
     rows, cols = x.shape
     o = out if out is not None else pair_empty(rows, cols, x.device)
-    check(lib.vbg_split_planes_pair(P(x), x.stride(0), rows, cols, P(o.buf), o.ld, o.plane, _stream()), "vbg_split_planes_pair")
+    check(lib.vbg_split_planes_pair(P(x), x.stride(0), rows, cols, P(o.buf), o.ld, o.plane, P(amax_slot_), P(colsum_out), _stream()), "vbg_split_planes_pair")
     return o
 
 
@@ -234,6 +235,12 @@ def split_planes_t_batched(src_flat, dst_planes, tbl_dev, njobs, total_tiles):
           "vbg_split_planes_t_batched")
 
 
+def split_planes_pair_t_batched(src_flat, dst_planes, tbl_dev, njobs, total_tiles):
+    """the same as fp16-pair planes (W^T operands of the form-1 data gradients)"""
+    check(lib.vbg_split_planes_pair_t_batched(P(src_flat), P(dst_planes), P(tbl_dev), int(njobs), int(total_tiles), dst_planes.stride(0), _stream()),
+          "vbg_split_planes_pair_t_batched")
+
+
 def split_planes_t(x, out=None):
     """x [rows, cols] fp32 -> Planes of x^T ([cols, rows]: the reduction index becomes x's row index)"""
     assert x.dim() == 2 and x.stride(1) == 1 and x.dtype == f32
@@ -244,7 +251,7 @@ def split_planes_t(x, out=None):
 
 
 def plane_gemm(a: Planes, b: Planes, out=None, *, bias=None, epi=EPI_NONE, C2=None, accumulate=False, splitk=1, alpha=1.0, tile=0,
-               out_planes=None, ldc=None, trans=False, colsum_out=None, form=0, out_pair=None):
+               out_planes=None, ldc=None, trans=False, colsum_out=None, form=0, out_pair=None, a_amax=None, c_amax=None):
     """out[M, N] (+)= alpha * a[M, K] b[N, K]^T (+ bias).  out_planes: Planes [M, N] that receive the split of the stored value.
     trans: out[Ma, Nb] (+)= alpha * a[K, Ma]^T b[K, Nb] (the operands' ROWS are the reduction index: weight gradients)."""
     d = PlaneGemmDesc()
@@ -265,11 +272,14 @@ def plane_gemm(a: Planes, b: Planes, out=None, *, bias=None, epi=EPI_NONE, C2=No
     if out_planes is not None:
         d.Cp, d.c_plane, d.ldp = out_planes.buf.data_ptr(), out_planes.plane, out_planes.ld
     d.epi, d.alpha, d.accumulate, d.splitk, d.tile = epi, float(alpha), int(bool(accumulate)), int(splitk), int(tile)
-    if form:                               # a, b: fp16-pair planes [2][rows][ld]
-        assert a.buf.shape[0] == 2 and b.buf.shape[0] == 2 and not trans
+    if form:                               # a, b: fp16-pair planes [2][rows][ld]; a_amax: the slot a's planes were scaled by
+        assert a.buf.shape[0] == 2 and b.buf.shape[0] == 2
         d.form = 1
+        d.a_amax = None if a_amax is None else a_amax.data_ptr()
     else:
         assert a.buf.shape[0] == 3 and b.buf.shape[0] == 3
+    if c_amax is not None:                 # amax slot that receives max |stored value|
+        d.c_amax = c_amax.data_ptr()
     if out_pair is not None:               # the stored value also as fp16-pair planes
         d.Cq, d.q_plane, d.ldq = out_pair.buf.data_ptr(), out_pair.plane, out_pair.ld
     if colsum_out is not None:             # += column sums of the stored values (a bias gradient)
@@ -308,9 +318,10 @@ def _sk_workspace(device):
     return w
 
 
-def plane_gemm_grouped(problems, *, trans=True, accumulate=True, tile=0, alpha=1.0):
+def plane_gemm_grouped(problems, *, trans=True, accumulate=True, tile=0, alpha=1.0, form=0, a_amax=None):
     """several independent plane products of ONE reduction length in one launch: problems = [(a: Planes, b: Planes, out), ...]
-    (trans: out[a.cols, b.cols] (+)= a^T b, the weight gradients of a layer)"""
+    (trans: out[a.cols, b.cols] (+)= a^T b, the weight gradients of a layer).  form=1: fp16-pair planes, a_amax = [slot or None per
+    problem] (the scale of each problem's A operand)"""
     assert 1 <= len(problems) <= 4
     if trans and tile == 0:
         # 256 x 128 output tiles move a third fewer operand bytes per product (csrc/gemm_planes.hip: the kernels are bound by what a CU
@@ -326,6 +337,9 @@ def plane_gemm_grouped(problems, *, trans=True, accumulate=True, tile=0, alpha=1
         g.A, g.a_plane, g.lda = a.buf.data_ptr(), a.plane, a.ld
         g.B, g.b_plane, g.ldb = b.buf.data_ptr(), b.plane, b.ld
         g.C, g.ldc = out.data_ptr(), out.stride(-2)
+        if form:
+            assert a.buf.shape[0] == 2 and b.buf.shape[0] == 2
+            g.a_amax = None if (a_amax is None or a_amax[i] is None) else a_amax[i].data_ptr()
         if trans:
             assert a.rows == b.rows
             g.M, g.N, kk = a.cols, b.cols, a.rows
@@ -335,6 +349,7 @@ def plane_gemm_grouped(problems, *, trans=True, accumulate=True, tile=0, alpha=1
         assert k is None or k == kk, "grouped products share the reduction length"
         k = kk
     d.K = k
+    d.form = int(bool(form))
     check(lib.vbg_plane_gemm(C.byref(d), _stream()), "vbg_plane_gemm (grouped)")
 
 
@@ -383,7 +398,7 @@ def weight_planes(owner, transposed=False, view=None, also=(), pair=False) -> Pl
         g, off = flat
         ver = (owner._version,) + tuple(t._version for t in also)
         if pair:
-            pl = g.pair_of(off, w.shape[0], w.shape[1], ver)
+            pl = g.planes_t_of(off, w.shape[0], w.shape[1], ver, pair=True) if transposed else g.pair_of(off, w.shape[0], w.shape[1], ver)
         else:
             pl = g.planes_t_of(off, w.shape[0], w.shape[1], ver) if transposed else g.planes_of(off, w.shape[0], w.shape[1], ver)
         if pl is not None:
@@ -396,7 +411,10 @@ def weight_planes(owner, transposed=False, view=None, also=(), pair=False) -> Pl
         return hit[1]
     with torch.no_grad():
         buf = hit[1] if hit is not None else None
-        pl = split_planes_pair(w.detach(), out=buf) if pair else (split_planes_t(w.detach(), out=buf) if transposed else split_planes(w.detach(), out=buf))
+        if pair and transposed:
+            pl = split_planes_pair(w.detach().t().contiguous(), out=buf)       # (no flat buffer: a plain transpose, tests only)
+        else:
+            pl = split_planes_pair(w.detach(), out=buf) if pair else (split_planes_t(w.detach(), out=buf) if transposed else split_planes(w.detach(), out=buf))
     cache[key] = (tag, pl)
     return pl
 

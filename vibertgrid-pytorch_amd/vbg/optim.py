@@ -96,10 +96,9 @@ class FlatGroup:
         self._planes_tag = None
         self._pair = None                    # fp16-pair image [2][total] (operands of the form-1 forward products)
         self._pair_tag = None
-        self._t_jobs = {}                    # (offset, rows, cols) -> (slot offset, ld)
-        self._t_buf = None
-        self._t_tbl = None
-        self._t_tag = None
+        # transposed images: bf16 planes (`_tp`) and fp16-pair planes (`_tq`); jobs: (offset, rows, cols) -> (slot offset, ld)
+        self._tp = {"jobs": {}, "buf": None, "tbl": None, "tag": None, "tiles": 0}
+        self._tq = {"jobs": {}, "buf": None, "tbl": None, "tag": None, "tiles": 0}
         self._ver = {}
 
     def zero_grad(self):
@@ -113,7 +112,7 @@ class FlatGroup:
         updates (`_version` of the buffer and of the parameter asked for) and load_state_dict; a write through `param.data`
         (`p.data.copy_(...)`, `p.data.mul_(...)`: EMA / weight-tying code) moves none of these counters -- call this, or
         vbg.ops.bump_weight_epoch(), after such a write"""
-        self._planes_tag = self._pair_tag = self._t_tag = None
+        self._planes_tag = self._pair_tag = self._tp["tag"] = self._tq["tag"] = None
         self._ver.clear()
 
     def _tag(self):
@@ -123,7 +122,7 @@ class FlatGroup:
         """refresh needed?  The optimizer kernels bump the epoch; torch in-place updates of a parameter (load_state_dict, tests) bump
         that parameter's own version counter, which is checked per request against the version seen at the last refresh."""
         seen = self._ver.setdefault(which, {})
-        if {"p": self._planes_tag, "q": self._pair_tag, "t": self._t_tag}[which] != self._tag() or seen.get(off, ver) != ver:
+        if {"p": self._planes_tag, "q": self._pair_tag, "t": self._tp["tag"], "u": self._tq["tag"]}[which] != self._tag() or seen.get(off, ver) != ver:
             seen.clear()
             seen[off] = ver
             return True
@@ -155,31 +154,33 @@ class FlatGroup:
             self._pair_tag = self._tag()
         return ops.Planes(self._pair[:, off:off + rows * cols].view(2, rows, cols), rows, cols, cols)
 
-    def planes_t_of(self, off: int, rows: int, cols: int, ver=0):
-        """plane operand of the TRANSPOSE of that matrix ([cols, rows], reduction over rows)"""
+    def planes_t_of(self, off: int, rows: int, cols: int, ver=0, pair=False):
+        """plane operand of the TRANSPOSE of that matrix ([cols, rows], reduction over rows); pair: as two fp16 planes (form 1)"""
         if off % 8:
             return None
+        st = self._tq if pair else self._tp
         key = (off, rows, cols)
-        if key not in self._t_jobs:
+        if key not in st["jobs"]:
             ld = (rows + 31) // 32 * 32
-            slot = sum(c * l for (_, _, c), (_, l) in self._t_jobs.items())
-            self._t_jobs[key] = (slot, ld)
-            self._t_tbl = None
-        if self._t_tbl is None:
-            tot = sum(c * l for (_, _, c), (_, l) in self._t_jobs.items())
-            self._t_buf = torch.empty((3, (tot + 7) // 8 * 8), device=self.pflat.device, dtype=torch.int16)
+            slot = sum(c * l for (_, _, c), (_, l) in st["jobs"].items())
+            st["jobs"][key] = (slot, ld)
+            st["tbl"] = None
+        if st["tbl"] is None:
+            tot = sum(c * l for (_, _, c), (_, l) in st["jobs"].items())
+            st["buf"] = torch.empty((2 if pair else 3, (tot + 7) // 8 * 8), device=self.pflat.device, dtype=torch.int16)
             rows_, first = [], 0
-            for (o, r, c), (slot, ld) in self._t_jobs.items():
+            for (o, r, c), (slot, ld) in st["jobs"].items():
                 rows_.append([o, r, c, slot, ld, first])
                 first += ((ld + 63) // 64) * ((c + 63) // 64)
-            self._t_tiles = first
-            self._t_tbl = torch.tensor(rows_, dtype=torch.int64).to(self.pflat.device)
-            self._t_tag = None
-        if self._stale("t", off, ver):
-            ops.split_planes_t_batched(self.pflat, self._t_buf, self._t_tbl, len(self._t_jobs), self._t_tiles)
-            self._t_tag = self._tag()
-        slot, ld = self._t_jobs[key]
-        return ops.Planes(self._t_buf[:, slot:slot + cols * ld].view(3, cols, ld), cols, rows, ld)
+            st["tiles"] = first
+            st["tbl"] = torch.tensor(rows_, dtype=torch.int64).to(self.pflat.device)
+            st["tag"] = None
+        which = "u" if pair else "t"
+        if self._stale(which, off, ver):
+            (ops.split_planes_pair_t_batched if pair else ops.split_planes_t_batched)(self.pflat, st["buf"], st["tbl"], len(st["jobs"]), st["tiles"])
+            st["tag"] = self._tag()
+        slot, ld = st["jobs"][key]
+        return ops.Planes(st["buf"][:, slot:slot + cols * ld].view(2 if pair else 3, cols, ld), cols, rows, ld)
 
     def view(self, flat: torch.Tensor, i: int) -> torch.Tensor:
         """parameter i's slice of another flat buffer of this layout (optimizer state), shaped / laid out like the parameter"""
