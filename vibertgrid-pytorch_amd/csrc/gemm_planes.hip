@@ -1307,7 +1307,7 @@ static int plane_gemm_dispatch(const vbg_plane_gemm_desc* desc, void* stream, vo
     if (d.splitk > 1) VBG_CHECK_ARG(d.accumulate == 1 && d.C);
     if (d.accumulate) VBG_CHECK_ARG(d.epi == VBG_EPI_NONE && d.Cp == nullptr);
     if (d.colsum) VBG_CHECK_ARG(d.splitk == 1 && d.ngroups == 0 && !d.trans && !d.accumulate && d.epi != VBG_EPI_GELU_DUAL && d.tile != 256256 && !(d.sk_ws && d.sk_cnt));
-    if (d.epi == VBG_EPI_GELU_DUAL) VBG_CHECK_ARG(d.C2 != nullptr || d.Cp != nullptr);
+    if (d.epi == VBG_EPI_GELU_DUAL) VBG_CHECK_ARG(d.C2 != nullptr || d.Cp != nullptr || d.Cq != nullptr);
     if (d.epi == VBG_EPI_MUL_GELU_GRAD) VBG_CHECK_ARG(d.C2 != nullptr && d.ngroups == 0 && !d.trans && !(d.sk_ws && d.sk_cnt));
     if (d.Cp) VBG_CHECK_ARG(d.ldp % 8 == 0 && d.ldp >= d.N && ((uintptr_t)d.Cp & 7) == 0 && d.c_plane % 4 == 0);
     if (d.Cq) VBG_CHECK_ARG(d.ldq % 8 == 0 && d.ldq >= d.N && ((uintptr_t)d.Cq & 7) == 0 && d.q_plane % 4 == 0 && !d.accumulate && d.ngroups == 0 &&

@@ -596,11 +596,11 @@ extern "C" int vbg_dropout_add_ln_fwd_planes(const float* x, const float* res, i
                                              const float* beta, float eps, float drop_p, unsigned long long seed,
                                              unsigned long long sid, float* y, float* xhat, float* rstd, unsigned short* y_planes, int ldp,
                                              long long plane, unsigned short* y_pair, int ldq, long long qplane, void* stream) {
-    VBG_CHECK_ARG(x && res && gamma && beta && y && xhat && rstd && y_planes);
+    VBG_CHECK_ARG(x && res && gamma && beta && y && xhat && rstd && (y_planes || y_pair));
     VBG_CHECK_ARG(!y_pair || (ldq % 4 == 0 && ldq >= hidden && qplane % 4 == 0 && qplane >= (long long)rows * ldq && ((uintptr_t)y_pair & 7) == 0));
     VBG_CHECK_ARG(hidden > 0 && hidden % 256 == 0 && hidden <= 256 * LN_V && drop_p >= 0.f && drop_p < 1.f);
     VBG_CHECK_ARG(((uintptr_t)x | (uintptr_t)res | (uintptr_t)gamma | (uintptr_t)beta | (uintptr_t)y | (uintptr_t)xhat) % 16 == 0);
-    VBG_CHECK_ARG(ldp % 4 == 0 && ldp >= hidden && plane % 4 == 0 && plane >= (long long)rows * ldp && ((uintptr_t)y_planes & 7) == 0);
+    VBG_CHECK_ARG(!y_planes || (ldp % 4 == 0 && ldp >= hidden && plane % 4 == 0 && plane >= (long long)rows * ldp && ((uintptr_t)y_planes & 7) == 0));
     if (rows <= 0) return VBG_OK;
     VBG_LAUNCH(dropout_add_ln_fwd_kernel, dim3(cdiv(rows, 4)), dim3(256), 0, (hipStream_t)stream, x, res, rows, hidden,
                gamma, beta, eps, drop_threshold(drop_p), 1.0f / (1.0f - drop_p), seed, sid, y, xhat, rstd, y_planes, ldp, plane, y_pair, ldq, qplane);

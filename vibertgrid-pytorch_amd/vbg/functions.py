@@ -581,9 +581,20 @@ class BertLayerFn(torch.autograd.Function):
         # products, csrc/gemm_planes.hip FORM 1) once the problem fills the 8-wave tiles; the pair planes of x arrive as an attribute of
         # the previous layer's bf16 planes (written by its closing LayerNorm)
         pair = planes and ops.pair_enabled() and ops.pair_tile(ntok, hid) != 0
-        xq = getattr(xpl, "_vbg_pair", None) if (pair and xpl is not None) else None
+        carrier_is_pair = xpl is not None and xpl.shape[0] == 2          # (the previous layer ran the all-pair path: xpl ARE the pair planes)
+        xq = (ops.Planes(xpl, ntok, hid, xpl.shape[2]) if carrier_is_pair else getattr(xpl, "_vbg_pair", None)) if (pair and xpl is not None) else None
+        # all-pair path: the backward products run on two fp16 pieces as well (needs every weight / bias gradient of the layer sunk into
+        # the flat buffers, the stacked Q/K/V layout and the fused attention), and so does the attention-output projection; the
+        # activations saved for backward are pair planes, no bf16 planes of x1 / gelu(h) / y / ctx are written at all
+        pair_bwd = (pair and ops.pair_bwd_enabled() and fused_qkv and dh == 64 and meta.maxlen <= 512 and ops.flash_enabled()
+                    and any(ctx.needs_input_grad)
+                    and all(wgrad_dest(t) is not None for t in (wq, wk, wv, bq, bk, bv, wo, bo, wi, bi, wo2, bo2)))
+        assert not carrier_is_pair or pair, "pair planes handed to a layer that does not run the pair form"
+        if pair_bwd and xq is None:
+            xq = ops.split_planes_pair(x)
         if planes:                 # operands split into bf16 planes once (csrc/gemm_planes.hip), weights once per optimizer step
-            px = ops.Planes(xpl, ntok, hid, xpl.shape[2]) if xpl is not None else ops.split_planes(x)
+            if not pair_bwd:           # (the bf16 planes of x: the QKV product's operand without the pair form, and its weight gradient's)
+                px = ops.Planes(xpl, ntok, hid, xpl.shape[2]) if (xpl is not None and not carrier_is_pair) else ops.split_planes(x)
             if fused_qkv and xq is not None:
                 ops.plane_gemm(xq, ops.weight_planes(wq, view=_stack3(wq), also=(wk, wv), pair=True), qkv, bias=_stack3(bq), out_planes=pqkv,
                                tile=ops.pair_tile(ntok, 3 * hid), form=1)
@@ -622,23 +633,28 @@ class BertLayerFn(torch.autograd.Function):
                          grp_max=(meta.maxlen, dh), b_ptr_off=2 * hid, a_relu_scale=1.0 / (1.0 - p))
         py = None
         if planes:
+            # (the attention-output projection stays on the six-product form, its operand's bf16 planes come from the attention kernel:
+            #  measured at full scale, moving it to the pair form as well raised the gradient error of the ill-conditioned trunk
+            #  convolutions from 6.3e-4 to 1.0e-3 of the reference -- the forward feeds everything; the backward products do not)
             if pctx is None:
                 pctx = ops.split_planes(ctxv)
             ao = ops.plane_gemm(pctx, ops.weight_planes(wo), torch.empty((ntok, hid), device=dev, dtype=f32), bias=bo, tile=ops._dense_tile(ntok, hid))
-            px1 = ops.planes_empty(ntok, hid, dev)
+            px1 = None if pair_bwd else ops.planes_empty(ntok, hid, dev)
             px1q = ops.pair_empty(ntok, hid, dev) if pair else None
             x1, xh1, rs1 = ops.dropout_add_ln_fwd(ao, x, g1, b1, eps, p, seed, sid + 1, out_planes=px1, out_pair=px1q)
             inter = wi.shape[0]
             h = torch.empty((ntok, inter), device=dev, dtype=f32)
             # gelu(h) leaves the FFN1 epilogue as planes only (the A operand of FFN2 and, untransposed, of its weight gradient)
-            pg = ops.planes_empty(ntok, inter, dev)
+            pg = None if pair_bwd else ops.planes_empty(ntok, inter, dev)
+            pgq = None
             if pair:
                 pgq = ops.pair_empty(ntok, inter, dev)
                 ops.plane_gemm(px1q, ops.weight_planes(wi, pair=True), h, bias=bi, epi=EPI_GELU_DUAL, out_planes=pg, out_pair=pgq,
                                tile=ops.pair_tile(ntok, inter, True), form=1)
                 fo = ops.plane_gemm(pgq, ops.weight_planes(wo2, pair=True), torch.empty((ntok, hid), device=dev, dtype=f32), bias=bo2,
                                     tile=ops.pair_tile(ntok, hid), form=1)
-                del pgq, px1q
+                if not pair_bwd:
+                    pgq = px1q = None
             else:
                 ops.plane_gemm(px1, ops.weight_planes(wi), h, bias=bi, epi=EPI_GELU_DUAL, out_planes=pg, tile=ops._dense_tile(ntok, inter, True))
                 fo = ops.plane_gemm(pg, ops.weight_planes(wo2), torch.empty((ntok, hid), device=dev, dtype=f32), bias=bo2, tile=ops._dense_tile(ntok, hid))
@@ -650,23 +666,30 @@ class BertLayerFn(torch.autograd.Function):
             fo = ops.linear_fwd(g, wo2, bo2)
         pyq = None
         if planes:
-            py = ops.planes_empty(ntok, hid, dev)
+            py = None if pair_bwd else ops.planes_empty(ntok, hid, dev)
             pyq = ops.pair_empty(ntok, hid, dev) if pair else None
         y, xh2, rs2 = ops.dropout_add_ln_fwd(fo, x1, g2, b2, eps, p, seed, sid + 2, out_planes=py, out_pair=pyq)
         ctx.meta, ctx.cfg = meta, (eps, p, seed, sid)
-        ctx.planes, ctx.flash = planes, flash
+        ctx.planes, ctx.flash, ctx.pair_bwd = planes, flash, pair_bwd
         ctx.w_refs = (wq, wk, wv, wo, wi, wo2)
         ctx.b_refs = (bq, bk, bv, bo, bi, bo2, g1, b1, g2, b2)
         if planes:
             # backward needs the activations only as GEMM operands: their planes stand in for x / ctx / x1 / gelu(h)
             ctx.pl_shape = (ntok, hid, wi.shape[0])
-            if flash:
+            if pair_bwd:
+                ctx.masks = masks
+                ctx.save_for_backward(wq, wk, wv, wo, g1, wi, wo2, g2, pqkv.buf, ctxv, xh1, rs1, h, xh2, rs2, xq.buf, px1q.buf, pgq.buf, lse, kbar)
+            elif flash:
                 ctx.masks = masks
                 ctx.save_for_backward(wq, wk, wv, wo, g1, wi, wo2, g2, pqkv.buf, ctxv, xh1, rs1, h, xh2, rs2, px.buf, pctx.buf, px1.buf, pg.buf, lse, kbar)
             else:
                 ctx.save_for_backward(wq, wk, wv, wo, g1, wi, wo2, g2, qkv, P, xh1, rs1, h, xh2, rs2, px.buf, pctx.buf, px1.buf, pg.buf)
         else:
             ctx.save_for_backward(x, wq, wk, wv, wo, g1, wi, wo2, g2, qkv, P, ctxv, xh1, rs1, x1, h, g, xh2, rs2)
+        if py is None and pyq is not None:            # all-pair path: the pair planes themselves travel to the next layer
+            ctx.mark_non_differentiable(pyq.buf)
+            ctx.set_materialize_grads(False)
+            return y, pyq.buf
         if py is None:
             return y, None
         ctx.mark_non_differentiable(py.buf)
@@ -674,6 +697,70 @@ class BertLayerFn(torch.autograd.Function):
         if pyq is not None:
             py.buf._vbg_pair = pyq             # (travels on the tensor object to the next layer's first product)
         return y, py.buf
+
+    @staticmethod
+    def _backward_pair(ctx, dy):
+        """backward of the all-pair path: every product on two fp16 pieces.  A gradient operand is split by a pass of its own once its
+        largest magnitude is known (LayerNorm backward -> fp32 -> vbg_amax -> scaled split with the bias column sums; the GELU-gradient
+        product reports the maximum of what it stores), scaled by the power of two of that maximum; products scale back (exact)."""
+        (wq, wk, wv, wo, g1, wi, wo2, g2, bqkv, ctxv, xh1, rs1, h, xh2, rs2, bx, bx1, bg, lse, kbar) = ctx.saved_tensors
+        meta = ctx.meta
+        eps, p, seed, sid = ctx.cfg
+        ntok, hid, inter = ctx.pl_shape
+        H, dh = meta.heads, meta.dh
+        dev = h.device
+        mk = lambda buf, cols: ops.Planes(buf, ntok, cols, buf.shape[2])
+        qx, qx1, qg = mk(bx, hid), mk(bx1, hid), mk(bg, inter)
+        qctx = ops.split_planes_pair(ctxv)            # (the attention output as the B operand of the output projection's weight gradient)
+        rbq, rbk, rbv, rbo, rbi, rbo2, rg1, rb1, rg2, rb2 = ctx.b_refs
+        rq, rk, rv, ro, ri, ro2 = ctx.w_refs
+        tile = lambda n, wide=False: ops.pair_tile(ntok, n, wide)
+        # ---- LayerNorm 2 backward -> dfo (fp32) -> pair planes, bias gradient of the FFN output projection on the split
+        dg2, db2, sunk2 = _affine_dest(rg2, rb2)
+        dfo, dx1 = ops.dropout_add_ln_bwd(_c(dy), xh2, rs2, g2, p, seed, sid + 2, dg2, db2)
+        dg2, db2 = _affine_done(rg2, rb2, dg2, db2, sunk2)
+        s_dfo = ops.amax(dfo)
+        qdfo = ops.split_planes_pair(dfo, amax_slot_=s_dfo, colsum_out=wgrad_dest(rbo2))
+        wgrad_done(rbo2)
+        del dfo
+        # ---- dL/dh = (dfo Wo2) o gelu'(h): fp32 out of the product's epilogue with its largest magnitude, then its own split
+        s_dh = ops.amax_slot(dev)
+        dh_ = torch.empty((ntok, inter), device=dev, dtype=f32)
+        ops.plane_gemm(qdfo, ops.weight_planes(ro2, True, view=wo2, pair=True), dh_, epi=EPI_MUL_GELU_GRAD, C2=h, tile=tile(inter, True), form=1,
+                       a_amax=s_dfo, c_amax=s_dh)
+        qdh = ops.split_planes_pair(dh_, amax_slot_=s_dh, colsum_out=wgrad_dest(rbi))
+        wgrad_done(rbi)
+        del dh_
+        ops.plane_gemm(qdh, ops.weight_planes(ri, True, view=wi, pair=True), dx1, accumulate=True, tile=tile(hid), form=1, a_amax=s_dh)
+        # ---- LayerNorm 1 backward -> dao
+        dg1, db1, sunk1 = _affine_dest(rg1, rb1)
+        dao, dx = ops.dropout_add_ln_bwd(dx1, xh1, rs1, g1, p, seed, sid + 1, dg1, db1)
+        dg1, db1 = _affine_done(rg1, rb1, dg1, db1, sunk1)
+        s_dao = ops.amax(dao)
+        qdao = ops.split_planes_pair(dao, amax_slot_=s_dao, colsum_out=wgrad_dest(rbo))
+        wgrad_done(rbo)
+        del dao
+        # ---- d(context): fp32 + bf16 planes (the dO operand of the fused attention backward, which stays on the six-product form)
+        pdctx = ops.planes_empty(ntok, hid, dev)
+        ops.plane_gemm(qdao, ops.weight_planes(ro, True, view=wo, pair=True), None, out_planes=pdctx, tile=tile(hid), form=1, a_amax=s_dao)
+        pqkv = ops.Planes(bqkv, ntok, 3 * hid, bqkv.shape[2])
+        delta = ctx.delta_buf
+        dqkv = torch.empty((ntok, 3 * hid), device=dev, dtype=f32)
+        sc = 1.0 / (dh ** 0.5)
+        ops.attn(meta, ATTN_DQ, pqkv, pdctx, dqkv, lse, delta, ctx.masks, sc, p, kbar=kbar, o=ctxv)
+        ops.attn(meta, ATTN_DKV, pqkv, pdctx, dqkv, lse, delta, ctx.masks, sc, p)
+        gq = [wgrad_dest(t) for t in (rq, rk, rv, rbq, rbk, rbv)]
+        s_dqkv = ops.amax(dqkv)
+        qdqkv = ops.split_planes_pair(dqkv, amax_slot_=s_dqkv, colsum_out=_stack3(gq[3]))
+        del dqkv
+        ops.plane_gemm(qdqkv, ops.weight_planes(rq, True, view=_stack3(wq), also=(rk, rv), pair=True), dx, accumulate=True, tile=tile(hid), form=1,
+                       a_amax=s_dqkv)
+        # ---- the four weight gradients: one grouped TN launch on pair planes
+        jobs = [(qdfo, qg, wgrad_dest(ro2)), (qdh, qx1, wgrad_dest(ri)), (qdao, qctx, wgrad_dest(ro)), (qdqkv, qx, _stack3(gq[0]))]
+        ops.plane_gemm_grouped(jobs, trans=True, accumulate=True, form=1, a_amax=[s_dfo, s_dh, s_dao, s_dqkv])
+        for t in (ro2, ri, ro, rq, rk, rv, rbq, rbk, rbv):
+            wgrad_done(t)
+        return (dx, None, None, None, None, None, None, None, None, None, dg1, db1, None, None, None, None, dg2, db2, None, None, None, None, None)
 
     @staticmethod
     def _backward_planes(ctx, dy):
@@ -810,7 +897,7 @@ class BertLayerFn(torch.autograd.Function):
     @staticmethod
     def backward(ctx, dy, _dplanes=None):
         if ctx.planes:
-            return BertLayerFn._backward_planes(ctx, dy)
+            return BertLayerFn._backward_pair(ctx, dy) if ctx.pair_bwd else BertLayerFn._backward_planes(ctx, dy)
         (x, wq, wk, wv, wo, g1, wi, wo2, g2, qkv, P, ctxv, xh1, rs1, x1, h, g, xh2, rs2) = ctx.saved_tensors
         meta = ctx.meta
         eps, p, seed, sid = ctx.cfg

@@ -221,6 +221,20 @@ def pair_enabled() -> bool:
     return _PAIR[0] and _PLANES[0] and _SPLIT3[0] and not _AMP[0]
 
 
+_PAIR_BWD = [os.environ.get("VBG_PAIR_BWD", "1") != "0"]
+
+
+def set_pair_bwd(on: bool):
+    """the BERT backward products (data gradients, grouped weight gradients) and the attention-output projection on two fp16 pieces as
+    well: gradient operands are split by a pass of their own after their largest magnitude is known (amax slots), scaled by its power
+    of two; the activations saved for backward are pair planes (4 instead of 6 bytes per element)"""
+    _PAIR_BWD[0] = bool(on)
+
+
+def pair_bwd_enabled() -> bool:
+    return pair_enabled() and _PAIR_BWD[0]
+
+
 def pair_tile(M, N, wide=False):
     """tile of a form-1 product [M, N], or 0 when the problem is too small for the form (it then runs the bf16 form)"""
     t = _dense_tile(M, N, wide)
@@ -872,10 +886,11 @@ def dropout_add_ln_fwd(x, res, gamma, beta, eps, p, seed, sid, out_planes=None, 
     y = torch.empty_like(x)
     xhat = torch.empty_like(x)
     rstd = torch.empty((rows,), device=x.device, dtype=f32)
-    if out_planes is not None:
-        assert out_planes.ld == hidden and out_planes.rows == rows
+    if out_planes is not None or out_pair is not None:
+        assert (out_planes is None or (out_planes.ld == hidden and out_planes.rows == rows)) and (out_pair is None or out_pair.ld == hidden)
         check(lib.vbg_dropout_add_ln_fwd_planes(P(x), P(res), rows, hidden, P(gamma), P(beta), eps, p, seed, sid, P(y), P(xhat), P(rstd),
-                                                P(out_planes.buf), out_planes.ld, out_planes.plane,
+                                                P(out_planes.buf) if out_planes is not None else None, out_planes.ld if out_planes is not None else 0,
+                                                out_planes.plane if out_planes is not None else 0,
                                                 P(out_pair.buf) if out_pair is not None else None, out_pair.ld if out_pair is not None else 0,
                                                 out_pair.plane if out_pair is not None else 0, _stream()), "vbg_dropout_add_ln_fwd_planes")
         return y, xhat, rstd
