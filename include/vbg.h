@@ -307,7 +307,8 @@ int vbg_dropout_add_ln_fwd_planes(const float* x, const float* res, int rows, in
 int vbg_ln_slots(void);
 int vbg_dropout_add_ln_bwd(const float* dy, const float* xhat, const float* rstd, int rows, int hidden,
                            const float* gamma, float drop_p, unsigned long long seed, unsigned long long stream_id,
-                           float* dx, float* dres, float* dgamma, float* dbeta, float* slots_ws, void* stream);
+                           float* dx, float* dres, float* dgamma, float* dbeta, float* slots_ws, unsigned* dx_amax, void* stream);
+/* dx_amax (optional): amax slot (zeroed by the caller) that receives max |dx| -- the scale of dx as an fp16-pair operand */
 /* the same with dx delivered as bf16 planes [3][rows][ldp] (not as fp32) and its column sums added into dbias_accum[hidden]: dx is the
  * gradient of the dense output in front of the LayerNorm, which is only ever a plane operand of that layer's gradient products, and
  * its column sums are that layer's bias gradient.  slots3_ws: fp32 [vbg_ln_slots()][3][hidden], zero on entry, left zero. */

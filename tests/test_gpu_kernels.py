@@ -362,7 +362,9 @@ def test_dropout_add_ln(ops, rows, Hd):
     assert torch.equal(y2, yo) and torch.equal(ypl.buf, ops.split_planes(yo).buf)          # planes written by the LayerNorm pass == split(y)
     assert close(yo, y, 1e-4, 1e-5)
     dg, db = torch.zeros(Hd, device=d), torch.zeros(Hd, device=d)
-    dx, dres = ops.dropout_add_ln_bwd(gy.to(d), xhat, rstd, gam.detach().to(d), 0.0, 1, 0, dg, db)
+    slot = ops.amax_slot(d)
+    dx, dres = ops.dropout_add_ln_bwd(gy.to(d), xhat, rstd, gam.detach().to(d), 0.0, 1, 0, dg, db, dx_amax=slot)
+    assert int(slot.max().item()) == int(dx.abs().max().view(torch.int32).item())          # max |dx| rides on the kernel
     assert close(dx, x.grad, 1e-3, 1e-5) and close(dres, r.grad, 1e-3, 1e-5)
     assert close(dg, gam.grad, 1e-3, 1e-3) and close(db, bet.grad, 1e-3, 1e-3)
     # a second call accumulates into dgamma / dbeta and finds the workspace clean

@@ -223,10 +223,11 @@ __global__ __launch_bounds__(256) void dropout_add_ln_bwd_kernel(
     const float* __restrict__ dy, const float* __restrict__ xhat, const float* __restrict__ rstd, int rows, int hidden,
     const float* __restrict__ gamma, uint32_t drop_thr, float keep_scale, uint64_t seed, uint64_t sid,
     float* __restrict__ dx, float* __restrict__ dres, float* dgamma, float* dbeta, float* slots,
-    unsigned short* __restrict__ dxp, int ldp, long long plane) {
+    unsigned short* __restrict__ dxp, int ldp, long long plane, unsigned* dx_amax) {
     const int lane = threadIdx.x & 63;
     const int nv = hidden >> 8;
     const int t0 = (blockIdx.x * 4 + (threadIdx.x >> 6)) * LN_WROWS;
+    float amx = 0.f;                                  // max |dx| of this thread (dx_amax: the scale of dx as a pair-plane operand)
     float4 gam[LN_V], ag[LN_V], ab[LN_V], ac[LN_V];
 #pragma unroll
     for (int j = 0; j < LN_V; ++j) {
@@ -263,6 +264,7 @@ __global__ __launch_bounds__(256) void dropout_add_ln_bwd_kernel(
                 const float4 dd = drop4(dz, drop_thr, keep_scale, seed, sid, (uint64_t)base + c);
                 if constexpr (!PL) {
                     *reinterpret_cast<float4*>(dx + base + c) = dd;
+                    amx = fmaxf(fmaxf(amx, fmaxf(fabsf(dd.x), fabsf(dd.y))), fmaxf(fabsf(dd.z), fabsf(dd.w)));
                 } else {
                     ac[j].x += dd.x; ac[j].y += dd.y; ac[j].z += dd.z; ac[j].w += dd.w;
                     const float e[4] = {dd.x, dd.y, dd.z, dd.w};
@@ -303,6 +305,12 @@ __global__ __launch_bounds__(256) void dropout_add_ln_bwd_kernel(
         unsafeAtomicAdd(dg + c, (red[0][0][c] + red[0][1][c]) + (red[0][2][c] + red[0][3][c]));
         unsafeAtomicAdd(db + c, (red[1][0][c] + red[1][1][c]) + (red[1][2][c] + red[1][3][c]));
         if constexpr (PL) unsafeAtomicAdd(dg + 2 * hidden + c, (red[2][0][c] + red[2][1][c]) + (red[2][2][c] + red[2][3][c]));
+    }
+    if constexpr (!PL) {
+        if (dx_amax) {                                // (uniform)
+            __syncthreads();
+            vbg_amax_publish(amx, dx_amax, &red[0][0][0]);
+        }
     }
 }
 
@@ -609,14 +617,14 @@ extern "C" int vbg_dropout_add_ln_fwd_planes(const float* x, const float* res, i
 
 extern "C" int vbg_dropout_add_ln_bwd(const float* dy, const float* xhat, const float* rstd, int rows, int hidden,
                                       const float* gamma, float drop_p, unsigned long long seed, unsigned long long sid,
-                                      float* dx, float* dres, float* dgamma, float* dbeta, float* slots_ws, void* stream) {
+                                      float* dx, float* dres, float* dgamma, float* dbeta, float* slots_ws, unsigned* dx_amax, void* stream) {
     VBG_CHECK_ARG(dy && xhat && rstd && gamma && dx && dres && dgamma && dbeta);
     VBG_CHECK_ARG(hidden > 0 && hidden % 256 == 0 && hidden <= 256 * LN_V && drop_p >= 0.f && drop_p < 1.f);
     VBG_CHECK_ARG(((uintptr_t)dy | (uintptr_t)xhat | (uintptr_t)gamma | (uintptr_t)dx | (uintptr_t)dres) % 16 == 0);
     if (rows <= 0) return VBG_OK;
     VBG_LAUNCH(dropout_add_ln_bwd_kernel<false>, dim3(cdiv(rows, 4 * LN_WROWS)), dim3(256), 0, (hipStream_t)stream, dy, xhat, rstd, rows,
                hidden, gamma, drop_threshold(drop_p), 1.0f / (1.0f - drop_p), seed, sid, dx, dres, dgamma, dbeta, slots_ws,
-               (unsigned short*)nullptr, 0, 0ll);
+               (unsigned short*)nullptr, 0, 0ll, dx_amax);
     if (slots_ws) VBG_LAUNCH(ln_fold_kernel, dim3(cdiv(2 * hidden, 256)), dim3(256), 0, (hipStream_t)stream, slots_ws, hidden, 2, dgamma, dbeta,
                              (float*)nullptr);
     VBG_LAUNCH_RET();
@@ -633,7 +641,7 @@ extern "C" int vbg_dropout_add_ln_bwd_planes(const float* dy, const float* xhat,
     if (rows <= 0) return VBG_OK;
     VBG_LAUNCH(dropout_add_ln_bwd_kernel<true>, dim3(cdiv(rows, 4 * LN_WROWS)), dim3(256), 0, (hipStream_t)stream, dy, xhat, rstd, rows,
                hidden, gamma, drop_threshold(drop_p), 1.0f / (1.0f - drop_p), seed, sid, (float*)nullptr, dres, dgamma, dbeta, slots3_ws,
-               dx_planes, ldp, plane);
+               dx_planes, ldp, plane, (unsigned*)nullptr);
     VBG_LAUNCH(ln_fold_kernel, dim3(cdiv(3 * hidden, 256)), dim3(256), 0, (hipStream_t)stream, slots3_ws, hidden, 3, dgamma, dbeta, dbias_accum);
     VBG_LAUNCH_RET();
 }

@@ -717,9 +717,9 @@ class BertLayerFn(torch.autograd.Function):
         tile = lambda n, wide=False: ops.pair_tile(ntok, n, wide)
         # ---- LayerNorm 2 backward -> dfo (fp32) -> pair planes, bias gradient of the FFN output projection on the split
         dg2, db2, sunk2 = _affine_dest(rg2, rb2)
-        dfo, dx1 = ops.dropout_add_ln_bwd(_c(dy), xh2, rs2, g2, p, seed, sid + 2, dg2, db2)
+        s_dfo = ops.amax_slot(dev)                    # (the largest magnitude of dfo rides on the kernel that writes it)
+        dfo, dx1 = ops.dropout_add_ln_bwd(_c(dy), xh2, rs2, g2, p, seed, sid + 2, dg2, db2, dx_amax=s_dfo)
         dg2, db2 = _affine_done(rg2, rb2, dg2, db2, sunk2)
-        s_dfo = ops.amax(dfo)
         qdfo = ops.split_planes_pair(dfo, amax_slot_=s_dfo, colsum_out=wgrad_dest(rbo2))
         wgrad_done(rbo2)
         del dfo
@@ -734,9 +734,9 @@ class BertLayerFn(torch.autograd.Function):
         ops.plane_gemm(qdh, ops.weight_planes(ri, True, view=wi, pair=True), dx1, accumulate=True, tile=tile(hid), form=1, a_amax=s_dh)
         # ---- LayerNorm 1 backward -> dao
         dg1, db1, sunk1 = _affine_dest(rg1, rb1)
-        dao, dx = ops.dropout_add_ln_bwd(dx1, xh1, rs1, g1, p, seed, sid + 1, dg1, db1)
+        s_dao = ops.amax_slot(dev)
+        dao, dx = ops.dropout_add_ln_bwd(dx1, xh1, rs1, g1, p, seed, sid + 1, dg1, db1, dx_amax=s_dao)
         dg1, db1 = _affine_done(rg1, rb1, dg1, db1, sunk1)
-        s_dao = ops.amax(dao)
         qdao = ops.split_planes_pair(dao, amax_slot_=s_dao, colsum_out=wgrad_dest(rbo))
         wgrad_done(rbo)
         del dao

@@ -930,13 +930,14 @@ def dropout_add_ln_bwd_planes(dy, xhat, rstd, gamma, p, seed, sid, dgamma, dbeta
     return pdx, dres
 
 
-def dropout_add_ln_bwd(dy, xhat, rstd, gamma, p, seed, sid, dgamma, dbeta):
+def dropout_add_ln_bwd(dy, xhat, rstd, gamma, p, seed, sid, dgamma, dbeta, dx_amax=None):
+    """dx_amax: zeroed amax slot that receives max |dx| (the scale of dx as an fp16-pair operand)"""
     rows, hidden = xhat.shape
     dx = torch.empty_like(xhat)
     dres = torch.empty_like(xhat)
     ws = _ln_workspace(xhat.device, hidden) if rows >= 512 else None
     check(lib.vbg_dropout_add_ln_bwd(P(dy), P(xhat), P(rstd), rows, hidden, P(gamma), p, seed, sid, P(dx), P(dres), P(dgamma),
-                                     P(dbeta), P(ws), _stream()), "vbg_dropout_add_ln_bwd")
+                                     P(dbeta), P(ws), P(dx_amax), _stream()), "vbg_dropout_add_ln_bwd")
     return dx, dres
 
 
