@@ -211,6 +211,7 @@ typedef struct vbg_attn_desc {
     const float* o;                 /* DQ: the forward's O as fp32 [ntok][ldk] (delta = rowsum(dO o O) is formed in the kernel) */
     const unsigned* mask_q; const unsigned* mask_k; const long long* mask_off;
     float scale, keep_scale;
+    unsigned* out_amax;             /* DQ / DKV, optional: amax slot (zeroed by the caller) that receives max |value written to out| */
 } vbg_attn_desc;
 int vbg_attn(const vbg_attn_desc* desc, void* stream);
 /* dropout keeps of one layer and step, both orientations (torch.nn.Dropout(attention_probs_dropout_prob) on the probabilities):

@@ -56,9 +56,11 @@ def _run(seq_len, heads, p, seed=0):
     assert torch.equal(opl.buf, ops.split_planes(O).buf), "planes of O written by the forward kernel != split(O)"
     delta = torch.zeros_like(lse[0])
     dqkv = torch.full((ntok, 3 * hid), float("nan"), device=dev)
-    ops.attn(meta, ATTN_DQ, pq, pdo, dqkv, lse, delta, masks, scale, p, kbar=kbar, o=O)
-    ops.attn(meta, ATTN_DKV, pq, pdo, dqkv, lse, delta, masks, scale, p)
+    slot = ops.amax_slot(dev)          # the largest magnitude of d(qkv) rides on the two backward kernels (fp16-pair planes' scale)
+    ops.attn(meta, ATTN_DQ, pq, pdo, dqkv, lse, delta, masks, scale, p, kbar=kbar, o=O, out_amax=slot)
+    ops.attn(meta, ATTN_DKV, pq, pdo, dqkv, lse, delta, masks, scale, p, out_amax=slot)
     torch.cuda.synchronize()
+    assert int(slot.max().item()) == int(dqkv.abs().max().view(torch.int32).item())
     # ---- reference: fp64, per (sequence, head) --------------------------------------------------------------------
     ks = ops.attn_keep_scale(p) if p > 0 else 1.0
     mq = masks[0].cpu().numpy().view(np.uint32) if p > 0 else None

@@ -447,9 +447,11 @@ __global__ __launch_bounds__(256, 2) void attn_kernel(const vbg_attn_desc p) {
     }
 
     // ---- epilogue: accumulators are [d][own row]: lane = own row writes 4 consecutive d per register quad -------------------
-    if (!active || own0 + lr >= L) return;
+    const bool live = active && own0 + lr < L;
+    if (FWD || !p.out_amax) { if (!live) return; }             // (backward with out_amax: every lane stays for the wave's maximum)
     const long long orow = (long long)(row0 + own0 + lr) * p.ldo;
     const long long krow = (long long)(row0 + own0 + lr) * p.ldk;
+    float vmax = 0.f;                                          // max |value stored into p.out| of this lane (backward, p.out_amax)
     auto store = [&](const f32x16 (&acc)[2], float mul, int col, float* dst) {
 #pragma unroll
         for (int db = 0; db < 2; ++db)
@@ -457,6 +459,7 @@ __global__ __launch_bounds__(256, 2) void attn_kernel(const vbg_attn_desc p) {
             for (int j = 0; j < 4; ++j) {
                 const float4 v = make_float4(acc[db][4 * j] * mul, acc[db][4 * j + 1] * mul, acc[db][4 * j + 2] * mul, acc[db][4 * j + 3] * mul);
                 *reinterpret_cast<float4*>(dst + orow + col + db * 32 + 8 * j + 4 * lh) = v;
+                if constexpr (!FWD) vmax = fmaxf(fmaxf(vmax, fmaxf(fabsf(v.x), fabsf(v.y))), fmaxf(fabsf(v.z), fabsf(v.w)));
             }
     };
     if constexpr (FWD) {
@@ -488,6 +491,7 @@ __global__ __launch_bounds__(256, 2) void attn_kernel(const vbg_attn_desc p) {
         if (want_kbar) store(acc1, il, head * 64, p.kbar + krow - orow);
         if (lh == 0) { p.lse[lsoff + own0 + lr] = m_run; p.lse[lsplane + lsoff + own0 + lr] = il; }
     } else if constexpr (DQ) {
+      if (live) {
         // delta = rowsum(dO o O) carries the accumulated rounding of O as an error COMMON to the whole row, which the key
         // contraction cannot average out (the unfused path sums P o dP itself).  The row's own sum_k P_k dP_k is known now; dQ is
         // linear in delta, so  dQ = scale (sum_k P_k (dP_k - delta) K_k - (delta' - delta) Kbar)  holds exactly, and the small
@@ -503,9 +507,25 @@ __global__ __launch_bounds__(256, 2) void attn_kernel(const vbg_attn_desc p) {
             }
         store(acc0, scale, head * 64, p.out);
         if (lh == 0) p.delta[lsoff + own0 + lr] = dnew;
+      }
     } else {
+      if (live) {
         store(acc0, scale, hid + head * 64, p.out);
         store(acc1, 1.0f, 2 * hid + head * 64, p.out);
+      }
+    }
+    if constexpr (!FWD) {
+        // the largest magnitude of d(qkv) rides on the kernels that write it (the scale of its fp16-pair planes): one atomic per
+        // wave at most, on the wave's own word of the amax slot
+        if (p.out_amax) {                                      // (uniform)
+#pragma unroll
+            for (int o = 32; o > 0; o >>= 1) vmax = fmaxf(vmax, __shfl_xor(vmax, o, 64));
+            if (lane == 0 && vmax > 0.f) {
+                const unsigned bits = __float_as_uint(vmax);
+                unsigned* word = p.out_amax + ((blockIdx.x * 4 + (threadIdx.x >> 6)) & (VBG_AMAX_WORDS - 1)) * VBG_AMAX_STRIDE;
+                if (bits > __hip_atomic_load(word, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT)) atomicMax(word, bits);
+            }
+        }
     }
 }
 

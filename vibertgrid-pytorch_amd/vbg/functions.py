@@ -747,10 +747,10 @@ class BertLayerFn(torch.autograd.Function):
         delta = ctx.delta_buf
         dqkv = torch.empty((ntok, 3 * hid), device=dev, dtype=f32)
         sc = 1.0 / (dh ** 0.5)
-        ops.attn(meta, ATTN_DQ, pqkv, pdctx, dqkv, lse, delta, ctx.masks, sc, p, kbar=kbar, o=ctxv)
-        ops.attn(meta, ATTN_DKV, pqkv, pdctx, dqkv, lse, delta, ctx.masks, sc, p)
+        s_dqkv = ops.amax_slot(dev)                   # (the largest magnitude of d(qkv) rides on the two kernels that write it)
+        ops.attn(meta, ATTN_DQ, pqkv, pdctx, dqkv, lse, delta, ctx.masks, sc, p, kbar=kbar, o=ctxv, out_amax=s_dqkv)
+        ops.attn(meta, ATTN_DKV, pqkv, pdctx, dqkv, lse, delta, ctx.masks, sc, p, out_amax=s_dqkv)
         gq = [wgrad_dest(t) for t in (rq, rk, rv, rbq, rbk, rbv)]
-        s_dqkv = ops.amax(dqkv)
         qdqkv = ops.split_planes_pair(dqkv, amax_slot_=s_dqkv, colsum_out=_stack3(gq[3]))
         del dqkv
         ops.plane_gemm(qdqkv, ops.weight_planes(rq, True, view=_stack3(wq), also=(rk, rv), pair=True), dx, accumulate=True, tile=tile(hid), form=1,

@@ -968,7 +968,7 @@ def attn_mask(meta, p, seed, sid):
     return mq, mk
 
 
-def attn(meta, mode, qkv: Planes, dO, out, lse, delta, masks, scale, p, kbar=None, out_planes=None, o=None):
+def attn(meta, mode, qkv: Planes, dO, out, lse, delta, masks, scale, p, kbar=None, out_planes=None, o=None, out_amax=None):
     """one fused attention pass (mode: lib.ATTN_FWD / ATTN_DQ / ATTN_DKV) over all (sequence, head) pairs of the packed batch"""
     d = AttnDesc()
     d.mode, d.heads, d.ntasks, d.max_len = int(mode), meta.heads, meta.ntasks, meta.maxlen
@@ -992,6 +992,8 @@ def attn(meta, mode, qkv: Planes, dO, out, lse, delta, masks, scale, p, kbar=Non
     else:
         d.keep_scale = 1.0
     d.scale = float(scale)
+    if out_amax is not None:              # DQ / DKV: amax slot that receives max |d(qkv)|
+        d.out_amax = out_amax.data_ptr()
     check(lib.vbg_attn(C.byref(d), _stream()), "vbg_attn")
     return out
 

@@ -94,6 +94,7 @@ class FlatGroup:
         # image [3][total] in ONE elementwise launch, the transposed images of the matrices that asked for one in ONE batched launch
         self._planes = None
         self._planes_tag = None
+        self._plain_keys, self._plain_tags = set(), {}
         self._pair = None                    # fp16-pair image [2][total] (operands of the form-1 forward products)
         self._pair_tag = None
         # transposed images: bf16 planes (`_tp`) and fp16-pair planes (`_tq`); jobs: (offset, rows, cols) -> (slot offset, ld)
@@ -113,6 +114,7 @@ class FlatGroup:
         (`p.data.copy_(...)`, `p.data.mul_(...)`: EMA / weight-tying code) moves none of these counters -- call this, or
         vbg.ops.bump_weight_epoch(), after such a write"""
         self._planes_tag = self._pair_tag = self._tp["tag"] = self._tq["tag"] = None
+        self._plain_tags.clear()
         self._ver.clear()
 
     def _tag(self):
@@ -136,6 +138,18 @@ class FlatGroup:
             return None
         if self._planes is None:
             self._planes = torch.empty((3, self.total), device=self.pflat.device, dtype=torch.int16)
+        key = (off, rows, cols)
+        self._plain_keys.add(key)
+        if len(self._plain_keys) <= 16:
+            # few matrices want the bf16 image (with the fp16-pair forms on: the 12 attention-output projections of bert-base, 7 MB of a
+            # 435 MB buffer): each is split on its own, once per parameter version -- not the whole buffer (0.2 ms per step)
+            tag = (self._tag(), ver)
+            if self._plain_tags.get(key) != tag:
+                with torch.no_grad():
+                    ops.split_planes(self.pflat.detach()[off:off + rows * cols].view(rows, cols),
+                                     out=ops.Planes(self._planes[:, off:off + rows * cols].view(3, rows, cols), rows, cols, cols))
+                self._plain_tags[key] = tag
+            return ops.Planes(self._planes[:, off:off + rows * cols].view(3, rows, cols), rows, cols, cols)
         if self._stale("p", off, ver):
             with torch.no_grad():
                 ops.split_planes(self.pflat.detach().view(-1, 32), out=ops.Planes(self._planes.view(3, -1, 32), self.total // 32, 32, 32))
