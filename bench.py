@@ -368,7 +368,7 @@ def main():
             fp32_leg = {"value": round(B * world * args.steps / fdt, 3), "unit": "docs/sec", "ms_per_step": round(1e3 * fdt / args.steps, 3),
                         "dtype": "f32 MFMA (v_mfma_f32_32x32x2_f32) for every product"}
             # ... and the strict six-product form everywhere: no fp16-pair products (forward BERT linears, wide 3x3 convolutions)
-            ops.set_pair(False)
+            ops.set_pair(False)          # (also takes the BERT backward off the pair form)
             ops.set_conv3_f16(False)
             sdt, _ = timed_leg()
             ops.set_pair(True)
@@ -419,7 +419,7 @@ def main():
             "dtype": "bf16" if args.amp else "f32", "data": "synthetic",
             "arithmetic": ("bf16 MFMA products of fp32 tensors, f32 accumulate" if args.amp else
                            "f32 MFMA for every product" if args.fp32_mfma else
-                           "fp32-grade on the bf16 / fp16 matrix cores, f32 accumulate: (a) exact 3-way bf16 split of every operand, 6 piece products per product -- every backward product of BERT, fused attention, the generic convolutions, 1x1 / heads; (b) 2 fp16 pieces per operand (round to nearest, hi + lo 2^-11: 2^-23 relative), 3 piece products, same measured error against fp64 -- the forward BERT linears QKV / FFN1 / FFN2 and the wide 3x3 convolutions forward, input gradient and weight gradient (gradient operands scaled by the power of two that centres their largest magnitude in fp16's range: exact); an operand outside fp16's range becomes inf, never a clipped value; the 64-filter and strided conv weight gradients and the unaligned stem on the f32 MFMA; the strict form (a) everywhere is the `bf16x3_strict` leg"),
+                           "fp32-grade on the bf16 / fp16 matrix cores, f32 accumulate: (a) exact 3-way bf16 split of every operand, 6 piece products per product -- fused attention, the attention-output projection, the generic convolutions, 1x1 / heads; (b) 2 fp16 pieces per operand (round to nearest, hi + lo 2^-11: 2^-23 relative), 3 piece products, same measured error against fp64 -- the BERT linears QKV / FFN1 / FFN2 forward, all BERT data and weight gradients, and the wide 3x3 convolutions forward, input gradient and weight gradient (gradient operands scaled by the power of two that centres their largest magnitude in fp16's range: exact); an operand outside fp16's range becomes inf, never a clipped value; the 64-filter and strided conv weight gradients and the unaligned stem on the f32 MFMA; the strict form (a) everywhere is the `bf16x3_strict` leg"),
             "config": {"workload": ("SROIE line-level cfg2: resnet_34_fpn_pretrained + bert-base-uncased (12L, vocab 30522, random init), "
                                     f"512x512, T=512 tokens, S=128 segments, batch {B}/GPU, fwd+bwd+SGD/AdamW, dropout 0.1, simp classifier")
                        if args.shape == "cfg2" else f"EXPLORATORY {args.shape}: {shape}, T=512, batch {B}/GPU (not the BASELINE metric's configuration)",
@@ -435,7 +435,7 @@ def main():
             "roofline": {"bound": "mfma",
                          "kernel": ("vbg::gemm_kernel<*,*,*,DENSE_K,DENSE_K,*,1> (bf16 MFMA NT GEMM, amp; every ungrouped launch)" if args.amp else
                                     "vbg::gemm_kernel<*,*,*,DENSE_K,DENSE_K,*,0> (fp32 MFMA NT GEMM; every ungrouped launch)" if args.fp32_mfma else
-                                    "vbg::plane_gemm_kernel<*,*,*,*,*,false,*,0|1> + vbg::gemm_kernel<*,*,*,DENSE_K,DENSE_K,*,3> (fp32-grade NT GEMM: the BERT linears from pre-split planes -- forward QKV / FFN1 / FFN2 as 3 fp16 piece products, the rest as 6 bf16 piece products --, 1x1 convs / heads with the in-kernel split; every ungrouped launch, timed in a leg of its own)"),
+                                    "vbg::plane_gemm_kernel<*,*,*,*,*,false,*,0|1> + vbg::gemm_kernel<*,*,*,DENSE_K,DENSE_K,*,3> (fp32-grade NT GEMM: the BERT linears from pre-split planes -- forward QKV / FFN1 / FFN2 and the data gradients as 3 fp16 piece products, the attention-output projection as 6 bf16 piece products --, 1x1 convs / heads with the in-kernel split; every ungrouped launch, timed in a leg of its own)"),
                          "achieved": round(mfma_rate, 1), "peak": round(mfma_peak, 1), "unit": "TFLOP/s", "frac": round(mfma_rate / mfma_peak, 4),
                          "achieved_fp32_equivalent": round(ach, 2), "piece_products_per_product": round(mfma_flops / max(flops, 1.0), 3),
                          "traffic": traffic, "traffic_source": traffic_src, "launches": launches, "avg_us": round(1e3 * ms / max(launches, 1), 2),
