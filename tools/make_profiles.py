@@ -126,7 +126,7 @@ for r in rows:
     if "plane_gemm_kernel" in nme:
         tn = re.search(r"plane_gemm_kernel<\d+, \d+, \d+, \d+, \d+, true", nme) is not None
         pair = re.search(r", 1>\(", nme) is not None
-        key = "plane GEMM TN (dense wgrad)" if tn else ("plane GEMM NT, fp16-pair form (forward QKV / FFN1 / FFN2)" if pair else "plane GEMM NT, bf16x3 form (dgrad, attention out)")
+        key = "plane GEMM TN (dense wgrad)" if tn else ("plane GEMM NT, fp16-pair form (QKV / FFN1 / FFN2 forward, data gradients)" if pair else "plane GEMM NT, bf16x3 form (attention out)")
     elif "conv3x3_wgrad" in nme or "conv3_wgrad_reduce" in nme: key = "conv wgrad, row-reuse kernel (conv3.hip)"
     elif "conv3x3_kernel" in nme or "conv3_wflip" in nme: key = "conv fwd + dgrad, row-reuse kernel (conv3.hip)"
     elif "gemm_kernel" in nme:
