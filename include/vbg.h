@@ -231,9 +231,17 @@ int vbg_colsum_f64(const float* x, long long ld, int M, int N, float* out, int a
  * (csrc/conv3.hip): y[B,H,W,N] (+)= conv(x[B,H,W,Cs], w[N,3,3,Cs]) (+ bias); stats: BatchNorm slot workspace [slots][2][N] fp64 that
  * receives the per-channel sum / sum of squares of y (not with accumulate).  Replaces torch.nn.Conv2d(k=3, s=1, p=1) forward
  * (model/ResNetFPN_ViBERTgrid.py:478-508, 612-648; model/semantic_segmentation_head.py) and, with the filter written by
- * vbg_conv3x3_wflip, its input gradient.  Requires W a power of two >= 16, H*W % 64 == 0, Cs % 16 == 0, N % 4 == 0. */
+ * vbg_conv3x3_wflip, its input gradient.  Requires W a power of two >= 16, H*W % 64 == 0, Cs % 16 == 0, N % 4 == 0 -- or H = W = 7:
+ * the [B,7,7,C] region-of-interest maps of the field-type head (model/field_type_classification_head.py:64-75), stored compactly, two
+ * images per 128-row tile.  Filter counts that are odd multiples of 64 run 64-filter tiles.
+ * nsplit > 1 (vbg_conv3x3_split(...) says how many: the late trunk stages with 64-128 tiles of 2304-4608 long reductions): nsplit
+ * workgroups share a tile, each reducing one filter row (nsplit % 3 == 0) and / or one channel group; they meet through split_slab
+ * ([tiles][nsplit][128*128] floats of caller scratch) and split_tickets ([tiles] words, zero on entry and left zero), the last
+ * arriver adding the partial tiles in a fixed order (deterministic).  nsplit = 1: both may be NULL. */
+int vbg_conv3x3_split(int B, int H, int W, int Cs, int N);
 int vbg_conv3x3(const float* x, const float* w, const float* bias, float* y, double* stats, int stats_slots, int B, int H, int W,
-                int Cs, int N, int accumulate, int form, const unsigned* x_amax, void* stream);
+                int Cs, int N, int accumulate, int form, const unsigned* x_amax, float* split_slab, unsigned* split_tickets,
+                int nsplit, void* stream);
 /* form 0: three bf16 pieces per operand, six piece products (any operands); form 1: two fp16 pieces (round to nearest), three piece
  * products -- same measured accuracy against fp64 and half the matrix-core work, for operands inside fp16's range; a magnitude of
  * 65520 or more becomes inf, never a silently clipped value.  x_amax (form 1, optional): amax slot (below) holding the bit pattern of
@@ -256,7 +264,8 @@ int vbg_conv3x3_wflip(const float* w, int Cout, int Cin, float* out, void* strea
  * The pixel range is cut into vbg_conv3x3_wgrad_strips(...) strips; slab = [strips][Cout,3,3,Cs] scratch -> each strip stores its
  * partial result plainly and a second launch adds them into dw in a fixed order (deterministic); slab = NULL -> float atomics.
  * Replaces the weight gradient autograd forms for torch.nn.Conv2d(k=3, s=1, p=1).  Requires W % 16 == 0, Cs % 32 == 0 and
- * Cout % 128 == 0 (or Cout % 64 == 0 and Cs % 64 == 0). */
+ * Cout % 128 == 0 (or Cout % 64 == 0 and Cs % 64 == 0); or H = W = 7 (region maps, Cout % 128 == 0): a k-tile is then two rows of the
+ * image's 8 x 8 slot grid. */
 int vbg_conv3x3_wgrad_strips(int B, int H, int W, int Cs, int Cout);
 int vbg_conv3x3_wgrad(const float* dy, const float* x, float* dw, float* slab, int B, int H, int W, int Cs, int Cout, int form,
                       const unsigned* dy_amax, const unsigned* x_amax, void* stream);

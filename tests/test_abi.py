@@ -37,7 +37,11 @@ def test_conv3_host_logic_without_a_gpu():
     weight gradient gives whole rounds of workgroups with at least 8 k-tiles per strip on the cfg2 shapes"""
     from vbg import lib as L
     f = L.lib.vbg_conv3x3
-    assert f(None, None, None, None, None, 0, 1, 16, 128, 16, 128, 0, 0, None, None) == -1   # null operands
+    assert f(None, None, None, None, None, 0, 1, 16, 128, 16, 128, 0, 0, None, None, None, 1, None) == -1   # null operands
+    split = L.lib.vbg_conv3x3_split
+    # late trunk stages (cfg2: 8 x 32 x 32 x 256, 8 x 16 x 16 x 512): >= 256 workgroups; wide maps, region maps, 64 filters: no split
+    assert split(8, 32, 32, 256, 256) * 128 >= 256 and split(8, 16, 16, 512, 512) * 64 >= 256
+    assert split(8, 128, 128, 256, 256) == 1 and split(8, 64, 64, 128, 128) == 1 and split(1024, 7, 7, 256, 256) == 1 and split(8, 32, 32, 64, 64) == 1
     strips = L.lib.vbg_conv3x3_wgrad_strips
     for (B, H, W, Cs, Cout, blocks) in [(8, 128, 128, 256, 256, 512), (8, 128, 128, 128, 128, 256), (8, 64, 64, 128, 128, 256),
                                         (8, 32, 32, 256, 256, 256), (8, 16, 16, 512, 512, 256)]:

@@ -52,10 +52,12 @@ def _cfg(v="generic"):
 
 def _dispatch(ops, v):
     """one kernel family on both sides: the generic kernels, or the row-reuse kernels whatever the tile count (1 document per rank
-    and 2 documents in one process would otherwise fall on different sides of the thresholds)"""
+    and 2 documents in one process would otherwise fall on different sides of the thresholds), and no split of a tile's reduction over
+    several workgroups (their number follows the tile count: 3 or 4 partial sums instead of 1 regroup the fp32 additions)"""
     if VARIANTS[v]["conv3"]:
         ops.set_conv3(True)
         ops._CONV3_MIN_TILES[0] = ops._CONV3_MIN_TILES_FWD[0] = ops._CONV3W_MIN[0] = 1
+        ops._CONV3_SPLITK[0] = False
     else:
         ops.set_conv3(False)
 
@@ -162,14 +164,14 @@ def test_two_ranks_syncbn_equals_one_process(tmp_path, v):
     dev = torch.device("cuda")
     net = _build(os.path.join(tmp, "single"), sync_bn=False, v=v).to(dev).train()
     random.seed(5)
-    saved = (ops._CONV3_MIN_TILES[0], ops._CONV3_MIN_TILES_FWD[0], ops._CONV3W_MIN[0])
+    saved = (ops._CONV3_MIN_TILES[0], ops._CONV3_MIN_TILES_FWD[0], ops._CONV3W_MIN[0], ops._CONV3_SPLITK[0])
     _dispatch(ops, v)
     try:
         loss = net(*to_dev(_docs(), dev))
         loss.backward()
     finally:
         ops.set_conv3(True)
-        ops._CONV3_MIN_TILES[0], ops._CONV3_MIN_TILES_FWD[0], ops._CONV3W_MIN[0] = saved
+        ops._CONV3_MIN_TILES[0], ops._CONV3_MIN_TILES_FWD[0], ops._CONV3W_MIN[0], ops._CONV3_SPLITK[0] = saved
     avg_loss = 0.5 * (r0["loss"] + r1["loss"])
     print("loss single", float(loss.detach()), "mean of ranks", avg_loss)
     assert abs(float(loss.detach()) - avg_loss) <= 1e-5 * abs(avg_loss)

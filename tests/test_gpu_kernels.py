@@ -196,7 +196,11 @@ def test_conv(ops, Cin, Cout, k, stride, pad, H, W):
                                         # 64-pixel tiles (few pixels): two / four image rows per tile
                                         (3, 6, 32, 32, 128), (2, 12, 16, 32, 256), (8, 32, 32, 64, 256),
                                         # rows wider than a tile: the neighbouring pixels are fetched into the halo rows
-                                        (2, 5, 256, 32, 128), (1, 3, 512, 16, 132)])
+                                        (2, 5, 256, 32, 128), (1, 3, 512, 16, 132),
+                                        # 64-filter tiles (odd multiples of 64 filters)
+                                        (1, 128, 128, 64, 64), (2, 8, 128, 32, 64), (2, 4, 128, 16, 192),
+                                        # 7 x 7 region maps stored compactly: two images per tile (an odd count leaves half a tile)
+                                        (5, 7, 7, 32, 128), (8, 7, 7, 64, 256), (1, 7, 7, 16, 64)])
 def test_conv3x3_row_reuse(ops, B, H, W, Cs, N):
     """csrc/conv3.hip (activation rows shared by the three horizontal taps) against fp64 torch conv2d: forward with bias and fused
     BatchNorm statistics, accumulate, the input gradient through the turned filter; and against the generic implicit GEMM (same
@@ -254,9 +258,47 @@ def test_conv3x3_row_reuse(ops, B, H, W, Cs, N):
         assert not bool(torch.isfinite(ops.conv3x3(gyh * 1e6, wf, f16x2=True)).all())
 
 
+@pytest.mark.parametrize("B,H,W,Cs,N,nz", [(8, 32, 32, 64, 256, 3), (8, 32, 32, 64, 256, 4), (2, 16, 16, 96, 128, 6), (2, 16, 16, 96, 128, 2),
+                                           (4, 16, 16, 192, 384, 12), (1, 8, 16, 32, 128, 3)])
+def test_conv3x3_split(ops, B, H, W, Cs, N, nz):
+    """split form of csrc/conv3.hip (nz workgroups per tile, one filter row and / or channel group each, slabs + arrival ticket, the
+    last arriver adds them in block order): against fp64 conv2d with bias and fused BatchNorm statistics, both arithmetic forms, the
+    input-gradient use (scaled operand, accumulate), run-to-run bit-identical, the tickets left at zero"""
+    x = rnd(B, Cs, H, W, seed=160)
+    w = rnd(N, Cs, 3, 3, seed=161) / math.sqrt(Cs * 9)
+    b = rnd(N, seed=162)
+    ref = F.conv2d(x.double(), w.double(), b.double(), 1, 1).float().permute(0, 2, 3, 1)
+    xh = x.permute(0, 2, 3, 1).contiguous().to(dev())
+    wh = w.permute(0, 2, 3, 1).contiguous().to(dev())
+    bh = b.to(dev())
+    tol = 3e-6 * float(ref.abs().max())
+    for f16 in (False, True):
+        stats = torch.zeros(ops.bn_slots() * 2 * N, device=dev(), dtype=torch.float64)
+        y = ops.conv3x3(xh, wh, bh, stats=stats, f16x2=f16, nsplit=nz)
+        assert close(y, ref, 2e-5, tol), f16
+        y1 = ops.conv3x3(xh, wh, bh, f16x2=f16, nsplit=1)
+        assert close(y, y1, 1e-5, tol)
+        assert torch.equal(y, ops.conv3x3(xh, wh, bh, f16x2=f16, nsplit=nz))
+        st = stats.view(-1, 2, N).sum(0).cpu()
+        y2 = ref.double().reshape(-1, N)
+        assert torch.allclose(st[0], y2.sum(0), rtol=1e-5, atol=1e-4) and torch.allclose(st[1], (y2 * y2).sum(0), rtol=1e-5, atol=1e-4)
+    # gradient-like operand: scaled through its amax slot, accumulated into an existing tensor
+    g = xh * 2.0 ** -24
+    base = ((ref - b.view(1, 1, 1, N)) * 2.0 ** -24).contiguous().to(dev())
+    acc = base.clone()
+    ops.conv3x3(g, wh, None, out=acc, accumulate=True, f16x2=True, x_amax=ops.amax(g), nsplit=nz)
+    assert close(acc * 2.0 ** 23, ref - b.view(1, 1, 1, N), 2e-5, 2 * tol)
+    assert all(int(t.abs().max().item()) == 0 for t in ops._CONV3_TICKETS.values())
+    # the library's own choice for the late trunk stages puts at least 256 workgroups on the chip
+    assert ops.conv3_split(8, 32, 32, 256, 256) * 128 >= 256 and ops.conv3_split(8, 16, 16, 512, 512) * 64 >= 256
+    assert ops.conv3_ok(8, 32, 32, 256, 256, 3, 3, 1, 1) and ops.conv3_ok(8, 16, 16, 512, 512, 3, 3, 1, 1)
+
+
 @pytest.mark.parametrize("B,H,W,Cs,Cout", [(2, 8, 32, 32, 128), (3, 4, 16, 64, 64), (1, 16, 64, 96, 256), (2, 5, 48, 64, 192),
                                            # image rows of 128 / 256 pixels (cfg2's 128 x 128 and cfg5's 256 x 256 maps): 8 / 16 k-tiles per row
-                                           (2, 6, 128, 64, 128), (1, 5, 256, 32, 128), (2, 3, 256, 64, 256)])
+                                           (2, 6, 128, 64, 128), (1, 5, 256, 32, 128), (2, 3, 256, 64, 256),
+                                           # 7 x 7 region maps: a k-tile is two rows of the image's 8 x 8 slot grid
+                                           (5, 7, 7, 32, 128), (9, 7, 7, 64, 256)])
 @pytest.mark.parametrize("slabs", [True, False])
 def test_conv3x3_wgrad(ops, B, H, W, Cs, Cout, slabs):
     """csrc/conv3.hip weight gradient (transposing LDS reads, X loaded once for nine taps) against fp64 autograd; accumulates into dw;
@@ -297,7 +339,7 @@ def test_conv3x3_wgrad(ops, B, H, W, Cs, Cout, slabs):
 def test_conv3x3_dispatch(ops):
     """conv2d_fwd / conv2d_dgrad take the row-reuse kernel for a wide trunk shape and agree with the generic path"""
     B, H, W, C = 2, 128, 128, 128
-    assert ops.conv3_ok(B, H, W, C, C, 3, 3, 1, 1) and not ops.conv3_ok(B, H, W, C, C, 3, 3, 2, 1) and not ops.conv3_ok(B, 16, 16, C, C, 3, 3, 1, 1)
+    assert ops.conv3_ok(B, H, W, C, C, 3, 3, 1, 1) and not ops.conv3_ok(B, H, W, C, C, 3, 3, 2, 1) and not ops.conv3_ok(1, 16, 16, C, C, 3, 3, 1, 1)
     xh = rnd(B, H, W, C, seed=64).to(dev())
     wh = (rnd(C, 3, 3, C, seed=65) / 34).to(dev())
     gy = rnd(B, H, W, C, seed=66).to(dev())

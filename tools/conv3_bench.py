@@ -13,7 +13,7 @@ from gemm_bench import report, timeit
 from vbg import ops
 
 dev = torch.device("cuda")
-for (B, H, W, Ci, Co) in [(8, 128, 128, 256, 256), (8, 128, 128, 128, 128), (8, 64, 64, 128, 128), (8, 64, 64, 256, 256), (8, 32, 32, 256, 256), (8, 16, 16, 512, 512), (8, 128, 128, 64, 64)]:
+for (B, H, W, Ci, Co) in [(8, 128, 128, 256, 256), (8, 128, 128, 128, 128), (8, 64, 64, 128, 128), (8, 64, 64, 256, 256), (8, 32, 32, 256, 256), (8, 16, 16, 512, 512), (8, 128, 128, 64, 64), (1024, 7, 7, 256, 256)]:
     x = torch.randn(B, H, W, Ci, device=dev)
     w = torch.randn(Co, 3, 3, Ci, device=dev) / (3 * Ci ** 0.5)
     dy = torch.randn(B, H, W, Co, device=dev)
@@ -34,3 +34,13 @@ for (B, H, W, Ci, Co) in [(8, 128, 128, 256, 256), (8, 128, 128, 128, 128), (8, 
     y0 = ops.conv2d_fwd(x, w, 1, 1)
     ops.set_conv3(True)
     print("   max |conv3 - generic| =", float((y1 - y0).abs().max()), " max |y| =", float(y0.abs().max()), flush=True)
+
+# split form of the forward / input-gradient kernel on the late trunk stages: workgroups per tile
+ops.set_conv3(True)
+for (B, H, W, Ci, Co) in [(8, 32, 32, 256, 256), (8, 16, 16, 512, 512)]:
+    x = torch.randn(B, H, W, Ci, device=dev)
+    w = torch.randn(Co, 3, 3, Ci, device=dev) / (3 * Ci ** 0.5)
+    fl = 2.0 * B * H * W * Ci * Co * 9
+    for f16 in (True, False):
+        for nz in (1, 2, 3, 4, 6, 8, 12):
+            report(f"conv3 {'f16x2' if f16 else 'bf16x3'} B{B} {H}x{W} {Ci}->{Co} nsplit {nz}", fl, timeit(lambda: ops.conv3x3(x, w, f16x2=f16, nsplit=nz)))

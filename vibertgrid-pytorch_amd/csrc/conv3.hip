@@ -33,6 +33,10 @@ struct conv3_args {
     double* stats;         // BatchNorm slot workspace [slots][2][N] or null
     int stats_slots;
     int H, W, wsh, Cs, N, M;
+    int roi;               // 0, or the number of 7 x 7 images: pixel tiles are 8 x 8 SLOT grids over compactly stored 7 x 7 images (below)
+    int ksplit, csplit;    // reduction split over gridDim.z = ksplit * csplit blocks per tile: filter rows (1 or 3) x channel groups
+    float* slab;           // [tiles][gridDim.z][BM * BN] partial tiles of the split form
+    unsigned* tickets;     // [tiles] arrival counters of the split form, zero between launches
     int accumulate;
     const unsigned* a_amax; // F16 form: bits of max |X| (a device word written by the producer of X), or null: X is used as it is
 };
@@ -99,9 +103,20 @@ struct c3_pipe {
 // fp16 pieces, three piece products with the two cross products in their own accumulators (scaled by 2^11), for operands inside fp16's
 // range (forward activations and filters; NOT gradients).  Measured against fp64 on the same data the two forms are equally accurate
 // (1.7e-7 vs 2.5e-7 of the summed magnitudes) and F16 needs half the matrix-core work: 457 vs 701 us at 256 x 256, 128 x 128 pixels.
-template <int BM, bool F16>
+//
+// BN = 128 filters per tile, or 64 (the 64-channel stage of the trunk: waves 2 x 2 of BM / 2 pixels x 32 filters).
+//
+// ROI mode (p.roi = number of images, H = W = 7: the [N * 49, C] region-of-interest maps of the field-type head, reference
+// model/field_type_classification_head.py:64-75): a 128-row tile is TWO images, each laid out as an 8 x 8 grid of slots whose
+// eighth row and column do not exist in memory -- their loads carry the invalid offset and read 0, so slot x = 7 is the zero pixel
+// between image rows that the W >= 16 layout inserts explicitly, and slot row y = 7 the zero row under the image.  Slots map to the
+// compact rows (image * 49 + y * 7 + x) in the loader and in the epilogue (invalid slots are neither stored nor counted in the
+// statistics); 49 of 64 MFMA rows are useful, against which the generic kernel's nine-fold re-fetch and re-split costs more.
+template <int BM, int BN, bool F16>
 __global__ __launch_bounds__(256, 2) void conv3x3_kernel(const conv3_args p) {
-    constexpr int BN = 128, NT = 256, SKH = 24;
+    constexpr int NT = 256, SKH = 24;
+    constexpr int TNF = BN / 64;                               // 32-column fragments per wave
+    constexpr int NBI = BN * 4 / NT;                           // filter float4s per thread and tile
     constexpr int NPL = F16 ? 2 : 3;                           // planes per operand tile
     constexpr int NAI = BM * 4 / NT;                           // activation float4s per thread and super-tile
     constexpr int TM = BM / 64;                                // 32-row fragments per wave (waves 2 x 2: BM / 2 pixels x 64 filters each)
@@ -136,21 +151,25 @@ __global__ __launch_bounds__(256, 2) void conv3x3_kernel(const conv3_args p) {
 
     // ---------------- loader state -------------------------------------------------------------
     const int HW = H * W;
-    const int nb = m0 / HW, p0 = m0 - nb * HW;                 // the tile lies inside one image (H*W % 128 == 0)
+    const int roi = p.roi;
+    const int nb = roi ? (int)tile_m * (BM / 64) : m0 / HW;    // the tile lies inside one image (H*W % 128 == 0); ROI: its first image
+    const int p0 = roi ? 0 : m0 - nb * HW;
     const float* const a_img = p.X + (long long)nb * HW * Cs;
     const int kc = (tid & 3) * 4;                              // this thread's 4 channels of a 16-channel chunk
-    int a_y[NAI], a_x[NAI], a_lrow[NAI];
-    unsigned avo[NAI], bvo[2];
+    const int psh = roi ? 31 : wsh;                            // (ROI: no explicit zero pixels between the rows)
+    int a_y[NAI], a_x[NAI], a_lrow[NAI], a_off[NAI];
+    unsigned avo[NAI], bvo[NBI];
 #pragma unroll
     for (int i = 0; i < NAI; ++i) {
         const int r = (tid + i * NT) >> 2;
         const int pix = p0 + r;
-        a_x[i] = pix & (W - 1);
-        a_y[i] = pix >> wsh;
-        a_lrow[i] = r + 1 + 2 * (r >> wsh);
+        a_x[i] = roi ? (r & 7) : (pix & (W - 1));
+        a_y[i] = roi ? ((r >> 3) & 7) : (pix >> wsh);
+        a_off[i] = roi ? ((r >> 6) * 49 + ((nb + (r >> 6) < roi && (r & 7) < 7 && ((r >> 3) & 7) < 7) ? 0 : (1 << 24))) : 0;   // image of the slot (or: no such pixel)
+        a_lrow[i] = r + 1 + 2 * (r >> psh);
     }
 #pragma unroll
-    for (int i = 0; i < 2; ++i) {
+    for (int i = 0; i < NBI; ++i) {
         const int r = (tid + i * NT) >> 2;
         bvo[i] = (n0 + r < N) ? (unsigned)((r * K + kc) * 4) : C3_INVALID;
     }
@@ -164,30 +183,35 @@ __global__ __launch_bounds__(256, 2) void conv3x3_kernel(const conv3_args p) {
 #pragma unroll
         for (int i = 0; i < NAI; ++i) {
             const int sy = a_y[i] + kh - 1;
-            avo[i] = ((unsigned)sy < (unsigned)H) ? (unsigned)(((sy * W + a_x[i]) * Cs + kc) * 4) : C3_INVALID;
+            avo[i] = ((unsigned)sy < (unsigned)H && a_off[i] < (1 << 24)) ? (unsigned)(((a_off[i] + sy * W + a_x[i]) * Cs + kc) * 4) : C3_INVALID;
         }
         const int sy = h_y + kh - 1;
         hvo = (wide && tid < 8 && (unsigned)sy < (unsigned)H && (unsigned)h_x < (unsigned)W) ? (unsigned)(((sy * W + h_x) * Cs + kc) * 4) : C3_INVALID;
     };
     const float* const wbase = p.Wt + (long long)n0 * K;
-    float4 ra[NAI], rb[2];
-    int a_kh = 0, a_c0 = 0;                    // next activation super-tile (filter row, channel chunk) to load
-    int b_kh = 0, b_c0 = 0, b_kw = 0;          // next weight tile to load: order (kh, chunk, kw)
+    float4 ra[NAI], rb[NBI];
+    // Split form (few pixel tiles: the late stages of the trunk): gridDim.z blocks share a tile, each reducing over one filter row
+    // (ksplit = 3) and / or one group of channels; they meet in the epilogue (slabs + arrival ticket, below)
+    const int nz = (int)gridDim.z, zz = (int)blockIdx.z;
+    const int kh0 = p.ksplit == 3 ? zz % 3 : 0;
+    const int cw = Cs / p.csplit, cbeg = (p.ksplit == 3 ? zz / 3 : zz) * cw, cend = cbeg + cw;
+    int a_kh = kh0, a_c0 = cbeg;               // next activation super-tile (filter row, channel chunk) to load
+    int b_kh = kh0, b_c0 = cbeg, b_kw = 0;     // next weight tile to load: order (kh, chunk, kw)
     auto load_a = [&]() {
         const __amdgpu_buffer_rsrc_t r = c3_rsrc(a_img + a_c0);
 #pragma unroll
         for (int i = 0; i < NAI; ++i) ra[i] = c3_load(r, avo[i]);
         if (wide) rh = c3_load(r, hvo);
         a_c0 += 16;
-        if (a_c0 >= Cs) { a_c0 = 0; ++a_kh; set_a(a_kh); }
+        if (a_c0 >= cend) { a_c0 = cbeg; ++a_kh; set_a(a_kh); }
     };
     auto load_b = [&]() {
         const __amdgpu_buffer_rsrc_t r = c3_rsrc(wbase + (b_kh * 3 + b_kw) * Cs + b_c0);
-        rb[0] = c3_load(r, bvo[0]);
-        rb[1] = c3_load(r, bvo[1]);
+#pragma unroll
+        for (int i = 0; i < NBI; ++i) rb[i] = c3_load(r, bvo[i]);
         if (++b_kw == 3) {
             b_kw = 0; b_c0 += 16;
-            if (b_c0 >= Cs) { b_c0 = 0; ++b_kh; }
+            if (b_c0 >= cend) { b_c0 = cbeg; ++b_kh; }
         }
     };
     auto store4 = [&](unsigned* dst, int PL, int row, const float4& v) {
@@ -214,19 +238,19 @@ __global__ __launch_bounds__(256, 2) void conv3x3_kernel(const conv3_args p) {
         if (wide && tid < 8) store4(As + buf * ASZ, PA, h_row, F16 ? scaled(rh) : rh);
     };
     auto store_b = [&](int buf) {
-        store4(Bs + buf * BSZ, PB, tid >> 2, rb[0]);
-        store4(Bs + buf * BSZ, PB, (tid + NT) >> 2, rb[1]);
+#pragma unroll
+        for (int i = 0; i < NBI; ++i) store4(Bs + buf * BSZ, PB, (tid + i * NT) >> 2, rb[i]);
     };
 
     // ---------------- main loop ---------------------------------------------------------------
     const int lane = tid & 63, wave = tid >> 6;
     const int wm = wave >> 1, wn = wave & 1;
     const int lr = lane & 31, lk = lane >> 5;
-    f32x16 acc[TM][2], acx[F16 ? TM : 1][2];                   // (F16: the cross products hi lo + lo hi, scaled by 2^11)
+    f32x16 acc[TM][TNF], acx[F16 ? TM : 1][TNF];               // (F16: the cross products hi lo + lo hi, scaled by 2^11)
 #pragma unroll
     for (int i = 0; i < TM; ++i)
 #pragma unroll
-        for (int j = 0; j < 2; ++j)
+        for (int j = 0; j < TNF; ++j)
 #pragma unroll
             for (int r = 0; r < 16; ++r) {
                 acc[i][j][r] = 0.f;
@@ -236,9 +260,9 @@ __global__ __launch_bounds__(256, 2) void conv3x3_kernel(const conv3_args p) {
 #pragma unroll
     for (int i = 0; i < TM; ++i) {
         const int r = wm * (BM / 2) + i * 32 + lr;
-        arow[i] = r + 2 * (r >> wsh);                         // LDS row of pixel x - 1 (tap kw adds kw)
+        arow[i] = r + 2 * (r >> psh);                         // LDS row of pixel x - 1 (tap kw adds kw)
     }
-    const int brow = wn * 64 + lr;
+    const int brow = wn * (BN / 2) + lr;
 
     using yes_t = std::integral_constant<bool, true>;
     using no_t = std::integral_constant<bool, false>;
@@ -248,13 +272,13 @@ __global__ __launch_bounds__(256, 2) void conv3x3_kernel(const conv3_args p) {
         constexpr bool LOADA = decltype(loada_tag)::value, MORE = decltype(more_tag)::value;
         const c3_u32x4* as = reinterpret_cast<const c3_u32x4*>(As + abuf * ASZ);
         const c3_u32x4* bs = reinterpret_cast<const c3_u32x4*>(Bs + bbuf * BSZ);
-        c3_u32x4 fa[NPL][TM], fb[NPL][2];
+        c3_u32x4 fa[NPL][TM], fb[NPL][TNF];
 #pragma unroll
         for (int q = 0; q < NPL; ++q) {
 #pragma unroll
             for (int i = 0; i < TM; ++i) fa[q][i] = as[q * (PA / 4) + (arow[i] + kw) * (SKH / 8) + lk];
 #pragma unroll
-            for (int j = 0; j < 2; ++j) fb[q][j] = bs[q * (PB / 4) + (brow + j * 32) * (SKH / 8) + lk];
+            for (int j = 0; j < TNF; ++j) fb[q][j] = bs[q * (PB / 4) + (brow + j * 32) * (SKH / 8) + lk];
         }
         __builtin_amdgcn_sched_barrier(0);
         if constexpr (MORE) load_b();
@@ -268,7 +292,7 @@ __global__ __launch_bounds__(256, 2) void conv3x3_kernel(const conv3_args p) {
 #pragma unroll
                 for (int i = 0; i < TM; ++i)
 #pragma unroll
-                    for (int n = 0; n < 2; ++n) {
+                    for (int n = 0; n < TNF; ++n) {
                         if constexpr (F16) {
                             f32x16& d = t < 2 ? acx[i][n] : acc[i][n];
                             d = __builtin_amdgcn_mfma_f32_32x32x16_f16(__builtin_bit_cast(c3_f16x8, fa[t == 0 ? 1 : 0][i]),
@@ -288,9 +312,9 @@ __global__ __launch_bounds__(256, 2) void conv3x3_kernel(const conv3_args p) {
             mma_range(ih{}, i1{});
             store_b(bbuf ^ 1);
             if constexpr (LOADA) store_a(abuf ^ 1);
-            constexpr int NL = LOADA ? 2 + NAI : 2;
-            if constexpr (F16) c3_pipe<0, 4 * TM, NL * 10, NL * 2>::run();
-            else c3_pipe<0, 8 * TM, NL * 22, NL * 3>::run();
+            constexpr int NL = LOADA ? NBI + NAI : NBI;
+            if constexpr (F16) c3_pipe<0, 2 * TNF * TM, NL * 10, NL * 2>::run();
+            else c3_pipe<0, 4 * TNF * TM, NL * 22, NL * 3>::run();
             __builtin_amdgcn_sched_barrier(0);
             __syncthreads();
         } else {
@@ -301,14 +325,14 @@ __global__ __launch_bounds__(256, 2) void conv3x3_kernel(const conv3_args p) {
 
     // the zero pixels beside the image rows are written once; the loop only ever stores the pixel rows
     for (int e = tid; e < 2 * ASZ / 4; e += NT) reinterpret_cast<uint4*>(As)[e] = make_uint4(0u, 0u, 0u, 0u);
-    set_a(0);
+    set_a(kh0);
     load_a();
     load_b();
     __syncthreads();
     store_a(0);
     store_b(0);
     __syncthreads();
-    const int nsup = 3 * Cs / 16;
+    const int nsup = (p.ksplit == 3 ? 1 : 3) * cw / 16;
     int t = 0;
     for (int s = 0; s + 1 < nsup; ++s) {
         k_tile(no_t{}, yes_t{}, s & 1, t & 1, 0); ++t;
@@ -328,23 +352,66 @@ __global__ __launch_bounds__(256, 2) void conv3x3_kernel(const conv3_args p) {
     __syncthreads();
     float* const Ct = reinterpret_cast<float*>(smem);
 #pragma unroll
-    for (int j = 0; j < 2; ++j)
+    for (int j = 0; j < TNF; ++j)
 #pragma unroll
         for (int i = 0; i < TM; ++i)
 #pragma unroll
             for (int r = 0; r < 16; ++r)
-                Ct[(wm * (BM / 2) + i * 32 + (r & 3) + 8 * (r >> 2) + 4 * lk) * CTS + wn * 64 + j * 32 + lr] =
+                Ct[(wm * (BM / 2) + i * 32 + (r & 3) + 8 * (r >> 2) + 4 * lk) * CTS + wn * (BN / 2) + j * 32 + lr] =
                     F16 ? (acc[i][j][r] + acx[i][j][r] * (1.f / 2048.f)) * a_sc.y : acc[i][j][r];
     __syncthreads();
     constexpr int QN = BN / 4;
+    // Split form: the block's partial tile goes to its slab (write-through stores), every wave drains its stores, and one relaxed
+    // agent-scope ticket per block decides who finishes the tile: the LAST arriver (one agent-scope acquire) adds the gridDim.z slabs in
+    // block order -- its own included, so the sum does not depend on who came last -- and runs the epilogue.  Nobody waits.
+    const float* part = nullptr;
+    if (nz > 1) {
+        __shared__ unsigned ticket_s;
+        const size_t tile = (size_t)tile_n * gx + tile_m;
+        float* const mine = p.slab + (tile * nz + zz) * (size_t)(BM * BN);
+        const __amdgpu_buffer_rsrc_t rs = __builtin_amdgcn_make_buffer_rsrc(mine, 0, BM * BN * 4, 0x00020000);
+#pragma unroll 4
+        for (int q = 0; q < BM * QN / NT; ++q) {
+            const int idx = tid + q * NT;
+            const int row = idx / QN, c = (idx % QN) * 4;
+            const c3_u32x4 v = *reinterpret_cast<const c3_u32x4*>(&Ct[row * CTS + c]);
+            __builtin_amdgcn_raw_buffer_store_b128(v, rs, (row * BN + c) * 4, 0, 16 /* sc1: write-through */);
+        }
+        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+        __syncthreads();
+        if (tid == 0) ticket_s = __hip_atomic_fetch_add(p.tickets + tile, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        __syncthreads();
+        if (ticket_s != (unsigned)(nz - 1)) return;            // (uniform) somebody else finishes this tile
+        if (tid == 0) {
+            __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "agent");
+            __hip_atomic_store(p.tickets + tile, 0u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);          // ready for the next launch
+        }
+        __syncthreads();
+        part = p.slab + tile * nz * (size_t)(BM * BN);
+    }
     float4 cs = make_float4(0.f, 0.f, 0.f, 0.f), cq = cs;
 #pragma unroll 4
     for (int q = 0; q < BM * QN / NT; ++q) {
         const int idx = tid + q * NT;
         const int row = idx / QN, c = (idx % QN) * 4;
-        const int gm = m0 + row, gn = n0 + c;
+        int gm = m0 + row;
+        const int gn = n0 + c;
         if (gn >= N) continue;                                 // (N % 4 == 0: a float4 is inside or outside)
-        float4 v = *reinterpret_cast<const float4*>(&Ct[row * CTS + c]);
+        if (roi) {                                             // slot -> compact row; the eighth row / column and images past the last do not exist
+            const int im = nb + (row >> 6), sy = (row >> 3) & 7, sx = row & 7;
+            if (im >= roi || sy == 7 || sx == 7) continue;
+            gm = im * 49 + sy * 7 + sx;
+        }
+        float4 v;
+        if (part) {
+            v = make_float4(0.f, 0.f, 0.f, 0.f);
+            for (int b = 0; b < nz; ++b) {
+                const float4 o = *reinterpret_cast<const float4*>(part + (size_t)b * (BM * BN) + row * BN + c);
+                v.x += o.x; v.y += o.y; v.z += o.z; v.w += o.w;
+            }
+        } else {
+            v = *reinterpret_cast<const float4*>(&Ct[row * CTS + c]);
+        }
         if (bias) { v.x += bias[gn]; v.y += bias[gn + 1]; v.z += bias[gn + 2]; v.w += bias[gn + 3]; }
         float* cp = p.Y + (long long)gm * N + gn;
         if (p.stats) {
@@ -413,6 +480,7 @@ struct conv3w_args {
     float* slab;           // ... or [strips][Cout, 3, 3, Cs]: every strip stores its partial block plainly, conv3_wgrad_reduce_kernel adds them up
     int H, W, Cs, Cout;
     int nchunks, per;      // 16-pixel chunks in total / per strip
+    int roi;               // 1: H = W = 7 images stored compactly; a chunk is two rows of the image's 8 x 8 slot grid (see conv3x3_kernel)
     const unsigned* dy_amax;   // F16 form: bit patterns of max |dY| and max |X| (device words), the operands' power-of-two scales
     const unsigned* x_amax;
 };
@@ -426,7 +494,7 @@ typedef __attribute__((address_space(3))) unsigned char* c3_lds_bytes;
 // to [2^13, 2^14) (exact), three piece products (lo hi, hi lo, hi hi) into the ONE accumulator of a tap (nine taps x two accumulators
 // would not fit the register file), the result scaled back in the epilogue.  Elements down to 2^-17 of the tensor's maximum keep 22
 // significant bits (lo is a normal fp16 there); below that the absolute error is <= 2^-25 (2^-39 of the maximum).
-template <int WCO, bool F16>
+template <int WCO, bool F16, bool ROI = false>
 __global__ __launch_bounds__(256, 2) void conv3x3_wgrad_kernel(const conv3w_args p) {
     constexpr int NT = 256, WCI = 4 / WCO, CO = 32 * WCO, CI = 32 * WCI;
     constexpr int NPL = F16 ? 2 : 3;
@@ -452,31 +520,62 @@ __global__ __launch_bounds__(256, 2) void conv3x3_wgrad_kernel(const conv3w_args
     }
 
     // ---- loader: per-thread constants, per-chunk scalars -------------------------------------------------------------------
+    // ROI mode: the k-tile is 16 SLOTS = two rows of an image's 8 x 8 slot grid (slot x = 7 / row 7: no such pixel, read as 0), the X
+    // image the 34 slots from (row - 1, x - 1) on at pitch 8 -- the zero slot x = 7 doubles as the padding left of x = 0 -- so a tap is
+    // again a row offset, kh * 8 + kw.  49 of 64 reduction rows are real pixels.
+    constexpr bool roi = ROI;
+    constexpr int pitch = roi ? 8 : 18;
     unsigned avo[NDA], bvo[NDB];
-    int alds[NDA], blds[NDB], b_r3[NDB], b_px[NDB];
+    int alds[NDA], blds[NDB], b_r3[NDB], b_px[NDB], a_yy[NDA];
 #pragma unroll
     for (int i = 0; i < NDA; ++i) {
         const int e = tid + i * NT, px = e / QA, c4 = e % QA;
-        avo[i] = (unsigned)((px * Cout + co0 + 4 * c4) * 4);
+        avo[i] = roi ? (unsigned)((((px >> 3) * 7 + (px & 7)) * Cout + co0 + 4 * c4) * 4) : (unsigned)((px * Cout + co0 + 4 * c4) * 4);
+        a_yy[i] = (px & 7) == 7 ? 100 : (px >> 3);             // (ROI: row of the slot inside the chunk; 100: no such slot)
         alds[i] = px * RSA + c4 * 8;
     }
 #pragma unroll
     for (int i = 0; i < NDB; ++i) {
         const int e = tid + i * NT;
-        const int r3 = e / (18 * QB), rem = e - r3 * (18 * QB), px = rem / QB, c4 = rem % QB;
-        const bool ok = e < NXB;
-        b_r3[i] = ok ? r3 : 1000000;                           // (never inside the image)
-        b_px[i] = px;
-        bvo[i] = (unsigned)(((r3 * W + px) * Cs + ci0 + 4 * c4) * 4);
-        blds[i] = ok ? (r3 * 18 + px) * RSB + c4 * 8 : 0;
+        if constexpr (roi) {
+            const int j = e / QB, c4 = e % QB, d = j - 9;       // slot j of the X image = slot d relative to the chunk's first
+            const bool ok = e < NXB && j < 34;
+            b_r3[i] = ok ? (d >> 3) : 1000000;                 // image row relative to the chunk's first (-2 .. 3)
+            b_px[i] = d & 7;
+            bvo[i] = ok ? (unsigned)(((((d >> 3) + 2) * 7 + (d & 7)) * Cs + ci0 + 4 * c4) * 4) : 0u;
+            blds[i] = e < NXB ? j * RSB + c4 * 8 : 0;
+        } else {
+            const int r3 = e / (18 * QB), rem = e - r3 * (18 * QB), px = rem / QB, c4 = rem % QB;
+            const bool ok = e < NXB;
+            b_r3[i] = ok ? r3 : 1000000;                       // (never inside the image)
+            b_px[i] = px;
+            bvo[i] = (unsigned)(((r3 * W + px) * Cs + ci0 + 4 * c4) * 4);
+            blds[i] = ok ? (r3 * 18 + px) * RSB + c4 * 8 : 0;
+        }
     }
     // chunk c = pixels [16 c, 16 c + 16) of the flattened [B, H, W] index: (image n, row y, first column x0) walk in scalars
     int pix = c0 * 16;
     int n = pix / (H * W);
     int y = (pix - n * H * W) / W;
     int x0 = pix - (n * H + y) * W;
+    int chunk = c0;
     float4 ra[NDA], rb[NDB];
     auto load_chunk = [&](unsigned inv) {
+        if constexpr (roi) {
+            const int img = chunk >> 2, cc = chunk & 3;         // four chunks (slot rows 0-1, 2-3, 4-5, 6-7) per image
+            const __amdgpu_buffer_rsrc_t rA = c3_rsrc(p.dY + (long long)(img * 49 + 14 * cc) * Cout);
+#pragma unroll
+            for (int i = 0; i < NDA; ++i) ra[i] = c3_load(rA, (a_yy[i] + 2 * cc < 7) ? (avo[i] | inv) : C3_INVALID);
+            // descriptor base: pixel (first row - 2, 0) of the image (lanes whose slot is no pixel carry the invalid offset)
+            const __amdgpu_buffer_rsrc_t rB = c3_rsrc(p.X + (long long)(img * 49 + (2 * cc - 2) * 7) * Cs);
+#pragma unroll
+            for (int i = 0; i < NDB; ++i) {
+                const bool ok = (unsigned)(2 * cc + b_r3[i]) < 7u && b_px[i] < 7;
+                rb[i] = c3_load(rB, ok ? (bvo[i] | inv) : C3_INVALID);
+            }
+            ++chunk;
+            return;
+        }
         const __amdgpu_buffer_rsrc_t rA = c3_rsrc(p.dY + (long long)pix * Cout);
 #pragma unroll
         for (int i = 0; i < NDA; ++i) ra[i] = c3_load(rA, avo[i] | inv);
@@ -559,7 +658,7 @@ __global__ __launch_bounds__(256, 2) void conv3x3_wgrad_kernel(const conv3w_args
         for (int tap = 0; tap < 9; ++tap) {
             c3_u32x4 fb[NPL];
 #pragma unroll
-            for (int q = 0; q < NPL; ++q) fb[q] = frag(bs + q * PB + ((tap / 3) * 18 + tap % 3) * RSB, RSB);
+            for (int q = 0; q < NPL; ++q) fb[q] = frag(bs + q * PB + ((tap / 3) * pitch + tap % 3) * RSB, RSB);
 #pragma unroll
             for (int t = 0; t < (F16 ? 3 : 6); ++t) {
                 if constexpr (F16)
@@ -611,7 +710,7 @@ __global__ void conv3_wgrad_reduce_kernel(const float4* __restrict__ slab, int n
 }  // namespace vbg
 
 extern "C" int vbg_conv3x3_wgrad_strips(int B, int H, int W, int Cs, int Cout) {
-    const long long nchunks = (long long)B * H * W / 16;
+    const long long nchunks = (H == 7 && W == 7) ? (long long)B * 4 : (long long)B * H * W / 16;
     const bool wide = Cout % 128 == 0;
     const long long tiles = wide ? (long long)(Cout / 128) * (Cs / 32) : (long long)(Cout / 64) * (Cs / 64);
     if (tiles <= 0 || nchunks <= 0) return 0;
@@ -632,7 +731,8 @@ extern "C" int vbg_conv3x3_wgrad_strips(int B, int H, int W, int Cs, int Cout) {
 
 extern "C" int vbg_conv3x3_wgrad(const float* dy, const float* x, float* dw, float* slab, int B, int H, int W, int Cs, int Cout, int form,
                                  const unsigned* dy_amax, const unsigned* x_amax, void* stream) {
-    VBG_CHECK_ARG(dy && x && dw && B > 0 && H > 0 && W >= 16 && W % 16 == 0);
+    const bool roi = H == 7 && W == 7;                          // [B, 7, 7, C] region maps
+    VBG_CHECK_ARG(dy && x && dw && B > 0 && H > 0 && (roi || (W >= 16 && W % 16 == 0)));
     VBG_CHECK_ARG(form == 0 || (form == 1 && dy_amax && x_amax));
     VBG_CHECK_ARG(Cs % 32 == 0 && Cout % 64 == 0);
     VBG_CHECK_ARG((((uintptr_t)x) & 15) == 0 && (((uintptr_t)dy) & 15) == 0);
@@ -642,13 +742,18 @@ extern "C" int vbg_conv3x3_wgrad(const float* dy, const float* x, float* dw, flo
     vbg::conv3w_args a;
     a.dY = dy; a.X = x; a.dW = dw; a.slab = slab; a.H = H; a.W = W; a.Cs = Cs; a.Cout = Cout;
     a.dy_amax = dy_amax; a.x_amax = x_amax;
-    a.nchunks = (int)(M / 16);
+    a.roi = roi ? 1 : 0;
+    a.nchunks = roi ? B * 4 : (int)(M / 16);
     const bool wide = Cout % 128 == 0;                         // [128 co x 32 ci] blocks, else [64 co x 64 ci]
     VBG_CHECK_ARG(wide || Cs % 64 == 0);
     const int nsplit = vbg_conv3x3_wgrad_strips(B, H, W, Cs, Cout);
     VBG_CHECK_ARG(nsplit >= 1 && (!slab || (((uintptr_t)slab) & 15) == 0) && (((uintptr_t)dw) & 15) == 0);
     a.per = (a.nchunks + nsplit - 1) / nsplit;
-    if (wide) {
+    if (roi) {
+        VBG_CHECK_ARG(wide);
+        if (form == 1) { VBG_LAUNCH((vbg::conv3x3_wgrad_kernel<4, true, true>), dim3(nsplit, Cs / 32, Cout / 128), dim3(256), 0, (hipStream_t)stream, a); }
+        else { VBG_LAUNCH((vbg::conv3x3_wgrad_kernel<4, false, true>), dim3(nsplit, Cs / 32, Cout / 128), dim3(256), 0, (hipStream_t)stream, a); }
+    } else if (wide) {
         if (form == 1) { VBG_LAUNCH((vbg::conv3x3_wgrad_kernel<4, true>), dim3(nsplit, Cs / 32, Cout / 128), dim3(256), 0, (hipStream_t)stream, a); }
         else { VBG_LAUNCH((vbg::conv3x3_wgrad_kernel<4, false>), dim3(nsplit, Cs / 32, Cout / 128), dim3(256), 0, (hipStream_t)stream, a); }
     } else {
@@ -663,32 +768,64 @@ extern "C" int vbg_conv3x3_wgrad(const float* dy, const float* x, float* dw, flo
     VBG_LAUNCH_RET();
 }
 
+// blocks per 128 x 128 tile the forward / input-gradient kernel wants for this shape (1: no split).  The late stages of the trunk have
+// 64-128 tiles whose reduction is 2304-4608 long: one block per tile leaves most of the chip idle for the ~75 us a lone block needs
+// for its k-loop.  Three blocks per tile (one filter row each) or four (a quarter of the channels each) put >= 256 blocks on the
+// chip.  VBG_CONV3_SPLIT_Z overrides (tuning; multiples of 3 split the filter rows).
+extern "C" int vbg_conv3x3_split(int B, int H, int W, int Cs, int N) {
+    static const int forced = getenv("VBG_CONV3_SPLIT_Z") ? atoi(getenv("VBG_CONV3_SPLIT_Z")) : 0;
+    if (W < 16 || (W & (W - 1)) != 0 || ((long long)H * W) % 128 != 0 || N % 128 != 0 || Cs % 16 != 0 || W >= 128) return 1;
+    const long long tiles = ((long long)B * H * W / 128) * (N / 128);
+    if (tiles >= 240 || tiles < 16) return 1;
+    int nz = tiles * 3 >= 256 ? 3 : tiles * 4 >= 256 ? 4 : tiles * 6 >= 256 ? 6 : 12;      // (measured: 512 channels at 16 x 16 pixels, 4: 63 us, 6: 66, 3: 71, 1: 137)
+    if (forced > 0) nz = forced;
+    const int cs = nz % 3 == 0 ? nz / 3 : nz;
+    if (Cs % cs != 0 || (Cs / cs) % 16 != 0) return 1;
+    return nz;
+}
+
 extern "C" int vbg_conv3x3(const float* x, const float* w, const float* bias, float* y, double* stats, int stats_slots, int B, int H,
-                           int W, int Cs, int N, int accumulate, int form, const unsigned* x_amax, void* stream) {
+                           int W, int Cs, int N, int accumulate, int form, const unsigned* x_amax, float* split_slab,
+                           unsigned* split_tickets, int nsplit, void* stream) {
     VBG_CHECK_ARG(form == 0 || form == 1);
     VBG_CHECK_ARG(!x_amax || form == 1);
     VBG_CHECK_ARG(x && w && y && B > 0 && H > 0);
-    VBG_CHECK_ARG(W >= 16 && W <= 4096 && (W & (W - 1)) == 0);
-    VBG_CHECK_ARG(((long long)H * W) % 64 == 0 && (long long)H * W * Cs < (1ll << 29));
+    const bool roi = H == 7 && W == 7;                          // [B, 7, 7, C] region maps: two images per 128-slot tile
+    VBG_CHECK_ARG(roi || (W >= 16 && W <= 4096 && (W & (W - 1)) == 0));
+    VBG_CHECK_ARG(roi || ((long long)H * W) % 64 == 0);
+    VBG_CHECK_ARG((long long)H * W * Cs < (1ll << 29) && (!roi || (long long)B * 49 * Cs < (1ll << 29)));
     VBG_CHECK_ARG(Cs >= 16 && Cs % 16 == 0 && N >= 4 && N % 4 == 0);
     VBG_CHECK_ARG((((uintptr_t)x) & 15) == 0 && (((uintptr_t)w) & 15) == 0 && (((uintptr_t)y) & 15) == 0);
     VBG_CHECK_ARG(!stats || (stats_slots >= 1 && !accumulate));
     vbg::conv3_args a;
     a.X = x; a.Wt = w; a.bias = bias; a.Y = y; a.stats = stats; a.stats_slots = stats_slots;
-    a.H = H; a.W = W; a.wsh = 31 - __builtin_clz((unsigned)W); a.Cs = Cs; a.N = N;
+    a.H = H; a.W = W; a.wsh = roi ? 3 : 31 - __builtin_clz((unsigned)W); a.Cs = Cs; a.N = N;
     const long long M = (long long)B * H * W;
     VBG_CHECK_ARG(M < (1ll << 31));
-    a.M = (int)M; a.accumulate = accumulate; a.a_amax = x_amax;
+    a.M = (int)M; a.accumulate = accumulate; a.a_amax = x_amax; a.roi = roi ? B : 0;
+    // split form: nsplit blocks per tile meet in split_slab [tiles][nsplit][128 * 128] / split_tickets [tiles] (zero; left zero)
+    const bool split = nsplit > 1;
+    VBG_CHECK_ARG(nsplit >= 1 && (!split || (split_slab && split_tickets && !roi && N % 128 == 0 && ((long long)H * W) % 128 == 0)));
+    a.ksplit = split && nsplit % 3 == 0 ? 3 : 1;
+    a.csplit = split ? nsplit / a.ksplit : 1;
+    a.slab = split_slab; a.tickets = split_tickets;
+    VBG_CHECK_ARG(Cs % a.csplit == 0 && (Cs / a.csplit) % 16 == 0 && (((uintptr_t)split_slab) & 15) == 0);
+    // filters per tile: 128, or 64 where the filter count is an odd multiple of 64 (the 64-channel stage)
     // 128-pixel tiles once they fill the chip (or the image does not divide into 64-pixel tiles any better), else 64-pixel tiles
-    const long long t128 = (M / 128) * vbg::cdiv(N, 128);
-    const bool big = ((long long)H * W) % 128 == 0 && (t128 >= 240 || W >= 128);
-    const dim3 g((unsigned)(M / (big ? 128 : 64)), (unsigned)vbg::cdiv(N, 128), 1);
-    if (form == 1) {
-        if (big) { VBG_LAUNCH((vbg::conv3x3_kernel<128, true>), g, dim3(256), 0, (hipStream_t)stream, a); }
-        else { VBG_LAUNCH((vbg::conv3x3_kernel<64, true>), g, dim3(256), 0, (hipStream_t)stream, a); }
+    auto is_big = [&](int bn_) { return roi || (((long long)H * W) % 128 == 0 && ((M / 128) * vbg::cdiv(N, bn_) >= 240 || W >= 128)); };
+    const bool n64 = N % 128 != 0 && N % 64 == 0 && is_big(64);
+    const int bn = n64 ? 64 : 128;
+    const bool big = split || is_big(bn);
+    const dim3 g(roi ? (unsigned)((B + 1) / 2) : (unsigned)(M / (big ? 128 : 64)), (unsigned)vbg::cdiv(N, bn), (unsigned)nsplit);
+    if (n64) {
+        if (form == 1) { VBG_LAUNCH((vbg::conv3x3_kernel<128, 64, true>), g, dim3(256), 0, (hipStream_t)stream, a); }
+        else { VBG_LAUNCH((vbg::conv3x3_kernel<128, 64, false>), g, dim3(256), 0, (hipStream_t)stream, a); }
+    } else if (form == 1) {
+        if (big) { VBG_LAUNCH((vbg::conv3x3_kernel<128, 128, true>), g, dim3(256), 0, (hipStream_t)stream, a); }
+        else { VBG_LAUNCH((vbg::conv3x3_kernel<64, 128, true>), g, dim3(256), 0, (hipStream_t)stream, a); }
     } else {
-        if (big) { VBG_LAUNCH((vbg::conv3x3_kernel<128, false>), g, dim3(256), 0, (hipStream_t)stream, a); }
-        else { VBG_LAUNCH((vbg::conv3x3_kernel<64, false>), g, dim3(256), 0, (hipStream_t)stream, a); }
+        if (big) { VBG_LAUNCH((vbg::conv3x3_kernel<128, 128, false>), g, dim3(256), 0, (hipStream_t)stream, a); }
+        else { VBG_LAUNCH((vbg::conv3x3_kernel<64, 128, false>), g, dim3(256), 0, (hipStream_t)stream, a); }
     }
     VBG_LAUNCH_RET();
 }

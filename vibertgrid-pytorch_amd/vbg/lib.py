@@ -86,7 +86,8 @@ SIGNATURES = {
     "vbg_attn_mask": (c_int, [c_vp, c_vp, c_int, c_int, c_int, c_f, c_ull, c_ull, c_vp, c_vp, c_vp]),
     "vbg_colsum": (c_int, [c_vp, c_ll, c_int, c_int, c_vp, c_int, c_vp]),
     "vbg_colsum_f64": (c_int, [c_vp, c_ll, c_int, c_int, c_vp, c_int, c_vp, c_vp]),
-    "vbg_conv3x3": (c_int, [c_vp, c_vp, c_vp, c_vp, c_vp, c_int, c_int, c_int, c_int, c_int, c_int, c_int, c_int, c_vp, c_vp]),
+    "vbg_conv3x3": (c_int, [c_vp, c_vp, c_vp, c_vp, c_vp, c_int, c_int, c_int, c_int, c_int, c_int, c_int, c_int, c_vp, c_vp, c_vp, c_int, c_vp]),
+    "vbg_conv3x3_split": (c_int, [c_int, c_int, c_int, c_int, c_int]),
     "vbg_amax": (c_int, [c_vp, c_ll, c_vp, c_vp]),
     "vbg_conv3x3_wflip": (c_int, [c_vp, c_int, c_int, c_vp, c_vp]),
     "vbg_conv3x3_wgrad_strips": (c_int, [c_int, c_int, c_int, c_int, c_int]),

@@ -647,14 +647,28 @@ _CONV3_MIN_TILES = [int(os.environ.get("VBG_CONV3_MIN_TILES", "480"))]
 _CONV3_MIN_TILES_FWD = [int(os.environ.get("VBG_CONV3_MIN_TILES_FWD", "256"))]
 
 
+_CONV3_ROI = [os.environ.get("VBG_CONV3_ROI", "1") != "0"]       # [N, 7, 7, C] region maps on the row-reuse kernels (two images per 128-slot tile)
+_CONV3_N64 = [os.environ.get("VBG_CONV3_N64", "1") != "0"]       # 64-filter tiles (the 64-channel stage of the trunk)
+
+
 def conv3_ok(B, H, W, Cs, N, kh, kw, stride, pad, fwd=False) -> bool:
     """shapes the row-reuse kernel takes: whole image rows per pixel tile, full 128-wide column tiles and at least 480 64-pixel tiles
     (= 240 of the 128-pixel tiles the kernel then uses).  Below that the kernel would run 64-pixel tiles, one 4-wave workgroup per CU:
     measured level with the generic 64 x 64 tiles (70 vs 72 us forward at 256 channels, 32 x 32 pixels) and behind them once the filter
-    has to be turned for the input gradient (84 vs 74 us) -- the late stages stay on the generic kernel; default split form only"""
-    return (_CONV3[0] and _SPLIT3[0] and not _AMP[0] and kh == 3 and kw == 3 and stride == 1 and pad == 1 and W in (16, 32, 64, 128, 256, 512, 1024)
-            and (H * W) % 64 == 0 and Cs % 16 == 0 and N % 128 == 0 and H * W * Cs < (1 << 29)
-            and (B * H * W // 64) * (N // 128) >= (_CONV3_MIN_TILES_FWD[0] if fwd and _CONV3_F16[0] else _conv3_min_tiles_bwd()))
+    has to be turned for the input gradient (84 vs 74 us) -- the late stages stay on the generic kernel; default split form only.
+    Also: 7 x 7 region maps (two images per tile, see csrc/conv3.hip) and filter counts that are odd multiples of 64 (64-wide tiles)"""
+    if not (_CONV3[0] and _SPLIT3[0] and not _AMP[0] and kh == 3 and kw == 3 and stride == 1 and pad == 1 and Cs % 16 == 0):
+        return False
+    min_tiles = _CONV3_MIN_TILES_FWD[0] if fwd and _CONV3_F16[0] else _conv3_min_tiles_bwd()
+    if H == 7 and W == 7:
+        return _CONV3_ROI[0] and N % 128 == 0 and B * 49 * Cs < (1 << 29) and ((B + 1) // 2) * 2 * (N // 128) >= min_tiles
+    if not (W in (16, 32, 64, 128, 256, 512, 1024) and (H * W) % 64 == 0 and H * W * Cs < (1 << 29)):
+        return False
+    if N % 128 == 0:
+        return (B * H * W // 64) * (N // 128) >= min_tiles or conv3_split(B, H, W, Cs, N) > 1
+    if N % 64 == 0 and _CONV3_N64[0]:
+        return (H * W) % 128 == 0 and (B * H * W // 128) * (N // 64) >= 240
+    return False
 
 
 _CONV3_F16 = [os.environ.get("VBG_CONV3_F16", "1") != "0"]
@@ -699,18 +713,44 @@ def amax(x, slot=None):
     return slot
 
 
-def conv3x3(x, w_ohwi, bias=None, out=None, stats=None, accumulate=False, f16x2=False, x_amax=None):
+_CONV3_SPLITK = [os.environ.get("VBG_CONV3_SPLITK", "1") != "0"]
+_CONV3_TICKETS = {}
+
+
+def conv3_split(B, H, W, Cs, N) -> int:
+    """workgroups per tile the row-reuse kernel wants for this shape (1: no split; csrc/conv3.hip vbg_conv3x3_split)"""
+    return int(lib.vbg_conv3x3_split(B, H, W, Cs, N)) if _CONV3_SPLITK[0] else 1
+
+
+def _conv3_tickets(device, tiles):
+    """the arrival counters of the split form: zero between launches; one set per (device, stream) -- two split convolutions on
+    different streams must not share counters"""
+    key = (device.index, torch.cuda.current_stream(device).cuda_stream)
+    t = _CONV3_TICKETS.get(key)
+    if t is None or t.numel() < tiles:
+        t = _CONV3_TICKETS[key] = torch.zeros(max(1024, tiles), device=device, dtype=torch.int32)
+    return t
+
+
+def conv3x3(x, w_ohwi, bias=None, out=None, stats=None, accumulate=False, f16x2=False, x_amax=None, nsplit=None):
     """y (+)= conv3x3(x NHWC, w [N,3,3,Cs]), stride 1, pad 1 (csrc/conv3.hip).  f16x2: the two-piece fp16 form -- for operands inside
     fp16's range (activations, filters); a gradient operand x needs x_amax (device word with the bits of max |x|): the kernel then
-    scales x by the power of two that centres it in fp16's range and the result back (exact)"""
+    scales x by the power of two that centres it in fp16's range and the result back (exact).  nsplit: workgroups per tile (None: the
+    library's choice for the shape)"""
     B, H, W, Cs = x.shape
     N = w_ohwi.shape[0]
     if out is None:
         assert not accumulate
         out = torch.empty((B, H, W, N), device=x.device, dtype=f32)
     assert x_amax is None or f16x2
+    nz = conv3_split(B, H, W, Cs, N) if nsplit is None else int(nsplit)
+    slab = tickets = None
+    if nz > 1:
+        tiles = (B * H * W // 128) * (N // 128)
+        slab = torch.empty((tiles * nz, 128 * 128), device=x.device, dtype=f32)
+        tickets = _conv3_tickets(x.device, tiles)
     check(lib.vbg_conv3x3(P(x), P(w_ohwi), P(bias), P(out), P(stats), bn_slots() if stats is not None else 0, B, H, W, Cs, N,
-                          int(accumulate), int(bool(f16x2)), P(x_amax), _stream()), "vbg_conv3x3")
+                          int(accumulate), int(bool(f16x2)), P(x_amax), P(slab), P(tickets), nz, _stream()), "vbg_conv3x3")
     return out
 
 
@@ -724,11 +764,12 @@ def conv3x3_wflip(w_ohwi):
 
 def conv3w_ok(B, H, W, Cs, Cout, kh, kw, stride, pad) -> bool:
     """shapes the row-reuse weight-gradient kernel takes (csrc/conv3.hip): default split form, strips of at least 8 k-tiles"""
-    if not (_CONV3[0] and _SPLIT3[0] and not _AMP[0] and kh == 3 and kw == 3 and stride == 1 and pad == 1 and W % 16 == 0
+    roi = H == 7 and W == 7 and _CONV3_ROI[0]              # region maps: four two-row chunks per image
+    if not (_CONV3[0] and _SPLIT3[0] and not _AMP[0] and kh == 3 and kw == 3 and stride == 1 and pad == 1 and (W % 16 == 0 or roi)
             and Cs % 32 == 0 and Cout % 128 == 0 and (3 * W + 18) * Cs < (1 << 28)):       # (64-wide filters: the generic kernel is faster)
         return False
     strips = int(lib.vbg_conv3x3_wgrad_strips(B, H, W, Cs, Cout))
-    return strips >= 1 and (B * H * W // 16) // strips >= _CONV3W_MIN[0]
+    return strips >= 1 and (B * 4 if roi else B * H * W // 16) // strips >= _CONV3W_MIN[0]
 
 
 _CONV3W_MIN = [int(os.environ.get("VBG_CONV3W_MIN", "8"))]
