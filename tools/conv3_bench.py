@@ -28,6 +28,11 @@ for (B, H, W, Ci, Co) in [(8, 128, 128, 256, 256), (8, 128, 128, 128, 128), (8, 
         report(f"{name} wgrad {tag}", fl, timeit(lambda: ops.conv2d_wgrad(dy, x, dw, 1, 1)))
         if on:
             report(f"{name} wgrad (atomics) {tag}", fl, timeit(lambda: ops.conv3x3_wgrad(dy, x, dw, slabs=False)))
+            if Co % 128 == 0 or (Co % 64 == 0 and Ci % 64 == 0):
+                ay, ax = ops.amax(dy), ops.amax(x)
+                report(f"{name} wgrad (kernel, bf16x3, slabs) {tag}", fl, timeit(lambda: ops.conv3x3_wgrad(dy, x, dw, slabs=True)))
+                report(f"{name} wgrad (kernel, f16x2, slabs) {tag}", fl, timeit(lambda: ops.conv3x3_wgrad(dy, x, dw, slabs=True, f16x2=True, dy_amax=ay, x_amax=ax)))
+                report(f"{name} wgrad (kernel, f16x2, atomics) {tag}", fl, timeit(lambda: ops.conv3x3_wgrad(dy, x, dw, slabs=False, f16x2=True, dy_amax=ay, x_amax=ax)))
     ops.set_conv3(True)
     y1 = ops.conv2d_fwd(x, w, 1, 1)
     ops.set_conv3(False)

@@ -96,7 +96,7 @@ if os.path.exists(G + "pmc_m/m_counter_collection.csv"):
            "# wait/active columns are fractions of SQ_WAVE_CYCLES.  gemm_kernel<BM, BN, BK, 256, A-kind, B-kind, vec, form>: kinds 0 DENSE_K, 1 DENSE_R, 2 CONV_K,",
            "# 3 CONV_R, 4 WT_R; form 0 = fp32 MFMA, 3 = in-kernel bf16x3 split.  plane_gemm_kernel<BM, BN, waves M, waves N, stages, TN, ping-pong, form>: pre-split planes,",
            "# form 0 = three bf16 planes / six piece products, 1 = two fp16 planes / three piece products (mfma_util counts BUSY cycles: half the products at equal time halve it).",
-           "# attn_kernel<mode, dropout>: 0 forward, 1 dQ, 2 dK/dV.  conv3x3_kernel<pixels per tile, fp16 form> / conv3x3_wgrad_kernel<waves along the filters, fp16 form>: csrc/conv3.hip.",
+           "# attn_kernel<mode, dropout>: 0 forward, 1 dQ, 2 dK/dV.  conv3x3_kernel<pixels per tile, filters per tile, fp16 form> / conv3x3_wgrad_kernel<waves along the filters, fp16 form, 7x7 region maps>: csrc/conv3.hip.",
            "kernel,launches_per_step,ms_per_step,clock_GHz,mfma_util,wait_any,wait_inst_any,active_inst_any,lds_bank_conflict_Mcycles"]
     tb = tc = 0
     for k, a_ in sorted(ag.items(), key=lambda kv: -kv[1]["ns"]):
