@@ -79,8 +79,20 @@ def test_dispatch_predicates():
     assert ops.conv3_ok(8, 128, 128, 256, 256, 3, 3, 1, 1, fwd=True) and ops.conv3_f16_bwd_ok(8, 128, 128, 256, 256, 3, 3, 1, 1)
     assert ops.conv3_f16_wgrad_ok(8, 128, 128, 256, 256, 3, 3, 1, 1) and ops.conv3_f16_wgrad_ok(8, 16, 16, 512, 512, 3, 3, 1, 1)
     assert not ops.conv3_ok(8, 128, 128, 256, 256, 3, 3, 2, 1) and not ops.conv3_f16_wgrad_ok(8, 128, 128, 64, 64, 3, 3, 1, 1)
-    # 256 channels at 32 x 32: forward on the row-reuse kernel (256 tiles), input gradient on the generic one (A/B: no gain)
-    assert ops.conv3_ok(8, 32, 32, 256, 256, 3, 3, 1, 1, fwd=True) and not ops.conv3_ok(8, 32, 32, 256, 256, 3, 3, 1, 1)
+    # the late trunk stages (256 channels at 32 x 32: 128 tiles, 512 at 16 x 16: 64): forward and input gradient on the row-reuse
+    # kernel with several workgroups per tile; without that form the input gradient falls back to the generic kernel
+    assert ops.conv3_ok(8, 32, 32, 256, 256, 3, 3, 1, 1, fwd=True) and ops.conv3_ok(8, 32, 32, 256, 256, 3, 3, 1, 1)
+    assert ops.conv3_split(8, 32, 32, 256, 256) == 3 and ops.conv3_split(8, 16, 16, 512, 512) == 4 and ops.conv3_split(8, 128, 128, 256, 256) == 1
+    ops._CONV3_SPLITK[0] = False
+    try:
+        assert ops.conv3_ok(8, 32, 32, 256, 256, 3, 3, 1, 1, fwd=True) and not ops.conv3_ok(8, 32, 32, 256, 256, 3, 3, 1, 1)
+        assert not ops.conv3_ok(8, 16, 16, 512, 512, 3, 3, 1, 1, fwd=True)
+    finally:
+        ops._CONV3_SPLITK[0] = True
+    # 7 x 7 region maps (two images per tile) and the 64-filter stage
+    assert ops.conv3_ok(1024, 7, 7, 256, 256, 3, 3, 1, 1) and ops.conv3_f16_wgrad_ok(1024, 7, 7, 256, 256, 3, 3, 1, 1)
+    assert not ops.conv3_ok(40, 7, 7, 256, 256, 3, 3, 1, 1, fwd=True)               # a handful of regions: the generic kernel
+    assert ops.conv3_ok(8, 128, 128, 64, 64, 3, 3, 1, 1) and not ops.conv3_ok(1, 64, 64, 64, 64, 3, 3, 1, 1)
     # the fp16-pair plane products need the 8-wave tiles: batch 8 takes them, a single document does not (unless forced)
     assert ops.pair_tile(4128, 768) == 128129 and ops.pair_tile(4128, 3072, True) == 256128 and ops.pair_tile(516, 768) == 0
     ops.set_pair(True, force=True)

@@ -1,10 +1,11 @@
 """largest idle gaps between consecutive kernels of the timed steps in a rocprofv3 kernel trace: which kernels sit on either side
-   python tools/gap_report.py gpurun_out/prof_g/g_kernel_trace.csv [nsteps_in_trace=13] [top=25]"""
+   python tools/gap_report.py gpurun_out/prof_g/g_kernel_trace.csv [nsteps_in_trace=13] [top=25] [steps after the timed ones=0]"""
 import csv, re, sys, collections
 path = sys.argv[1]; nsteps = int(sys.argv[2]) if len(sys.argv) > 2 else 13; top = int(sys.argv[3]) if len(sys.argv) > 3 else 25
 rows = [(int(r['Start_Timestamp']), int(r['End_Timestamp']), r['Kernel_Name']) for r in csv.DictReader(open(path))]
 rows.sort()
-n = len(rows); per = n // nsteps; seg = rows[n - 10 * per:]
+skip = int(sys.argv[4]) if len(sys.argv) > 4 else 0
+n = len(rows); per = n // nsteps; seg = rows[n - (10 + skip) * per:n - skip * per]
 short = lambda s: re.sub(r"^void |vbg::|\(.*$", "", s)[:70]
 gaps = [(seg[i + 1][0] - seg[i][1], short(seg[i][2]), short(seg[i + 1][2])) for i in range(len(seg) - 1)]
 busy = sum(e - s for s, e, _ in seg); span = seg[-1][1] - seg[0][0]

@@ -6,16 +6,16 @@ python - <<'P'
 import csv
 rows=list(csv.DictReader(open('gpurun_out/prof_s/s_kernel_stats.csv')))
 tot=sum(int(r['TotalDurationNs']) for r in rows)
-print('kernel ms/step', tot/13/1e6)
+print('kernel ms/step', tot/23/1e6)
 for r in rows[:int(__import__('os').environ.get('TOPN','30'))]:
-    print(f"{int(r['TotalDurationNs'])/13/1e6:7.3f} ms {int(r['Calls'])/13:6.1f} {float(r['AverageNs'])/1e3:8.1f}us  {r['Name'][:110]}")
+    print(f"{int(r['TotalDurationNs'])/23/1e6:7.3f} ms {int(r['Calls'])/23:6.1f} {float(r['AverageNs'])/1e3:8.1f}us  {r['Name'][:110]}")
 P
 python - <<'P'
 import csv
 rows=[(int(r['Start_Timestamp']),int(r['End_Timestamp'])) for r in csv.DictReader(open('gpurun_out/prof_s/s_kernel_trace.csv'))]
 rows.sort()
 # the timed region = the last 10 of 13 steps: take the last 10/13 of the launches
-n=len(rows); per=n//13; seg=rows[n-10*per:]
+n=len(rows); per=n//23; seg=rows[n-10*per:]
 busy=sum(e-s for s,e in seg); span=seg[-1][1]-seg[0][0]
 gaps=[seg[i+1][0]-seg[i][1] for i in range(len(seg)-1)]
 big=sorted(gaps)[-10:]

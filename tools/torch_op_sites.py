@@ -26,15 +26,18 @@ with profile(activities=[ProfilerActivity.CPU, ProfilerActivity.CUDA], record_sh
     torch.cuda.synchronize()
 agg = collections.defaultdict(lambda: [0, 0.0])
 for ev in prof.events():
-    if not ev.name.startswith("aten::") or ev.device_time_total <= 0 or ev.cpu_children:
+    dt = getattr(ev, "self_device_time_total", None)
+    if dt is None:
+        dt = getattr(ev, "self_cuda_time_total", 0)
+    if not ev.name.startswith("aten::") or dt <= 0:
         continue
     site = "?"
-    for fr in ev.stack:
+    for fr in (ev.stack or []):
         if "vibertgrid-pytorch_amd" in fr or "bench.py" in fr:
             site = fr.split("vibertgrid-pytorch_amd/")[-1]
             break
     k = (ev.name, str(ev.input_shapes)[:70], site[:90])
-    agg[k][0] += 1; agg[k][1] += ev.device_time_total
+    agg[k][0] += 1; agg[k][1] += dt
 tot = sum(v[1] for v in agg.values())
 print(f"torch kernels: {sum(v[0] for v in agg.values())} launches, {tot / 1e3:.2f} ms device time per step")
 for k, v in sorted(agg.items(), key=lambda kv: -kv[1][1])[:45]:

@@ -155,7 +155,7 @@ class BERTgridGenerator(nn.Module):
         blob = np.concatenate([pk.ids.astype(np.int64), pk.pos.astype(np.int64), soff.astype(np.int64), pk.seq_len,
                                np.full(len(pk.seq_len), ld, np.int64)] + [tabs[k].reshape(-1) for k in ("qk", "pv", "dp", "dv", "dq")]
                               + [mask_off, row0, pad_off, tok_pad, tasks.reshape(-1)])
-        d = torch.from_numpy(blob).to(dev, non_blocking=False)
+        d = ops.h2d(blob, dev)
         o = 0
 
         def take(cnt):
@@ -234,7 +234,7 @@ class BERTgridGenerator(nn.Module):
             tok_rows.append(pk.kept_rows[b])
             base += nb
         blob = np.concatenate(tok_rows + starts + lens).astype(np.int32)
-        d = torch.from_numpy(blob).to(dev)
+        d = ops.h2d(blob, dev)
         nt, ns = base, sum(counts)
         tok_row, run_start, run_len = d[:nt], d[nt:nt + ns], d[nt + ns:]
         mode = 0 if self.grid_mode == "mean" else 1
@@ -249,7 +249,7 @@ class BERTgridGenerator(nn.Module):
         boxes = torch.cat([c.reshape(-1, 4).int() for c in coors], 0).contiguous()
         off = np.concatenate([[0], np.cumsum(counts)]).astype(np.int32)
         doc = np.repeat(np.arange(len(counts), dtype=np.int32), counts)
-        d = torch.from_numpy(np.concatenate([off, doc])).to(dev)
+        d = ops.h2d(np.concatenate([off, doc]), dev)
         return boxes, d[:len(off)], d[len(off):]
 
     def BERTgrid_embedding(self, image_shape: Tuple, BERT_embeddings: Tuple[torch.Tensor], coors: Tuple[torch.Tensor], layout: int = 1):

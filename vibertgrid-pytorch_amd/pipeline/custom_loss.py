@@ -57,20 +57,21 @@ class RandomSamplePlan:
     def count_tensors(self):
         return [c.cnt_dev for c in self.cats]
 
-    def resolve(self, counts: Sequence[int]):
-        dev = self.labels.device
+    def draw(self, counts: Sequence[int]):
+        """host half of the selection: the random draws in the reference's order -> [(category, positions or None)]"""
         self.num_keep_total = 0
+        out = []
         if self.plain:
-            return
+            return out
         for c, n, k in zip(self.cats, counts, self.sample_list):
             c.n = int(n)
             keep = min(k, c.n)
             self.num_keep_total += keep
-            if keep == k:
-                sel = torch.tensor(random.sample(range(c.n), keep), dtype=torch.int32).to(dev)
-                c.elem = ops.gather_i32(c.idx, sel)
-            else:
-                c.elem = c.idx[:c.n]
+            out.append((c, random.sample(range(c.n), keep) if keep == k else None))
+        return out
+
+    def resolve(self, counts: Sequence[int]):
+        _apply_draws(self.draw(counts), self.labels.device)
 
 
 class OhemPlan:
@@ -90,14 +91,29 @@ class OhemPlan:
     def count_tensors(self):
         return [c.cnt_dev for c in self.cats]
 
-    def resolve(self, counts: Sequence[int]):
-        dev = self.labels.device
+    def draw(self, counts: Sequence[int]):
+        out = []
         for c, n, k in zip(self.cats, counts, (self.num_pos, self.num_neg)):
             c.n = int(n)
+            out.append((c, random.sample(range(c.n), 2 * k) if self.rand and 2 * k < c.n else None))
+        return out
+
+    def resolve(self, counts: Sequence[int]):
+        _apply_draws(self.draw(counts), self.labels.device)
+
+
+def _apply_draws(draws, dev):
+    """device half: ALL drawn positions travel in one pinned, asynchronous upload (a pageable copy per category made the host wait for
+    the stream six times per step), then one gather per category"""
+    sel = [p for _, p in draws if p is not None]
+    d = ops.h2d(np.asarray([x for p in sel for x in p], dtype=np.int32), dev) if sel else None
+    o = 0
+    for c, p in draws:
+        if p is None:
             c.elem = c.idx[:c.n]
-            if self.rand and 2 * k < c.n:
-                sel = torch.tensor(random.sample(range(c.n), 2 * k), dtype=torch.int32).to(dev)
-                c.elem = ops.gather_i32(c.idx, sel)
+        else:
+            c.elem = ops.gather_i32(c.idx, d[o:o + len(p)])
+            o += len(p)
 
 
 class PendingCounts:
@@ -123,10 +139,14 @@ class PendingCounts:
             self.event.synchronize()
             counts = self.host.tolist()
         o = 0
+        draws, dev = [], None
         for p in self.plans:
             k = len(p.count_tensors())
-            p.resolve(counts[o:o + k])
+            draws += p.draw(counts[o:o + k])
+            dev = p.labels.device
             o += k
+        if draws:
+            _apply_draws(draws, dev)
 
 
 def resolve_plans(plans):

@@ -69,6 +69,20 @@ def side_streams():
     return list(_SIDE.values())
 
 
+_ASYNC_H2D = [os.environ.get("VBG_ASYNC_H2D", "1") != "0"]
+
+
+def h2d(host, device):
+    """numpy array / CPU tensor -> device tensor through pinned staging memory and an ASYNCHRONOUS copy.  A pageable `.to(device)`
+    returns only when the copy has run, i.e. after everything enqueued before it: one such upload in the middle of the forward costs
+    the host its whole lead over the device (measured: 30-200 us idle gaps behind every one of them, tools/gap_report.py)"""
+    t = torch.from_numpy(host) if not torch.is_tensor(host) else host
+    device = torch.device(device)
+    if device.type != "cuda" or not _ASYNC_H2D[0]:
+        return t.to(device)
+    return t.pin_memory().to(device, non_blocking=True)
+
+
 def P(t):
     if t is None:
         return None
