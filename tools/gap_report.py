@@ -21,3 +21,12 @@ for g, a, b in gaps:
 print("pairs (before -> after) by total idle time, gaps > 8 us:")
 for (a, b), (c, t) in sorted(agg.items(), key=lambda kv: -kv[1][1])[:top]:
     print(f"  {t/10/1e3:8.1f} us/step  x{c/10:5.1f}  {a}  ->  {b}")
+
+# where in the step the idle time sits: the launches of ONE step (the last of the window) in groups of 40
+one = seg[-per:]
+print("one step, groups of 40 launches: idle us | busy us | first kernel of the group")
+for g0 in range(0, len(one) - 1, 40):
+    grp = one[g0:g0 + 41]
+    idle = sum(grp[i + 1][0] - grp[i][1] for i in range(len(grp) - 1))
+    busy = sum(e - s_ for s_, e, _ in grp[:-1])
+    print(f"  {g0:5d}  idle {idle / 1e3:7.0f}  busy {busy / 1e3:7.0f}   {short(grp[0][2])}")
