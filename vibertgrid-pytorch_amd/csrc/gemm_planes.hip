@@ -68,7 +68,7 @@ __global__ __launch_bounds__(WGM * WGN * 64) void plane_gemm_kernel(const vbg_pl
     constexpr int STAGE = NPL * (PA + PB);
     constexpr int NIA = NPL * BM / 16 / NW, NIB = NPL * BN / 16 / NW;      // DMA instructions per wave and stage
     static_assert((NPL * BM / 16) % NW == 0 && (NPL * BN / 16) % NW == 0, "DMA units must divide over the waves");
-    static_assert(NST == 2 || NST == 3, "two or three LDS stages");
+    static_assert(NST == 2 || NST == 3 || (NST == 4 && !TRANS && WGM * WGN == 8 && PP), "two or three LDS stages (four: ping-pong loop only)");
     constexpr int CTS = BN + 4;
     constexpr int SMEM = (NST * STAGE > BM * CTS * 4) ? NST * STAGE : BM * CTS * 4;
     __shared__ __attribute__((aligned(1024))) unsigned char smem[SMEM];          // (the ONE LDS object of the kernel)
@@ -327,10 +327,13 @@ __global__ __launch_bounds__(WGM * WGN * 64) void plane_gemm_kernel(const vbg_pl
     // Every accumulator sees the same MFMAs in the same order as in the lockstep loop: results are bit-identical.
     if constexpr (!TRANS && NW == 8 && PP) {
         const int grp = wave >> 2;
+        //   NST = 4: the same with tile t + 3 (two tiles stay in flight across the wait): the L2 misses of a stage -- one row piece in
+        //            seven comes from the Infinity Cache at 3000+ clocks under load -- then have three k-tiles of products to hide behind
         issue(0, 0u);
-        if constexpr (NST == 3) {
-            issue(1, ntiles > 1 ? 0u : PG_INVALID);
-            asm volatile("s_waitcnt vmcnt(%0)" ::"n"(NIW) : "memory");
+        if constexpr (NST >= 3) {
+#pragma unroll
+            for (int s_ = 1; s_ < NST - 1; ++s_) issue(s_, ntiles > s_ ? 0u : PG_INVALID);
+            asm volatile("s_waitcnt vmcnt(%0)" ::"n"((NST - 2) * NIW) : "memory");
         } else {
             asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
         }
@@ -339,10 +342,10 @@ __global__ __launch_bounds__(WGM * WGN * 64) void plane_gemm_kernel(const vbg_pl
         int cur = 0;
         for (int t = 0; t < ntiles; ++t) {
             const int nxt = (cur + 1 == NST) ? 0 : cur + 1;
-            const int nn = (nxt + 1 == NST) ? 0 : nxt + 1;
+            const int nn = (cur == 0) ? NST - 1 : cur - 1;  // the stage of tile t - 1: where tile t + NST - 1 goes
             const unsigned inv = (t + NST - 1 < ntiles) ? 0u : PG_INVALID;
             __builtin_amdgcn_sched_barrier(0);
-            if constexpr (NST == 3) issue_a(nn, inv); else issue(nxt, inv);
+            if constexpr (NST >= 3) issue_a(nn, inv); else issue(nxt, inv);
             read_frags(cur, fo0, fa0, fb0);
             __builtin_amdgcn_sched_barrier(0);
             asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
@@ -354,10 +357,10 @@ __global__ __launch_bounds__(WGM * WGN * 64) void plane_gemm_kernel(const vbg_pl
             __builtin_amdgcn_sched_barrier(0);
             __builtin_amdgcn_s_barrier();
             __builtin_amdgcn_sched_barrier(0);
-            if constexpr (NST == 3) issue_b(nn, inv);
+            if constexpr (NST >= 3) issue_b(nn, inv);
             read_frags(cur, fo1, fa0, fb0);
             __builtin_amdgcn_sched_barrier(0);
-            if constexpr (NST == 3) asm volatile("s_waitcnt vmcnt(%0) lgkmcnt(0)" ::"n"(NIW) : "memory");
+            if constexpr (NST >= 3) asm volatile("s_waitcnt vmcnt(%0) lgkmcnt(0)" ::"n"((NST - 2) * NIW) : "memory");
             else asm volatile("s_waitcnt vmcnt(0) lgkmcnt(0)" ::: "memory");
             __builtin_amdgcn_s_barrier();
             __builtin_amdgcn_sched_barrier(0);
@@ -1318,15 +1321,25 @@ static int plane_gemm_dispatch(const vbg_plane_gemm_desc* desc, void* stream, vo
     if (d.form == 1) {
         // two fp16 planes per operand (csrc/gemm_planes.hip FORM 1): the 8-wave tiles only
         VBG_CHECK_ARG(d.splitk == 1 && !(d.sk_ws && d.sk_cnt) && (d.ngroups == 0 || d.trans));
+        // two planes per operand leave room for one more LDS stage than the three-plane form has (128 x 128: 4 x 32 KB, 256 x 128:
+        // 3 x 48 KB): a deeper ring hides the Infinity-Cache round trips of the row pieces an XCD touches first.  VBG_PAIR_DEEP=0: the
+        // stage counts of the three-plane kernels (A/B switch)
+        static const bool deep = !(getenv("VBG_PAIR_DEEP") && atoi(getenv("VBG_PAIR_DEEP")) == 0);
         if (d.trans) {
-            if (tile == 256128) pg_launch_pair<256, 128, 4, 2, 2, true>(d, s, (hipEvent_t)e0, (hipEvent_t)e1);
-            else pg_launch_pair<128, 128, 4, 2, 3, true>(d, s, (hipEvent_t)e0, (hipEvent_t)e1);
+            if (tile == 256128) {
+                if (deep) pg_launch_pair<256, 128, 4, 2, 3, true>(d, s, (hipEvent_t)e0, (hipEvent_t)e1);
+                else pg_launch_pair<256, 128, 4, 2, 2, true>(d, s, (hipEvent_t)e0, (hipEvent_t)e1);
+            } else pg_launch_pair<128, 128, 4, 2, 3, true>(d, s, (hipEvent_t)e0, (hipEvent_t)e1);
             VBG_LAUNCH_RET();
         }
-        if (tile == 256128) pg_launch_pair<256, 128, 4, 2, 2>(d, s, (hipEvent_t)e0, (hipEvent_t)e1);
-        else if (tile == 128130) pg_launch_pair<128, 128, 2, 4, 3>(d, s, (hipEvent_t)e0, (hipEvent_t)e1);
-        else if (tile == 128129 || tile == 0) pg_launch_pair<128, 128, 4, 2, 3>(d, s, (hipEvent_t)e0, (hipEvent_t)e1);
-        else return VBG_EARG;
+        if (tile == 256128) {
+            if (deep) pg_launch_pair<256, 128, 4, 2, 3>(d, s, (hipEvent_t)e0, (hipEvent_t)e1);
+            else pg_launch_pair<256, 128, 4, 2, 2>(d, s, (hipEvent_t)e0, (hipEvent_t)e1);
+        } else if (tile == 128130) pg_launch_pair<128, 128, 2, 4, 3>(d, s, (hipEvent_t)e0, (hipEvent_t)e1);
+        else if (tile == 128129 || tile == 0) {
+            if (deep) pg_launch_pair<128, 128, 4, 2, 4>(d, s, (hipEvent_t)e0, (hipEvent_t)e1);
+            else pg_launch_pair<128, 128, 4, 2, 3>(d, s, (hipEvent_t)e0, (hipEvent_t)e1);
+        } else return VBG_EARG;
         VBG_LAUNCH_RET();
     }
     VBG_CHECK_ARG(d.form == 0);
