@@ -313,9 +313,14 @@ def main():
     # vbg_*_timed) -- in a leg of its own, so that the headline region above carries no instrumentation
     prof = ops.GemmProfiler(OP_DENSE_K, OP_DENSE_K, False)       # the dense NT GEMM (BERT linears, 1x1 convs): dominant kernel
     ops.set_gemm_profiler(prof)
+    c3rec = []
+    ops.set_conv3_profiler(c3rec)                                # the second family by time: the row-reuse 3x3 convolutions (fwd + dgrad)
     timed_leg(0)
     ops.set_gemm_profiler(None)
+    ops.set_conv3_profiler(None)
     launches, flops, ms, mfma_flops = prof.summary()
+    c3_ms = sum(e0.elapsed_time(e1) for _, _, e0, e1 in c3rec)
+    c3_fl, c3_exec = sum(r[0] for r in c3rec), sum(r[0] * r[1] for r in c3rec)
 
     h2d_leg = None
     if not args.h2d and not args.no_h2d_leg:      # the same steps with the batch uploaded inside every step (SURVEY §8d step body)
@@ -441,6 +446,15 @@ def main():
                          "traffic": traffic, "traffic_source": traffic_src, "launches": launches, "avg_us": round(1e3 * ms / max(launches, 1), 2),
                          "vs_fp32_mfma_peak": round(ach / PEAK_F32_TF, 4)},
         }
+        if c3rec and c3_ms > 0:
+            # the largest kernel family by time since round 3: same definition as `roofline` -- executed matrix-core
+            # flops (3 or 6 piece products per product; only real pixels count on the 7x7 region maps, whose tiles carry 49 of 64
+            # rows) over the launches' own time (event pairs on the launch stream, in the roofline leg) against the dense peak
+            out["roofline_conv3"] = {"bound": "mfma", "kernel": "vbg::conv3x3_kernel<*,*,*> (3x3 / stride-1 convolutions, forward + input gradient, csrc/conv3.hip)",
+                                     "achieved": round(c3_exec / c3_ms / 1e9, 1), "peak": round(mfma_peak, 1), "unit": "TFLOP/s",
+                                     "frac": round(c3_exec / c3_ms / 1e9 / mfma_peak, 4), "achieved_fp32_equivalent": round(c3_fl / c3_ms / 1e9, 2),
+                                     "launches": len(c3rec), "avg_us": round(1e3 * c3_ms / len(c3rec), 2),
+                                     "ms_per_step": round(c3_ms / args.steps, 3)}
         if h2d_leg is not None:
             out["h2d_inclusive"] = h2d_leg
         if amp_leg is not None:

@@ -763,9 +763,25 @@ def conv3x3(x, w_ohwi, bias=None, out=None, stats=None, accumulate=False, f16x2=
         tiles = (B * H * W // 128) * (N // 128)
         slab = torch.empty((tiles * nz, 128 * 128), device=x.device, dtype=f32)
         tickets = _conv3_tickets(x.device, tiles)
+    ev = None
+    if _CONV3_PROF[0] is not None:           # bench.py's second roofline object: events around the launch, on the launch stream
+        ev = (torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True))
+        ev[0].record()
     check(lib.vbg_conv3x3(P(x), P(w_ohwi), P(bias), P(out), P(stats), bn_slots() if stats is not None else 0, B, H, W, Cs, N,
                           int(accumulate), int(bool(f16x2)), P(x_amax), P(slab), P(tickets), nz, _stream()), "vbg_conv3x3")
+    if ev is not None:
+        ev[1].record()
+        _CONV3_PROF[0].append((2.0 * B * H * W * Cs * N * 9, 3 if f16x2 else 6, ev[0], ev[1]))
     return out
+
+
+_CONV3_PROF = [None]
+
+
+def set_conv3_profiler(records):
+    """records: a list that receives (algorithmic flops, piece products per product, start event, stop event) per row-reuse
+    forward / input-gradient launch -- or None (off)"""
+    _CONV3_PROF[0] = records
 
 
 def conv3x3_wflip(w_ohwi):
