@@ -42,7 +42,7 @@ for (B, H, W, Ci, Co) in [(8, 128, 128, 256, 256), (8, 128, 128, 128, 128), (8, 
 
 # split form of the forward / input-gradient kernel on the late trunk stages: workgroups per tile
 ops.set_conv3(True)
-for (B, H, W, Ci, Co) in [(8, 32, 32, 256, 256), (8, 16, 16, 512, 512)]:
+for (B, H, W, Ci, Co) in [(8, 32, 32, 256, 256), (8, 16, 16, 512, 512), (8, 64, 64, 128, 128), (8, 64, 64, 256, 256)]:
     x = torch.randn(B, H, W, Ci, device=dev)
     w = torch.randn(Co, 3, 3, Ci, device=dev) / (3 * Ci ** 0.5)
     fl = 2.0 * B * H * W * Ci * Co * 9
