@@ -23,6 +23,7 @@ import time
 
 ROOT = os.path.dirname(os.path.abspath(__file__))
 sys.path.insert(0, os.path.join(ROOT, "vibertgrid-pytorch_amd"))
+os.environ.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")        # dmabuf IPC: what RCCL needs on this driver for N > 1
 
 import torch
 import torch.distributed as dist
@@ -157,6 +158,12 @@ def main():
     ap.add_argument("--cpu-threads", type=int, default=0, help="threads of the CPU baseline (default: all cores AND 16, both reported)")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-syncbn", action="store_true")
+    ap.add_argument("--syncbn-comm", default="shared", choices=["shared", "own"],
+                    help="N > 1: SyncBatchNorm statistics on the gradient buckets' communicator (default: one communicator, one "
+                         "rank-invariant order of collectives) or on an own communicator concurrent with the buckets (the A/B)")
+    ap.add_argument("--no-ddp-overlap", action="store_true", help="N > 1: launch every gradient bucket after backward (A/B of the overlap)")
+    ap.add_argument("--dist-timeout", type=int, default=int(os.environ.get("VBG_DIST_TIMEOUT", "240")),
+                    help="N > 1: process-group timeout in seconds; a stalled step also prints which bucket / SyncBatchNorm collective every rank is at")
     ap.add_argument("--amp", action="store_true", help="time the `amp: True` path (bf16 matrix cores) as the headline value instead "
                     "of fp32; the default run reports it beside the fp32 value under \"amp\"")
     ap.add_argument("--no-amp-leg", action="store_true", help="skip the secondary amp / fp32-MFMA measurements of the default run")
@@ -187,7 +194,10 @@ def main():
     if world > 1:
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
         # VBG_DIST_BACKEND=gloo lets two ranks share ONE GPU for functional validation of the N>1 path
-        dist.init_process_group(os.environ.get("VBG_DIST_BACKEND", "nccl"), rank=rank, world_size=world)
+        import datetime
+        dist.init_process_group(os.environ.get("VBG_DIST_BACKEND", "nccl"), rank=rank, world_size=world,
+                                timeout=datetime.timedelta(seconds=args.dist_timeout),
+                                **({"device_id": dev} if os.environ.get("VBG_DIST_BACKEND", "nccl") == "nccl" else {}))
         # host-side agreement on per-step decisions (gradient clipping): a gloo group over the loopback interface (single node)
         os.environ.setdefault("GLOO_SOCKET_IFNAME", "lo")
         try:
@@ -219,7 +229,11 @@ def main():
     opt_cnn = FusedSGD(cnn, dev, lr=0.005, momentum=0.9, weight_decay=0.005)
     opt_bert = FusedAdamW(bert, dev, lr=5e-5, betas=(0.9, 0.999), eps=1e-8, weight_decay=0.01)
     opts = [opt_cnn, opt_bert]
-    reducer = FlatReducer(opts)
+    # one communicator in flight by default (classifier_mode simp: the same graph on every rank, every step); --syncbn-comm own
+    # is the overlapped two-communicator form of round 3, kept as the A/B
+    reducer = FlatReducer(opts, sync_bn_group=("new" if args.syncbn_comm == "own" else "default"), overlap=not args.no_ddp_overlap)
+    if world > 1:
+        reducer.start_watchdog(max(30.0, args.dist_timeout / 2))        # a stalled step leaves a line per rank on stderr
 
     B = args.batch or shape["batch"]
     batch = synthetic_batch(B, shape["img"], shape["img"], 512, shape["S"], shape["ncls"], shape["vocab"], 1234 + rank)
@@ -401,14 +415,16 @@ def main():
                 print(f"[sync check] {len(bad)} of {len(named)} parameters differ between ranks; first: {[named[i][0] for i in bad[:12]]}", file=sys.stderr, flush=True)
     # HBM-side bytes per launch of the same kernel: rocprofv3 PMC passes of this command (cannot be collected in-process),
     # summarised in profiles/ by the round that produced them; null when the file is absent
-    traffic, traffic_src = None, None
-    for rnd in ("r03", "r02", "r01"):
-        tf = os.path.join(os.path.dirname(os.path.abspath(__file__)), "profiles", f"{rnd}_gemm_hbm_traffic.json")
-        if os.path.exists(tf):
-            with open(tf) as fh:
-                traffic = round(float(json.load(fh)["bytes_per_launch"]), 0)
-            traffic_src = f"profiles/{rnd}_gemm_hbm_traffic.json: rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE passes of this command (counters cannot be read in-process), not this run"
-            break
+    def pmc_traffic(stem):
+        for rnd in ("r04", "r03", "r02", "r01"):
+            tf = os.path.join(ROOT, "profiles", f"{rnd}_{stem}.json")
+            if os.path.exists(tf):
+                with open(tf) as fh:
+                    return (round(float(json.load(fh)["bytes_per_launch"]), 0),
+                            f"profiles/{rnd}_{stem}.json: rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE passes of this command (counters cannot be read in-process), not this run")
+        return None, None
+    traffic, traffic_src = pmc_traffic("gemm_hbm_traffic")
+    traffic_c3, traffic_c3_src = pmc_traffic("conv3_hbm_traffic")
 
     if rank == 0:
         docs = B * world * args.steps
@@ -429,32 +445,40 @@ def main():
                                     f"512x512, T=512 tokens, S=128 segments, batch {B}/GPU, fwd+bwd+SGD/AdamW, dropout 0.1, simp classifier")
                        if args.shape == "cfg2" else f"EXPLORATORY {args.shape}: {shape}, T=512, batch {B}/GPU (not the BASELINE metric's configuration)",
                        "global_batch": B * world, "seq_len": 512, "parallelism": f"dp{world}" + ("+syncbn" if sync_bn else ""),
-                       **({"step_barrier": not args.no_step_barrier} if world > 1 else {}),
+                       **({"step_barrier": not args.no_step_barrier, "syncbn_comm": reducer.sync_bn_mode, "ddp_overlap": reducer.overlap,
+                           "buckets": len(reducer.buckets), "backend": dist.get_backend()} if world > 1 else {}),
                        "last_loss": round(float(last), 4), **({"ranks_in_sync": ranks_in_sync} if ranks_in_sync is not None else {}), **({"h2d_in_step": packed_src.nbytes()} if args.h2d else {})},
             # algorithmic (fp32-equivalent, PAD-free) TFLOP/s of the whole step; as a fraction of the six-product form's
             # matrix-core ceiling (2500 / 6) -- a lower bound of the pipe's share now that part of the step runs three products
             "step_tflops": round(value / world * f_step / 1e3, 2),
             "step_frac_of_six_product_ceiling": round(value / world * f_step / 1e3 / (PEAK_BF16_TF / SPLIT_PRODUCTS), 4),
-            # the dense NT GEMM launches (own leg, see above): `achieved` = algorithmic fp32-equivalent TFLOP/s; `mfma_rate` = what the
-            # matrix pipe executes (6 or 3 piece products per product, per launch); peak = the dense bf16 / fp16 MFMA peak; frac = share of it
-            "roofline": {"bound": "mfma",
-                         "kernel": ("vbg::gemm_kernel<*,*,*,DENSE_K,DENSE_K,*,1> (bf16 MFMA NT GEMM, amp; every ungrouped launch)" if args.amp else
-                                    "vbg::gemm_kernel<*,*,*,DENSE_K,DENSE_K,*,0> (fp32 MFMA NT GEMM; every ungrouped launch)" if args.fp32_mfma else
-                                    "vbg::plane_gemm_kernel<*,*,*,*,*,false,*,0|1> + vbg::gemm_kernel<*,*,*,DENSE_K,DENSE_K,*,3> (fp32-grade NT GEMM: the BERT linears from pre-split planes -- forward QKV / FFN1 / FFN2 and the data gradients as 3 fp16 piece products, the attention-output projection as 6 bf16 piece products --, 1x1 convs / heads with the in-kernel split; every ungrouped launch, timed in a leg of its own)"),
-                         "achieved": round(mfma_rate, 1), "peak": round(mfma_peak, 1), "unit": "TFLOP/s", "frac": round(mfma_rate / mfma_peak, 4),
-                         "achieved_fp32_equivalent": round(ach, 2), "piece_products_per_product": round(mfma_flops / max(flops, 1.0), 3),
-                         "traffic": traffic, "traffic_source": traffic_src, "launches": launches, "avg_us": round(1e3 * ms / max(launches, 1), 2),
-                         "vs_fp32_mfma_peak": round(ach / PEAK_F32_TF, 4)},
         }
+        # Roofline objects (the step is bound by the matrix cores).  Definition, the same for both: `achieved` = ALGORITHMIC
+        # (fp32-equivalent, 2 M N K per product; only real pixels on the 7x7 region maps) TFLOP/s over the launches' own time -- event pairs
+        # in the dispatch packets / on the launch stream, in a leg of its own --; `peak` = the dense bf16 / fp16 MFMA peak divided by the
+        # piece products the arithmetic form issues per product (3: two fp16 pieces, 6: three bf16 pieces; the launch-weighted mean when a
+        # family mixes them); `frac` = achieved / peak = executed matrix-core flops / the dense peak (`mfma_executed` / `mfma_peak`).
+        pp_nt = mfma_flops / max(flops, 1.0)
+        nt = {"bound": "mfma",
+              "kernel": ("vbg::gemm_kernel<*,*,*,DENSE_K,DENSE_K,*,1> (bf16 MFMA NT GEMM, amp; every ungrouped launch)" if args.amp else
+                         "vbg::gemm_kernel<*,*,*,DENSE_K,DENSE_K,*,0> (fp32 MFMA NT GEMM; every ungrouped launch)" if args.fp32_mfma else
+                         "vbg::plane_gemm_kernel<*,*,*,*,*,false,*,0|1> + vbg::gemm_kernel<*,*,*,DENSE_K,DENSE_K,*,3> (fp32-grade NT GEMM: the BERT linears from pre-split planes, 1x1 convs / heads with the in-kernel split; every ungrouped launch)"),
+              "achieved": round(ach, 2), "peak": round(mfma_peak / max(pp_nt, 1.0), 1), "unit": "TFLOP/s", "frac": round(mfma_rate / mfma_peak, 4),
+              "mfma_executed": round(mfma_rate, 1), "mfma_peak": round(mfma_peak, 1), "piece_products_per_product": round(pp_nt, 3),
+              "traffic": traffic, "traffic_source": traffic_src, "launches": launches, "avg_us": round(1e3 * ms / max(launches, 1), 2),
+              "ms_per_step": round(ms / args.steps, 3), "vs_fp32_mfma_peak": round(ach / PEAK_F32_TF, 4)}
         if c3rec and c3_ms > 0:
-            # the largest kernel family by time since round 3: same definition as `roofline` -- executed matrix-core
-            # flops (3 or 6 piece products per product; only real pixels count on the 7x7 region maps, whose tiles carry 49 of 64
-            # rows) over the launches' own time (event pairs on the launch stream, in the roofline leg) against the dense peak
-            out["roofline_conv3"] = {"bound": "mfma", "kernel": "vbg::conv3x3_kernel<*,*,*> (3x3 / stride-1 convolutions, forward + input gradient, csrc/conv3.hip)",
-                                     "achieved": round(c3_exec / c3_ms / 1e9, 1), "peak": round(mfma_peak, 1), "unit": "TFLOP/s",
-                                     "frac": round(c3_exec / c3_ms / 1e9 / mfma_peak, 4), "achieved_fp32_equivalent": round(c3_fl / c3_ms / 1e9, 2),
-                                     "launches": len(c3rec), "avg_us": round(1e3 * c3_ms / len(c3rec), 2),
-                                     "ms_per_step": round(c3_ms / args.steps, 3)}
+            # the dominant kernel family by time since round 3: the row-reuse 3x3 convolutions, forward + input gradient
+            pp_c3 = c3_exec / max(c3_fl, 1.0)
+            out["roofline"] = {"bound": "mfma", "kernel": "vbg::conv3x3_kernel<*,*,*> (3x3 / stride-1 convolutions, forward + input gradient, csrc/conv3.hip): the largest kernel family of the step",
+                               "achieved": round(c3_fl / c3_ms / 1e9, 2), "peak": round(mfma_peak / max(pp_c3, 1.0), 1), "unit": "TFLOP/s",
+                               "frac": round(c3_exec / c3_ms / 1e9 / mfma_peak, 4), "mfma_executed": round(c3_exec / c3_ms / 1e9, 1), "mfma_peak": round(mfma_peak, 1),
+                               "piece_products_per_product": round(pp_c3, 3), "traffic": traffic_c3, "traffic_source": traffic_c3_src,
+                               "launches": len(c3rec), "avg_us": round(1e3 * c3_ms / len(c3rec), 2), "ms_per_step": round(c3_ms / args.steps, 3),
+                               "vs_fp32_mfma_peak": round(c3_fl / c3_ms / 1e9 / PEAK_F32_TF, 4)}
+            out["roofline_nt"] = nt
+        else:
+            out["roofline"] = nt
         if h2d_leg is not None:
             out["h2d_inclusive"] = h2d_leg
         if amp_leg is not None:
@@ -471,7 +495,7 @@ def main():
             out["cpu_baseline"] = cpu_baseline(args.cpu_threads or min(ncpu, 16))
             if not args.cpu_threads and ncpu > 16:
                 import subprocess
-                limit = 150
+                limit = 30          # the attempt is a note beside the baseline, not worth minutes of an idle GPU
                 try:
                     r = subprocess.run([sys.executable, os.path.abspath(__file__), "--cpu-baseline-only", str(ncpu)], capture_output=True, text=True, timeout=limit)
                     line = [l for l in r.stdout.splitlines() if l.startswith("{")]

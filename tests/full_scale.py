@@ -25,6 +25,8 @@ CASES = {
     "cfg5": dict(bert="roberta-base", vocab=50265, max_pos=514, type_vocab=1, roberta=True, ln_eps=1e-5,
                  backbone="resnet_34_fpn", ncls=5, img=1024, T=512, S=128, S1=111, box_w=(8, 72), box_h=(8, 24)),
 }
+# FUNSD segment-level, resnet_34_fpn (own layout) + bert-base-uncased, 4 classes (BASELINE configs[2]; train_FUNSD.py:198-202)
+CASES["cfg3"] = dict(CASES["cfg2"], backbone="resnet_34_fpn", ncls=4, S1=90)
 # cfg2 with the constructor's DEFAULT loss arguments (`loss_aux_sample_list=None`, every `num_hard_*` = -1: plain mean cross
 # entropies, model/ViBERTgrid_net.py:143-150).  The sampled / OHEM losses pick elements by sorted rank, so a 1e-7 change of one
 # logit moves the reference's own gradients by percents (DESIGN.md "OHEM ties"); with the plain losses the gradient is a smooth
@@ -40,6 +42,11 @@ CASES["cfg2e"] = dict(CASES["cfg2"], plain=True, bn_frozen=True)
 # paths) model of configs[4]
 CASES["cfg4e"] = dict(CASES["cfg4"], plain=True, bn_frozen=True)
 CASES["cfg5e"] = dict(CASES["cfg5"], plain=True, bn_frozen=True)
+CASES["cfg3e"] = dict(CASES["cfg3"], plain=True, bn_frozen=True)
+# the BENCHMARK's batch: eight cfg2 documents (four full, four ragged) through the reference in one step.  The -m gpu test runs it
+# with the library's OWN dispatch (nothing forced): the tile choices, split counts and arithmetic forms bench.py times
+# (256 x 128 NT tiles, `vbg_conv3x3_split` counts at 8 x 32^2 / 16^2, region maps at N ~ 900 RoIs) are held to the reference here.
+CASES["cfg2e8"] = dict(CASES["cfg2"], plain=True, bn_frozen=True, B=8)
 # parameters whose gradients are stored as strided samples (the norms of ALL parameter gradients are stored too)
 GRAD_PICK = ["bert_model.embeddings.word_embeddings.weight", "bert_model.encoder.layer.0.attention.self.query.weight",
              "bert_model.encoder.layer.5.intermediate.dense.weight", "bert_model.encoder.layer.11.output.dense.weight",
@@ -75,12 +82,12 @@ def inputs(name):
     """(imgs, segs, classes, coors, corpus, mask) like data/SROIE_dataset.py's collate hands them to the model"""
     c = CASES[name]
     g = torch.Generator().manual_seed(20260929 + sum(map(ord, name[:4])))
-    B, H, W, T, S = 2, c["img"], c["img"], c["T"], c["S"]
+    B, H, W, T, S = c.get("B", 2), c["img"], c["img"], c["T"], c["S"]
     imgs = tuple(torch.rand(3, H, W, generator=g) for _ in range(B))
     per = T // S
     coors, segs, classes = [], [], []
     for b in range(B):
-        s = S if b == 0 else c["S1"]
+        s = S if b % 2 == 0 else c["S1"]           # every second document is ragged
         x1 = torch.randint(0, W - c["box_w"][1], (s,), generator=g)
         y1 = torch.randint(0, H - c["box_h"][1], (s,), generator=g)
         w = torch.randint(c["box_w"][0], c["box_w"][1] + 1, (s,), generator=g)
@@ -91,8 +98,8 @@ def inputs(name):
     corpus = torch.randint(1000, c["vocab"], (B, T), generator=g)
     mask = torch.ones(B, T, dtype=torch.int32)
     n1 = c["S1"] * per
-    corpus[1, n1:] = 0
-    mask[1, n1:] = 0
+    corpus[1::2, n1:] = 0
+    mask[1::2, n1:] = 0
     return imgs, tuple(segs), tuple(classes), tuple(coors), corpus, mask
 
 

@@ -249,3 +249,118 @@ def test_syncbn_unequal_row_counts(tmp_path):
     assert close(r[0]["dg"] + r[1]["dg"], one["dg"], 1e-4) and close(r[0]["db"] + r[1]["db"], one["db"], 1e-4)
     for k in range(2):                                             # every rank tracks the GLOBAL running statistics
         assert close(r[k]["rm"], one["rm"]) and close(r[k]["rv"], one["rv"])
+
+
+# ---------------------------------------------------------------------------------------------------------------------------------
+# (iv) the reference's UNMODIFIED wrapper (train_SROIE.py:202-235): convert_sync_batchnorm + DistributedDataParallel(model,
+# device_ids=[gpu], find_unused_parameters=True) + torch.optim.SGD / AdamW split by "bert_model" in the parameter name
+# ---------------------------------------------------------------------------------------------------------------------------------
+def _stock_worker(rank, world, port, tmp):
+    import sys
+    here = os.path.dirname(os.path.abspath(__file__))
+    for p in (here, os.path.join(os.path.dirname(here), "oracle"), os.path.join(os.path.dirname(here), "vibertgrid-pytorch_amd")):
+        if p not in sys.path:
+            sys.path.insert(0, p)
+    os.environ.update(MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port))
+    torch.cuda.set_device(0)
+    dev = torch.device("cuda", 0)
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    from test_gpu_model import to_dev
+    from vbg import ops
+    from vbg.optim import FlatReducer, FusedAdamW, FusedSGD, split_parameters
+    v = "conv3"
+    _dispatch(ops, v)
+    dbatch = to_dev(_slice(_docs(), rank, rank + 1), dev)
+    hyper = dict(lr_cnn=0.005, mom=0.9, wd_cnn=0.005, lr_bert=5e-5, wd_bert=0.01)
+    res = {}
+
+    # ---- route A: the reference's own wiring, nothing from vbg.optim ------------------------------------------------------------
+    model = _build(os.path.join(tmp, f"stock{rank}"), sync_bn=False, v=v)
+    init = {n: p.detach().clone() for n, p in model.named_parameters()}
+    model = torch.nn.SyncBatchNorm.convert_sync_batchnorm(model)                                  # train_SROIE.py:202-203
+    model = model.to(dev)
+    model = torch.nn.parallel.DistributedDataParallel(model, device_ids=[0], find_unused_parameters=True)      # :206-209
+    params_cnn, params_bert = [], []
+    for name, parameters in model.named_parameters():                                             # :215-221
+        if "bert_model" in name and parameters.requires_grad:
+            params_bert.append(parameters)
+        elif parameters.requires_grad:
+            params_cnn.append(parameters)
+    optimizer_cnn = torch.optim.SGD(params=params_cnn, lr=hyper["lr_cnn"], momentum=hyper["mom"], weight_decay=hyper["wd_cnn"])
+    optimizer_bert = torch.optim.AdamW(params=params_bert, lr=hyper["lr_bert"], betas=(0.9, 0.999), eps=1e-8, weight_decay=hyper["wd_bert"])
+    model.train()
+    res["stock_losses"] = []
+    for step in range(3):                                                                         # pipeline/train_val_utils.py:264-284
+        random.seed(5)
+        train_loss = model(*dbatch)
+        res["stock_losses"].append(float(train_loss.item()))
+        optimizer_cnn.zero_grad()
+        optimizer_bert.zero_grad()
+        train_loss.backward()
+        optimizer_cnn.step()
+        optimizer_bert.step()
+    torch.cuda.synchronize()
+    res["stock"] = {n: p.detach().cpu().clone() for n, p in model.module.named_parameters()}
+    res["stock_rm"] = model.module.backbone.conv_1[1].running_mean.cpu().clone()
+    res["stock_has_grad"] = sorted(n for n, p in model.module.named_parameters() if p.grad is not None)
+    del model, optimizer_cnn, optimizer_bert
+    torch.cuda.empty_cache()
+
+    # ---- route B: flat buffers + FlatReducer + fused optimizers ("faster step") -----------------------
+    net = _build(os.path.join(tmp, f"flat{rank}"), sync_bn=True, v=v).to(dev).train()
+    cnn, bert = split_parameters(net)
+    opts = [FusedSGD(cnn, dev, lr=hyper["lr_cnn"], momentum=hyper["mom"], weight_decay=hyper["wd_cnn"]),
+            FusedAdamW(bert, dev, lr=hyper["lr_bert"], betas=(0.9, 0.999), eps=1e-8, weight_decay=hyper["wd_bert"])]
+    red = FlatReducer(opts)
+    res["flat_losses"] = []
+    for step in range(3):
+        random.seed(5)
+        loss = net(*dbatch)
+        res["flat_losses"].append(float(loss.item()))
+        for o in opts:
+            o.zero_grad()
+        loss.backward()
+        red.finish()
+        for o in opts:
+            o.step()
+    torch.cuda.synchronize()
+    res["flat"] = {n: p.detach().cpu().clone() for n, p in net.named_parameters()}
+    res["flat_rm"] = net.backbone.conv_1[1].running_mean.cpu().clone()
+    res["init"] = {n: t.cpu() for n, t in init.items()}
+    res["sync_bn_mode"] = red.sync_bn_mode
+    torch.save(res, os.path.join(tmp, f"stock_res{rank}.pt"))
+    dist.barrier()
+    dist.destroy_process_group()
+
+
+def test_stock_ddp_wrapper_equals_flat_reducer(tmp_path):
+    """The reference's unmodified multi-GPU wiring around the drop-in model -- SyncBatchNorm.convert_sync_batchnorm,
+    DistributedDataParallel(device_ids=[gpu], find_unused_parameters=True), torch.optim.SGD + AdamW (train_SROIE.py:202-235) -- on two
+    ranks sharing the GPU over gloo: after 3 steps both ranks hold the same parameters, and they are the parameters the FlatReducer /
+    fused-optimizer route produces (losses per step to 1e-5, every parameter's 3-step change to 1e-3 rel-L2: the two routes differ by
+    where 1 / world is applied and by the optimizer kernels' rounding)."""
+    tmp = str(tmp_path)
+    port = _free_port()
+    mp.spawn(_stock_worker, args=(2, port, tmp), nprocs=2, join=True)
+    r0, r1 = (torch.load(os.path.join(tmp, f"stock_res{r}.pt")) for r in range(2))
+    assert r0["sync_bn_mode"] == "shared communicator"
+    # DDP keeps replicas identical: bit-equal parameters on both ranks, for both routes
+    for route in ("stock", "flat"):
+        for k in r0[route]:
+            assert torch.equal(r0[route][k], r1[route][k]), (route, k)
+    # the static unused set of the reference (find_unused_parameters=True): pooler never gets a gradient
+    assert not any("pooler" in n for n in r0["stock_has_grad"])
+    assert torch.allclose(r0["stock_rm"], r0["flat_rm"], rtol=1e-5, atol=1e-7)
+    print("losses stock", r0["stock_losses"], "flat", r0["flat_losses"])
+    for a, b in zip(r0["stock_losses"], r0["flat_losses"]):
+        assert abs(a - b) <= 1e-5 * abs(b), (a, b)
+    worst = []
+    for k, p0 in r0["init"].items():
+        if k.startswith("BERTgrid_generator.") or "pooler" in k or "key.bias" in k:
+            continue
+        da, db = (r0["stock"][k] - p0).double(), (r0["flat"][k] - p0).double()
+        assert float(db.norm()) > 0, k                      # the parameter moved
+        worst.append((float((da - db).norm() / (db.norm() + 1e-30)), k))
+    worst.sort(reverse=True)
+    print("stock DDP vs FlatReducer, rel-L2 of the 3-step parameter change, worst:", worst[:5], "median", worst[len(worst) // 2])
+    assert worst[0][0] < 1e-3, worst[:8]

@@ -70,7 +70,8 @@ def _setup(golden, tmp_path, name):
     from vbg import ops
     # the forward BERT linears take the fp16-pair form from ~100 tiles of 128 x 128 on (batch 8); these tests run batch 2 and force
     # it, so that the arithmetic held to the reference here is the arithmetic of the benchmark (VBG_PAIR=0: the six-product form)
-    ops.set_pair(os.environ.get("VBG_PAIR", "1") != "0", force=True)
+    # (the batch-8 case runs the library's own dispatch: nothing forced)
+    ops.set_pair(os.environ.get("VBG_PAIR", "1") != "0", force=(c.get("B", 2) < 8))
     net = build_full(tmp_path, name)
     # state_dict inventory == the reference's, weights = the deterministic values the fixture was generated with
     ref_shapes = {str(k): str(v) for k, v in zip(g["keys"], g["key_shapes"])}
@@ -105,7 +106,8 @@ def _check_eval(g, c, net, dbatch, name, loss_tol):
     print(f"{name}: class-probability error / (1e-4 rel + 1e-5 abs) = {err:.3f}; max abs {float((pred.cpu() - ref).abs().max()):.3e}")
     # north_star: logits within 1e-4 rel of the reference
     assert torch.allclose(pred.cpu(), ref, rtol=1e-4, atol=1e-5)
-    assert pm.shape == (2, 3, c["img"], c["img"]) and ps.shape == (2, c["ncls"], c["img"], c["img"])
+    nb = c.get("B", 2)
+    assert pm.shape == (nb, 3, c["img"], c["img"]) and ps.shape == (nb, c["ncls"], c["img"], c["img"])
     # segmentation logits (model/semantic_segmentation_head.py:66-78): 1e-4 of the tensor's largest logit in the max norm and 1e-4
     # relative L2 -- element-wise relative error is meaningless where a logit crosses zero.  Where the fixture carries the
     # reference's OWN change of these tensors under a one-ulp move of its weights (`*_1ulp`, plain-loss cases), that floor is
@@ -146,9 +148,9 @@ def _grad_errors(g, net):
 HEAD_ONLY = ("field_type_classification_head.", "late_fusion_net.fuse_embedding_net.", "late_fusion_net.ROI_embedding_net.linear.")
 
 
-@pytest.mark.parametrize("name", ["cfg2", "cfg4", "cfg5"])
+@pytest.mark.parametrize("name", ["cfg2", "cfg3", "cfg4", "cfg5"])
 def test_full_scale_vs_reference_golden(golden, tmp_path, name):
-    """BASELINE configs[1], [3], [4] with the losses of example_config.yaml:40-50 (sampled / OHEM)."""
+    """BASELINE configs[1], [2], [3], [4] with the losses of example_config.yaml:40-50 (sampled / OHEM)."""
     g, c, net, dbatch = _setup(golden, tmp_path, name)
     # loss: the reference's value depends on the tie order of its unstable sort (DESIGN.md "OHEM ties") -> 5e-3
     loss = _check_eval(g, c, net, dbatch, name, 5e-3)
@@ -190,11 +192,15 @@ def test_full_scale_vs_reference_golden(golden, tmp_path, name):
     assert torch.allclose(sdn[bnk + ".running_var"].cpu(), T(g["bn_rv"]), rtol=1e-4, atol=1e-6)
 
 
-@pytest.mark.parametrize("name", ["cfg2p", "cfg2e", "cfg4e", "cfg5e"])
+@pytest.mark.parametrize("name", ["cfg2p", "cfg2e", "cfg3e", "cfg4e", "cfg5e", "cfg2e8"])
 def test_full_scale_every_gradient_vs_reference(golden, tmp_path, name):
     """The cfg2 model with the constructor's DEFAULT losses (plain mean cross entropies: smooth in the weights), train-mode
-    BatchNorm (cfg2p) and frozen BatchNorm (cfg2e), and the configs[3] / configs[4] models (char-level 12-class own-layout resnet;
-    RoBERTa + 1024 x 1024) with frozen BatchNorm (cfg4e / cfg5e): loss and EVERY parameter gradient against the reference's autograd.
+    BatchNorm (cfg2p) and frozen BatchNorm (cfg2e), and the configs[2] / configs[3] / configs[4] models (FUNSD 4-class own-layout
+    resnet-34; char-level 12-class own-layout resnet; RoBERTa + 1024 x 1024) with frozen BatchNorm (cfg3e / cfg4e / cfg5e): loss and
+    EVERY parameter gradient against the reference's autograd.  cfg2e8 = the BENCHMARK's batch (eight cfg2 documents in one step of the
+    reference) under the library's own dispatch -- the tile choices, split counts and arithmetic forms bench.py times; the test
+    asserts that the batch-8 paths really ran (fp16-pair BERT products unforced, row-reuse convolutions incl. the split late stages
+    and the region maps).
     The fixture also carries the reference's own gradient change under a one-ulp perturbation of its weights (`ulpnoise_*`):
     the rounding-error floor of this model.  cfg2e: every gradient within 1e-3 relative L2.  cfg2p (batch statistics couple
     every pixel; the reference moves by 6e-3 under one ulp): within 3x the reference's own one-ulp change (floor 1e-4: bias gradients are fp32 sums of 5e5 terms)."""
@@ -202,10 +208,18 @@ def test_full_scale_every_gradient_vs_reference(golden, tmp_path, name):
     form = os.environ.get("VBG_TEST_PRECISION", "split")        # diagnostic: "fp32" = every product on the fp32 matrix pipe
     from vbg import ops
     ops.set_precision(form)
+    seen = ops.dispatch_log(True) if c.get("B", 2) >= 8 else None
     try:
         _every_gradient(g, c, net, dbatch, name + ("" if form == "split" else "_" + form))
     finally:
         ops.set_precision("split")
+        ops.dispatch_log(False)
+    if seen is not None and form == "split" and os.environ.get("VBG_PAIR", "1") != "0":
+        print(f"{name}: dispatch seen:", {k: seen[k] for k in sorted(seen)})
+        # the paths bench.py's batch takes, unforced
+        assert seen.get("plane_gemm:pair", 0) >= 36 + 48, seen          # forward QKV / FFN1 / FFN2 + the data gradients on two fp16 pieces
+        assert seen.get("conv3:fwd", 0) >= 30 and seen.get("conv3:split", 0) >= 10 and seen.get("conv3:roi", 0) >= 2, seen
+        assert seen.get("conv3:wgrad", 0) >= 25, seen
 
 
 def _every_gradient(g, c, net, dbatch, name):

@@ -524,12 +524,6 @@ __global__ __launch_bounds__(WGM * WGN * 64) void plane_gemm_kernel(const vbg_pl
             *reinterpret_cast<uint2*>(o + p.q_plane) = l;
         }
     }
-    // optional: the largest magnitude this launch stored (the scale of the fp16-pair planes a split pass makes of C next)
-    if (p.c_amax) {                                   // (uniform)
-        __syncthreads();
-        vbg_amax_publish(vmax, p.c_amax, Ct);
-        __syncthreads();
-    }
     // optional column sums of the stored values (the bias gradient of the layer whose dL/d(output) this product produces): one thread
     // per column of the staged tile, one atomic per column and row tile (rows past M hold zeros: their operand rows were read as zeros)
     if (p.colsum) {                                   // (uniform)
@@ -540,6 +534,12 @@ __global__ __launch_bounds__(WGM * WGN * 64) void plane_gemm_kernel(const vbg_pl
             for (int r = 0; r < rows; ++r) cs += Ct[r * CTS + tid];
             unsafeAtomicAdd(p.colsum + n0 + tid, cs);
         }
+    }
+    // optional: the largest magnitude this launch stored (the scale of the fp16-pair planes a split pass makes of C next).  LAST: the
+    // publish borrows the first words of the staged tile as its per-wave scratch, and the column sums above read that tile
+    if (p.c_amax) {                                   // (uniform)
+        __syncthreads();
+        vbg_amax_publish(vmax, p.c_amax, Ct);
     }
 }
 
@@ -1310,6 +1310,9 @@ static int plane_gemm_dispatch(const vbg_plane_gemm_desc* desc, void* stream, vo
     if (d.splitk > 1) VBG_CHECK_ARG(d.accumulate == 1 && d.C);
     if (d.accumulate) VBG_CHECK_ARG(d.epi == VBG_EPI_NONE && d.Cp == nullptr);
     if (d.colsum) VBG_CHECK_ARG(d.splitk == 1 && d.ngroups == 0 && !d.trans && !d.accumulate && d.epi != VBG_EPI_GELU_DUAL && d.tile != 256256 && !(d.sk_ws && d.sk_cnt));
+    // the amax by-product exists in the epilogue of the 8-wave NT tiles only: elsewhere the slot would stay 0 and the consumer's scale
+    // would be meaningless (gradient pieces underflowing in fp16) -- refuse instead of ignoring it
+    if (d.c_amax) VBG_CHECK_ARG(d.tile != 256256 && !(d.sk_ws && d.sk_cnt) && !d.trans && d.ngroups == 0 && d.splitk == 1);
     if (d.epi == VBG_EPI_GELU_DUAL) VBG_CHECK_ARG(d.C2 != nullptr || d.Cp != nullptr || d.Cq != nullptr);
     if (d.epi == VBG_EPI_MUL_GELU_GRAD) VBG_CHECK_ARG(d.C2 != nullptr && d.ngroups == 0 && !d.trans && !(d.sk_ws && d.sk_cnt));
     if (d.Cp) VBG_CHECK_ARG(d.ldp % 8 == 0 && d.ldp >= d.N && ((uintptr_t)d.Cp & 7) == 0 && d.c_plane % 4 == 0);

@@ -73,12 +73,26 @@ def _affine_done(gamma_param, beta_param, dg, db, sunk):
     return dg, db
 
 
+def _amax_tag(x):
+    """the amax slot the producer of x published (ConvBnFn tags its output), or None.  The tag carries the tensor's version counter:
+    an in-place write between producer and consumer (x.add_(...), a user hook) may have raised max |x| above what the slot says, and
+    a too-small amax lets the scaled fp16 pieces of the weight-gradient operand overflow to inf -- a stale tag is ignored and the
+    consumer measures the tensor itself (one vbg_amax pass).  """
+    tag = getattr(x, "_vbg_amax", None)
+    if tag is None:
+        return None
+    slot, version = tag
+    return slot if x._version == version else None
+
+
 class SyncCtx:
     """Process group for SyncBatchNorm statistics (train_SROIE.py:202-203 `convert_sync_batchnorm`).  `before`: optional hook run on
     the compute stream in front of every SyncBatchNorm collective (vbg/optim.FlatReducer(serialize_syncbn=True) makes the stream wait
     for the gradient buckets in flight on the staging stream, so that never two communicators have a collective in flight)."""
     group = None
     before = None
+    seq = 0            # statistics collectives issued since the reducer was built; `last` = (seq, numel) -- for hang reports
+    last = None
 
     @classmethod
     def active(cls):
@@ -88,6 +102,8 @@ class SyncCtx:
     def all_reduce(cls, t):
         if cls.before is not None:
             cls.before()
+        cls.seq += 1
+        cls.last = (cls.seq, t.numel())
         dist.all_reduce(t, group=cls.group)
 
 
@@ -275,7 +291,7 @@ class ConvFn(torch.autograd.Function):
 
     @staticmethod
     def forward(ctx, x, w, b, stride, pad):
-        ctx.x_amax = getattr(x, "_vbg_amax", None)        # the producer's word with the bits of max |x| (see ConvBnFn), if any
+        ctx.x_amax = _amax_tag(x)                         # the producer's word with the bits of max |x| (see ConvBnFn), if any
         x = _c(x)
         w4 = ohwi(w)
         y, col, _ = _conv_any(x, w4, stride, pad, b)
@@ -320,7 +336,7 @@ class ConvBnFn(torch.autograd.Function):
 
     @staticmethod
     def forward(ctx, x, w, gamma, beta, running_mean, running_var, res, stride, pad, relu, training, momentum, eps, sync):
-        ctx.x_amax = getattr(x, "_vbg_amax", None)        # the producer's word with the bits of max |x|, if any
+        ctx.x_amax = _amax_tag(x)                         # the producer's word with the bits of max |x|, if any
         x = _c(x)
         sync = bool(sync) and SyncCtx.active()
         w4 = ohwi(w)
@@ -350,7 +366,7 @@ class ConvBnFn(torch.autograd.Function):
         y_amax = ops.amax_slot(x.device) if (any(ctx.needs_input_grad) and ops.conv3_f16_bwd_enabled()) else None
         y = ops.bn_apply(z2, r2, mean, invstd, gamma, beta, relu, y_amax=y_amax).view(z.shape)
         if y_amax is not None:
-            y._vbg_amax = y_amax
+            y._vbg_amax = (y_amax, y._version)
         ctx.cfg = (stride, pad, relu, training, count, res is not None, sync)
         ctx.w_ref, ctx.affine = w, (gamma, beta)
         ctx.save_for_backward(x, w4, col, z, y if relu else None, mean, invstd, gamma, count_dev)

@@ -312,7 +312,10 @@ def plane_gemm(a: Planes, b: Planes, out=None, *, bias=None, epi=EPI_NONE, C2=No
         d.Cq, d.q_plane, d.ldq = out_pair.buf.data_ptr(), out_pair.plane, out_pair.ld
     if colsum_out is not None:             # += column sums of the stored values (a bias gradient)
         d.colsum = colsum_out.data_ptr()
-    if _STREAMK[0] and colsum_out is None and not trans and splitk == 1 and tile in (128129, 128130):
+    if _DISPATCH[0] is not None:
+        _seen("plane_gemm:pair" if form else "plane_gemm:bf16x3")
+        _seen(f"plane_gemm:tile{int(tile)}")
+    if _STREAMK[0] and not form and c_amax is None and colsum_out is None and not trans and splitk == 1 and tile in (128129, 128130):
         ws, cnt, ncu = _sk_workspace(a.buf.device)
         d.sk_ws, d.sk_cnt, d.sk_blocks = ws.data_ptr(), cnt.data_ptr(), ncu
     prof = _GEMM_PROF
@@ -763,6 +766,14 @@ def conv3x3(x, w_ohwi, bias=None, out=None, stats=None, accumulate=False, f16x2=
         tiles = (B * H * W // 128) * (N // 128)
         slab = torch.empty((tiles * nz, 128 * 128), device=x.device, dtype=f32)
         tickets = _conv3_tickets(x.device, tiles)
+    if _DISPATCH[0] is not None:
+        _seen("conv3:fwd")
+        if nz > 1:
+            _seen("conv3:split")
+        if H == 7 and W == 7:
+            _seen("conv3:roi")
+        if f16x2:
+            _seen("conv3:f16x2")
     ev = None
     if _CONV3_PROF[0] is not None:           # bench.py's second roofline object: events around the launch, on the launch stream
         ev = (torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True))
@@ -776,6 +787,21 @@ def conv3x3(x, w_ohwi, bias=None, out=None, stats=None, accumulate=False, f16x2=
 
 
 _CONV3_PROF = [None]
+_DISPATCH = [None]
+
+
+def dispatch_log(on: bool):
+    """on: start counting which kernel families the next calls take ({"plane_gemm:pair": n, "conv3:fwd": n, "conv3:split": n,
+    "conv3:roi": n, "conv3:wgrad": n, ...}) and return the dict; off: stop.  The batch-8 parity test asserts with it that the paths
+    bench.py times are the ones it held to the reference (tests/test_gpu_full_scale.py)."""
+    _DISPATCH[0] = {} if on else None
+    return _DISPATCH[0]
+
+
+def _seen(key):
+    d = _DISPATCH[0]
+    if d is not None:
+        d[key] = d.get(key, 0) + 1
 
 
 def set_conv3_profiler(records):
@@ -818,6 +844,7 @@ def conv3x3_wgrad(dy, x, dw_ohwi, slabs=True, f16x2=False, dy_amax=None, x_amax=
     if f16x2:
         dy_amax = amax(dy) if dy_amax is None else dy_amax
         x_amax = amax(x) if x_amax is None else x_amax
+    _seen("conv3:wgrad")
     check(lib.vbg_conv3x3_wgrad(P(dy), P(x), P(dw_ohwi), P(slab), B, H, W, Cs, Cout, int(bool(f16x2)), P(dy_amax), P(x_amax), _stream()),
           "vbg_conv3x3_wgrad")
     return dw_ohwi

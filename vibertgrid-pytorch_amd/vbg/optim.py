@@ -15,12 +15,14 @@ pipeline/train_val_utils.py:272-284, designed for MI355X instead of translated:
   stem / word embeddings last), so contiguous buckets complete roughly in the order autograd produces them; buckets are launched
   strictly in ONE sequence that is identical on every rank (the completion order rank 0 observed in its first step, broadcast
   once), so data-dependent graphs (classifier_mode full / crf: a per-class net may get no gradient on one rank) can never make two
-  ranks issue collectives in different orders.  SyncBatchNorm statistics travel on their OWN process group (own communicator and
-  stream), so a 4 KB statistics all-reduce on the critical path never queues behind a 32 MB bucket.  Parameters that never receive a gradient
+  ranks issue collectives in different orders.  SyncBatchNorm statistics share the reducer's communicator by default (one
+  communicator, one rank-invariant program order: the boring configuration for graphs that are the same on every rank); an own
+  communicator for them, concurrent with the buckets, is the opt-in (`sync_bn_group="new"`, FlatReducer.__init__).  Parameters that never receive a gradient
   (`bert_model.pooler.*`, `backbone.resnet.fc.*`) are kept out of the buffers, which is what
   `find_unused_parameters=True` + "skip params with grad None" amounts to in the reference.
 """
 import os
+import time
 from typing import Dict, List, Sequence, Tuple
 
 import torch
@@ -369,7 +371,8 @@ class FlatReducer:
     broadcast) -- from step 2 on the buckets fire during backward.  A rank whose graph skips a sub-module in some step simply
     issues the affected bucket (and everything behind it) from `finish()`; the sequence is unchanged."""
 
-    def __init__(self, optimizers, bucket_mb: float = 32.0, group=None, sync_bn_group="new", serialize_syncbn=None, dry_run=False):
+    def __init__(self, optimizers, bucket_mb: float = 32.0, group=None, sync_bn_group="auto", serialize_syncbn=None, overlap=None,
+                 dry_run=False):
         """dry_run (one process): same buckets, same hooks and the same launch sequence, but a bucket's "collective" is a timestamp on
         the stream it would be issued from -- `timeline()` then tells when, inside backward, every bucket could have left
         (tools/bucket_timeline.py)"""
@@ -379,7 +382,7 @@ class FlatReducer:
         self.optimizers = optimizers
         self.world = dist.get_world_size(group) if self.enabled else 1
         self.buckets = []          # [tensor view, member count, pending count]
-        self.handles = []
+        self.handles = []          # (bucket index, work) of the collectives in flight
         self.bucket_of = {}        # id(param) -> bucket index
         self._reported = set()     # sunk parameters already counted this step
         self.order = None          # the agreed launch sequence (bucket indices); None until the first finish()
@@ -389,37 +392,53 @@ class FlatReducer:
         self._stage = None         # stream the collectives are issued from
         self._streams = {}         # raw handle -> torch stream: compute streams gradients were reported from in this step
         self._events = []          # dry run: (bucket, event) in issue order
+        self.steps_done = 0
+        self.sync_bn_mode = "none"
+        self._phase = "idle"       # what the host is doing, for the watchdog's report
+        self._beat = time.monotonic()
+        self._watch = None
+        self.overlap = (os.environ.get("VBG_DDP_OVERLAP", "1") != "0") if overlap is None else bool(overlap)
         if self.dry:
             self.enabled = False
         elif not self.enabled:
             return
         # SyncBatchNorm statistics and gradient buckets.  The buckets follow ONE rank-agreed sequence, the SyncBatchNorm collectives
-        # the program order of forward / backward; how the two sequences INTERLEAVE is not rank-invariant once a rank's graph skips a
-        # sub-module (its bucket then fires from finish() instead of from a hook), so they cannot share a communicator in general:
-        #   sync_bn_group="new" (default, only with group=None -- dist.new_group is a collective over the DEFAULT group, every rank
-        #       must construct its reducer): an own communicator for the statistics.  torch documents concurrent collectives on two
-        #       NCCL communicators as unsafe when their kernels cannot co-reside; serialize_syncbn=True (VBG_SERIALIZE_SYNCBN=1) then
-        #       makes the compute stream wait for the buckets in flight before every SyncBatchNorm collective -- one communicator in
-        #       flight at any time, at the price of the overlap at those points;
-        #   sync_bn_group="default" (VBG_SYNCBN_GROUP=default): the statistics on the reducer's own group -- valid when every rank
-        #       runs the same graph every step (classifier_mode simp), nothing concurrent;
-        #   sync_bn_group=<ProcessGroup>: the caller's communicator (required with a sub-group).
+        # the program order of forward / backward.  Where the bucket launches fall BETWEEN the SyncBatchNorm collectives is rank-invariant
+        # exactly when every rank runs the same autograd graph (classifier_mode simp / crf, every sub-module used every step):
+        #   sync_bn_group="default" ("auto" without VBG_SYNCBN_GROUP: THE DEFAULT): statistics and buckets share the reducer's
+        #       communicator -- one communicator, one rank-invariant program order of collectives, nothing concurrent.  A statistics
+        #       all-reduce queues behind the buckets in flight (a 32 MB bucket: a fraction of a millisecond over xGMI); the encoder's
+        #       backward, where most of the gradient bytes leave, contains no BatchNorm.  overlap=False (VBG_DDP_OVERLAP=0) launches every
+        #       bucket from finish() instead of from inside backward: the order is then rank-invariant for ANY graph, at the price of
+        #       the overlap -- the setting for data-dependent graphs (classifier_mode full) on one communicator;
+        #   sync_bn_group="new" (VBG_SYNCBN_GROUP=new; only with group=None -- dist.new_group is a collective over the DEFAULT group,
+        #       every rank must construct its reducer): an own communicator for the statistics, collectives of the two communicators
+        #       concurrently in flight.  Tolerates rank-varying graphs WITH overlap, but torch documents concurrent collectives on two
+        #       NCCL communicators as unsafe when their kernels cannot co-reside: the opt-in A/B, not the default.
+        #       serialize_syncbn=True (VBG_SERIALIZE_SYNCBN=1) makes the compute stream wait for the buckets in flight (work.wait() of
+        #       every outstanding handle: the collectives run on the backend's own stream) before each statistics collective --
+        #       meaningful only with rank-invariant graphs, where the one-communicator default does the same thing for free;
+        #   sync_bn_group=<ProcessGroup>: the caller's communicator (required with a sub-group for "new"-style separation).
         if self.dry:
             sync_bn_group = None
-        if sync_bn_group == "new":
-            sync_bn_group = os.environ.get("VBG_SYNCBN_GROUP", "new")
+        if sync_bn_group == "auto":
+            sync_bn_group = os.environ.get("VBG_SYNCBN_GROUP", "default")
         if sync_bn_group == "new":
             if group is not None:
                 raise ValueError("FlatReducer(group=<sub-group>): pass sync_bn_group=<ProcessGroup> or 'default' -- dist.new_group is a "
                                  "collective over the default group and would hang when only the sub-group's ranks call it")
             Fn.SyncCtx.group = dist.new_group(ranks=list(range(dist.get_world_size())))
+            self.sync_bn_mode = "own communicator"
         elif sync_bn_group == "default":
             Fn.SyncCtx.group = group
+            self.sync_bn_mode = "shared communicator"
         elif sync_bn_group is not None:
             Fn.SyncCtx.group = sync_bn_group
+            self.sync_bn_mode = "caller's communicator"
         if serialize_syncbn is None:
             serialize_syncbn = os.environ.get("VBG_SERIALIZE_SYNCBN", "0") != "0"
         Fn.SyncCtx.before = self._wait_for_buckets if (serialize_syncbn and not self.dry) else None
+        Fn.SyncCtx.seq = 0
         Fn.GRAD_READY[0] = self._param_ready      # sunk gradients (written by the wgrad kernels) report here
         cap = int(bucket_mb * (1 << 20) / 4)
         for o in optimizers:
@@ -475,7 +494,7 @@ class FlatReducer:
             self._events.append((idx, ev))
             return
         if not buf.is_cuda:
-            self.handles.append(dist.all_reduce(buf, group=self.pg, async_op=True))
+            self.handles.append((idx, dist.all_reduce(buf, group=self.pg, async_op=True)))
             return
         # gradients are written on more than one compute stream (the encoder's backward runs on vbg.ops.side_stream): the
         # collective is issued from a staging stream that waits for every stream a gradient was reported from and for the side
@@ -487,7 +506,7 @@ class FlatReducer:
         for s in list(self._streams.values()) + [t for t in ops.side_streams() if t.device == dev]:
             self._stage.wait_stream(s)
         with torch.cuda.stream(self._stage):
-            self.handles.append(dist.all_reduce(buf, group=self.pg, async_op=True))
+            self.handles.append((idx, dist.all_reduce(buf, group=self.pg, async_op=True)))
 
     def timeline(self, start_event):
         """dry run: [(bucket, MB, ms since start_event)] of the last step, in issue order; clears the record (call after a sync)"""
@@ -496,9 +515,13 @@ class FlatReducer:
         return out
 
     def _wait_for_buckets(self):
-        """compute stream waits for the bucket collectives issued so far (serialize_syncbn)"""
-        if self._stage is not None:
-            torch.cuda.current_stream(self._stage.device).wait_stream(self._stage)
+        """compute stream waits for the bucket collectives issued so far (serialize_syncbn).  The collectives were issued with
+        async_op=True: they run on the BACKEND's stream (ProcessGroupNCCL's own), which the staging stream only joins at work.wait() --
+        so the current stream has to wait for the works themselves (waiting for the staging stream alone left the buckets
+        free to overlap the statistics collective).  work.wait() on NCCL blocks the current STREAM, not the host; on gloo the host.
+        The handles stay listed for finish()."""
+        for _, h in self.handles:
+            h.wait()
 
     def _ready(self, idx):
         b = self.buckets[idx]
@@ -510,7 +533,7 @@ class FlatReducer:
             return
         self._observed.append(idx)
         self._complete.add(idx)
-        if self.order is None:
+        if self.order is None or not self.overlap:
             return
         while self._next < len(self.order) and self.order[self._next] in self._complete:
             self._issue(self.order[self._next])
@@ -533,6 +556,7 @@ class FlatReducer:
             return
         if not self.enabled:
             return
+        self._phase, self._beat = "finish", time.monotonic()
         if self.order is None:
             seen = self._observed + [i for i in range(len(self.buckets)) if i not in self._complete]
             t = torch.tensor(seen, dtype=torch.int64, device=self.buckets[0][0].device)
@@ -542,7 +566,7 @@ class FlatReducer:
         while self._next < len(self.order):        # a parameter got no gradient this step (zero rows): reduce what is there
             self._issue(self.order[self._next])
             self._next += 1
-        for h in self.handles:
+        for _, h in self.handles:
             h.wait()
         self.handles = []
         for b in self.buckets:
@@ -550,3 +574,43 @@ class FlatReducer:
         self._reported.clear()
         self._streams.clear()
         self._observed, self._complete, self._next = [], set(), 0
+        self.steps_done += 1
+        self._phase, self._beat = "between steps", time.monotonic()
+
+    # ------------------------------------------------------------------------------------------------------------------------
+    def describe_pending(self) -> str:
+        """one line for a hang report: which bucket / which SyncBatchNorm collective this rank is at"""
+        rank = dist.get_rank() if dist.is_initialized() else 0
+        pend = []
+        for idx, h in self.handles:
+            try:
+                done = h.is_completed()
+            except Exception:
+                done = None
+            if not done:
+                pend.append(idx)
+        nxt = self.order[self._next] if (self.order is not None and self._next < len(self.order)) else None
+        waiting = [i for i in range(len(self.buckets)) if self.buckets[i][2] > 0]
+        return (f"[vbg reducer] rank {rank}: step {self.steps_done} ({self._phase}), {self.sync_bn_mode if self.enabled else 'disabled'}, "
+                f"overlap {'on' if self.overlap else 'off'}; buckets issued {self._next}/{len(self.buckets)}, in flight {pend}, next in sequence {nxt}, "
+                f"still collecting gradients {waiting[:8]}{'...' if len(waiting) > 8 else ''}; SyncBatchNorm collectives issued so far "
+                f"{getattr(Fn.SyncCtx, 'seq', 0)} (last: {getattr(Fn.SyncCtx, 'last', None)})")
+
+    def start_watchdog(self, seconds: float, exit_code=None):
+        """daemon thread: when no step completes for `seconds`, print `describe_pending()` to stderr (once per stall) so that a hung
+        collective leaves a diagnostic instead of an empty record; exit_code != None then ends the process"""
+        import sys
+        import threading
+
+        def run():
+            reported = -1
+            while True:
+                time.sleep(min(5.0, seconds / 4))
+                if time.monotonic() - self._beat > seconds and reported != self.steps_done:
+                    reported = self.steps_done
+                    print(self.describe_pending() + f" -- no progress for {seconds:.0f} s", file=sys.stderr, flush=True)
+                    if exit_code is not None:
+                        os._exit(exit_code)
+
+        self._watch = threading.Thread(target=run, daemon=True, name="vbg-reducer-watchdog")
+        self._watch.start()
