@@ -259,6 +259,26 @@ int vbg_amax(const float* x, long long n, unsigned* amax, void* stream);
  * same convolution of dy */
 int vbg_conv3x3_wflip(const float* w, int Cout, int Cin, float* out, void* stream);
 
+/* The same convolution in form 1 with the FILTER PRE-SPLIT (round 4): `w_planes` = the fp16-pair image of the filter that
+ * vbg_conv3x3_wprep wrote (flip = 0: the forward of torch.nn.Conv2d(k=3, s=1, p=1); flip = 1: the filter of the input gradient, i.e.
+ * vbg_conv3x3_wflip + split in one pass).  The kernel streams the filter through LDS-DMA in 128-byte lines and spends no VALU on it;
+ * results equal vbg_conv3x3(form 1) bit for bit (same pieces, same products, same order).  Needs 128-pixel tiles (the shapes for which
+ * vbg_conv3x3 picks them, incl. every nsplit > 1 and the 7x7 region maps); other shapes are argument errors.
+ * vbg_conv3x3_wprep: ONE launch for a table of filters (the caller keeps the table in device AND host memory; entries must stay valid
+ * until the launch has run): entry = {w [Cout,3,3,Cin] fp32, out, Cout, Cin, flip, bn}; `out` receives vbg_conv3x3_wprep_bytes(Cout,
+ * Cin, flip) bytes; bn = rows per filter tile = 64 when the image's row count (flip ? Cin : Cout) is an odd multiple of 64, else 128.
+ * The reduction width (flip ? Cout : Cin) must be a multiple of 16. */
+typedef struct vbg_conv3_wprep_entry {
+    const float* w;
+    void* out;
+    int Cout, Cin, flip, bn;
+} vbg_conv3_wprep_entry;
+long long vbg_conv3x3_wprep_bytes(int Cout, int Cin, int flip);
+int vbg_conv3x3_wprep(const vbg_conv3_wprep_entry* table_dev, const vbg_conv3_wprep_entry* table_host, int n, void* stream);
+int vbg_conv3x3_pw(const float* x, const void* w_planes, const float* bias, float* y, double* stats, int stats_slots, int B, int H, int W,
+                   int Cs, int N, int accumulate, const unsigned* x_amax, float* split_slab, unsigned* split_tickets, int nsplit,
+                   void* stream);
+
 /* weight gradient of that convolution: dw[Cout,3,3,Cs] += sum over pixels dy[B,H,W,Cout]^T * shifted x[B,H,W,Cs] (csrc/conv3.hip:
  * operands stay [pixel][channel] in LDS, fragments through transposing LDS reads, one load + split of x serves all nine taps).
  * The pixel range is cut into vbg_conv3x3_wgrad_strips(...) strips; slab = [strips][Cout,3,3,Cs] scratch -> each strip stores its

@@ -53,6 +53,13 @@ def test_conv3_host_logic_without_a_gpu():
     assert strips(1, 4, 16, 32, 128) == 1                                                    # 4 chunks: one strip
     assert L.lib.vbg_conv3x3_wgrad(None, None, None, None, 1, 16, 16, 32, 128, 0, None, None, None) == -1
     assert L.lib.vbg_conv3x3_wflip(None, 1, 1, None, None) == -1
+    # pre-split filter images (round 4): byte counts of the k-tile-ordered plane image, argument errors without a launch
+    nb = L.lib.vbg_conv3x3_wprep_bytes
+    assert nb(256, 256, 0) == 256 * 256 * 9 * 4 and nb(64, 64, 1) == 64 * 64 * 9 * 4          # 4 bytes per element, like the fp32 filter
+    assert nb(132, 16, 0) == 2 * 9 * 1 * 64 * 128                                             # rows padded to whole filter tiles
+    assert nb(128, 24, 0) == 0 and nb(24, 128, 1) == 0                                         # reduction width must be a multiple of 16
+    assert L.lib.vbg_conv3x3_wprep(None, None, 1, None) == -1 and L.lib.vbg_conv3x3_wprep(None, None, 0, None) == 0
+    assert L.lib.vbg_conv3x3_pw(None, None, None, None, None, 0, 1, 16, 128, 16, 128, 0, None, None, None, 1, None) == -1
 
 
 def test_gemm_desc_layout_matches_header():
@@ -68,13 +75,13 @@ def test_gemm_desc_offsets_against_the_c_compiler(tmp_path):
     import ctypes as C
     import shutil
     import subprocess
-    from vbg.lib import AttnDesc, GemmDesc, ConvGeo, PlaneGemmDesc, PlaneGroup
+    from vbg.lib import AttnDesc, Conv3WprepEntry, GemmDesc, ConvGeo, PlaneGemmDesc, PlaneGroup
     if shutil.which("gcc") is None:
         pytest.skip("no C compiler")
     root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
     src = ['#include <stdio.h>', '#include <stddef.h>', '#include "vbg.h"', 'int main(void) {']
     for st, cls in (("vbg_gemm_desc", GemmDesc), ("vbg_conv_geo", ConvGeo), ("vbg_plane_gemm_desc", PlaneGemmDesc), ("vbg_plane_group", PlaneGroup),
-                    ("vbg_attn_desc", AttnDesc)):
+                    ("vbg_attn_desc", AttnDesc), ("vbg_conv3_wprep_entry", Conv3WprepEntry)):
         src.append(f'printf("{st} sizeof %zu\\n", sizeof({st}));')
         for name, _ in cls._fields_:
             src.append(f'printf("{st} {name} %zu\\n", offsetof({st}, {name}));')
@@ -86,7 +93,7 @@ def test_gemm_desc_offsets_against_the_c_compiler(tmp_path):
     out = subprocess.run([exe], check=True, capture_output=True, text=True).stdout.split("\n")
     got = {(a, b): int(c) for a, b, c in (ln.split() for ln in out if ln)}
     for st, cls in (("vbg_gemm_desc", GemmDesc), ("vbg_conv_geo", ConvGeo), ("vbg_plane_gemm_desc", PlaneGemmDesc), ("vbg_plane_group", PlaneGroup),
-                    ("vbg_attn_desc", AttnDesc)):
+                    ("vbg_attn_desc", AttnDesc), ("vbg_conv3_wprep_entry", Conv3WprepEntry)):
         assert got[(st, "sizeof")] == C.sizeof(cls)
         for name, _ in cls._fields_:
             assert got[(st, name)] == getattr(cls, name).offset, (st, name)

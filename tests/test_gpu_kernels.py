@@ -294,6 +294,72 @@ def test_conv3x3_split(ops, B, H, W, Cs, N, nz):
     assert ops.conv3_ok(8, 32, 32, 256, 256, 3, 3, 1, 1) and ops.conv3_ok(8, 16, 16, 512, 512, 3, 3, 1, 1)
 
 
+@pytest.mark.parametrize("B,H,W,Cs,N,nz", [(2, 8, 128, 32, 128, 1), (1, 128, 128, 64, 64, 1), (2, 5, 256, 32, 128, 1), (1, 3, 512, 16, 132, 1),
+                                           (2, 4, 128, 16, 192, 1), (8, 64, 64, 32, 128, 1),
+                                           (5, 7, 7, 32, 128, 1), (8, 7, 7, 64, 256, 1), (1, 7, 7, 16, 64, 1),
+                                           (8, 32, 32, 64, 256, 3), (2, 16, 16, 96, 128, 6), (4, 16, 16, 192, 384, 12), (8, 16, 16, 64, 128, 4)])
+def test_conv3x3_presplit_filter(ops, B, H, W, Cs, N, nz):
+    """PW form of csrc/conv3.hip (round 4): the filter arrives as the fp16-pair plane image conv3_wprep_kernel wrote (k-tile order,
+    LDS-DMA) instead of being split by every workgroup.  Same pieces, same products, same order: BIT-IDENTICAL to the in-kernel form, for
+    the forward (bias, statistics, accumulate), the input gradient (turned filter written as planes only, scaled dy), whole rows /
+    wide rows / 64-filter tiles / region maps / split reductions; and the images follow the weights (in-place update seen by torch's
+    version counter, library kernels seen through the weight epoch)."""
+    x = rnd(B, Cs, H, W, seed=260)
+    w = rnd(N, Cs, 3, 3, seed=261) / math.sqrt(Cs * 9)
+    b = rnd(N, seed=262)
+    xh = x.permute(0, 2, 3, 1).contiguous().to(dev())
+    wd = w.to(dev()).contiguous(memory_format=torch.channels_last)          # the parameter as the model holds it (OIHW, channels_last)
+    w4 = wd.permute(0, 2, 3, 1)
+    assert w4.is_contiguous() and w4.data_ptr() == wd.data_ptr()
+    bh = b.to(dev())
+    wp = ops.conv3_planes(wd, w4, False)
+    bn = 64 if (N % 128 != 0 and N % 64 == 0) else 128                     # rows per filter tile of the image
+    assert wp is not None and wp.numel() == ((N + bn - 1) // bn) * 9 * (Cs // 16) * 64 * bn
+    assert nz > 1 or ops.conv3_pw_ok(B, H, W, Cs, N)
+    s0 = torch.zeros(ops.bn_slots() * 2 * N, device=dev(), dtype=torch.float64)
+    s1 = torch.zeros_like(s0)
+    y0 = ops.conv3x3(xh, w4, bh, stats=s0, f16x2=True, nsplit=nz)
+    y1 = ops.conv3x3(xh, w4, bh, stats=s1, f16x2=True, nsplit=nz, w_planes=wp)
+    assert torch.equal(y0, y1)
+    assert torch.allclose(s0.view(-1, 2, N).sum(0), s1.view(-1, 2, N).sum(0), rtol=1e-12, atol=1e-9)
+    ref = F.conv2d(x.double(), w.double(), b.double(), 1, 1).float().permute(0, 2, 3, 1)
+    assert close(y1, ref, 2e-5, 3e-6 * float(ref.abs().max()))
+    acc0, acc1 = y0.clone(), y0.clone()
+    ops.conv3x3(xh, w4, None, out=acc0, accumulate=True, f16x2=True, nsplit=nz)
+    ops.conv3x3(xh, w4, None, out=acc1, accumulate=True, f16x2=True, nsplit=nz, w_planes=wp)
+    assert torch.equal(acc0, acc1)
+    # input gradient: dy [B, H, W, N] with the turned filter; reduction over the N output channels
+    def split_ok(nz_, red, nout):
+        cs = nz_ // 3 if nz_ % 3 == 0 else nz_
+        return nz_ == 1 or (nout % 128 == 0 and (H * W) % 128 == 0 and H != 7 and red % cs == 0 and (red // cs) % 16 == 0)
+    if N % 16 == 0 and Cs % 8 == 0:
+        nzb = nz if split_ok(nz, N, Cs) else 1
+        if nzb > 1 or ops.conv3_pw_ok(B, H, W, N, Cs):
+            gy = rnd(B, N, H, W, seed=263).permute(0, 2, 3, 1).contiguous().to(dev()) * 2.0 ** -22
+            am = ops.amax(gy)
+            wpf = ops.conv3_planes(wd, w4, True)
+            assert wpf is not None
+            d0 = ops.conv3x3(gy, ops.conv3x3_wflip(w4), f16x2=True, x_amax=am, nsplit=nzb)
+            d1 = ops.conv3x3(gy, w4, f16x2=True, x_amax=am, nsplit=nzb, w_planes=wpf, n_out=Cs)
+            assert torch.equal(d0, d1)
+    # the images follow the weights: torch's version counter ...
+    with torch.no_grad():
+        wd.mul_(2.0)
+    wp2 = ops.conv3_planes(wd, w4, False)
+    assert wp2.data_ptr() == wp.data_ptr()                                   # same storage, rewritten
+    y2 = ops.conv3x3(xh, w4, None, f16x2=True, nsplit=nz, w_planes=wp2)
+    assert torch.equal(y2, ops.conv3x3(xh, w4, None, f16x2=True, nsplit=nz))
+    assert close(y2, 2 * (ref - b.view(1, 1, 1, N)), 2e-5, 6e-6 * float(ref.abs().max()))
+    # ... and the library's own writes (optimizer kernels) through the weight epoch
+    ops.scale_(wd.permute(0, 2, 3, 1).reshape(-1), 0.5)
+    stale = ops.conv3x3(xh, w4, None, f16x2=True, nsplit=nz, w_planes=wp2)
+    assert torch.equal(stale, y2)                                            # (nobody told the cache yet)
+    ops.bump_weight_epoch()
+    y3 = ops.conv3x3(xh, w4, None, f16x2=True, nsplit=nz, w_planes=ops.conv3_planes(wd, w4, False))
+    assert torch.equal(y3, ops.conv3x3(xh, w4, None, f16x2=True, nsplit=nz))
+    assert close(y3, ref - b.view(1, 1, 1, N), 2e-5, 3e-6 * float(ref.abs().max()))
+
+
 @pytest.mark.parametrize("B,H,W,Cs,Cout", [(2, 8, 32, 32, 128), (3, 4, 16, 64, 64), (1, 16, 64, 96, 256), (2, 5, 48, 64, 192),
                                            # image rows of 128 / 256 pixels (cfg2's 128 x 128 and cfg5's 256 x 256 maps): 8 / 16 k-tiles per row
                                            (2, 6, 128, 64, 128), (1, 5, 256, 32, 128), (2, 3, 256, 64, 256),

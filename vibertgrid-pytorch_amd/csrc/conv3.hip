@@ -28,6 +28,7 @@ constexpr unsigned C3_INVALID = 0x80000000u;       // outside every descriptor: 
 struct conv3_args {
     const float* X;        // [B, H, W, Cs]
     const float* Wt;       // [N, 3, 3, Cs]
+    const unsigned short* Wp; // PW kernels: the filter as fp16-pair planes in k-tile order (conv3_wprep_kernel below), Wt unused
     const float* bias;     // [N] or null
     float* Y;              // [B, H, W, N]
     double* stats;         // BatchNorm slot workspace [slots][2][N] or null
@@ -112,9 +113,22 @@ struct c3_pipe {
 // between image rows that the W >= 16 layout inserts explicitly, and slot row y = 7 the zero row under the image.  Slots map to the
 // compact rows (image * 49 + y * 7 + x) in the loader and in the epilogue (invalid slots are neither stored nor counted in the
 // statistics); 49 of 64 MFMA rows are useful, against which the generic kernel's nine-fold re-fetch and re-split costs more.
-template <int BM, int BN, bool F16>
+//
+// PW ("pre-split weights", F16 form, 128-pixel tiles): the filter operand does not pass through registers at all.  conv3_wprep_kernel
+// writes it ONCE per weight version as fp16-pair planes in the order this kernel walks it: one contiguous 64 * BN byte block per
+// (filter tile, tap, 16-channel chunk) = [plane][32-row block][8-channel half][row][8 x fp16] -- the image a lane-linear LDS-DMA
+// lands conflict free for the ds_read_b128 fragment pattern (a 16-lane group reads 16 different 16-byte bank quads).  The k-loop then
+// issues BN / 64 `buffer_load ... lds` per wave and k-tile into a ring of NSB stages (counted vmcnt, D = NSB - 1 tiles in flight) and
+// spends no VALU and no ds_write on the filter: 4 bytes per element from L2 as before (two fp16 pieces = one fp32), in full 128-byte
+// lines instead of 64-byte row pieces, and three quarters of the kernel's split work gone (the activation super-tile, loaded every
+// third k-tile, is the rest).
+template <int BM, int BN, bool F16, bool PW = false>
 __global__ __launch_bounds__(256, 2) void conv3x3_kernel(const conv3_args p) {
+    static_assert(!PW || (F16 && BM == 128), "pre-split weights: the fp16-pair form on 128-pixel tiles");
     constexpr int NT = 256, SKH = 24;
+    constexpr int NSB = 4, DPF = NSB - 1;                      // PW: stages of the filter ring / k-tiles in flight
+    constexpr int BTILE = 64 * BN;                             // PW: bytes of one k-tile of the filter (2 planes x BN rows x 32 B)
+    constexpr int NDB = BN / 64;                               // PW: 1 KiB DMA units per wave and k-tile
     constexpr int TNF = BN / 64;                               // 32-column fragments per wave
     constexpr int NBI = BN * 4 / NT;                           // filter float4s per thread and tile
     constexpr int NPL = F16 ? 2 : 3;                           // planes per operand tile
@@ -124,7 +138,8 @@ __global__ __launch_bounds__(256, 2) void conv3x3_kernel(const conv3_args p) {
     constexpr int PA = AROWS * SKH / 2, PB = BN * SKH / 2;     // one bf16 plane (dwords)
     constexpr int ASZ = NPL * PA, BSZ = NPL * PB;
     constexpr int CTS = BN + 4;
-    constexpr int SMEM = 2 * (ASZ + BSZ) > BM * CTS ? 2 * (ASZ + BSZ) : BM * CTS;      // 76 KB at BM = 128, three planes: two workgroups per CU
+    constexpr int LOOPSZ = PW ? 2 * ASZ + NSB * BTILE / 4 : 2 * (ASZ + BSZ);
+    constexpr int SMEM = LOOPSZ > BM * CTS ? LOOPSZ : BM * CTS;                        // 76 KB at BM = 128, three planes: two workgroups per CU
     __shared__ __attribute__((aligned(16))) unsigned smem[SMEM];
     unsigned* const As = smem;
     unsigned* const Bs = smem + 2 * ASZ;
@@ -173,6 +188,17 @@ __global__ __launch_bounds__(256, 2) void conv3x3_kernel(const conv3_args p) {
         const int r = (tid + i * NT) >> 2;
         bvo[i] = (n0 + r < N) ? (unsigned)((r * K + kc) * 4) : C3_INVALID;
     }
+    // PW: unit u = wave + 4 i of a k-tile's filter block (1 KiB: plane u / (BN / 32), row block u % (BN / 32)); lane l moves bytes
+    // [16 l, 16 l + 16) of the unit, source and LDS image alike
+    typedef __attribute__((address_space(3))) void* c3_lds_ptr;
+    unsigned char* const ring = reinterpret_cast<unsigned char*>(smem + 2 * ASZ);
+    unsigned dvo[NDB];
+    int dlds[NDB];
+#pragma unroll
+    for (int i = 0; i < NDB; ++i) {
+        dvo[i] = (unsigned)(((tid >> 6) + 4 * i) * 1024 + (tid & 63) * 16);
+        dlds[i] = __builtin_amdgcn_readfirstlane(((tid >> 6) + 4 * i) * 1024);
+    }
     // image rows wider than the tile (W = 256, 512, ...: the tile is a piece of ONE row): the pixels left and right of it are real
     // pixels, not padding -- eight lanes fetch them per super-tile into the two halo rows of the LDS image
     const bool wide = W > BM;
@@ -209,6 +235,24 @@ __global__ __launch_bounds__(256, 2) void conv3x3_kernel(const conv3_args p) {
         const __amdgpu_buffer_rsrc_t r = c3_rsrc(wbase + (b_kh * 3 + b_kw) * Cs + b_c0);
 #pragma unroll
         for (int i = 0; i < NBI; ++i) rb[i] = c3_load(r, bvo[i]);
+        if (++b_kw == 3) {
+            b_kw = 0; b_c0 += 16;
+            if (b_c0 >= cend) { b_c0 = cbeg; ++b_kh; }
+        }
+    };
+    // PW: the DMA of the next filter k-tile in walking order (kh, chunk, kw) into ring stage `d_stage`; past the block's last k-tile
+    // every lane carries the invalid offset (zeros into a stage nobody reads, no memory traffic): the vmcnt arithmetic stays uniform
+    const int nchk = Cs >> 4;
+    int d_left = 0, d_stage = 0;               // k-tiles still to issue / the stage the next one goes to
+    auto issue_b = [&]() {
+        const unsigned inv = d_left > 0 ? 0u : C3_INVALID;
+        const unsigned short* src = p.Wp + (size_t)(((int)tile_n * 9 + b_kh * 3 + b_kw) * nchk + (b_c0 >> 4)) * (BTILE / 2);
+        const __amdgpu_buffer_rsrc_t r = c3_rsrc(reinterpret_cast<const float*>(src));
+#pragma unroll
+        for (int i = 0; i < NDB; ++i)
+            __builtin_amdgcn_raw_ptr_buffer_load_lds(r, (c3_lds_ptr)(ring + d_stage * BTILE + dlds[i]), 16, (int)(dvo[i] | inv), 0, 0, 0);
+        --d_left;
+        d_stage = d_stage + 1 == NSB ? 0 : d_stage + 1;
         if (++b_kw == 3) {
             b_kw = 0; b_c0 += 16;
             if (b_c0 >= cend) { b_c0 = cbeg; ++b_kh; }
@@ -278,11 +322,19 @@ __global__ __launch_bounds__(256, 2) void conv3x3_kernel(const conv3_args p) {
 #pragma unroll
             for (int i = 0; i < TM; ++i) fa[q][i] = as[q * (PA / 4) + (arow[i] + kw) * (SKH / 8) + lk];
 #pragma unroll
-            for (int j = 0; j < TNF; ++j) fb[q][j] = bs[q * (PB / 4) + (brow + j * 32) * (SKH / 8) + lk];
+            for (int j = 0; j < TNF; ++j) {
+                if constexpr (PW) fb[q][j] = *reinterpret_cast<const c3_u32x4*>(ring + bbuf * BTILE + q * (BTILE / 2) + (wn * TNF + j) * 1024 + lk * 512 + lr * 16);
+                else fb[q][j] = bs[q * (PB / 4) + (brow + j * 32) * (SKH / 8) + lk];
+            }
         }
         __builtin_amdgcn_sched_barrier(0);
-        if constexpr (MORE) load_b();
-        if constexpr (LOADA) load_a();
+        if constexpr (PW) {
+            if constexpr (LOADA) load_a();     // (in front of the DMA: waiting for these registers must not wait for the DMA behind them)
+            issue_b();
+        } else {
+            if constexpr (MORE) load_b();
+            if constexpr (LOADA) load_a();
+        }
         __builtin_amdgcn_sched_barrier(0);
         // piece products, smallest first: (lo,hi) (hi,lo) (mid,mid) (mid,hi) (hi,mid) (hi,hi); F16: (lo,hi) (hi,lo) -> cross sums, (hi,hi)
         constexpr int qa[6] = {F16 ? 1 : 2, 0, 1, 1, 0, 0}, qb[6] = {0, F16 ? 1 : 2, F16 ? 0 : 1, 0, 1, 0};
@@ -306,7 +358,19 @@ __global__ __launch_bounds__(256, 2) void conv3x3_kernel(const conv3_args p) {
         using i0 = std::integral_constant<int, 0>;
         using ih = std::integral_constant<int, F16 ? 1 : 2>;
         using i1 = std::integral_constant<int, F16 ? 3 : 6>;
-        if constexpr (MORE) {
+        if constexpr (MORE && PW) {
+            mma_range(i0{}, ih{});
+            __builtin_amdgcn_sched_barrier(0);
+            mma_range(ih{}, i1{});
+            if constexpr (LOADA) {
+                store_a(abuf ^ 1);
+                c3_pipe<0, 2 * TNF * TM, NAI * 10, NAI * 2>::run();
+            }
+            __builtin_amdgcn_sched_barrier(0);
+            // this wave's share of the NEXT k-tile has landed (the DPF - 1 tiles behind it stay in flight), then everybody's
+            asm volatile("s_waitcnt vmcnt(%0)" ::"n"((DPF - 1) * NDB) : "memory");
+            __syncthreads();
+        } else if constexpr (MORE) {
             mma_range(i0{}, ih{});
             __builtin_amdgcn_sched_barrier(0);
             mma_range(ih{}, i1{});
@@ -326,13 +390,37 @@ __global__ __launch_bounds__(256, 2) void conv3x3_kernel(const conv3_args p) {
     // the zero pixels beside the image rows are written once; the loop only ever stores the pixel rows
     for (int e = tid; e < 2 * ASZ / 4; e += NT) reinterpret_cast<uint4*>(As)[e] = make_uint4(0u, 0u, 0u, 0u);
     set_a(kh0);
+    const int nsup = (p.ksplit == 3 ? 1 : 3) * cw / 16;
+    if constexpr (PW) {
+        d_left = 3 * nsup;
+        load_a();
+        __syncthreads();                       // (the zero fill above)
+#pragma unroll
+        for (int d = 0; d < DPF; ++d) issue_b();
+        store_a(0);
+        asm volatile("s_waitcnt vmcnt(%0)" ::"n"((DPF - 1) * NDB) : "memory");       // k-tile 0 has landed
+        __syncthreads();
+        int bst = 0;
+        auto nx = [&]() { const int c = bst; bst = bst + 1 == NSB ? 0 : bst + 1; return c; };
+        for (int s = 0; s + 1 < nsup; ++s) {
+            k_tile(no_t{}, yes_t{}, s & 1, nx(), 0);
+            k_tile(no_t{}, yes_t{}, s & 1, nx(), 1);
+            k_tile(yes_t{}, yes_t{}, s & 1, nx(), 2);
+        }
+        {
+            const int s = nsup - 1;
+            k_tile(no_t{}, yes_t{}, s & 1, nx(), 0);
+            k_tile(no_t{}, yes_t{}, s & 1, nx(), 1);
+            k_tile(no_t{}, no_t{}, s & 1, nx(), 2);
+        }
+        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");       // the zero-writing DMAs past the end must not land in the staged tile
+    } else {
     load_a();
     load_b();
     __syncthreads();
     store_a(0);
     store_b(0);
     __syncthreads();
-    const int nsup = (p.ksplit == 3 ? 1 : 3) * cw / 16;
     int t = 0;
     for (int s = 0; s + 1 < nsup; ++s) {
         k_tile(no_t{}, yes_t{}, s & 1, t & 1, 0); ++t;
@@ -344,6 +432,7 @@ __global__ __launch_bounds__(256, 2) void conv3x3_kernel(const conv3_args p) {
         k_tile(no_t{}, yes_t{}, s & 1, t & 1, 0); ++t;
         k_tile(no_t{}, yes_t{}, s & 1, t & 1, 1); ++t;
         k_tile(no_t{}, no_t{}, s & 1, t & 1, 2);
+    }
     }
 
     // ---------------- epilogue: staged through LDS, float4 row pieces, optional bias / accumulate / BatchNorm statistics ---------
@@ -460,6 +549,50 @@ __global__ void conv3_wflip_kernel(const float* __restrict__ w, int Cout, int Ci
     }
 }
 
+// Filter planes of the PW kernels, for every 3x3 filter of a model in ONE launch (blockIdx.y = table entry).  Entry e describes one
+// image: the filter itself (flip = 0: rows = output channels, reduction = input channels) or the filter of the input gradient
+// (flip = 1: turned by 180 degrees, channel roles swapped -- rows = input channels, reduction = output channels; what conv3_wflip_kernel
+// writes as fp32).  Image layout (BN = bn rows per filter tile): block ((tile * 9 + tap) * (K / 16) + chunk) of 64 * bn bytes =
+// [plane: hi, lo][row block of 32][8-channel half][row][8 x fp16]; rows past `rows` are zeros.  One thread = one (row, half) group of 8
+// elements: hi = fp16(w), lo = fp16((w - hi) * 2^11), both rounded to nearest (c3_split2).
+__global__ __launch_bounds__(256) void conv3_wprep_kernel(const vbg_conv3_wprep_entry* __restrict__ tab) {
+    const vbg_conv3_wprep_entry e = tab[blockIdx.y];
+    const int bn = e.bn, rows = e.flip ? e.Cin : e.Cout, K = e.flip ? e.Cout : e.Cin;
+    const int gpb = bn * 2;                                    // groups per filter block
+    const long long g = (long long)blockIdx.x * 256 + threadIdx.x;
+    const long long nblocks = (long long)((rows + bn - 1) / bn) * 9 * (K / 16);
+    if (g >= nblocks * gpb) return;
+    const long long blk = g / gpb;
+    const int in = (int)(g - blk * gpb);                       // = (rb * 2 + half) * 32 + row
+    const int row32 = in & 31, half = (in >> 5) & 1, rb = in >> 6;
+    const int chunk = (int)(blk % (K / 16));
+    const int tap = (int)((blk / (K / 16)) % 9);
+    const int tile = (int)(blk / ((long long)(K / 16) * 9));
+    const int r = tile * bn + rb * 32 + row32;
+    const int k0 = chunk * 16 + half * 8;
+    float v[8];
+    if (r < rows) {
+        if (!e.flip) {
+            const float4* src = reinterpret_cast<const float4*>(e.w + ((long long)r * 9 + tap) * e.Cin + k0);
+            const float4 a = src[0], b = src[1];
+            v[0] = a.x; v[1] = a.y; v[2] = a.z; v[3] = a.w; v[4] = b.x; v[5] = b.y; v[6] = b.z; v[7] = b.w;
+        } else {
+#pragma unroll
+            for (int j = 0; j < 8; ++j) v[j] = e.w[((long long)(k0 + j) * 9 + (8 - tap)) * e.Cin + r];
+        }
+    } else {
+#pragma unroll
+        for (int j = 0; j < 8; ++j) v[j] = 0.f;
+    }
+    uint4 h, l;
+    c3_split2(v[0], v[1], h.x, l.x);
+    c3_split2(v[2], v[3], h.y, l.y);
+    c3_split2(v[4], v[5], h.z, l.z);
+    c3_split2(v[6], v[7], h.w, l.w);
+    unsigned char* dst = reinterpret_cast<unsigned char*>(e.out) + blk * (64ll * bn) + (long long)rb * 1024 + half * 512 + row32 * 16;
+    *reinterpret_cast<uint4*>(dst) = h;
+    *reinterpret_cast<uint4*>(dst + 32 * bn) = l;
+}
 
 // ------------------------------------------------------------------------------------------------------------------------------
 // Weight gradient of the same convolution: dW[co][kh][kw][ci] += sum_p dY[p][co] * X[p + (kh-1) W + (kw-1)][ci].
@@ -784,12 +917,58 @@ extern "C" int vbg_conv3x3_split(int B, int H, int W, int Cs, int N) {
     return nz;
 }
 
+// rows per filter tile of the plane image of a filter with `rows` output rows (vbg_conv3x3_wprep / vbg_conv3x3_pw agree on it)
+static int conv3_pw_bn(int rows) { return (rows % 128 != 0 && rows % 64 == 0) ? 64 : 128; }
+
+extern "C" long long vbg_conv3x3_wprep_bytes(int Cout, int Cin, int flip) {
+    const int rows = flip ? Cin : Cout, K = flip ? Cout : Cin;
+    if (rows <= 0 || K <= 0 || K % 16 != 0) return 0;
+    const int bn = conv3_pw_bn(rows);
+    return (long long)((rows + bn - 1) / bn) * 9 * (K / 16) * 64 * bn;
+}
+
+extern "C" int vbg_conv3x3_wprep(const vbg_conv3_wprep_entry* table_dev, const vbg_conv3_wprep_entry* table_host, int n, void* stream) {
+    VBG_CHECK_ARG(n >= 0 && (n == 0 || (table_dev && table_host)));
+    if (n == 0) return VBG_OK;
+    long long most = 0;
+    for (int i = 0; i < n; ++i) {
+        const vbg_conv3_wprep_entry& e = table_host[i];
+        const int rows = e.flip ? e.Cin : e.Cout, K = e.flip ? e.Cout : e.Cin;
+        VBG_CHECK_ARG(e.w && e.out && rows > 0 && K > 0 && K % 16 == 0 && e.Cin % 8 == 0 && e.bn == conv3_pw_bn(rows));
+        VBG_CHECK_ARG((((uintptr_t)e.w) & 15) == 0 && (((uintptr_t)e.out) & 15) == 0);
+        const long long groups = (long long)((rows + e.bn - 1) / e.bn) * 9 * (K / 16) * e.bn * 2;
+        most = groups > most ? groups : most;
+    }
+    VBG_CHECK_ARG((most + 255) / 256 < (1ll << 31));
+    VBG_LAUNCH(vbg::conv3_wprep_kernel, dim3((unsigned)((most + 255) / 256), (unsigned)n), dim3(256), 0, (hipStream_t)stream, table_dev);
+    VBG_LAUNCH_RET();
+}
+
+static int conv3x3_impl(const float* x, const float* w, const unsigned short* wp, const float* bias, float* y, double* stats, int stats_slots,
+                        int B, int H, int W, int Cs, int N, int accumulate, int form, const unsigned* x_amax, float* split_slab,
+                        unsigned* split_tickets, int nsplit, void* stream);
+
 extern "C" int vbg_conv3x3(const float* x, const float* w, const float* bias, float* y, double* stats, int stats_slots, int B, int H,
                            int W, int Cs, int N, int accumulate, int form, const unsigned* x_amax, float* split_slab,
                            unsigned* split_tickets, int nsplit, void* stream) {
+    VBG_CHECK_ARG(w);
+    return conv3x3_impl(x, w, nullptr, bias, y, stats, stats_slots, B, H, W, Cs, N, accumulate, form, x_amax, split_slab, split_tickets, nsplit, stream);
+}
+
+extern "C" int vbg_conv3x3_pw(const float* x, const void* w_planes, const float* bias, float* y, double* stats, int stats_slots, int B, int H,
+                              int W, int Cs, int N, int accumulate, const unsigned* x_amax, float* split_slab, unsigned* split_tickets,
+                              int nsplit, void* stream) {
+    VBG_CHECK_ARG(w_planes && (((uintptr_t)w_planes) & 15) == 0);
+    return conv3x3_impl(x, nullptr, (const unsigned short*)w_planes, bias, y, stats, stats_slots, B, H, W, Cs, N, accumulate, 1, x_amax, split_slab,
+                        split_tickets, nsplit, stream);
+}
+
+static int conv3x3_impl(const float* x, const float* w, const unsigned short* wp, const float* bias, float* y, double* stats, int stats_slots,
+                        int B, int H, int W, int Cs, int N, int accumulate, int form, const unsigned* x_amax, float* split_slab,
+                        unsigned* split_tickets, int nsplit, void* stream) {
     VBG_CHECK_ARG(form == 0 || form == 1);
     VBG_CHECK_ARG(!x_amax || form == 1);
-    VBG_CHECK_ARG(x && w && y && B > 0 && H > 0);
+    VBG_CHECK_ARG(x && (w || wp) && y && B > 0 && H > 0);
     const bool roi = H == 7 && W == 7;                          // [B, 7, 7, C] region maps: two images per 128-slot tile
     VBG_CHECK_ARG(roi || (W >= 16 && W <= 4096 && (W & (W - 1)) == 0));
     VBG_CHECK_ARG(roi || ((long long)H * W) % 64 == 0);
@@ -798,7 +977,7 @@ extern "C" int vbg_conv3x3(const float* x, const float* w, const float* bias, fl
     VBG_CHECK_ARG((((uintptr_t)x) & 15) == 0 && (((uintptr_t)w) & 15) == 0 && (((uintptr_t)y) & 15) == 0);
     VBG_CHECK_ARG(!stats || (stats_slots >= 1 && !accumulate));
     vbg::conv3_args a;
-    a.X = x; a.Wt = w; a.bias = bias; a.Y = y; a.stats = stats; a.stats_slots = stats_slots;
+    a.X = x; a.Wt = w; a.Wp = wp; a.bias = bias; a.Y = y; a.stats = stats; a.stats_slots = stats_slots;
     a.H = H; a.W = W; a.wsh = roi ? 3 : 31 - __builtin_clz((unsigned)W); a.Cs = Cs; a.N = N;
     const long long M = (long long)B * H * W;
     VBG_CHECK_ARG(M < (1ll << 31));
@@ -817,6 +996,13 @@ extern "C" int vbg_conv3x3(const float* x, const float* w, const float* bias, fl
     const int bn = n64 ? 64 : 128;
     const bool big = split || is_big(bn);
     const dim3 g(roi ? (unsigned)((B + 1) / 2) : (unsigned)(M / (big ? 128 : 64)), (unsigned)vbg::cdiv(N, bn), (unsigned)nsplit);
+    if (wp) {
+        // the plane image was written for conv3_pw_bn(N) rows per filter tile: the launch must walk it with the same tile
+        VBG_CHECK_ARG(big && bn == conv3_pw_bn(N));
+        if (n64) { VBG_LAUNCH((vbg::conv3x3_kernel<128, 64, true, true>), g, dim3(256), 0, (hipStream_t)stream, a); }
+        else { VBG_LAUNCH((vbg::conv3x3_kernel<128, 128, true, true>), g, dim3(256), 0, (hipStream_t)stream, a); }
+        VBG_LAUNCH_RET();
+    }
     if (n64) {
         if (form == 1) { VBG_LAUNCH((vbg::conv3x3_kernel<128, 64, true>), g, dim3(256), 0, (hipStream_t)stream, a); }
         else { VBG_LAUNCH((vbg::conv3x3_kernel<128, 64, false>), g, dim3(256), 0, (hipStream_t)stream, a); }

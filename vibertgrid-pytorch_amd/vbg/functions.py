@@ -239,7 +239,7 @@ class SegLinearFn(torch.autograd.Function):
 
 
 # ----------------------------------------------------------------------------------------------
-def _conv_any(x, w4, stride, pad, bias=None, want_stats=False):
+def _conv_any(x, w4, stride, pad, bias=None, want_stats=False, w_owner=None):
     """x NHWC; w4 = OHWI weight.  Cin=3 stem goes through im2col (K=147, row stride 148).
     want_stats: -> third result = BatchNorm slot workspace holding the output's column sums / sums of squares (fused into the GEMM
     epilogue), or None when the product is one the library may split (the caller then runs ops.bn_stats)."""
@@ -254,7 +254,7 @@ def _conv_any(x, w4, stride, pad, bias=None, want_stats=False):
         out = torch.empty((B, Ho, Wo, Cout), device=x.device, dtype=f32)
         ops.gemm_raw(B * Ho * Wo, Cout, K, col, Kp, OP_DENSE_K, w4, K, OP_DENSE_K, out, Cout, bias=bias, stats=stats)
         return out, col, stats
-    return ops.conv2d_fwd(x, w4, stride, pad, bias, stats=stats), None, stats
+    return ops.conv2d_fwd(x, w4, stride, pad, bias, stats=stats, w_owner=w_owner), None, stats
 
 
 def _conv_wgrad_any(dy, x, col, w4_shape, stride, pad, w_param=None, dy_amax=None, x_amax=None):
@@ -294,7 +294,7 @@ class ConvFn(torch.autograd.Function):
         ctx.x_amax = _amax_tag(x)                         # the producer's word with the bits of max |x| (see ConvBnFn), if any
         x = _c(x)
         w4 = ohwi(w)
-        y, col, _ = _conv_any(x, w4, stride, pad, b)
+        y, col, _ = _conv_any(x, w4, stride, pad, b, w_owner=w)
         ctx.stride, ctx.pad, ctx.has_bias = stride, pad, b is not None
         ctx.w_ref, ctx.b_ref = w, b
         ctx.save_for_backward(x, w4, col)
@@ -310,7 +310,7 @@ class ConvFn(torch.autograd.Function):
         f16_d = ctx.needs_input_grad[0] and ops.conv3_f16_bwd_ok(B_, H_, W_, Cout_, Cin_, kh, kw, ctx.stride, ctx.pad)
         f16_w = col is None and ops.conv3_f16_wgrad_ok(B_, H_, W_, Cin_, Cout_, kh, kw, ctx.stride, ctx.pad)
         dy_amax = ops.amax(dy) if (f16_d or f16_w) else None
-        dx = ops.conv2d_dgrad(dy, w4, tuple(x.shape), ctx.stride, ctx.pad, dy_amax=dy_amax) if ctx.needs_input_grad[0] else None
+        dx = ops.conv2d_dgrad(dy, w4, tuple(x.shape), ctx.stride, ctx.pad, dy_amax=dy_amax, w_owner=ctx.w_ref) if ctx.needs_input_grad[0] else None
         dw = _conv_wgrad_any(dy, x, col, tuple(w4.shape), ctx.stride, ctx.pad, ctx.w_ref, dy_amax=dy_amax, x_amax=ctx.x_amax)
         db = _bias_grad(ctx.b_ref, dy.view(-1, dy.shape[-1])) if ctx.has_bias else None
         return dx, dw, db, None, None
@@ -340,7 +340,7 @@ class ConvBnFn(torch.autograd.Function):
         x = _c(x)
         sync = bool(sync) and SyncCtx.active()
         w4 = ohwi(w)
-        z, col, stats = _conv_any(x, w4, stride, pad, want_stats=training)
+        z, col, stats = _conv_any(x, w4, stride, pad, want_stats=training, w_owner=w)
         C = z.shape[-1]
         z2 = z.view(-1, C)
         M = z2.shape[0]
@@ -398,7 +398,7 @@ class ConvBnFn(torch.autograd.Function):
         dz_amax = ops.amax_slot(dy2.device) if want_amax else None
         dz2, dres2 = ops.bn_bwd_apply(dy2, y2, z2, mean, invstd, gamma, sums, count, relu, has_res, None, None, count_dev, dx_amax=dz_amax)
         dz = dz2.view(z.shape)
-        dx = ops.conv2d_dgrad(dz, w4, tuple(x.shape), stride, pad, dy_amax=dz_amax) if ctx.needs_input_grad[0] else None
+        dx = ops.conv2d_dgrad(dz, w4, tuple(x.shape), stride, pad, dy_amax=dz_amax, w_owner=ctx.w_ref) if ctx.needs_input_grad[0] else None
         dw = _conv_wgrad_any(dz, x, col, tuple(w4.shape), stride, pad, ctx.w_ref, dy_amax=dz_amax, x_amax=ctx.x_amax)
         dres = dres2.view(z.shape) if has_res else None
         return dx, dw, dgamma, dbeta, None, None, dres, None, None, None, None, None, None, None

@@ -35,6 +35,10 @@ class GemmDesc(C.Structure):
                 ("stats", c_vp), ("stats_slots", c_int), ("bf16", c_int)]
 
 
+class Conv3WprepEntry(C.Structure):          # include/vbg.h vbg_conv3_wprep_entry
+    _fields_ = [("w", c_vp), ("out", c_vp), ("Cout", c_int), ("Cin", c_int), ("flip", c_int), ("bn", c_int)]
+
+
 class PlaneGroup(C.Structure):
     _fields_ = [("A", c_vp), ("B", c_vp), ("C", c_vp), ("a_plane", c_ll), ("lda", c_ll), ("b_plane", c_ll), ("ldb", c_ll), ("ldc", c_ll),
                 ("M", c_int), ("N", c_int), ("tiles_m", c_int), ("tiles_n", c_int), ("a_amax", c_vp)]
@@ -88,6 +92,9 @@ SIGNATURES = {
     "vbg_colsum_f64": (c_int, [c_vp, c_ll, c_int, c_int, c_vp, c_int, c_vp, c_vp]),
     "vbg_conv3x3": (c_int, [c_vp, c_vp, c_vp, c_vp, c_vp, c_int, c_int, c_int, c_int, c_int, c_int, c_int, c_int, c_vp, c_vp, c_vp, c_int, c_vp]),
     "vbg_conv3x3_split": (c_int, [c_int, c_int, c_int, c_int, c_int]),
+    "vbg_conv3x3_pw": (c_int, [c_vp, c_vp, c_vp, c_vp, c_vp, c_int, c_int, c_int, c_int, c_int, c_int, c_int, c_vp, c_vp, c_vp, c_int, c_vp]),
+    "vbg_conv3x3_wprep": (c_int, [c_vp, c_vp, c_int, c_vp]),
+    "vbg_conv3x3_wprep_bytes": (c_ll, [c_int, c_int, c_int]),
     "vbg_amax": (c_int, [c_vp, c_ll, c_vp, c_vp]),
     "vbg_conv3x3_wflip": (c_int, [c_vp, c_int, c_int, c_vp, c_vp]),
     "vbg_conv3x3_wgrad_strips": (c_int, [c_int, c_int, c_int, c_int, c_int]),

@@ -749,17 +749,18 @@ def _conv3_tickets(device, tiles):
     return t
 
 
-def conv3x3(x, w_ohwi, bias=None, out=None, stats=None, accumulate=False, f16x2=False, x_amax=None, nsplit=None):
+def conv3x3(x, w_ohwi, bias=None, out=None, stats=None, accumulate=False, f16x2=False, x_amax=None, nsplit=None, w_planes=None, n_out=None):
     """y (+)= conv3x3(x NHWC, w [N,3,3,Cs]), stride 1, pad 1 (csrc/conv3.hip).  f16x2: the two-piece fp16 form -- for operands inside
     fp16's range (activations, filters); a gradient operand x needs x_amax (device word with the bits of max |x|): the kernel then
     scales x by the power of two that centres it in fp16's range and the result back (exact).  nsplit: workgroups per tile (None: the
     library's choice for the shape)"""
     B, H, W, Cs = x.shape
-    N = w_ohwi.shape[0]
+    N = w_ohwi.shape[0] if n_out is None else int(n_out)
     if out is None:
         assert not accumulate
         out = torch.empty((B, H, W, N), device=x.device, dtype=f32)
     assert x_amax is None or f16x2
+    assert w_planes is None or f16x2
     nz = conv3_split(B, H, W, Cs, N) if nsplit is None else int(nsplit)
     slab = tickets = None
     if nz > 1:
@@ -778,8 +779,13 @@ def conv3x3(x, w_ohwi, bias=None, out=None, stats=None, accumulate=False, f16x2=
     if _CONV3_PROF[0] is not None:           # bench.py's second roofline object: events around the launch, on the launch stream
         ev = (torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True))
         ev[0].record()
-    check(lib.vbg_conv3x3(P(x), P(w_ohwi), P(bias), P(out), P(stats), bn_slots() if stats is not None else 0, B, H, W, Cs, N,
-                          int(accumulate), int(bool(f16x2)), P(x_amax), P(slab), P(tickets), nz, _stream()), "vbg_conv3x3")
+    if w_planes is not None:                 # the filter as pre-split fp16-pair planes (conv3_planes): no filter work in the kernel
+        _seen("conv3:pw")
+        check(lib.vbg_conv3x3_pw(P(x), P(w_planes), P(bias), P(out), P(stats), bn_slots() if stats is not None else 0, B, H, W, Cs, N,
+                                 int(accumulate), P(x_amax), P(slab), P(tickets), nz, _stream()), "vbg_conv3x3_pw")
+    else:
+        check(lib.vbg_conv3x3(P(x), P(w_ohwi), P(bias), P(out), P(stats), bn_slots() if stats is not None else 0, B, H, W, Cs, N,
+                              int(accumulate), int(bool(f16x2)), P(x_amax), P(slab), P(tickets), nz, _stream()), "vbg_conv3x3")
     if ev is not None:
         ev[1].record()
         _CONV3_PROF[0].append((2.0 * B * H * W * Cs * N * 9, 3 if f16x2 else 6, ev[0], ev[1]))
@@ -808,6 +814,89 @@ def set_conv3_profiler(records):
     """records: a list that receives (algorithmic flops, piece products per product, start event, stop event) per row-reuse
     forward / input-gradient launch -- or None (off)"""
     _CONV3_PROF[0] = records
+
+
+# ---- pre-split filter images for the PW form of the row-reuse kernels (csrc/conv3.hip conv3_wprep_kernel) ------------------------------
+_CONV3_PW = [os.environ.get("VBG_CONV3_PW", "1") != "0"]
+_C3PW = {"entries": [], "table": None, "host": None, "n": 0}
+
+
+def set_conv3_pw(on: bool):
+    """filters of the fp16-form 3x3 convolutions as pre-split planes streamed by LDS-DMA (on) or split inside every workgroup (off)"""
+    _CONV3_PW[0] = bool(on)
+
+
+class _C3Entry:
+    __slots__ = ("ref", "flip", "out", "tag", "shape", "ptr")
+
+
+def _c3pw_tag(owner):
+    return (_W_EPOCH[0], owner._version, owner.data_ptr())
+
+
+def _c3pw_table(entries, device):
+    """(host table, device table, n) describing the plane images of `entries` for vbg_conv3x3_wprep"""
+    from .lib import Conv3WprepEntry
+    n = len(entries)
+    host = (Conv3WprepEntry * n)()
+    for i, e in enumerate(entries):
+        Cout, Cin = e.shape
+        rows = Cin if e.flip else Cout
+        host[i].w, host[i].out, host[i].Cout, host[i].Cin, host[i].flip = e.ptr, e.out.data_ptr(), Cout, Cin, int(e.flip)
+        host[i].bn = 64 if (rows % 128 != 0 and rows % 64 == 0) else 128
+    raw = torch.frombuffer(bytearray(bytes(host)), dtype=torch.uint8)
+    return host, h2d(raw, device), n
+
+
+def _c3pw_refresh(device):
+    """every registered image that is stale (the optimizer kernels ran, load_state_dict, ...) in ONE launch; the device table is kept
+    while the set of registered filters does not change"""
+    st = _C3PW
+    live = []
+    for e in st["entries"]:
+        owner = e.ref()
+        if owner is not None and owner.data_ptr() == e.ptr and owner.device == device:
+            live.append(e)
+        elif owner is not None:
+            owner.__dict__.pop("_vbg_c3pw", None)          # moved: registers again on its next use
+    if len(live) != len(st["entries"]) or st["table"] is None or st["table"].device != device:
+        st["entries"] = live
+        st["host"], st["table"], st["n"] = _c3pw_table(live, device) if live else (None, None, 0)
+    if not live:
+        return
+    check(lib.vbg_conv3x3_wprep(P(st["table"]), C.byref(st["host"]), st["n"], _stream()), "vbg_conv3x3_wprep")
+    for e in live:
+        e.tag = _c3pw_tag(e.ref())
+
+
+def conv3_planes(owner, w_ohwi, flip):
+    """fp16-pair plane image of the 3x3 filter `owner` (an OIHW parameter in channels_last memory, `w_ohwi` its free [O,3,3,I] view) for
+    vbg_conv3x3_pw: flip = False the forward filter, True the filter of the input gradient.  Written once per weight version for ALL
+    registered filters by one launch (first use: one launch for the new image).  None: no PW form for this filter."""
+    if owner is None or not _CONV3_PW[0] or not w_ohwi.is_cuda or w_ohwi.data_ptr() != owner.data_ptr():
+        return None
+    Cout, kh, kw, Cin = w_ohwi.shape
+    if kh != 3 or kw != 3 or Cin % 8 != 0 or (Cout if flip else Cin) % 16 != 0:
+        return None
+    slot = owner.__dict__.setdefault("_vbg_c3pw", {})
+    e = slot.get(bool(flip))
+    if e is None or e.ptr != owner.data_ptr():
+        import weakref
+        e = _C3Entry()
+        e.ref, e.flip, e.shape, e.ptr = weakref.ref(owner), bool(flip), (int(Cout), int(Cin)), owner.data_ptr()
+        nbytes = int(lib.vbg_conv3x3_wprep_bytes(int(Cout), int(Cin), int(bool(flip))))
+        e.out = torch.empty((nbytes,), device=w_ohwi.device, dtype=torch.uint8)
+        slot[bool(flip)] = e
+        st = _C3PW
+        st["entries"] = [x for x in st["entries"] if not (x.ref() is owner and x.flip == e.flip)] + [e]
+        st["table"] = None                                  # the full table is rebuilt at the next refresh
+        host, tab, n = _c3pw_table([e], w_ohwi.device)     # the new image alone
+        check(lib.vbg_conv3x3_wprep(P(tab), C.byref(host), n, _stream()), "vbg_conv3x3_wprep")
+        e.tag = _c3pw_tag(owner)                            # (the table tensor is freed stream-ordered: the launch has it)
+        return e.out
+    if e.tag != _c3pw_tag(owner):
+        _c3pw_refresh(w_ohwi.device)
+    return e.out
 
 
 def conv3x3_wflip(w_ohwi):
@@ -850,7 +939,7 @@ def conv3x3_wgrad(dy, x, dw_ohwi, slabs=True, f16x2=False, dy_amax=None, x_amax=
     return dw_ohwi
 
 
-def conv2d_fwd(x, w_ohwi, stride, pad, bias=None, out=None, stats=None):
+def conv2d_fwd(x, w_ohwi, stride, pad, bias=None, out=None, stats=None, w_owner=None):
     """x NHWC [B,H,W,Cin] contiguous; w_ohwi [Cout,kh,kw,Cin] contiguous -> y NHWC [B,Ho,Wo,Cout]."""
     _chk_f32(x, w_ohwi, bias)
     B, H, W, Cin = x.shape
@@ -861,7 +950,8 @@ def conv2d_fwd(x, w_ohwi, stride, pad, bias=None, out=None, stats=None):
         out = torch.empty((B, Ho, Wo, Cout), device=x.device, dtype=f32)
     M, K = B * Ho * Wo, kh * kw * Cin
     if conv3_ok(B, H, W, Cin, Cout, kh, kw, stride, pad, fwd=True):
-        return conv3x3(x, w_ohwi, bias, out, stats, f16x2=_CONV3_F16[0])
+        wp = conv3_planes(w_owner, w_ohwi, False) if (_CONV3_F16[0] and conv3_pw_ok(B, H, W, Cin, Cout)) else None
+        return conv3x3(x, w_ohwi, bias, out, stats, f16x2=_CONV3_F16[0], w_planes=wp)
     if kh == 1 and kw == 1 and stride == 1 and pad == 0:
         gemm_raw(M, Cout, K, x, Cin, OP_DENSE_K, w_ohwi, K, OP_DENSE_K, out, Cout, bias=bias, stats=stats)
     else:
@@ -891,7 +981,19 @@ def conv3_f16_bwd_ok(B, H, W, Cout, Cin, kh, kw, stride, pad) -> bool:
     return _CONV3_F16[0] and _CONV3_F16_BWD[0] and conv3_ok(B, H, W, Cout, Cin, kh, kw, stride, pad)
 
 
-def conv2d_dgrad(dy, w_ohwi, x_shape, stride, pad, out=None, accumulate=False, dy_amax=None):
+def conv3_pw_ok(B, H, W, Cs, N) -> bool:
+    """does vbg_conv3x3 run 128-pixel tiles on this shape (what the PW kernels exist for)?  Mirrors csrc/conv3.hip conv3x3_impl."""
+    if H == 7 and W == 7:
+        return True
+    if (H * W) % 128 != 0:
+        return False
+    if conv3_split(B, H, W, Cs, N) > 1 or W >= 128:
+        return True
+    bn = 64 if (N % 128 != 0 and N % 64 == 0) else 128
+    return (B * H * W // 128) * ((N + bn - 1) // bn) >= 240
+
+
+def conv2d_dgrad(dy, w_ohwi, x_shape, stride, pad, out=None, accumulate=False, dy_amax=None, w_owner=None):
     """dx NHWC [B,H,W,Cin] (+)= conv_transpose(dy NHWC [B,Ho,Wo,Cout], w).  dy_amax: device word with the bits of max |dy| when the
     producer of dy wrote one (bn_bwd_apply); otherwise the fp16 form takes it with one vbg_amax pass over dy"""
     _chk_f32(dy, w_ohwi)
@@ -906,6 +1008,10 @@ def conv2d_dgrad(dy, w_ohwi, x_shape, stride, pad, out=None, accumulate=False, d
     if conv3_ok(B, H, W, Cout, Cin, kh, kw, stride, pad):
         # the input gradient of a 3x3 / s1 / p1 convolution is the same convolution of dy with the turned, channel-swapped filter
         if _CONV3_F16[0] and _CONV3_F16_BWD[0]:
+            wp = conv3_planes(w_owner, w_ohwi, True) if conv3_pw_ok(B, H, W, Cout, Cin) else None
+            if wp is not None:       # the turned filter exists as plane image only: no fp32 copy of it is written
+                return conv3x3(dy, w_ohwi, None, out, None, accumulate, f16x2=True, x_amax=dy_amax if dy_amax is not None else amax(dy),
+                               w_planes=wp, n_out=Cin)
             return conv3x3(dy, conv3x3_wflip(w_ohwi), None, out, None, accumulate, f16x2=True, x_amax=dy_amax if dy_amax is not None else amax(dy))
         return conv3x3(dy, conv3x3_wflip(w_ohwi), None, out, None, accumulate)
     if kh == 1 and kw == 1 and stride == 1 and pad == 0:
