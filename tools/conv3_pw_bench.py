@@ -35,7 +35,7 @@ for (B, H, W, Ci, Co) in SHAPES:
     if H * W % 128 == 0 and H != 7 and W < 128:
         for z in (1, 2, 3, 4, 6, 8):
             cs = z // 3 if z % 3 == 0 else z
-            if Ci % cs or (Ci // cs) % 16 or (z == 1 and not ops.conv3_pw_ok(B, H, W, Ci, Co)):
+            if Ci % cs or (Ci // cs) % 16 or (z == 1 and nz > 1):
                 continue
             report(f"fwd   PW               {tag} nsplit {z} (forced)", fl, timeit(lambda: ops.conv3x3(x, w4, f16x2=True, w_planes=wp, nsplit=z)))
 # the prep launch itself: every 3x3 filter of a resnet-34 trunk + FPN + heads, both directions, one launch

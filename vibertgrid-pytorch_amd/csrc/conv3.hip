@@ -99,6 +99,21 @@ struct c3_pipe {
     }
 };
 
+// software-pipelined loop: after MFMA M one LDS read (the next k-tile's fragments) while any are left, then its share of the NV VALU
+// and ND LDS-write instructions of the region
+template <int M, int NM, int NRD, int NV, int ND>
+struct c3_pipe2 {
+    static __device__ __forceinline__ void run() {
+        __builtin_amdgcn_sched_group_barrier(0x008, 1, 0);
+        if constexpr (M < NRD) __builtin_amdgcn_sched_group_barrier(0x100, 1, 0);
+        constexpr int v = ((M + 1) * NV) / NM - (M * NV) / NM;
+        if constexpr (v > 0) __builtin_amdgcn_sched_group_barrier(0x002, v, 0);
+        constexpr int w = ((M + 1) * ND) / NM - (M * ND) / NM;
+        if constexpr (w > 0) __builtin_amdgcn_sched_group_barrier(0x200, w, 0);
+        if constexpr (M + 1 < NM) c3_pipe2<M + 1, NM, NRD, NV, ND>::run();
+    }
+};
+
 // BM = 128 pixels per tile, or 64 for the late stages whose pixel count would leave half the chip without a 128-pixel tile
 // F16: the arithmetic form -- false: three bf16 pieces per operand, six piece products (the library's default everywhere); true: two
 // fp16 pieces, three piece products with the two cross products in their own accumulators (scaled by 2^11), for operands inside fp16's
@@ -122,8 +137,14 @@ struct c3_pipe {
 // spends no VALU and no ds_write on the filter: 4 bytes per element from L2 as before (two fp16 pieces = one fp32), in full 128-byte
 // lines instead of 64-byte row pieces, and three quarters of the kernel's split work gone (the activation super-tile, loaded every
 // third k-tile, is the rest).
-template <int BM, int BN, bool F16, bool PW = false>
+// PWM = 2: the same with a software-pipelined k-loop -- the fragments of k-tile t + 1 are read from LDS in the gaps of the MFMAs of
+// k-tile t (two register sets), the activation super-tile is stored one k-tile earlier (loaded at kw = 0, split and stored at kw = 1,
+// first read during kw = 2), and the DMA runs one k-tile further ahead of its readers.  A wave's k-tile is then MFMAs + one barrier: what
+// the one-round launches of the trunk (one wave per SIMD, nobody to hide the LDS latency behind) were missing.  Same products in the
+// same order per accumulator: bit-identical.
+template <int BM, int BN, bool F16, int PWM = 0>
 __global__ __launch_bounds__(256, 2) void conv3x3_kernel(const conv3_args p) {
+    constexpr bool PW = PWM != 0;
     static_assert(!PW || (F16 && BM == 128), "pre-split weights: the fp16-pair form on 128-pixel tiles");
     constexpr int NT = 256, SKH = 24;
     constexpr int NSB = 4, DPF = NSB - 1;                      // PW: stages of the filter ring / k-tiles in flight
@@ -140,7 +161,10 @@ __global__ __launch_bounds__(256, 2) void conv3x3_kernel(const conv3_args p) {
     constexpr int CTS = BN + 4;
     constexpr int LOOPSZ = PW ? 2 * ASZ + NSB * BTILE / 4 : 2 * (ASZ + BSZ);
     constexpr int SMEM = LOOPSZ > BM * CTS ? LOOPSZ : BM * CTS;                        // 76 KB at BM = 128, three planes: two workgroups per CU
-    __shared__ __attribute__((aligned(16))) unsigned smem[SMEM];
+    // (the ONE LDS object of the kernel: with a second one the LDS lowering tags every access with alias scopes, and the compiler then
+    //  puts `s_waitcnt vmcnt(0)` in front of every LDS read that follows an LDS-DMA into the same object -- the ring would never run
+    //  ahead.  The split form's arrival ticket lives in the last word.)
+    __shared__ __attribute__((aligned(16))) unsigned smem[SMEM + 4];
     unsigned* const As = smem;
     unsigned* const Bs = smem + 2 * ASZ;
 
@@ -391,7 +415,115 @@ __global__ __launch_bounds__(256, 2) void conv3x3_kernel(const conv3_args p) {
     for (int e = tid; e < 2 * ASZ / 4; e += NT) reinterpret_cast<uint4*>(As)[e] = make_uint4(0u, 0u, 0u, 0u);
     set_a(kh0);
     const int nsup = (p.ksplit == 3 ? 1 : 3) * cw / 16;
-    if constexpr (PW) {
+    if constexpr (PWM == 2) {
+        // Ring of NSB = 4 stages; the DMA of k-tile t + 4 is issued at the END of k-tile t into the stage of k-tile t itself (its
+        // fragments were read during k-tile t - 1), and must have landed by the end of k-tile t + 2: two k-tiles of lead.
+        // What hipcc adds on its own (measured in the ISA): nothing in front of an LDS READ that follows an LDS-DMA as long as the
+        // kernel has ONE LDS object, but `s_waitcnt vmcnt` for the most recent LDS-DMA in front of every LDS WRITE -- so the
+        // activation super-tile is split in registers in the gaps of the MFMAs and WRITTEN at the end of its k-tile, in front of that
+        // k-tile's DMA issue, where the most recent DMA is a whole k-tile old.  No fence-carrying __syncthreads() in the loop (its
+        // release fence drains vmcnt to 0): counted waits and bare barriers.
+        d_left = 3 * nsup;
+        load_a();
+        __syncthreads();                       // (the zero fill above)
+        store_a(0);
+#pragma unroll
+        for (int d = 0; d < NSB; ++d) issue_b();
+        asm volatile("s_waitcnt vmcnt(%0) lgkmcnt(0)" ::"n"(2 * NDB) : "memory");    // k-tiles 0 and 1 have landed
+        __builtin_amdgcn_s_barrier();
+        c3_u32x4 fA[2][NPL][TM], fB[2][NPL][TNF];
+        auto read_frags = [&](auto par_tag, int abuf, int stage, int kw) {
+            constexpr int P = decltype(par_tag)::value;
+            const c3_u32x4* as = reinterpret_cast<const c3_u32x4*>(As + abuf * ASZ);
+            const unsigned char* bsb = ring + stage * BTILE + (wn * TNF) * 1024 + lk * 512 + lr * 16;
+#pragma unroll
+            for (int q = 0; q < NPL; ++q) {
+#pragma unroll
+                for (int i = 0; i < TM; ++i) fA[P][q][i] = as[q * (PA / 4) + (arow[i] + kw) * (SKH / 8) + lk];
+#pragma unroll
+                for (int j = 0; j < TNF; ++j) fB[P][q][j] = *reinterpret_cast<const c3_u32x4*>(bsb + q * (BTILE / 2) + j * 1024);
+            }
+        };
+        auto mma_set = [&](auto par_tag) {
+            constexpr int P = decltype(par_tag)::value;
+#pragma unroll
+            for (int t = 0; t < 3; ++t)
+#pragma unroll
+                for (int i = 0; i < TM; ++i)
+#pragma unroll
+                    for (int n = 0; n < TNF; ++n) {
+                        f32x16& d = t < 2 ? acx[i][n] : acc[i][n];
+                        d = __builtin_amdgcn_mfma_f32_32x32x16_f16(__builtin_bit_cast(c3_f16x8, fA[P][t == 0 ? 1 : 0][i]),
+                                                                   __builtin_bit_cast(c3_f16x8, fB[P][t == 1 ? 1 : 0][n]), d, 0, 0, 0);
+                    }
+        };
+        // the activation super-tile in two steps: pieces into registers (VALU, in the MFMA gaps), then the LDS writes
+        uint2 sh[NAI + 1], sl[NAI + 1];
+        auto split_a = [&]() {
+#pragma unroll
+            for (int i = 0; i < NAI; ++i) {
+                const float4 v = scaled(ra[i]);
+                c3_split2(v.x, v.y, sh[i].x, sl[i].x);
+                c3_split2(v.z, v.w, sh[i].y, sl[i].y);
+            }
+            const float4 v = scaled(rh);
+            c3_split2(v.x, v.y, sh[NAI].x, sl[NAI].x);
+            c3_split2(v.z, v.w, sh[NAI].y, sl[NAI].y);
+        };
+        auto write_a = [&](int buf) {
+            unsigned* dst = As + buf * ASZ;
+#pragma unroll
+            for (int i = 0; i < NAI; ++i) {
+                const int o = a_lrow[i] * (SKH / 2) + kc / 2;
+                *reinterpret_cast<uint2*>(&dst[o]) = sh[i];
+                *reinterpret_cast<uint2*>(&dst[o + PA]) = sl[i];
+            }
+            if (wide && tid < 8) {
+                const int o = h_row * (SKH / 2) + kc / 2;
+                *reinterpret_cast<uint2*>(&dst[o]) = sh[NAI];
+                *reinterpret_cast<uint2*>(&dst[o + PA]) = sl[NAI];
+            }
+        };
+        using p0 = std::integral_constant<int, 0>;
+        using p1 = std::integral_constant<int, 1>;
+        int bst = 0;                           // ring stage of the current k-tile
+        // one k-tile: P = register set holding its fragments, KW = its tap column; `s` its super-tile
+        auto tile = [&](auto par_tag, auto kw_tag, int s) {
+            constexpr int P = decltype(par_tag)::value, KW = decltype(kw_tag)::value;
+            const int nst = bst + 1 == NSB ? 0 : bst + 1;
+            __builtin_amdgcn_sched_barrier(0);
+            if constexpr (P == 0) read_frags(p1{}, KW < 2 ? (s & 1) : ((s + 1) & 1), nst, KW < 2 ? KW + 1 : 0);
+            else read_frags(p0{}, KW < 2 ? (s & 1) : ((s + 1) & 1), nst, KW < 2 ? KW + 1 : 0);
+            if constexpr (P == 0) mma_set(p0{}); else mma_set(p1{});
+            if constexpr (KW == 1) split_a();
+            constexpr int NM = 3 * TM * TNF, NRD = NPL * (TM + TNF);
+            c3_pipe2<0, NM, NRD, KW == 1 ? (NAI + 1) * 10 : 0, 0>::run();
+            __builtin_amdgcn_sched_barrier(0);
+            if constexpr (KW == 1) write_a((s + 1) & 1);   // super-tile s + 1: read from k-tile (s, 2) on
+            // (activation loads in FRONT of the DMA: loads return in order, and waiting for these registers in the next k-tile must not
+            //  mean waiting for the DMA issued behind them)
+            if constexpr (KW == 0) load_a();                // super-tile s + 1 (past the end: zeros or rows nobody uses)
+            issue_b();                                      // k-tile t + 4 into this k-tile's stage
+            if constexpr (KW == 0) {
+                // k-tile t + 2 has landed: t + 3, t + 4 and the activation loads just issued may stay in flight
+                if (wide) asm volatile("s_waitcnt vmcnt(%0) lgkmcnt(0)" ::"n"(2 * NDB + NAI + 1) : "memory");
+                else asm volatile("s_waitcnt vmcnt(%0) lgkmcnt(0)" ::"n"(2 * NDB + NAI) : "memory");
+            } else {
+                asm volatile("s_waitcnt vmcnt(%0) lgkmcnt(0)" ::"n"(2 * NDB) : "memory");
+            }
+            __builtin_amdgcn_s_barrier();
+            bst = nst;
+        };
+        read_frags(p0{}, 0, 0, 0);
+        using k0 = std::integral_constant<int, 0>;
+        using k1 = std::integral_constant<int, 1>;
+        using k2 = std::integral_constant<int, 2>;
+        for (int s = 0; s < nsup; s += 2) {
+            tile(p0{}, k0{}, s); tile(p1{}, k1{}, s); tile(p0{}, k2{}, s);
+            if (s + 1 < nsup) { tile(p1{}, k0{}, s + 1); tile(p0{}, k1{}, s + 1); tile(p1{}, k2{}, s + 1); }
+        }
+        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");       // the zero-writing DMAs past the end must not land in the staged tile
+    } else if constexpr (PW) {
         d_left = 3 * nsup;
         load_a();
         __syncthreads();                       // (the zero fill above)
@@ -455,7 +587,7 @@ __global__ __launch_bounds__(256, 2) void conv3x3_kernel(const conv3_args p) {
     // block order -- its own included, so the sum does not depend on who came last -- and runs the epilogue.  Nobody waits.
     const float* part = nullptr;
     if (nz > 1) {
-        __shared__ unsigned ticket_s;
+        unsigned& ticket_s = smem[SMEM];
         const size_t tile = (size_t)tile_n * gx + tile_m;
         float* const mine = p.slab + (tile * nz + zz) * (size_t)(BM * BN);
         const __amdgpu_buffer_rsrc_t rs = __builtin_amdgcn_make_buffer_rsrc(mine, 0, BM * BN * 4, 0x00020000);
@@ -999,8 +1131,15 @@ static int conv3x3_impl(const float* x, const float* w, const unsigned short* wp
     if (wp) {
         // the plane image was written for conv3_pw_bn(N) rows per filter tile: the launch must walk it with the same tile
         VBG_CHECK_ARG(big && bn == conv3_pw_bn(N));
-        if (n64) { VBG_LAUNCH((vbg::conv3x3_kernel<128, 64, true, true>), g, dim3(256), 0, (hipStream_t)stream, a); }
-        else { VBG_LAUNCH((vbg::conv3x3_kernel<128, 128, true, true>), g, dim3(256), 0, (hipStream_t)stream, a); }
+        // VBG_CONV3_PIPE=0: the lockstep k-loop of the PW kernels (A/B switch of the software-pipelined loop)
+        static const bool pipe = !(getenv("VBG_CONV3_PIPE") && atoi(getenv("VBG_CONV3_PIPE")) == 0);
+        if (pipe) {
+            if (n64) { VBG_LAUNCH((vbg::conv3x3_kernel<128, 64, true, 2>), g, dim3(256), 0, (hipStream_t)stream, a); }
+            else { VBG_LAUNCH((vbg::conv3x3_kernel<128, 128, true, 2>), g, dim3(256), 0, (hipStream_t)stream, a); }
+        } else {
+            if (n64) { VBG_LAUNCH((vbg::conv3x3_kernel<128, 64, true, 1>), g, dim3(256), 0, (hipStream_t)stream, a); }
+            else { VBG_LAUNCH((vbg::conv3x3_kernel<128, 128, true, 1>), g, dim3(256), 0, (hipStream_t)stream, a); }
+        }
         VBG_LAUNCH_RET();
     }
     if (n64) {
