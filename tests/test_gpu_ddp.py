@@ -341,7 +341,7 @@ def test_stock_ddp_wrapper_equals_flat_reducer(tmp_path):
     """The reference's unmodified multi-GPU wiring around the drop-in model -- SyncBatchNorm.convert_sync_batchnorm,
     DistributedDataParallel(device_ids=[gpu], find_unused_parameters=True), torch.optim.SGD + AdamW (train_SROIE.py:202-235) -- on two
     ranks sharing the GPU over gloo: after 3 steps both ranks hold the same parameters, and they are the parameters the FlatReducer /
-    fused-optimizer route produces: the loss of every step to 1e-5 and every parameter's change over the FIRST step to 1e-3 rel-L2 (the
+    fused-optimizer route produces: the loss of every step to 1e-5 and every parameter's change over the FIRST step to 5e-3 rel-L2 (the
     two routes differ by where 1 / world is applied, by the optimizer kernels' rounding and by the kernel family of the weight
     gradients).  Over three steps the tiny fixture (two documents, train-mode BatchNorm) amplifies those 1e-6 differences like any
     other rounding change -- the reference's own gradients move by percents under a one-ulp change there -- so the 3-step change is
@@ -361,7 +361,9 @@ def test_stock_ddp_wrapper_equals_flat_reducer(tmp_path):
     print("running mean of the stem BatchNorm: max |stock - flat|", float((r0["stock_rm"] - r0["flat_rm"]).abs().max()), "max |.|", float(r0["flat_rm"].abs().max()))
     for a, b in zip(r0["stock_losses"], r0["flat_losses"]):
         assert abs(a - b) <= 1e-5 * abs(b), (a, b)
-    for tag, ka, kb, tol in (("first step", "stock1", "flat1", 1e-3), ("three steps", "stock", "flat", 5e-2)):
+    # (first step: median 3e-6; AdamW's first update is lr * g / (|g| + eps) = +-lr for every element whose gradient is far above eps = 1e-8,
+    #  and the few LayerNorm-weight elements with |g| ~ eps put the worst tensors at 1.2e-3 -- the sign of a 1e-8 gradient is noise)
+    for tag, ka, kb, tol in (("first step", "stock1", "flat1", 5e-3), ("three steps", "stock", "flat", 5e-2)):
         worst = []
         for k, p0 in r0["init"].items():
             if k.startswith("BERTgrid_generator.") or "pooler" in k or "key.bias" in k:
@@ -372,4 +374,5 @@ def test_stock_ddp_wrapper_equals_flat_reducer(tmp_path):
         worst.sort(reverse=True)
         print(f"stock DDP vs FlatReducer, rel-L2 of the parameter change over the {tag}, worst:", worst[:4], "median", worst[len(worst) // 2])
         assert worst[0][0] < tol, (tag, worst[:8])
+        assert worst[len(worst) // 2][0] < (1e-4 if tag == "first step" else tol), (tag, worst[len(worst) // 2])
     assert torch.allclose(r0["stock_rm"], r0["flat_rm"], rtol=1e-4, atol=1e-6)
