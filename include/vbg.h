@@ -157,7 +157,20 @@ typedef struct vbg_plane_gemm_desc {
     const unsigned* a_amax;
     /* optional (NT): amax slot that receives max |stored value| of this launch (zeroed by the caller) */
     unsigned* c_amax;
+    /* optional (NT 8-wave tiles, with Cq; round 4): the Cq planes hold (stored value) * 2^e where e comes from a rigorous BOUND of the
+       stored values instead of their measured maximum -- a GRADIENT leaves the epilogue as pair planes without a split pass of its own:
+       bound = value(cq_ref_in: an amax slot holding max |A operand|, unscaled) * value(*cq_l1_in: float bits of max_j sum_k |B[j][k]|, the
+       largest row L1 norm of the NT B operand; NULL: 1) * cq_mul (the epilogue's Lipschitz constant, e.g. 1.13 for the GELU gradient, and
+       the rounding margin); |sum_k a_k b_jk| <= max |a| * sum_k |b_jk| holds for every element.  The bound's bit pattern is written to
+       word 0 of the zeroed amax slot cq_ref_out: consumers pass that slot as a_amax.  The two-piece form keeps 22 bits over ~30 binades,
+       so a bound 2^5 ... 2^10 above the true maximum costs no precision. */
+    const unsigned* cq_ref_in; const unsigned* cq_l1_in; float cq_mul; unsigned* cq_ref_out;
 } vbg_plane_gemm_desc;
+/* out[i] = max(out[i], bits of max_c sum_r |w_i[r][c]|) for n matrices (w_i [rows_i][cols_i], row stride ld_i): the largest column L1
+ * norm -- with w = the nn.Linear weight [out, in] of a layer, the bound factor of the data gradient dY W (a cq_l1_in word).  One launch
+ * for a table of matrices (device memory; max_cols = the largest cols_i); `out` words are maxed into: zero them first. */
+typedef struct vbg_l1_entry { const float* w; long long ld; int rows, cols; } vbg_l1_entry;
+int vbg_col_l1_max(const vbg_l1_entry* table_dev, int n, int max_cols, unsigned* out, void* stream);
 int vbg_plane_gemm(const vbg_plane_gemm_desc* desc, void* stream);
 int vbg_plane_gemm_timed(const vbg_plane_gemm_desc* desc, void* stream, void* start_event, void* stop_event);
 /* x [rows][cols] fp32 (row stride ldx) -> planes [3][rows][ldp] (plane stride `plane` elements), columns cols..ldp-1 zero;

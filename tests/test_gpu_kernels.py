@@ -841,6 +841,33 @@ def test_roi_align(ops):
     assert close(df.permute(0, 3, 1, 2), feat.grad, 1e-4, 1e-5)
 
 
+@pytest.mark.parametrize("C_", [256, 40])
+def test_roi_align_cfg2_like_boxes(ops, C_):
+    """RoIAlign forward against the CPU oracle on cfg2-like boxes (8-72 x 8-24 pixels) plus clipped, degenerate, one-pixel and
+    completely-outside ones and a whole-map RoI (42 samples per bin), at the model's channel count and at a ragged one.  (A RoI of
+    6 x 7 samples x 4 taps sums 168 fp32 terms in another order than the oracle: atol 3e-5.)"""
+    B, H, W = 2, 40, 48
+    g = torch.Generator().manual_seed(321)
+    feat = torch.randn(B, C_, H, W, generator=g)
+    boxes = []
+    for b in range(B):
+        n = 37
+        x1 = torch.randint(0, 4 * W - 72, (n,), generator=g); y1 = torch.randint(0, 4 * H - 24, (n,), generator=g)
+        w = torch.randint(8, 73, (n,), generator=g); h = torch.randint(8, 25, (n,), generator=g)
+        bx = torch.stack([x1, y1, x1 + w, y1 + h], 1).int()
+        extra = torch.tensor([[0, 0, 4 * W, 4 * H], [4 * W - 6, 4 * H - 5, 4 * W + 40, 4 * H + 30], [10, 10, 10, 10], [0, 0, 3, 2],
+                              [4 * W + 50, 4 * H + 50, 4 * W + 90, 4 * H + 70], [17, 3, 18, 150]], dtype=torch.int32)
+        boxes.append(torch.cat([bx, extra]))
+    ref = O.roi_align(feat, [b.float() for b in boxes], 7, 0.25)
+    allb, off, doc = _pack_boxes(boxes)
+    d = dev()
+    fh = feat.permute(0, 2, 3, 1).contiguous().to(d)
+    y = ops.roi_align_fwd(fh, allb.to(d), doc.to(d), 7, 0.25)
+    err = (y.permute(0, 3, 1, 2).cpu() - ref).abs()
+    print("RoIAlign vs oracle: max abs error", float(err.max()), "max |ref|", float(ref.abs().max()))
+    assert close(y.permute(0, 3, 1, 2), ref, 1e-4, 3e-5)
+
+
 # ------------------------------------------------------------------------------------------
 # losses / selection primitives
 # ------------------------------------------------------------------------------------------
@@ -1280,6 +1307,66 @@ def test_plane_gemm_pair_form_vs_fp64(tile):
     pl, pq = ops.planes_empty(520, 768, dev), ops.pair_empty(520, 768, dev)
     y, _, _ = ops.dropout_add_ln_fwd(x, r, gam, bet, 1e-12, 0.0, 1, 2, out_planes=pl, out_pair=pq)
     assert torch.equal(pl.buf, ops.split_planes(y).buf) and torch.equal(pq.buf, ops.split_planes_pair(y).buf)
+
+
+def test_plane_gemm_bound_scaled_pair_output():
+    """round 4: a GRADIENT leaves the product's epilogue as fp16-pair planes scaled by the power of two of a rigorous BOUND of the stored
+    values -- max |A| (amax slot) x the largest column L1 norm of W (vbg_col_l1_max) x the epilogue's constant -- instead of a measured
+    maximum: no fp32 round trip, no split pass.  Checked: the L1 word against torch; the bound really bounds; the planes are those of
+    (stored value) x 2^e with e from the bound (bit for bit against the scaled split of the fp32 result); the bias column sums; and the
+    consumers (NT data gradient, TN weight gradient) with the published bound as their a_amax against fp64 -- at gradient magnitudes
+    2^-30 ... 2^10, with the GELU-gradient epilogue of the BERT backward."""
+    from vbg import ops
+    from vbg.lib import EPI_MUL_GELU_GRAD
+    dev = torch.device("cuda")
+    g = torch.Generator().manual_seed(77)
+    M, K, N = 1000, 96 * 3, 768 + 64                        # tokens, features of dfo, features of h
+    w = (torch.randn(K, N, generator=g) / K ** 0.5).to(dev)            # nn.Linear(N -> K).weight: [K, N]; dh = dfo @ w
+    w2 = (torch.randn(N, 160, generator=g) / N ** 0.5).to(dev)
+    xs = torch.randn(M, 64, generator=g).to(dev)
+    h = torch.randn(M, N, generator=g).to(dev) * 1.5
+    l1 = ops.weight_col_l1max(w)
+    assert abs(float(l1.view(torch.float32).item()) - float(w.abs().sum(0).max())) <= 1e-5 * float(w.abs().sum(0).max())
+    qwt = ops.split_planes_pair(w.t().contiguous())                    # B operand of the NT product: rows = features of h
+    for sc in (1.0, 2.0 ** -30, 2.0 ** -19, 2.0 ** 10):
+        dfo = (torch.randn(M, K, generator=g) * torch.exp2(torch.randint(-5, 5, (M, 1), generator=g).float())).to(dev) * sc
+        s_in = ops.amax(dfo)
+        qd = ops.split_planes_pair(dfo, amax_slot_=s_in)
+        ref = (dfo.double() @ w.double()) * torch.special.erf(h.double() / 2 ** 0.5).mul(0.5).add(0.5).add(
+            h.double() * torch.exp(-0.5 * h.double() ** 2) / (2 * math.pi) ** 0.5)                # dfo w o gelu'(h)
+        scale = float((dfo.double().abs() @ w.double().abs()).max())
+        # measured path: fp32 result, its own scaled split
+        dh = torch.empty(M, N, device=dev)
+        cam = ops.amax_slot(dev)
+        ops.plane_gemm(qd, qwt, dh, epi=EPI_MUL_GELU_GRAD, C2=h, tile=128129, form=1, a_amax=s_in, c_amax=cam)
+        assert float((dh.double() - ref).abs().max()) <= 3e-6 * scale, sc
+        # bound path: planes straight from the epilogue
+        s_b = ops.amax_slot(dev)
+        cs = torch.zeros((N,), device=dev)
+        qh = ops.pair_empty(M, N, dev)
+        ops.plane_gemm(qd, qwt, None, epi=EPI_MUL_GELU_GRAD, C2=h, tile=128129, form=1, a_amax=s_in, out_pair=qh, q_ref_in=s_in, q_l1=l1,
+                       q_mul=1.13 * 1.01, q_ref_out=s_b, colsum_out=cs)
+        bound = float(s_b.view(torch.float32).max().item())
+        true_max = float(dh.abs().max())
+        assert bound >= true_max and bound <= 2.0 ** 12 * true_max, (bound, true_max)            # rigorous, and not absurdly loose
+        e = 13 - int(math.floor(math.log2(bound)))
+        assert torch.equal(qh.buf[0, :, :N].view(torch.float16), (dh * 2.0 ** e).half())          # hi plane = fp16(stored value * 2^e)
+        chk = ops.split_planes_pair(dh, amax_slot_=s_b)                                            # the scaled split of the fp32 result, same slot
+        assert torch.equal(qh.buf[:, :, :N], chk.buf[:, :, :N])
+        assert torch.allclose(cs.double() / sc, dh.double().sum(0) / sc, rtol=1e-5, atol=2e-4 * M ** 0.5)
+        # consumers with the bound as their scale: NT data gradient dh @ w2 and TN weight gradient dh^T xs
+        dx = torch.empty(M, 160, device=dev)
+        ops.plane_gemm(qh, ops.split_planes_pair(w2.t().contiguous()), dx, tile=128129, form=1, a_amax=s_b)
+        r2 = dh.double() @ w2.double()
+        assert float((dx.double() - r2).abs().max()) <= 3e-6 * float((dh.double().abs() @ w2.double().abs()).max()), sc
+        dw = torch.zeros(N, 64, device=dev)
+        ops.plane_gemm_grouped([(qh, ops.split_planes_pair(xs), dw)], trans=True, accumulate=True, form=1, a_amax=[s_b])
+        r3 = dh.double().t() @ xs.double()
+        assert float((dw.double() - r3).abs().max()) <= 3e-6 * float((dh.double().abs().t() @ xs.double().abs()).max()), sc
+    # the word follows the weights (library writes are seen through the weight epoch)
+    ops.scale_(w.view(-1), 2.0)
+    ops.bump_weight_epoch()
+    assert abs(float(ops.weight_col_l1max(w).view(torch.float32).item()) - float(w.abs().sum(0).max())) <= 1e-5 * float(w.abs().sum(0).max())
 
 
 def test_plane_gemm_pair_form_gradients_vs_fp64():

@@ -1,4 +1,4 @@
-# every rocprofv3 collection the committed profiles/ are made from, on one box:  gpurun -- bash tools/collect_profiles.sh ; python tools/make_profiles.py r03
+# every rocprofv3 collection the committed profiles/ are made from, on one box:  gpurun -- bash tools/collect_profiles.sh ; python tools/make_profiles.py r04
 cd /tmp && export TMPDIR=/tmp && cd $GRAFT_REPO_ROOT
 B="python bench.py --steps 3 --warmup 1 --no-cpu-baseline --no-amp-leg --no-h2d-leg"
 timeout 900 python bench.py --steps 20 --warmup 5 2>gpurun_out/bench_line.err | grep "^{" > gpurun_out/bench_line.json
@@ -12,6 +12,8 @@ timeout 600 python tools/gemm_bench.py --amp > gpurun_out/gemm_shapes_amp.txt 2>
 timeout 600 python tools/plane_gemm_bench.py > gpurun_out/plane_gemm_shapes.txt 2>&1
 timeout 600 python tools/conv3_bench.py 2>&1 | grep -v amdgpu.ids > gpurun_out/conv3_shapes.txt
 timeout 600 python tools/conv3_forms_bench.py 2>&1 | grep -v amdgpu.ids > gpurun_out/conv3_forms.txt
+timeout 600 python tools/conv3_pw_bench.py 2>&1 | grep -v amdgpu.ids > gpurun_out/conv3_pw.txt
+timeout 600 python tools/step_conv3_profile.py 2>/dev/null > gpurun_out/step_conv3.txt
 timeout 300 python tools/attn_bench.py 2>&1 | grep -v amdgpu.ids > gpurun_out/attn_shapes.txt
 rm -f gpurun_out/prof_amp/amp_kernel_trace.csv
 ls -la gpurun_out/prof_e gpurun_out/pmc_f gpurun_out/pmc_m | head -30; cut -c1-400 gpurun_out/bench_line.json

@@ -1,13 +1,13 @@
 #!/usr/bin/env python3
 """Summarise the rocprofv3 runs of gpurun_out/ into the committed profiles/ (names carry the round tag).
 
-    python tools/make_profiles.py [r03] [steps in the kernel trace = 23] [steps in the PMC traces = 7]
+    python tools/make_profiles.py [r04] [steps in the kernel trace = 23] [steps in the PMC traces = 7]
 
 expects (tools/collect_profiles.sh): gpurun_out/prof_e (kernel-trace + stats of `bench.py --steps 10 --warmup 3 --no-h2d-leg`),
 gpurun_out/pmc_f / pmc_w (FETCH_SIZE / WRITE_SIZE passes of `bench.py --steps 3 --warmup 1 --no-h2d-leg`), gpurun_out/pmc_m (SQ / GRBM
 pass of the same command), gpurun_out/gemm_shapes.txt, gpurun_out/bench_line.json"""
 import collections, csv, json, os, re, shutil, subprocess, sys
-TAG = sys.argv[1] if len(sys.argv) > 1 else "r03"
+TAG = sys.argv[1] if len(sys.argv) > 1 else "r04"
 NSTEP = int(sys.argv[2]) if len(sys.argv) > 2 else 23          # bench.py --steps 10 --warmup 3: 3 + 10 (headline) + 10 (roofline leg)
 NPMC = int(sys.argv[3]) if len(sys.argv) > 3 else 7            # bench.py --steps 3 --warmup 1: 1 + 3 + 3
 R = os.path.dirname(os.path.dirname(os.path.abspath(__file__))) + "/"
@@ -55,6 +55,17 @@ if os.path.exists(G + "pmc_f/f_counter_collection.csv") and os.path.exists(G + "
         lines.append(f"{k[0]:58s} grid {int(k[1]):>8d}  x{f[k][0] / NPMC:6.1f}  fetch {fm:8.1f} MB  write {wm:8.1f} MB  {f[k][2] / f[k][0]:8.1f} us")
         if is_roofline_launch("void vbg::" + k[0] + ("(vbg_plane_gemm_desc)" if "plane" in k[0] else "(vbg_gemm_desc)"), k[1]):
             nf += 2 * f[k][1] * 1024; nw += w[k][1] * 1024 if k in w else 0; n += f[k][0]
+    # the row-reuse 3x3 convolution launches (forward + input gradient): bench.py's primary `roofline` since round 4
+    cf = cw = cn = 0
+    for k in f:
+        if k[0].startswith("conv3x3_kernel<"):
+            cf += 2 * f[k][1] * 1024; cw += w[k][1] * 1024 if k in w else 0; cn += f[k][0]
+    if cn:
+        json.dump({"kernel": "conv3x3_kernel<*,*,*,*> (every row-reuse 3x3 convolution launch of one bench step, forward + input gradient: the launches bench.py's `roofline` times)",
+                   "launches_per_step": cn / NPMC, "fetch_bytes_per_launch": cf / cn, "write_bytes_per_launch": cw / cn, "bytes_per_launch": (cf + cw) / cn,
+                   "source": "profiles/" + TAG + "_gemm_hbm_traffic.txt (rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE, separate passes; FETCH_SIZE x2 gfx950 correction; L2 misses incl. Infinity-Cache hits)"},
+                  open(P + "conv3_hbm_traffic.json", "w"), indent=1)
+        lines.append(f"# row-reuse 3x3 convolution launches (forward + input gradient): {cn / NPMC:.0f} launches/step, fetch {cf / cn / 1e6:.1f} MB + write {cw / cn / 1e6:.1f} MB per launch")
     tot_f = sum(2 * v[1] * 1024 for v in f.values()) / NPMC
     tot_w = sum(v[1] * 1024 for v in w.values()) / NPMC
     lines.append(f"# all matrix-core launches: fetch {tot_f / 1e9:.1f} GB + write {tot_w / 1e9:.1f} GB per step (round 1: 45.1 + 12.6 GB; before the XCD-aware block->tile map 112.7 GB fetched)")
@@ -128,7 +139,7 @@ for r in rows:
         pair = re.search(r", 1>\(", nme) is not None
         key = "plane GEMM TN (dense wgrad)" if tn else ("plane GEMM NT, fp16-pair form (QKV / FFN1 / FFN2 forward, data gradients)" if pair else "plane GEMM NT, bf16x3 form (attention out)")
     elif "conv3x3_wgrad" in nme or "conv3_wgrad_reduce" in nme: key = "conv wgrad, row-reuse kernel (conv3.hip)"
-    elif "conv3x3_kernel" in nme or "conv3_wflip" in nme: key = "conv fwd + dgrad, row-reuse kernel (conv3.hip)"
+    elif "conv3x3_kernel" in nme or "conv3_wflip" in nme or "conv3_wprep" in nme: key = "conv fwd + dgrad, row-reuse kernel (conv3.hip)"
     elif "gemm_kernel" in nme:
         m = re.search(r"256, (\d), (\d)", nme)
         key = {("0", "0"): "dense NT in-kernel split (1x1, heads, stem)", ("0", "1"): "dense NN (dgrad)", ("1", "1"): "dense TN (wgrad)", ("2", "0"): "conv fwd",
@@ -144,11 +155,21 @@ for r in rows:
 summary = [f"kernel ms/step {tot:.2f}"] + [f"{k:44s} {v:6.2f} ms {100 * v / tot:5.1f} %" for k, v in sorted(cat.items(), key=lambda kv: -kv[1])]
 open(P + "step_breakdown.txt", "w").write("# kernel time per step by category, from " + TAG + "_bench_kernel_stats.csv (rocprofv3 --kernel-trace --stats)\n" + "\n".join(summary) + "\n")
 print("\n".join(summary))
-tw = tn = 0.0
-for r in rows:
-    if is_roofline_launch(r["Name"], None):
-        print(short(r["Name"])[:70], int(r["Calls"]) // NSTEP, round(float(r["AverageNs"]) / 1e3, 1))
-        tw += float(r["TotalDurationNs"]); tn += int(r["Calls"])
-if tn:
-    print(f"roofline launches: {tn / NSTEP:.0f} per step, average {tw / tn / 1e3:.1f} us (rocprofv3)")
+# ---- agreement of bench.py's live event timing with the kernel trace (generated, never hand-written: VERDICT r3) ------------------------
+line = json.loads(open(P + "bench_line.json").read().strip().splitlines()[-1])
+agr = ["# agreement check of bench.py's roofline objects with rocprofv3's kernel trace (tools/make_profiles.py; both runs on one box, the",
+       "# bench line WITHOUT the profiler, the trace with it: profiled launches run a few per cent slower, MI355X_MICROARCH.md DVFS note)"]
+for fam, sel, key in (("row-reuse 3x3 convolutions (conv3x3_kernel, forward + input gradient)", lambda n: "conv3x3_kernel<" in n, "roofline"),
+                      ("ungrouped dense NT products (plane_gemm NT + gemm_kernel DENSE_K x DENSE_K)", lambda n: is_roofline_launch(n, None), "roofline_nt")):
+    tw = tn = 0.0
+    agr.append(f"{fam}:")
+    for r in rows:
+        if sel(r["Name"]):
+            agr.append(f"    {short(r['Name'])[:84]:84s} x{int(r['Calls']) / NSTEP:6.1f} / step   {float(r['AverageNs']) / 1e3:8.1f} us")
+            tw += float(r["TotalDurationNs"]); tn += int(r["Calls"])
+    live = line.get(key) or {}
+    if tn:
+        agr.append(f"    kernel trace: {tn / NSTEP:.0f} launches per step, average {tw / tn / 1e3:.2f} us;  bench.py live ({key}): {live.get('launches', 0) / max(line.get('steps', 1), 1):.0f} launches per step, average {live.get('avg_us')} us")
+open(P + "agreement.txt", "w").write("\n".join(agr) + "\n")
+print("\n".join(agr))
 print(open(P + "bench_line.json").read()[:1500])

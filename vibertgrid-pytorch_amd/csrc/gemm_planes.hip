@@ -467,6 +467,17 @@ __global__ __launch_bounds__(WGM * WGN * 64) void plane_gemm_kernel(const vbg_pl
     unsigned short* const Cp = p.Cp;
     unsigned short* const Cq = p.Cq;                 // optional fp16-pair planes of the stored value [2][M][ldq]
     float vmax = 0.f;                                // max |stored value| of this thread (p.c_amax)
+    // Cq of a GRADIENT (cq_ref_in): scaled by the power of two of a rigorous bound of the stored values, max |A| * max row-L1 of B *
+    // cq_mul -- every workgroup derives the same bound from the same two device words; one thread publishes its bit pattern for the
+    // consumers (their a_amax)
+    float qsc = 1.f;
+    if (Cq && p.cq_ref_in) {                         // (uniform)
+        const float amx = __uint_as_float(vbg_amax_read(p.cq_ref_in));
+        const float l1 = p.cq_l1_in ? __uint_as_float(*p.cq_l1_in) : 1.f;
+        const float bound = amx * l1 * p.cq_mul;
+        qsc = vbg_pow2_scale(__float_as_uint(bound)).x;
+        if (p.cq_ref_out && pid == 0 && tid == 0) p.cq_ref_out[0] = __float_as_uint(bound);
+    }
 #pragma unroll
     for (int q = 0; q < BM * QN / NT; ++q) {
         const int idx = tid + q * NT;
@@ -518,8 +529,8 @@ __global__ __launch_bounds__(WGM * WGN * 64) void plane_gemm_kernel(const vbg_pl
         if (Cq) {
             unsigned short* o = Cq + (long long)gm * p.ldq + gn;
             uint2 h, l;
-            pg_split2(v.x, v.y, h.x, l.x);
-            pg_split2(v.z, v.w, h.y, l.y);
+            pg_split2(v.x * qsc, v.y * qsc, h.x, l.x);
+            pg_split2(v.z * qsc, v.w * qsc, h.y, l.y);
             *reinterpret_cast<uint2*>(o) = h;
             *reinterpret_cast<uint2*>(o + p.q_plane) = l;
         }
@@ -1139,6 +1150,18 @@ __global__ __launch_bounds__(256) void split_planes_pair_kernel(const float* __r
 
 // x [rows][cols] fp32 -> TRANSPOSED planes [3][cols][ldp] bf16 with ldp >= rows (multiple of 32), entries rows..ldp-1 zero:
 // out[q][c][r] = piece_q(x[r][c]).  64 x 64 tiles through LDS.
+// out[matrix] = max over columns of sum over rows |w[r][c]| (bit pattern, atomicMax: floats >= 0 order like their bits)
+__global__ __launch_bounds__(256) void col_l1_max_kernel(const vbg_l1_entry* __restrict__ tab, unsigned* __restrict__ out) {
+    const vbg_l1_entry e = tab[blockIdx.y];
+    const int c = blockIdx.x * 256 + threadIdx.x;
+    float s = 0.f;
+    if (c < e.cols)
+        for (int r = 0; r < e.rows; ++r) s += fabsf(e.w[(long long)r * e.ld + c]);
+    __shared__ float sh[16];
+    s = block_max(s, sh);
+    if (threadIdx.x == 0 && blockIdx.x * 256 < e.cols) atomicMax(out + blockIdx.y, __float_as_uint(s));
+}
+
 __global__ __launch_bounds__(256) void split_planes_t_kernel(const float* __restrict__ x, long long ldx, int rows, int cols,
                                                               unsigned short* __restrict__ out, int ldp, long long plane) {
     __shared__ float t[64][65];
@@ -1298,7 +1321,9 @@ static int plane_gemm_dispatch(const vbg_plane_gemm_desc* desc, void* stream, vo
         d.a_plane = d.grp[0].a_plane; d.b_plane = d.grp[0].b_plane; d.lda = d.grp[0].lda; d.ldb = d.grp[0].ldb; d.ldc = d.grp[0].ldc;
         if (!d.trans && d.tile != 64064) d.tile = 128129;
     }
-    VBG_CHECK_ARG(d.A && d.B && (d.C || d.Cp));
+    VBG_CHECK_ARG(d.A && d.B && (d.C || d.Cp || d.Cq));
+    // bound-scaled Cq: the epilogue of the 8-wave NT tiles only (as for c_amax)
+    if (d.cq_ref_in) VBG_CHECK_ARG(d.Cq && d.cq_mul > 0.f && d.tile != 256256 && !(d.sk_ws && d.sk_cnt) && !d.trans && d.ngroups == 0 && d.splitk == 1);
     VBG_CHECK_ARG(d.M >= 0 && d.N >= 0 && d.K > 0);
     if (d.trans) VBG_CHECK_ARG(d.lda % 32 == 0 && d.ldb % 32 == 0 && d.lda >= d.M && d.ldb >= d.N);
     else VBG_CHECK_ARG(d.K % 32 == 0 && d.lda % 8 == 0 && d.ldb % 8 == 0 && d.lda >= d.K && d.ldb >= d.K);
@@ -1456,6 +1481,14 @@ extern "C" int vbg_split_planes_pair(const float* x, long long ldx, int rows, in
         g = 256 * 16;
     }
     VBG_LAUNCH(split_planes_pair_kernel, dim3((unsigned)g), dim3(256), lds, (hipStream_t)stream, x, ldx, rows, cols, out, ldp, plane, amax, colsum_accum);
+    VBG_LAUNCH_RET();
+}
+
+extern "C" int vbg_col_l1_max(const vbg_l1_entry* table_dev, int n, int max_cols, unsigned* out, void* stream) {
+    VBG_CHECK_ARG(n >= 0 && max_cols >= 0);
+    if (n == 0 || max_cols == 0) return VBG_OK;
+    VBG_CHECK_ARG(table_dev && out);
+    VBG_LAUNCH(col_l1_max_kernel, dim3((unsigned)((max_cols + 255) / 256), (unsigned)n), dim3(256), 0, (hipStream_t)stream, table_dev, out);
     VBG_LAUNCH_RET();
 }
 

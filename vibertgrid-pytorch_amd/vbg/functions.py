@@ -239,7 +239,7 @@ class SegLinearFn(torch.autograd.Function):
 
 
 # ----------------------------------------------------------------------------------------------
-def _conv_any(x, w4, stride, pad, bias=None, want_stats=False, w_owner=None):
+def _conv_any(x, w4, stride, pad, bias=None, want_stats=False, w_owner=None, x_amax=None):
     """x NHWC; w4 = OHWI weight.  Cin=3 stem goes through im2col (K=147, row stride 148).
     want_stats: -> third result = BatchNorm slot workspace holding the output's column sums / sums of squares (fused into the GEMM
     epilogue), or None when the product is one the library may split (the caller then runs ops.bn_stats)."""
@@ -254,7 +254,7 @@ def _conv_any(x, w4, stride, pad, bias=None, want_stats=False, w_owner=None):
         out = torch.empty((B, Ho, Wo, Cout), device=x.device, dtype=f32)
         ops.gemm_raw(B * Ho * Wo, Cout, K, col, Kp, OP_DENSE_K, w4, K, OP_DENSE_K, out, Cout, bias=bias, stats=stats)
         return out, col, stats
-    return ops.conv2d_fwd(x, w4, stride, pad, bias, stats=stats, w_owner=w_owner), None, stats
+    return ops.conv2d_fwd(x, w4, stride, pad, bias, stats=stats, w_owner=w_owner, x_amax=x_amax), None, stats
 
 
 def _conv_wgrad_any(dy, x, col, w4_shape, stride, pad, w_param=None, dy_amax=None, x_amax=None):
@@ -294,7 +294,7 @@ class ConvFn(torch.autograd.Function):
         ctx.x_amax = _amax_tag(x)                         # the producer's word with the bits of max |x| (see ConvBnFn), if any
         x = _c(x)
         w4 = ohwi(w)
-        y, col, _ = _conv_any(x, w4, stride, pad, b, w_owner=w)
+        y, col, _ = _conv_any(x, w4, stride, pad, b, w_owner=w, x_amax=ctx.x_amax)
         ctx.stride, ctx.pad, ctx.has_bias = stride, pad, b is not None
         ctx.w_ref, ctx.b_ref = w, b
         ctx.save_for_backward(x, w4, col)
@@ -340,7 +340,7 @@ class ConvBnFn(torch.autograd.Function):
         x = _c(x)
         sync = bool(sync) and SyncCtx.active()
         w4 = ohwi(w)
-        z, col, stats = _conv_any(x, w4, stride, pad, want_stats=training, w_owner=w)
+        z, col, stats = _conv_any(x, w4, stride, pad, want_stats=training, w_owner=w, x_amax=ctx.x_amax)
         C = z.shape[-1]
         z2 = z.view(-1, C)
         M = z2.shape[0]
@@ -739,14 +739,22 @@ class BertLayerFn(torch.autograd.Function):
         qdfo = ops.split_planes_pair(dfo, amax_slot_=s_dfo, colsum_out=wgrad_dest(rbo2))
         wgrad_done(rbo2)
         del dfo
-        # ---- dL/dh = (dfo Wo2) o gelu'(h): fp32 out of the product's epilogue with its largest magnitude, then its own split
+        # ---- dL/dh = (dfo Wo2) o gelu'(h) leaves the product's epilogue as pair planes (round 4): scaled by the power of two of a rigorous
+        #      BOUND -- max |dfo| (measured: s_dfo) * the largest column L1 norm of Wo2 (once per weight version) * max gelu' (1.129) -- instead
+        #      of a measured maximum, so it needs no fp32 round trip and no split pass; s_dh receives the bound (the consumers' scale)
         s_dh = ops.amax_slot(dev)
-        dh_ = torch.empty((ntok, inter), device=dev, dtype=f32)
-        ops.plane_gemm(qdfo, ops.weight_planes(ro2, True, view=wo2, pair=True), dh_, epi=EPI_MUL_GELU_GRAD, C2=h, tile=tile(inter, True), form=1,
-                       a_amax=s_dfo, c_amax=s_dh)
-        qdh = ops.split_planes_pair(dh_, amax_slot_=s_dh, colsum_out=wgrad_dest(rbi))
+        if ops.bound_planes_enabled():
+            qdh = ops.pair_empty(ntok, inter, dev)
+            ops.plane_gemm(qdfo, ops.weight_planes(ro2, True, view=wo2, pair=True), None, epi=EPI_MUL_GELU_GRAD, C2=h, tile=tile(inter, True), form=1,
+                           a_amax=s_dfo, out_pair=qdh, q_ref_in=s_dfo, q_l1=ops.weight_col_l1max(ro2, view=wo2), q_mul=1.13 * 1.01, q_ref_out=s_dh,
+                           colsum_out=wgrad_dest(rbi))
+        else:
+            dh_ = torch.empty((ntok, inter), device=dev, dtype=f32)
+            ops.plane_gemm(qdfo, ops.weight_planes(ro2, True, view=wo2, pair=True), dh_, epi=EPI_MUL_GELU_GRAD, C2=h, tile=tile(inter, True), form=1,
+                           a_amax=s_dfo, c_amax=s_dh)
+            qdh = ops.split_planes_pair(dh_, amax_slot_=s_dh, colsum_out=wgrad_dest(rbi))
+            del dh_
         wgrad_done(rbi)
-        del dh_
         ops.plane_gemm(qdh, ops.weight_planes(ri, True, view=wi, pair=True), dx1, accumulate=True, tile=tile(hid), form=1, a_amax=s_dh)
         # ---- LayerNorm 1 backward -> dao
         dg1, db1, sunk1 = _affine_dest(rg1, rb1)

@@ -53,7 +53,12 @@ class PlaneGemmDesc(C.Structure):
                 ("epi", c_int), ("alpha", c_f), ("accumulate", c_int), ("splitk", c_int), ("tile", c_int), ("trans", c_int),
                 ("ngroups", c_int), ("grp", PlaneGroup * 4),
                 ("sk_ws", c_vp), ("sk_cnt", c_vp), ("sk_blocks", c_int), ("sk_full", c_int), ("sk_tiles_m", c_int), ("sk_tiles_n", c_int),
-                ("colsum", c_vp), ("form", c_int), ("Cq", c_vp), ("q_plane", c_ll), ("ldq", c_ll), ("a_amax", c_vp), ("c_amax", c_vp)]
+                ("colsum", c_vp), ("form", c_int), ("Cq", c_vp), ("q_plane", c_ll), ("ldq", c_ll), ("a_amax", c_vp), ("c_amax", c_vp),
+                ("cq_ref_in", c_vp), ("cq_l1_in", c_vp), ("cq_mul", c_f), ("cq_ref_out", c_vp)]
+
+
+class L1Entry(C.Structure):                  # include/vbg.h vbg_l1_entry
+    _fields_ = [("w", c_vp), ("ld", c_ll), ("rows", c_int), ("cols", c_int)]
 
 
 class AttnDesc(C.Structure):
@@ -81,6 +86,7 @@ SIGNATURES = {
     "vbg_plane_gemm": (c_int, [C.POINTER(PlaneGemmDesc), c_vp]),
     "vbg_plane_gemm_timed": (c_int, [C.POINTER(PlaneGemmDesc), c_vp, c_vp, c_vp]),
     "vbg_split_planes": (c_int, [c_vp, c_ll, c_int, c_int, c_vp, c_int, c_ll, c_int, c_vp, c_vp]),
+    "vbg_col_l1_max": (c_int, [c_vp, c_int, c_int, c_vp, c_vp]),
     "vbg_split_planes_pair": (c_int, [c_vp, c_ll, c_int, c_int, c_vp, c_int, c_ll, c_vp, c_vp, c_vp]),
     "vbg_split_planes_t": (c_int, [c_vp, c_ll, c_int, c_int, c_vp, c_int, c_ll, c_vp]),
     "vbg_split_planes_t_batched": (c_int, [c_vp, c_vp, c_vp, c_int, c_int, c_ll, c_vp]),

@@ -245,6 +245,14 @@ def set_pair_bwd(on: bool):
     _PAIR_BWD[0] = bool(on)
 
 
+_BOUND_PLANES = [os.environ.get("VBG_BOUND_PLANES", "1") != "0"]
+
+
+def bound_planes_enabled() -> bool:
+    """gradient pair planes straight from the producing GEMM's epilogue, scaled by a bound instead of a measured maximum (no split pass)"""
+    return _BOUND_PLANES[0]
+
+
 def pair_bwd_enabled() -> bool:
     return pair_enabled() and _PAIR_BWD[0]
 
@@ -279,7 +287,8 @@ def split_planes_t(x, out=None):
 
 
 def plane_gemm(a: Planes, b: Planes, out=None, *, bias=None, epi=EPI_NONE, C2=None, accumulate=False, splitk=1, alpha=1.0, tile=0,
-               out_planes=None, ldc=None, trans=False, colsum_out=None, form=0, out_pair=None, a_amax=None, c_amax=None):
+               out_planes=None, ldc=None, trans=False, colsum_out=None, form=0, out_pair=None, a_amax=None, c_amax=None,
+               q_ref_in=None, q_l1=None, q_mul=1.0, q_ref_out=None):
     """out[M, N] (+)= alpha * a[M, K] b[N, K]^T (+ bias).  out_planes: Planes [M, N] that receive the split of the stored value.
     trans: out[Ma, Nb] (+)= alpha * a[K, Ma]^T b[K, Nb] (the operands' ROWS are the reduction index: weight gradients)."""
     d = PlaneGemmDesc()
@@ -310,6 +319,10 @@ def plane_gemm(a: Planes, b: Planes, out=None, *, bias=None, epi=EPI_NONE, C2=No
         d.c_amax = c_amax.data_ptr()
     if out_pair is not None:               # the stored value also as fp16-pair planes
         d.Cq, d.q_plane, d.ldq = out_pair.buf.data_ptr(), out_pair.plane, out_pair.ld
+        if q_ref_in is not None:           # ... of a GRADIENT: scaled by the power of two of a bound (include/vbg.h cq_ref_in), not of a measured maximum
+            d.cq_ref_in, d.cq_mul = q_ref_in.data_ptr(), float(q_mul)
+            d.cq_l1_in = None if q_l1 is None else q_l1.data_ptr()
+            d.cq_ref_out = None if q_ref_out is None else q_ref_out.data_ptr()
     if colsum_out is not None:             # += column sums of the stored values (a bias gradient)
         d.colsum = colsum_out.data_ptr()
     if _DISPATCH[0] is not None:
@@ -816,6 +829,50 @@ def set_conv3_profiler(records):
     _CONV3_PROF[0] = records
 
 
+# ---- largest column L1 norm of weight matrices (the bound factor of a data gradient dY W, include/vbg.h cq_l1_in) -------------------------
+_WL1 = {"entries": [], "table": None, "host": None, "out": None, "maxc": 0}
+
+
+def weight_col_l1max(owner, view=None):
+    """one device word with the float bits of max_c sum_r |w[r][c]| of the 2-D weight `owner` (or of `view`, a matrix starting at it),
+    recomputed once per weight version for ALL registered matrices by one launch (+ one fill)"""
+    from .lib import L1Entry
+    import weakref
+    w = owner if view is None else view
+    assert w.dim() == 2 and w.stride(1) == 1
+    st = _WL1
+    slot = owner.__dict__.get("_vbg_l1")
+    tag = (_W_EPOCH[0], owner._version, w.data_ptr())
+    if slot is not None and slot["tag"] == tag:
+        return st["out"][slot["idx"]:slot["idx"] + 1]
+    if slot is None or slot["ptr"] != w.data_ptr():
+        slot = {"idx": -1, "tag": None, "ptr": w.data_ptr(), "shape": tuple(w.shape), "ld": w.stride(0), "ref": weakref.ref(owner)}
+        owner.__dict__["_vbg_l1"] = slot
+        st["entries"].append(slot)
+        st["table"] = None
+    if any(e["ref"]() is None for e in st["entries"]):          # a model went away: its matrices leave the table (never read freed memory)
+        st["entries"] = [e for e in st["entries"] if e["ref"]() is not None]
+        st["table"] = None
+    if st["table"] is None or st["out"] is None or st["table"].device != w.device:
+        n = len(st["entries"])
+        host = (L1Entry * n)()
+        for i, e in enumerate(st["entries"]):
+            e["idx"] = i
+            host[i].w, host[i].ld, host[i].rows, host[i].cols = e["ptr"], e["ld"], e["shape"][0], e["shape"][1]
+        st["host"] = host
+        st["table"] = h2d(torch.frombuffer(bytearray(bytes(host)), dtype=torch.uint8), w.device)
+        st["out"] = torch.zeros((max(n, 64),), device=w.device, dtype=torch.int32)
+        st["maxc"] = max(e["shape"][1] for e in st["entries"])
+    else:
+        st["out"].zero_()
+    check(lib.vbg_col_l1_max(P(st["table"]), len(st["entries"]), st["maxc"], P(st["out"]), _stream()), "vbg_col_l1_max")
+    for e in st["entries"]:
+        o = e["ref"]()
+        if o is not None:
+            e["tag"] = (_W_EPOCH[0], o._version, e["ptr"])
+    return st["out"][slot["idx"]:slot["idx"] + 1]
+
+
 # ---- pre-split filter images for the PW form of the row-reuse kernels (csrc/conv3.hip conv3_wprep_kernel) ------------------------------
 _CONV3_PW = [os.environ.get("VBG_CONV3_PW", "1") != "0"]
 _C3PW = {"entries": [], "table": None, "host": None, "n": 0}
@@ -939,7 +996,7 @@ def conv3x3_wgrad(dy, x, dw_ohwi, slabs=True, f16x2=False, dy_amax=None, x_amax=
     return dw_ohwi
 
 
-def conv2d_fwd(x, w_ohwi, stride, pad, bias=None, out=None, stats=None, w_owner=None):
+def conv2d_fwd(x, w_ohwi, stride, pad, bias=None, out=None, stats=None, w_owner=None, x_amax=None):
     """x NHWC [B,H,W,Cin] contiguous; w_ohwi [Cout,kh,kw,Cin] contiguous -> y NHWC [B,Ho,Wo,Cout]."""
     _chk_f32(x, w_ohwi, bias)
     B, H, W, Cin = x.shape
@@ -951,7 +1008,10 @@ def conv2d_fwd(x, w_ohwi, stride, pad, bias=None, out=None, stats=None, w_owner=
     M, K = B * Ho * Wo, kh * kw * Cin
     if conv3_ok(B, H, W, Cin, Cout, kh, kw, stride, pad, fwd=True):
         wp = conv3_planes(w_owner, w_ohwi, False) if (_CONV3_F16[0] and conv3_pw_ok(B, H, W, Cin, Cout)) else None
-        return conv3x3(x, w_ohwi, bias, out, stats, f16x2=_CONV3_F16[0], w_planes=wp)
+        # x_amax: the producer's amax slot of the activation, when it published one (bn_apply in a training step).  The fp16 form then
+        # scales x by the power of two that centres its largest magnitude in fp16's range, like a gradient operand: an activation of
+        # 65520 or more no longer becomes inf, and small activations keep more bits -- exact either way
+        return conv3x3(x, w_ohwi, bias, out, stats, f16x2=_CONV3_F16[0], w_planes=wp, x_amax=x_amax if _CONV3_F16[0] else None)
     if kh == 1 and kw == 1 and stride == 1 and pad == 0:
         gemm_raw(M, Cout, K, x, Cin, OP_DENSE_K, w_ohwi, K, OP_DENSE_K, out, Cout, bias=bias, stats=stats)
     else:
