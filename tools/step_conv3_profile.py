@@ -26,7 +26,7 @@ def w1(x, w, *a, **k):
     e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
     e0.record(); r = o1(x, w, *a, **k); e1.record()
     B, H, W, C = x.shape
-    kind = "dgrad" if (k.get("x_amax") is not None or (len(a) > 3 and a[3])) else "fwd/dgrad"
+    kind = "dgrad" if (k.get("n_out") is not None or (len(a) > 3 and a[3])) else "fwd"          # (the PW input gradient passes n_out)
     recs.append((f"{kind:9s} B{B} {H}x{W} {C}->{w.shape[0]} f16={int(bool(k.get('f16x2')))}", 2.0 * B * H * W * C * w.shape[0] * 9, e0, e1))
     return r
 def w2(dy, x, dw, *a, **k):
