@@ -1150,16 +1150,42 @@ __global__ __launch_bounds__(256) void split_planes_pair_kernel(const float* __r
 
 // x [rows][cols] fp32 -> TRANSPOSED planes [3][cols][ldp] bf16 with ldp >= rows (multiple of 32), entries rows..ldp-1 zero:
 // out[q][c][r] = piece_q(x[r][c]).  64 x 64 tiles through LDS.
-// out[matrix] = max over columns of sum over rows |w[r][c]| (bit pattern, atomicMax: floats >= 0 order like their bits)
+// out[matrix] = max over columns of sum over rows |w[r][c]| (bit pattern, atomicMax: floats >= 0 order like their bits).  A block =
+// 64 columns (16 lanes x float4) x 16 row groups; the row groups meet in LDS.  (First version: one thread per column walking all rows,
+// 144 blocks -> 278 us per launch; this one reads the 113 MB of the twelve bert-base matrices at HBM speed.)
 __global__ __launch_bounds__(256) void col_l1_max_kernel(const vbg_l1_entry* __restrict__ tab, unsigned* __restrict__ out) {
     const vbg_l1_entry e = tab[blockIdx.y];
-    const int c = blockIdx.x * 256 + threadIdx.x;
-    float s = 0.f;
-    if (c < e.cols)
-        for (int r = 0; r < e.rows; ++r) s += fabsf(e.w[(long long)r * e.ld + c]);
-    __shared__ float sh[16];
-    s = block_max(s, sh);
-    if (threadIdx.x == 0 && blockIdx.x * 256 < e.cols) atomicMax(out + blockIdx.y, __float_as_uint(s));
+    const int c0 = blockIdx.x * 64;
+    if (c0 >= e.cols) return;
+    const int tx = threadIdx.x & 15, ty = threadIdx.x >> 4;
+    const int c = c0 + tx * 4;
+    const bool vec = (e.ld & 3) == 0 && ((((uintptr_t)e.w) & 15) == 0) && c + 4 <= e.cols;
+    float4 s = make_float4(0.f, 0.f, 0.f, 0.f);
+#pragma unroll 4
+    for (int r = ty; r < e.rows; r += 16) {
+        const float* p = e.w + (long long)r * e.ld + c;
+        if (vec) {
+            const float4 v = *reinterpret_cast<const float4*>(p);
+            s.x += fabsf(v.x); s.y += fabsf(v.y); s.z += fabsf(v.z); s.w += fabsf(v.w);
+        } else {
+            if (c < e.cols) s.x += fabsf(p[0]);
+            if (c + 1 < e.cols) s.y += fabsf(p[1]);
+            if (c + 2 < e.cols) s.z += fabsf(p[2]);
+            if (c + 3 < e.cols) s.w += fabsf(p[3]);
+        }
+    }
+    __shared__ float4 red[16][16];
+    red[ty][tx] = s;
+    __syncthreads();
+    if (ty == 0) {
+        float4 t = red[0][tx];
+#pragma unroll
+        for (int g = 1; g < 16; ++g) { const float4 v = red[g][tx]; t.x += v.x; t.y += v.y; t.z += v.z; t.w += v.w; }
+        float m = fmaxf(fmaxf(t.x, t.y), fmaxf(t.z, t.w));
+#pragma unroll
+        for (int o = 8; o > 0; o >>= 1) m = fmaxf(m, __shfl_xor(m, o, 64));
+        if (tx == 0) atomicMax(out + blockIdx.y, __float_as_uint(m));
+    }
 }
 
 __global__ __launch_bounds__(256) void split_planes_t_kernel(const float* __restrict__ x, long long ldx, int rows, int cols,
@@ -1488,7 +1514,7 @@ extern "C" int vbg_col_l1_max(const vbg_l1_entry* table_dev, int n, int max_cols
     VBG_CHECK_ARG(n >= 0 && max_cols >= 0);
     if (n == 0 || max_cols == 0) return VBG_OK;
     VBG_CHECK_ARG(table_dev && out);
-    VBG_LAUNCH(col_l1_max_kernel, dim3((unsigned)((max_cols + 255) / 256), (unsigned)n), dim3(256), 0, (hipStream_t)stream, table_dev, out);
+    VBG_LAUNCH(col_l1_max_kernel, dim3((unsigned)((max_cols + 63) / 64), (unsigned)n), dim3(256), 0, (hipStream_t)stream, table_dev, out);
     VBG_LAUNCH_RET();
 }
 
