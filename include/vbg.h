@@ -286,11 +286,14 @@ typedef struct vbg_conv3_wprep_entry {
     void* out;
     int Cout, Cin, flip, bn;
 } vbg_conv3_wprep_entry;
-long long vbg_conv3x3_wprep_bytes(int Cout, int Cin, int flip);
+long long vbg_conv3x3_wprep_bytes(int Cout, int Cin, int flip, int bn);
 int vbg_conv3x3_wprep(const vbg_conv3_wprep_entry* table_dev, const vbg_conv3_wprep_entry* table_host, int n, void* stream);
 int vbg_conv3x3_pw(const float* x, const void* w_planes, const float* bias, float* y, double* stats, int stats_slots, int B, int H, int W,
                    int Cs, int N, int accumulate, const unsigned* x_amax, float* split_slab, unsigned* split_tickets, int nsplit,
-                   void* stream);
+                   int bn, void* stream);
+/* bn (vbg_conv3x3_pw / vbg_conv3x3_wprep_bytes): filters per tile the image was written for -- 0: the library's rule above; 64 / 128: the
+ * caller's choice (64-filter tiles double the tile count of a launch: the late trunk stages, whose 128-filter tiles do not fill the chip);
+ * the launch then runs 128-pixel tiles whatever the tile count, and nsplit > 1 needs N % bn == 0 (slabs of 128 * bn floats). */
 
 /* weight gradient of that convolution: dw[Cout,3,3,Cs] += sum over pixels dy[B,H,W,Cout]^T * shifted x[B,H,W,Cs] (csrc/conv3.hip:
  * operands stay [pixel][channel] in LDS, fragments through transposing LDS reads, one load + split of x serves all nine taps).

@@ -55,11 +55,11 @@ def test_conv3_host_logic_without_a_gpu():
     assert L.lib.vbg_conv3x3_wflip(None, 1, 1, None, None) == -1
     # pre-split filter images (round 4): byte counts of the k-tile-ordered plane image, argument errors without a launch
     nb = L.lib.vbg_conv3x3_wprep_bytes
-    assert nb(256, 256, 0) == 256 * 256 * 9 * 4 and nb(64, 64, 1) == 64 * 64 * 9 * 4          # 4 bytes per element, like the fp32 filter
-    assert nb(132, 16, 0) == 2 * 9 * 1 * 64 * 128                                             # rows padded to whole filter tiles
-    assert nb(128, 24, 0) == 0 and nb(24, 128, 1) == 0                                         # reduction width must be a multiple of 16
+    assert nb(256, 256, 0, 0) == 256 * 256 * 9 * 4 and nb(64, 64, 1, 0) == 64 * 64 * 9 * 4 and nb(256, 256, 0, 64) == 256 * 256 * 9 * 4          # 4 bytes per element, like the fp32 filter
+    assert nb(132, 16, 0, 0) == 2 * 9 * 1 * 64 * 128                                             # rows padded to whole filter tiles
+    assert nb(128, 24, 0, 0) == 0 and nb(24, 128, 1, 0) == 0 and nb(128, 32, 0, 96) == 0                                         # reduction width must be a multiple of 16
     assert L.lib.vbg_conv3x3_wprep(None, None, 1, None) == -1 and L.lib.vbg_conv3x3_wprep(None, None, 0, None) == 0
-    assert L.lib.vbg_conv3x3_pw(None, None, None, None, None, 0, 1, 16, 128, 16, 128, 0, None, None, None, 1, None) == -1
+    assert L.lib.vbg_conv3x3_pw(None, None, None, None, None, 0, 1, 16, 128, 16, 128, 0, None, None, None, 1, 0, None) == -1
 
 
 def test_gemm_desc_layout_matches_header():

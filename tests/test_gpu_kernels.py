@@ -342,6 +342,18 @@ def test_conv3x3_presplit_filter(ops, B, H, W, Cs, N, nz):
             d0 = ops.conv3x3(gy, ops.conv3x3_wflip(w4), f16x2=True, x_amax=am, nsplit=nzb)
             d1 = ops.conv3x3(gy, w4, f16x2=True, x_amax=am, nsplit=nzb, w_planes=wpf, n_out=Cs)
             assert torch.equal(d0, d1)
+    # 64-filter tiles by the caller's choice (the late trunk stages: twice the tiles), its own image, any split the shape allows
+    if N % 64 == 0 and H != 7 and (H * W) % 128 == 0:
+        wp64 = ops.conv3_planes(wd, w4, False, bn=64)
+        assert wp64 is not None and wp64.data_ptr() != wp.data_ptr()
+        for z in (1, nz):
+            if z > 1 and N % 64:
+                continue
+            y64 = ops.conv3x3(xh, w4, bh, f16x2=True, nsplit=z, w_planes=wp64, bn=64)
+            assert close(y64, ref, 2e-5, 3e-6 * float(ref.abs().max())), z
+            assert torch.equal(y64, ops.conv3x3(xh, w4, bh, f16x2=True, nsplit=z, w_planes=wp64, bn=64))
+        if nz == 1:
+            assert torch.equal(ops.conv3x3(xh, w4, bh, f16x2=True, nsplit=1, w_planes=wp64, bn=64), y0)     # (same pieces, products, order)
     # the images follow the weights: torch's version counter ...
     with torch.no_grad():
         wd.mul_(2.0)

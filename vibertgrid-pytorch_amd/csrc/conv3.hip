@@ -1052,10 +1052,10 @@ extern "C" int vbg_conv3x3_split(int B, int H, int W, int Cs, int N) {
 // rows per filter tile of the plane image of a filter with `rows` output rows (vbg_conv3x3_wprep / vbg_conv3x3_pw agree on it)
 static int conv3_pw_bn(int rows) { return (rows % 128 != 0 && rows % 64 == 0) ? 64 : 128; }
 
-extern "C" long long vbg_conv3x3_wprep_bytes(int Cout, int Cin, int flip) {
+extern "C" long long vbg_conv3x3_wprep_bytes(int Cout, int Cin, int flip, int bn_req) {
     const int rows = flip ? Cin : Cout, K = flip ? Cout : Cin;
-    if (rows <= 0 || K <= 0 || K % 16 != 0) return 0;
-    const int bn = conv3_pw_bn(rows);
+    if (rows <= 0 || K <= 0 || K % 16 != 0 || !(bn_req == 0 || bn_req == 64 || bn_req == 128)) return 0;
+    const int bn = bn_req ? bn_req : conv3_pw_bn(rows);
     return (long long)((rows + bn - 1) / bn) * 9 * (K / 16) * 64 * bn;
 }
 
@@ -1066,7 +1066,7 @@ extern "C" int vbg_conv3x3_wprep(const vbg_conv3_wprep_entry* table_dev, const v
     for (int i = 0; i < n; ++i) {
         const vbg_conv3_wprep_entry& e = table_host[i];
         const int rows = e.flip ? e.Cin : e.Cout, K = e.flip ? e.Cout : e.Cin;
-        VBG_CHECK_ARG(e.w && e.out && rows > 0 && K > 0 && K % 16 == 0 && e.Cin % 8 == 0 && e.bn == conv3_pw_bn(rows));
+        VBG_CHECK_ARG(e.w && e.out && rows > 0 && K > 0 && K % 16 == 0 && e.Cin % 8 == 0 && (e.bn == 64 || e.bn == 128));
         VBG_CHECK_ARG((((uintptr_t)e.w) & 15) == 0 && (((uintptr_t)e.out) & 15) == 0);
         const long long groups = (long long)((rows + e.bn - 1) / e.bn) * 9 * (K / 16) * e.bn * 2;
         most = groups > most ? groups : most;
@@ -1078,7 +1078,7 @@ extern "C" int vbg_conv3x3_wprep(const vbg_conv3_wprep_entry* table_dev, const v
 
 static int conv3x3_impl(const float* x, const float* w, const unsigned short* wp, const float* bias, float* y, double* stats, int stats_slots,
                         int B, int H, int W, int Cs, int N, int accumulate, int form, const unsigned* x_amax, float* split_slab,
-                        unsigned* split_tickets, int nsplit, void* stream);
+                        unsigned* split_tickets, int nsplit, void* stream, int bn_req = 0);
 
 extern "C" int vbg_conv3x3(const float* x, const float* w, const float* bias, float* y, double* stats, int stats_slots, int B, int H,
                            int W, int Cs, int N, int accumulate, int form, const unsigned* x_amax, float* split_slab,
@@ -1089,16 +1089,17 @@ extern "C" int vbg_conv3x3(const float* x, const float* w, const float* bias, fl
 
 extern "C" int vbg_conv3x3_pw(const float* x, const void* w_planes, const float* bias, float* y, double* stats, int stats_slots, int B, int H,
                               int W, int Cs, int N, int accumulate, const unsigned* x_amax, float* split_slab, unsigned* split_tickets,
-                              int nsplit, void* stream) {
-    VBG_CHECK_ARG(w_planes && (((uintptr_t)w_planes) & 15) == 0);
+                              int nsplit, int bn, void* stream) {
+    VBG_CHECK_ARG(w_planes && (((uintptr_t)w_planes) & 15) == 0 && (bn == 0 || bn == 64 || bn == 128));
     return conv3x3_impl(x, nullptr, (const unsigned short*)w_planes, bias, y, stats, stats_slots, B, H, W, Cs, N, accumulate, 1, x_amax, split_slab,
-                        split_tickets, nsplit, stream);
+                        split_tickets, nsplit, stream, bn);
 }
 
 static int conv3x3_impl(const float* x, const float* w, const unsigned short* wp, const float* bias, float* y, double* stats, int stats_slots,
                         int B, int H, int W, int Cs, int N, int accumulate, int form, const unsigned* x_amax, float* split_slab,
-                        unsigned* split_tickets, int nsplit, void* stream) {
+                        unsigned* split_tickets, int nsplit, void* stream, int bn_req) {
     VBG_CHECK_ARG(form == 0 || form == 1);
+    VBG_CHECK_ARG(bn_req == 0 || wp);
     VBG_CHECK_ARG(!x_amax || form == 1);
     VBG_CHECK_ARG(x && (w || wp) && y && B > 0 && H > 0);
     const bool roi = H == 7 && W == 7;                          // [B, 7, 7, C] region maps: two images per 128-slot tile
@@ -1116,7 +1117,7 @@ static int conv3x3_impl(const float* x, const float* w, const unsigned short* wp
     a.M = (int)M; a.accumulate = accumulate; a.a_amax = x_amax; a.roi = roi ? B : 0;
     // split form: nsplit blocks per tile meet in split_slab [tiles][nsplit][128 * 128] / split_tickets [tiles] (zero; left zero)
     const bool split = nsplit > 1;
-    VBG_CHECK_ARG(nsplit >= 1 && (!split || (split_slab && split_tickets && !roi && N % 128 == 0 && ((long long)H * W) % 128 == 0)));
+    VBG_CHECK_ARG(nsplit >= 1 && (!split || (split_slab && split_tickets && !roi && N % (bn_req ? bn_req : 128) == 0 && ((long long)H * W) % 128 == 0)));
     a.ksplit = split && nsplit % 3 == 0 ? 3 : 1;
     a.csplit = split ? nsplit / a.ksplit : 1;
     a.slab = split_slab; a.tickets = split_tickets;
@@ -1124,13 +1125,14 @@ static int conv3x3_impl(const float* x, const float* w, const unsigned short* wp
     // filters per tile: 128, or 64 where the filter count is an odd multiple of 64 (the 64-channel stage)
     // 128-pixel tiles once they fill the chip (or the image does not divide into 64-pixel tiles any better), else 64-pixel tiles
     auto is_big = [&](int bn_) { return roi || (((long long)H * W) % 128 == 0 && ((M / 128) * vbg::cdiv(N, bn_) >= 240 || W >= 128)); };
-    const bool n64 = N % 128 != 0 && N % 64 == 0 && is_big(64);
+    // bn_req (PW launches): the caller's choice of filters per tile -- the plane image was written for it -- on 128-pixel tiles
+    const bool n64 = bn_req ? bn_req == 64 : (N % 128 != 0 && N % 64 == 0 && is_big(64));
     const int bn = n64 ? 64 : 128;
-    const bool big = split || is_big(bn);
+    const bool big = bn_req ? (roi || ((long long)H * W) % 128 == 0) : (split || is_big(bn));
     const dim3 g(roi ? (unsigned)((B + 1) / 2) : (unsigned)(M / (big ? 128 : 64)), (unsigned)vbg::cdiv(N, bn), (unsigned)nsplit);
     if (wp) {
         // the plane image was written for conv3_pw_bn(N) rows per filter tile: the launch must walk it with the same tile
-        VBG_CHECK_ARG(big && bn == conv3_pw_bn(N));
+        VBG_CHECK_ARG(big && (bn_req || bn == conv3_pw_bn(N)));
         // VBG_CONV3_PIPE=0: the lockstep k-loop of the PW kernels (A/B switch of the software-pipelined loop)
         static const bool pipe = !(getenv("VBG_CONV3_PIPE") && atoi(getenv("VBG_CONV3_PIPE")) == 0);
         if (pipe) {

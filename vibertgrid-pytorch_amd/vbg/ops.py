@@ -762,7 +762,7 @@ def _conv3_tickets(device, tiles):
     return t
 
 
-def conv3x3(x, w_ohwi, bias=None, out=None, stats=None, accumulate=False, f16x2=False, x_amax=None, nsplit=None, w_planes=None, n_out=None):
+def conv3x3(x, w_ohwi, bias=None, out=None, stats=None, accumulate=False, f16x2=False, x_amax=None, nsplit=None, w_planes=None, n_out=None, bn=0):
     """y (+)= conv3x3(x NHWC, w [N,3,3,Cs]), stride 1, pad 1 (csrc/conv3.hip).  f16x2: the two-piece fp16 form -- for operands inside
     fp16's range (activations, filters); a gradient operand x needs x_amax (device word with the bits of max |x|): the kernel then
     scales x by the power of two that centres it in fp16's range and the result back (exact).  nsplit: workgroups per tile (None: the
@@ -777,8 +777,8 @@ def conv3x3(x, w_ohwi, bias=None, out=None, stats=None, accumulate=False, f16x2=
     nz = conv3_split(B, H, W, Cs, N) if nsplit is None else int(nsplit)
     slab = tickets = None
     if nz > 1:
-        tiles = (B * H * W // 128) * (N // 128)
-        slab = torch.empty((tiles * nz, 128 * 128), device=x.device, dtype=f32)
+        tiles = (B * H * W // 128) * (N // (bn or 128))
+        slab = torch.empty((tiles * nz, 128 * (bn or 128)), device=x.device, dtype=f32)
         tickets = _conv3_tickets(x.device, tiles)
     if _DISPATCH[0] is not None:
         _seen("conv3:fwd")
@@ -788,6 +788,8 @@ def conv3x3(x, w_ohwi, bias=None, out=None, stats=None, accumulate=False, f16x2=
             _seen("conv3:roi")
         if f16x2:
             _seen("conv3:f16x2")
+        if bn == 64:
+            _seen("conv3:bn64")
     ev = None
     if _CONV3_PROF[0] is not None:           # bench.py's second roofline object: events around the launch, on the launch stream
         ev = (torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True))
@@ -795,7 +797,7 @@ def conv3x3(x, w_ohwi, bias=None, out=None, stats=None, accumulate=False, f16x2=
     if w_planes is not None:                 # the filter as pre-split fp16-pair planes (conv3_planes): no filter work in the kernel
         _seen("conv3:pw")
         check(lib.vbg_conv3x3_pw(P(x), P(w_planes), P(bias), P(out), P(stats), bn_slots() if stats is not None else 0, B, H, W, Cs, N,
-                                 int(accumulate), P(x_amax), P(slab), P(tickets), nz, _stream()), "vbg_conv3x3_pw")
+                                 int(accumulate), P(x_amax), P(slab), P(tickets), nz, int(bn), _stream()), "vbg_conv3x3_pw")
     else:
         check(lib.vbg_conv3x3(P(x), P(w_ohwi), P(bias), P(out), P(stats), bn_slots() if stats is not None else 0, B, H, W, Cs, N,
                               int(accumulate), int(bool(f16x2)), P(x_amax), P(slab), P(tickets), nz, _stream()), "vbg_conv3x3")
@@ -884,7 +886,7 @@ def set_conv3_pw(on: bool):
 
 
 class _C3Entry:
-    __slots__ = ("ref", "flip", "out", "tag", "shape", "ptr")
+    __slots__ = ("ref", "flip", "out", "tag", "shape", "ptr", "bn")
 
 
 def _c3pw_tag(owner):
@@ -900,7 +902,7 @@ def _c3pw_table(entries, device):
         Cout, Cin = e.shape
         rows = Cin if e.flip else Cout
         host[i].w, host[i].out, host[i].Cout, host[i].Cin, host[i].flip = e.ptr, e.out.data_ptr(), Cout, Cin, int(e.flip)
-        host[i].bn = 64 if (rows % 128 != 0 and rows % 64 == 0) else 128
+        host[i].bn = e.bn if e.bn else (64 if (rows % 128 != 0 and rows % 64 == 0) else 128)
     raw = torch.frombuffer(bytearray(bytes(host)), dtype=torch.uint8)
     return host, h2d(raw, device), n
 
@@ -926,7 +928,7 @@ def _c3pw_refresh(device):
         e.tag = _c3pw_tag(e.ref())
 
 
-def conv3_planes(owner, w_ohwi, flip):
+def conv3_planes(owner, w_ohwi, flip, bn=0):
     """fp16-pair plane image of the 3x3 filter `owner` (an OIHW parameter in channels_last memory, `w_ohwi` its free [O,3,3,I] view) for
     vbg_conv3x3_pw: flip = False the forward filter, True the filter of the input gradient.  Written once per weight version for ALL
     registered filters by one launch (first use: one launch for the new image).  None: no PW form for this filter."""
@@ -936,16 +938,17 @@ def conv3_planes(owner, w_ohwi, flip):
     if kh != 3 or kw != 3 or Cin % 8 != 0 or (Cout if flip else Cin) % 16 != 0:
         return None
     slot = owner.__dict__.setdefault("_vbg_c3pw", {})
-    e = slot.get(bool(flip))
+    key = (bool(flip), int(bn))
+    e = slot.get(key)
     if e is None or e.ptr != owner.data_ptr():
         import weakref
         e = _C3Entry()
-        e.ref, e.flip, e.shape, e.ptr = weakref.ref(owner), bool(flip), (int(Cout), int(Cin)), owner.data_ptr()
-        nbytes = int(lib.vbg_conv3x3_wprep_bytes(int(Cout), int(Cin), int(bool(flip))))
+        e.ref, e.flip, e.shape, e.ptr, e.bn = weakref.ref(owner), bool(flip), (int(Cout), int(Cin)), owner.data_ptr(), int(bn)
+        nbytes = int(lib.vbg_conv3x3_wprep_bytes(int(Cout), int(Cin), int(bool(flip)), int(bn)))
         e.out = torch.empty((nbytes,), device=w_ohwi.device, dtype=torch.uint8)
-        slot[bool(flip)] = e
+        slot[key] = e
         st = _C3PW
-        st["entries"] = [x for x in st["entries"] if not (x.ref() is owner and x.flip == e.flip)] + [e]
+        st["entries"] = [x for x in st["entries"] if not (x.ref() is owner and x.flip == e.flip and x.bn == e.bn)] + [e]
         st["table"] = None                                  # the full table is rebuilt at the next refresh
         host, tab, n = _c3pw_table([e], w_ohwi.device)     # the new image alone
         check(lib.vbg_conv3x3_wprep(P(tab), C.byref(host), n, _stream()), "vbg_conv3x3_wprep")
@@ -1007,6 +1010,11 @@ def conv2d_fwd(x, w_ohwi, stride, pad, bias=None, out=None, stats=None, w_owner=
         out = torch.empty((B, Ho, Wo, Cout), device=x.device, dtype=f32)
     M, K = B * Ho * Wo, kh * kw * Cin
     if conv3_ok(B, H, W, Cin, Cout, kh, kw, stride, pad, fwd=True):
+        late = conv3_late_choice(B, H, W, Cin, Cout) if _CONV3_F16[0] else None
+        if late is not None:
+            wp = conv3_planes(w_owner, w_ohwi, False, bn=late[0])
+            if wp is not None:
+                return conv3x3(x, w_ohwi, bias, out, stats, f16x2=True, w_planes=wp, x_amax=x_amax, nsplit=late[1], bn=late[0])
         wp = conv3_planes(w_owner, w_ohwi, False) if (_CONV3_F16[0] and conv3_pw_ok(B, H, W, Cin, Cout)) else None
         # x_amax: the producer's amax slot of the activation, when it published one (bn_apply in a training step).  The fp16 form then
         # scales x by the power of two that centres its largest magnitude in fp16's range, like a gradient operand: an activation of
@@ -1041,6 +1049,29 @@ def conv3_f16_bwd_ok(B, H, W, Cout, Cin, kh, kw, stride, pad) -> bool:
     return _CONV3_F16[0] and _CONV3_F16_BWD[0] and conv3_ok(B, H, W, Cout, Cin, kh, kw, stride, pad)
 
 
+_CONV3_BN64 = [os.environ.get("VBG_CONV3_BN64", "1") != "0"]
+
+
+def conv3_late_choice(B, H, W, Cs, N):
+    """(filters per tile, workgroups per tile) for the PW kernels on the LATE trunk stages -- 16-239 tiles of 128 x 128 --, or None.
+    64-filter tiles double the tile count: 256 channels at 32 x 32 then fill the chip with ONE workgroup per tile (no slabs, no tickets:
+    37 vs 48 us with three workgroups per 128-filter tile), 512 channels at 16 x 16 take four per tile on half the slab bytes (42 vs 49 us;
+    tools/conv3_bn_sweep.py)"""
+    if not (_CONV3_BN64[0] and _CONV3_PW[0] and _CONV3_SPLITK[0]) or (H == 7 and W == 7) or N % 128 or (H * W) % 128 or W >= 128 or Cs % 16:
+        return None
+    t128 = (B * H * W // 128) * (N // 128)
+    if t128 >= 240 or t128 < 16:
+        return None
+    t64 = 2 * t128
+    nz = 1 if t64 >= 240 else min(4, -(-480 // t64))
+    while nz > 1:
+        cs = nz // 3 if nz % 3 == 0 else nz
+        if Cs % cs == 0 and (Cs // cs) % 16 == 0:
+            break
+        nz -= 1
+    return 64, nz
+
+
 def conv3_pw_ok(B, H, W, Cs, N) -> bool:
     """does vbg_conv3x3 run 128-pixel tiles on this shape (what the PW kernels exist for)?  Mirrors csrc/conv3.hip conv3x3_impl."""
     if H == 7 and W == 7:
@@ -1068,6 +1099,12 @@ def conv2d_dgrad(dy, w_ohwi, x_shape, stride, pad, out=None, accumulate=False, d
     if conv3_ok(B, H, W, Cout, Cin, kh, kw, stride, pad):
         # the input gradient of a 3x3 / s1 / p1 convolution is the same convolution of dy with the turned, channel-swapped filter
         if _CONV3_F16[0] and _CONV3_F16_BWD[0]:
+            late = conv3_late_choice(B, H, W, Cout, Cin)
+            if late is not None:
+                wp = conv3_planes(w_owner, w_ohwi, True, bn=late[0])
+                if wp is not None:
+                    return conv3x3(dy, w_ohwi, None, out, None, accumulate, f16x2=True, x_amax=dy_amax if dy_amax is not None else amax(dy),
+                                   w_planes=wp, n_out=Cin, nsplit=late[1], bn=late[0])
             wp = conv3_planes(w_owner, w_ohwi, True) if conv3_pw_ok(B, H, W, Cout, Cin) else None
             if wp is not None:       # the turned filter exists as plane image only: no fp32 copy of it is written
                 return conv3x3(dy, w_ohwi, None, out, None, accumulate, f16x2=True, x_amax=dy_amax if dy_amax is not None else amax(dy),
