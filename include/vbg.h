@@ -362,6 +362,14 @@ int vbg_dropout_add_ln_bwd_planes(const float* dy, const float* xhat, const floa
                                   const float* gamma, float drop_p, unsigned long long seed, unsigned long long stream_id,
                                   unsigned short* dx_planes, int ldp, long long plane, float* dres, float* dgamma, float* dbeta,
                                   float* dbias_accum, float* slots3_ws, void* stream);
+/* the same with dx delivered as fp16-pair planes [2][rows][ldp] scaled by the power of two of a rigorous bound of |dx| (round 4: no split
+ * pass for this gradient): bound = max |dy| (amax slot dy_amax) * max |gamma| * max rstd * (2 + sqrt(hidden)) / keep * 1.01; its bit
+ * pattern goes to word 0 of the zeroed slot dx_bound (the consumers' a_amax), max |dx| itself into the zeroed slot dx_amax (optional) */
+int vbg_dropout_add_ln_bwd_pair(const float* dy, const float* xhat, const float* rstd, int rows, int hidden,
+                                const float* gamma, float drop_p, unsigned long long seed, unsigned long long stream_id,
+                                unsigned short* dx_pair, int ldp, long long plane, float* dres, float* dgamma, float* dbeta,
+                                float* dbias_accum, float* slots3_ws, const unsigned* dy_amax, unsigned* dx_amax, unsigned* dx_bound,
+                                void* stream);
 /* attention probabilities, in place on the grouped score buffer: for group g (= seq*heads + head)
  * rows L=len[g/heads], row stride ldp[g/heads], block offset off[g]; P = softmax(S*scale);
  * dropped entries are stored NEGATED (sign bit = dropped), kept entries unscaled; pad columns = 0. */

@@ -1321,6 +1321,37 @@ def test_plane_gemm_pair_form_vs_fp64(tile):
     assert torch.equal(pl.buf, ops.split_planes(y).buf) and torch.equal(pq.buf, ops.split_planes_pair(y).buf)
 
 
+def test_layernorm_backward_bound_scaled_pair_planes():
+    """round 4: the LayerNorm backward delivers dx as fp16-pair planes scaled by a rigorous bound (max |dy| x max |gamma| x max rstd x
+    (2 + sqrt H) / keep) instead of fp32 + amax + split pass: the planes equal the scaled split of the fp32-path dx bit for bit, the bound
+    really bounds (and is at most 2^10 loose on random data), dres / dgamma / dbeta / the bias column sums / max |dx| equal the fp32 path's,
+    at gradient magnitudes 2^-30 ... 2^8, with and without dropout."""
+    from vbg import ops
+    dev = torch.device("cuda")
+    g = torch.Generator().manual_seed(91)
+    rows, hid = 1000, 768
+    x, r = torch.randn(rows, hid, generator=g).to(dev), torch.randn(rows, hid, generator=g).to(dev)
+    gam, bet = (1 + 0.2 * torch.randn(hid, generator=g)).to(dev), (0.1 * torch.randn(hid, generator=g)).to(dev)
+    for p_drop in (0.0, 0.1):
+        y, xhat, rstd = ops.dropout_add_ln_fwd(x, r, gam, bet, 1e-12, p_drop, 5, 3)
+        for sc in (1.0, 2.0 ** -30, 2.0 ** -17, 2.0 ** 8):
+            dy = (torch.randn(rows, hid, generator=g) * torch.exp2(torch.randint(-4, 4, (rows, 1), generator=g).float())).to(dev) * sc
+            dg0, db0 = torch.zeros(hid, device=dev), torch.zeros(hid, device=dev)
+            s0 = ops.amax_slot(dev)
+            dx0, dres0 = ops.dropout_add_ln_bwd(dy, xhat, rstd, gam, p_drop, 5, 3, dg0, db0, dx_amax=s0)
+            dg1, db1, dbias = torch.zeros(hid, device=dev), torch.zeros(hid, device=dev), torch.zeros(hid, device=dev)
+            s_true, s_ref = ops.amax_slot(dev), ops.amax_slot(dev)
+            q, dres1 = ops.dropout_add_ln_bwd_pair(dy, xhat, rstd, gam, p_drop, 5, 3, dg1, db1, dbias, ops.amax(dy), s_true, s_ref)
+            assert torch.equal(dres0, dres1)
+            assert int(s_true.max().item()) == int(s0.max().item())
+            bound, true_max = float(s_ref.view(torch.float32).max().item()), float(dx0.abs().max())
+            assert true_max <= bound <= 2.0 ** 10 * true_max, (bound, true_max)
+            chk = ops.split_planes_pair(dx0, amax_slot_=s_ref)
+            assert torch.equal(q.buf, chk.buf), (p_drop, sc)
+            assert torch.allclose(dg0, dg1, rtol=1e-5, atol=1e-5 * float(dg0.abs().max())) and torch.allclose(db0, db1, rtol=1e-5, atol=1e-5 * float(db0.abs().max()))
+            assert torch.allclose(dbias.double(), dx0.double().sum(0), rtol=1e-4, atol=2e-5 * float(dx0.abs().max()) * rows ** 0.5)
+
+
 def test_plane_gemm_bound_scaled_pair_output():
     """round 4: a GRADIENT leaves the product's epilogue as fp16-pair planes scaled by the power of two of a rigorous BOUND of the stored
     values -- max |A| (amax slot) x the largest column L1 norm of W (vbg_col_l1_max) x the epilogue's constant -- instead of a measured

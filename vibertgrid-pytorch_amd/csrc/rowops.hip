@@ -218,12 +218,19 @@ __global__ __launch_bounds__(256) void dropout_add_ln_fwd_kernel(
 // PL: dx (the gradient of the dense output in front of this LayerNorm) leaves as bf16 planes [3][rows][ldp] instead of fp32 -- it is
 // only ever a plane operand of that layer's data- and weight-gradient products -- and its column sums (the dense layer's bias
 // gradient) ride along in a third slot array; slots are then [LN_SLOTS][3][hidden] and mandatory.
-template <bool PL>
+// PL = 0: dx as fp32 (+ its largest magnitude); 1: dx as three bf16 planes + column sums; 2 (round 4): dx as TWO fp16 planes scaled by the
+// power of two of a rigorous BOUND of |dx| -- no fp32 round trip and no split pass for a gradient that is only ever a plane operand --,
+// + column sums + the true largest magnitude (the next producer's bound needs it).  The bound: dz = rstd (g gamma - mean(g gamma) -
+// xhat mean(g gamma xhat)) with |xhat| <= sqrt(H) and mean |xhat| <= 1, so |dx| <= keep^-1 max rstd max |gamma| max |dy| (2 + sqrt H):
+// max |dy| from the amax slot of the producer of dy, max |gamma| from the wave's own registers, max rstd by every block over the rstd
+// vector (16 KB, L2 resident).  Every block derives the same bound; block 0 publishes its bit pattern (the consumers' a_amax).
+template <int PL>
 __global__ __launch_bounds__(256) void dropout_add_ln_bwd_kernel(
     const float* __restrict__ dy, const float* __restrict__ xhat, const float* __restrict__ rstd, int rows, int hidden,
     const float* __restrict__ gamma, uint32_t drop_thr, float keep_scale, uint64_t seed, uint64_t sid,
     float* __restrict__ dx, float* __restrict__ dres, float* dgamma, float* dbeta, float* slots,
-    unsigned short* __restrict__ dxp, int ldp, long long plane, unsigned* dx_amax) {
+    unsigned short* __restrict__ dxp, int ldp, long long plane, unsigned* dx_amax, const unsigned* dy_amax = nullptr,
+    unsigned* dx_bound = nullptr) {
     const int lane = threadIdx.x & 63;
     const int nv = hidden >> 8;
     const int t0 = (blockIdx.x * 4 + (threadIdx.x >> 6)) * LN_WROWS;
@@ -234,6 +241,20 @@ __global__ __launch_bounds__(256) void dropout_add_ln_bwd_kernel(
         ac[j] = make_float4(0.f, 0.f, 0.f, 0.f);
         ag[j] = ab[j] = make_float4(0.f, 0.f, 0.f, 0.f);
         gam[j] = (j < nv) ? *reinterpret_cast<const float4*>(gamma + (lane + 64 * j) * 4) : ag[j];
+    }
+    float qsc = 1.f;
+    if constexpr (PL == 2) {
+        __shared__ float sh_b[16];
+        float gm = 0.f, rm = 0.f;
+#pragma unroll
+        for (int j = 0; j < LN_V; ++j) gm = fmaxf(gm, fmaxf(fmaxf(fabsf(gam[j].x), fabsf(gam[j].y)), fmaxf(fabsf(gam[j].z), fabsf(gam[j].w))));
+        gm = wave_max(gm);
+        for (int i = threadIdx.x; i < rows; i += 256) rm = fmaxf(rm, rstd[i]);
+        rm = block_max(rm, sh_b);
+        const float ady = __uint_as_float(vbg_amax_read(dy_amax));
+        const float bound = ady * gm * rm * (2.f + sqrtf((float)hidden)) * keep_scale * 1.01f;
+        qsc = vbg_pow2_scale(__float_as_uint(bound)).x;
+        if (dx_bound && blockIdx.x == 0 && threadIdx.x == 0) dx_bound[0] = __float_as_uint(bound);
     }
     for (int t = t0; t < min(rows, t0 + LN_WROWS); ++t) {
         const long long base = (long long)t * hidden;
@@ -262,9 +283,21 @@ __global__ __launch_bounds__(256) void dropout_add_ln_bwd_kernel(
                 dz.z = rs * (g[j].z * gam[j].z - m1 - xh[j].z * m2); dz.w = rs * (g[j].w * gam[j].w - m1 - xh[j].w * m2);
                 *reinterpret_cast<float4*>(dres + base + c) = dz;
                 const float4 dd = drop4(dz, drop_thr, keep_scale, seed, sid, (uint64_t)base + c);
-                if constexpr (!PL) {
+                if constexpr (PL == 0) {
                     *reinterpret_cast<float4*>(dx + base + c) = dd;
                     amx = fmaxf(fmaxf(amx, fmaxf(fabsf(dd.x), fabsf(dd.y))), fmaxf(fabsf(dd.z), fabsf(dd.w)));
+                } else if constexpr (PL == 2) {
+                    ac[j].x += dd.x; ac[j].y += dd.y; ac[j].z += dd.z; ac[j].w += dd.w;
+                    amx = fmaxf(fmaxf(amx, fmaxf(fabsf(dd.x), fabsf(dd.y))), fmaxf(fabsf(dd.z), fabsf(dd.w)));
+                    typedef float f32x2_t __attribute__((ext_vector_type(2)));
+                    typedef _Float16 f16x2_t __attribute__((ext_vector_type(2)));
+                    const f32x2_t v0 = {dd.x * qsc, dd.y * qsc}, v1 = {dd.z * qsc, dd.w * qsc};
+                    const f16x2_t h0 = __builtin_convertvector(v0, f16x2_t), h1 = __builtin_convertvector(v1, f16x2_t);
+                    const f16x2_t l0 = __builtin_convertvector((v0 - __builtin_convertvector(h0, f32x2_t)) * 2048.f, f16x2_t);
+                    const f16x2_t l1 = __builtin_convertvector((v1 - __builtin_convertvector(h1, f32x2_t)) * 2048.f, f16x2_t);
+                    unsigned short* op = dxp + (long long)t * ldp + c;
+                    *reinterpret_cast<uint2*>(op) = make_uint2(__builtin_bit_cast(unsigned, h0), __builtin_bit_cast(unsigned, h1));
+                    *reinterpret_cast<uint2*>(op + plane) = make_uint2(__builtin_bit_cast(unsigned, l0), __builtin_bit_cast(unsigned, l1));
                 } else {
                     ac[j].x += dd.x; ac[j].y += dd.y; ac[j].z += dd.z; ac[j].w += dd.w;
                     const float e[4] = {dd.x, dd.y, dd.z, dd.w};
@@ -285,7 +318,7 @@ __global__ __launch_bounds__(256) void dropout_add_ln_bwd_kernel(
             }
     }
     // cross-wave reduction of the column partials through LDS, then ONE atomic per column per block
-    constexpr int NA = PL ? 3 : 2;
+    constexpr int NA = PL != 0 ? 3 : 2;
     __shared__ float red[NA][4][256 * LN_V];
     const int w = threadIdx.x >> 6;
 #pragma unroll
@@ -294,7 +327,7 @@ __global__ __launch_bounds__(256) void dropout_add_ln_bwd_kernel(
             const int c = (lane + 64 * j) * 4;
             *reinterpret_cast<float4*>(&red[0][w][c]) = ag[j];
             *reinterpret_cast<float4*>(&red[1][w][c]) = ab[j];
-            if constexpr (PL) *reinterpret_cast<float4*>(&red[2][w][c]) = ac[j];
+            if constexpr (PL != 0) *reinterpret_cast<float4*>(&red[2][w][c]) = ac[j];
         }
     __syncthreads();
     // same-address atomics serialise (~516 blocks at cfg2): with a slot workspace the block sums land in one of LN_SLOTS slot
@@ -304,9 +337,9 @@ __global__ __launch_bounds__(256) void dropout_add_ln_bwd_kernel(
     for (int c = threadIdx.x; c < hidden; c += 256) {
         unsafeAtomicAdd(dg + c, (red[0][0][c] + red[0][1][c]) + (red[0][2][c] + red[0][3][c]));
         unsafeAtomicAdd(db + c, (red[1][0][c] + red[1][1][c]) + (red[1][2][c] + red[1][3][c]));
-        if constexpr (PL) unsafeAtomicAdd(dg + 2 * hidden + c, (red[2][0][c] + red[2][1][c]) + (red[2][2][c] + red[2][3][c]));
+        if constexpr (PL != 0) unsafeAtomicAdd(dg + 2 * hidden + c, (red[2][0][c] + red[2][1][c]) + (red[2][2][c] + red[2][3][c]));
     }
-    if constexpr (!PL) {
+    if constexpr (PL != 1) {
         if (dx_amax) {                                // (uniform)
             __syncthreads();
             vbg_amax_publish(amx, dx_amax, &red[0][0][0]);
@@ -622,7 +655,7 @@ extern "C" int vbg_dropout_add_ln_bwd(const float* dy, const float* xhat, const 
     VBG_CHECK_ARG(hidden > 0 && hidden % 256 == 0 && hidden <= 256 * LN_V && drop_p >= 0.f && drop_p < 1.f);
     VBG_CHECK_ARG(((uintptr_t)dy | (uintptr_t)xhat | (uintptr_t)gamma | (uintptr_t)dx | (uintptr_t)dres) % 16 == 0);
     if (rows <= 0) return VBG_OK;
-    VBG_LAUNCH(dropout_add_ln_bwd_kernel<false>, dim3(cdiv(rows, 4 * LN_WROWS)), dim3(256), 0, (hipStream_t)stream, dy, xhat, rstd, rows,
+    VBG_LAUNCH(dropout_add_ln_bwd_kernel<0>, dim3(cdiv(rows, 4 * LN_WROWS)), dim3(256), 0, (hipStream_t)stream, dy, xhat, rstd, rows,
                hidden, gamma, drop_threshold(drop_p), 1.0f / (1.0f - drop_p), seed, sid, dx, dres, dgamma, dbeta, slots_ws,
                (unsigned short*)nullptr, 0, 0ll, dx_amax);
     if (slots_ws) VBG_LAUNCH(ln_fold_kernel, dim3(cdiv(2 * hidden, 256)), dim3(256), 0, (hipStream_t)stream, slots_ws, hidden, 2, dgamma, dbeta,
@@ -639,9 +672,26 @@ extern "C" int vbg_dropout_add_ln_bwd_planes(const float* dy, const float* xhat,
     VBG_CHECK_ARG(((uintptr_t)dy | (uintptr_t)xhat | (uintptr_t)gamma | (uintptr_t)dres) % 16 == 0);
     VBG_CHECK_ARG(ldp % 4 == 0 && ldp >= hidden && plane % 4 == 0 && plane >= (long long)rows * ldp && ((uintptr_t)dx_planes & 7) == 0);
     if (rows <= 0) return VBG_OK;
-    VBG_LAUNCH(dropout_add_ln_bwd_kernel<true>, dim3(cdiv(rows, 4 * LN_WROWS)), dim3(256), 0, (hipStream_t)stream, dy, xhat, rstd, rows,
+    VBG_LAUNCH(dropout_add_ln_bwd_kernel<1>, dim3(cdiv(rows, 4 * LN_WROWS)), dim3(256), 0, (hipStream_t)stream, dy, xhat, rstd, rows,
                hidden, gamma, drop_threshold(drop_p), 1.0f / (1.0f - drop_p), seed, sid, (float*)nullptr, dres, dgamma, dbeta, slots3_ws,
                dx_planes, ldp, plane, (unsigned*)nullptr);
+    VBG_LAUNCH(ln_fold_kernel, dim3(cdiv(3 * hidden, 256)), dim3(256), 0, (hipStream_t)stream, slots3_ws, hidden, 3, dgamma, dbeta, dbias_accum);
+    VBG_LAUNCH_RET();
+}
+
+extern "C" int vbg_dropout_add_ln_bwd_pair(const float* dy, const float* xhat, const float* rstd, int rows, int hidden,
+                                           const float* gamma, float drop_p, unsigned long long seed, unsigned long long sid,
+                                           unsigned short* dx_pair, int ldp, long long plane, float* dres, float* dgamma, float* dbeta,
+                                           float* dbias_accum, float* slots3_ws, const unsigned* dy_amax, unsigned* dx_amax, unsigned* dx_bound,
+                                           void* stream) {
+    VBG_CHECK_ARG(dy && xhat && rstd && gamma && dx_pair && dres && dgamma && dbeta && dbias_accum && slots3_ws && dy_amax && dx_bound);
+    VBG_CHECK_ARG(hidden > 0 && hidden % 256 == 0 && hidden <= 256 * LN_V && drop_p >= 0.f && drop_p < 1.f);
+    VBG_CHECK_ARG(((uintptr_t)dy | (uintptr_t)xhat | (uintptr_t)gamma | (uintptr_t)dres) % 16 == 0);
+    VBG_CHECK_ARG(ldp % 4 == 0 && ldp >= hidden && plane % 4 == 0 && plane >= (long long)rows * ldp && ((uintptr_t)dx_pair & 7) == 0);
+    if (rows <= 0) return VBG_OK;
+    VBG_LAUNCH(dropout_add_ln_bwd_kernel<2>, dim3(cdiv(rows, 4 * LN_WROWS)), dim3(256), 0, (hipStream_t)stream, dy, xhat, rstd, rows,
+               hidden, gamma, drop_threshold(drop_p), 1.0f / (1.0f - drop_p), seed, sid, (float*)nullptr, dres, dgamma, dbeta, slots3_ws,
+               dx_pair, ldp, plane, dx_amax, dy_amax, dx_bound);
     VBG_LAUNCH(ln_fold_kernel, dim3(cdiv(3 * hidden, 256)), dim3(256), 0, (hipStream_t)stream, slots3_ws, hidden, 3, dgamma, dbeta, dbias_accum);
     VBG_LAUNCH_RET();
 }

@@ -731,14 +731,26 @@ class BertLayerFn(torch.autograd.Function):
         rbq, rbk, rbv, rbo, rbi, rbo2, rg1, rb1, rg2, rb2 = ctx.b_refs
         rq, rk, rv, ro, ri, ro2 = ctx.w_refs
         tile = lambda n, wide=False: ops.pair_tile(ntok, n, wide)
-        # ---- LayerNorm 2 backward -> dfo (fp32) -> pair planes, bias gradient of the FFN output projection on the split
+        # ---- LayerNorm 2 backward -> dfo.  Round 4: straight as pair planes scaled by a rigorous bound (max |dy| x max |gamma| x max rstd x
+        #      (2 + sqrt H) / keep; csrc/rowops.hip PL = 2) with the bias gradient of the FFN output projection riding along -- no fp32 dfo,
+        #      no split pass.  s_dfo = true max |dfo| (the next bound's input), s_dfo_ref = the scale the planes were written with.
         dg2, db2, sunk2 = _affine_dest(rg2, rb2)
-        s_dfo = ops.amax_slot(dev)                    # (the largest magnitude of dfo rides on the kernel that writes it)
-        dfo, dx1 = ops.dropout_add_ln_bwd(_c(dy), xh2, rs2, g2, p, seed, sid + 2, dg2, db2, dx_amax=s_dfo)
+        s_dfo = ops.amax_slot(dev)
+        bound = ops.bound_planes_enabled() and sunk2 and hid % 256 == 0
+        dyc = _c(dy)
+        if bound:
+            s_dy = _amax_tag(dy)
+            if s_dy is None:
+                s_dy = ops.amax(dyc)                  # (the top layer: its output gradient is a sum autograd formed)
+            s_dfo_ref = ops.amax_slot(dev)
+            qdfo, dx1 = ops.dropout_add_ln_bwd_pair(dyc, xh2, rs2, g2, p, seed, sid + 2, dg2, db2, wgrad_dest(rbo2), s_dy, s_dfo, s_dfo_ref)
+        else:
+            s_dfo_ref = s_dfo
+            dfo, dx1 = ops.dropout_add_ln_bwd(dyc, xh2, rs2, g2, p, seed, sid + 2, dg2, db2, dx_amax=s_dfo)
+            qdfo = ops.split_planes_pair(dfo, amax_slot_=s_dfo, colsum_out=wgrad_dest(rbo2))
+            del dfo
         dg2, db2 = _affine_done(rg2, rb2, dg2, db2, sunk2)
-        qdfo = ops.split_planes_pair(dfo, amax_slot_=s_dfo, colsum_out=wgrad_dest(rbo2))
         wgrad_done(rbo2)
-        del dfo
         # ---- dL/dh = (dfo Wo2) o gelu'(h) leaves the product's epilogue as pair planes (round 4): scaled by the power of two of a rigorous
         #      BOUND -- max |dfo| (measured: s_dfo) * the largest column L1 norm of Wo2 (once per weight version) * max gelu' (1.129) -- instead
         #      of a measured maximum, so it needs no fp32 round trip and no split pass; s_dh receives the bound (the consumers' scale)
@@ -746,27 +758,33 @@ class BertLayerFn(torch.autograd.Function):
         if ops.bound_planes_enabled():
             qdh = ops.pair_empty(ntok, inter, dev)
             ops.plane_gemm(qdfo, ops.weight_planes(ro2, True, view=wo2, pair=True), None, epi=EPI_MUL_GELU_GRAD, C2=h, tile=tile(inter, True), form=1,
-                           a_amax=s_dfo, out_pair=qdh, q_ref_in=s_dfo, q_l1=ops.weight_col_l1max(ro2, view=wo2), q_mul=1.13 * 1.01, q_ref_out=s_dh,
+                           a_amax=s_dfo_ref, out_pair=qdh, q_ref_in=s_dfo, q_l1=ops.weight_col_l1max(ro2, view=wo2), q_mul=1.13 * 1.01, q_ref_out=s_dh,
                            colsum_out=wgrad_dest(rbi))
         else:
             dh_ = torch.empty((ntok, inter), device=dev, dtype=f32)
             ops.plane_gemm(qdfo, ops.weight_planes(ro2, True, view=wo2, pair=True), dh_, epi=EPI_MUL_GELU_GRAD, C2=h, tile=tile(inter, True), form=1,
-                           a_amax=s_dfo, c_amax=s_dh)
+                           a_amax=s_dfo_ref, c_amax=s_dh)
             qdh = ops.split_planes_pair(dh_, amax_slot_=s_dh, colsum_out=wgrad_dest(rbi))
             del dh_
         wgrad_done(rbi)
-        ops.plane_gemm(qdh, ops.weight_planes(ri, True, view=wi, pair=True), dx1, accumulate=True, tile=tile(hid), form=1, a_amax=s_dh)
-        # ---- LayerNorm 1 backward -> dao
+        s_dx1 = ops.amax_slot(dev) if bound else None           # (max |dx1| rides on the product that completes it: LayerNorm 1's bound)
+        ops.plane_gemm(qdh, ops.weight_planes(ri, True, view=wi, pair=True), dx1, accumulate=True, tile=tile(hid), form=1, a_amax=s_dh, c_amax=s_dx1)
+        # ---- LayerNorm 1 backward -> dao (pair planes by the same bound, or fp32 + split)
         dg1, db1, sunk1 = _affine_dest(rg1, rb1)
         s_dao = ops.amax_slot(dev)
-        dao, dx = ops.dropout_add_ln_bwd(dx1, xh1, rs1, g1, p, seed, sid + 1, dg1, db1, dx_amax=s_dao)
+        if bound and sunk1:
+            s_dao_ref = ops.amax_slot(dev)
+            qdao, dx = ops.dropout_add_ln_bwd_pair(dx1, xh1, rs1, g1, p, seed, sid + 1, dg1, db1, wgrad_dest(rbo), s_dx1, s_dao, s_dao_ref)
+        else:
+            s_dao_ref = s_dao
+            dao, dx = ops.dropout_add_ln_bwd(dx1, xh1, rs1, g1, p, seed, sid + 1, dg1, db1, dx_amax=s_dao)
+            qdao = ops.split_planes_pair(dao, amax_slot_=s_dao, colsum_out=wgrad_dest(rbo))
+            del dao
         dg1, db1 = _affine_done(rg1, rb1, dg1, db1, sunk1)
-        qdao = ops.split_planes_pair(dao, amax_slot_=s_dao, colsum_out=wgrad_dest(rbo))
         wgrad_done(rbo)
-        del dao
         # ---- d(context): fp32 + bf16 planes (the dO operand of the fused attention backward, which stays on the six-product form)
         pdctx = ops.planes_empty(ntok, hid, dev)
-        ops.plane_gemm(qdao, ops.weight_planes(ro, True, view=wo, pair=True), None, out_planes=pdctx, tile=tile(hid), form=1, a_amax=s_dao)
+        ops.plane_gemm(qdao, ops.weight_planes(ro, True, view=wo, pair=True), None, out_planes=pdctx, tile=tile(hid), form=1, a_amax=s_dao_ref)
         pqkv = ops.Planes(bqkv, ntok, 3 * hid, bqkv.shape[2])
         delta = ctx.delta_buf
         dqkv = torch.empty((ntok, 3 * hid), device=dev, dtype=f32)
@@ -777,11 +795,14 @@ class BertLayerFn(torch.autograd.Function):
         gq = [wgrad_dest(t) for t in (rq, rk, rv, rbq, rbk, rbv)]
         qdqkv = ops.split_planes_pair(dqkv, amax_slot_=s_dqkv, colsum_out=_stack3(gq[3]))
         del dqkv
+        s_dx = ops.amax_slot(dev) if bound else None            # (max |dx| for the layer below: its LayerNorm 2 bound)
         ops.plane_gemm(qdqkv, ops.weight_planes(rq, True, view=_stack3(wq), also=(rk, rv), pair=True), dx, accumulate=True, tile=tile(hid), form=1,
-                       a_amax=s_dqkv)
+                       a_amax=s_dqkv, c_amax=s_dx)
+        if s_dx is not None:
+            dx._vbg_amax = (s_dx, dx._version)
         # ---- the four weight gradients: one grouped TN launch on pair planes
         jobs = [(qdfo, qg, wgrad_dest(ro2)), (qdh, qx1, wgrad_dest(ri)), (qdao, qctx, wgrad_dest(ro)), (qdqkv, qx, _stack3(gq[0]))]
-        ops.plane_gemm_grouped(jobs, trans=True, accumulate=True, form=1, a_amax=[s_dfo, s_dh, s_dao, s_dqkv])
+        ops.plane_gemm_grouped(jobs, trans=True, accumulate=True, form=1, a_amax=[s_dfo_ref, s_dh, s_dao_ref, s_dqkv])
         for t in (ro2, ri, ro, rq, rk, rv, rbq, rbk, rbv):
             wgrad_done(t)
         return (dx, None, None, None, None, None, None, None, None, None, dg1, db1, None, None, None, None, dg2, db2, None, None, None, None, None)

@@ -114,6 +114,7 @@ SIGNATURES = {
     "vbg_dropout_add_ln_fwd_planes": (c_int, [c_vp, c_vp, c_int, c_int, c_vp, c_vp, c_f, c_f, c_ull, c_ull, c_vp, c_vp, c_vp, c_vp, c_int, c_ll, c_vp, c_int, c_ll, c_vp]),
     "vbg_ln_slots": (c_int, []),
     "vbg_dropout_add_ln_bwd": (c_int, [c_vp, c_vp, c_vp, c_int, c_int, c_vp, c_f, c_ull, c_ull, c_vp, c_vp, c_vp, c_vp, c_vp, c_vp, c_vp]),
+    "vbg_dropout_add_ln_bwd_pair": (c_int, [c_vp, c_vp, c_vp, c_int, c_int, c_vp, c_f, c_ull, c_ull, c_vp, c_int, c_ll, c_vp, c_vp, c_vp, c_vp, c_vp, c_vp, c_vp, c_vp, c_vp]),
     "vbg_dropout_add_ln_bwd_planes": (c_int, [c_vp, c_vp, c_vp, c_int, c_int, c_vp, c_f, c_ull, c_ull, c_vp, c_int, c_ll, c_vp, c_vp, c_vp, c_vp, c_vp, c_vp]),
     "vbg_softmax_fwd": (c_int, [c_vp, c_vp, c_vp, c_vp, c_int, c_int, c_int, c_f, c_f, c_ull, c_ull, c_vp]),
     "vbg_softmax_bwd": (c_int, [c_vp, c_vp, c_vp, c_vp, c_vp, c_int, c_int, c_int, c_f, c_f, c_vp]),

@@ -1231,6 +1231,25 @@ def dropout_add_ln_bwd_planes(dy, xhat, rstd, gamma, p, seed, sid, dgamma, dbeta
     return pdx, dres
 
 
+def dropout_add_ln_bwd_pair(dy, xhat, rstd, gamma, p, seed, sid, dgamma, dbeta, dbias, dy_amax, dx_amax, dx_bound):
+    """LayerNorm backward with dx as fp16-pair planes scaled by a BOUND (-> Planes, dres): dy_amax = amax slot of dy (in), dx_amax = zeroed
+    slot for max |dx| (out), dx_bound = zeroed slot that receives the bound (out: pass it as a_amax of the products that read the planes);
+    dbias += column sums of dx"""
+    rows, hidden = xhat.shape
+    dev = xhat.device
+    key = (dev, hidden, raw_stream(dev))
+    ws = _LN_WS3.get(key)
+    if ws is None:
+        ws = _LN_WS3[key] = torch.zeros((int(lib.vbg_ln_slots()) * 3 * hidden,), device=dev, dtype=f32)
+    qdx = pair_empty(rows, hidden, dev)
+    assert qdx.ld == hidden
+    dres = torch.empty_like(xhat)
+    check(lib.vbg_dropout_add_ln_bwd_pair(P(dy), P(xhat), P(rstd), rows, hidden, P(gamma), p, seed, sid, P(qdx.buf), qdx.ld, qdx.plane, P(dres),
+                                          P(dgamma), P(dbeta), P(dbias), P(ws), P(dy_amax), P(dx_amax), P(dx_bound), _stream()),
+          "vbg_dropout_add_ln_bwd_pair")
+    return qdx, dres
+
+
 def dropout_add_ln_bwd(dy, xhat, rstd, gamma, p, seed, sid, dgamma, dbeta, dx_amax=None):
     """dx_amax: zeroed amax slot that receives max |dx| (the scale of dx as an fp16-pair operand)"""
     rows, hidden = xhat.shape
