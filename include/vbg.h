@@ -225,6 +225,8 @@ typedef struct vbg_attn_desc {
     const unsigned* mask_q; const unsigned* mask_k; const long long* mask_off;
     float scale, keep_scale;
     unsigned* out_amax;             /* DQ / DKV, optional: amax slot (zeroed by the caller) that receives max |value written to out| */
+    unsigned short* out_pair; long long oq_plane, oq_ld;     /* FWD, optional (round 4): O also as fp16-pair planes [2][ntok][oq_ld] -- the B operand
+                                                                of the output projection's weight gradient, saved for backward instead of split there */
 } vbg_attn_desc;
 int vbg_attn(const vbg_attn_desc* desc, void* stream);
 /* dropout keeps of one layer and step, both orientations (torch.nn.Dropout(attention_probs_dropout_prob) on the probabilities):

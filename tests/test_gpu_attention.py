@@ -52,8 +52,11 @@ def _run(seq_len, heads, p, seed=0):
     lse = torch.zeros(2, heads, meta.ntok_pad, device=dev)
     kbar = torch.zeros(ntok, hid, device=dev)
     opl = ops.planes_empty(ntok, hid, dev)
-    ops.attn(meta, ATTN_FWD, pq, None, O, lse, None, masks, scale, p, kbar=kbar, out_planes=opl)
+    oq = ops.pair_empty(ntok, hid, dev)
+    oq.buf.zero_()
+    ops.attn(meta, ATTN_FWD, pq, None, O, lse, None, masks, scale, p, kbar=kbar, out_planes=opl, out_pair=oq)
     assert torch.equal(opl.buf, ops.split_planes(O).buf), "planes of O written by the forward kernel != split(O)"
+    assert torch.equal(oq.buf, ops.split_planes_pair(O).buf), "fp16-pair planes of O written by the forward kernel != split_pair(O)"
     delta = torch.zeros_like(lse[0])
     dqkv = torch.full((ntok, 3 * hid), float("nan"), device=dev)
     slot = ops.amax_slot(dev)          # the largest magnitude of d(qkv) rides on the two backward kernels (fp16-pair planes' scale)

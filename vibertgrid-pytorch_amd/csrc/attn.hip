@@ -488,6 +488,23 @@ __global__ __launch_bounds__(256, 2) void attn_kernel(const vbg_attn_desc p) {
                     *reinterpret_cast<uint2*>(o + 2 * p.op_plane) = make_uint2(l[0] | (l[1] << 16), l[2] | (l[3] << 16));
                 }
         }
+        if (p.out_pair) {                             // the same values as two fp16 pieces (hi, (x - hi) 2^11; round to nearest), 8 bytes per plane and quad
+            typedef float f32x2_t __attribute__((ext_vector_type(2)));
+            typedef _Float16 f16x2_t __attribute__((ext_vector_type(2)));
+            unsigned short* pq0 = p.out_pair + (long long)(row0 + own0 + lr) * p.oq_ld + head * 64;
+#pragma unroll
+            for (int db = 0; db < 2; ++db)
+#pragma unroll
+                for (int j = 0; j < 4; ++j) {
+                    const f32x2_t v0 = {acc0[db][4 * j] * il, acc0[db][4 * j + 1] * il}, v1 = {acc0[db][4 * j + 2] * il, acc0[db][4 * j + 3] * il};
+                    const f16x2_t h0 = __builtin_convertvector(v0, f16x2_t), h1 = __builtin_convertvector(v1, f16x2_t);
+                    const f16x2_t l0 = __builtin_convertvector((v0 - __builtin_convertvector(h0, f32x2_t)) * 2048.f, f16x2_t);
+                    const f16x2_t l1 = __builtin_convertvector((v1 - __builtin_convertvector(h1, f32x2_t)) * 2048.f, f16x2_t);
+                    unsigned short* o = pq0 + db * 32 + 8 * j + 4 * lh;
+                    *reinterpret_cast<uint2*>(o) = make_uint2(__builtin_bit_cast(unsigned, h0), __builtin_bit_cast(unsigned, h1));
+                    *reinterpret_cast<uint2*>(o + p.oq_plane) = make_uint2(__builtin_bit_cast(unsigned, l0), __builtin_bit_cast(unsigned, l1));
+                }
+        }
         if (want_kbar) store(acc1, il, head * 64, p.kbar + krow - orow);
         if (lh == 0) { p.lse[lsoff + own0 + lr] = m_run; p.lse[lsplane + lsoff + own0 + lr] = il; }
     } else if constexpr (DQ) {
@@ -575,6 +592,7 @@ extern "C" int vbg_attn(const vbg_attn_desc* desc, void* stream) {
     VBG_CHECK_ARG(d.tasks && d.seq_len && d.seq_row0 && d.pad_off && d.qkv && d.out && d.lse);
     VBG_CHECK_ARG(d.qkv_ld % 8 == 0 && ((uintptr_t)d.qkv & 15) == 0 && d.qkv_plane % 8 == 0 && 6 * d.qkv_plane < 0x7fffffffll);
     VBG_CHECK_ARG(((uintptr_t)d.kbar & 15) == 0 && d.ldk % 4 == 0);
+    if (d.out_pair) VBG_CHECK_ARG(d.mode == VBG_ATTN_FWD && ((uintptr_t)d.out_pair & 7) == 0 && d.oq_ld % 4 == 0 && d.oq_plane % 4 == 0);
     if (d.out_planes) VBG_CHECK_ARG(d.mode == VBG_ATTN_FWD && ((uintptr_t)d.out_planes & 7) == 0 && d.op_ld % 4 == 0 && d.op_plane % 4 == 0);
     VBG_CHECK_ARG(d.ldo % 4 == 0 && ((uintptr_t)d.out & 15) == 0 && d.ntok_pad % 32 == 0 && ((uintptr_t)d.lse & 15) == 0);
     if (d.mode != VBG_ATTN_FWD) {

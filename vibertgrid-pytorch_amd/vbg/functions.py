@@ -638,7 +638,10 @@ class BertLayerFn(torch.autograd.Function):
             masks = ops.attn_mask(meta, p, seed, sid + 0) if p > 0 else None
             kbar = torch.empty((ntok, hid), device=dev, dtype=f32) if any(ctx.needs_input_grad) else None
             pctx = ops.planes_empty(ntok, hid, dev)
-            ops.attn(meta, ATTN_FWD, pqkv, None, ctxv, lse, None, masks, 1.0 / (dh ** 0.5), p, kbar=kbar, out_planes=pctx)
+            # (all-pair backward: O also as fp16-pair planes -- the B operand of the output projection's weight gradient, saved instead of
+            #  the split pass the backward used to run over the fp32 O)
+            pctxq = ops.pair_empty(ntok, hid, dev) if (pair_bwd and any(ctx.needs_input_grad)) else None
+            ops.attn(meta, ATTN_FWD, pqkv, None, ctxv, lse, None, masks, 1.0 / (dh ** 0.5), p, kbar=kbar, out_planes=pctx, out_pair=pctxq)
         else:
             # scores -> probabilities (in place), grouped over (sequence, head)
             P = torch.empty((meta.s_elems,), device=dev, dtype=f32)
@@ -694,7 +697,8 @@ class BertLayerFn(torch.autograd.Function):
             ctx.pl_shape = (ntok, hid, wi.shape[0])
             if pair_bwd:
                 ctx.masks = masks
-                ctx.save_for_backward(wq, wk, wv, wo, g1, wi, wo2, g2, pqkv.buf, ctxv, xh1, rs1, h, xh2, rs2, xq.buf, px1q.buf, pgq.buf, lse, kbar)
+                ctx.save_for_backward(wq, wk, wv, wo, g1, wi, wo2, g2, pqkv.buf, ctxv, xh1, rs1, h, xh2, rs2, xq.buf, px1q.buf, pgq.buf, lse, kbar,
+                                      None if pctxq is None else pctxq.buf)
             elif flash:
                 ctx.masks = masks
                 ctx.save_for_backward(wq, wk, wv, wo, g1, wi, wo2, g2, pqkv.buf, ctxv, xh1, rs1, h, xh2, rs2, px.buf, pctx.buf, px1.buf, pg.buf, lse, kbar)
@@ -719,7 +723,7 @@ class BertLayerFn(torch.autograd.Function):
         """backward of the all-pair path: every product on two fp16 pieces.  A gradient operand is split by a pass of its own once its
         largest magnitude is known (LayerNorm backward -> fp32 -> vbg_amax -> scaled split with the bias column sums; the GELU-gradient
         product reports the maximum of what it stores), scaled by the power of two of that maximum; products scale back (exact)."""
-        (wq, wk, wv, wo, g1, wi, wo2, g2, bqkv, ctxv, xh1, rs1, h, xh2, rs2, bx, bx1, bg, lse, kbar) = ctx.saved_tensors
+        (wq, wk, wv, wo, g1, wi, wo2, g2, bqkv, ctxv, xh1, rs1, h, xh2, rs2, bx, bx1, bg, lse, kbar, bctxq) = ctx.saved_tensors
         meta = ctx.meta
         eps, p, seed, sid = ctx.cfg
         ntok, hid, inter = ctx.pl_shape
@@ -727,7 +731,8 @@ class BertLayerFn(torch.autograd.Function):
         dev = h.device
         mk = lambda buf, cols: ops.Planes(buf, ntok, cols, buf.shape[2])
         qx, qx1, qg = mk(bx, hid), mk(bx1, hid), mk(bg, inter)
-        qctx = ops.split_planes_pair(ctxv)            # (the attention output as the B operand of the output projection's weight gradient)
+        # (the attention output as the B operand of the output projection's weight gradient: pair planes written by the forward kernel)
+        qctx = mk(bctxq, hid) if bctxq is not None else ops.split_planes_pair(ctxv)
         rbq, rbk, rbv, rbo, rbi, rbo2, rg1, rb1, rg2, rb2 = ctx.b_refs
         rq, rk, rv, ro, ri, ro2 = ctx.w_refs
         tile = lambda n, wide=False: ops.pair_tile(ntok, n, wide)

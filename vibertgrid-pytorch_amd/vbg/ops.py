@@ -1288,7 +1288,7 @@ def attn_mask(meta, p, seed, sid):
     return mq, mk
 
 
-def attn(meta, mode, qkv: Planes, dO, out, lse, delta, masks, scale, p, kbar=None, out_planes=None, o=None, out_amax=None):
+def attn(meta, mode, qkv: Planes, dO, out, lse, delta, masks, scale, p, kbar=None, out_planes=None, o=None, out_amax=None, out_pair=None):
     """one fused attention pass (mode: lib.ATTN_FWD / ATTN_DQ / ATTN_DKV) over all (sequence, head) pairs of the packed batch"""
     d = AttnDesc()
     d.mode, d.heads, d.ntasks, d.max_len = int(mode), meta.heads, meta.ntasks, meta.maxlen
@@ -1306,6 +1306,8 @@ def attn(meta, mode, qkv: Planes, dO, out, lse, delta, masks, scale, p, kbar=Non
         d.o = o.data_ptr()
     if out_planes is not None:            # FWD: the planes of O ride along (the A operand of the output projection)
         d.out_planes, d.op_plane, d.op_ld = out_planes.buf.data_ptr(), out_planes.plane, out_planes.ld
+    if out_pair is not None:              # FWD: ... and as fp16-pair planes (saved for the output projection's weight gradient)
+        d.out_pair, d.oq_plane, d.oq_ld = out_pair.buf.data_ptr(), out_pair.plane, out_pair.ld
     if masks is not None:
         d.mask_q, d.mask_k, d.mask_off = masks[0].data_ptr(), masks[1].data_ptr(), meta.mask_off.data_ptr()
         d.keep_scale = attn_keep_scale(p)
