@@ -33,8 +33,8 @@ bytes_per_step = {
     "softmax_bwd_kernel": 12 * 3 * s_elems * f4,
     # LayerNorm forward: reads x, res; writes y, xhat and the fp16-pair planes of y (4 B / element: the A operand of the next product)
     "dropout_add_ln_fwd_kernel": 24 * (4 * tok + NTOK * HID * 4),
-    # LayerNorm backward (all-pair path): reads dy, xhat; writes dres and dx as fp32 (dx is split by a pass of its own, below)
-    "dropout_add_ln_bwd_kernel": 24 * (4 * tok),
+    # LayerNorm backward (all-pair path, round 4): reads dy, xhat; writes dres and dx as two fp16 planes (4 B / element) scaled by a bound
+    "dropout_add_ln_bwd_kernel": 24 * (3 * tok + NTOK * HID * 4),
     "gelu_bwd_kernel": 12 * 3 * NTOK * 3072 * f4,
     "adamw_kernel": 28 * 108.9e6,
     "sgd_kernel": 20 * 41.8e6,
@@ -50,9 +50,9 @@ bytes_per_step = {
     "normalize_resize_kernel": 2 * B * H * W * 3 * f4,
     "seg_reduce_fwd_kernel": 4096 * HID * f4 + NSEG * HID * f4,
     "seg_reduce_bwd_kernel": 4096 * HID * f4 + NSEG * HID * f4,
-    # gradient operands of the BERT backward (round 3/4 launch set): per layer dfo, dao [ntok, 768], dh [ntok, 3072], dqkv [ntok, 2304] and
-    # the saved attention output [ntok, 768] -- fp32 in, two fp16 planes out (4 + 4 B / element), column sums riding along
-    "split_planes_pair_kernel": 12 * NTOK * (3 * 768 + 3072 + 2304) * 8 + 2 * NTOK * HID * 8,
+    # gradient operands that still take a split pass of their own (end of round 4): d(qkv) [ntok, 2304] per layer, the encoder input and
+    # one more [ntok, 768] tensor per step -- fp32 in, two fp16 planes out (4 + 4 B / element), column sums riding along
+    "split_planes_pair_kernel": 12 * NTOK * 2304 * 8 + 2 * NTOK * HID * 8,
     # fused attention: q / k / v planes (6 B / element) in, O + planes + Kbar out (forward); planes of q, k, v, dO in, dq (dk, dv) out;
     # K / V (Q / dO) are re-streamed once per 128-row block of the other side: 4 blocks at L = 512 (algorithmic = one pass)
     "attn_kernel<0": 12 * (NTOK * 2304 * 6 + NTOK * HID * (4 + 6 + 4)),

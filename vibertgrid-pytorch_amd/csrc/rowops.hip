@@ -249,7 +249,18 @@ __global__ __launch_bounds__(256) void dropout_add_ln_bwd_kernel(
 #pragma unroll
         for (int j = 0; j < LN_V; ++j) gm = fmaxf(gm, fmaxf(fmaxf(fabsf(gam[j].x), fabsf(gam[j].y)), fmaxf(fabsf(gam[j].z), fabsf(gam[j].w))));
         gm = wave_max(gm);
-        for (int i = threadIdx.x; i < rows; i += 256) rm = fmaxf(rm, rstd[i]);
+        {   // max rstd over ALL rows (16 KB at cfg2, L2 resident): float4 loads, all of a thread's loads in flight together
+            const int n4 = (((uintptr_t)rstd & 15) == 0) ? rows >> 2 : 0;
+            const float4* r4 = reinterpret_cast<const float4*>(rstd);
+            float4 v[4];
+            for (int i0 = threadIdx.x; i0 < n4; i0 += 1024) {
+#pragma unroll
+                for (int u = 0; u < 4; ++u) v[u] = (i0 + 256 * u < n4) ? r4[i0 + 256 * u] : make_float4(0.f, 0.f, 0.f, 0.f);
+#pragma unroll
+                for (int u = 0; u < 4; ++u) rm = fmaxf(rm, fmaxf(fmaxf(v[u].x, v[u].y), fmaxf(v[u].z, v[u].w)));
+            }
+            for (int i = 4 * n4 + threadIdx.x; i < rows; i += 256) rm = fmaxf(rm, rstd[i]);
+        }
         rm = block_max(rm, sh_b);
         const float ady = __uint_as_float(vbg_amax_read(dy_amax));
         const float bound = ady * gm * rm * (2.f + sqrtf((float)hidden)) * keep_scale * 1.01f;
