@@ -43,13 +43,17 @@ def set_overlap(on: bool):
     _OVERLAP[0] = bool(on)
 
 
-_WGRAD_STREAM = [os.environ.get("VBG_WGRAD_STREAM", "1") != "0"]
+_WGRAD_STREAM = [os.environ.get("VBG_WGRAD_STREAM", "0") != "0"]
 
 
 def wgrad_stream_enabled() -> bool:
     """the grouped weight-gradient launch of an encoder layer goes on its own stream (it depends on nothing the rest of the
     backward waits for): its 216 tiles and the next layer's data-gradient products share the chip"""
-    return _OVERLAP[0] and _WGRAD_STREAM[0]
+    return _WGRAD_STREAM[0]
+
+
+def set_wgrad_stream(on: bool):
+    _WGRAD_STREAM[0] = bool(on)
 
 
 def side_stream(device, name: str = "side") -> "torch.cuda.Stream":
