@@ -147,7 +147,9 @@ typedef struct vbg_plane_gemm_desc {
        vbg_split_planes_pair, a producer's pair output or Cq below: hi = fp16(x), lo' = fp16((x - hi) 2^11), round to nearest; three
        piece products (hi hi, and lo' hi + hi lo' scaled by 2^-11 in the epilogue).  Half the matrix-core work and 4 instead of 6
        operand bytes per element for operands inside fp16's range (the forward products: LayerNorm / GELU outputs and weights);
-       |x| >= 65520 becomes inf.  form 0: three bf16 planes, six piece products. */
+       |x| >= 65520 becomes inf.  form 0: three bf16 planes, six piece products.
+       form 2 (`amp`: the reference's autocast linears, pipeline/train_val_utils.py:264): the same fp16-pair operands, ONE product on their hi
+       planes (x rounded to fp16; a_amax as in form 1), fp32 accumulation; tiles 128129 / 256128, NT and the weight-gradient products. */
     int form;
     /* optional: the stored value (after bias / GELU) also as fp16-pair planes [2][M][ldq] (plane stride q_plane elements) */
     unsigned short* Cq; long long q_plane; long long ldq;
@@ -293,6 +295,12 @@ int vbg_conv3x3_wprep(const vbg_conv3_wprep_entry* table_dev, const vbg_conv3_wp
 int vbg_conv3x3_pw(const float* x, const void* w_planes, const float* bias, float* y, double* stats, int stats_slots, int B, int H, int W,
                    int Cs, int N, int accumulate, const unsigned* x_amax, float* split_slab, unsigned* split_tickets, int nsplit,
                    int bn, void* stream);
+/* `amp` form of vbg_conv3x3_pw (the reference's `amp: True`, pipeline/train_val_utils.py:264: autocast convolutions): ONE product on the
+ * hi pieces -- x (scaled into range by x_amax as above) and the filter rounded to fp16, fp32 accumulation; the lo planes of the image are
+ * not loaded at 128 filters per tile.  Same arguments, same image. */
+int vbg_conv3x3_pw_amp(const float* x, const void* w_planes, const float* bias, float* y, double* stats, int stats_slots, int B, int H, int W,
+                       int Cs, int N, int accumulate, const unsigned* x_amax, float* split_slab, unsigned* split_tickets, int nsplit,
+                       int bn, void* stream);
 /* bn (vbg_conv3x3_pw / vbg_conv3x3_wprep_bytes): filters per tile the image was written for -- 0: the library's rule above; 64 / 128: the
  * caller's choice (64-filter tiles double the tile count of a launch: the late trunk stages, whose 128-filter tiles do not fill the chip);
  * the launch then runs 128-pixel tiles whatever the tile count, and nsplit > 1 needs N % bn == 0 (slabs of 128 * bn floats). */

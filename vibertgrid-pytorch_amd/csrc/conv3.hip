@@ -142,17 +142,23 @@ struct c3_pipe2 {
 // first read during kw = 2), and the DMA runs one k-tile further ahead of its readers.  A wave's k-tile is then MFMAs + one barrier: what
 // the one-round launches of the trunk (one wave per SIMD, nobody to hide the LDS latency behind) were missing.  Same products in the
 // same order per accumulator: bit-identical.
-template <int BM, int BN, bool F16, int PWM = 0>
+// ONEP (`amp`, PWM = 2 only): ONE product -- the hi pieces of both operands (x rounded to fp16: the operand of the reference's autocast
+// convolution; gradients scaled into range as in the pair form), fp32 accumulation.  The lo pieces are neither written, loaded (128-filter
+// tiles: the hi plane is the first half of a k-tile's block) nor read.
+template <int BM, int BN, bool F16, int PWM = 0, bool ONEP = false>
 __global__ __launch_bounds__(256, 2) void conv3x3_kernel(const conv3_args p) {
     constexpr bool PW = PWM != 0;
     static_assert(!PW || (F16 && BM == 128), "pre-split weights: the fp16-pair form on 128-pixel tiles");
+    static_assert(!ONEP || PWM == 2, "the one-product form exists for the pipelined pre-split kernels");
     constexpr int NT = 256, SKH = 24;
     constexpr int NSB = 4, DPF = NSB - 1;                      // PW: stages of the filter ring / k-tiles in flight
     constexpr int BTILE = 64 * BN;                             // PW: bytes of one k-tile of the filter (2 planes x BN rows x 32 B)
     constexpr int NDB = BN / 64;                               // PW: 1 KiB DMA units per wave and k-tile
+    constexpr int NDBE = (ONEP && NDB == 2) ? 1 : NDB;         // ... that are issued (ONEP at 128 filters: the hi plane = units 0-3 only)
     constexpr int TNF = BN / 64;                               // 32-column fragments per wave
     constexpr int NBI = BN * 4 / NT;                           // filter float4s per thread and tile
     constexpr int NPL = F16 ? 2 : 3;                           // planes per operand tile
+    constexpr int NQ = ONEP ? 1 : NPL;                         // planes that are read
     constexpr int NAI = BM * 4 / NT;                           // activation float4s per thread and super-tile
     constexpr int TM = BM / 64;                                // 32-row fragments per wave (waves 2 x 2: BM / 2 pixels x 64 filters each)
     constexpr int AROWS = BM + BM / 8;                         // + a zero pixel on either side of each image row (W >= 16)
@@ -273,7 +279,7 @@ __global__ __launch_bounds__(256, 2) void conv3x3_kernel(const conv3_args p) {
         const unsigned short* src = p.Wp + (size_t)(((int)tile_n * 9 + b_kh * 3 + b_kw) * nchk + (b_c0 >> 4)) * (BTILE / 2);
         const __amdgpu_buffer_rsrc_t r = c3_rsrc(reinterpret_cast<const float*>(src));
 #pragma unroll
-        for (int i = 0; i < NDB; ++i)
+        for (int i = 0; i < NDBE; ++i)
             __builtin_amdgcn_raw_ptr_buffer_load_lds(r, (c3_lds_ptr)(ring + d_stage * BTILE + dlds[i]), 16, (int)(dvo[i] | inv), 0, 0, 0);
         --d_left;
         d_stage = d_stage + 1 == NSB ? 0 : d_stage + 1;
@@ -429,7 +435,7 @@ __global__ __launch_bounds__(256, 2) void conv3x3_kernel(const conv3_args p) {
         store_a(0);
 #pragma unroll
         for (int d = 0; d < NSB; ++d) issue_b();
-        asm volatile("s_waitcnt vmcnt(%0) lgkmcnt(0)" ::"n"(2 * NDB) : "memory");    // k-tiles 0 and 1 have landed
+        asm volatile("s_waitcnt vmcnt(%0) lgkmcnt(0)" ::"n"(2 * NDBE) : "memory");    // k-tiles 0 and 1 have landed
         __builtin_amdgcn_s_barrier();
         c3_u32x4 fA[2][NPL][TM], fB[2][NPL][TNF];
         auto read_frags = [&](auto par_tag, int abuf, int stage, int kw) {
@@ -437,7 +443,7 @@ __global__ __launch_bounds__(256, 2) void conv3x3_kernel(const conv3_args p) {
             const c3_u32x4* as = reinterpret_cast<const c3_u32x4*>(As + abuf * ASZ);
             const unsigned char* bsb = ring + stage * BTILE + (wn * TNF) * 1024 + lk * 512 + lr * 16;
 #pragma unroll
-            for (int q = 0; q < NPL; ++q) {
+            for (int q = 0; q < NQ; ++q) {
 #pragma unroll
                 for (int i = 0; i < TM; ++i) fA[P][q][i] = as[q * (PA / 4) + (arow[i] + kw) * (SKH / 8) + lk];
 #pragma unroll
@@ -447,7 +453,7 @@ __global__ __launch_bounds__(256, 2) void conv3x3_kernel(const conv3_args p) {
         auto mma_set = [&](auto par_tag) {
             constexpr int P = decltype(par_tag)::value;
 #pragma unroll
-            for (int t = 0; t < 3; ++t)
+            for (int t = ONEP ? 2 : 0; t < 3; ++t)
 #pragma unroll
                 for (int i = 0; i < TM; ++i)
 #pragma unroll
@@ -476,12 +482,12 @@ __global__ __launch_bounds__(256, 2) void conv3x3_kernel(const conv3_args p) {
             for (int i = 0; i < NAI; ++i) {
                 const int o = a_lrow[i] * (SKH / 2) + kc / 2;
                 *reinterpret_cast<uint2*>(&dst[o]) = sh[i];
-                *reinterpret_cast<uint2*>(&dst[o + PA]) = sl[i];
+                if constexpr (!ONEP) *reinterpret_cast<uint2*>(&dst[o + PA]) = sl[i];
             }
             if (wide && tid < 8) {
                 const int o = h_row * (SKH / 2) + kc / 2;
                 *reinterpret_cast<uint2*>(&dst[o]) = sh[NAI];
-                *reinterpret_cast<uint2*>(&dst[o + PA]) = sl[NAI];
+                if constexpr (!ONEP) *reinterpret_cast<uint2*>(&dst[o + PA]) = sl[NAI];
             }
         };
         using p0 = std::integral_constant<int, 0>;
@@ -496,8 +502,8 @@ __global__ __launch_bounds__(256, 2) void conv3x3_kernel(const conv3_args p) {
             else read_frags(p0{}, KW < 2 ? (s & 1) : ((s + 1) & 1), nst, KW < 2 ? KW + 1 : 0);
             if constexpr (P == 0) mma_set(p0{}); else mma_set(p1{});
             if constexpr (KW == 1) split_a();
-            constexpr int NM = 3 * TM * TNF, NRD = NPL * (TM + TNF);
-            c3_pipe2<0, NM, NRD, KW == 1 ? (NAI + 1) * 10 : 0, 0>::run();
+            constexpr int NM = (ONEP ? 1 : 3) * TM * TNF, NRD = NQ * (TM + TNF);
+            c3_pipe2<0, NM, NRD, KW == 1 ? (NAI + 1) * (ONEP ? 6 : 10) : 0, 0>::run();
             __builtin_amdgcn_sched_barrier(0);
             if constexpr (KW == 1) write_a((s + 1) & 1);   // super-tile s + 1: read from k-tile (s, 2) on
             // (activation loads in FRONT of the DMA: loads return in order, and waiting for these registers in the next k-tile must not
@@ -506,10 +512,10 @@ __global__ __launch_bounds__(256, 2) void conv3x3_kernel(const conv3_args p) {
             issue_b();                                      // k-tile t + 4 into this k-tile's stage
             if constexpr (KW == 0) {
                 // k-tile t + 2 has landed: t + 3, t + 4 and the activation loads just issued may stay in flight
-                if (wide) asm volatile("s_waitcnt vmcnt(%0) lgkmcnt(0)" ::"n"(2 * NDB + NAI + 1) : "memory");
-                else asm volatile("s_waitcnt vmcnt(%0) lgkmcnt(0)" ::"n"(2 * NDB + NAI) : "memory");
+                if (wide) asm volatile("s_waitcnt vmcnt(%0) lgkmcnt(0)" ::"n"(2 * NDBE + NAI + 1) : "memory");
+                else asm volatile("s_waitcnt vmcnt(%0) lgkmcnt(0)" ::"n"(2 * NDBE + NAI) : "memory");
             } else {
-                asm volatile("s_waitcnt vmcnt(%0) lgkmcnt(0)" ::"n"(2 * NDB) : "memory");
+                asm volatile("s_waitcnt vmcnt(%0) lgkmcnt(0)" ::"n"(2 * NDBE) : "memory");
             }
             __builtin_amdgcn_s_barrier();
             bst = nst;
@@ -579,7 +585,7 @@ __global__ __launch_bounds__(256, 2) void conv3x3_kernel(const conv3_args p) {
 #pragma unroll
             for (int r = 0; r < 16; ++r)
                 Ct[(wm * (BM / 2) + i * 32 + (r & 3) + 8 * (r >> 2) + 4 * lk) * CTS + wn * (BN / 2) + j * 32 + lr] =
-                    F16 ? (acc[i][j][r] + acx[i][j][r] * (1.f / 2048.f)) * a_sc.y : acc[i][j][r];
+                    ONEP ? acc[i][j][r] * a_sc.y : (F16 ? (acc[i][j][r] + acx[i][j][r] * (1.f / 2048.f)) * a_sc.y : acc[i][j][r]);
     __syncthreads();
     constexpr int QN = BN / 4;
     // Split form: the block's partial tile goes to its slab (write-through stores), every wave drains its stores, and one relaxed
@@ -759,8 +765,11 @@ typedef __attribute__((address_space(3))) unsigned char* c3_lds_bytes;
 // to [2^13, 2^14) (exact), three piece products (lo hi, hi lo, hi hi) into the ONE accumulator of a tap (nine taps x two accumulators
 // would not fit the register file), the result scaled back in the epilogue.  Elements down to 2^-17 of the tensor's maximum keep 22
 // significant bits (lo is a normal fp16 there); below that the absolute error is <= 2^-25 (2^-39 of the maximum).
-template <int WCO, bool F16, bool ROI = false>
+// ONEP (`amp`): the hi pieces only, one product per tap (the lo planes are neither written nor read).
+template <int WCO, bool F16, bool ROI = false, bool ONEP = false>
 __global__ __launch_bounds__(256, 2) void conv3x3_wgrad_kernel(const conv3w_args p) {
+    static_assert(!ONEP || F16, "the one-product form is the fp16 form's hi x hi product");
+    constexpr int NQ = ONEP ? 1 : (F16 ? 2 : 3);               // planes that are written and read
     constexpr int NT = 256, WCI = 4 / WCO, CO = 32 * WCO, CI = 32 * WCI;
     constexpr int NPL = F16 ? 2 : 3;
     // bytes of a pixel row of the dY / X image: an odd multiple of 64 B (16 banks), so that the four consecutive pixel rows a
@@ -870,7 +879,7 @@ __global__ __launch_bounds__(256, 2) void conv3x3_wgrad_kernel(const conv3w_args
         const f16x2_t l0 = __builtin_convertvector(v0 - __builtin_convertvector(h0, f32x2_t), f16x2_t);
         const f16x2_t l1 = __builtin_convertvector(v1 - __builtin_convertvector(h1, f32x2_t), f16x2_t);
         *reinterpret_cast<uint2*>(dst) = make_uint2(__builtin_bit_cast(unsigned, h0), __builtin_bit_cast(unsigned, h1));
-        *reinterpret_cast<uint2*>(dst + PL) = make_uint2(__builtin_bit_cast(unsigned, l0), __builtin_bit_cast(unsigned, l1));
+        if constexpr (!ONEP) *reinterpret_cast<uint2*>(dst + PL) = make_uint2(__builtin_bit_cast(unsigned, l0), __builtin_bit_cast(unsigned, l1));
     };
     auto store_chunk = [&](int stage) {
         unsigned char* sa = smem + stage * STAGE;
@@ -916,16 +925,16 @@ __global__ __launch_bounds__(256, 2) void conv3x3_wgrad_kernel(const conv3w_args
         c3_lds_bytes bs = (c3_lds_bytes)(smem + stage * STAGE + NPL * PA) + tb;
         c3_u32x4 fa[NPL];
 #pragma unroll
-        for (int q = 0; q < NPL; ++q) fa[q] = frag(as + q * PA, RSA);
+        for (int q = 0; q < NQ; ++q) fa[q] = frag(as + q * PA, RSA);
         // piece products, smallest first; F16: (lo,hi) (hi,lo) (hi,hi)
         constexpr int qa[6] = {F16 ? 1 : 2, 0, F16 ? 0 : 1, 1, 0, 0}, qb[6] = {0, F16 ? 1 : 2, F16 ? 0 : 1, 0, 1, 0};
 #pragma unroll
         for (int tap = 0; tap < 9; ++tap) {
             c3_u32x4 fb[NPL];
 #pragma unroll
-            for (int q = 0; q < NPL; ++q) fb[q] = frag(bs + q * PB + ((tap / 3) * pitch + tap % 3) * RSB, RSB);
+            for (int q = 0; q < NQ; ++q) fb[q] = frag(bs + q * PB + ((tap / 3) * pitch + tap % 3) * RSB, RSB);
 #pragma unroll
-            for (int t = 0; t < (F16 ? 3 : 6); ++t) {
+            for (int t = ONEP ? 2 : 0; t < (F16 ? 3 : 6); ++t) {
                 if constexpr (F16)
                     acc[tap] = __builtin_amdgcn_mfma_f32_32x32x16_f16(__builtin_bit_cast(c3_f16x8, fa[qa[t]]), __builtin_bit_cast(c3_f16x8, fb[qb[t]]),
                                                                       acc[tap], 0, 0, 0);
@@ -998,7 +1007,7 @@ extern "C" int vbg_conv3x3_wgrad(const float* dy, const float* x, float* dw, flo
                                  const unsigned* dy_amax, const unsigned* x_amax, void* stream) {
     const bool roi = H == 7 && W == 7;                          // [B, 7, 7, C] region maps
     VBG_CHECK_ARG(dy && x && dw && B > 0 && H > 0 && (roi || (W >= 16 && W % 16 == 0)));
-    VBG_CHECK_ARG(form == 0 || (form == 1 && dy_amax && x_amax));
+    VBG_CHECK_ARG(form == 0 || ((form == 1 || form == 2) && dy_amax && x_amax));          // (2: `amp`, the hi x hi product only)
     VBG_CHECK_ARG(Cs % 32 == 0 && Cout % 64 == 0);
     VBG_CHECK_ARG((((uintptr_t)x) & 15) == 0 && (((uintptr_t)dy) & 15) == 0);
     VBG_CHECK_ARG((long long)(3 * W + 18) * Cs < (1ll << 28) && (long long)16 * Cout < (1ll << 28));
@@ -1016,13 +1025,16 @@ extern "C" int vbg_conv3x3_wgrad(const float* dy, const float* x, float* dw, flo
     a.per = (a.nchunks + nsplit - 1) / nsplit;
     if (roi) {
         VBG_CHECK_ARG(wide);
-        if (form == 1) { VBG_LAUNCH((vbg::conv3x3_wgrad_kernel<4, true, true>), dim3(nsplit, Cs / 32, Cout / 128), dim3(256), 0, (hipStream_t)stream, a); }
+        if (form == 2) { VBG_LAUNCH((vbg::conv3x3_wgrad_kernel<4, true, true, true>), dim3(nsplit, Cs / 32, Cout / 128), dim3(256), 0, (hipStream_t)stream, a); }
+        else if (form == 1) { VBG_LAUNCH((vbg::conv3x3_wgrad_kernel<4, true, true>), dim3(nsplit, Cs / 32, Cout / 128), dim3(256), 0, (hipStream_t)stream, a); }
         else { VBG_LAUNCH((vbg::conv3x3_wgrad_kernel<4, false, true>), dim3(nsplit, Cs / 32, Cout / 128), dim3(256), 0, (hipStream_t)stream, a); }
     } else if (wide) {
-        if (form == 1) { VBG_LAUNCH((vbg::conv3x3_wgrad_kernel<4, true>), dim3(nsplit, Cs / 32, Cout / 128), dim3(256), 0, (hipStream_t)stream, a); }
+        if (form == 2) { VBG_LAUNCH((vbg::conv3x3_wgrad_kernel<4, true, false, true>), dim3(nsplit, Cs / 32, Cout / 128), dim3(256), 0, (hipStream_t)stream, a); }
+        else if (form == 1) { VBG_LAUNCH((vbg::conv3x3_wgrad_kernel<4, true>), dim3(nsplit, Cs / 32, Cout / 128), dim3(256), 0, (hipStream_t)stream, a); }
         else { VBG_LAUNCH((vbg::conv3x3_wgrad_kernel<4, false>), dim3(nsplit, Cs / 32, Cout / 128), dim3(256), 0, (hipStream_t)stream, a); }
     } else {
-        if (form == 1) { VBG_LAUNCH((vbg::conv3x3_wgrad_kernel<2, true>), dim3(nsplit, Cs / 64, Cout / 64), dim3(256), 0, (hipStream_t)stream, a); }
+        if (form == 2) { VBG_LAUNCH((vbg::conv3x3_wgrad_kernel<2, true, false, true>), dim3(nsplit, Cs / 64, Cout / 64), dim3(256), 0, (hipStream_t)stream, a); }
+        else if (form == 1) { VBG_LAUNCH((vbg::conv3x3_wgrad_kernel<2, true>), dim3(nsplit, Cs / 64, Cout / 64), dim3(256), 0, (hipStream_t)stream, a); }
         else { VBG_LAUNCH((vbg::conv3x3_wgrad_kernel<2, false>), dim3(nsplit, Cs / 64, Cout / 64), dim3(256), 0, (hipStream_t)stream, a); }
     }
     if (slab) {
@@ -1095,12 +1107,20 @@ extern "C" int vbg_conv3x3_pw(const float* x, const void* w_planes, const float*
                         split_tickets, nsplit, stream, bn);
 }
 
+extern "C" int vbg_conv3x3_pw_amp(const float* x, const void* w_planes, const float* bias, float* y, double* stats, int stats_slots, int B, int H,
+                                  int W, int Cs, int N, int accumulate, const unsigned* x_amax, float* split_slab, unsigned* split_tickets,
+                                  int nsplit, int bn, void* stream) {
+    VBG_CHECK_ARG(w_planes && (((uintptr_t)w_planes) & 15) == 0 && (bn == 0 || bn == 64 || bn == 128));
+    return conv3x3_impl(x, nullptr, (const unsigned short*)w_planes, bias, y, stats, stats_slots, B, H, W, Cs, N, accumulate, 2, x_amax, split_slab,
+                        split_tickets, nsplit, stream, bn);
+}
+
 static int conv3x3_impl(const float* x, const float* w, const unsigned short* wp, const float* bias, float* y, double* stats, int stats_slots,
                         int B, int H, int W, int Cs, int N, int accumulate, int form, const unsigned* x_amax, float* split_slab,
                         unsigned* split_tickets, int nsplit, void* stream, int bn_req) {
-    VBG_CHECK_ARG(form == 0 || form == 1);
+    VBG_CHECK_ARG(form == 0 || form == 1 || (form == 2 && wp));          // (2: the one-product `amp` form of the pre-split kernels)
     VBG_CHECK_ARG(bn_req == 0 || wp);
-    VBG_CHECK_ARG(!x_amax || form == 1);
+    VBG_CHECK_ARG(!x_amax || form >= 1);
     VBG_CHECK_ARG(x && (w || wp) && y && B > 0 && H > 0);
     const bool roi = H == 7 && W == 7;                          // [B, 7, 7, C] region maps: two images per 128-slot tile
     VBG_CHECK_ARG(roi || (W >= 16 && W <= 4096 && (W & (W - 1)) == 0));
@@ -1135,7 +1155,10 @@ static int conv3x3_impl(const float* x, const float* w, const unsigned short* wp
         VBG_CHECK_ARG(big && (bn_req || bn == conv3_pw_bn(N)));
         // VBG_CONV3_PIPE=0: the lockstep k-loop of the PW kernels (A/B switch of the software-pipelined loop)
         static const bool pipe = !(getenv("VBG_CONV3_PIPE") && atoi(getenv("VBG_CONV3_PIPE")) == 0);
-        if (pipe) {
+        if (form == 2) {
+            if (n64) { VBG_LAUNCH((vbg::conv3x3_kernel<128, 64, true, 2, true>), g, dim3(256), 0, (hipStream_t)stream, a); }
+            else { VBG_LAUNCH((vbg::conv3x3_kernel<128, 128, true, 2, true>), g, dim3(256), 0, (hipStream_t)stream, a); }
+        } else if (pipe) {
             if (n64) { VBG_LAUNCH((vbg::conv3x3_kernel<128, 64, true, 2>), g, dim3(256), 0, (hipStream_t)stream, a); }
             else { VBG_LAUNCH((vbg::conv3x3_kernel<128, 128, true, 2>), g, dim3(256), 0, (hipStream_t)stream, a); }
         } else {

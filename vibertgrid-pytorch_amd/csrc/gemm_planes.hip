@@ -56,12 +56,14 @@ typedef __attribute__((address_space(3))) pg_v4s* pg_lds_v4s;
 // inf from 65520 on -- and three piece products: hi hi into the main accumulators, lo' hi + hi lo' into a second set that the epilogue
 // scales by 2^-11.  Half the matrix-core work and 4 instead of 6 operand bytes per element, for operands inside fp16's range: the
 // forward products, whose operands are LayerNorm / GELU outputs and weights.
+// FORM = 2 (`amp`): the same fp16-pair operands, ONE product -- only the hi planes are loaded (x rounded to fp16, the reference's autocast
+// operand; gradients scaled into range by their amax slots exactly as in FORM 1), fp32 accumulation.
 template <int BM, int BN, int WGM, int WGN, int NST, bool TRANS, bool PP = true, int FORM = 0>
 __global__ __launch_bounds__(WGM * WGN * 64) void plane_gemm_kernel(const vbg_plane_gemm_desc p) {
     static_assert(!TRANS || ((BM == 128 || BM == 256) && BN == 128), "TN: 128- or 256-column A tiles, 128-column B tiles");
     constexpr int NW = WGM * WGN, NT = NW * 64;
     constexpr int BK = 32;
-    constexpr int NPL = FORM ? 2 : 3;                          // planes per operand
+    constexpr int NPL = FORM == 2 ? 1 : (FORM ? 2 : 3);        // planes per operand that are loaded
     static_assert(FORM == 0 || (NW == 8 && (TRANS || PP)), "the fp16-pair form exists for the 8-wave tiles (NT: ping-pong loop)");
     constexpr int WM = BM / WGM, WN = BN / WGN, TM = WM / 32, TN = WN / 32;
     constexpr int PA = BM * 64, PB = BN * 64;                  // bytes of one plane of a stage (64 B per row)
@@ -233,7 +235,7 @@ __global__ __launch_bounds__(WGM * WGN * 64) void plane_gemm_kernel(const vbg_pl
     for (int i = 0; i < TM; ++i) ta[i] = (8 * lk + (i16 >> 2)) * RSA + (((wm * TM + i) ^ (i16 >> 2)) << 6) + (16 * tg + 4 * (i16 & 3)) * 2;
 #pragma unroll
     for (int j = 0; j < TN; ++j) tb[j] = (8 * lk + (i16 >> 2)) * RSB + (((wn * TN + j) ^ (i16 >> 2)) << 6) + (16 * tg + 4 * (i16 & 3)) * 2;
-    f32x16 acc[TM][TN], acx[FORM ? TM : 1][FORM ? TN : 1];         // (FORM 1: the cross products, scaled by 2^11)
+    f32x16 acc[TM][TN], acx[FORM == 1 ? TM : 1][FORM == 1 ? TN : 1];         // (FORM 1: the cross products, scaled by 2^11)
 #pragma unroll
     for (int i = 0; i < TM; ++i)
 #pragma unroll
@@ -241,7 +243,7 @@ __global__ __launch_bounds__(WGM * WGN * 64) void plane_gemm_kernel(const vbg_pl
 #pragma unroll
             for (int r = 0; r < 16; ++r) {
                 acc[i][j][r] = 0.f;
-                if constexpr (FORM) acx[i][j][r] = 0.f;
+                if constexpr (FORM == 1) acx[i][j][r] = 0.f;
             }
 
     pg_u32x4 fa0[NPL][TM], fb0[NPL][TN], fa1[NPL][TM], fb1[NPL][TN];       // fragment sets of k-step 0 / 1 of a tile
@@ -280,7 +282,13 @@ __global__ __launch_bounds__(WGM * WGN * 64) void plane_gemm_kernel(const vbg_pl
     };
     // piece products, smallest first: (lo,hi) (hi,lo) (mid,mid) (mid,hi) (hi,mid) (hi,hi); FORM 1: (lo',hi) (hi,lo') -> cross sums, (hi,hi)
     auto mma = [&](const pg_u32x4 (&fa)[NPL][TM], const pg_u32x4 (&fb)[NPL][TN]) {
-        if constexpr (FORM) {
+        if constexpr (FORM == 2) {
+#pragma unroll
+            for (int i = 0; i < TM; ++i)
+#pragma unroll
+                for (int j = 0; j < TN; ++j)
+                    acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_f16(__builtin_bit_cast(pg_f16x8, fa[0][i]), __builtin_bit_cast(pg_f16x8, fb[0][j]), acc[i][j], 0, 0, 0);
+        } else if constexpr (FORM) {
 #pragma unroll
             for (int t = 0; t < 3; ++t)
 #pragma unroll
@@ -312,7 +320,7 @@ __global__ __launch_bounds__(WGM * WGN * 64) void plane_gemm_kernel(const vbg_pl
     // is read -- no bubble after the barrier.  NST = 2 (the 8-wave tile, 2 waves per SIMD cover each other): tile t+1 travels
     // during tile t, barrier at the end of the iteration.
     constexpr int NIW = NIA + NIB;
-    constexpr int NMMA = (FORM ? 3 : 6) * TM * TN, NRD = (TRANS ? 2 * NPL : NPL) * (TM + TN);
+    constexpr int NMMA = (FORM == 2 ? 1 : (FORM ? 3 : 6)) * TM * TN, NRD = (TRANS ? 2 * NPL : NPL) * (TM + TN);
     // ---- ping-pong schedule of the 8-wave NT tiles --------------------------------------------------------------------------
     // Waves w and w + 4 of a workgroup share a SIMD (measured: tools/probes/pingpong_gemm_probe.hip prints HW_ID).  In lockstep both
     // issue their DMA, read their fragments and then want the matrix pipe at the same moments: matrix-pipe busy 0.40-0.47 of a full
@@ -460,7 +468,7 @@ __global__ __launch_bounds__(WGM * WGN * 64) void plane_gemm_kernel(const vbg_pl
 #pragma unroll
             for (int r = 0; r < 16; ++r)
                 Ct[(wm * WM + i * 32 + (r & 3) + 8 * (r >> 2) + 4 * lk) * CTS + wn * WN + j * 32 + lr] =
-                    (FORM ? acc[i][j][r] + acx[FORM ? i : 0][FORM ? j : 0][r] * (1.f / 2048.f) : acc[i][j][r]) * alpha;
+                    (FORM == 1 ? acc[i][j][r] + acx[FORM == 1 ? i : 0][FORM == 1 ? j : 0][r] * (1.f / 2048.f) : acc[i][j][r]) * alpha;
     __syncthreads();
     constexpr int QN = BN / 4;
     // optional bf16 planes of the stored value (the A operand of the next product): [3][M][ldp], K-contiguous = along n here
@@ -1290,7 +1298,7 @@ static bool pg_pingpong() {
     return on;
 }
 
-template <int BM, int BN, int WGM, int WGN, int NST, bool TRANS = false>
+template <int BM, int BN, int WGM, int WGN, int NST, bool TRANS = false, int FORM = 1>
 static void pg_launch_pair(const vbg_plane_gemm_desc& d, hipStream_t s, hipEvent_t e0, hipEvent_t e1) {
     dim3 g(cdiv(d.M, BM), cdiv(d.N, BN), 1);
     if (d.ngroups > 0) {
@@ -1299,8 +1307,8 @@ static void pg_launch_pair(const vbg_plane_gemm_desc& d, hipStream_t s, hipEvent
         g = dim3(total, 1, 1);
     }
     (void)hipGetLastError();
-    if (e0 && e1) hipExtLaunchKernelGGL((plane_gemm_kernel<BM, BN, WGM, WGN, NST, TRANS, true, 1>), g, dim3(WGM * WGN * 64), 0, s, e0, e1, 0, d);
-    else hipLaunchKernelGGL((plane_gemm_kernel<BM, BN, WGM, WGN, NST, TRANS, true, 1>), g, dim3(WGM * WGN * 64), 0, s, d);
+    if (e0 && e1) hipExtLaunchKernelGGL((plane_gemm_kernel<BM, BN, WGM, WGN, NST, TRANS, true, FORM>), g, dim3(WGM * WGN * 64), 0, s, e0, e1, 0, d);
+    else hipLaunchKernelGGL((plane_gemm_kernel<BM, BN, WGM, WGN, NST, TRANS, true, FORM>), g, dim3(WGM * WGN * 64), 0, s, d);
 }
 
 template <int BM, int BN, int WGM, int WGN, int NST, bool TRANS = false>
@@ -1372,27 +1380,37 @@ static int plane_gemm_dispatch(const vbg_plane_gemm_desc* desc, void* stream, vo
     if (d.M == 0 || d.N == 0) return VBG_OK;
     hipStream_t s = (hipStream_t)stream;
     int tile = d.tile;
-    if (d.form == 1) {
-        // two fp16 planes per operand (csrc/gemm_planes.hip FORM 1): the 8-wave tiles only
+    if (d.form == 1 || d.form == 2) {
+        // two fp16 planes per operand (csrc/gemm_planes.hip FORM 1; FORM 2 = `amp`: their hi planes only, one product): the 8-wave tiles only
         VBG_CHECK_ARG(d.splitk == 1 && !(d.sk_ws && d.sk_cnt) && (d.ngroups == 0 || d.trans));
         // two planes per operand leave room for one more LDS stage than the three-plane form has (128 x 128: 4 x 32 KB, 256 x 128:
         // 3 x 48 KB): a deeper ring hides the Infinity-Cache round trips of the row pieces an XCD touches first.  VBG_PAIR_DEEP=0: the
         // stage counts of the three-plane kernels (A/B switch)
         static const bool deep = !(getenv("VBG_PAIR_DEEP") && atoi(getenv("VBG_PAIR_DEEP")) == 0);
+        hipEvent_t ev0 = (hipEvent_t)e0, ev1 = (hipEvent_t)e1;
+        if (d.form == 2) {
+            if (d.trans) {
+                if (tile == 256128) pg_launch_pair<256, 128, 4, 2, 3, true, 2>(d, s, ev0, ev1);
+                else pg_launch_pair<128, 128, 4, 2, 3, true, 2>(d, s, ev0, ev1);
+            } else if (tile == 256128) pg_launch_pair<256, 128, 4, 2, 3, false, 2>(d, s, ev0, ev1);
+            else if (tile == 128129 || tile == 0) pg_launch_pair<128, 128, 4, 2, 4, false, 2>(d, s, ev0, ev1);
+            else return VBG_EARG;
+            VBG_LAUNCH_RET();
+        }
         if (d.trans) {
             if (tile == 256128) {
-                if (deep) pg_launch_pair<256, 128, 4, 2, 3, true>(d, s, (hipEvent_t)e0, (hipEvent_t)e1);
-                else pg_launch_pair<256, 128, 4, 2, 2, true>(d, s, (hipEvent_t)e0, (hipEvent_t)e1);
-            } else pg_launch_pair<128, 128, 4, 2, 3, true>(d, s, (hipEvent_t)e0, (hipEvent_t)e1);
+                if (deep) pg_launch_pair<256, 128, 4, 2, 3, true>(d, s, ev0, ev1);
+                else pg_launch_pair<256, 128, 4, 2, 2, true>(d, s, ev0, ev1);
+            } else pg_launch_pair<128, 128, 4, 2, 3, true>(d, s, ev0, ev1);
             VBG_LAUNCH_RET();
         }
         if (tile == 256128) {
-            if (deep) pg_launch_pair<256, 128, 4, 2, 3>(d, s, (hipEvent_t)e0, (hipEvent_t)e1);
-            else pg_launch_pair<256, 128, 4, 2, 2>(d, s, (hipEvent_t)e0, (hipEvent_t)e1);
-        } else if (tile == 128130) pg_launch_pair<128, 128, 2, 4, 3>(d, s, (hipEvent_t)e0, (hipEvent_t)e1);
+            if (deep) pg_launch_pair<256, 128, 4, 2, 3>(d, s, ev0, ev1);
+            else pg_launch_pair<256, 128, 4, 2, 2>(d, s, ev0, ev1);
+        } else if (tile == 128130) pg_launch_pair<128, 128, 2, 4, 3>(d, s, ev0, ev1);
         else if (tile == 128129 || tile == 0) {
-            if (deep) pg_launch_pair<128, 128, 4, 2, 4>(d, s, (hipEvent_t)e0, (hipEvent_t)e1);
-            else pg_launch_pair<128, 128, 4, 2, 3>(d, s, (hipEvent_t)e0, (hipEvent_t)e1);
+            if (deep) pg_launch_pair<128, 128, 4, 2, 4>(d, s, ev0, ev1);
+            else pg_launch_pair<128, 128, 4, 2, 3>(d, s, ev0, ev1);
         } else return VBG_EARG;
         VBG_LAUNCH_RET();
     }

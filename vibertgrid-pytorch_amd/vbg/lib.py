@@ -99,6 +99,7 @@ SIGNATURES = {
     "vbg_conv3x3": (c_int, [c_vp, c_vp, c_vp, c_vp, c_vp, c_int, c_int, c_int, c_int, c_int, c_int, c_int, c_int, c_vp, c_vp, c_vp, c_int, c_vp]),
     "vbg_conv3x3_split": (c_int, [c_int, c_int, c_int, c_int, c_int]),
     "vbg_conv3x3_pw": (c_int, [c_vp, c_vp, c_vp, c_vp, c_vp, c_int, c_int, c_int, c_int, c_int, c_int, c_int, c_vp, c_vp, c_vp, c_int, c_int, c_vp]),
+    "vbg_conv3x3_pw_amp": (c_int, [c_vp, c_vp, c_vp, c_vp, c_vp, c_int, c_int, c_int, c_int, c_int, c_int, c_int, c_vp, c_vp, c_vp, c_int, c_int, c_vp]),
     "vbg_conv3x3_wprep": (c_int, [c_vp, c_vp, c_int, c_vp]),
     "vbg_conv3x3_wprep_bytes": (c_ll, [c_int, c_int, c_int, c_int]),
     "vbg_amax": (c_int, [c_vp, c_ll, c_vp, c_vp]),

@@ -236,7 +236,7 @@ def set_pair(on: bool, force: bool = False):
 
 
 def pair_enabled() -> bool:
-    return _PAIR[0] and _PLANES[0] and _SPLIT3[0] and not _AMP[0]
+    return _PAIR[0] and _PLANES[0] and _SPLIT3[0] and not _amp_generic()
 
 
 _PAIR_BWD = [os.environ.get("VBG_PAIR_BWD", "1") != "0"]
@@ -315,7 +315,7 @@ def plane_gemm(a: Planes, b: Planes, out=None, *, bias=None, epi=EPI_NONE, C2=No
     d.epi, d.alpha, d.accumulate, d.splitk, d.tile = epi, float(alpha), int(bool(accumulate)), int(splitk), int(tile)
     if form:                               # a, b: fp16-pair planes [2][rows][ld]; a_amax: the slot a's planes were scaled by
         assert a.buf.shape[0] == 2 and b.buf.shape[0] == 2
-        d.form = 1
+        d.form = 2 if _AMP[0] else 1       # (autocast region: the hi planes only, one product)
         d.a_amax = None if a_amax is None else a_amax.data_ptr()
     else:
         assert a.buf.shape[0] == 3 and b.buf.shape[0] == 3
@@ -330,7 +330,7 @@ def plane_gemm(a: Planes, b: Planes, out=None, *, bias=None, epi=EPI_NONE, C2=No
     if colsum_out is not None:             # += column sums of the stored values (a bias gradient)
         d.colsum = colsum_out.data_ptr()
     if _DISPATCH[0] is not None:
-        _seen("plane_gemm:pair" if form else "plane_gemm:bf16x3")
+        _seen(("plane_gemm:onep" if _AMP[0] else "plane_gemm:pair") if form else "plane_gemm:bf16x3")
         _seen(f"plane_gemm:tile{int(tile)}")
     if _STREAMK[0] and not form and c_amax is None and colsum_out is None and not trans and splitk == 1 and tile in (128129, 128130):
         ws, cnt, ncu = _sk_workspace(a.buf.device)
@@ -339,7 +339,7 @@ def plane_gemm(a: Planes, b: Planes, out=None, *, bias=None, epi=EPI_NONE, C2=No
     if prof is not None and not trans and prof.match(OP_DENSE_K, OP_DENSE_K, False):
         e0, e1 = prof.events()
         check(lib.vbg_plane_gemm_timed(C.byref(d), _stream(), e0, e1), "vbg_plane_gemm_timed")
-        prof.add(2.0 * d.M * d.N * (a.rows if trans else a.cols), e0, e1, 3 if form else 6)
+        prof.add(2.0 * d.M * d.N * (a.rows if trans else a.cols), e0, e1, (1 if _AMP[0] else 3) if form else 6)
         return out
     check(lib.vbg_plane_gemm(C.byref(d), _stream()), "vbg_plane_gemm")
     return out
@@ -397,7 +397,7 @@ def plane_gemm_grouped(problems, *, trans=True, accumulate=True, tile=0, alpha=1
         assert k is None or k == kk, "grouped products share the reduction length"
         k = kk
     d.K = k
-    d.form = int(bool(form))
+    d.form = (2 if _AMP[0] else 1) if form else 0       # (autocast region: the hi planes only, one product)
     check(lib.vbg_plane_gemm(C.byref(d), _stream()), "vbg_plane_gemm (grouped)")
 
 
@@ -411,7 +411,7 @@ def set_planes(on: bool):
 
 
 def planes_enabled() -> bool:
-    return _PLANES[0] and _SPLIT3[0] and not _AMP[0]
+    return _PLANES[0] and _SPLIT3[0] and not _amp_generic()
 
 
 _FLASH = [os.environ.get("VBG_FLASH", "1") != "0"]
@@ -541,6 +541,29 @@ _FORCE = [0, 0]
 # dtype and no loss scaling is needed for range (a GradScaler passed by the caller keeps working on the fp32 gradients).
 # ViBERTgridNet.forward latches torch.is_autocast_enabled() here; the backward of that forward sees the same setting.
 _AMP = [False]
+# Round 4: inside an autocast region the FAST kernels run in a one-product form instead of handing the work to the generic kernels:
+# the fp16-pair plane products (BERT linears, forward / data gradient / weight gradient) and the pre-split-filter row-reuse
+# convolutions (forward, input gradient, weight gradient) multiply the hi pieces only -- the operand rounded to fp16, which IS the
+# operand of the reference's fp16 autocast (pipeline/train_val_utils.py:264), gradients scaled into range by their amax slots as in
+# the pair form -- with fp32 accumulation; everything else (1x1 convolutions, heads, stem) stays on the bf16 form of csrc/gemm.hip.
+# VBG_AMP_FAST=0: every product of an autocast region on the generic kernels (rounds 1-3).
+_AMP_FAST = [os.environ.get("VBG_AMP_FAST", "1") != "0"]
+
+
+def set_amp_fast(on: bool):
+    _AMP_FAST[0] = bool(on)
+
+
+def _amp_generic() -> bool:
+    """autocast region AND the fast kernels' one-product forms switched off: the generic kernels take every product"""
+    return _AMP[0] and not _AMP_FAST[0]
+
+
+def amp_one_product() -> bool:
+    """inside an autocast region with the one-product forms of the fast kernels on"""
+    return _AMP[0] and _AMP_FAST[0]
+
+
 _SPLIT3 = [True]        # fp32-grade products as six bf16 piece products (exact three-way operand split), see csrc/gemm.hip
 
 
@@ -691,7 +714,7 @@ def conv3_ok(B, H, W, Cs, N, kh, kw, stride, pad, fwd=False) -> bool:
     measured level with the generic 64 x 64 tiles (70 vs 72 us forward at 256 channels, 32 x 32 pixels) and behind them once the filter
     has to be turned for the input gradient (84 vs 74 us) -- the late stages stay on the generic kernel; default split form only.
     Also: 7 x 7 region maps (two images per tile, see csrc/conv3.hip) and filter counts that are odd multiples of 64 (64-wide tiles)"""
-    if not (_CONV3[0] and _SPLIT3[0] and not _AMP[0] and kh == 3 and kw == 3 and stride == 1 and pad == 1 and Cs % 16 == 0):
+    if not (_CONV3[0] and _SPLIT3[0] and not _amp_generic() and kh == 3 and kw == 3 and stride == 1 and pad == 1 and Cs % 16 == 0):
         return False
     min_tiles = _CONV3_MIN_TILES_FWD[0] if fwd and _CONV3_F16[0] else _conv3_min_tiles_bwd()
     if H == 7 and W == 7:
@@ -800,14 +823,18 @@ def conv3x3(x, w_ohwi, bias=None, out=None, stats=None, accumulate=False, f16x2=
         ev[0].record()
     if w_planes is not None:                 # the filter as pre-split fp16-pair planes (conv3_planes): no filter work in the kernel
         _seen("conv3:pw")
-        check(lib.vbg_conv3x3_pw(P(x), P(w_planes), P(bias), P(out), P(stats), bn_slots() if stats is not None else 0, B, H, W, Cs, N,
-                                 int(accumulate), P(x_amax), P(slab), P(tickets), nz, int(bn), _stream()), "vbg_conv3x3_pw")
+        onep = _AMP[0] and _AMP_FAST[0]       # autocast region: the hi pieces only, one product
+        if onep:
+            _seen("conv3:onep")
+        check((lib.vbg_conv3x3_pw_amp if onep else lib.vbg_conv3x3_pw)(P(x), P(w_planes), P(bias), P(out), P(stats), bn_slots() if stats is not None else 0,
+                                                                     B, H, W, Cs, N, int(accumulate), P(x_amax), P(slab), P(tickets), nz, int(bn), _stream()),
+              "vbg_conv3x3_pw")
     else:
         check(lib.vbg_conv3x3(P(x), P(w_ohwi), P(bias), P(out), P(stats), bn_slots() if stats is not None else 0, B, H, W, Cs, N,
                               int(accumulate), int(bool(f16x2)), P(x_amax), P(slab), P(tickets), nz, _stream()), "vbg_conv3x3")
     if ev is not None:
         ev[1].record()
-        _CONV3_PROF[0].append((2.0 * B * H * W * Cs * N * 9, 3 if f16x2 else 6, ev[0], ev[1]))
+        _CONV3_PROF[0].append((2.0 * B * H * W * Cs * N * 9, (1 if (w_planes is not None and _AMP[0] and _AMP_FAST[0]) else 3) if f16x2 else 6, ev[0], ev[1]))
     return out
 
 
@@ -974,7 +1001,7 @@ def conv3x3_wflip(w_ohwi):
 def conv3w_ok(B, H, W, Cs, Cout, kh, kw, stride, pad) -> bool:
     """shapes the row-reuse weight-gradient kernel takes (csrc/conv3.hip): default split form, strips of at least 8 k-tiles"""
     roi = H == 7 and W == 7 and _CONV3_ROI[0]              # region maps: four two-row chunks per image
-    if not (_CONV3[0] and _SPLIT3[0] and not _AMP[0] and kh == 3 and kw == 3 and stride == 1 and pad == 1 and (W % 16 == 0 or roi)
+    if not (_CONV3[0] and _SPLIT3[0] and not _amp_generic() and kh == 3 and kw == 3 and stride == 1 and pad == 1 and (W % 16 == 0 or roi)
             and Cs % 32 == 0 and Cout % 128 == 0 and (3 * W + 18) * Cs < (1 << 28)):       # (64-wide filters: the generic kernel is faster)
         return False
     strips = int(lib.vbg_conv3x3_wgrad_strips(B, H, W, Cs, Cout))
@@ -998,7 +1025,10 @@ def conv3x3_wgrad(dy, x, dw_ohwi, slabs=True, f16x2=False, dy_amax=None, x_amax=
         dy_amax = amax(dy) if dy_amax is None else dy_amax
         x_amax = amax(x) if x_amax is None else x_amax
     _seen("conv3:wgrad")
-    check(lib.vbg_conv3x3_wgrad(P(dy), P(x), P(dw_ohwi), P(slab), B, H, W, Cs, Cout, int(bool(f16x2)), P(dy_amax), P(x_amax), _stream()),
+    form = (2 if (_AMP[0] and _AMP_FAST[0]) else 1) if f16x2 else 0
+    if form == 2:
+        _seen("conv3:wgrad_onep")
+    check(lib.vbg_conv3x3_wgrad(P(dy), P(x), P(dw_ohwi), P(slab), B, H, W, Cs, Cout, form, P(dy_amax), P(x_amax), _stream()),
           "vbg_conv3x3_wgrad")
     return dw_ohwi
 
@@ -1045,7 +1075,7 @@ def set_conv3_f16_bwd(on: bool):
 
 
 def conv3_f16_bwd_enabled() -> bool:
-    return _CONV3[0] and _SPLIT3[0] and not _AMP[0] and _CONV3_F16[0] and _CONV3_F16_BWD[0]
+    return _CONV3[0] and _SPLIT3[0] and not _amp_generic() and _CONV3_F16[0] and _CONV3_F16_BWD[0]
 
 
 def conv3_f16_bwd_ok(B, H, W, Cout, Cin, kh, kw, stride, pad) -> bool:
