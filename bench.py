@@ -164,7 +164,7 @@ def main():
     ap.add_argument("--no-ddp-overlap", action="store_true", help="N > 1: launch every gradient bucket after backward (A/B of the overlap)")
     ap.add_argument("--dist-timeout", type=int, default=int(os.environ.get("VBG_DIST_TIMEOUT", "240")),
                     help="N > 1: process-group timeout in seconds; a stalled step also prints which bucket / SyncBatchNorm collective every rank is at")
-    ap.add_argument("--amp", action="store_true", help="time the `amp: True` path (bf16 matrix cores) as the headline value instead "
+    ap.add_argument("--amp", action="store_true", help="time the `amp: True` path (one reduced-precision product per product) as the headline value instead "
                     "of fp32; the default run reports it beside the fp32 value under \"amp\"")
     ap.add_argument("--no-amp-leg", action="store_true", help="skip the secondary amp / fp32-MFMA measurements of the default run")
     ap.add_argument("--fp32-mfma", action="store_true", help="time the step with every product on the fp32 matrix pipe "
@@ -395,7 +395,8 @@ def main():
             strict_leg = {"value": round(B * world * args.steps / sdt, 3), "unit": "docs/sec", "ms_per_step": round(1e3 * sdt / args.steps, 3),
                           "dtype": "three bf16 pieces per operand / six piece products for EVERY fp32-grade product (VBG_PAIR=0 VBG_CONV3_F16=0)"}
         amp_leg = {"value": round(B * world * args.steps / adt, 3), "unit": "docs/sec", "ms_per_step": round(1e3 * adt / args.steps, 3),
-                   "dtype": "bf16 MFMA products, f32 accumulate / storage / everything else", "last_loss": round(float(amp_last), 4)}
+                   "dtype": "one reduced-precision MFMA product per product (fp16 hi pieces on the plane / row-reuse kernels, bf16 on the generic ones), "
+                            "f32 accumulate / storage / everything else", "last_loss": round(float(amp_last), 4)}
     ranks_in_sync = None
     if world > 1:          # self-check of the gradient exchange: every rank must hold bit-identical parameters after the timed steps
         chk = torch.stack([o.group.pflat.double().sum() for o in opts] + [o.group.pflat.double().abs().sum() for o in opts])
@@ -437,8 +438,10 @@ def main():
             "metric": "training docs/sec, 512x512 img + seq_len 512, bert-base+resnet34; 1/2/4/8 GPU",
             "value": round(value, 3), "unit": "docs/sec", "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
             "ms_per_step": round(1e3 * dt / args.steps, 3), "higher_is_better": True, "scaling": "weak", "vs_baseline": None,
-            "dtype": "bf16" if args.amp else "f32", "data": "synthetic",
-            "arithmetic": ("bf16 MFMA products of fp32 tensors, f32 accumulate" if args.amp else
+            "dtype": "fp16+bf16" if args.amp else "f32", "data": "synthetic",
+            "arithmetic": ("one reduced-precision MFMA product per product of fp32 tensors, f32 accumulate: operands rounded to fp16 (the hi pieces of the "
+                           "fp16-pair planes / pre-split filters; gradients scaled into range by their amax slots) on the BERT linears and the wide 3x3 "
+                           "convolutions, to bf16 on the generic kernels (1x1, heads, stem); attention and its output projection stay on six bf16 piece products" if args.amp else
                            "f32 MFMA for every product" if args.fp32_mfma else
                            "fp32-grade on the bf16 / fp16 matrix cores, f32 accumulate: (a) exact 3-way bf16 split of every operand, 6 piece products per product -- fused attention, the attention-output projection, the generic convolutions, 1x1 / heads; (b) 2 fp16 pieces per operand (round to nearest, hi + lo 2^-11: 2^-23 relative), 3 piece products, same measured error against fp64 -- the BERT linears QKV / FFN1 / FFN2 forward, all BERT data and weight gradients, and the wide 3x3 convolutions forward, input gradient and weight gradient (gradient operands scaled by the power of two that centres their largest magnitude in fp16's range: exact); an operand outside fp16's range becomes inf, never a clipped value; the 64-filter and strided conv weight gradients and the unaligned stem on the f32 MFMA; the strict form (a) everywhere is the `bf16x3_strict` leg"),
             "config": {"workload": ("SROIE line-level cfg2: resnet_34_fpn_pretrained + bert-base-uncased (12L, vocab 30522, random init), "
@@ -460,7 +463,7 @@ def main():
         # family mixes them); `frac` = achieved / peak = executed matrix-core flops / the dense peak (`mfma_executed` / `mfma_peak`).
         pp_nt = mfma_flops / max(flops, 1.0)
         nt = {"bound": "mfma",
-              "kernel": ("vbg::gemm_kernel<*,*,*,DENSE_K,DENSE_K,*,1> (bf16 MFMA NT GEMM, amp; every ungrouped launch)" if args.amp else
+              "kernel": ("vbg::plane_gemm_kernel<*,*,*,*,*,false,*,2> + vbg::gemm_kernel<*,*,*,DENSE_K,DENSE_K,*,1> (one-product NT GEMM, amp: fp16 hi planes / bf16; every ungrouped launch)" if args.amp else
                          "vbg::gemm_kernel<*,*,*,DENSE_K,DENSE_K,*,0> (fp32 MFMA NT GEMM; every ungrouped launch)" if args.fp32_mfma else
                          "vbg::plane_gemm_kernel<*,*,*,*,*,false,*,0|1> + vbg::gemm_kernel<*,*,*,DENSE_K,DENSE_K,*,3> (fp32-grade NT GEMM: the BERT linears from pre-split planes, 1x1 convs / heads with the in-kernel split; every ungrouped launch)"),
               "achieved": round(ach, 2), "peak": round(mfma_peak / max(pp_nt, 1.0), 1), "unit": "TFLOP/s", "frac": round(mfma_rate / mfma_peak, 4),

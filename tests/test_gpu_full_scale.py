@@ -223,6 +223,52 @@ def test_full_scale_every_gradient_vs_reference(golden, tmp_path, name):
         assert seen.get("conv3:wgrad", 0) >= 25, seen
 
 
+def test_full_scale_amp_one_product_forms(golden, tmp_path):
+    """`amp: True` at the BENCHMARK's batch (cfg2e8: eight cfg2 documents, frozen BatchNorm, plain losses) under the library's own
+    dispatch: inside the autocast region the fast kernels run their ONE-product forms (round 4: fp16-pair plane products on the hi planes,
+    pre-split-filter convolutions and their weight gradients on the hi pieces) -- asserted through the dispatch log -- and the step stays
+    a reduced-precision version of the fp32 step: loss within 5e-3 of the reference's fp32 loss (measured 6e-4; the reference's own autocast
+    run sits 1.7 % from its fp32 run on the e2e fixture, tests/test_gpu_model.py), every sampled parameter gradient pointing the fp32 way
+    (cosine >= 0.995, median >= 0.9995; measured 0.9995 / 0.99994), storage fp32."""
+    name = "cfg2e8"
+    g, c, net, dbatch = _setup(golden, tmp_path, name)
+    from vbg import ops
+    net.train()
+    for m in net.modules():
+        if isinstance(m, torch.nn.modules.batchnorm._BatchNorm):
+            m.eval()
+    random.seed(7)
+    seen = ops.dispatch_log(True)
+    try:
+        with torch.autocast("cuda", dtype=torch.bfloat16):
+            tl = net(*dbatch)
+        assert ops.amp_enabled() and tl.dtype in (torch.float32, torch.float64)
+        tl.backward()
+    finally:
+        ops.dispatch_log(False)
+        ops.set_amp(False)
+    print(f"{name} amp: dispatch seen:", {k: seen[k] for k in sorted(seen)})
+    assert seen.get("plane_gemm:onep", 0) >= 36 + 48 and seen.get("plane_gemm:pair", 0) == 0, seen
+    assert seen.get("conv3:onep", 0) >= 30 and seen.get("conv3:wgrad_onep", 0) >= 25, seen
+    rl = float(np.asarray(g["train_loss"]).reshape(-1)[0])
+    print(f"{name} amp: train loss {float(tl.detach()):.6f} reference (fp32) {rl:.6f}")
+    assert abs(float(tl.detach()) - rl) <= 5e-3 * abs(rl)
+    assert abs(float(tl.detach()) - rl) > 1e-7 * abs(rl)               # (a reduced-precision step really ran)
+    named = dict(net.named_parameters())
+    cos = {}
+    for f in g.files:
+        if f.startswith("grad::") and "key.bias" not in f:
+            k = f[6:]
+            b = T(g[f]).double()
+            if float(b.norm()) == 0:
+                continue
+            a = F.sample(named[k].grad, 1024 if b.numel() <= 1024 else 4096).cpu().double()
+            cos[k] = float((a * b).sum() / (a.norm() * b.norm() + 1e-300))
+    vals = sorted(cos.values())
+    print(f"{name} amp: {len(vals)} gradient cosines vs the fp32 reference: min {vals[0]:.4f} ({min(cos, key=cos.get)}), median {vals[len(vals) // 2]:.5f}")
+    assert vals[0] >= 0.995 and vals[len(vals) // 2] >= 0.9995, (vals[:5], min(cos, key=cos.get))
+
+
 def _every_gradient(g, c, net, dbatch, name):
     _check_eval(g, c, net, dbatch, name, 1e-5)
     net.train()
