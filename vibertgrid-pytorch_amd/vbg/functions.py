@@ -637,10 +637,12 @@ class BertLayerFn(torch.autograd.Function):
             ctx.delta_buf = st[2]
             masks = ops.attn_mask(meta, p, seed, sid + 0) if p > 0 else None
             kbar = torch.empty((ntok, hid), device=dev, dtype=f32) if any(ctx.needs_input_grad) else None
-            pctx = ops.planes_empty(ntok, hid, dev)
             # (all-pair backward: O also as fp16-pair planes -- the B operand of the output projection's weight gradient, saved instead of
             #  the split pass the backward used to run over the fp32 O)
             pctxq = ops.pair_empty(ntok, hid, dev) if (pair_bwd and any(ctx.needs_input_grad)) else None
+            # (autocast region: the output projection multiplies the hi plane of those, no bf16 planes of O are written)
+            amp_ao = pctxq is not None and ops.amp_one_product()
+            pctx = None if amp_ao else ops.planes_empty(ntok, hid, dev)
             ops.attn(meta, ATTN_FWD, pqkv, None, ctxv, lse, None, masks, 1.0 / (dh ** 0.5), p, kbar=kbar, out_planes=pctx, out_pair=pctxq)
         else:
             # scores -> probabilities (in place), grouped over (sequence, head)
@@ -655,9 +657,13 @@ class BertLayerFn(torch.autograd.Function):
             # (the attention-output projection stays on the six-product form, its operand's bf16 planes come from the attention kernel:
             #  measured at full scale, moving it to the pair form as well raised the gradient error of the ill-conditioned trunk
             #  convolutions from 6.3e-4 to 1.0e-3 of the reference -- the forward feeds everything; the backward products do not)
-            if pctx is None:
-                pctx = ops.split_planes(ctxv)
-            ao = ops.plane_gemm(pctx, ops.weight_planes(wo), torch.empty((ntok, hid), device=dev, dtype=f32), bias=bo, tile=ops._dense_tile(ntok, hid))
+            if flash and amp_ao:
+                ao = ops.plane_gemm(pctxq, ops.weight_planes(wo, pair=True),
+                                    torch.empty((ntok, hid), device=dev, dtype=f32), bias=bo, tile=ops.pair_tile(ntok, hid) or 128129, form=1)
+            else:
+                if pctx is None:
+                    pctx = ops.split_planes(ctxv)
+                ao = ops.plane_gemm(pctx, ops.weight_planes(wo), torch.empty((ntok, hid), device=dev, dtype=f32), bias=bo, tile=ops._dense_tile(ntok, hid))
             px1 = None if pair_bwd else ops.planes_empty(ntok, hid, dev)
             px1q = ops.pair_empty(ntok, hid, dev) if pair else None
             x1, xh1, rs1 = ops.dropout_add_ln_fwd(ao, x, g1, b1, eps, p, seed, sid + 1, out_planes=px1, out_pair=px1q)
