@@ -470,6 +470,11 @@ def main():
               "mfma_executed": round(mfma_rate, 1), "mfma_peak": round(mfma_peak, 1), "piece_products_per_product": round(pp_nt, 3),
               "traffic": traffic, "traffic_source": traffic_src, "launches": launches, "avg_us": round(1e3 * ms / max(launches, 1), 2),
               "ms_per_step": round(ms / args.steps, 3), "vs_fp32_mfma_peak": round(ach / PEAK_F32_TF, 4)}
+        if getattr(prof, "ingest", None) and prof.ingest[0] and prof.ingest[2] > 0:
+            # what the plane products of the family are bound by: bytes their workgroups move from L2 into LDS -- tiles x k-tiles
+            # x stage bytes, every operand panel once per tile that uses it -- over the same launch times
+            nt["l2_to_lds"] = {"launches": prof.ingest[0], "MB_per_launch": round(prof.ingest[1] / prof.ingest[0] / 1e6, 1),
+                               "TB_per_s": round(prof.ingest[1] / (prof.ingest[2] * 1e-3) / 1e12, 2), "ms_per_step": round(prof.ingest[2] / args.steps, 3)}
         if c3rec and c3_ms > 0:
             # the dominant kernel family by time since round 3: the row-reuse 3x3 convolutions, forward + input gradient
             pp_c3 = c3_exec / max(c3_fl, 1.0)

@@ -15,6 +15,9 @@ timeout 600 python tools/conv3_forms_bench.py 2>&1 | grep -v amdgpu.ids > gpurun
 timeout 600 python tools/conv3_pw_bench.py 2>&1 | grep -v amdgpu.ids > gpurun_out/conv3_pw.txt
 timeout 600 python tools/step_conv3_profile.py 2>/dev/null > gpurun_out/step_conv3.txt
 timeout 300 python tools/attn_bench.py 2>&1 | grep -v amdgpu.ids > gpurun_out/attn_shapes.txt
+timeout 300 python tools/step_plane_profile.py 2>/dev/null > gpurun_out/step_plane.txt
+timeout 300 python tools/plane_pair_bench.py 30 2>&1 | grep -v amdgpu.ids > gpurun_out/plane_pair_shapes.txt
+timeout 600 python bench.py --amp --steps 20 --warmup 5 --no-cpu-baseline --no-h2d-leg 2>/dev/null | grep "^{" > gpurun_out/bench_amp_line.json
 rm -f gpurun_out/prof_amp/amp_kernel_trace.csv
 ls -la gpurun_out/prof_e gpurun_out/pmc_f gpurun_out/pmc_m | head -30; cut -c1-400 gpurun_out/bench_line.json
 # exploratory shapes and legs of the same build

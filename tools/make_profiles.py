@@ -81,7 +81,10 @@ if os.path.exists(G + "pmc_f/f_counter_collection.csv") and os.path.exists(G + "
 shutil.copy(G + "prof_e/e_kernel_stats.csv", P + "bench_kernel_stats.csv")
 shutil.copy(G + "prof_e/e_domain_stats.csv", P + "bench_domain_stats.csv")
 for src, dst in (("gemm_shapes.txt", "gemm_shapes.txt"), ("bench_line.json", "bench_line.json"), ("plane_gemm_shapes.txt", "plane_gemm_shapes.txt"),
-                 ("gemm_shapes_amp.txt", "gemm_shapes_amp.txt"), ("conv3_shapes.txt", "conv3_shapes.txt")):
+                 ("gemm_shapes_amp.txt", "gemm_shapes_amp.txt"), ("conv3_shapes.txt", "conv3_shapes.txt"),
+                 ("conv3_pw.txt", "conv3_pw.txt"), ("step_conv3.txt", "step_conv3.txt"), ("conv3_forms.txt", "conv3_forms.txt"),
+                 ("attn_shapes.txt", "attn_shapes.txt"), ("step_plane.txt", "step_plane.txt"), ("plane_pair_shapes.txt", "plane_pair_shapes.txt"),
+                 ("bench_amp_line.json", "bench_amp_line.json"), ("infer_latency.txt", "infer_latency.txt")):
     if os.path.exists(G + src):
         shutil.copy(G + src, P + dst)
 if os.path.exists(G + "prof_amp/amp_kernel_stats.csv"):

@@ -339,7 +339,10 @@ def plane_gemm(a: Planes, b: Planes, out=None, *, bias=None, epi=EPI_NONE, C2=No
     if prof is not None and not trans and prof.match(OP_DENSE_K, OP_DENSE_K, False):
         e0, e1 = prof.events()
         check(lib.vbg_plane_gemm_timed(C.byref(d), _stream(), e0, e1), "vbg_plane_gemm_timed")
-        prof.add(2.0 * d.M * d.N * (a.rows if trans else a.cols), e0, e1, (1 if _AMP[0] else 3) if form else 6)
+        bm, bn = {256128: (256, 128), 64064: (64, 64), 128064: (128, 64)}.get(int(d.tile), (128, 128)) if (form or int(d.tile)) else (0, 0)
+        npl = (1 if _AMP[0] else 2) if form else 3
+        ing = (-(-d.M // bm)) * (-(-d.N // bn)) * float(d.K) * (bm + bn) * npl * 2 if bm else None
+        prof.add(2.0 * d.M * d.N * (a.rows if trans else a.cols), e0, e1, (1 if _AMP[0] else 3) if form else 6, ingest=ing)
         return out
     check(lib.vbg_plane_gemm(C.byref(d), _stream()), "vbg_plane_gemm")
     return out
@@ -504,21 +507,25 @@ class GemmProfiler:
             out.append(h)
         return out
 
-    def add(self, flops, e0, e1, products=6):
+    def add(self, flops, e0, e1, products=6, ingest=None):
         """products: MFMA piece products the launch executes per algorithmic product (6: three bf16 pieces per operand, 3: two fp16
-        pieces, 1: amp / the fp32 matrix pipe)"""
-        self.records.append((flops, e0, e1, products))
+        pieces, 1: amp / the fp32 matrix pipe).  ingest: bytes the launch's workgroups move from L2 into LDS (plane products: tiles x
+        k-tiles x stage bytes), or None"""
+        self.records.append((flops, e0, e1, products, ingest))
 
     def summary(self):
         """-> (launches, total algorithmic flops, total ms, total EXECUTED matrix-core flops)  (call after a device sync); releases
         the events"""
         ms = 0.0
-        for _, e0, e1, _ in self.records:
+        self.ingest = [0, 0.0, 0.0]              # launches with a known operand ingest, their bytes, their ms
+        for _, e0, e1, _, ing in self.records:
             v = C.c_float()
             check(lib.vbg_timer_elapsed_ms(e0, e1, C.byref(v)), "vbg_timer_elapsed_ms")
             ms += v.value
+            if ing is not None:
+                self.ingest[0] += 1; self.ingest[1] += ing; self.ingest[2] += v.value
         out = (len(self.records), sum(r[0] for r in self.records), ms, sum(r[0] * r[3] for r in self.records))
-        for _, e0, e1, _ in self.records:
+        for _, e0, e1, _, _ in self.records:
             lib.vbg_timer_destroy(e0)
             lib.vbg_timer_destroy(e1)
         self.records = []
