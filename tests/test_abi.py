@@ -60,6 +60,7 @@ def test_conv3_host_logic_without_a_gpu():
     assert nb(128, 24, 0, 0) == 0 and nb(24, 128, 1, 0) == 0 and nb(128, 32, 0, 96) == 0                                         # reduction width must be a multiple of 16
     assert L.lib.vbg_conv3x3_wprep(None, None, 1, None) == -1 and L.lib.vbg_conv3x3_wprep(None, None, 0, None) == 0
     assert L.lib.vbg_conv3x3_pw(None, None, None, None, None, 0, 1, 16, 128, 16, 128, 0, None, None, None, 1, 0, None) == -1
+    assert L.lib.vbg_conv3x3_pw_amp(None, None, None, None, None, 0, 1, 16, 128, 16, 128, 0, None, None, None, 1, 0, None) == -1          # the one-product form: same checks
 
 
 def test_gemm_desc_layout_matches_header():

@@ -105,6 +105,19 @@ def test_dispatch_predicates():
         assert not ops.pair_enabled() and not ops.pair_bwd_enabled()
     finally:
         ops.set_pair(True)
+    # an autocast region keeps the fast paths (their one-product forms) unless VBG_AMP_FAST=0 / set_amp_fast(False) hands every product
+    # of the region to the generic kernels, as rounds 1-3 did
+    assert not ops.amp_one_product()
+    with ops.amp_scope(True):
+        assert ops.amp_one_product() and ops.pair_enabled() and ops.planes_enabled() and ops.conv3_ok(8, 128, 128, 256, 256, 3, 3, 1, 1)
+        assert ops.conv3_f16_bwd_enabled() and ops.conv3_f16_wgrad_ok(8, 128, 128, 256, 256, 3, 3, 1, 1)
+        ops.set_amp_fast(False)
+        try:
+            assert not ops.amp_one_product() and not ops.pair_enabled() and not ops.planes_enabled()
+            assert not ops.conv3_ok(8, 128, 128, 256, 256, 3, 3, 1, 1) and not ops.conv3_f16_bwd_enabled()
+        finally:
+            ops.set_amp_fast(True)
+    assert not ops.amp_enabled() and ops.pair_enabled()
 
 
 def test_reducer_refuses_a_subgroup_without_a_syncbn_group():
