@@ -269,6 +269,44 @@ def test_full_scale_amp_one_product_forms(golden, tmp_path):
     assert vals[0] >= 0.995 and vals[len(vals) // 2] >= 0.9995, (vals[:5], min(cos, key=cos.get))
 
 
+def test_wgrad_stream_gives_the_same_gradients(golden, tmp_path):
+    """the opt-in `VBG_WGRAD_STREAM=1` route (grouped weight-gradient launch of every encoder layer on a stream of its own, operands
+    reserved with record_stream, joined by an end-of-backward callback): the same kernels on the same operands -- every parameter gradient
+    equal to the one-stream backward at rounding level, and the caller's stream is ordered behind the side stream when backward() returns (the
+    gradients are read right after it here)."""
+    g, c, net, dbatch = _setup(golden, tmp_path, "cfg2e")
+    from vbg import ops
+    net.train()
+    for m in net.modules():
+        if isinstance(m, torch.nn.modules.batchnorm._BatchNorm):
+            m.eval()
+    grads = []
+    for on in (False, True, True):
+        for o in net._vbg_test_opts:
+            o.zero_grad()
+        ops.set_wgrad_stream(on)
+        try:
+            random.seed(7)
+            torch.manual_seed(11)
+            tl = net(*dbatch)
+            tl.backward()
+            grads.append({k: p.grad.clone() for k, p in net.named_parameters() if p.grad is not None})
+        finally:
+            ops.set_wgrad_stream(False)
+    assert ops.side_streams(), "the weight-gradient stream was never created: the route did not run"
+    # (the step is not bit-reproducible run to run -- float atomics in a few reductions upstream of the encoder's backward --, so the
+    #  comparison is at noise level: 1e-3 of a gradient's largest entry (measured run to run: up to 1.2e-5).  What the test is for are the failures a missing wait would
+    #  produce: a weight gradient read before the side stream wrote it, or operands recycled under it)
+    checked = 0
+    for k, a in grads[0].items():
+        if "key.bias" in k:          # analytically zero (softmax is shift invariant): rounding noise on every run
+            continue
+        tol = 1e-3 * float(a.abs().max()) + 1e-12
+        assert float((a - grads[1][k]).abs().max()) <= tol and float((a - grads[2][k]).abs().max()) <= tol, k
+        checked += k.startswith("bert_model.encoder.layer.") and k.endswith(".weight") and "LayerNorm" not in k
+    assert checked == 12 * 6                      # the 72 weight gradients the side stream writes were among them
+
+
 def _every_gradient(g, c, net, dbatch, name):
     _check_eval(g, c, net, dbatch, name, 1e-5)
     net.train()
