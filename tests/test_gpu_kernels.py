@@ -671,6 +671,32 @@ def test_softmax(ops):
     assert abs(rate - 0.9) < 0.01
 
 
+def test_gelu_erf_epilogues(ops):
+    """the library's branch-free erf (vbg_common.h vbg_erff: both pieces of the single-precision erf evaluated, one selected; exp through
+    v_exp_f32) seen through the two GELU epilogues that use it: gelu(h) and gelu'(h) against fp64 over a dense grid of [-6, 6] plus
+    normal samples -- absolute error <= 2.5e-7 max(1, |h|) (fp32 rounding of the result itself is 6e-8 |gelu|), exact zeros at 0"""
+    from vbg.lib import EPI_GELU_DUAL
+    d = dev()
+    h = torch.cat([torch.linspace(-6, 6, 1 << 20), torch.randn(1 << 20) * 1.5, torch.zeros(64)]).view(-1, 64).contiguous()
+    hd = h.double()
+    cdf = 0.5 * (1 + torch.special.erf(hd / 2 ** 0.5))
+    ref_d = cdf + hd * torch.exp(-0.5 * hd * hd) / (2 * math.pi) ** 0.5
+    ones = torch.ones_like(h).to(d)
+    got_d = ops.gelu_bwd_(h.to(d), ones.clone()).cpu().double()                    # 1 * gelu'(h)
+    assert float(((got_d - ref_d).abs() / hd.abs().clamp_min(1.0)).max()) <= 2.5e-7
+    # gelu(h) through the GELU-dual epilogue of a product with the identity: h = I h
+    n = 64
+    x = h[:4096].to(d)
+    eye = torch.eye(n, device=d)
+    out, gl = ops.linear_fwd(x, eye, None, EPI_GELU_DUAL)
+    assert float((out - x).abs().max()) <= 1e-6
+    od = out.cpu().double()
+    err = (gl.cpu().double() - od * 0.5 * (1 + torch.special.erf(od / 2 ** 0.5))).abs() / od.abs().clamp_min(1.0)
+    assert float(err.max()) <= 2.5e-7
+    z = torch.zeros(128, n, device=d)
+    assert float(ops.linear_fwd(z, eye, None, EPI_GELU_DUAL)[1].abs().max()) == 0.0
+
+
 def test_gelu_relu_bwd(ops):
     n = 4099
     h, g = rnd(n, seed=62) * 2, rnd(n, seed=63)

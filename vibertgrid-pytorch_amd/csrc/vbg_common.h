@@ -72,9 +72,33 @@ static inline uint32_t drop_threshold(float p) {
     return (uint32_t)t;
 }
 
-__device__ __forceinline__ float gelu_erf(float x) { return 0.5f * x * (1.0f + erff(x * 0.70710678118654752440f)); }
+// erf to < 1 ulp-and-a-bit without a branch: both pieces of N. Juffa's single-precision erf (minimax polynomial in x^2 below 0.9277,
+// 1 - exp(polynomial) above) are evaluated and one is selected -- 21 VALU instructions against the 33 + two exec-mask switches the
+// library's erff costs once a wave's lanes straddle |x| = 1 (they always do in a GELU epilogue); exp through v_exp_f32 (the argument
+// is <= 0: the absolute error it adds to erf stays below 4e-8).  Checked against erf in fp64 over [-6, 6] and N(0, 1.5) samples:
+// 0.94 ulp with an exact exp (tests/test_gpu_kernels.py::test_gelu_erf_epilogues).
+__device__ __forceinline__ float vbg_erff(float a) {
+    const float t = fabsf(a), s = a * a;
+    float r = fmaf(-1.72853470e-5f, t, 3.83197126e-4f);
+    const float u = fmaf(-3.88396438e-3f, t, 2.42546219e-2f);
+    r = fmaf(r, s, u);
+    r = fmaf(r, t, -1.06777877e-1f);
+    r = fmaf(r, t, -6.34846687e-1f);
+    r = fmaf(r, t, -1.28717512e-1f);
+    r = fmaf(r, t, -t);
+    const float big = 1.0f - __expf(r);
+    float q = -5.96761703e-4f;
+    q = fmaf(q, s, 4.99119423e-3f);
+    q = fmaf(q, s, -2.67681349e-2f);
+    q = fmaf(q, s, 1.12819925e-1f);
+    q = fmaf(q, s, -3.76125336e-1f);
+    q = fmaf(q, s, 1.28379166e-1f);
+    q = fmaf(q, t, t);
+    return copysignf(t > 0.927734375f ? big : q, a);
+}
+__device__ __forceinline__ float gelu_erf(float x) { return 0.5f * x * (1.0f + vbg_erff(x * 0.70710678118654752440f)); }
 __device__ __forceinline__ float gelu_erf_grad(float x) {
-    const float cdf = 0.5f * (1.0f + erff(x * 0.70710678118654752440f));
+    const float cdf = 0.5f * (1.0f + vbg_erff(x * 0.70710678118654752440f));
     const float pdf = 0.39894228040143267794f * __expf(-0.5f * x * x);
     return cdf + x * pdf;
 }
