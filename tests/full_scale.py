@@ -47,6 +47,22 @@ CASES["cfg3e"] = dict(CASES["cfg3"], plain=True, bn_frozen=True)
 # with the library's OWN dispatch (nothing forced): the tile choices, split counts and arithmetic forms bench.py times
 # (256 x 128 NT tiles, `vbg_conv3x3_split` counts at 8 x 32^2 / 16^2, region maps at N ~ 900 RoIs) are held to the reference here.
 CASES["cfg2e8"] = dict(CASES["cfg2"], plain=True, bn_frozen=True, B=8)
+# BASELINE configs[3] at its stated per-GPU batch: eight char-level documents (S = 512: ~3 900 RoIs through the region-map kernels) in ONE step of
+# the reference, library's own dispatch
+CASES["cfg4e8"] = dict(CASES["cfg4"], plain=True, bn_frozen=True, B=8)
+# BASELINE configs[4] at its stated per-GPU batch: SIXTEEN 1024 x 1024 documents.  One step of the reference at that batch does not fit this
+# container (the reference's segmentation head keeps [16, 256, 1024, 1024] fp32 activations: 17 GB each, 64 GB of RAM), so the fixture is
+# assembled from EIGHT steps of the reference on consecutive pairs of the sixteen documents (`chunk`): with frozen BatchNorm the documents
+# are independent, and with the plain losses the batch loss is (mean over all pixels) + (mean over all segments) -- every pair holds the same
+# number of pixels and of segments (one full + one ragged document), so loss and gradients of the batch are the plain means of the pairs'.
+# tests/golden/make_golden.py checks that rule where the direct run exists (cfg2e8 from four pairs against full_cfg2e8.npz) and stores the
+# deviation in the fixture (`chunk_rule_check`).
+CASES["cfg5e16"] = dict(CASES["cfg5"], plain=True, bn_frozen=True, B=16, chunk=2)
+CASES["cfg2e8c"] = dict(CASES["cfg2"], plain=True, bn_frozen=True, B=8, chunk=2, seed_of="cfg2e8")     # (the rule's check case; no fixture)
+# BASELINE configs[0] at its stated size: ONE 256 x 256 document, resnet_18_fpn + 12-layer bert-base-uncased, T = 128 tokens, S = 32 segments
+# (the reference's own CPU-runnable case), losses of example_config.yaml; the fixture also carries `inference()`
+CASES["cfg1"] = dict(bert="bert-base-uncased", vocab=30522, max_pos=512, type_vocab=2, roberta=False, ln_eps=1e-12,
+                     backbone="resnet_18_fpn", ncls=5, img=256, T=128, S=32, S1=32, box_w=(8, 48), box_h=(8, 16), B=1)
 # parameters whose gradients are stored as strided samples (the norms of ALL parameter gradients are stored too)
 GRAD_PICK = ["bert_model.embeddings.word_embeddings.weight", "bert_model.encoder.layer.0.attention.self.query.weight",
              "bert_model.encoder.layer.5.intermediate.dense.weight", "bert_model.encoder.layer.11.output.dense.weight",
@@ -57,6 +73,7 @@ GRAD_PICK = ["bert_model.embeddings.word_embeddings.weight", "bert_model.encoder
 GRAD_PICK_BACKBONE = {
     "resnet_34_fpn_pretrained": ["backbone.resnet.conv1.weight", "backbone.resnet.layer3.2.conv1.weight", "backbone.early_fusion.weight"],
     "resnet_34_fpn": ["backbone.conv_1.0.weight", "backbone.conv_4_x.2.conv_1.weight", "backbone.conv_3_x.early_fusion.weight"],
+    "resnet_18_fpn": ["backbone.conv_1.0.weight", "backbone.conv_4_x.1.conv_1.weight", "backbone.conv_3_x.early_fusion.weight"],
 }
 
 
@@ -81,7 +98,7 @@ def loss_kwargs(name):
 def inputs(name):
     """(imgs, segs, classes, coors, corpus, mask) like data/SROIE_dataset.py's collate hands them to the model"""
     c = CASES[name]
-    g = torch.Generator().manual_seed(20260929 + sum(map(ord, name[:4])))
+    g = torch.Generator().manual_seed(20260929 + sum(map(ord, c.get("seed_of", name)[:4])))
     B, H, W, T, S = c.get("B", 2), c["img"], c["img"], c["T"], c["S"]
     imgs = tuple(torch.rand(3, H, W, generator=g) for _ in range(B))
     per = T // S
@@ -101,6 +118,13 @@ def inputs(name):
     corpus[1::2, n1:] = 0
     mask[1::2, n1:] = 0
     return imgs, tuple(segs), tuple(classes), tuple(coors), corpus, mask
+
+
+def chunk_of(batch, i, n):
+    """documents [i*n, (i+1)*n) of a batch, as a batch"""
+    imgs, segs, classes, coors, corpus, mask = batch
+    sl = slice(i * n, (i + 1) * n)
+    return imgs[sl], segs[sl], classes[sl], coors[sl], corpus[sl], mask[sl]
 
 
 def checksums(batch):

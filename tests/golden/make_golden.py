@@ -650,10 +650,9 @@ def gen_e2e_amp(V, tmp):
     npz("e2e_amp.npz", **out)
 
 
-def gen_full(V, tmp, name):
-    """Full-scale reference runs (12-layer bert-base / roberta-base dims, real vocab sizes, resnet-34, 512x512 / 1024x1024, T=512 ->
-    two windows): tests/full_scale.py defines the cases and the seeded inputs; the outputs of model/ViBERTgrid_net.py:501-544 in
-    eval mode (5-tuple) and train mode (loss, gradients) are stored.  Dropout 0 (the masks of two RNGs cannot agree)."""
+def _full_net(V, tmp, name):
+    """the reference's ViBERTgridNet for a tests/full_scale.py case (12-layer BERT / RoBERTa of the real dimensions, random init replaced
+    by the deterministic synthetic weights by the caller)"""
     sys.path.insert(0, os.path.join(ROOT, "tests"))
     import full_scale as F
     c = F.CASES[name]
@@ -682,6 +681,121 @@ def gen_full(V, tmp, name):
                               work_mode="eval", **F.loss_kwargs(name))
     finally:
         os.chdir(cwd)
+    return net
+
+
+def gen_full_chunked(V, tmp, name, check_against=None, extra=None):
+    """A full-scale fixture for a batch whose single reference step does not fit this container (tests/full_scale.py `chunk`): the reference
+    runs on consecutive groups of `chunk` documents -- frozen BatchNorm, plain losses: documents independent, every group the same number of
+    pixels and segments -- and loss / gradients of the batch are the means over the groups (gradients accumulate in `.grad` over the groups'
+    backward passes, as the reference's own autograd would sum them).  check_against: an existing DIRECT fixture of the same batch -- prints and
+    returns (median, max) relative L2 distance of every stored gradient sample instead of writing a file."""
+    sys.path.insert(0, os.path.join(ROOT, "tests"))
+    import full_scale as F
+    import time
+    c = F.CASES[name]
+    assert c.get("plain") and c.get("bn_frozen") and c["B"] % c["chunk"] == 0
+    nch = c["B"] // c["chunk"]
+    net = _full_net(V, tmp, name)
+    load_synth(net)
+    batch = F.inputs(name)
+    segs_per = {sum(int(t.shape[0]) for t in F.chunk_of(batch, i, c["chunk"])[2]) for i in range(nch)}
+    assert len(segs_per) == 1, f"groups hold different numbers of segments {segs_per}: the batch loss is not the mean of the groups'"
+    out = {"checksums": np.array(F.checksums(batch))}
+
+    def eval_pass(tag):
+        net.eval()
+        acc = {"loss": [], "pm": [], "ps": [], "gt": [], "pred": []}
+        t0 = time.time()
+        for i in range(nch):
+            random.seed(7)
+            with torch.no_grad():
+                loss, pm, ps, gt, pred = net(*F.chunk_of(batch, i, c["chunk"]))
+            acc["loss"].append(loss.double())
+            acc["pm"].append(pm[:, :, 5::16, 3::16].clone())
+            acc["ps"].append(ps[:, :, 5::16, 3::16].clone())
+            acc["gt"].append(gt)
+            acc["pred"].append(pred)
+            del pm, ps
+        print(name, tag, "eval forwards", round(time.time() - t0, 1), "s")
+        return (torch.stack(acc["loss"]).mean(0), torch.cat(acc["pm"]), torch.cat(acc["ps"]), torch.cat(acc["gt"]), torch.cat(acc["pred"]))
+
+    def train_pass(tag):
+        net.train()
+        for m in net.modules():
+            if isinstance(m, torch.nn.modules.batchnorm._BatchNorm):
+                m.eval()
+        net.zero_grad()
+        losses = []
+        t0 = time.time()
+        for i in range(nch):
+            random.seed(7)
+            loss = net(*F.chunk_of(batch, i, c["chunk"]))
+            (loss / nch).backward()
+            losses.append(loss.detach().double())
+            print(name, tag, "group", i, "train step done at", round(time.time() - t0, 1), "s", flush=True)
+        return torch.stack(losses).mean(0)
+
+    loss, pm, ps, gt, pred = eval_pass("")
+    out.update(eval_loss=loss, gt=gt, pred=pred, pred_mask=pm, pred_ss=ps)
+    out["train_loss"] = train_pass("")
+    named = dict(net.named_parameters())
+    gn = {k: (0.0 if p.grad is None else float(p.grad.double().norm())) for k, p in named.items() if not k.startswith("BERTgrid_generator.")}
+    out["gradnorm_keys"] = np.array(sorted(gn.keys()))
+    out["gradnorm_vals"] = np.array([gn[k] for k in sorted(gn.keys())])
+    for k in sorted(gn.keys()):
+        if named[k].grad is not None:
+            out[f"grad::{k}"] = F.sample(named[k].grad, 1024).clone()
+    if check_against is not None:
+        ref = np.load(os.path.join(HERE, check_against))
+        d = []
+        for f in ref.files:
+            if f.startswith("grad::") and f in out and "key.bias" not in f:
+                a, b = out[f].double(), torch.from_numpy(ref[f]).double()
+                if float(b.norm()) > 0:
+                    d.append((float((a - b).norm() / b.norm()), f[6:]))
+        d.sort()
+        dl = abs(float(out["train_loss"]) - float(np.asarray(ref["train_loss"]).reshape(-1)[0])) / abs(float(np.asarray(ref["train_loss"]).reshape(-1)[0]))
+        dp = float((out["pred"] - torch.from_numpy(ref["pred"])).abs().max())
+        print(f"{name}: mean-of-groups rule vs the direct step of {check_against}: loss rel {dl:.2e}, class probabilities max abs {dp:.2e}, "
+              f"{len(d)} gradients rel-L2 median {d[len(d) // 2][0]:.2e} max {d[-1][0]:.2e} ({d[-1][1]}); the direct fixture's own one-ulp noise median "
+              f"{float(np.median(ref['ulpnoise_vals'])):.2e}")
+        return np.array([d[len(d) // 2][0], d[-1][0], dl, dp])
+    sd = net.state_dict()
+    bnk = "backbone.resnet.bn1" if c["backbone"].endswith("pretrained") else "backbone.conv_1.1"
+    out["bn_rm"], out["bn_rv"] = sd[bnk + ".running_mean"].clone(), sd[bnk + ".running_var"].clone()
+    # the reference's own one-ulp sensitivity on the same batch (see gen_full)
+    first = {k: out[f"grad::{k}"].clone() for k in sorted(gn.keys()) if f"grad::{k}" in out}
+    gen = torch.Generator().manual_seed(1)
+    with torch.no_grad():
+        for k, p in net.named_parameters():
+            if not k.startswith("BERTgrid_generator."):
+                p.mul_(1 + 1.2e-7 * torch.randn(p.shape, generator=gen))
+    out["train_loss_1ulp"] = train_pass("one-ulp")
+    keys, vals = [], []
+    for k, a in first.items():
+        b = F.sample(named[k].grad, 1024).double()
+        keys.append(k)
+        vals.append(float((a.double() - b).norm() / (a.double().norm() + 1e-30)))
+    out["ulpnoise_keys"], out["ulpnoise_vals"] = np.array(keys), np.array(vals)
+    print(name, "1-ulp gradient noise: median", float(np.median(vals)), "max", float(np.max(vals)))
+    _, pm1, ps1, _, pred1 = eval_pass("one-ulp")
+    out.update(pred_1ulp=pred1, pred_mask_1ulp=pm1, pred_ss_1ulp=ps1)
+    if extra:
+        out.update(extra)
+    out["keys"] = np.array(list(shapes_of(net).keys()))
+    out["key_shapes"] = np.array([str(v) for v in shapes_of(net).values()])
+    npz(f"full_{name}.npz", **out)
+
+
+def gen_full(V, tmp, name):
+    """Full-scale reference runs (12-layer bert-base / roberta-base dims, real vocab sizes, resnet-34, 512x512 / 1024x1024, T=512 ->
+    two windows): tests/full_scale.py defines the cases and the seeded inputs; the outputs of model/ViBERTgrid_net.py:501-544 in
+    eval mode (5-tuple) and train mode (loss, gradients) are stored.  Dropout 0 (the masks of two RNGs cannot agree)."""
+    sys.path.insert(0, os.path.join(ROOT, "tests"))
+    import full_scale as F
+    c = F.CASES[name]
+    net = _full_net(V, tmp, name)
     load_synth(net)
     batch = F.inputs(name)
     imgs, segs, classes, coors, corpus, mask = batch
@@ -694,6 +808,9 @@ def gen_full(V, tmp, name):
         loss, pm, ps, gt, pred = net(imgs, segs, classes, coors, corpus, mask)
     print(name, "eval forward", round(time.time() - t0, 1), "s")
     out.update(eval_loss=loss, gt=gt, pred=pred, pred_mask=pm[:, :, 5::16, 3::16], pred_ss=ps[:, :, 5::16, 3::16])
+    if name == "cfg1":          # the deployment entry point on the same document (model/ViBERTgrid_net.py:470-499)
+        with torch.no_grad():
+            out["inference"] = net.inference(imgs, segs, coors, corpus, mask)
     net.train()
     if c.get("bn_frozen"):
         for m in net.modules():
@@ -774,7 +891,7 @@ def main():
     import pipeline.custom_loss as L
     import pipeline.transform as T
 
-    which = sys.argv[1:] or ["transform", "windows", "aggregate", "scatter", "losses", "labels", "bert", "backbone", "backbone_d", "e2e", "e2e_roberta", "losses_bce", "e2e_modes", "e2e_amp", "full_cfg2", "full_cfg4", "full_cfg5", "full_cfg2p", "full_cfg2e", "full_cfg4e", "full_cfg5e", "full_cfg3", "full_cfg3e", "full_cfg2e8"]
+    which = sys.argv[1:] or ["transform", "windows", "aggregate", "scatter", "losses", "labels", "bert", "backbone", "backbone_d", "e2e", "e2e_roberta", "losses_bce", "e2e_modes", "e2e_amp", "full_cfg2", "full_cfg4", "full_cfg5", "full_cfg2p", "full_cfg2e", "full_cfg4e", "full_cfg5e", "full_cfg3", "full_cfg3e", "full_cfg2e8", "full_cfg4e8", "full_cfg1", "full_cfg5e16"]
     if "transform" in which:
         gen_transform(T)
     if "windows" in which:
@@ -803,9 +920,14 @@ def main():
         gen_e2e_modes(V, tmp)
     if "e2e_amp" in which:
         gen_e2e_amp(V, tmp)
-    for name in ("cfg2", "cfg4", "cfg5", "cfg2p", "cfg2e", "cfg4e", "cfg5e", "cfg3", "cfg3e", "cfg2e8"):
+    for name in ("cfg2", "cfg4", "cfg5", "cfg2p", "cfg2e", "cfg4e", "cfg5e", "cfg3", "cfg3e", "cfg2e8", "cfg4e8", "cfg1"):
         if "full_" + name in which:
             gen_full(V, tmp, name)
+    if "chunk_rule" in which:          # (prints only) the mean-of-groups rule against the direct batch-8 step of full_cfg2e8.npz
+        gen_full_chunked(V, tmp, "cfg2e8c", check_against="full_cfg2e8.npz")
+    if "full_cfg5e16" in which:        # batch 16 x 1024^2 from eight reference steps of two documents; the rule's check rides in the fixture
+        chk = gen_full_chunked(V, tmp, "cfg2e8c", check_against="full_cfg2e8.npz")
+        gen_full_chunked(V, tmp, "cfg5e16", extra={"chunk_rule_check": chk})
 
 
 if __name__ == "__main__":

@@ -51,9 +51,12 @@ def _worker(rank, world, port, out, mode):
     assert [n for n, _ in bert] == ["bert_model.weight", "bert_model.bias"]
     opts = [Opt(cnn), Opt(bert)]
     # tiny buckets -> several async all-reduces in flight
-    if mode == "shared":             # the default: SyncBatchNorm statistics on the reducer's communicator
-        red = FlatReducer(opts, bucket_mb=1e-4)
+    if mode in ("shared", "violated"):   # SyncBatchNorm statistics on the reducer's communicator, buckets from inside backward: the caller's
+        red = FlatReducer(opts, bucket_mb=1e-4, static_graph=True)      # word that the graph is rank-invariant is what allows the overlap
         assert Fn.SyncCtx.group is None and red.sync_bn_mode == "shared communicator" and red.overlap
+    elif mode == "default":          # THE DEFAULT: shared communicator, nothing asserted about the graph -> buckets after backward
+        red = FlatReducer(opts, bucket_mb=1e-4)
+        assert red.sync_bn_mode == "shared communicator" and not red.overlap
     elif mode == "own":              # opt-in: an own communicator for the statistics (tolerates rank-varying graphs with overlap)
         red = FlatReducer(opts, bucket_mb=1e-4, sync_bn_group="new", serialize_syncbn=True)
         assert dist.get_world_size(Fn.SyncCtx.group) == 2 and Fn.SyncCtx.group is not None and Fn.SyncCtx.before is not None
@@ -74,14 +77,22 @@ def _worker(rank, world, port, out, mode):
         if step > 0:
             assert red.order is not None and sorted(red.order) == list(range(len(red.buckets)))
             if step == 1:            # (in the last step rank 1's sequence may be held up by the bucket it skipped)
-                assert (len(red.handles) > 0) == (mode != "late")      # buckets left during backward unless overlap is off
+                assert (len(red.handles) > 0) == (mode not in ("late", "default"))      # buckets left during backward unless overlap is off
             if mode == "own" and step == 1:
                 # a statistics collective behind buckets in flight waits for them.  Only in a step where both ranks run the same graph:
                 # serialising the two communicators against each other is a deadlock once the ranks' sequences interleave differently
                 # (rank 0 waits for a bucket that rank 1 only issues from finish(), behind the statistics collective rank 0 has not
                 # reached) -- FlatReducer.__init__ says so, and it is why serialisation is not the default
                 Fn.SyncCtx.all_reduce(torch.ones(2))
+            if mode == "violated" and step == 1:
+                Fn.SyncCtx.all_reduce(torch.ones(2))          # (a SyncBatchNorm statistics collective on the shared communicator)
             assert "buckets issued" in red.describe_pending() and f"rank {rank}" in red.describe_pending()
+        if mode == "violated" and step == STEPS - 1 and rank == 1:
+            # static_graph=True was asserted and this rank's graph skipped a sub-module: the late flush is reported, not passed over
+            with pytest.raises(RuntimeError, match="static_graph=True"):
+                red.finish()
+            red.handles = []
+            continue
         red.finish()
         assert red.steps_done == step + 1 and not red.handles
     orders = [None, None]
@@ -94,7 +105,7 @@ def _worker(rank, world, port, out, mode):
     dist.destroy_process_group()
 
 
-@pytest.mark.parametrize("mode", ["shared", "own", "late"])
+@pytest.mark.parametrize("mode", ["shared", "default", "own", "late", "violated"])
 def test_flat_reducer_two_ranks(tmp_path, mode):
     port, out = _free_port(), str(tmp_path / "g.pt")
     mp.spawn(_worker, args=(2, port, out, mode), nprocs=2, join=True)

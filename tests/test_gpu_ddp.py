@@ -113,7 +113,7 @@ def _worker(rank, world, port, tmp, v):
     assert any(isinstance(m, torch.nn.SyncBatchNorm) for m in net.modules())
     cnn, bert = split_parameters(net)
     opts = [FusedSGD(cnn, dev, lr=0.005, momentum=0.9, weight_decay=0.005), FusedAdamW(bert, dev, lr=5e-5, weight_decay=0.01)]
-    red = FlatReducer(opts, serialize_syncbn=VARIANTS[v]["serialize"])
+    red = FlatReducer(opts, serialize_syncbn=VARIANTS[v]["serialize"], static_graph=True)
     dbatch = to_dev(_slice(_docs(), rank, rank + 1), dev)
     res = {}
     for step in range(3):
@@ -308,30 +308,36 @@ def _stock_worker(rank, world, port, tmp):
     del model, optimizer_cnn, optimizer_bert
     torch.cuda.empty_cache()
 
-    # ---- route B: flat buffers + FlatReducer + fused optimizers ("faster step") -----------------------
-    net = _build(os.path.join(tmp, f"flat{rank}"), sync_bn=True, v=v).to(dev).train()
-    cnn, bert = split_parameters(net)
-    opts = [FusedSGD(cnn, dev, lr=hyper["lr_cnn"], momentum=hyper["mom"], weight_decay=hyper["wd_cnn"]),
-            FusedAdamW(bert, dev, lr=hyper["lr_bert"], betas=(0.9, 0.999), eps=1e-8, weight_decay=hyper["wd_bert"])]
-    red = FlatReducer(opts)
-    res["flat_losses"] = []
-    for step in range(3):
-        random.seed(5)
-        loss = net(*dbatch)
-        res["flat_losses"].append(float(loss.item()))
-        for o in opts:
-            o.zero_grad()
-        loss.backward()
-        red.finish()
-        for o in opts:
-            o.step()
-        if step == 0:
-            res["flat1"] = {n: p.detach().cpu().clone() for n, p in net.named_parameters()}
-    torch.cuda.synchronize()
-    res["flat"] = {n: p.detach().cpu().clone() for n, p in net.named_parameters()}
+    # ---- route B: flat buffers + FlatReducer + fused optimizers ("faster step"), run TWICE: the distance of
+    #      the two runs of the SAME route is the noise floor the 3-step comparison of the two routes is read against ----------------------
+    def flat_route(tag):
+        net = _build(os.path.join(tmp, f"{tag}{rank}"), sync_bn=True, v=v).to(dev).train()
+        cnn, bert = split_parameters(net)
+        opts = [FusedSGD(cnn, dev, lr=hyper["lr_cnn"], momentum=hyper["mom"], weight_decay=hyper["wd_cnn"]),
+                FusedAdamW(bert, dev, lr=hyper["lr_bert"], betas=(0.9, 0.999), eps=1e-8, weight_decay=hyper["wd_bert"])]
+        red = FlatReducer(opts, static_graph=True)
+        losses, after1 = [], None
+        for step in range(3):
+            random.seed(5)
+            loss = net(*dbatch)
+            losses.append(float(loss.item()))
+            for o in opts:
+                o.zero_grad()
+            loss.backward()
+            red.finish()
+            for o in opts:
+                o.step()
+            if step == 0:
+                after1 = {n: p.detach().cpu().clone() for n, p in net.named_parameters()}
+        torch.cuda.synchronize()
+        return net, red, losses, after1, {n: p.detach().cpu().clone() for n, p in net.named_parameters()}
+
+    net, red, res["flat_losses"], res["flat1"], res["flat"] = flat_route("flat")
     res["flat_rm"] = net.backbone.conv_1[1].running_mean.cpu().clone()
-    res["init"] = {n: t.cpu() for n, t in init.items()}
     res["sync_bn_mode"] = red.sync_bn_mode
+    del net, red
+    _, _, res["flat_losses_b"], _, res["flat_b"] = flat_route("flatb")
+    res["init"] = {n: t.cpu() for n, t in init.items()}
     torch.save(res, os.path.join(tmp, f"stock_res{rank}.pt"))
     dist.barrier()
     dist.destroy_process_group()
@@ -364,7 +370,17 @@ def test_stock_ddp_wrapper_equals_flat_reducer(tmp_path):
         assert abs(a - b) <= tol * abs(b), (a, b, tol)
     # (first step: median 3e-6; AdamW's first update is lr * g / (|g| + eps) = +-lr for every element whose gradient is far above eps = 1e-8,
     #  and the few LayerNorm-weight elements with |g| ~ eps put the worst tensors at 1.2e-3 -- the sign of a 1e-8 gradient is noise)
-    for tag, ka, kb, tol in (("first step", "stock1", "flat1", 5e-3), ("three steps", "stock", "flat", 5e-2)):
+    # the noise floor of the 3-step comparison: the SAME route run twice in the same processes (float atomics order; round 5 measured the
+    # step-3 loss of one route moving by 4e-4 between two runs, more than the routes differ)
+    floor = []
+    for k, p0 in r0["init"].items():
+        if k.startswith("BERTgrid_generator.") or "pooler" in k or "key.bias" in k:
+            continue
+        da, db = (r0["flat_b"][k] - p0).double(), (r0["flat"][k] - p0).double()
+        floor.append((float((da - db).norm() / (db.norm() + 1e-30)), k))
+    floor.sort(reverse=True)
+    print("the flat route against ITSELF over three steps (run-to-run), worst:", floor[:3], "median", floor[len(floor) // 2], "losses", r0["flat_losses_b"])
+    for tag, ka, kb, tol in (("first step", "stock1", "flat1", 5e-3), ("three steps", "stock", "flat", max(5e-2, 4.0 * floor[0][0]))):
         worst = []
         for k, p0 in r0["init"].items():
             if k.startswith("BERTgrid_generator.") or "pooler" in k or "key.bias" in k:
@@ -379,3 +395,129 @@ def test_stock_ddp_wrapper_equals_flat_reducer(tmp_path):
     # (running mean after three steps of the amplifying fixture above: 1e-5 of the largest entry measured, run to run; the bound is relative
     #  to that entry -- an elementwise rtol would test the entries that happen to sit near zero)
     assert float((r0["stock_rm"] - r0["flat_rm"]).abs().max()) <= 1e-4 * float(r0["flat_rm"].abs().max())
+
+
+def _rccl_worker(rank, port, tmp):
+    """one rank, backend "nccl" (= RCCL on ROCm): the data-parallel machinery on the real backend"""
+    import sys
+    here = os.path.dirname(os.path.abspath(__file__))
+    for p in (here, os.path.join(os.path.dirname(here), "oracle"), os.path.join(os.path.dirname(here), "vibertgrid-pytorch_amd")):
+        if p not in sys.path:
+            sys.path.insert(0, p)
+    os.environ.update(MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port), HSA_ENABLE_IPC_MODE_LEGACY="0")
+    torch.cuda.set_device(0)
+    dev = torch.device("cuda", 0)
+    import datetime
+    dist.init_process_group("nccl", rank=0, world_size=1, device_id=dev, timeout=datetime.timedelta(seconds=120))
+    assert dist.get_backend() == "nccl"
+    from test_gpu_model import to_dev
+    from vbg import functions as Fn
+    from vbg import ops
+    from vbg.optim import FlatReducer, FusedAdamW, FusedSGD, split_parameters
+    res = {}
+
+    # ---- (a) a toy torch model: autograd-accumulated gradients -> post-accumulate hooks -> buckets from the staging stream -------------
+    class Toy(torch.nn.Module):
+        def __init__(self):
+            super().__init__()
+            torch.manual_seed(0)
+            self.bert_model = torch.nn.Linear(64, 48)
+            self.head = torch.nn.Sequential(torch.nn.Linear(48, 72), torch.nn.ReLU(), torch.nn.Linear(72, 8))
+            self.conv = torch.nn.Conv2d(8, 8, 3, padding=1).to(memory_format=torch.channels_last)
+
+        def forward(self, x, img):
+            return self.head(self.bert_model(x)).square().mean() + self.conv(img).square().mean()
+
+    def toy_run(with_reducer):
+        net = Toy().to(dev)
+        cnn, bert = split_parameters(net)
+        opts = [FusedSGD(cnn, dev, lr=0.05, momentum=0.9, weight_decay=0.005), FusedAdamW(bert, dev, lr=1e-3, weight_decay=0.01)]
+        red = FlatReducer(opts, bucket_mb=2e-3, force_enable=True, static_graph=True) if with_reducer else None
+        if red is not None:
+            assert red.enabled and red.forced and len(red.buckets) >= 3 and red.overlap
+        g = torch.Generator().manual_seed(3)
+        for step in range(3):
+            x, img = torch.randn(16, 64, generator=g).to(dev), torch.randn(2, 8, 9, 9, generator=g).to(dev)
+            for o in opts:
+                o.zero_grad()
+            net(x, img).backward()
+            if red is not None:
+                if step > 0:
+                    assert len(red.handles) > 0            # buckets left during backward (async works of ProcessGroupNCCL)
+                    assert "buckets issued" in red.describe_pending()
+                red.finish()
+                assert not red.handles and red.steps_done == step + 1
+            for o in opts:
+                o.step()
+        torch.cuda.synchronize()
+        return [o.group.pflat.clone() for o in opts], red
+
+    pa, red = toy_run(True)
+    pb, _ = toy_run(False)
+    res["toy_equal"] = all(torch.equal(a, b) for a, b in zip(pa, pb))       # an all-reduce over one rank is the identity, 1 / world = 1
+    res["toy_order"] = red.order
+
+    # ---- (b) the resnet-18 + 2-layer-BERT model with SyncBatchNorm: sunk gradients (GRAD_READY), statistics collectives on the buckets'
+    #      communicator, three steps; against the same steps without process-group involvement ------------------------------------------
+    dbatch = to_dev(_docs(), dev)
+
+    def net_run(with_reducer):
+        net = _build(os.path.join(tmp, f"rccl{int(with_reducer)}"), sync_bn=with_reducer).to(dev).train()
+        cnn, bert = split_parameters(net)
+        opts = [FusedSGD(cnn, dev, lr=0.005, momentum=0.9, weight_decay=0.005), FusedAdamW(bert, dev, lr=5e-5, weight_decay=0.01)]
+        red = None
+        if with_reducer:
+            assert any(isinstance(m, torch.nn.SyncBatchNorm) for m in net.modules())
+            red = FlatReducer(opts, bucket_mb=4.0, force_enable=True, static_graph=True)
+            assert red.sync_bn_mode == "shared communicator" and Fn.SyncCtx.active()
+            red.start_watchdog(60.0)
+        else:
+            Fn.SyncCtx.force = False
+            Fn.GRAD_READY[0] = None
+        losses, g0 = [], None
+        for step in range(3):
+            random.seed(5)
+            loss = net(*dbatch)
+            for o in opts:
+                o.zero_grad()
+            loss.backward()
+            if red is not None:
+                red.finish()
+            if step == 0:
+                g0 = {n: p.grad.detach().clone() for n, p in net.named_parameters() if p.grad is not None and not n.startswith("BERTgrid_generator.")}
+            losses.append(float(loss.detach()))
+            for o in opts:
+                o.step()
+        torch.cuda.synchronize()
+        return losses, g0, red
+
+    seq0 = Fn.SyncCtx.seq
+    la, ga, red = net_run(True)
+    res["syncbn_collectives"] = Fn.SyncCtx.seq
+    res["buckets"], res["order"], res["steps_done"] = len(red.buckets), red.order, red.steps_done
+    lb, gb, _ = net_run(False)
+    res["losses"] = (la, lb)
+    res["grad_err"] = max((float((ga[k] - gb[k]).norm() / (gb[k].norm() + 1e-30)), k) for k in gb if "key.bias" not in k)
+    torch.save(res, os.path.join(tmp, "rccl_res.pt"))
+    dist.destroy_process_group()
+
+
+def test_rccl_one_rank_runs_the_reducer_and_syncbn(tmp_path):
+    """pipeline/distributed_utils.py:89-98 is `backend="nccl"`: until a multi-GPU node runs this code, the one GPU of the test box runs the
+    REAL backend with a process group of one rank and `FlatReducer(force_enable=True)` -- RCCL loads, ProcessGroupNCCL builds its
+    communicator, buckets are issued as async works from the staging stream inside backward, `finish()` waits on them (work.wait() blocks
+    the STREAM on this backend, the host on gloo), SyncBatchNorm statistics (fp64 [sum, sumsq, count]) travel as all-reduces on the same
+    communicator between them, the watchdog thread runs.  Every collective over one rank is the identity, so: the toy model's parameters
+    after three steps are BIT-equal to the reducer-less run, and the resnet-18 + BERT model's first-step loss / gradients equal the plain
+    BatchNorm run (1e-5 / 1e-4: SyncBatchNorm takes the fold -> all_reduce -> finalize route with fp64 statistics)."""
+    tmp = str(tmp_path)
+    mp.spawn(_rccl_worker, args=(_free_port(), tmp), nprocs=1, join=True)
+    r = torch.load(os.path.join(tmp, "rccl_res.pt"))
+    print("RCCL one-rank run:", {k: r[k] for k in ("toy_equal", "toy_order", "syncbn_collectives", "buckets", "order", "steps_done", "losses", "grad_err")})
+    assert r["toy_equal"]
+    assert r["steps_done"] == 3 and sorted(r["order"]) == list(range(r["buckets"])) and r["buckets"] >= 3
+    assert r["syncbn_collectives"] >= 3 * 2 * 20                   # forward + backward statistics of every BatchNorm layer, three steps
+    la, lb = r["losses"]
+    assert abs(la[0] - lb[0]) <= 1e-5 * abs(lb[0]), (la, lb)
+    assert r["grad_err"][0] < 1e-4, r["grad_err"]
+    assert all(abs(a - b) <= 2e-3 * abs(b) for a, b in zip(la, lb)), (la, lb)

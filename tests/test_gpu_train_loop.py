@@ -193,3 +193,60 @@ def test_checkpoint_round_trip_like_eval_script(golden, tmp_path):
     # the duplicated BERT registration (bert_model. / BERTgrid_generator.model.) stays ONE storage after loading
     assert fresh.bert_model.embeddings.word_embeddings.weight.data_ptr() == \
         fresh.BERTgrid_generator.model.embeddings.word_embeddings.weight.data_ptr()
+
+
+def test_stock_loop_on_model_owned_flat_storage(golden, tmp_path):
+    """pipeline/train_val_utils.py:264-284 verbatim with torch.optim around the drop-in model, which homes its parameters in flat storage
+    at its first training forward (vbg.optim.home_parameters): (a) after the first forward every trainable parameter is a view of one of
+    two flat buffers and stays one through zero_grad(set_to_none) / backward / optimizer.step(); (b) the weights the NEXT forward multiplies
+    are the stepped ones (plane / filter images follow the parameters' version counters): three steps equal three steps of the same loop
+    with homing switched off (VBG_HOME=0: parameters where torch put them, per-parameter caches) -- first step to 1e-5 on every
+    parameter, the next losses to 1e-3 (the tiny fixture amplifies rounding differences step by step, see
+    test_gradscaler_loop_torch_and_fused); (c) `clip_grad_norm` and a second zero_grad()/backward() cycle see the flat views."""
+    from vbg import ops
+    dev = torch.device("cuda")
+    dbatch = to_dev(_e2e_inputs(golden("e2e.npz")), dev)
+    res = {}
+    for mode in ("homed", "plain"):
+        ops.set_home(mode == "homed")
+        try:
+            net = _net(tmp_path, mode, dev)
+            oc, ob = _torch_opts(net)
+            ls, after1 = [], None
+            for step in range(3):
+                random.seed(100 + step)
+                loss = net(*dbatch)
+                ls.append(loss.item())
+                oc.zero_grad()
+                ob.zero_grad()
+                assert all(p.grad is None for p in net.parameters())
+                loss.backward()
+                if loss > 10:
+                    torch.nn.utils.clip_grad_norm(net.parameters(), max_norm=2)
+                if mode == "homed":
+                    groups = {id(p._vbg_flat[0]) for n, p in net.named_parameters() if "pooler" not in n and "resnet.fc" not in n}
+                    assert len(groups) == 2
+                    for n, p in net.named_parameters():
+                        if "pooler" in n or "resnet.fc" in n:
+                            assert p.grad is None and not hasattr(p, "_vbg_flat"), n
+                            continue
+                        g, off = p._vbg_flat
+                        assert p.data_ptr() == g.pflat.data_ptr() + 4 * off and p.grad.data_ptr() == g.gflat.data_ptr() + 4 * off, n
+                else:
+                    assert not any(hasattr(p, "_vbg_flat") for p in net.parameters())
+                oc.step()
+                ob.step()
+                if step == 0:
+                    after1 = {k: v.detach().clone() for k, v in net.named_parameters()}
+            res[mode] = (ls, after1, net)
+        finally:
+            ops.set_home(True)
+    (lh, ah, nh), (lp, ap, npn) = res["homed"], res["plain"]
+    print("stock loop, homed vs plain losses:", lh, lp)
+    assert abs(lh[0] - lp[0]) <= 1e-6 * abs(lp[0])
+    worst = max((float((ah[k] - ap[k]).norm() / (ap[k].norm() + 1e-12)), k) for k in ah if "pooler" not in k and "key.bias" not in k)
+    print("worst parameter distance after the first step:", worst)
+    assert worst[0] < 1e-5, worst
+    assert abs(lh[1] - lh[0]) > 1e-3 * abs(lh[0])                 # (the second forward saw other weights than the first ...)
+    for a, b in zip(lh[1:], lp[1:]):                               # (... the stepped ones)
+        assert abs(a - b) <= 1e-3 * abs(b), (lh, lp)

@@ -232,7 +232,26 @@ class ViBERTgridNet(nn.Module):
         with bn_tick_scope():          # the BatchNorm step counters of the whole forward advance in one launch
             return self._forward(image, seg_indices, segment_classes, coors, corpus, mask)
 
+    def _home(self):
+        """Flat parameter / gradient storage, owned by the model (vbg.optim.home_parameters): built at the first training forward on
+        the device the parameters are on by then (after `.to(device)`, `convert_sync_batchnorm`, the DDP wrapper: train_SROIE.py:202-210),
+        rebuilt when something moved them (`.to()`, a fresh `.data`).  The all-pair encoder backward, the once-per-step plane / filter
+        images and the in-place weight-gradient accumulation hang on this storage and on nothing the caller constructs: torch.optim.SGD /
+        AdamW step the views like any other parameter."""
+        home = self.__dict__.get("_vbg_home_state")
+        if home is None or not home.valid():
+            from vbg.optim import ModelHome
+            home = ModelHome(self, track_unused=self.classifier_mode == "full")
+            self.__dict__["_vbg_home_state"] = home
+        return home
+
+    def _rooted(self, loss, home):
+        return loss if home is None else Fn.StepRootFn.apply(loss, home)
+
     def _forward(self, image, seg_indices, segment_classes, coors, corpus, mask):
+        # (training forward on the device: the parameters live in flat storage from here on; validation under no_grad does not need it)
+        home = self._home() if (self.training and torch.is_grad_enabled() and ops.home_enabled()
+                                and next(self.late_fusion_net.parameters()).is_cuda) else None
         # `amp: True`: the caller wraps this call in torch.cuda.amp.autocast (reference pipeline/train_val_utils.py:264); the
         # matrix products of this forward AND of its backward then run on the bf16 matrix cores (see vbg.ops.set_amp)
         ops.set_amp(torch.is_autocast_enabled("cuda"))
@@ -247,7 +266,7 @@ class ViBERTgridNet(nn.Module):
             roi = self.grid_roi_align_net(p_fuse, icoors, None, packed=packed)
             fuse = self.late_fusion_net(roi, emb_cat)
             loss_c, gt_label, pred_label = cls_head(fuse, segment_classes)
-            total_loss = loss_c + self.loss_control_lambda * loss_aux
+            total_loss = self._rooted(loss_c + self.loss_control_lambda * loss_aux, home)
             if train_only:
                 return total_loss
             return total_loss, pred_mask, pred_ss, gt_label, pred_label
@@ -266,7 +285,7 @@ class ViBERTgridNet(nn.Module):
         roi = self.grid_roi_align_net(p_fuse, icoors, None, packed=packed)
         fuse = self.late_fusion_net(roi, emb_cat)
         loss_c, gt_label, pred_label = cls_head(fuse, segment_classes, prepared=(label_class, label_pn, plans[2:]))
-        total_loss = loss_c + self.loss_control_lambda * loss_aux
+        total_loss = self._rooted(loss_c + self.loss_control_lambda * loss_aux, home)
         if train_only:
             return total_loss
         return total_loss, pred_mask, pred_ss, gt_label, pred_label

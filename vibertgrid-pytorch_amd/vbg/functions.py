@@ -37,9 +37,20 @@ GRAD_READY = [None]        # callable(param) or None
 
 
 def wgrad_dest(w):
-    if getattr(w, "_vbg_sunk", False) and w.grad is not None:
-        return w.grad
+    if getattr(w, "_vbg_sunk", False):
+        g = w.grad
+        if g is None:
+            # `.grad` was set to None (optimizer.zero_grad() of torch.optim) and no StepRootFn armed this backward (a Function used on
+            # its own): the flat view comes back zeroed
+            g = w._vbg_flat[0].attach(w)
+        return g
     return None
+
+
+def sinks(w) -> bool:
+    """will the BACKWARD of this step find a flat gradient view for w?  (asked in forward, where the reference's loop has not called
+    optimizer.zero_grad() yet -- `.grad` may be None there and attached again, by StepRootFn, when the backward starts)"""
+    return getattr(w, "_vbg_sunk", False)
 
 
 def wgrad_done(w):
@@ -93,10 +104,11 @@ class SyncCtx:
     before = None
     seq = 0            # statistics collectives issued since the reducer was built; `last` = (seq, numel) -- for hang reports
     last = None
+    force = False      # a process group of ONE rank runs the collectives as well (FlatReducer(force_enable=True): the one-GPU RCCL check)
 
     @classmethod
     def active(cls):
-        return dist.is_available() and dist.is_initialized() and dist.get_world_size(cls.group) > 1
+        return dist.is_available() and dist.is_initialized() and (dist.get_world_size(cls.group) > 1 or cls.force)
 
     @classmethod
     def all_reduce(cls, t):
@@ -363,7 +375,9 @@ class ConvBnFn(torch.autograd.Function):
         # the largest magnitude of y rides on the kernel that writes it: the scale of y as an operand of the next convolution's
         # fp16-form weight gradient (the tag travels on the tensor object; a consumer that does not find one takes a vbg_amax pass)
         # (grad mode is off inside forward(): whether a backward will come is what ctx.needs_input_grad says)
-        y_amax = ops.amax_slot(x.device) if (any(ctx.needs_input_grad) and ops.conv3_f16_bwd_enabled()) else None
+        # ... and the scale of y as the ACTIVATION operand of the next convolution's fp16-form forward (an activation of 65520 or more no
+        # longer becomes inf): published whenever that form is on, inference and no_grad included
+        y_amax = ops.amax_slot(x.device) if (ops.conv3_f16_enabled() or (any(ctx.needs_input_grad) and ops.conv3_f16_bwd_enabled())) else None
         y = ops.bn_apply(z2, r2, mean, invstd, gamma, beta, relu, y_amax=y_amax).view(z.shape)
         if y_amax is not None:
             y._vbg_amax = (y_amax, y._version)
@@ -604,7 +618,7 @@ class BertLayerFn(torch.autograd.Function):
         # activations saved for backward are pair planes, no bf16 planes of x1 / gelu(h) / y / ctx are written at all
         pair_bwd = (pair and ops.pair_bwd_enabled() and fused_qkv and dh == 64 and meta.maxlen <= 512 and ops.flash_enabled()
                     and any(ctx.needs_input_grad)
-                    and all(wgrad_dest(t) is not None for t in (wq, wk, wv, bq, bk, bv, wo, bo, wi, bi, wo2, bo2)))
+                    and all(sinks(t) for t in (wq, wk, wv, bq, bk, bv, wo, bo, wi, bi, wo2, bo2)))
         assert not carrier_is_pair or pair, "pair planes handed to a layer that does not run the pair form"
         if pair_bwd and xq is None:
             xq = ops.split_planes_pair(x)
@@ -1027,6 +1041,30 @@ class BertLayerFn(torch.autograd.Function):
             ops.linear_dgrad(dj, w, out=dx, accumulate=True)
         return (dx, None, dws[0], dbs[0], dws[1], dbs[1], dws[2], dbs[2], dwo, dbo, dg1, db1, dwi, dbi, dwo2, dbo2,
                 dg2, db2, None, None, None, None, None)
+
+
+class StepRootFn(torch.autograd.Function):
+    """Identity on the loss ViBERTgridNet.forward returns.  Its backward is the first node of the model's graph to run (behind the
+    caller's own scaling of the loss, e.g. GradScaler.scale): it re-arms the flat gradient buffers of the parameter groups the model
+    is homed in (vbg.optim.FlatGroup.arm) -- the reference's loop drops every `.grad` between forward and backward
+    (`optimizer.zero_grad()`, pipeline/train_val_utils.py:272-273) -- and, for graphs that depend on the data (classifier_mode full:
+    a per-class net may see no sample), hands back `None` for the parameters that took no part in this step, as torch would have
+    left them (`touched`: a set the groups' post-accumulate hooks fill)."""
+
+    @staticmethod
+    def forward(ctx, loss, home):
+        ctx.home = home
+        return loss.view_as(loss)
+
+    @staticmethod
+    def backward(ctx, dloss):
+        home = ctx.home
+        for g in home.groups:
+            g.arm()
+        if home.touched is not None:
+            home.touched.clear()
+            torch.autograd.Variable._execution_engine.queue_callback(home.drop_untouched)
+        return dloss, None
 
 
 class JoinSideFn(torch.autograd.Function):

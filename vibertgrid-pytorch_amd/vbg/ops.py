@@ -87,6 +87,14 @@ def h2d(host, device):
     return t.pin_memory().to(device, non_blocking=True)
 
 
+def _untag(t):
+    """a kernel of this library is about to write INTO t through its raw pointer (accumulate launches): torch's version counter does not
+    move, so an amax tag a producer left on the tensor object (vbg.functions._amax_tag validates tags by `_version`) would survive a
+    change of max |t| -- the tag is dropped here instead; the producer that completes the tensor sets a new one"""
+    if t is not None:
+        t.__dict__.pop("_vbg_amax", None)
+
+
 def P(t):
     if t is None:
         return None
@@ -144,6 +152,8 @@ def gemm_raw(M, N, K, A, lda, a_kind, B, ldb, b_kind, Cout, ldc, *, bias=None, e
         splitk = 0          # training: let the library split few-tile / long-K products; no_grad (inference, eval) stays bit-reproducible
     if splitk == 0 and accumulate:
         splitk = 1
+    if accumulate:
+        _untag(Cout)
     d.epi, d.alpha, d.accumulate, d.splitk, d.tile = epi, float(alpha), int(bool(accumulate)), int(splitk), int(tile)
     d.bk = int(bk)
     if _AMP[0] or _SPLIT3[0]:
@@ -312,6 +322,8 @@ def plane_gemm(a: Planes, b: Planes, out=None, *, bias=None, epi=EPI_NONE, C2=No
     d.bias = None if bias is None else bias.data_ptr()
     if out_planes is not None:
         d.Cp, d.c_plane, d.ldp = out_planes.buf.data_ptr(), out_planes.plane, out_planes.ld
+    if accumulate:
+        _untag(out)
     d.epi, d.alpha, d.accumulate, d.splitk, d.tile = epi, float(alpha), int(bool(accumulate)), int(splitk), int(tile)
     if form:                               # a, b: fp16-pair planes [2][rows][ld]; a_amax: the slot a's planes were scaled by
         assert a.buf.shape[0] == 2 and b.buf.shape[0] == 2
@@ -401,6 +413,7 @@ def plane_gemm_grouped(problems, *, trans=True, accumulate=True, tile=0, alpha=1
         k = kk
     d.K = k
     d.form = (2 if _AMP[0] else 1) if form else 0       # (autocast region: the hi planes only, one product)
+    _seen(("plane_gemm:grouped_onep" if _AMP[0] else "plane_gemm:grouped_pair") if form else "plane_gemm:grouped_bf16x3")
     check(lib.vbg_plane_gemm(C.byref(d), _stream()), "vbg_plane_gemm (grouped)")
 
 
@@ -427,6 +440,19 @@ def set_flash(on: bool):
 
 def flash_enabled() -> bool:
     return _FLASH[0]
+
+
+_HOME = [os.environ.get("VBG_HOME", "1") != "0"]
+
+
+def set_home(on: bool):
+    """ViBERTgridNet homes its trainable parameters in flat storage at its first training forward (vbg.optim.home_parameters); off =
+    parameters stay where the caller put them unless an optimizer of vbg.optim moves them (the A/B, and the generic per-parameter route)"""
+    _HOME[0] = bool(on)
+
+
+def home_enabled() -> bool:
+    return _HOME[0]
 
 
 def bump_weight_epoch():
@@ -746,6 +772,11 @@ def _conv3_min_tiles_bwd():
     return _CONV3_MIN_TILES[0]          # (the forward's 256 was A/B-ed in the step for the fp16-form input gradient: 190.97 vs 190.74 docs/s, no gain)
 
 
+def conv3_f16_enabled() -> bool:
+    """the wide 3x3 convolutions' FORWARD runs the two-piece fp16 form (and consumes an activation's amax slot when the producer left one)"""
+    return _CONV3_F16[0] and _CONV3[0] and _SPLIT3[0]
+
+
 def set_conv3_f16(on: bool):
     """forward convolutions of csrc/conv3.hip on two fp16 pieces per operand (three piece products) instead of three bf16 pieces (six)"""
     _CONV3_F16[0] = bool(on)
@@ -806,6 +837,8 @@ def conv3x3(x, w_ohwi, bias=None, out=None, stats=None, accumulate=False, f16x2=
     if out is None:
         assert not accumulate
         out = torch.empty((B, H, W, N), device=x.device, dtype=f32)
+    elif accumulate:
+        _untag(out)
     assert x_amax is None or f16x2
     assert w_planes is None or f16x2
     nz = conv3_split(B, H, W, Cs, N) if nsplit is None else int(nsplit)
@@ -886,12 +919,24 @@ def weight_col_l1max(owner, view=None):
     if slot is not None and slot["tag"] == tag:
         return st["out"][slot["idx"]:slot["idx"] + 1]
     if slot is None or slot["ptr"] != w.data_ptr():
+        # (a parameter that MOVED -- flattened into a flat buffer after a warm-up step, .to(), a fresh .data -- registers again; its old
+        #  entry leaves the table: the kernel must never read rows x cols floats from an address that may have been freed)
+        st["entries"] = [e for e in st["entries"] if e["ref"]() is not owner]
         slot = {"idx": -1, "tag": None, "ptr": w.data_ptr(), "shape": tuple(w.shape), "ld": w.stride(0), "ref": weakref.ref(owner)}
         owner.__dict__["_vbg_l1"] = slot
         st["entries"].append(slot)
         st["table"] = None
-    if any(e["ref"]() is None for e in st["entries"]):          # a model went away: its matrices leave the table (never read freed memory)
-        st["entries"] = [e for e in st["entries"] if e["ref"]() is not None]
+    # a model went away, or another registered matrix moved since it registered: those leave the table as well (as _c3pw_refresh does);
+    # a moved one registers again on its next use
+    keep = []
+    for e in st["entries"]:
+        o = e["ref"]()
+        if o is not None and (e is slot or o.data_ptr() == e["ptr"]):
+            keep.append(e)
+        elif o is not None:
+            o.__dict__.pop("_vbg_l1", None)
+    if len(keep) != len(st["entries"]):
+        st["entries"] = keep
         st["table"] = None
     if st["table"] is None or st["out"] is None or st["table"].device != w.device:
         n = len(st["entries"])
@@ -1369,17 +1414,20 @@ def row_softmax(x):
 
 
 def gelu_bwd_(h, dg):
+    _untag(dg)
     check(lib.vbg_gelu_bwd(P(h), P(dg), dg.numel(), _stream()), "vbg_gelu_bwd")
     return dg
 
 
 def relu_bwd_(y, dy):
+    _untag(dy)
     check(lib.vbg_relu_bwd(P(y), P(dy), dy.numel(), _stream()), "vbg_relu_bwd")
     return dy
 
 
 def add_(a, b):
     assert a.numel() == b.numel() and a.is_contiguous() and b.is_contiguous()
+    _untag(a)
     check(lib.vbg_add_inplace(P(a), P(b), a.numel(), _stream()), "vbg_add_inplace")
     return a
 
@@ -1568,6 +1616,8 @@ def sumpool(hi, f, out=None, accumulate=False):
     if out is None:
         out = torch.empty((B, H // f, W // f, C_), device=hi.device, dtype=f32)
         accumulate = False
+    elif accumulate:
+        _untag(out)
     check(lib.vbg_sumpool(P(hi), B, H, W, C_, f, P(out), int(accumulate), _stream()), "vbg_sumpool")
     return out
 

@@ -85,13 +85,19 @@ class FlatGroup:
         self.total = (o + 31) // 32 * 32
         self.pflat = torch.zeros((self.total,), device=device, dtype=torch.float32)
         self.gflat = torch.zeros((self.total,), device=device, dtype=torch.float32)
+        self.gviews = []                     # the persistent gradient views (re-attached when something set .grad to None)
+        self._ptrs = []                      # device address every parameter must still have for the group to be its home
         for p, off in zip(self.params, self.offsets):
             v = _phys_view(self.pflat, off, p.data)
             v.copy_(p.data)
             p.data = v
-            p.grad = _phys_view(self.gflat, off, p.data)
+            gv = _phys_view(self.gflat, off, p.data)
+            p.grad = gv
             p._vbg_sunk = True               # weight-gradient GEMMs accumulate straight into this view
             p._vbg_flat = (self, off)
+            self.gviews.append(gv)
+            self._ptrs.append(self.pflat.data_ptr() + 4 * off)
+        self._index = {id(p): i for i, p in enumerate(self.params)}
         # bf16 planes of the whole buffer (csrc/gemm_planes.hip operands), refreshed at most once per parameter version: the plain
         # image [3][total] in ONE elementwise launch, the transposed images of the matrices that asked for one in ONE batched launch
         self._planes = None
@@ -106,9 +112,37 @@ class FlatGroup:
 
     def zero_grad(self):
         self.gflat.zero_()
-        for p, off in zip(self.params, self.offsets):       # re-attach if something set grads to None
-            if p.grad is None or p.grad.data_ptr() != self.gflat.data_ptr() + 4 * off:
-                p.grad = _phys_view(self.gflat, off, p.data)
+        for p, gv in zip(self.params, self.gviews):          # re-attach if something set grads to None
+            if p.grad is not gv:
+                p.grad = gv
+
+    def valid(self) -> bool:
+        """every parameter still lives where the group put it (Module.to / .half / a fresh `p.data = ...` moves it away)"""
+        return all(p.data_ptr() == a for p, a in zip(self.params, self._ptrs))
+
+    def arm(self):
+        """start of a backward pass (vbg.functions.StepRootFn): the reference's loop calls `optimizer.zero_grad()` between forward and
+        backward (pipeline/train_val_utils.py:272-273) and torch.optim's default is set_to_none -- every `.grad` is None then.  The
+        gradient views come back, over ONE memset of the flat buffer when all of them were dropped (the usual case), slice by slice
+        otherwise (a caller that keeps some gradients to accumulate into).  A gradient the caller left in place is accumulated into,
+        as torch would."""
+        missing = [i for i, p in enumerate(self.params) if p.grad is None]
+        if not missing:
+            return
+        if len(missing) == len(self.params):
+            self.gflat.zero_()
+        else:
+            for i in missing:
+                self.gviews[i].zero_()
+        for i in missing:
+            self.params[i].grad = self.gviews[i]
+
+    def attach(self, p):
+        """gradient view of one parameter whose `.grad` is None outside an armed backward (a Function used on its own): zeroed, attached"""
+        gv = self.gviews[self._index[id(p)]]
+        gv.zero_()
+        p.grad = gv
+        return gv
 
     def invalidate(self):
         """forget every cached plane image of the buffer.  The caches follow the optimizer kernels (weight epoch), torch in-place
@@ -228,6 +262,67 @@ def split_parameters(model: torch.nn.Module, unused: Sequence[str] = STATIC_UNUS
     return cnn, bert
 
 
+def home_parameters(model: torch.nn.Module, device=None) -> List[FlatGroup]:
+    """Flat parameter / gradient storage owned by the MODEL (called by ViBERTgridNet at its first training forward): the trainable
+    parameters move into one flat buffer per optimizer group of the reference (train_SROIE.py:215-221: "bert_model" in name -> AdamW,
+    the rest -> SGD), their `.grad` become views of a flat gradient buffer that the weight-gradient kernels accumulate into, and the
+    plane / filter images the matrix kernels read are refreshed once per weight version for the whole buffer.  None of this depends on
+    the optimizer class the caller constructs: torch.optim.SGD / AdamW update the views in place (their version counters tell the
+    caches), FusedSGD / FusedAdamW adopt the groups they find.  Groups that are already in place (and still valid) are kept."""
+    cnn, bert = split_parameters(model)
+    groups = []
+    for named in (cnn, bert):
+        if not named:
+            continue
+        found = {}
+        for _, p in named:
+            g = getattr(p, "_vbg_flat", (None,))[0]
+            found[id(g)] = g
+        if None not in found.values() and all(g.valid() for g in found.values()):
+            # already homed (an optimizer of vbg.optim built before the first forward, possibly over a different split): kept as is
+            groups.extend(g for g in found.values() if all(g is not h for h in groups))
+            continue
+        dev = device if device is not None else named[0][1].device
+        g = FlatGroup(list(named), dev)
+        g.ref_names = list(named.ref_names)
+        groups.append(g)
+    return groups
+
+
+class ModelHome:
+    """What ViBERTgridNet keeps about the flat storage its parameters live in: the groups, and -- for graphs that depend on the data --
+    which parameters took part in the current backward (post-accumulate hooks fire for every parameter whose autograd node ran, also
+    when a Function wrote the gradient itself and returned None), so that the others get `.grad = None` back when the backward ends,
+    as torch.optim expects of parameters that received no gradient (it skips them: no weight decay, no momentum step)."""
+
+    def __init__(self, model, track_unused: bool):
+        self.groups = home_parameters(model)
+        self.touched = set() if track_unused else None
+        if track_unused:
+            for g in self.groups:
+                for p in g.params:
+                    if not getattr(p, "_vbg_touch_hook", False):
+                        p.register_post_accumulate_grad_hook(self._touch)
+                        p._vbg_touch_hook = True
+                    p._vbg_home = self
+
+    @staticmethod
+    def _touch(p):
+        h = getattr(p, "_vbg_home", None)
+        if h is not None and h.touched is not None:
+            h.touched.add(id(p))
+
+    def valid(self) -> bool:
+        return all(g.valid() for g in self.groups)
+
+    def drop_untouched(self):
+        t = self.touched
+        for g in self.groups:
+            for p in g.params:
+                if id(p) not in t:
+                    p.grad = None
+
+
 def _torch_defaults(cls, **kw):
     """the param_group keys of the torch optimizer this one stands in for (so a checkpoint written here loads into it)"""
     return dict(cls([torch.nn.Parameter(torch.zeros(1))], **kw).defaults)
@@ -249,7 +344,15 @@ class _FlatOptimizer(torch.optim.Optimizer):
     def __init__(self, named, device, defaults: Dict):
         ref = getattr(named, "ref_names", None)
         named = list(named)
-        self.group = FlatGroup(named, device)
+        # a group the model (or an earlier optimizer) already homed exactly these parameters in is adopted, not rebuilt
+        homes = {id(getattr(p, "_vbg_flat", (None,))[0]): getattr(p, "_vbg_flat", (None,))[0] for _, p in named}
+        g = next(iter(homes.values())) if len(homes) == 1 else None
+        if (g is not None and len(g.params) == len(named) and set(g._index) == {id(p) for _, p in named} and g.valid()
+                and g.pflat.device.type == torch.device(device).type and torch.device(device).index in (None, g.pflat.device.index)):
+            self.group = g
+            g.zero_grad()
+        else:
+            self.group = FlatGroup(named, device)
         if ref is not None:                 # indices of the reference optimizer's full parameter list (unused tensors included)
             assert set(n for n, _ in named) <= set(ref)
             self.group.ref_names = list(ref)
@@ -372,12 +475,28 @@ class FlatReducer:
     issues the affected bucket (and everything behind it) from `finish()`; the sequence is unchanged."""
 
     def __init__(self, optimizers, bucket_mb: float = 32.0, group=None, sync_bn_group="auto", serialize_syncbn=None, overlap=None,
-                 dry_run=False):
-        """dry_run (one process): same buckets, same hooks and the same launch sequence, but a bucket's "collective" is a timestamp on
+                 dry_run=False, force_enable=None, static_graph=None):
+        """force_enable (VBG_FORCE_REDUCER=1): run the whole machinery -- hooks, rank-agreed sequence, collectives issued from the staging
+        stream, work.wait(), SyncBatchNorm statistics on the communicator -- on a process group of ONE rank as well (every collective is an
+        identity there): the one-GPU check of the real backend (ProcessGroupNCCL = RCCL) before a multi-GPU node sees this code.
+        static_graph: the caller's word that every rank runs the same autograd graph every step (classifier_mode simp / crf with every
+        sub-module used).  With SyncBatchNorm statistics on the buckets' communicator AND overlap, a bucket that one rank issues from
+        finish() while the others issue it inside backward sits at a different place among the statistics collectives -- mismatched
+        collectives on one communicator.  So on a shared communicator the buckets only leave from inside backward when
+        static_graph=True; without that word every bucket is issued from finish(), a rank-invariant point for ANY graph (the overlap is
+        what is given up; `sync_bn_group="new"` keeps it for rank-varying graphs on a second communicator).  A rank that asserted
+        static_graph=True and then has to flush a bucket from finish() after step 1 raises instead of risking a silent mismatch.
+        dry_run (one process): same buckets, same hooks and the same launch sequence, but a bucket's "collective" is a timestamp on
         the stream it would be issued from -- `timeline()` then tells when, inside backward, every bucket could have left
         (tools/bucket_timeline.py)"""
         self.dry = bool(dry_run)
-        self.enabled = dist.is_available() and dist.is_initialized() and dist.get_world_size(group) > 1
+        if force_enable is None:
+            force_enable = os.environ.get("VBG_FORCE_REDUCER", "0") != "0"
+        self.forced = bool(force_enable) and dist.is_available() and dist.is_initialized() and dist.get_world_size(group) == 1
+        self.enabled = dist.is_available() and dist.is_initialized() and (dist.get_world_size(group) > 1 or self.forced)
+        if static_graph is None and os.environ.get("VBG_STATIC_GRAPH") is not None:
+            static_graph = os.environ["VBG_STATIC_GRAPH"] != "0"
+        self.static_graph = static_graph
         self.pg = group
         self.optimizers = optimizers
         self.world = dist.get_world_size(group) if self.enabled else 1
@@ -439,6 +558,9 @@ class FlatReducer:
             serialize_syncbn = os.environ.get("VBG_SERIALIZE_SYNCBN", "0") != "0"
         Fn.SyncCtx.before = self._wait_for_buckets if (serialize_syncbn and not self.dry) else None
         Fn.SyncCtx.seq = 0
+        Fn.SyncCtx.force = self.forced
+        if self.sync_bn_mode == "shared communicator" and self.overlap and not self.static_graph:
+            self.overlap = False       # graphs not known to be rank-invariant on ONE communicator: every bucket from finish()
         Fn.GRAD_READY[0] = self._param_ready      # sunk gradients (written by the wgrad kernels) report here
         cap = int(bucket_mb * (1 << 20) / 4)
         for o in optimizers:
@@ -563,11 +685,19 @@ class FlatReducer:
             dist.broadcast(t, src=dist.get_global_rank(self.pg, 0) if self.pg is not None else 0, group=self.pg)
             self.order = [int(i) for i in t.tolist()]
             assert sorted(self.order) == list(range(len(self.buckets)))
+        late = 0
         while self._next < len(self.order):        # a parameter got no gradient this step (zero rows): reduce what is there
             self._issue(self.order[self._next])
             self._next += 1
+            late += 1
         for _, h in self.handles:
             h.wait()
+        if (late and self.overlap and self.static_graph and self.sync_bn_mode == "shared communicator" and self.steps_done >= 1
+                and Fn.SyncCtx.seq > 0 and not self.forced):
+            raise RuntimeError(f"vbg.optim.FlatReducer(static_graph=True): {late} gradient bucket(s) had to be issued from finish() in step "
+                               f"{self.steps_done + 1} -- this rank's autograd graph skipped a sub-module, so its collectives did not interleave "
+                               "with the SyncBatchNorm statistics the way the other ranks' did.  Build the reducer with static_graph=False "
+                               "(buckets after backward) or sync_bn_group='new' (own communicator for the statistics).")
         self.handles = []
         for b in self.buckets:
             b[2] = b[1]
