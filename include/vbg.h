@@ -236,6 +236,12 @@ int vbg_attn(const vbg_attn_desc* desc, void* stream);
 unsigned vbg_attn_drop_thr16(float drop_p);
 int vbg_attn_mask(const int* seq_len, const long long* mask_off, int nseq, int heads, int maxlen, float drop_p,
                   unsigned long long seed, unsigned long long stream_id, unsigned* mask_q, unsigned* mask_k, void* stream);
+/* the same for `nlayers` encoder layers of one step in ONE launch (transformers BertSelfAttention.dropout of every layer of
+ * model/BERTgrid_generator.py:134's encoder): layer l draws from stream id stream_id0 + l * stream_id_stride and owns the words
+ * [l * layer_words, (l + 1) * layer_words) of mask_q / mask_k; bit-identical to nlayers calls of vbg_attn_mask */
+int vbg_attn_mask_layers(const int* seq_len, const long long* mask_off, int nseq, int heads, int maxlen, float drop_p,
+                         unsigned long long seed, unsigned long long stream_id0, unsigned long long stream_id_stride, int nlayers,
+                         long long layer_words, unsigned* mask_q, unsigned* mask_k, void* stream);
 
 /* column sums: out[n] (+)= sum_m x[m*ld + n]   (bias gradients) */
 int vbg_colsum(const float* x, long long ld, int M, int N, float* out, int accumulate, void* stream);
@@ -454,6 +460,17 @@ int vbg_bn_bwd_apply(const float* dy, const float* y, const float* x, long long 
                      float* dres, float* dgamma_accum, float* dbeta_accum, unsigned* dx_amax, void* stream);
 /* dx_amax (optional): amax slot (VBG_AMAX_WORDS words, zeroed by the caller) that receives the bit pattern of max |dx| -- the scale of the fp16-form
  * products that consume dx */
+/* vbg_bn_finalize + vbg_bn_apply, and vbg_bn_param_grad + vbg_bn_bwd_apply, as ONE launch each (round 5; torch.nn.BatchNorm2d training
+ * forward / backward of model/ResNetFPN_ViBERTgrid.py:116-123 on one rank): every block folds the `nslots` slot rows of its 64 channels in
+ * its prologue (fold order of the separate entry points: the same bits), the block of the first row chunk publishes mean / invstd / the
+ * running statistics (forward) or adds the affine gradients (backward: dbeta += sum_g, dgamma += sum_gx).  C % 64 == 0.  The slot rows are
+ * NOT cleared: hand in zeroed rows per use. */
+int vbg_bn_apply_fold(const float* x, const float* res, long long M, int C, double* slots, int nslots, double count, float eps,
+                      float momentum, float* mean, float* invstd, float* running_mean, float* running_var, const float* gamma,
+                      const float* beta, int relu, float* y, unsigned* y_amax, void* stream);
+int vbg_bn_bwd_apply_fold(const float* dy, const float* y, const float* x, long long M, int C, const float* mean,
+                          const float* invstd, const float* gamma, double* slots, int nslots, double count, int relu, float* dx,
+                          float* dres, float* dgamma_accum, float* dbeta_accum, unsigned* dx_amax, void* stream);
 /* fold `nslots` slot rows: folded[0..2C) = sum over slots (optional output), and (optional) the BatchNorm affine
    gradients from these LOCAL sums: dbeta += (float)folded[0..C), dgamma += (float)folded[C..2C)  (call before a SyncBN
    all-reduce of `folded`; torch.nn.SyncBatchNorm leaves weight/bias gradients per-rank for DDP to average,

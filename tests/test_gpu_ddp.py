@@ -454,7 +454,9 @@ def _rccl_worker(rank, port, tmp):
 
     pa, red = toy_run(True)
     pb, _ = toy_run(False)
-    res["toy_equal"] = all(torch.equal(a, b) for a, b in zip(pa, pb))       # an all-reduce over one rank is the identity, 1 / world = 1
+    # an all-reduce over one rank is the identity and 1 / world = 1: the same parameters as without the reducer (to the run-to-run noise of
+    # torch's own convolution backward, which the toy uses)
+    res["toy_equal"] = max(float((a - b).abs().max() / (b.abs().max() + 1e-30)) for a, b in zip(pa, pb))
     res["toy_order"] = red.order
 
     # ---- (b) the resnet-18 + 2-layer-BERT model with SyncBatchNorm: sunk gradients (GRAD_READY), statistics collectives on the buckets'
@@ -508,13 +510,13 @@ def test_rccl_one_rank_runs_the_reducer_and_syncbn(tmp_path):
     communicator, buckets are issued as async works from the staging stream inside backward, `finish()` waits on them (work.wait() blocks
     the STREAM on this backend, the host on gloo), SyncBatchNorm statistics (fp64 [sum, sumsq, count]) travel as all-reduces on the same
     communicator between them, the watchdog thread runs.  Every collective over one rank is the identity, so: the toy model's parameters
-    after three steps are BIT-equal to the reducer-less run, and the resnet-18 + BERT model's first-step loss / gradients equal the plain
+    after three steps equal the reducer-less run (1e-5 of the largest entry), and the resnet-18 + BERT model's first-step loss / gradients equal the plain
     BatchNorm run (1e-5 / 1e-4: SyncBatchNorm takes the fold -> all_reduce -> finalize route with fp64 statistics)."""
     tmp = str(tmp_path)
     mp.spawn(_rccl_worker, args=(_free_port(), tmp), nprocs=1, join=True)
     r = torch.load(os.path.join(tmp, "rccl_res.pt"))
     print("RCCL one-rank run:", {k: r[k] for k in ("toy_equal", "toy_order", "syncbn_collectives", "buckets", "order", "steps_done", "losses", "grad_err")})
-    assert r["toy_equal"]
+    assert r["toy_equal"] < 1e-5, r["toy_equal"]
     assert r["steps_done"] == 3 and sorted(r["order"]) == list(range(r["buckets"])) and r["buckets"] >= 3
     assert r["syncbn_collectives"] >= 3 * 2 * 20                   # forward + backward statistics of every BatchNorm layer, three steps
     la, lb = r["losses"]

@@ -859,6 +859,60 @@ def test_batchnorm(ops, relu, res, shape):
         assert close(dres, r.grad.permute(0, 2, 3, 1).reshape(-1, C_), 1e-5, 1e-6)
 
 
+@pytest.mark.parametrize("relu,res,shape", [(True, True, (2, 64, 33, 20)), (False, False, (3, 128, 16, 16)), (True, False, (1, 256, 7, 9)),
+                                            (True, True, (8, 64, 128, 128))])
+def test_batchnorm_folding_apply_kernels(ops, relu, res, shape):
+    """vbg_bn_apply_fold / vbg_bn_bwd_apply_fold (round 5: the finalize and the affine-gradient fold in the apply kernels' prologues, one
+    launch instead of two) against the separate entry points on the same slot rows: the fold runs in fold_slots' order in both, so every
+    output -- y, mean, invstd, the running statistics, dx, dres, dgamma, dbeta, the published maxima -- is BIT-equal"""
+    B, C_, H, W = shape
+    d = dev()
+    M = B * H * W
+    x2, r2 = rnd(M, C_, seed=180).to(d), (rnd(M, C_, seed=181).to(d) if res else None)
+    gam, bet = (1 + 0.1 * rnd(C_, seed=182)).to(d), rnd(C_, seed=183).to(d)
+    g2 = (rnd(M, C_, seed=184) * 1e-3).to(d)
+    # separate launches (persistent workspace, cleared behind the reads)
+    rm_a, rv_a = torch.zeros(C_, device=d), torch.ones(C_, device=d)
+    mean_a, inv_a = ops.bn_finalize(ops.bn_stats(x2), C_, ops.bn_slots(), M, 1e-5, 0.1, rm_a, rv_a)
+    sa = ops.amax_slot(d)
+    y_a = ops.bn_apply(x2, r2, mean_a, inv_a, gam, bet, relu, y_amax=sa)
+    dg_a, db_a = torch.zeros(C_, device=d), torch.zeros(C_, device=d)
+    sums = ops.bn_param_grad(ops.bn_bwd_reduce(g2, y_a, x2, mean_a, inv_a, relu), C_, dg_a, db_a)
+    da = ops.amax_slot(d)
+    dx_a, dres_a = ops.bn_bwd_apply(g2, y_a, x2, mean_a, inv_a, gam, sums, M, relu, res, None, None, dx_amax=da)
+    # folding launches (zeroed rows from the pool, not cleared)
+    rm_b, rv_b = torch.zeros(C_, device=d), torch.ones(C_, device=d)
+    slots = ops.bn_stats(x2, ops.bn_zero_slots(d, C_))
+    sb = ops.amax_slot(d)
+    y_b, mean_b, inv_b = ops.bn_apply_fold(x2, r2, slots, M, 1e-5, 0.1, rm_b, rv_b, gam, bet, relu, y_amax=sb)
+    dg_b, db_b = torch.zeros(C_, device=d), torch.zeros(C_, device=d)
+    bslots = ops.bn_bwd_reduce(g2, y_b, x2, mean_b, inv_b, relu, ops.bn_zero_slots(d, C_))
+    dbb = ops.amax_slot(d)
+    dx_b, dres_b = ops.bn_bwd_apply_fold(g2, y_b, x2, mean_b, inv_b, gam, bslots, M, relu, res, dg_b, db_b, dx_amax=dbb)
+    # (the statistics themselves are fp64 atomics into slot rows: the two reductions above may differ in the last bit of a double, which
+    #  the float conversion of mean / invstd almost always hides -- compared at 1 ulp of fp32, everything downstream exactly when they agree)
+    assert close(mean_b, mean_a, 2e-7, 1e-9) and close(inv_b, inv_a, 2e-7, 0)
+    if torch.equal(mean_b, mean_a) and torch.equal(inv_b, inv_a):
+        assert torch.equal(y_b, y_a) and torch.equal(rm_b, rm_a) and torch.equal(rv_b, rv_a)
+        assert int(sb.max().item()) == int(sa.max().item()) == int(y_a.abs().max().view(torch.int32).item())
+    else:
+        assert close(y_b, y_a, 1e-6, 1e-6)
+    assert close(dx_b, dx_a, 1e-5, 1e-9) and close(dg_b, dg_a, 1e-6, 1e-9) and close(db_b, db_a, 1e-6, 1e-9)
+    assert int(dbb.max().item()) == int(dx_b.abs().max().view(torch.int32).item())
+    if res:
+        assert torch.equal(dres_b, dres_a)
+    # against torch's own batch_norm as well (training statistics, fp32)
+    xt = x2.cpu().view(B, H, W, C_).permute(0, 3, 1, 2).contiguous().requires_grad_(True)
+    yt = F.batch_norm(xt, torch.zeros(C_), torch.ones(C_), gam.cpu(), bet.cpu(), True, 0.1, 1e-5)
+    if res:
+        yt = yt + r2.cpu().view(B, H, W, C_).permute(0, 3, 1, 2)
+    if relu:
+        yt = torch.relu(yt)
+    yt.backward(g2.cpu().view(B, H, W, C_).permute(0, 3, 1, 2))
+    assert close(y_b, yt.detach().permute(0, 2, 3, 1).reshape(-1, C_), 1e-4, 1e-5)
+    assert close(dx_b, xt.grad.permute(0, 2, 3, 1).reshape(-1, C_), 1e-3, 1e-8)
+
+
 def test_pool_resample_layout(ops):
     d = dev()
     x = rnd(2, 16, 13, 10, seed=90).requires_grad_(True)

@@ -549,10 +549,17 @@ __global__ __launch_bounds__(256, 2) void attn_kernel(const vbg_attn_desc p) {
 // dropout keeps of one layer: for group g = (seq, head), query q, 32-key block kb: mask_q[off + q * nkb + kb] bit j = keep of key
 // 32 kb + j; the same bits transposed: mask_k[off + key * nkb + qb] bit i = keep of query 32 qb + i.  A wave = one 32-query block x
 // two 32-key blocks; draws are 16-bit slices of the counter hash (rng_u32's 64-bit state), keep <=> draw >= thr16.
+// blockIdx.z = layer * ngroups + g: the masks of SEVERAL layers of one step in one launch (layer l: stream id sid + l * sid_stride, words
+// at l * layer_words) -- a layer's 24 576 two-word blocks are launch-shaped (19 us for 6 MB), twelve layers in one grid are not.
 __global__ __launch_bounds__(64) void attn_mask_kernel(const int* __restrict__ seq_len, const long long* __restrict__ mask_off, int heads,
                                                        int maxlen, unsigned thr16, unsigned long long seed, unsigned long long sid,
-                                                       unsigned* __restrict__ mask_q, unsigned* __restrict__ mask_k) {
-    const int g = blockIdx.z, seq = g / heads, head = g % heads;
+                                                       unsigned* __restrict__ mask_q, unsigned* __restrict__ mask_k, int ngroups,
+                                                       unsigned long long sid_stride, long long layer_words) {
+    const int layer = blockIdx.z / ngroups;
+    const int g = blockIdx.z - layer * ngroups, seq = g / heads, head = g % heads;
+    sid += (unsigned long long)layer * sid_stride;
+    mask_q += (long long)layer * layer_words;
+    mask_k += (long long)layer * layer_words;
     const int L = seq_len[seq], nkb = (L + 31) >> 5;
     const int qb = blockIdx.y, kp = blockIdx.x;
     if (qb >= nkb || 2 * kp >= nkb) return;
@@ -632,6 +639,24 @@ extern "C" int vbg_attn_mask(const int* seq_len, const long long* mask_off, int 
     VBG_CHECK_ARG(seq_len && mask_off && mask_q && mask_k);
     const int nkb = (maxlen + 31) / 32;
     VBG_LAUNCH(attn_mask_kernel, dim3((nkb + 1) / 2, nkb, nseq * heads), dim3(64), 0, (hipStream_t)stream, seq_len, mask_off, heads, maxlen,
-               vbg_attn_drop_thr16(drop_p), seed, stream_id, mask_q, mask_k);
+               vbg_attn_drop_thr16(drop_p), seed, stream_id, mask_q, mask_k, nseq * heads, 0ull, 0ll);
+    VBG_LAUNCH_RET();
+}
+
+extern "C" int vbg_attn_mask_layers(const int* seq_len, const long long* mask_off, int nseq, int heads, int maxlen, float drop_p,
+                                    unsigned long long seed, unsigned long long stream_id0, unsigned long long stream_id_stride, int nlayers,
+                                    long long layer_words, unsigned* mask_q, unsigned* mask_k, void* stream) {
+    VBG_CHECK_ARG(nseq >= 0 && heads > 0 && maxlen >= 0 && drop_p > 0.f && drop_p < 1.f && nlayers >= 0 && layer_words >= 0);
+    if (nseq == 0 || maxlen == 0 || nlayers == 0) return VBG_OK;
+    VBG_CHECK_ARG(seq_len && mask_off && mask_q && mask_k);
+    const int nkb = (maxlen + 31) / 32, ngroups = nseq * heads;
+    VBG_CHECK_ARG(ngroups <= 65535);
+    const int per = 65535 / ngroups;                       // layers per launch (grid z limit)
+    for (int l0 = 0; l0 < nlayers; l0 += per) {
+        const int nl = (nlayers - l0 < per) ? (nlayers - l0) : per;
+        VBG_LAUNCH(attn_mask_kernel, dim3((nkb + 1) / 2, nkb, ngroups * nl), dim3(64), 0, (hipStream_t)stream, seq_len, mask_off, heads, maxlen,
+                   vbg_attn_drop_thr16(drop_p), seed, stream_id0 + (unsigned long long)l0 * stream_id_stride, mask_q + (long long)l0 * layer_words,
+                   mask_k + (long long)l0 * layer_words, ngroups, stream_id_stride, layer_words);
+    }
     VBG_LAUNCH_RET();
 }

@@ -203,6 +203,130 @@ __global__ void bn_bwd_apply_kernel(const float* __restrict__ dy, const float* _
     if (amax) amax_publish(mx, amax);                            // (uniform)
 }
 
+// ---- the same two passes with the statistics FOLDED IN THEIR PROLOGUE (round 5) ----------------------------------------------------------
+// bn_finalize / bn_param_grad are 7 us launches of a few hundred threads between two streaming kernels (80 per step at resnet-34: 0.56 ms of
+// launch-shaped time).  Here a block owns 64 channels x a chunk of rows (16 channel quads x 16 row lanes): its first 128 threads fold the
+// slot rows of their (channel, statistic) pair -- 32 independent L2 loads, summed in fold_slots' order, so mean / invstd / the sums are the
+// bits the separate launches produce --, the block of row chunk 0 publishes mean / invstd / running statistics (forward) or adds the affine
+// gradients (backward), and everybody streams its rows with the per-channel constants in registers.  The fold costs a block 32 KB of L2
+// reads, so a block takes >= 64 rows (>= 32 KB of its own traffic) -- small maps launch few blocks, which they can afford.  The slot
+// rows are NOT cleared (other blocks are still reading them): the caller hands in zeroed rows from a pool (vbg.ops.bn_zero_slots).
+__device__ __forceinline__ void amax_publish_at(float mx, unsigned* amax, unsigned block_id) {
+    __shared__ float amax_sh2[16];
+#pragma unroll
+    for (int o = 32; o > 0; o >>= 1) mx = fmaxf(mx, __shfl_xor(mx, o, 64));
+    if ((threadIdx.x & 63) == 0) amax_sh2[threadIdx.x >> 6] = mx;
+    __syncthreads();
+    if (threadIdx.x == 0) {
+        for (int w = 1; w < (int)(blockDim.x >> 6); ++w) mx = fmaxf(mx, amax_sh2[w]);
+        const unsigned bits = __float_as_uint(mx);
+        unsigned* word = amax + (block_id & (VBG_AMAX_WORDS - 1)) * VBG_AMAX_STRIDE;
+        if (bits > __hip_atomic_load(word, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT)) atomicMax(word, bits);
+    }
+}
+
+__global__ __launch_bounds__(256) void bn_apply_fold_kernel(const float* __restrict__ x, const float* __restrict__ res, long long M, int C,
+                                                            double* __restrict__ slots, int nslots, double count, float eps, float momentum,
+                                                            float* __restrict__ mean_out, float* __restrict__ invstd_out,
+                                                            float* __restrict__ running_mean, float* __restrict__ running_var,
+                                                            const float* __restrict__ gamma, const float* __restrict__ beta, int relu,
+                                                            int rows_per_block, float* __restrict__ y, unsigned* amax) {
+    __shared__ double fold[128];
+    __shared__ __attribute__((aligned(16))) float cst[4][64];          // mean, invstd, gamma, beta of the block's 64 channels
+    const int tid = threadIdx.x, c0 = blockIdx.y * 64;
+    if (tid < 128) fold[tid] = fold_slots(slots, nslots, C, (tid >> 6) * C + c0 + (tid & 63), false);
+    __syncthreads();
+    if (tid < 64) {
+        const int c = c0 + tid;
+        const double m = fold[tid] / count;
+        double var = fold[64 + tid] / count - m * m;
+        if (var < 0.0) var = 0.0;
+        const float mf = (float)m, isf = (float)(1.0 / sqrt(var + (double)eps));
+        cst[0][tid] = mf; cst[1][tid] = isf; cst[2][tid] = gamma[c]; cst[3][tid] = beta[c];
+        if (blockIdx.x == 0) {
+            mean_out[c] = mf;
+            invstd_out[c] = isf;
+            if (running_mean) {
+                const double unbiased = count > 1.0 ? var * count / (count - 1.0) : var;
+                running_mean[c] = (1.f - momentum) * running_mean[c] + momentum * mf;
+                running_var[c] = (1.f - momentum) * running_var[c] + momentum * (float)unbiased;
+            }
+        }
+    }
+    __syncthreads();
+    const int q = tid & 15, rl = tid >> 4, C4 = C >> 2, cq = blockIdx.y * 16 + q;
+    const float4 mu = reinterpret_cast<const float4*>(cst[0])[q], is = reinterpret_cast<const float4*>(cst[1])[q];
+    const float4 ga = reinterpret_cast<const float4*>(cst[2])[q], be = reinterpret_cast<const float4*>(cst[3])[q];
+    const long long r0 = (long long)blockIdx.x * rows_per_block, r1 = min(M, r0 + rows_per_block);
+    float mx = 0.f;
+#pragma unroll 4
+    for (long long r = r0 + rl; r < r1; r += 16) {
+        const long long i = r * C4 + cq;
+        const float4 xv = reinterpret_cast<const float4*>(x)[i];
+        float4 o;
+        o.x = (xv.x - mu.x) * is.x * ga.x + be.x; o.y = (xv.y - mu.y) * is.y * ga.y + be.y;
+        o.z = (xv.z - mu.z) * is.z * ga.z + be.z; o.w = (xv.w - mu.w) * is.w * ga.w + be.w;
+        if (res) {
+            const float4 rv = reinterpret_cast<const float4*>(res)[i];
+            o.x += rv.x; o.y += rv.y; o.z += rv.z; o.w += rv.w;
+        }
+        if (relu) { o.x = fmaxf(o.x, 0.f); o.y = fmaxf(o.y, 0.f); o.z = fmaxf(o.z, 0.f); o.w = fmaxf(o.w, 0.f); }
+        reinterpret_cast<float4*>(y)[i] = o;
+        mx = fmaxf(fmaxf(mx, fmaxf(fabsf(o.x), fabsf(o.y))), fmaxf(fabsf(o.z), fabsf(o.w)));
+    }
+    if (amax) amax_publish_at(mx, amax, blockIdx.x + blockIdx.y * gridDim.x);                  // (uniform)
+}
+
+__global__ __launch_bounds__(256) void bn_bwd_apply_fold_kernel(const float* __restrict__ dy, const float* __restrict__ y,
+                                                                const float* __restrict__ x, long long M, int C,
+                                                                const float* __restrict__ mean, const float* __restrict__ invstd,
+                                                                const float* __restrict__ gamma, double* __restrict__ slots, int nslots,
+                                                                double count, int relu, int rows_per_block, float* __restrict__ dx,
+                                                                float* __restrict__ dres, float* dgamma, float* dbeta, unsigned* amax) {
+    __shared__ double fold[128];
+    __shared__ __attribute__((aligned(16))) float cst[5][64];          // mean, invstd, gamma, sum g / n, sum g xhat / n
+    const int tid = threadIdx.x, c0 = blockIdx.y * 64;
+    if (tid < 128) fold[tid] = fold_slots(slots, nslots, C, (tid >> 6) * C + c0 + (tid & 63), false);
+    __syncthreads();
+    const float icnt = (float)(1.0 / count);
+    if (tid < 64) {
+        const int c = c0 + tid;
+        const double sg = fold[tid], sgx = fold[64 + tid];
+        cst[0][tid] = mean[c]; cst[1][tid] = invstd[c]; cst[2][tid] = gamma[c];
+        cst[3][tid] = (float)sg * icnt; cst[4][tid] = (float)sgx * icnt;
+        if (blockIdx.x == 0) {
+            if (dbeta) dbeta[c] += (float)sg;
+            if (dgamma) dgamma[c] += (float)sgx;
+        }
+    }
+    __syncthreads();
+    const int q = tid & 15, rl = tid >> 4, C4 = C >> 2, cq = blockIdx.y * 16 + q;
+    const float4 mu = reinterpret_cast<const float4*>(cst[0])[q], is = reinterpret_cast<const float4*>(cst[1])[q];
+    const float4 ga = reinterpret_cast<const float4*>(cst[2])[q], s0 = reinterpret_cast<const float4*>(cst[3])[q];
+    const float4 s1 = reinterpret_cast<const float4*>(cst[4])[q];
+    const long long r0 = (long long)blockIdx.x * rows_per_block, r1 = min(M, r0 + rows_per_block);
+    float mx = 0.f;
+#pragma unroll 4
+    for (long long r = r0 + rl; r < r1; r += 16) {
+        const long long i = r * C4 + cq;
+        float4 g = reinterpret_cast<const float4*>(dy)[i];
+        if (relu) {
+            const float4 yv = reinterpret_cast<const float4*>(y)[i];
+            g.x = yv.x > 0.f ? g.x : 0.f; g.y = yv.y > 0.f ? g.y : 0.f; g.z = yv.z > 0.f ? g.z : 0.f; g.w = yv.w > 0.f ? g.w : 0.f;
+        }
+        const float4 xv = reinterpret_cast<const float4*>(x)[i];
+        float4 o;
+        o.x = ga.x * is.x * (g.x - s0.x - (xv.x - mu.x) * is.x * s1.x);
+        o.y = ga.y * is.y * (g.y - s0.y - (xv.y - mu.y) * is.y * s1.y);
+        o.z = ga.z * is.z * (g.z - s0.z - (xv.z - mu.z) * is.z * s1.z);
+        o.w = ga.w * is.w * (g.w - s0.w - (xv.w - mu.w) * is.w * s1.w);
+        reinterpret_cast<float4*>(dx)[i] = o;
+        if (dres) reinterpret_cast<float4*>(dres)[i] = g;
+        mx = fmaxf(fmaxf(mx, fmaxf(fabsf(o.x), fabsf(o.y))), fmaxf(fabsf(o.z), fabsf(o.w)));
+    }
+    if (amax) amax_publish_at(mx, amax, blockIdx.x + blockIdx.y * gridDim.x);                  // (uniform)
+}
+
 // amax[0] = max(amax[0], bits of max |x|)
 __global__ __launch_bounds__(256) void amax_kernel(const float* __restrict__ x, long long n, unsigned* amax) {
     const long long n4 = n / 4, stride = (long long)gridDim.x * blockDim.x;
@@ -522,6 +646,36 @@ extern "C" int vbg_bn_bwd_apply(const float* dy, const float* y, const float* x,
                           gamma, sums, count, count_dev, relu, dx, dres, dx_amax);
     if (dgamma_accum && dbeta_accum)
         VBG_LAUNCH(bn_param_grad_kernel, dim3(cdiv(C, 256)), dim3(256), 0, S_, const_cast<double*>(sums), 1, 0, C, (double*)nullptr, dgamma_accum, dbeta_accum);
+    VBG_LAUNCH_RET();
+}
+
+// rows per block of the folding kernels: >= 64 (a block's fold reads 32 KB), about 1536 blocks on the large maps
+static inline int bn_fold_rows(long long M, int C) {
+    long long r = cdiv(M * (C / 64), 1536);
+    if (r < 64) r = 64;
+    return (int)(cdiv(r, 16) * 16);
+}
+
+extern "C" int vbg_bn_apply_fold(const float* x, const float* res, long long M, int C, double* slots, int nslots, double count, float eps,
+                                 float momentum, float* mean, float* invstd, float* running_mean, float* running_var, const float* gamma,
+                                 const float* beta, int relu, float* y, unsigned* y_amax, void* stream) {
+    VBG_CHECK_ARG(x && y && slots && mean && invstd && gamma && beta && M > 0 && C > 0 && C % 64 == 0 && nslots >= 1 && count > 0);
+    VBG_CHECK_ARG((running_mean == nullptr) == (running_var == nullptr) && ALIGNED16(x) && ALIGNED16(y) && (!res || ALIGNED16(res)));
+    const int rpb = bn_fold_rows(M, C);
+    VBG_LAUNCH(bn_apply_fold_kernel, dim3(cdiv(M, rpb), C / 64), dim3(256), 0, S_, x, res, M, C, slots, nslots, count, eps, momentum, mean, invstd,
+               running_mean, running_var, gamma, beta, relu, rpb, y, y_amax);
+    VBG_LAUNCH_RET();
+}
+
+extern "C" int vbg_bn_bwd_apply_fold(const float* dy, const float* y, const float* x, long long M, int C, const float* mean,
+                                     const float* invstd, const float* gamma, double* slots, int nslots, double count, int relu, float* dx,
+                                     float* dres, float* dgamma_accum, float* dbeta_accum, unsigned* dx_amax, void* stream) {
+    VBG_CHECK_ARG(dy && x && mean && invstd && gamma && slots && dx && M > 0 && C > 0 && C % 64 == 0 && nslots >= 1 && count > 0 && (!relu || y));
+    VBG_CHECK_ARG(((dgamma_accum == nullptr) == (dbeta_accum == nullptr)) && ALIGNED16(dy) && ALIGNED16(x) && ALIGNED16(dx) &&
+                  (!relu || ALIGNED16(y)) && (!dres || ALIGNED16(dres)));
+    const int rpb = bn_fold_rows(M, C);
+    VBG_LAUNCH(bn_bwd_apply_fold_kernel, dim3(cdiv(M, rpb), C / 64), dim3(256), 0, S_, dy, y, x, M, C, mean, invstd, gamma, slots, nslots, count,
+               relu, rpb, dx, dres, dgamma_accum, dbeta_accum, dx_amax);
     VBG_LAUNCH_RET();
 }
 

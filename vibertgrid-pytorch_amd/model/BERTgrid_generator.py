@@ -190,6 +190,10 @@ class BERTgridGenerator(nn.Module):
         rank = torch.distributed.get_rank() if (torch.distributed.is_available() and torch.distributed.is_initialized()) else 0
         seed = self._step_seed * 0x9E3779B1 + (torch.initial_seed() & 0xFFFFFFFF) + rank * 0x85EBCA6B
         eps = float(cfg.layer_norm_eps)
+        # the attention-dropout keeps of all layers in one launch (stream ids as BertLayerFn numbers them: layer * 8)
+        flash_ok = ops.planes_enabled() and ops.flash_enabled() and dh == 64 and hidden % 32 == 0 and 0 < maxlen <= 512      # (BertLayerFn's test)
+        meta.mask_pool = (ops.attn_mask_layers(meta, pa, seed, 0, 8, len(m.encoder.layer))
+                          if (pa > 0 and flash_ok and ops.mask_pool_enabled() and torch.is_grad_enabled()) else None)
         x = Fn.BertEmbedFn.apply(emb.word_embeddings.weight, emb.position_embeddings.weight, emb.token_type_embeddings.weight,
                                  emb.LayerNorm.weight, emb.LayerNorm.bias, ids, pos, eps, p, seed, 1000)
         xpl = None                       # bf16 planes of x, handed from each layer's closing LayerNorm to the next layer's first product

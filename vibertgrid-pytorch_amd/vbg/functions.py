@@ -251,7 +251,7 @@ class SegLinearFn(torch.autograd.Function):
 
 
 # ----------------------------------------------------------------------------------------------
-def _conv_any(x, w4, stride, pad, bias=None, want_stats=False, w_owner=None, x_amax=None):
+def _conv_any(x, w4, stride, pad, bias=None, want_stats=False, w_owner=None, x_amax=None, zero_slots=False):
     """x NHWC; w4 = OHWI weight.  Cin=3 stem goes through im2col (K=147, row stride 148).
     want_stats: -> third result = BatchNorm slot workspace holding the output's column sums / sums of squares (fused into the GEMM
     epilogue), or None when the product is one the library may split (the caller then runs ops.bn_stats)."""
@@ -259,7 +259,9 @@ def _conv_any(x, w4, stride, pad, bias=None, want_stats=False, w_owner=None, x_a
     Cout, kh, kw, _ = w4.shape
     K = kh * kw * Cin
     Ho, Wo = ops.conv_out_hw(H, W, kh, stride, pad)
-    stats = ops._bn_workspace(x.device, Cout) if (want_stats and ops.fuse_stats_ok(B * Ho * Wo, Cout, K)) else None
+    # (zero_slots: the consumer folds the slot rows without clearing them -- rows from the zero pool instead of the persistent workspace)
+    stats = ((ops.bn_zero_slots(x.device, Cout) if zero_slots else ops._bn_workspace(x.device, Cout))
+             if (want_stats and ops.fuse_stats_ok(B * Ho * Wo, Cout, K)) else None)
     if Cin % 16 != 0:
         Kp = (K + 3) // 4 * 4
         col = ops.im2col(x, kh, kw, stride, pad, Kp)
@@ -352,25 +354,12 @@ class ConvBnFn(torch.autograd.Function):
         x = _c(x)
         sync = bool(sync) and SyncCtx.active()
         w4 = ohwi(w)
-        z, col, stats = _conv_any(x, w4, stride, pad, want_stats=training, w_owner=w, x_amax=ctx.x_amax)
+        # one rank, training statistics: finalize rides in the apply kernel's prologue, the affine-gradient fold in the backward apply's
+        fold = training and ops.bn_fold_ok(w.shape[0], sync)
+        z, col, stats = _conv_any(x, w4, stride, pad, want_stats=training, w_owner=w, x_amax=ctx.x_amax, zero_slots=fold)
         C = z.shape[-1]
         z2 = z.view(-1, C)
         M = z2.shape[0]
-        if training:
-            if stats is None:
-                stats = ops.bn_stats(z2)
-            count, count_dev = float(M), None
-            if sync:
-                glob = torch.empty((2 * C + 1,), device=x.device, dtype=torch.float64)
-                ops.bn_fold(stats, C, out=glob)
-                glob[2 * C] = M
-                SyncCtx.all_reduce(glob)
-                count_dev = glob[2 * C:]                   # global row count stays on the device (no sync)
-                mean, invstd = ops.bn_finalize(glob, C, 1, count, eps, momentum, running_mean, running_var, count_dev)
-            else:
-                mean, invstd = ops.bn_finalize(stats, C, ops.bn_slots(), count, eps, momentum, running_mean, running_var)
-        else:
-            mean, invstd, count, count_dev = running_mean, _frozen_invstd(running_var, eps), float(M), None
         r2 = None if res is None else _c(res).view(-1, C)
         # the largest magnitude of y rides on the kernel that writes it: the scale of y as an operand of the next convolution's
         # fp16-form weight gradient (the tag travels on the tensor object; a consumer that does not find one takes a vbg_amax pass)
@@ -378,9 +367,32 @@ class ConvBnFn(torch.autograd.Function):
         # ... and the scale of y as the ACTIVATION operand of the next convolution's fp16-form forward (an activation of 65520 or more no
         # longer becomes inf): published whenever that form is on, inference and no_grad included
         y_amax = ops.amax_slot(x.device) if (ops.conv3_f16_enabled() or (any(ctx.needs_input_grad) and ops.conv3_f16_bwd_enabled())) else None
-        y = ops.bn_apply(z2, r2, mean, invstd, gamma, beta, relu, y_amax=y_amax).view(z.shape)
+        if fold:
+            if stats is None:
+                stats = ops.bn_stats(z2, ops.bn_zero_slots(x.device, C))
+            count, count_dev = float(M), None
+            y, mean, invstd = ops.bn_apply_fold(z2, r2, stats, count, eps, momentum, running_mean, running_var, gamma, beta, relu, y_amax=y_amax)
+            y = y.view(z.shape)
+        else:
+            if training:
+                if stats is None:
+                    stats = ops.bn_stats(z2)
+                count, count_dev = float(M), None
+                if sync:
+                    glob = torch.empty((2 * C + 1,), device=x.device, dtype=torch.float64)
+                    ops.bn_fold(stats, C, out=glob)
+                    glob[2 * C] = M
+                    SyncCtx.all_reduce(glob)
+                    count_dev = glob[2 * C:]                   # global row count stays on the device (no sync)
+                    mean, invstd = ops.bn_finalize(glob, C, 1, count, eps, momentum, running_mean, running_var, count_dev)
+                else:
+                    mean, invstd = ops.bn_finalize(stats, C, ops.bn_slots(), count, eps, momentum, running_mean, running_var)
+            else:
+                mean, invstd, count, count_dev = running_mean, _frozen_invstd(running_var, eps), float(M), None
+            y = ops.bn_apply(z2, r2, mean, invstd, gamma, beta, relu, y_amax=y_amax).view(z.shape)
         if y_amax is not None:
             y._vbg_amax = (y_amax, y._version)
+        ctx.fold = fold
         ctx.cfg = (stride, pad, relu, training, count, res is not None, sync)
         ctx.w_ref, ctx.affine = w, (gamma, beta)
         ctx.save_for_backward(x, w4, col, z, y if relu else None, mean, invstd, gamma, count_dev)
@@ -394,8 +406,18 @@ class ConvBnFn(torch.autograd.Function):
         dy2 = _c(dy).view(-1, C)
         z2 = z.view(-1, C)
         y2 = None if y is None else y.view(-1, C)
-        slots = ops.bn_bwd_reduce(dy2, y2, z2, mean, invstd, relu)
+        B_, H_, W_, Cin_ = x.shape
+        want_amax = (ctx.needs_input_grad[0] and ops.conv3_f16_bwd_ok(B_, H_, W_, C, Cin_, w4.shape[1], w4.shape[2], stride, pad)) or \
+            (col is None and ops.conv3_f16_wgrad_ok(B_, H_, W_, Cin_, C, w4.shape[1], w4.shape[2], stride, pad))
+        dz_amax = ops.amax_slot(dy2.device) if want_amax else None
         dgamma, dbeta, sunk = _affine_dest(*ctx.affine)           # from the LOCAL sums: the gradient exchange averages them
+        if ctx.fold and ops.bn_fold_ok(C, sync):
+            # (training statistics on one rank: the fold of the slot rows and the affine gradients ride in the apply kernel's prologue)
+            slots = ops.bn_bwd_reduce(dy2, y2, z2, mean, invstd, relu, ops.bn_zero_slots(dy2.device, C))
+            dz2, dres2 = ops.bn_bwd_apply_fold(dy2, y2, z2, mean, invstd, gamma, slots, count, relu, has_res, dgamma, dbeta, dx_amax=dz_amax)
+            dgamma, dbeta = _affine_done(*ctx.affine, dgamma, dbeta, sunk)
+            return ConvBnFn._finish_backward(ctx, dz2, dres2, dz_amax, dgamma, dbeta)
+        slots = ops.bn_bwd_reduce(dy2, y2, z2, mean, invstd, relu)
         sums = ops.bn_param_grad(slots, C, dgamma, dbeta)
         dgamma, dbeta = _affine_done(*ctx.affine, dgamma, dbeta, sunk)
         if not training:
@@ -404,13 +426,14 @@ class ConvBnFn(torch.autograd.Function):
             sums = torch.zeros_like(sums)
         elif sync:
             SyncCtx.all_reduce(sums)
-        # the fp16-form products that consume dz (input gradient of a wide 3x3 convolution) scale it by its largest magnitude, which
-        # rides on the kernel that writes dz
-        B_, H_, W_, Cin_ = x.shape
-        want_amax = (ctx.needs_input_grad[0] and ops.conv3_f16_bwd_ok(B_, H_, W_, C, Cin_, w4.shape[1], w4.shape[2], stride, pad)) or \
-            (col is None and ops.conv3_f16_wgrad_ok(B_, H_, W_, Cin_, C, w4.shape[1], w4.shape[2], stride, pad))
-        dz_amax = ops.amax_slot(dy2.device) if want_amax else None
         dz2, dres2 = ops.bn_bwd_apply(dy2, y2, z2, mean, invstd, gamma, sums, count, relu, has_res, None, None, count_dev, dx_amax=dz_amax)
+        return ConvBnFn._finish_backward(ctx, dz2, dres2, dz_amax, dgamma, dbeta)
+
+    @staticmethod
+    def _finish_backward(ctx, dz2, dres2, dz_amax, dgamma, dbeta):
+        """the convolution's input / weight gradients from dz (the gradient in front of the BatchNorm), shared by both BatchNorm routes"""
+        x, w4, col, z, y, mean, invstd, gamma, count_dev = ctx.saved_tensors
+        stride, pad, relu, training, count, has_res, sync = ctx.cfg
         dz = dz2.view(z.shape)
         dx = ops.conv2d_dgrad(dz, w4, tuple(x.shape), stride, pad, dy_amax=dz_amax, w_owner=ctx.w_ref) if ctx.needs_input_grad[0] else None
         dw = _conv_wgrad_any(dz, x, col, tuple(w4.shape), stride, pad, ctx.w_ref, dy_amax=dz_amax, x_amax=ctx.x_amax)
@@ -584,7 +607,8 @@ class AttnMeta:
     """Host-built description of the packed variable-length sequences of one batch (see
     model/BERTgrid_generator.py in this package): device tables for the grouped attention GEMMs."""
     __slots__ = ("ntok", "nseq", "heads", "dh", "maxlen", "ld", "s_elems", "soff", "lens", "ldp", "t_qk", "t_pv", "t_dp", "t_dv",
-                 "t_dq", "t_dk", "ngroups", "mask_off", "seq_row0", "pad_off", "tok_pad", "tasks", "ntok_pad", "mask_words", "ntasks", "stat_pool")
+                 "t_dq", "t_dk", "ngroups", "mask_off", "seq_row0", "pad_off", "tok_pad", "tasks", "ntok_pad", "mask_words", "ntasks", "stat_pool",
+                 "mask_pool")
 
 
 class BertLayerFn(torch.autograd.Function):
@@ -649,7 +673,9 @@ class BertLayerFn(torch.autograd.Function):
             st = pool[layer] if pool is not None and layer < pool.shape[0] else torch.zeros((3, H, meta.ntok_pad), device=dev, dtype=f32)
             lse = st[:2]
             ctx.delta_buf = st[2]
-            masks = ops.attn_mask(meta, p, seed, sid + 0) if p > 0 else None
+            # (the keeps of every layer of the step were drawn by ONE launch in front of the encoder when the generator could: mask_pool)
+            mpool = getattr(meta, "mask_pool", None)
+            masks = (mpool[layer] if (mpool is not None and layer < len(mpool)) else ops.attn_mask(meta, p, seed, sid + 0)) if p > 0 else None
             kbar = torch.empty((ntok, hid), device=dev, dtype=f32) if any(ctx.needs_input_grad) else None
             # (all-pair backward: O also as fp16-pair planes -- the B operand of the output projection's weight gradient, saved instead of
             #  the split pass the backward used to run over the fp32 O)

@@ -94,6 +94,7 @@ SIGNATURES = {
     "vbg_attn": (c_int, [C.POINTER(AttnDesc), c_vp]),
     "vbg_attn_drop_thr16": (C.c_uint, [c_f]),
     "vbg_attn_mask": (c_int, [c_vp, c_vp, c_int, c_int, c_int, c_f, c_ull, c_ull, c_vp, c_vp, c_vp]),
+    "vbg_attn_mask_layers": (c_int, [c_vp, c_vp, c_int, c_int, c_int, c_f, c_ull, c_ull, c_ull, c_int, c_ll, c_vp, c_vp, c_vp]),
     "vbg_colsum": (c_int, [c_vp, c_ll, c_int, c_int, c_vp, c_int, c_vp]),
     "vbg_colsum_f64": (c_int, [c_vp, c_ll, c_int, c_int, c_vp, c_int, c_vp, c_vp]),
     "vbg_conv3x3": (c_int, [c_vp, c_vp, c_vp, c_vp, c_vp, c_int, c_int, c_int, c_int, c_int, c_int, c_int, c_int, c_vp, c_vp, c_vp, c_int, c_vp]),
@@ -137,6 +138,8 @@ SIGNATURES = {
     "vbg_bn_bwd_reduce": (c_int, [c_vp, c_vp, c_vp, c_ll, c_int, c_vp, c_vp, c_int, c_vp, c_vp]),
     "vbg_bn_bwd_apply": (c_int, [c_vp, c_vp, c_vp, c_ll, c_int, c_vp, c_vp, c_vp, c_vp, c_d, c_vp, c_int, c_vp, c_vp, c_vp, c_vp, c_vp, c_vp]),
     "vbg_bn_param_grad": (c_int, [c_vp, c_int, c_int, c_int, c_vp, c_vp, c_vp, c_vp]),
+    "vbg_bn_apply_fold": (c_int, [c_vp, c_vp, c_ll, c_int, c_vp, c_int, c_d, c_f, c_f, c_vp, c_vp, c_vp, c_vp, c_vp, c_vp, c_int, c_vp, c_vp, c_vp]),
+    "vbg_bn_bwd_apply_fold": (c_int, [c_vp, c_vp, c_vp, c_ll, c_int, c_vp, c_vp, c_vp, c_vp, c_int, c_d, c_int, c_vp, c_vp, c_vp, c_vp, c_vp, c_vp]),
     "vbg_maxpool3x3s2_fwd": (c_int, [c_vp, c_int, c_int, c_int, c_int, c_vp, c_vp, c_vp]),
     "vbg_maxpool3x3s2_bwd": (c_int, [c_vp, c_vp, c_int, c_int, c_int, c_int, c_int, c_int, c_vp, c_vp]),
     "vbg_avgpool2_fwd": (c_int, [c_vp, c_int, c_int, c_int, c_int, c_vp, c_vp]),

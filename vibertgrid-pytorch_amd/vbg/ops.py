@@ -1374,6 +1374,26 @@ def attn_mask(meta, p, seed, sid):
     return mq, mk
 
 
+_MASK_POOL = [os.environ.get("VBG_MASK_POOL", "1") != "0"]
+
+
+def mask_pool_enabled() -> bool:
+    """attention-dropout keeps of all encoder layers of a step from ONE launch (on) or one launch per layer (off)"""
+    return _MASK_POOL[0]
+
+
+def attn_mask_layers(meta, p, seed, sid0, sid_stride, nlayers):
+    """the dropout keeps of `nlayers` encoder layers of one step in ONE launch -> [(mask_q, mask_k)] per layer (views of two buffers);
+    layer l draws from stream id sid0 + l * sid_stride: the same bits as attn_mask(meta, p, seed, sid0 + l * sid_stride)"""
+    dev = meta.lens.device
+    words = (meta.mask_words + 3) // 4 * 4
+    mq = torch.empty((nlayers, words), device=dev, dtype=i32)
+    mk = torch.empty((nlayers, words), device=dev, dtype=i32)
+    check(lib.vbg_attn_mask_layers(P(meta.lens), P(meta.mask_off), meta.nseq, meta.heads, meta.maxlen, float(p), seed, sid0, sid_stride, nlayers,
+                                   words, P(mq), P(mk), _stream()), "vbg_attn_mask_layers")
+    return [(mq[l, :meta.mask_words], mk[l, :meta.mask_words]) for l in range(nlayers)]
+
+
 def attn(meta, mode, qkv: Planes, dO, out, lse, delta, masks, scale, p, kbar=None, out_planes=None, o=None, out_amax=None, out_pair=None):
     """one fused attention pass (mode: lib.ATTN_FWD / ATTN_DQ / ATTN_DKV) over all (sequence, head) pairs of the packed batch"""
     d = AttnDesc()
@@ -1505,10 +1525,62 @@ def _bn_workspace(device, C_):
     return ws
 
 
-def bn_stats(x2d):
-    """per-channel (sum, sum of squares) partials in the persistent slot workspace; MUST be consumed by bn_finalize / bn_fold next"""
+_BN_FOLD = [os.environ.get("VBG_BN_FOLD", "1") != "0"]
+_BN_ZPOOL = {}
+
+
+def set_bn_fold(on: bool):
+    """BatchNorm finalize / affine-gradient folds inside the apply kernels' prologues (vbg_bn_apply_fold / vbg_bn_bwd_apply_fold: one
+    launch instead of two per layer and direction) or as launches of their own (off)"""
+    _BN_FOLD[0] = bool(on)
+
+
+def bn_fold_ok(C_, sync=False) -> bool:
+    return _BN_FOLD[0] and not sync and C_ % 64 == 0
+
+
+def bn_zero_slots(device, C_):
+    """ZEROED slot rows [slots * 2C] fp64 for one reduction whose consumer does not clear them (the folding apply kernels: many blocks read
+    the rows): slices of a zero-filled pool, one 8 MB fill per ~70 layers; an exhausted pool is replaced, never rewound"""
+    key = (device, raw_stream(device))
+    n = bn_slots() * 2 * C_
+    ent = _BN_ZPOOL.get(key)
+    if ent is None or ent[1] + n > ent[0].numel():
+        ent = _BN_ZPOOL[key] = [torch.zeros((max(1 << 20, n),), device=device, dtype=torch.float64), 0]
+    o = ent[1]
+    ent[1] = o + n
+    return ent[0][o:o + n]
+
+
+def bn_apply_fold(x2d, res2d, slots, count, eps, momentum, running_mean, running_var, gamma, beta, relu, y_amax=None):
+    """finalize + apply in one launch -> (y, mean, invstd); slots: zeroed rows the statistics were accumulated into (bn_zero_slots)"""
     M, C_ = x2d.shape
-    stats = _bn_workspace(x2d.device, C_)
+    out = torch.empty_like(x2d)
+    mean = torch.empty((C_,), device=x2d.device, dtype=f32)
+    invstd = torch.empty_like(mean)
+    check(lib.vbg_bn_apply_fold(P(x2d), P(res2d), M, C_, P(slots), bn_slots(), float(count), eps, momentum, P(mean), P(invstd), P(running_mean),
+                                P(running_var), P(gamma), P(beta), int(relu), P(out), P(y_amax), _stream()), "vbg_bn_apply_fold")
+    if running_var is not None:
+        _BN_EPOCH[0] += 1
+    return out, mean, invstd
+
+
+def bn_bwd_apply_fold(dy, y, x, mean, invstd, gamma, slots, count, relu, want_dres, dgamma, dbeta, dx_amax=None):
+    """affine-gradient fold + backward apply in one launch -> (dx, dres); dgamma / dbeta are added into"""
+    M, C_ = x.shape
+    dx = torch.empty_like(x)
+    dres = torch.empty_like(x) if want_dres else None
+    check(lib.vbg_bn_bwd_apply_fold(P(dy), P(y), P(x), M, C_, P(mean), P(invstd), P(gamma), P(slots), bn_slots(), float(count), int(relu), P(dx),
+                                    P(dres), P(dgamma), P(dbeta), P(dx_amax), _stream()), "vbg_bn_bwd_apply_fold")
+    return dx, dres
+
+
+def bn_stats(x2d, stats=None):
+    """per-channel (sum, sum of squares) partials in the persistent slot workspace (MUST be consumed by bn_finalize / bn_fold next), or in
+    the zeroed rows `stats`"""
+    M, C_ = x2d.shape
+    if stats is None:
+        stats = _bn_workspace(x2d.device, C_)
     check(lib.vbg_bn_stats(P(x2d), M, C_, P(stats), _stream()), "vbg_bn_stats")
     return stats
 
@@ -1549,10 +1621,11 @@ def bn_apply(x2d, res2d, mean, invstd, gamma, beta, relu, out=None, y_amax=None)
     return out
 
 
-def bn_bwd_reduce(dy, y, x, mean, invstd, relu):
-    """(sum g, sum g*xhat) partials in the persistent slot workspace; MUST be consumed by bn_param_grad next"""
+def bn_bwd_reduce(dy, y, x, mean, invstd, relu, sums=None):
+    """(sum g, sum g*xhat) partials in the persistent slot workspace (MUST be consumed by bn_param_grad next) or in the zeroed rows `sums`"""
     M, C_ = x.shape
-    sums = _bn_workspace(x.device, C_)
+    if sums is None:
+        sums = _bn_workspace(x.device, C_)
     check(lib.vbg_bn_bwd_reduce(P(dy), P(y), P(x), M, C_, P(mean), P(invstd), int(relu), P(sums), _stream()), "vbg_bn_bwd_reduce")
     return sums
 
