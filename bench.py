@@ -273,6 +273,12 @@ def main():
         print(json.dumps(cpu_baseline(args.cpu_baseline_only, args.cpu_baseline_shape)), flush=True)
         return
 
+    # stdout carries the ONE JSON line and nothing else: file descriptor 1 is pointed at stderr for the rest of the run (librccl prints a
+    # version banner to stdout when the first communicator is built, gloo its connection notes), the line goes out through a duplicate
+    real_stdout = os.dup(1)
+    sys.stdout.flush()
+    os.dup2(2, 1)
+
     world = int(os.environ.get("WORLD_SIZE", "1"))
     rank = int(os.environ.get("RANK", "0"))
     local = int(os.environ.get("LOCAL_RANK", "0"))
@@ -650,7 +656,8 @@ def main():
                 best = max(done, key=lambda r: r["value"]) if done else cpu_baseline(min(ncpu, 16))
                 out["cpu_baseline"] = dict(best, sweep=[{"threads": r.get("threads"), "value": r.get("value"), **({"note": r["note"]} if r.get("note") else {})} for r in runs])
                 out["cpu_baseline"]["cfg1"] = child(best["threads"], "cfg1", 60)
-        print(json.dumps(out), flush=True)
+        sys.stdout.flush()
+        os.write(real_stdout, (json.dumps(out) + "\n").encode())
     if world > 1 or forced:
         dist.destroy_process_group()
 

@@ -31,12 +31,15 @@ def worker(rank, world, port, tmp):
     model = torch.nn.parallel.DistributedDataParallel(model, device_ids=[0], find_unused_parameters=True)
     pc = [p for n, p in model.named_parameters() if "bert_model" not in n and p.requires_grad]
     pb = [p for n, p in model.named_parameters() if "bert_model" in n and p.requires_grad]
-    oc = torch.optim.SGD(params=pc, lr=0.0, momentum=0.9, weight_decay=0.0)
-    ob = torch.optim.AdamW(params=pb, lr=0.0, betas=(0.9, 0.999), eps=1e-8, weight_decay=0.0)
+    live = os.environ.get("VBG_PROBE_LIVE", "0") != "0"          # the test's hyper-parameters instead of learning rate 0
+    oc = torch.optim.SGD(params=pc, lr=0.005 if live else 0.0, momentum=0.9, weight_decay=0.005 if live else 0.0)
+    ob = torch.optim.AdamW(params=pb, lr=5e-5 if live else 0.0, betas=(0.9, 0.999), eps=1e-8, weight_decay=0.01 if live else 0.0)
     model.train()
-    for m in model.modules():          # frozen running statistics would still move; keep BatchNorm in train mode but momentum 0
-        if isinstance(m, torch.nn.modules.batchnorm._BatchNorm):
-            m.momentum = 0.0
+    if not live:
+        for m in model.modules():          # frozen running statistics would still move; keep BatchNorm in train mode but momentum 0
+            if isinstance(m, torch.nn.modules.batchnorm._BatchNorm):
+                m.momentum = 0.0
+    trace = []
     first = None
     for step in range(3):
         random.seed(5)
@@ -57,6 +60,11 @@ def worker(rank, world, port, tmp):
                 print(f"step {step + 1} loss {lv:.7f}: gradients vs step 1, worst:", [(f"{a:.2e}", k) for a, k in d[:6]], "median", f"{d[len(d) // 2][0]:.2e}", flush=True)
         oc.step()
         ob.step()
+        if live and rank == 0:
+            torch.cuda.synchronize()
+            trace.append(({k: v.cpu() for k, v in g.items()}, {n: p.detach().cpu().clone() for n, p in model.module.named_parameters()}, lv))
+    if live and rank == 0 and os.environ.get("VBG_PROBE_DUMP"):
+        torch.save(trace, os.environ["VBG_PROBE_DUMP"])
     dist.barrier()
     dist.destroy_process_group()
 

@@ -473,11 +473,11 @@ def weight_planes(owner, transposed=False, view=None, also=(), pair=False) -> Pl
         # the parameter lives in a flat buffer (vbg/optim.FlatGroup): its planes are a view of the buffer's plane image, which one
         # launch per optimizer step refreshes for all weights
         g, off = flat
-        ver = (owner._version,) + tuple(t._version for t in also)
+        owners = (owner,) + tuple(also)          # (their version counters tell the buffer's images about torch's in-place updates)
         if pair:
-            pl = g.planes_t_of(off, w.shape[0], w.shape[1], ver, pair=True) if transposed else g.pair_of(off, w.shape[0], w.shape[1], ver)
+            pl = g.planes_t_of(off, w.shape[0], w.shape[1], owners, pair=True) if transposed else g.pair_of(off, w.shape[0], w.shape[1], owners)
         else:
-            pl = g.planes_t_of(off, w.shape[0], w.shape[1], ver) if transposed else g.planes_of(off, w.shape[0], w.shape[1], ver)
+            pl = g.planes_t_of(off, w.shape[0], w.shape[1], owners) if transposed else g.planes_of(off, w.shape[0], w.shape[1], owners)
         if pl is not None:
             return pl
     cache = owner.__dict__.setdefault("_vbg_wplanes", {})

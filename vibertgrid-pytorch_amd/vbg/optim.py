@@ -109,6 +109,7 @@ class FlatGroup:
         self._tp = {"jobs": {}, "buf": None, "tbl": None, "tag": None, "tiles": 0}
         self._tq = {"jobs": {}, "buf": None, "tbl": None, "tag": None, "tiles": 0}
         self._ver = {}
+        self._owners = {}
 
     def zero_grad(self):
         self.gflat.zero_()
@@ -156,18 +157,26 @@ class FlatGroup:
     def _tag(self):
         return (ops._W_EPOCH[0], self.pflat._version)
 
-    def _stale(self, which: str, off: int, ver) -> bool:
-        """refresh needed?  The optimizer kernels bump the epoch; torch in-place updates of a parameter (load_state_dict, tests) bump
-        that parameter's own version counter, which is checked per request against the version seen at the last refresh."""
+    def _stale(self, which: str, off: int, owners) -> bool:
+        """refresh of the whole-buffer image `which` needed for the matrix at `off`?  The optimizer kernels of this library bump the epoch
+        (`_tag`); torch's own in-place updates (torch.optim on the flat views, load_state_dict, tests) only move the version counters of
+        the parameters they touch.  `owners`: the parameter(s) the matrix consists of.  The image is split from the WHOLE buffer, so at a
+        refresh the versions of every matrix registered for it are noted -- a matrix asked for later in the same step is then known to be
+        current, and one whose counter has moved since (the next step) is known to be stale.  (Round 5: until then a matrix that had not
+        been asked for since the last refresh counted as current -- the transposed images, which register their matrices one refresh at a
+        time, served the previous step's weights to the data-gradient products under torch.optim.)"""
+        reg = self._owners.setdefault(which, {})
+        reg[off] = owners
+        ver = tuple(t._version for t in owners)
         seen = self._ver.setdefault(which, {})
-        if {"p": self._planes_tag, "q": self._pair_tag, "t": self._tp["tag"], "u": self._tq["tag"]}[which] != self._tag() or seen.get(off, ver) != ver:
-            seen.clear()
-            seen[off] = ver
-            return True
-        seen[off] = ver
-        return False
+        if {"p": self._planes_tag, "q": self._pair_tag, "t": self._tp["tag"], "u": self._tq["tag"]}[which] == self._tag() and seen.get(off) == ver:
+            return False
+        seen.clear()
+        for o2, ow in reg.items():
+            seen[o2] = tuple(t._version for t in ow)
+        return True
 
-    def planes_of(self, off: int, rows: int, cols: int, ver=0):
+    def planes_of(self, off: int, rows: int, cols: int, owners=()):
         """plane operand of the matrix [rows, cols] stored at element offset `off` of the parameter buffer (None if its layout does not
         allow it)"""
         if cols % 32 or off % 8:
@@ -179,32 +188,32 @@ class FlatGroup:
         if len(self._plain_keys) <= 16:
             # few matrices want the bf16 image (with the fp16-pair forms on: the 12 attention-output projections of bert-base, 7 MB of a
             # 435 MB buffer): each is split on its own, once per parameter version -- not the whole buffer (0.2 ms per step)
-            tag = (self._tag(), ver)
+            tag = (self._tag(), tuple(t._version for t in owners))
             if self._plain_tags.get(key) != tag:
                 with torch.no_grad():
                     ops.split_planes(self.pflat.detach()[off:off + rows * cols].view(rows, cols),
                                      out=ops.Planes(self._planes[:, off:off + rows * cols].view(3, rows, cols), rows, cols, cols))
                 self._plain_tags[key] = tag
             return ops.Planes(self._planes[:, off:off + rows * cols].view(3, rows, cols), rows, cols, cols)
-        if self._stale("p", off, ver):
+        if self._stale("p", off, owners):
             with torch.no_grad():
                 ops.split_planes(self.pflat.detach().view(-1, 32), out=ops.Planes(self._planes.view(3, -1, 32), self.total // 32, 32, 32))
             self._planes_tag = self._tag()
         return ops.Planes(self._planes[:, off:off + rows * cols].view(3, rows, cols), rows, cols, cols)
 
-    def pair_of(self, off: int, rows: int, cols: int, ver=0):
+    def pair_of(self, off: int, rows: int, cols: int, owners=()):
         """the same matrix as an fp16-pair plane operand (csrc/gemm_planes.hip FORM 1): one launch per optimizer step for the whole buffer"""
         if cols % 32 or off % 8:
             return None
         if self._pair is None:
             self._pair = torch.empty((2, self.total), device=self.pflat.device, dtype=torch.int16)
-        if self._stale("q", off, ver):
+        if self._stale("q", off, owners):
             with torch.no_grad():
                 ops.split_planes_pair(self.pflat.detach().view(-1, 32), out=ops.Planes(self._pair.view(2, -1, 32), self.total // 32, 32, 32))
             self._pair_tag = self._tag()
         return ops.Planes(self._pair[:, off:off + rows * cols].view(2, rows, cols), rows, cols, cols)
 
-    def planes_t_of(self, off: int, rows: int, cols: int, ver=0, pair=False):
+    def planes_t_of(self, off: int, rows: int, cols: int, owners=(), pair=False):
         """plane operand of the TRANSPOSE of that matrix ([cols, rows], reduction over rows); pair: as two fp16 planes (form 1)"""
         if off % 8:
             return None
@@ -226,7 +235,7 @@ class FlatGroup:
             st["tbl"] = torch.tensor(rows_, dtype=torch.int64).to(self.pflat.device)
             st["tag"] = None
         which = "u" if pair else "t"
-        if self._stale(which, off, ver):
+        if self._stale(which, off, owners):
             (ops.split_planes_pair_t_batched if pair else ops.split_planes_t_batched)(self.pflat, st["buf"], st["tbl"], len(st["jobs"]), st["tiles"])
             st["tag"] = self._tag()
         slot, ld = st["jobs"][key]
