@@ -243,9 +243,10 @@ def main():
     ap.add_argument("--cpu-threads", type=int, default=0, help="threads of the CPU baseline (default: all cores AND 16, both reported)")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-syncbn", action="store_true")
-    ap.add_argument("--syncbn-comm", default="shared", choices=["shared", "own"],
-                    help="N > 1: SyncBatchNorm statistics on the gradient buckets' communicator (default: one communicator, one "
-                         "rank-invariant order of collectives) or on an own communicator concurrent with the buckets (the A/B)")
+    ap.add_argument("--syncbn-comm", default="direct", choices=["direct", "shared", "own"],
+                    help="N > 1: SyncBatchNorm statistics as ncclAllReduce calls of a communicator of the library's own on the compute stream "
+                         "(default, vbg/rccl.py), on the gradient buckets' torch.distributed communicator (shared: one communicator, one order of "
+                         "collectives), or on a second torch.distributed communicator (own) -- the A/Bs")
     ap.add_argument("--no-ddp-overlap", action="store_true", help="N > 1: launch every gradient bucket after backward (A/B of the overlap)")
     ap.add_argument("--dist-timeout", type=int, default=int(os.environ.get("VBG_DIST_TIMEOUT", "240")),
                     help="N > 1: process-group timeout in seconds; a stalled step also prints which bucket / SyncBatchNorm collective every rank is at")
@@ -339,7 +340,9 @@ def main():
     # is the overlapped two-communicator form of round 3, kept as the A/B
     # (static_graph: classifier_mode simp runs the same autograd graph on every rank, every step -- the word FlatReducer needs to let the
     #  buckets leave from inside backward while the SyncBatchNorm statistics share their communicator)
-    reducer = FlatReducer(opts, sync_bn_group=("new" if args.syncbn_comm == "own" else "default"), overlap=not args.no_ddp_overlap,
+    gloo_run = os.environ.get("VBG_DIST_BACKEND", "nccl") != "nccl"          # (functional runs of several ranks on one GPU: no RCCL)
+    reducer = FlatReducer(opts, sync_bn_group={"own": "new", "shared": "default", "direct": "default" if gloo_run else "direct"}[args.syncbn_comm],
+                          overlap=not args.no_ddp_overlap,
                           static_graph=True, force_enable=forced)
     if world > 1 or forced:
         reducer.start_watchdog(max(30.0, args.dist_timeout / 2))        # a stalled step leaves a line per rank on stderr

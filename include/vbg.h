@@ -465,9 +465,14 @@ int vbg_bn_bwd_apply(const float* dy, const float* y, const float* x, long long 
  * its prologue (fold order of the separate entry points: the same bits), the block of the first row chunk publishes mean / invstd / the
  * running statistics (forward) or adds the affine gradients (backward: dbeta += sum_g, dgamma += sum_gx).  C % 64 == 0.  The slot rows are
  * NOT cleared: hand in zeroed rows per use. */
-int vbg_bn_apply_fold(const float* x, const float* res, long long M, int C, double* slots, int nslots, double count, float eps,
-                      float momentum, float* mean, float* invstd, float* running_mean, float* running_var, const float* gamma,
-                      const float* beta, int relu, float* y, unsigned* y_amax, void* stream);
+int vbg_bn_apply_fold(const float* x, const float* res, long long M, int C, double* slots, int nslots, double count,
+                      const double* count_dev, float eps, float momentum, float* mean, float* invstd, float* running_mean,
+                      float* running_var, const float* gamma, const float* beta, int relu, float* y, unsigned* y_amax, void* stream);
+/* (count_dev, optional: a device scalar that overrides `count` -- SyncBatchNorm hands in the all-reduced [sum, sumsq, count] buffer as
+ * slots with nslots = 1 and its last element as count_dev)
+ * vbg_bn_fold_count: fold the slot rows into folded[0..2C) and put `count` (this rank's row count) into folded[2C]: the buffer of
+ * torch.nn.SyncBatchNorm's forward all-reduce, from one launch */
+int vbg_bn_fold_count(double* slots, int nslots, int clear_slots, int C, double* folded, double count, void* stream);
 int vbg_bn_bwd_apply_fold(const float* dy, const float* y, const float* x, long long M, int C, const float* mean,
                           const float* invstd, const float* gamma, double* slots, int nslots, double count, int relu, float* dx,
                           float* dres, float* dgamma_accum, float* dbeta_accum, unsigned* dx_amax, void* stream);

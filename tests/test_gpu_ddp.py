@@ -463,15 +463,18 @@ def _rccl_worker(rank, port, tmp):
     #      communicator, three steps; against the same steps without process-group involvement ------------------------------------------
     dbatch = to_dev(_docs(), dev)
 
-    def net_run(with_reducer):
-        net = _build(os.path.join(tmp, f"rccl{int(with_reducer)}"), sync_bn=with_reducer).to(dev).train()
+    def net_run(with_reducer, mode="direct"):
+        net = _build(os.path.join(tmp, f"rccl{int(with_reducer)}{mode}"), sync_bn=with_reducer).to(dev).train()
         cnn, bert = split_parameters(net)
         opts = [FusedSGD(cnn, dev, lr=0.005, momentum=0.9, weight_decay=0.005), FusedAdamW(bert, dev, lr=5e-5, weight_decay=0.01)]
         red = None
         if with_reducer:
             assert any(isinstance(m, torch.nn.SyncBatchNorm) for m in net.modules())
-            red = FlatReducer(opts, bucket_mb=4.0, force_enable=True, static_graph=True)
-            assert red.sync_bn_mode == "shared communicator" and Fn.SyncCtx.active()
+            red = FlatReducer(opts, bucket_mb=4.0, force_enable=True, static_graph=True, sync_bn_group="auto" if mode == "direct" else "default")
+            # (the default on RCCL: the statistics as ncclAllReduce calls of a communicator of the library's own on the compute stream,
+            #  vbg/rccl.py; "shared": through torch.distributed on the buckets' communicator)
+            assert red.sync_bn_mode == ("direct RCCL communicator on the compute stream" if mode == "direct" else "shared communicator")
+            assert Fn.SyncCtx.active() and (Fn.SyncCtx.direct is not None) == (mode == "direct")
             red.start_watchdog(60.0)
         else:
             Fn.SyncCtx.force = False
@@ -493,9 +496,12 @@ def _rccl_worker(rank, port, tmp):
         torch.cuda.synchronize()
         return losses, g0, red
 
-    seq0 = Fn.SyncCtx.seq
     la, ga, red = net_run(True)
     res["syncbn_collectives"] = Fn.SyncCtx.seq
+    res["direct_calls"] = Fn.SyncCtx.direct.calls
+    ls, gs, _ = net_run(True, "shared")
+    res["shared_vs_direct"] = (max(abs(a - b) / abs(b) for a, b in zip(ls, la)),
+                               max(float((gs[k] - ga[k]).norm() / (ga[k].norm() + 1e-30)) for k in ga if "key.bias" not in k))
     res["buckets"], res["order"], res["steps_done"] = len(red.buckets), red.order, red.steps_done
     lb, gb, _ = net_run(False)
     res["losses"] = (la, lb)
@@ -508,14 +514,17 @@ def test_rccl_one_rank_runs_the_reducer_and_syncbn(tmp_path):
     """pipeline/distributed_utils.py:89-98 is `backend="nccl"`: until a multi-GPU node runs this code, the one GPU of the test box runs the
     REAL backend with a process group of one rank and `FlatReducer(force_enable=True)` -- RCCL loads, ProcessGroupNCCL builds its
     communicator, buckets are issued as async works from the staging stream inside backward, `finish()` waits on them (work.wait() blocks
-    the STREAM on this backend, the host on gloo), SyncBatchNorm statistics (fp64 [sum, sumsq, count]) travel as all-reduces on the same
-    communicator between them, the watchdog thread runs.  Every collective over one rank is the identity, so: the toy model's parameters
+    the STREAM on this backend, the host on gloo), SyncBatchNorm statistics (fp64 [sum, sumsq, count]) travel as ncclAllReduce calls of
+    the library's own communicator on the compute stream (vbg/rccl.py, the default on RCCL) and, in a second run, as torch.distributed
+    all-reduces on the buckets' communicator; the watchdog thread runs.  Every collective over one rank is the identity, so: the toy model's parameters
     after three steps equal the reducer-less run (1e-5 of the largest entry), and the resnet-18 + BERT model's first-step loss / gradients equal the plain
     BatchNorm run (1e-5 / 1e-4: SyncBatchNorm takes the fold -> all_reduce -> finalize route with fp64 statistics)."""
     tmp = str(tmp_path)
     mp.spawn(_rccl_worker, args=(_free_port(), tmp), nprocs=1, join=True)
     r = torch.load(os.path.join(tmp, "rccl_res.pt"))
-    print("RCCL one-rank run:", {k: r[k] for k in ("toy_equal", "toy_order", "syncbn_collectives", "buckets", "order", "steps_done", "losses", "grad_err")})
+    print("RCCL one-rank run:", {k: r[k] for k in ("toy_equal", "toy_order", "syncbn_collectives", "direct_calls", "shared_vs_direct", "buckets", "order", "steps_done", "losses", "grad_err")})
+    assert r["direct_calls"] == r["syncbn_collectives"] >= 3 * 2 * 20          # every statistics collective went through vbg/rccl.py
+    assert r["shared_vs_direct"][0] < 2e-3 and r["shared_vs_direct"][1] < 1e-4, r["shared_vs_direct"]
     assert r["toy_equal"] < 1e-5, r["toy_equal"]
     assert r["steps_done"] == 3 and sorted(r["order"]) == list(range(r["buckets"])) and r["buckets"] >= 3
     assert r["syncbn_collectives"] >= 3 * 2 * 20                   # forward + backward statistics of every BatchNorm layer, three steps

@@ -226,7 +226,8 @@ __device__ __forceinline__ void amax_publish_at(float mx, unsigned* amax, unsign
 }
 
 __global__ __launch_bounds__(256) void bn_apply_fold_kernel(const float* __restrict__ x, const float* __restrict__ res, long long M, int C,
-                                                            double* __restrict__ slots, int nslots, double count, float eps, float momentum,
+                                                            double* __restrict__ slots, int nslots, double count,
+                                                            const double* __restrict__ count_dev, float eps, float momentum,
                                                             float* __restrict__ mean_out, float* __restrict__ invstd_out,
                                                             float* __restrict__ running_mean, float* __restrict__ running_var,
                                                             const float* __restrict__ gamma, const float* __restrict__ beta, int relu,
@@ -234,6 +235,7 @@ __global__ __launch_bounds__(256) void bn_apply_fold_kernel(const float* __restr
     __shared__ double fold[128];
     __shared__ __attribute__((aligned(16))) float cst[4][64];          // mean, invstd, gamma, beta of the block's 64 channels
     const int tid = threadIdx.x, c0 = blockIdx.y * 64;
+    if (count_dev) count = count_dev[0];                 // (SyncBatchNorm: the all-reduced row count, nslots = 1: the all-reduced sums)
     if (tid < 128) fold[tid] = fold_slots(slots, nslots, C, (tid >> 6) * C + c0 + (tid & 63), false);
     __syncthreads();
     if (tid < 64) {
@@ -340,8 +342,9 @@ __global__ __launch_bounds__(256) void amax_kernel(const float* __restrict__ x, 
 }
 
 __global__ void bn_param_grad_kernel(double* __restrict__ slots, int nslots, int clear, int C, double* __restrict__ folded, float* dgamma,
-                                     float* dbeta) {
+                                     float* dbeta, double tail = -1.0) {
     const int c = blockIdx.x * blockDim.x + threadIdx.x;
+    if (c == 0 && folded && tail >= 0.0) folded[2 * C] = tail;        // (the local row count behind the sums: one buffer, one all-reduce)
     if (c >= C) return;
     const double sg = fold_slots(slots, nslots, C, c, clear), sgx = fold_slots(slots, nslots, C, C + c, clear);
     if (folded) { folded[c] = sg; folded[C + c] = sgx; }
@@ -645,7 +648,7 @@ extern "C" int vbg_bn_bwd_apply(const float* dy, const float* y, const float* x,
     if (M > 0) VBG_LAUNCH(bn_bwd_apply_kernel, dim3(ew_grid(M * (C / 4), 256)), dim3(256), 0, S_, dy, y, x, M, C / 4, C, mean, invstd,
                           gamma, sums, count, count_dev, relu, dx, dres, dx_amax);
     if (dgamma_accum && dbeta_accum)
-        VBG_LAUNCH(bn_param_grad_kernel, dim3(cdiv(C, 256)), dim3(256), 0, S_, const_cast<double*>(sums), 1, 0, C, (double*)nullptr, dgamma_accum, dbeta_accum);
+        VBG_LAUNCH(bn_param_grad_kernel, dim3(cdiv(C, 256)), dim3(256), 0, S_, const_cast<double*>(sums), 1, 0, C, (double*)nullptr, dgamma_accum, dbeta_accum, -1.0);
     VBG_LAUNCH_RET();
 }
 
@@ -656,13 +659,13 @@ static inline int bn_fold_rows(long long M, int C) {
     return (int)(cdiv(r, 16) * 16);
 }
 
-extern "C" int vbg_bn_apply_fold(const float* x, const float* res, long long M, int C, double* slots, int nslots, double count, float eps,
-                                 float momentum, float* mean, float* invstd, float* running_mean, float* running_var, const float* gamma,
-                                 const float* beta, int relu, float* y, unsigned* y_amax, void* stream) {
-    VBG_CHECK_ARG(x && y && slots && mean && invstd && gamma && beta && M > 0 && C > 0 && C % 64 == 0 && nslots >= 1 && count > 0);
+extern "C" int vbg_bn_apply_fold(const float* x, const float* res, long long M, int C, double* slots, int nslots, double count,
+                                 const double* count_dev, float eps, float momentum, float* mean, float* invstd, float* running_mean,
+                                 float* running_var, const float* gamma, const float* beta, int relu, float* y, unsigned* y_amax, void* stream) {
+    VBG_CHECK_ARG(x && y && slots && mean && invstd && gamma && beta && M > 0 && C > 0 && C % 64 == 0 && nslots >= 1 && (count > 0 || count_dev));
     VBG_CHECK_ARG((running_mean == nullptr) == (running_var == nullptr) && ALIGNED16(x) && ALIGNED16(y) && (!res || ALIGNED16(res)));
     const int rpb = bn_fold_rows(M, C);
-    VBG_LAUNCH(bn_apply_fold_kernel, dim3(cdiv(M, rpb), C / 64), dim3(256), 0, S_, x, res, M, C, slots, nslots, count, eps, momentum, mean, invstd,
+    VBG_LAUNCH(bn_apply_fold_kernel, dim3(cdiv(M, rpb), C / 64), dim3(256), 0, S_, x, res, M, C, slots, nslots, count, count_dev, eps, momentum, mean, invstd,
                running_mean, running_var, gamma, beta, relu, rpb, y, y_amax);
     VBG_LAUNCH_RET();
 }
@@ -690,7 +693,13 @@ extern "C" int vbg_amax(const float* x, long long n, unsigned* amax, void* strea
 extern "C" int vbg_bn_param_grad(double* slots, int nslots, int clear_slots, int C, double* folded, float* dgamma_accum,
                                  float* dbeta_accum, void* stream) {
     VBG_CHECK_ARG(slots && nslots >= 1 && C > 0 && ((dgamma_accum == nullptr) == (dbeta_accum == nullptr)) && (folded || dgamma_accum));
-    VBG_LAUNCH(bn_param_grad_kernel, dim3(cdiv(C, 256)), dim3(256), 0, S_, slots, nslots, clear_slots, C, folded, dgamma_accum, dbeta_accum);
+    VBG_LAUNCH(bn_param_grad_kernel, dim3(cdiv(C, 256)), dim3(256), 0, S_, slots, nslots, clear_slots, C, folded, dgamma_accum, dbeta_accum, -1.0);
+    VBG_LAUNCH_RET();
+}
+
+extern "C" int vbg_bn_fold_count(double* slots, int nslots, int clear_slots, int C, double* folded, double count, void* stream) {
+    VBG_CHECK_ARG(slots && folded && nslots >= 1 && C > 0 && count >= 0);
+    VBG_LAUNCH(bn_param_grad_kernel, dim3(cdiv(C, 256)), dim3(256), 0, S_, slots, nslots, clear_slots, C, folded, (float*)nullptr, (float*)nullptr, count);
     VBG_LAUNCH_RET();
 }
 

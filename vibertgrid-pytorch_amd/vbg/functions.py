@@ -105,6 +105,7 @@ class SyncCtx:
     seq = 0            # statistics collectives issued since the reducer was built; `last` = (seq, numel) -- for hang reports
     last = None
     force = False      # a process group of ONE rank runs the collectives as well (FlatReducer(force_enable=True): the one-GPU RCCL check)
+    direct = None      # vbg.rccl.DirectComm: the statistics as ncclAllReduce calls on the compute stream (no torch.distributed in between)
 
     @classmethod
     def active(cls):
@@ -116,7 +117,10 @@ class SyncCtx:
             cls.before()
         cls.seq += 1
         cls.last = (cls.seq, t.numel())
-        dist.all_reduce(t, group=cls.group)
+        if cls.direct is not None and t.is_cuda:
+            cls.direct.all_reduce_(t)
+        else:
+            dist.all_reduce(t, group=cls.group)
 
 
 # ----------------------------------------------------------------------------------------------
@@ -379,17 +383,21 @@ class ConvBnFn(torch.autograd.Function):
                     stats = ops.bn_stats(z2)
                 count, count_dev = float(M), None
                 if sync:
-                    glob = torch.empty((2 * C + 1,), device=x.device, dtype=torch.float64)
-                    ops.bn_fold(stats, C, out=glob)
-                    glob[2 * C] = M
+                    glob = ops.bn_fold_count(stats, C, M)        # [sum, sumsq, rows of this rank] from one launch
                     SyncCtx.all_reduce(glob)
                     count_dev = glob[2 * C:]                   # global row count stays on the device (no sync)
-                    mean, invstd = ops.bn_finalize(glob, C, 1, count, eps, momentum, running_mean, running_var, count_dev)
+                    if ops.bn_fold_ok(C):                      # finalize from the all-reduced sums in the apply kernel's prologue
+                        y, mean, invstd = ops.bn_apply_fold(z2, r2, glob, count, eps, momentum, running_mean, running_var, gamma, beta, relu,
+                                                            y_amax=y_amax, nslots=1, count_dev=count_dev)
+                        y = y.view(z.shape)
+                    else:
+                        mean, invstd = ops.bn_finalize(glob, C, 1, count, eps, momentum, running_mean, running_var, count_dev)
                 else:
                     mean, invstd = ops.bn_finalize(stats, C, ops.bn_slots(), count, eps, momentum, running_mean, running_var)
             else:
                 mean, invstd, count, count_dev = running_mean, _frozen_invstd(running_var, eps), float(M), None
-            y = ops.bn_apply(z2, r2, mean, invstd, gamma, beta, relu, y_amax=y_amax).view(z.shape)
+            if not (training and sync and ops.bn_fold_ok(C)):
+                y = ops.bn_apply(z2, r2, mean, invstd, gamma, beta, relu, y_amax=y_amax).view(z.shape)
         if y_amax is not None:
             y._vbg_amax = (y_amax, y._version)
         ctx.fold = fold

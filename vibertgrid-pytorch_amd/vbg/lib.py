@@ -138,7 +138,8 @@ SIGNATURES = {
     "vbg_bn_bwd_reduce": (c_int, [c_vp, c_vp, c_vp, c_ll, c_int, c_vp, c_vp, c_int, c_vp, c_vp]),
     "vbg_bn_bwd_apply": (c_int, [c_vp, c_vp, c_vp, c_ll, c_int, c_vp, c_vp, c_vp, c_vp, c_d, c_vp, c_int, c_vp, c_vp, c_vp, c_vp, c_vp, c_vp]),
     "vbg_bn_param_grad": (c_int, [c_vp, c_int, c_int, c_int, c_vp, c_vp, c_vp, c_vp]),
-    "vbg_bn_apply_fold": (c_int, [c_vp, c_vp, c_ll, c_int, c_vp, c_int, c_d, c_f, c_f, c_vp, c_vp, c_vp, c_vp, c_vp, c_vp, c_int, c_vp, c_vp, c_vp]),
+    "vbg_bn_apply_fold": (c_int, [c_vp, c_vp, c_ll, c_int, c_vp, c_int, c_d, c_vp, c_f, c_f, c_vp, c_vp, c_vp, c_vp, c_vp, c_vp, c_int, c_vp, c_vp, c_vp]),
+    "vbg_bn_fold_count": (c_int, [c_vp, c_int, c_int, c_int, c_vp, c_d, c_vp]),
     "vbg_bn_bwd_apply_fold": (c_int, [c_vp, c_vp, c_vp, c_ll, c_int, c_vp, c_vp, c_vp, c_vp, c_int, c_d, c_int, c_vp, c_vp, c_vp, c_vp, c_vp, c_vp]),
     "vbg_maxpool3x3s2_fwd": (c_int, [c_vp, c_int, c_int, c_int, c_int, c_vp, c_vp, c_vp]),
     "vbg_maxpool3x3s2_bwd": (c_int, [c_vp, c_vp, c_int, c_int, c_int, c_int, c_int, c_int, c_vp, c_vp]),

@@ -1552,14 +1552,23 @@ def bn_zero_slots(device, C_):
     return ent[0][o:o + n]
 
 
-def bn_apply_fold(x2d, res2d, slots, count, eps, momentum, running_mean, running_var, gamma, beta, relu, y_amax=None):
-    """finalize + apply in one launch -> (y, mean, invstd); slots: zeroed rows the statistics were accumulated into (bn_zero_slots)"""
+def bn_fold_count(slots, C_, count):
+    """[2C + 1] fp64 = the folded slot rows (cleared behind the read) and this rank's row count: the SyncBatchNorm all-reduce buffer"""
+    out = torch.empty((2 * C_ + 1,), device=slots.device, dtype=torch.float64)
+    check(lib.vbg_bn_fold_count(P(slots), bn_slots(), 1, C_, P(out), float(count), _stream()), "vbg_bn_fold_count")
+    return out
+
+
+def bn_apply_fold(x2d, res2d, slots, count, eps, momentum, running_mean, running_var, gamma, beta, relu, y_amax=None, nslots=None, count_dev=None):
+    """finalize + apply in one launch -> (y, mean, invstd); slots: zeroed rows the statistics were accumulated into (bn_zero_slots), or
+    (nslots = 1, count_dev) the all-reduced sums of a SyncBatchNorm and their row count on the device"""
     M, C_ = x2d.shape
     out = torch.empty_like(x2d)
     mean = torch.empty((C_,), device=x2d.device, dtype=f32)
     invstd = torch.empty_like(mean)
-    check(lib.vbg_bn_apply_fold(P(x2d), P(res2d), M, C_, P(slots), bn_slots(), float(count), eps, momentum, P(mean), P(invstd), P(running_mean),
-                                P(running_var), P(gamma), P(beta), int(relu), P(out), P(y_amax), _stream()), "vbg_bn_apply_fold")
+    check(lib.vbg_bn_apply_fold(P(x2d), P(res2d), M, C_, P(slots), bn_slots() if nslots is None else int(nslots), float(count), P(count_dev), eps, momentum,
+                                P(mean), P(invstd), P(running_mean), P(running_var), P(gamma), P(beta), int(relu), P(out), P(y_amax), _stream()),
+          "vbg_bn_apply_fold")
     if running_var is not None:
         _BN_EPOCH[0] += 1
     return out, mean, invstd

@@ -550,8 +550,27 @@ class FlatReducer:
         if self.dry:
             sync_bn_group = None
         if sync_bn_group == "auto":
-            sync_bn_group = os.environ.get("VBG_SYNCBN_GROUP", "default")
-        if sync_bn_group == "new":
+            from . import rccl
+            sync_bn_group = os.environ.get("VBG_SYNCBN_GROUP", "direct" if (group is None and rccl.available()) else "default")
+        Fn.SyncCtx.direct = None
+        if sync_bn_group == "direct":
+            # THE DEFAULT on RCCL (round 5): the statistics on a communicator of this library's own, enqueued on the compute stream
+            # (vbg/rccl.py): no event hand-overs to and from ProcessGroupNCCL's stream (measured on one rank: 40.9 vs 41.2 ms per step --
+            # the ~70 us a SyncBatchNorm layer costs is RCCL's own small-message kernel and the route's extra launches, not the
+            # dispatcher), and -- the point at N > 1 -- never queued behind a 32 MB gradient bucket on that stream.  Two communicators
+            # then have kernels in flight during backward.  That is deadlock-free when every rank ENQUEUES them in the same relative
+            # order (streams beyond the device's hardware queues share one, and a collective's kernel parked at the head of a queue holds
+            # up whatever sits behind it): the same program on every rank issues the same sequence, which is what static_graph=True
+            # asserts -- without it the buckets leave from finish(), behind every statistics collective of the step, as on the shared
+            # communicator.
+            from . import rccl
+            if group is not None or not rccl.available():
+                raise ValueError("sync_bn_group='direct' needs backend 'nccl' (RCCL) and the default process group")
+            dev = optimizers[0].group.pflat.device
+            Fn.SyncCtx.group = group
+            Fn.SyncCtx.direct = rccl.DirectComm(dev)
+            self.sync_bn_mode = "direct RCCL communicator on the compute stream"
+        elif sync_bn_group == "new":
             if group is not None:
                 raise ValueError("FlatReducer(group=<sub-group>): pass sync_bn_group=<ProcessGroup> or 'default' -- dist.new_group is a "
                                  "collective over the default group and would hang when only the sub-group's ranks call it")
@@ -568,8 +587,8 @@ class FlatReducer:
         Fn.SyncCtx.before = self._wait_for_buckets if (serialize_syncbn and not self.dry) else None
         Fn.SyncCtx.seq = 0
         Fn.SyncCtx.force = self.forced
-        if self.sync_bn_mode == "shared communicator" and self.overlap and not self.static_graph:
-            self.overlap = False       # graphs not known to be rank-invariant on ONE communicator: every bucket from finish()
+        if self.sync_bn_mode in ("shared communicator", "direct RCCL communicator on the compute stream") and self.overlap and not self.static_graph:
+            self.overlap = False       # graphs not known to be rank-invariant: every bucket from finish(), a rank-invariant point
         Fn.GRAD_READY[0] = self._param_ready      # sunk gradients (written by the wgrad kernels) report here
         cap = int(bucket_mb * (1 << 20) / 4)
         for o in optimizers:
@@ -701,7 +720,7 @@ class FlatReducer:
             late += 1
         for _, h in self.handles:
             h.wait()
-        if (late and self.overlap and self.static_graph and self.sync_bn_mode == "shared communicator" and self.steps_done >= 1
+        if (late and self.overlap and self.static_graph and self.sync_bn_mode != "own communicator" and self.sync_bn_mode != "none" and self.steps_done >= 1
                 and Fn.SyncCtx.seq > 0 and not self.forced):
             raise RuntimeError(f"vbg.optim.FlatReducer(static_graph=True): {late} gradient bucket(s) had to be issued from finish() in step "
                                f"{self.steps_done + 1} -- this rank's autograd graph skipped a sub-module, so its collectives did not interleave "
