@@ -546,7 +546,7 @@ def main():
     # HBM-side bytes per launch of the same kernel: rocprofv3 PMC passes of this command (cannot be collected in-process),
     # summarised in profiles/ by the round that produced them; null when the file is absent
     def pmc_traffic(stem):
-        for rnd in ("r04", "r03", "r02", "r01"):
+        for rnd in ("r05", "r04", "r03", "r02", "r01"):
             tf = os.path.join(ROOT, "profiles", f"{rnd}_{stem}.json")
             if os.path.exists(tf):
                 with open(tf) as fh:
@@ -654,11 +654,11 @@ def main():
                 out["cpu_baseline"] = cpu_baseline(args.cpu_threads)
             else:
                 counts = sorted({min(ncpu, c) for c in (16, 32, 64)} | ({ncpu} if ncpu <= 128 else set()))
-                runs = [child(c, "cfg2", 60) for c in counts]
+                runs = [child(c, "cfg2", 40) for c in counts]
                 done = [r for r in runs if r.get("value")]
                 best = max(done, key=lambda r: r["value"]) if done else cpu_baseline(min(ncpu, 16))
                 out["cpu_baseline"] = dict(best, sweep=[{"threads": r.get("threads"), "value": r.get("value"), **({"note": r["note"]} if r.get("note") else {})} for r in runs])
-                out["cpu_baseline"]["cfg1"] = child(best["threads"], "cfg1", 60)
+                out["cpu_baseline"]["cfg1"] = child(best["threads"], "cfg1", 40)
         sys.stdout.flush()
         os.write(real_stdout, (json.dumps(out) + "\n").encode())
     if world > 1 or forced:

@@ -229,6 +229,11 @@ typedef struct vbg_attn_desc {
     unsigned* out_amax;             /* DQ / DKV, optional: amax slot (zeroed by the caller) that receives max |value written to out| */
     unsigned short* out_pair; long long oq_plane, oq_ld;     /* FWD, optional (round 4): O also as fp16-pair planes [2][ntok][oq_ld] -- the B operand
                                                                 of the output projection's weight gradient, saved for backward instead of split there */
+    int form;                       /* round 5.  0: qkv / dO are three bf16 planes, six piece products per product (above);
+                                       1: qkv / dO are fp16-pair planes [2][ntok][ld] (hi, (x - hi) 2^11; vbg_plane_gemm's Cq output), three fp16 piece
+                                          products per product into one accumulator set (one operand of each cross product carries the 2^-11);
+                                       2: the hi planes of the same tensors alone, one product (`amp`: what fp16 autocast multiplies) */
+    const unsigned* do_amax;        /* forms 1 / 2, DQ / DKV: the amax slot dO's planes were scaled with (their producer's bound; NULL: unscaled) */
 } vbg_attn_desc;
 int vbg_attn(const vbg_attn_desc* desc, void* stream);
 /* dropout keeps of one layer and step, both orientations (torch.nn.Dropout(attention_probs_dropout_prob) on the probabilities):

@@ -34,7 +34,9 @@ def _keep_matrix(words, off, head, L):
     return bits[:L, :L].astype(bool)
 
 
-def _run(seq_len, heads, p, seed=0):
+def _run(seq_len, heads, p, seed=0, form=0, dscale=1.0):
+    """form 0: three bf16 planes / six piece products; 1: fp16-pair planes / three piece products (dO's planes scaled by the power of two of
+    its largest magnitude, like the bound-scaled planes of the encoder's backward); 2: inside an autocast region -- the hi planes alone"""
     from vbg import ops
     from vbg.lib import ATTN_DKV, ATTN_DQ, ATTN_FWD
     dev = torch.device("cuda")
@@ -43,9 +45,15 @@ def _run(seq_len, heads, p, seed=0):
     g = torch.Generator().manual_seed(seed)
     # wide dynamic range across columns, like real q / k / v
     qkv = torch.randn(ntok, 3 * hid, generator=g) * torch.exp2(torch.randint(-3, 2, (3 * hid,), generator=g).float())
-    dO = torch.randn(ntok, hid, generator=g)
-    pq = ops.split_planes(qkv.to(dev))
-    pdo = ops.split_planes(dO.to(dev))
+    dO = torch.randn(ntok, hid, generator=g) * dscale
+    slot_do = None
+    if form == 0:
+        pq = ops.split_planes(qkv.to(dev))
+        pdo = ops.split_planes(dO.to(dev))
+    else:
+        pq = ops.split_planes_pair(qkv.to(dev))
+        slot_do = ops.amax(dO.to(dev))
+        pdo = ops.split_planes_pair(dO.to(dev), amax_slot_=slot_do)
     scale = 0.125
     masks = ops.attn_mask(meta, p, 1234, 5) if p > 0 else None
     O = torch.zeros(ntok, hid, device=dev)
@@ -54,14 +62,17 @@ def _run(seq_len, heads, p, seed=0):
     opl = ops.planes_empty(ntok, hid, dev)
     oq = ops.pair_empty(ntok, hid, dev)
     oq.buf.zero_()
+    if form == 2:
+        ops.set_amp(True)
     ops.attn(meta, ATTN_FWD, pq, None, O, lse, None, masks, scale, p, kbar=kbar, out_planes=opl, out_pair=oq)
     assert torch.equal(opl.buf, ops.split_planes(O).buf), "planes of O written by the forward kernel != split(O)"
     assert torch.equal(oq.buf, ops.split_planes_pair(O).buf), "fp16-pair planes of O written by the forward kernel != split_pair(O)"
     delta = torch.zeros_like(lse[0])
     dqkv = torch.full((ntok, 3 * hid), float("nan"), device=dev)
     slot = ops.amax_slot(dev)          # the largest magnitude of d(qkv) rides on the two backward kernels (fp16-pair planes' scale)
-    ops.attn(meta, ATTN_DQ, pq, pdo, dqkv, lse, delta, masks, scale, p, kbar=kbar, o=O, out_amax=slot)
-    ops.attn(meta, ATTN_DKV, pq, pdo, dqkv, lse, delta, masks, scale, p, out_amax=slot)
+    ops.attn(meta, ATTN_DQ, pq, pdo, dqkv, lse, delta, masks, scale, p, kbar=kbar, o=O, out_amax=slot, do_amax=slot_do)
+    ops.attn(meta, ATTN_DKV, pq, pdo, dqkv, lse, delta, masks, scale, p, out_amax=slot, do_amax=slot_do)
+    ops.set_amp(False)
     torch.cuda.synchronize()
     assert int(slot.max().item()) == int(dqkv.abs().max().view(torch.int32).item())
     # ---- reference: fp64, per (sequence, head) --------------------------------------------------------------------
@@ -124,3 +135,48 @@ def test_fused_attention_dropout():
     for name, sl in (("dq", slice(0, hid)), ("dk", slice(hid, 2 * hid)), ("dv", slice(2 * hid, 3 * hid))):
         e = _relerr(r["dqkv"][:, sl], r["dref"][:, sl])
         assert e < 5e-6, (name, e)
+
+
+@pytest.mark.parametrize("seq_len,heads,dscale", [([512, 4, 130, 33, 200], 3, 1.0), ([4, 2], 2, 1e-7), ([512] * 2 + [4] * 2, 12, 3e-9), ([129, 128, 127, 97], 2, 2e4)])
+def test_fused_attention_pair_form_vs_fp64(seq_len, heads, dscale):
+    """csrc/attn.hip FORM 1 (round 5): q / k / v / dO as fp16-pair planes, three fp16 piece products per product into ONE accumulator set
+    (one operand of each cross product carries the 2^-11), probabilities / score gradients split into two fp16 pieces after a power-of-two
+    scaling.  Same gates as the six-product form (fp32-grade), with dO at gradient magnitudes 3e-9 ... 2e4 (its planes are scaled by the
+    power of two of the slot, the kernels scale back)."""
+    r = _run(seq_len, heads, 0.0, form=1, dscale=dscale)
+    assert torch.isfinite(r["O"]).all() and torch.isfinite(r["dqkv"]).all()
+    e = _relerr(r["O"], r["Oref"])
+    print("pair form: O", e, "lse", float((r["lse"] - r["lse_ref"]).abs().max()),
+          [(_relerr(r["dqkv"][:, sl], r["dref"][:, sl])) for sl in (slice(0, r["hid"]), slice(r["hid"], 2 * r["hid"]), slice(2 * r["hid"], 3 * r["hid"]))])
+    assert e < 2e-6, e
+    assert float((r["lse"] - r["lse_ref"]).abs().max()) < 5e-6
+    hid = r["hid"]
+    for name, sl in (("dq", slice(0, hid)), ("dk", slice(hid, 2 * hid)), ("dv", slice(2 * hid, 3 * hid))):
+        e = _relerr(r["dqkv"][:, sl], r["dref"][:, sl])
+        print("pair form:", name, e)
+        assert e < 5e-6, (name, e)
+
+
+def test_fused_attention_pair_form_dropout():
+    r = _run([512, 130, 4], 2, 0.1, seed=3, form=1, dscale=1e-6)
+    assert torch.isfinite(r["O"]).all() and torch.isfinite(r["dqkv"]).all()
+    assert _relerr(r["O"], r["Oref"]) < 2e-6
+    hid = r["hid"]
+    for name, sl in (("dq", slice(0, hid)), ("dk", slice(hid, 2 * hid)), ("dv", slice(2 * hid, 3 * hid))):
+        e = _relerr(r["dqkv"][:, sl], r["dref"][:, sl])
+        assert e < 5e-6, (name, e)
+
+
+def test_fused_attention_one_product_form():
+    """FORM 2 (`amp`): the hi planes alone, probabilities and score gradients rounded to fp16 once -- what fp16 autocast multiplies.  Held to
+    the fp64 result at reduced-precision level: 3e-3 of the largest magnitude (fp16's 2^-11 per rounded operand through two products)."""
+    r = _run([512, 130, 4, 33], 3, 0.1, seed=5, form=2, dscale=1e-5)
+    assert torch.isfinite(r["O"]).all() and torch.isfinite(r["dqkv"]).all()
+    e = _relerr(r["O"], r["Oref"])
+    print("one-product form: O", e)
+    assert 1e-7 < e < 3e-3, e
+    hid = r["hid"]
+    for name, sl in (("dq", slice(0, hid)), ("dk", slice(hid, 2 * hid)), ("dv", slice(2 * hid, 3 * hid))):
+        e = _relerr(r["dqkv"][:, sl], r["dref"][:, sl])
+        print("one-product form:", name, e)
+        assert e < 3e-3, (name, e)

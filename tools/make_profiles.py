@@ -7,7 +7,7 @@ expects (tools/collect_profiles.sh): gpurun_out/prof_e (kernel-trace + stats of 
 gpurun_out/pmc_f / pmc_w (FETCH_SIZE / WRITE_SIZE passes of `bench.py --steps 3 --warmup 1 --no-h2d-leg`), gpurun_out/pmc_m (SQ / GRBM
 pass of the same command), gpurun_out/gemm_shapes.txt, gpurun_out/bench_line.json"""
 import collections, csv, json, os, re, shutil, subprocess, sys
-TAG = sys.argv[1] if len(sys.argv) > 1 else "r04"
+TAG = sys.argv[1] if len(sys.argv) > 1 else "r05"
 NSTEP = int(sys.argv[2]) if len(sys.argv) > 2 else 23          # bench.py --steps 10 --warmup 3: 3 + 10 (headline) + 10 (roofline leg)
 NPMC = int(sys.argv[3]) if len(sys.argv) > 3 else 7            # bench.py --steps 3 --warmup 1: 1 + 3 + 3
 R = os.path.dirname(os.path.dirname(os.path.abspath(__file__))) + "/"
@@ -84,7 +84,8 @@ for src, dst in (("gemm_shapes.txt", "gemm_shapes.txt"), ("bench_line.json", "be
                  ("gemm_shapes_amp.txt", "gemm_shapes_amp.txt"), ("conv3_shapes.txt", "conv3_shapes.txt"),
                  ("conv3_pw.txt", "conv3_pw.txt"), ("step_conv3.txt", "step_conv3.txt"), ("conv3_forms.txt", "conv3_forms.txt"),
                  ("attn_shapes.txt", "attn_shapes.txt"), ("step_plane.txt", "step_plane.txt"), ("plane_pair_shapes.txt", "plane_pair_shapes.txt"),
-                 ("bench_amp_line.json", "bench_amp_line.json"), ("infer_latency.txt", "infer_latency.txt")):
+                 ("bench_amp_line.json", "bench_amp_line.json"), ("infer_latency.txt", "infer_latency.txt"),
+                 ("stock_loop_phases.txt", "stock_loop_phases.txt"), ("forced_reducer.txt", "forced_reducer.txt")):
     if os.path.exists(G + src):
         shutil.copy(G + src, P + dst)
 if os.path.exists(G + "prof_amp/amp_kernel_stats.csv"):
@@ -170,7 +171,9 @@ for fam, sel, key in (("row-reuse 3x3 convolutions (conv3x3_kernel, forward + in
         if sel(r["Name"]):
             agr.append(f"    {short(r['Name'])[:84]:84s} x{int(r['Calls']) / NSTEP:6.1f} / step   {float(r['AverageNs']) / 1e3:8.1f} us")
             tw += float(r["TotalDurationNs"]); tn += int(r["Calls"])
-    live = line.get(key) or {}
+    # (since round 5 `roofline` is whichever family takes more of the step; the other one rides as roofline_conv3 / roofline_nt)
+    want = "conv3x3" if key == "roofline" else "plane_gemm"
+    live = next((line[k] for k in ("roofline", "roofline_conv3", "roofline_nt") if k in line and want in line[k].get("kernel", "")), {})
     if tn:
         agr.append(f"    kernel trace: {tn / NSTEP:.0f} launches per step, average {tw / tn / 1e3:.2f} us;  bench.py live ({key}): {live.get('launches', 0) / max(line.get('steps', 1), 1):.0f} launches per step, average {live.get('avg_us')} us")
 open(P + "agreement.txt", "w").write("\n".join(agr) + "\n")

@@ -60,11 +60,42 @@ __device__ __forceinline__ void at_split16(const float (&x)[16], at_u32x4 (&bp)[
 }
 
 #define AT_MFMA(a, b, c) __builtin_amdgcn_mfma_f32_32x32x16_bf16(__builtin_bit_cast(at_bf16x8, a), __builtin_bit_cast(at_bf16x8, b), c, 0, 0, 0)
+#define AT_MFMA_H(a, b, c) __builtin_amdgcn_mfma_f32_32x32x16_f16(__builtin_bit_cast(at_f16x8, a), __builtin_bit_cast(at_f16x8, b), c, 0, 0, 0)
 
-template <int MODE, bool DROP>
+// ---- the two-piece fp16 form (FORM 1; round 5) and its one-product cut (FORM 2: `amp`) -------------------------------------------------
+// Operands arrive as the fp16-pair planes of csrc/gemm_planes.hip: x = hi + lo' 2^-11, hi = fp16(x), lo' = fp16((x - hi) 2^11) (round to
+// nearest both; q / k / v as they are, dO scaled by the power of two its producer derived from a bound: vbg_attn_desc.do_amax).  A product
+// is hi hi + 2^-11 (hi lo' + lo' hi): three fp16 MFMAs instead of six bf16 ones, two planes through LDS instead of three.
+//   * Score-type products (S = K Q^T, dP = V dO^T: a reduction over the 64 columns of a head): ONE accumulator.  The 2^-11 is folded into
+//     the stationary operand (the workgroup's own rows, one row per lane = the N index of the product), which is first scaled by the
+//     per-lane power of two c = 2^(13 - exponent(max |row|)) so that the folded pieces stay normal fp16 numbers: fragments hi c,
+//     lo' c 2^-11, hi c 2^-11; the product leaves as c S and is scaled back per lane.  (Folding into unscaled fragments -- the first
+//     build -- loses the cross terms of every element below 2^-3: hi 2^-11 is an fp16 subnormal there.)
+//   * Second products (O^T += V^T P^T, dQ^T += K^T dS^T, ...: a reduction over up to 512 streamed rows): the cross products go into
+//     accumulators of their own that live for ONE tile and are folded into the main ones times 2^-11 behind it.  The matrix pipe
+//     aligns the products of an instruction to the accumulator it adds them to; against a running sum over hundreds of rows a cross
+//     product (2^-12 of a main product, 2^-21 of the sum) arrived with a bit or two -- the second build, measured: switching the
+//     cross products off moved O by 1e-6 of an error of 2.4e-4.
+//   * Register operands are scaled into fp16's range before they are split (hi, lo' as above): probabilities (<= 1.12) by 2^13, score
+//     gradients by a running per-lane power of two derived from a BOUND known before the values are (|dS| <= max |dP| keep + max
+//     |delta| over the tile, P <= 1); when the bound grows the lane's accumulators are multiplied by the exact ratio.  Nothing can
+//     overflow: every scale comes from a maximum or a bound of what it scales.  The streamed operand is used as it lies in LDS.
+typedef _Float16 at_f16x8 __attribute__((ext_vector_type(8)));
+typedef _Float16 at_h2 __attribute__((ext_vector_type(2)));
+typedef float at_f2 __attribute__((ext_vector_type(2)));
+__device__ __forceinline__ float at_hlo(unsigned u) { return (float)__builtin_bit_cast(at_h2, u).x; }
+__device__ __forceinline__ float at_hhi(unsigned u) { return (float)__builtin_bit_cast(at_h2, u).y; }
+
+template <int MODE, bool DROP, int FORM>
 __global__ __launch_bounds__(256, 2) void attn_kernel(const vbg_attn_desc p) {
     constexpr bool FWD = MODE == VBG_ATTN_FWD, DQ = MODE == VBG_ATTN_DQ, DKV = MODE == VBG_ATTN_DKV;
     constexpr int NS = FWD ? 1 : 2;                                   // stationary operands
+    // FORM 0: three bf16 planes, six piece products; FORM 1: two fp16 planes, three; FORM 2: the hi plane alone, one (`amp`)
+    constexpr int NP = FORM == 0 ? 3 : (FORM == 1 ? 2 : 1);           // planes of a streamed operand that travel through LDS
+    constexpr int NST = FORM == 2 ? 1 : 3;                            // fragment sets of a stationary operand (FORM 1: hi, lo' 2^-11, hi 2^-11)
+    constexpr int NE = FORM == 0 ? 3 : (FORM == 1 ? 2 : 1);           // pieces of a register operand (FORM 1: hi, lo')
+    constexpr int AT_OP = NP * AT_PL, AT_STAGE = 2 * AT_OP;           // (shadow the three-plane sizes of the file scope)
+    constexpr float ESC = FORM == 0 ? 1.f : 8192.f, IESC = FORM == 0 ? 1.f : 1.f / 8192.f;     // scale of the probabilities as a register operand
     // behind the two tile stages: the dropout keep words of the workgroup's own rows (128 rows x 16 tiles) and, DKV, the statistics
     // (m, 1 / l, delta) of every query of the sequence (3 x 512 floats) -- staged ONCE, so that the tile loop issues no ordinary
     // global load (hipcc waits vmcnt(0) for any such load while LDS-DMA is in flight: it drained the tile pipeline every iteration)
@@ -107,11 +138,11 @@ __global__ __launch_bounds__(256, 2) void attn_kernel(const vbg_attn_desc p) {
     //      lane l -> row 8 w + l / 8, physical chunk l % 8 <- logical chunk (l % 8) ^ f(row) -----------------------------------
     const int drow = 8 * wave + (lane >> 3);
     const int dchunk = (lane & 7) ^ at_swz(drow);
-    unsigned dvo[2][3];
+    unsigned dvo[2][NP];
 #pragma unroll
     for (int o = 0; o < 2; ++o)
 #pragma unroll
-        for (int q = 0; q < 3; ++q) dvo[o][q] = (unsigned)(((long long)q * splane[o] + (long long)drow * sld[o]) * 2 + dchunk * 16);
+        for (int q = 0; q < NP; ++q) dvo[o][q] = (unsigned)(((long long)q * splane[o] + (long long)drow * sld[o]) * 2 + dchunk * 16);
     auto issue = [&](int stage, int t) {
         const unsigned inv = (t * 32 + drow < L) ? 0u : AT_INVALID;          // rows past the sequence land as zeros
 #pragma unroll
@@ -119,26 +150,64 @@ __global__ __launch_bounds__(256, 2) void attn_kernel(const vbg_attn_desc p) {
             const __amdgpu_buffer_rsrc_t rs = __builtin_amdgcn_make_buffer_rsrc(const_cast<unsigned short*>(sbase[o]), 0, (int)0x80000000u, 0x00020000);
             const int soff = (int)((long long)t * 32 * sld[o] * 2);
 #pragma unroll
-            for (int q = 0; q < 3; ++q)
+            for (int q = 0; q < NP; ++q)
                 __builtin_amdgcn_raw_ptr_buffer_load_lds(rs, (at_lds_ptr)(smem + stage * AT_STAGE + o * AT_OP + q * AT_PL + wave * 1024), 16,
                                                          (int)(dvo[o][q] | inv), soff, 0, 0);
         }
     };
 
     // ---- stationary fragments (B operands of the score-type products): own row lr, k-step ks = 16 B at column 16 ks + 8 lh ----
-    at_u32x4 st[NS][3][4];
+    at_u32x4 st[NS][NST][4];
+    at_u32x4 dlo[FORM == 1 && DQ ? 4 : 1];          // FORM 1, DQ: the lo' pieces of dO as stored, for delta in the prologue only
+    at_u32x4 dhi[FORM != 0 && DQ ? 4 : 1];          // FORM 1 / 2, DQ: the hi pieces of dO as stored
+    float cinv[NS];                                 // FORM 1 / 2: 1 / (the power of two this lane's stationary row was scaled by)
     {
         const bool ok = own0 + lr < L;
 #pragma unroll
-        for (int s = 0; s < NS; ++s)
+        for (int s = 0; s < NS; ++s) {
+            if constexpr (FORM == 0) {
 #pragma unroll
-            for (int q = 0; q < 3; ++q)
+                for (int q = 0; q < 3; ++q)
+#pragma unroll
+                    for (int ks = 0; ks < 4; ++ks) {
+                        at_u32x4 v = {0u, 0u, 0u, 0u};
+                        if (ok) v = *reinterpret_cast<const at_u32x4*>(tbase[s] + (long long)q * tplane[s] + (long long)(own0 + lr) * tld[s] + 16 * ks + 8 * lh);
+                        st[s][q][ks] = v;
+                    }
+                cinv[s] = 1.f;
+            } else {
+                at_u32x4 rh[4], rl[4];
+                float mx = 0.f;
 #pragma unroll
                 for (int ks = 0; ks < 4; ++ks) {
-                    at_u32x4 v = {0u, 0u, 0u, 0u};
-                    if (ok) v = *reinterpret_cast<const at_u32x4*>(tbase[s] + (long long)q * tplane[s] + (long long)(own0 + lr) * tld[s] + 16 * ks + 8 * lh);
-                    st[s][q][ks] = v;
+                    rh[ks] = at_u32x4{0u, 0u, 0u, 0u}; rl[ks] = rh[ks];
+                    if (ok) {
+                        rh[ks] = *reinterpret_cast<const at_u32x4*>(tbase[s] + (long long)(own0 + lr) * tld[s] + 16 * ks + 8 * lh);
+                        if constexpr (FORM == 1) rl[ks] = *reinterpret_cast<const at_u32x4*>(tbase[s] + tplane[s] + (long long)(own0 + lr) * tld[s] + 16 * ks + 8 * lh);
+                    }
+#pragma unroll
+                    for (int j = 0; j < 4; ++j) mx = fmaxf(mx, fmaxf(fabsf(at_hlo(rh[ks][j])), fabsf(at_hhi(rh[ks][j]))));
                 }
+                mx = fmaxf(mx, __shfl_xor(mx, 32, 64));                       // (the two half-waves hold the two halves of the row)
+                const float2 cs = vbg_pow2_scale(__float_as_uint(mx));        // (max = 0, inf or NaN: no scaling)
+                cinv[s] = cs.y;
+                const float c0 = cs.x, c1 = cs.x * 0.00048828125f;
+#pragma unroll
+                for (int ks = 0; ks < 4; ++ks) {
+                    if constexpr (DQ) { if (s == 1) { dhi[ks] = rh[ks]; if constexpr (FORM == 1) dlo[ks] = rl[ks]; } }
+#pragma unroll
+                    for (int j = 0; j < 4; ++j) {
+                        const at_f2 h = {at_hlo(rh[ks][j]), at_hhi(rh[ks][j])};
+                        st[s][0][ks][j] = __builtin_bit_cast(unsigned, __builtin_convertvector(h * c0, at_h2));            // hi c
+                        if constexpr (FORM == 1) {
+                            const at_f2 l = {at_hlo(rl[ks][j]), at_hhi(rl[ks][j])};
+                            st[s][1][ks][j] = __builtin_bit_cast(unsigned, __builtin_convertvector(l * c1, at_h2));        // lo' c 2^-11
+                            st[s][2][ks][j] = __builtin_bit_cast(unsigned, __builtin_convertvector(h * c1, at_h2));        // hi c 2^-11
+                        }
+                    }
+                }
+            }
+        }
     }
 
     // ---- LDS fragment addresses ---------------------------------------------------------------------------------------------
@@ -161,40 +230,88 @@ __global__ __launch_bounds__(256, 2) void attn_kernel(const vbg_attn_desc p) {
     }
     constexpr int qa[6] = {2, 0, 1, 1, 0, 0}, qb[6] = {0, 2, 1, 0, 1, 0};       // piece products, smallest first
     // score-type product: D[streamed row][own row] += X_stream[row][:] . X_own[row][:]
-    auto sprod = [&](const unsigned char* img, const at_u32x4 (&sb)[3][4], f32x16& acc) {
+    // the piece products of one k-step, smallest first, into ONE accumulator (FORM 1: the stationary side carries the 2^-11)
+    auto sp3 = [&](const at_u32x4 (&fa)[NP], const at_u32x4 (&sb)[NST][4], int ks, f32x16& acc, int first, int last) {
+        if constexpr (FORM == 0) {
+#pragma unroll
+            for (int t = 0; t < 6; ++t) if (t >= first && t < last) acc = AT_MFMA(fa[qa[t]], sb[qb[t]][ks], acc);
+        } else if constexpr (FORM == 1) {
+            if (first <= 0 && 0 < last) acc = AT_MFMA_H(fa[1], sb[2][ks], acc);
+            if (first <= 1 && 1 < last) acc = AT_MFMA_H(fa[0], sb[1][ks], acc);
+            if (first <= 2 && 2 < last) acc = AT_MFMA_H(fa[0], sb[0][ks], acc);
+        } else {
+            if (first <= 0 && 0 < last) acc = AT_MFMA_H(fa[0], sb[0][ks], acc);
+        }
+    };
+    auto sprod = [&](const unsigned char* img, const at_u32x4 (&sb)[NST][4], f32x16& acc) {
 #pragma unroll
         for (int ks = 0; ks < 4; ++ks) {
-            at_u32x4 fa[3];
+            at_u32x4 fa[NP];
 #pragma unroll
-            for (int q = 0; q < 3; ++q) fa[q] = *reinterpret_cast<const at_u32x4*>(img + q * AT_PL + fra[ks]);
-#pragma unroll
-            for (int t = 0; t < 6; ++t) acc = AT_MFMA(fa[qa[t]], sb[qb[t]][ks], acc);
+            for (int q = 0; q < NP; ++q) fa[q] = *reinterpret_cast<const at_u32x4*>(img + q * AT_PL + fra[ks]);
+            sp3(fa, sb, ks, acc, 0, 6);
         }
     };
     // second product: D[column d of the streamed operand][own row] += sum over streamed rows X_stream[row][d] E[row][own row]
-    auto tprod = [&](const unsigned char* img, const at_u32x4 (&bp)[3][2], f32x16 (&acc)[2]) {
-        typedef __attribute__((address_space(3))) unsigned char* lds_bytes;
+    // fragments of the streamed operand for the second product, group g = 2 ks + db: the NP planes by transposing reads, used as they lie
+    constexpr int NF = NP;
+    typedef __attribute__((address_space(3))) unsigned char* lds_bytes;
+    auto trd = [&](lds_bytes im, int g, at_u32x4 (&f)[NF]) {
+        const int ks = g >> 1, db = g & 1;
+#pragma unroll
+        for (int q = 0; q < NP; ++q) {
+            const at_v4s lo = __builtin_amdgcn_ds_read_tr16_b64_v4i16((at_lds_v4s)(im + q * AT_PL + ks * 2048 + tra[0][db]));
+            const at_v4s hi = __builtin_amdgcn_ds_read_tr16_b64_v4i16((at_lds_v4s)(im + q * AT_PL + ks * 2048 + tra[1][db]));
+            const uint2 l2 = __builtin_bit_cast(uint2, lo), h2 = __builtin_bit_cast(uint2, hi);
+            f[q] = at_u32x4{l2.x, l2.y, h2.x, h2.y};
+        }
+    };
+    // FORM 1: the two cross products of the SECOND product go into accumulators of their own (`ax`, zero at the start of every tile's
+    // product and folded into the main ones times 2^-11 behind it): the main accumulators run over up to 512 streamed rows and the matrix
+    // pipe aligns the 16 products of an instruction to the accumulator it adds them to -- cross products 2^-12 of a main product and
+    // 2^-21 of the running sum arrived with one or two bits (measured: switching them off changed O by 1e-6 of an error of 2.4e-4).
+    // Over one tile the cross sums are of the size of their own terms.  (The score-type products reduce over 64 columns only: there the
+    // one accumulator with the folded 2^-11 is accurate, lse to 8e-7.)
+    auto tp3 = [&](const at_u32x4 (&fa)[NF], const at_u32x4 (&bp)[NE][2], int ks, f32x16& acc, f32x16& ax, int first, int last) {
+        if constexpr (FORM == 0) {
+#pragma unroll
+            for (int t = 0; t < 6; ++t) if (t >= first && t < last) acc = AT_MFMA(fa[qa[t]], bp[qb[t]][ks], acc);
+        } else if constexpr (FORM == 1) {
+            if (first <= 0 && 0 < last) ax = AT_MFMA_H(fa[1], bp[0][ks], ax);             // lo' x hi
+            if (first <= 1 && 1 < last) ax = AT_MFMA_H(fa[0], bp[1][ks], ax);             // hi x lo'
+            if (first <= 2 && 2 < last) acc = AT_MFMA_H(fa[0], bp[0][ks], acc);           // hi x hi
+        } else {
+            if (first <= 0 && 0 < last) acc = AT_MFMA_H(fa[0], bp[0][ks], acc);
+        }
+    };
+    auto tfold = [&](f32x16 (&acc)[2], const f32x16 (&ax)[FORM == 1 ? 2 : 1]) {
+        if constexpr (FORM == 1) {
+#pragma unroll
+            for (int db = 0; db < 2; ++db)
+#pragma unroll
+                for (int r = 0; r < 16; ++r) acc[db][r] = fmaf(ax[db][r], 0.00048828125f, acc[db][r]);
+        }
+    };
+    auto tprod = [&](const unsigned char* img, const at_u32x4 (&bp)[NE][2], f32x16 (&acc)[2]) {
         lds_bytes im = (lds_bytes)img;
+        f32x16 ax[FORM == 1 ? 2 : 1];
+        if constexpr (FORM == 1) {
 #pragma unroll
-        for (int ks = 0; ks < 2; ++ks)
+            for (int db = 0; db < 2; ++db)
 #pragma unroll
-            for (int db = 0; db < 2; ++db) {
-                at_u32x4 fa[3];
+                for (int r = 0; r < 16; ++r) ax[db][r] = 0.f;
+        }
 #pragma unroll
-                for (int q = 0; q < 3; ++q) {
-                    const at_v4s lo = __builtin_amdgcn_ds_read_tr16_b64_v4i16((at_lds_v4s)(im + q * AT_PL + ks * 2048 + tra[0][db]));
-                    const at_v4s hi = __builtin_amdgcn_ds_read_tr16_b64_v4i16((at_lds_v4s)(im + q * AT_PL + ks * 2048 + tra[1][db]));
-                    const uint2 l2 = __builtin_bit_cast(uint2, lo), h2 = __builtin_bit_cast(uint2, hi);
-                    fa[q] = at_u32x4{l2.x, l2.y, h2.x, h2.y};
-                }
-#pragma unroll
-                for (int t = 0; t < 6; ++t) acc[db] = AT_MFMA(fa[qa[t]], bp[qb[t]][ks], acc[db]);
-            }
+        for (int g = 0; g < 4; ++g) {
+            at_u32x4 fa[NF];
+            trd(im, g, fa);
+            tp3(fa, bp, g >> 1, acc[g & 1], ax[FORM == 1 ? (g & 1) : 0], 0, 6);
+        }
+        if constexpr (FORM == 1) tfold(acc, ax);
     };
 
     // low-precision companion of tprod (first plane of both operands only): the forward's Kbar^T += K^T P^T
     auto kprod = [&](const unsigned char* img, const at_u32x4 (&bh)[2], f32x16 (&acc)[2]) {
-        typedef __attribute__((address_space(3))) unsigned char* lds_bytes;
         lds_bytes im = (lds_bytes)img;
 #pragma unroll
         for (int ks = 0; ks < 2; ++ks)
@@ -204,7 +321,8 @@ __global__ __launch_bounds__(256, 2) void attn_kernel(const vbg_attn_desc p) {
                 const at_v4s hi = __builtin_amdgcn_ds_read_tr16_b64_v4i16((at_lds_v4s)(im + ks * 2048 + tra[1][db]));
                 const uint2 l2 = __builtin_bit_cast(uint2, lo), h2 = __builtin_bit_cast(uint2, hi);
                 const at_u32x4 fa = at_u32x4{l2.x, l2.y, h2.x, h2.y};
-                acc[db] = AT_MFMA(fa, bh[ks], acc[db]);
+                if constexpr (FORM == 0) acc[db] = AT_MFMA(fa, bh[ks], acc[db]);
+                else acc[db] = AT_MFMA_H(fa, bh[ks], acc[db]);
             }
     };
 
@@ -213,63 +331,99 @@ __global__ __launch_bounds__(256, 2) void attn_kernel(const vbg_attn_desc p) {
     // pipe for 32 clocks, ~25 VALU instructions of a pair fit behind three of them.  (hipcc's own schedule puts the ~200 VALU
     // instructions of a tile in one block between the products; with one wave per SIMD nothing then overlaps the matrix pipe.)
     // Fragments are read one group ahead.
-    auto sprod_woven = [&](const unsigned char* img, const at_u32x4 (&sb)[3][4], f32x16& acc, auto&& work) {
-        at_u32x4 fa[2][3];
+    // (the six / three / one piece products of a k-step are cut in two groups with a slot for element-wise work behind each)
+    constexpr int NPR = FORM == 0 ? 6 : (FORM == 1 ? 3 : 1), CUT = FORM == 0 ? 3 : (FORM == 1 ? 2 : 1);
+    auto sprod_woven = [&](const unsigned char* img, const at_u32x4 (&sb)[NST][4], f32x16& acc, auto&& work) {
+        at_u32x4 fa[2][NP];
 #pragma unroll
-        for (int q = 0; q < 3; ++q) fa[0][q] = *reinterpret_cast<const at_u32x4*>(img + q * AT_PL + fra[0]);
+        for (int q = 0; q < NP; ++q) fa[0][q] = *reinterpret_cast<const at_u32x4*>(img + q * AT_PL + fra[0]);
 #pragma unroll
         for (int ks = 0; ks < 4; ++ks) {
             if (ks + 1 < 4) {
 #pragma unroll
-                for (int q = 0; q < 3; ++q) fa[(ks + 1) & 1][q] = *reinterpret_cast<const at_u32x4*>(img + q * AT_PL + fra[ks + 1]);
+                for (int q = 0; q < NP; ++q) fa[(ks + 1) & 1][q] = *reinterpret_cast<const at_u32x4*>(img + q * AT_PL + fra[ks + 1]);
             }
-#pragma unroll
-            for (int hf = 0; hf < 2; ++hf) {
-#pragma unroll
-                for (int t = 3 * hf; t < 3 * hf + 3; ++t) acc = AT_MFMA(fa[ks & 1][qa[t]], sb[qb[t]][ks], acc);
-                __builtin_amdgcn_sched_barrier(0);
-                work(2 * ks + hf);
-                __builtin_amdgcn_sched_barrier(0);
-            }
+            sp3(fa[ks & 1], sb, ks, acc, 0, CUT);
+            __builtin_amdgcn_sched_barrier(0);
+            work(2 * ks);
+            __builtin_amdgcn_sched_barrier(0);
+            sp3(fa[ks & 1], sb, ks, acc, CUT, NPR);
+            __builtin_amdgcn_sched_barrier(0);
+            work(2 * ks + 1);
+            __builtin_amdgcn_sched_barrier(0);
         }
     };
-    auto tprod_woven = [&](const unsigned char* img, const at_u32x4 (&bp)[3][2], f32x16 (&acc)[2], auto&& work) {
-        typedef __attribute__((address_space(3))) unsigned char* lds_bytes;
+    auto tprod_woven = [&](const unsigned char* img, const at_u32x4 (&bp)[NE][2], f32x16 (&acc)[2], auto&& work) {
         lds_bytes im = (lds_bytes)img;
-        at_u32x4 fa[2][3];
-        auto rd = [&](int g, at_u32x4 (&f)[3]) {                       // group g = 2 ks + db
-            const int ks = g >> 1, db = g & 1;
+        at_u32x4 fa[2][NF];
+        f32x16 ax[FORM == 1 ? 2 : 1];
+        if constexpr (FORM == 1) {
 #pragma unroll
-            for (int q = 0; q < 3; ++q) {
-                const at_v4s lo = __builtin_amdgcn_ds_read_tr16_b64_v4i16((at_lds_v4s)(im + q * AT_PL + ks * 2048 + tra[0][db]));
-                const at_v4s hi = __builtin_amdgcn_ds_read_tr16_b64_v4i16((at_lds_v4s)(im + q * AT_PL + ks * 2048 + tra[1][db]));
-                const uint2 l2 = __builtin_bit_cast(uint2, lo), h2 = __builtin_bit_cast(uint2, hi);
-                f[q] = at_u32x4{l2.x, l2.y, h2.x, h2.y};
-            }
-        };
-        rd(0, fa[0]);
+            for (int db = 0; db < 2; ++db)
+#pragma unroll
+                for (int r = 0; r < 16; ++r) ax[db][r] = 0.f;
+        }
+        trd(im, 0, fa[0]);
 #pragma unroll
         for (int g = 0; g < 4; ++g) {
-            if (g + 1 < 4) rd(g + 1, fa[(g + 1) & 1]);
-#pragma unroll
-            for (int hf = 0; hf < 2; ++hf) {
-#pragma unroll
-                for (int t = 3 * hf; t < 3 * hf + 3; ++t) acc[g & 1] = AT_MFMA(fa[g & 1][qa[t]], bp[qb[t]][g >> 1], acc[g & 1]);
-                __builtin_amdgcn_sched_barrier(0);
-                work(2 * g + hf);
-                __builtin_amdgcn_sched_barrier(0);
+            if (g + 1 < 4) trd(im, g + 1, fa[(g + 1) & 1]);
+            tp3(fa[g & 1], bp, g >> 1, acc[g & 1], ax[FORM == 1 ? (g & 1) : 0], 0, CUT);
+            __builtin_amdgcn_sched_barrier(0);
+            work(2 * g);
+            __builtin_amdgcn_sched_barrier(0);
+            tp3(fa[g & 1], bp, g >> 1, acc[g & 1], ax[FORM == 1 ? (g & 1) : 0], CUT, NPR);
+            __builtin_amdgcn_sched_barrier(0);
+            work(2 * g + 1);
+            __builtin_amdgcn_sched_barrier(0);
+        }
+        if constexpr (FORM == 1) tfold(acc, ax);
+    };
+    // exact three-way split of the register pair (2 pi, 2 pi + 1) into its slot of the B-operand fragments (as at_split16)
+    auto split_pair = [&](float a, float b, int pi, at_u32x4 (&bp)[NE][2]) {
+        if constexpr (FORM == 0) {
+            const float ra = a - __uint_as_float(__float_as_uint(a) & 0xffff0000u), rb = b - __uint_as_float(__float_as_uint(b) & 0xffff0000u);
+            const float sa = ra - __uint_as_float(__float_as_uint(ra) & 0xffff0000u), sb2 = rb - __uint_as_float(__float_as_uint(rb) & 0xffff0000u);
+            bp[0][pi >> 2][pi & 3] = __builtin_amdgcn_perm(__float_as_uint(b), __float_as_uint(a), 0x07060302u);
+            bp[1][pi >> 2][pi & 3] = __builtin_amdgcn_perm(__float_as_uint(rb), __float_as_uint(ra), 0x07060302u);
+            bp[2][pi >> 2][pi & 3] = __builtin_amdgcn_perm(__float_as_uint(sb2), __float_as_uint(sa), 0x07060302u);
+        } else {                                    // fp16 pieces of values the caller scaled to the top of fp16's range; FORM 2: the hi piece
+            const at_h2 h = __builtin_convertvector((at_f2){a, b}, at_h2);
+            bp[0][pi >> 2][pi & 3] = __builtin_bit_cast(unsigned, h);
+            if constexpr (FORM == 1) {
+                const at_f2 hf = __builtin_convertvector(h, at_f2);
+                bp[1][pi >> 2][pi & 3] = __builtin_bit_cast(unsigned, __builtin_convertvector((at_f2){(a - hf.x) * 2048.f, (b - hf.y) * 2048.f}, at_h2));      // lo' = remainder 2^11
             }
         }
     };
-    // exact three-way split of the register pair (2 pi, 2 pi + 1) into its slot of the B-operand fragments (as at_split16)
-    auto split_pair = [&](float a, float b, int pi, at_u32x4 (&bp)[3][2]) {
-        const float ra = a - __uint_as_float(__float_as_uint(a) & 0xffff0000u), rb = b - __uint_as_float(__float_as_uint(b) & 0xffff0000u);
-        const float sa = ra - __uint_as_float(__float_as_uint(ra) & 0xffff0000u), sb2 = rb - __uint_as_float(__float_as_uint(rb) & 0xffff0000u);
-        bp[0][pi >> 2][pi & 3] = __builtin_amdgcn_perm(__float_as_uint(b), __float_as_uint(a), 0x07060302u);
-        bp[1][pi >> 2][pi & 3] = __builtin_amdgcn_perm(__float_as_uint(rb), __float_as_uint(ra), 0x07060302u);
-        bp[2][pi >> 2][pi & 3] = __builtin_amdgcn_perm(__float_as_uint(sb2), __float_as_uint(sa), 0x07060302u);
+    auto split16 = [&](const float (&x)[16], at_u32x4 (&bp)[NE][2]) {
+#pragma unroll
+        for (int pi = 0; pi < 8; ++pi) split_pair(x[2 * pi], x[2 * pi + 1], pi, bp);
     };
-
+    // scale of dO's planes: the power of two its producer derived from the amax slot (FORM 0 planes are exact: 1)
+    float dinv = 1.f;
+    if constexpr (!FWD && FORM != 0) {
+        if (p.do_amax) dinv = vbg_pow2_scale(vbg_amax_read(p.do_amax)).y;
+    }
+    // running per-lane scale of the score gradients as a register operand (FORM 1 / 2): the power of two that brings the largest BOUND
+    // seen so far to [2^13, 2^14); esc = 0: no tile yet
+    float esc = 0.f, bmax = 0.f;
+    auto ds_scale = [&](float bound, f32x16 (&acc)[2]) {                 // bound >= every |dS| of this lane in this tile (both half-waves)
+        bound = fmaxf(bound, __shfl_xor(bound, 32, 64));
+        if (bound > bmax) {
+            bmax = bound;
+            const float ne = vbg_pow2_scale(__float_as_uint(bound)).x;
+            if (ne != esc) {
+                if (esc != 0.f) {
+                    const float f = ne / esc;                            // (a power of two: exact)
+#pragma unroll
+                    for (int db = 0; db < 2; ++db)
+#pragma unroll
+                        for (int r = 0; r < 16; ++r) acc[db][r] *= f;
+                }
+                esc = ne;
+            }
+        }
+    };
     f32x16 acc0[2], acc1[2];                     // FWD: O^T, Kbar^T; DQ: dQ^T; DKV: dK^T (acc0), dV^T (acc1)
 #pragma unroll
     for (int db = 0; db < 2; ++db)
@@ -294,15 +448,25 @@ __global__ __launch_bounds__(256, 2) void attn_kernel(const vbg_attn_desc p) {
                 const float ov[8] = {o0.x, o0.y, o0.z, o0.w, o1.x, o1.y, o1.z, o1.w};
 #pragma unroll
                 for (int j = 0; j < 4; ++j) {
-                    const unsigned h = st[1][0][ks][j], m = st[1][1][ks][j], l = st[1][2][ks][j];
-                    const float lo_e = (__uint_as_float(h << 16) + __uint_as_float(m << 16)) + __uint_as_float(l << 16);
-                    const float hi_e = (__uint_as_float(h & 0xffff0000u) + __uint_as_float(m & 0xffff0000u)) + __uint_as_float(l & 0xffff0000u);
+                    float lo_e, hi_e;
+                    if constexpr (FORM == 0) {
+                        const unsigned h = st[1][0][ks][j], m = st[1][1][ks][j], l = st[1][2][ks][j];
+                        lo_e = (__uint_as_float(h << 16) + __uint_as_float(m << 16)) + __uint_as_float(l << 16);
+                        hi_e = (__uint_as_float(h & 0xffff0000u) + __uint_as_float(m & 0xffff0000u)) + __uint_as_float(l & 0xffff0000u);
+                    } else {                      // dO 2^e = hi + lo' 2^-11 (FORM 2: the hi piece alone is what the products see)
+                        const unsigned h = dhi[ks][j];
+                        lo_e = at_hlo(h); hi_e = at_hhi(h);
+                        if constexpr (FORM == 1) {
+                            lo_e = fmaf(at_hlo(dlo[ks][j]), 0.00048828125f, lo_e);
+                            hi_e = fmaf(at_hhi(dlo[ks][j]), 0.00048828125f, hi_e);
+                        }
+                    }
                     del_own = fmaf(lo_e, ov[2 * j], del_own);
                     del_own = fmaf(hi_e, ov[2 * j + 1], del_own);
                 }
             }
         }
-        del_own += __shfl_xor(del_own, 32, 64);
+        del_own = (del_own + __shfl_xor(del_own, 32, 64)) * dinv;          // (FORM 1 / 2: dO's planes carry the scale 2^e)
     }
     const float scale = p.scale, keep_scale = p.keep_scale;
     const bool want_kbar = FWD && p.kbar != nullptr;
@@ -345,7 +509,7 @@ __global__ __launch_bounds__(256, 2) void attn_kernel(const vbg_attn_desc p) {
             if constexpr (FWD) {
                 float x[16];
 #pragma unroll
-                for (int r = 0; r < 16; ++r) x[r] = s[r] * scale;
+                for (int r = 0; r < 16; ++r) x[r] = s[r] * (scale * cinv[0]);
                 if (t * 32 + 32 > L) {
 #pragma unroll
                     for (int r = 0; r < 16; ++r)
@@ -375,16 +539,21 @@ __global__ __launch_bounds__(256, 2) void attn_kernel(const vbg_attn_desc p) {
 #pragma unroll
                     for (int ks = 0; ks < 2; ++ks)
 #pragma unroll
-                        for (int j = 0; j < 4; ++j)
-                            bh[ks][j] = __builtin_amdgcn_perm(__float_as_uint(x[8 * ks + 2 * j + 1]), __float_as_uint(x[8 * ks + 2 * j]), 0x07060302u);
+                        for (int j = 0; j < 4; ++j) {
+                            if constexpr (FORM == 0) bh[ks][j] = __builtin_amdgcn_perm(__float_as_uint(x[8 * ks + 2 * j + 1]), __float_as_uint(x[8 * ks + 2 * j]), 0x07060302u);
+                            else bh[ks][j] = __builtin_bit_cast(unsigned, __builtin_convertvector((at_f2){x[8 * ks + 2 * j], x[8 * ks + 2 * j + 1]}, at_h2));
+                        }
                     kprod(im0, bh, acc1);
                 }
                 if constexpr (DROP) {
 #pragma unroll
-                    for (int r = 0; r < 16; ++r) x[r] = ((mw >> ((r & 3) + 8 * (r >> 2))) & 1u) ? x[r] * keep_scale : 0.f;
+                    for (int r = 0; r < 16; ++r) x[r] = ((mw >> ((r & 3) + 8 * (r >> 2))) & 1u) ? x[r] * (keep_scale * ESC) : 0.f;
+                } else if constexpr (FORM != 0) {
+#pragma unroll
+                    for (int r = 0; r < 16; ++r) x[r] *= ESC;
                 }
-                at_u32x4 bp[3][2];
-                at_split16(x, bp);
+                at_u32x4 bp[NE][2];
+                split16(x, bp);
                 tprod(im1, bp, acc0);
             } else {
                 f32x16 dp;
@@ -393,24 +562,32 @@ __global__ __launch_bounds__(256, 2) void attn_kernel(const vbg_attn_desc p) {
                 float pr[16], ds[16];
                 if constexpr (DQ) {
 #pragma unroll
-                    for (int r = 0; r < 16; ++r) pr[r] = __expf(s[r] * scale - m_own) * il_own;
+                    for (int r = 0; r < 16; ++r) pr[r] = __expf(s[r] * (scale * cinv[0]) - m_own) * il_own;
                     sprod(im1, st[1], dp);
+                    const float dmul = dinv * cinv[1];
+                    float gmax = 0.f;
 #pragma unroll
                     for (int r = 0; r < 16; ++r) {
-                        float g = dp[r];
+                        float g = dp[r] * dmul;
                         if constexpr (DROP) g = ((mw >> ((r & 3) + 8 * (r >> 2))) & 1u) ? g * keep_scale : 0.f;
                         ds[r] = pr[r] * (g - del_own);
                         dsum = fmaf(pr[r], g, dsum);
+                        gmax = fmaxf(gmax, fabsf(g));
                     }
-                    at_u32x4 bp[3][2];
-                    at_split16(ds, bp);
+                    if constexpr (FORM != 0) {                           // |dS| <= |g| + |delta| (P <= 1): the lane's scale before the values exist
+                        ds_scale(gmax + fabsf(del_own), acc0);
+#pragma unroll
+                        for (int r = 0; r < 16; ++r) ds[r] *= esc;
+                    }
+                    at_u32x4 bp[NE][2];
+                    split16(ds, bp);
                     tprod(im0, bp, acc0);                                  // dQ^T += K^T dS^T
                 } else {
                     // statistics of the streamed queries: register r = query 8 (r >> 2) + 4 lh + (r & 3) of the tile (loaded an
                     // iteration ahead: a use of a fresh global load in here would drain the tile DMA in flight)
                     // Phase A: P, its dropped / scaled form and the split of that only need S -> woven into the dP product.
                     float pv[16];
-                    at_u32x4 bpv[3][2], bpk[3][2];
+                    at_u32x4 bpv[NE][2], bpk[NE][2];
                     sprod_woven(im1, st[1], dp, [&](int pi) {
                         // registers 2 pi, 2 pi + 1 = queries 8 (pi >> 1) + 2 (pi & 1) (+ 1) of this half-wave's rows
                         const float2 mq = *reinterpret_cast<const float2*>(stile + 8 * (pi >> 1) + 2 * (pi & 1));
@@ -419,12 +596,26 @@ __global__ __launch_bounds__(256, 2) void attn_kernel(const vbg_attn_desc p) {
 #pragma unroll
                         for (int e = 0; e < 2; ++e) {
                             const int r = 2 * pi + e;
-                            pv[r] = __expf(s[r] * scale - (e ? mq.y : mq.x)) * (e ? iq.y : iq.x);
-                            pd[e] = pv[r];
-                            if constexpr (DROP) pd[e] = ((mw >> ((r & 3) + 8 * (r >> 2))) & 1u) ? pv[r] * keep_scale : 0.f;
+                            pv[r] = __expf(s[r] * (scale * cinv[0]) - (e ? mq.y : mq.x)) * (e ? iq.y : iq.x);
+                            pd[e] = pv[r] * ESC;
+                            if constexpr (DROP) pd[e] = ((mw >> ((r & 3) + 8 * (r >> 2))) & 1u) ? pv[r] * (keep_scale * ESC) : 0.f;
                         }
                         split_pair(pd[0], pd[1], pi, bpv);
                     });
+                    const float dmul = dinv * cinv[1];
+                    if constexpr (FORM != 0) {
+                        // the lane's scale of dS from a bound: |dS| <= max |dP| keep_scale + max |delta| over the tile's queries (P <= 1)
+                        float gmax = 0.f, dmax = 0.f;
+#pragma unroll
+                        for (int r = 0; r < 16; ++r) gmax = fmaxf(gmax, fabsf(dp[r]));
+#pragma unroll
+                        for (int pi = 0; pi < 8; ++pi) {
+                            const float2 dq = *reinterpret_cast<const float2*>(stile + 1024 + 8 * (pi >> 1) + 2 * (pi & 1));
+                            dmax = fmaxf(dmax, fmaxf(fabsf(dq.x), fabsf(dq.y)));
+                        }
+                        ds_scale(gmax * (dmul * keep_scale) + dmax, acc0);
+                    }
+                    const float dse = FORM == 0 ? 1.f : esc;
                     // Phase B: dS and its split need dP -> woven into the dV product
                     tprod_woven(im1, bpv, acc1, [&](int pi) {                                 // dV^T += dO^T Pd
                         const float2 dq = *reinterpret_cast<const float2*>(stile + 1024 + 8 * (pi >> 1) + 2 * (pi & 1));
@@ -432,9 +623,9 @@ __global__ __launch_bounds__(256, 2) void attn_kernel(const vbg_attn_desc p) {
 #pragma unroll
                         for (int e = 0; e < 2; ++e) {
                             const int r = 2 * pi + e;
-                            float g = dp[r];
+                            float g = dp[r] * dmul;
                             if constexpr (DROP) g = ((mw >> ((r & 3) + 8 * (r >> 2))) & 1u) ? g * keep_scale : 0.f;
-                            dsv[e] = pv[r] * (g - (e ? dq.y : dq.x));
+                            dsv[e] = pv[r] * (g - (e ? dq.y : dq.x)) * dse;
                         }
                         split_pair(dsv[0], dsv[1], pi, bpk);
                     });
@@ -446,6 +637,8 @@ __global__ __launch_bounds__(256, 2) void attn_kernel(const vbg_attn_desc p) {
         __builtin_amdgcn_s_barrier();
     }
 
+    // (FORM 1 / 2: the score-gradient accumulators carry this lane's running scale; no tile seen: they are zero)
+    const float dsi = (FORM == 0 || FWD) ? 1.f : (esc != 0.f ? 1.f / esc : 0.f);
     // ---- epilogue: accumulators are [d][own row]: lane = own row writes 4 consecutive d per register quad -------------------
     const bool live = active && own0 + lr < L;
     if (FWD || !p.out_amax) { if (!live) return; }             // (backward with out_amax: every lane stays for the wave's maximum)
@@ -464,7 +657,8 @@ __global__ __launch_bounds__(256, 2) void attn_kernel(const vbg_attn_desc p) {
     };
     if constexpr (FWD) {
         const float lt = l_run + __shfl_xor(l_run, 32, 64);
-        const float il = 1.0f / lt;
+        const float ilk = 1.0f / lt;                 // of Kbar (its probabilities were not scaled)
+        const float il = ilk * IESC;                 // of O: the probabilities entered the second product times ESC
         store(acc0, il, head * 64, p.out);
         if (p.out_planes) {                           // exact three-way split of the stored values, 4 bf16 (8 bytes) per plane and quad
             unsigned short* pr0 = p.out_planes + (long long)(row0 + own0 + lr) * p.op_ld + head * 64;
@@ -505,8 +699,8 @@ __global__ __launch_bounds__(256, 2) void attn_kernel(const vbg_attn_desc p) {
                     *reinterpret_cast<uint2*>(o + p.oq_plane) = make_uint2(__builtin_bit_cast(unsigned, l0), __builtin_bit_cast(unsigned, l1));
                 }
         }
-        if (want_kbar) store(acc1, il, head * 64, p.kbar + krow - orow);
-        if (lh == 0) { p.lse[lsoff + own0 + lr] = m_run; p.lse[lsplane + lsoff + own0 + lr] = il; }
+        if (want_kbar) store(acc1, ilk, head * 64, p.kbar + krow - orow);
+        if (lh == 0) { p.lse[lsoff + own0 + lr] = m_run; p.lse[lsplane + lsoff + own0 + lr] = ilk; }
     } else if constexpr (DQ) {
       if (live) {
         // delta = rowsum(dO o O) carries the accumulated rounding of O as an error COMMON to the whole row, which the key
@@ -520,15 +714,16 @@ __global__ __launch_bounds__(256, 2) void attn_kernel(const vbg_attn_desc p) {
 #pragma unroll
             for (int j = 0; j < 4; ++j) {
                 const float4 kb = *reinterpret_cast<const float4*>(p.kbar + krow + head * 64 + db * 32 + 8 * j + 4 * lh);
-                acc0[db][4 * j] -= c * kb.x; acc0[db][4 * j + 1] -= c * kb.y; acc0[db][4 * j + 2] -= c * kb.z; acc0[db][4 * j + 3] -= c * kb.w;
+                acc0[db][4 * j] = acc0[db][4 * j] * dsi - c * kb.x; acc0[db][4 * j + 1] = acc0[db][4 * j + 1] * dsi - c * kb.y;
+                acc0[db][4 * j + 2] = acc0[db][4 * j + 2] * dsi - c * kb.z; acc0[db][4 * j + 3] = acc0[db][4 * j + 3] * dsi - c * kb.w;
             }
         store(acc0, scale, head * 64, p.out);
         if (lh == 0) p.delta[lsoff + own0 + lr] = dnew;
       }
     } else {
       if (live) {
-        store(acc0, scale, hid + head * 64, p.out);
-        store(acc1, 1.0f, 2 * hid + head * 64, p.out);
+        store(acc0, scale * dsi, hid + head * 64, p.out);
+        store(acc1, dinv * IESC, 2 * hid + head * 64, p.out);
       }
     }
     if constexpr (!FWD) {
@@ -594,7 +789,7 @@ using namespace vbg;
 extern "C" int vbg_attn(const vbg_attn_desc* desc, void* stream) {
     VBG_CHECK_ARG(desc != nullptr);
     const vbg_attn_desc& d = *desc;
-    VBG_CHECK_ARG(d.mode >= VBG_ATTN_FWD && d.mode <= VBG_ATTN_DKV && d.heads > 0 && d.ntasks >= 0);
+    VBG_CHECK_ARG(d.mode >= VBG_ATTN_FWD && d.mode <= VBG_ATTN_DKV && d.heads > 0 && d.ntasks >= 0 && d.form >= 0 && d.form <= 2);
     if (d.ntasks == 0) return VBG_OK;
     VBG_CHECK_ARG(d.tasks && d.seq_len && d.seq_row0 && d.pad_off && d.qkv && d.out && d.lse);
     VBG_CHECK_ARG(d.qkv_ld % 8 == 0 && ((uintptr_t)d.qkv & 15) == 0 && d.qkv_plane % 8 == 0 && 6 * d.qkv_plane < 0x7fffffffll);
@@ -613,15 +808,22 @@ extern "C" int vbg_attn(const vbg_attn_desc* desc, void* stream) {
     hipStream_t s = (hipStream_t)stream;
     const dim3 g(d.ntasks, d.heads), b(256);
     (void)hipGetLastError();
+#define AT_GO2(M, F)                                                                                  \
+    do {                                                                                              \
+        if (drop) hipLaunchKernelGGL((attn_kernel<M, true, F>), g, b, 0, s, d);                       \
+        else hipLaunchKernelGGL((attn_kernel<M, false, F>), g, b, 0, s, d);                           \
+    } while (0)
 #define AT_GO(M)                                                                                      \
     do {                                                                                              \
-        if (drop) hipLaunchKernelGGL((attn_kernel<M, true>), g, b, 0, s, d);                          \
-        else hipLaunchKernelGGL((attn_kernel<M, false>), g, b, 0, s, d);                              \
+        if (d.form == 0) AT_GO2(M, 0);                                                                \
+        else if (d.form == 1) AT_GO2(M, 1);                                                           \
+        else AT_GO2(M, 2);                                                                            \
     } while (0)
     if (d.mode == VBG_ATTN_FWD) AT_GO(VBG_ATTN_FWD);
     else if (d.mode == VBG_ATTN_DQ) AT_GO(VBG_ATTN_DQ);
     else AT_GO(VBG_ATTN_DKV);
 #undef AT_GO
+#undef AT_GO2
     VBG_LAUNCH_RET();
 }
 

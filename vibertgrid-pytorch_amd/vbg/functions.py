@@ -637,8 +637,6 @@ class BertLayerFn(torch.autograd.Function):
         px = pctx = px1 = pg = pqkv = qkv = P = lse = masks = kbar = None
         if not flash:
             qkv = torch.empty((ntok, 3 * hid), device=dev, dtype=f32)
-        else:                      # q, k, v leave the projection as planes only: the fused attention kernels' operands
-            pqkv = ops.planes_empty(ntok, 3 * hid, dev)
         # forward products whose operands are LayerNorm / GELU outputs and weights run on two fp16 pieces per operand (three piece
         # products, csrc/gemm_planes.hip FORM 1) once the problem fills the 8-wave tiles; the pair planes of x arrive as an attribute of
         # the previous layer's bf16 planes (written by its closing LayerNorm)
@@ -654,12 +652,19 @@ class BertLayerFn(torch.autograd.Function):
         assert not carrier_is_pair or pair, "pair planes handed to a layer that does not run the pair form"
         if pair_bwd and xq is None:
             xq = ops.split_planes_pair(x)
+        # q, k, v leave the projection as planes only (the fused attention kernels' operands): fp16-pair planes when the projection runs
+        # the pair form and the backward that follows is the all-pair one (round 5: the attention then runs three fp16 piece products per
+        # product, csrc/attn.hip FORM 1), three bf16 planes otherwise
+        attn_pair = (flash and pair and fused_qkv and xq is not None and ops.attn_pair_enabled() and ops.bound_planes_enabled()
+                     and (pair_bwd or not any(ctx.needs_input_grad)))
+        if flash:
+            pqkv = ops.pair_empty(ntok, 3 * hid, dev) if attn_pair else ops.planes_empty(ntok, 3 * hid, dev)
         if planes:                 # operands split into bf16 planes once (csrc/gemm_planes.hip), weights once per optimizer step
             if not pair_bwd:           # (the bf16 planes of x: the QKV product's operand without the pair form, and its weight gradient's)
                 px = ops.Planes(xpl, ntok, hid, xpl.shape[2]) if (xpl is not None and not carrier_is_pair) else ops.split_planes(x)
             if fused_qkv and xq is not None:
-                ops.plane_gemm(xq, ops.weight_planes(wq, view=_stack3(wq), also=(wk, wv), pair=True), qkv, bias=_stack3(bq), out_planes=pqkv,
-                               tile=ops.pair_tile(ntok, 3 * hid), form=1)
+                ops.plane_gemm(xq, ops.weight_planes(wq, view=_stack3(wq), also=(wk, wv), pair=True), qkv, bias=_stack3(bq),
+                               out_planes=None if attn_pair else pqkv, out_pair=pqkv if attn_pair else None, tile=ops.pair_tile(ntok, 3 * hid), form=1)
             elif fused_qkv:
                 ops.plane_gemm(px, ops.weight_planes(wq, view=_stack3(wq), also=(wk, wv)), qkv, bias=_stack3(bq), out_planes=pqkv,
                                tile=ops._dense_tile(ntok, 3 * hid))
@@ -841,16 +846,25 @@ class BertLayerFn(torch.autograd.Function):
             del dao
         dg1, db1 = _affine_done(rg1, rb1, dg1, db1, sunk1)
         wgrad_done(rbo)
-        # ---- d(context): fp32 + bf16 planes (the dO operand of the fused attention backward, which stays on the six-product form)
-        pdctx = ops.planes_empty(ntok, hid, dev)
-        ops.plane_gemm(qdao, ops.weight_planes(ro, True, view=wo, pair=True), None, out_planes=pdctx, tile=tile(hid), form=1, a_amax=s_dao_ref)
+        # ---- d(context), the dO operand of the fused attention backward: as the planes the forward's q / k / v planes call for -- fp16-pair
+        #      planes scaled by a bound (max |dao| x the largest column L1 norm of W_o; the attention kernels read the scale from s_dctx),
+        #      or three bf16 planes (six-product attention)
         pqkv = ops.Planes(bqkv, ntok, 3 * hid, bqkv.shape[2])
+        s_dctx = None
+        if bqkv.shape[0] == 2:
+            pdctx = ops.pair_empty(ntok, hid, dev)
+            s_dctx = ops.amax_slot(dev)
+            ops.plane_gemm(qdao, ops.weight_planes(ro, True, view=wo, pair=True), None, tile=tile(hid), form=1, a_amax=s_dao_ref, out_pair=pdctx,
+                           q_ref_in=s_dao, q_l1=ops.weight_col_l1max(ro, view=wo), q_mul=1.01, q_ref_out=s_dctx)
+        else:
+            pdctx = ops.planes_empty(ntok, hid, dev)
+            ops.plane_gemm(qdao, ops.weight_planes(ro, True, view=wo, pair=True), None, out_planes=pdctx, tile=tile(hid), form=1, a_amax=s_dao_ref)
         delta = ctx.delta_buf
         dqkv = torch.empty((ntok, 3 * hid), device=dev, dtype=f32)
         sc = 1.0 / (dh ** 0.5)
         s_dqkv = ops.amax_slot(dev)                   # (the largest magnitude of d(qkv) rides on the two kernels that write it)
-        ops.attn(meta, ATTN_DQ, pqkv, pdctx, dqkv, lse, delta, ctx.masks, sc, p, kbar=kbar, o=ctxv, out_amax=s_dqkv)
-        ops.attn(meta, ATTN_DKV, pqkv, pdctx, dqkv, lse, delta, ctx.masks, sc, p, out_amax=s_dqkv)
+        ops.attn(meta, ATTN_DQ, pqkv, pdctx, dqkv, lse, delta, ctx.masks, sc, p, kbar=kbar, o=ctxv, out_amax=s_dqkv, do_amax=s_dctx)
+        ops.attn(meta, ATTN_DKV, pqkv, pdctx, dqkv, lse, delta, ctx.masks, sc, p, out_amax=s_dqkv, do_amax=s_dctx)
         gq = [wgrad_dest(t) for t in (rq, rk, rv, rbq, rbk, rbv)]
         qdqkv = ops.split_planes_pair(dqkv, amax_slot_=s_dqkv, colsum_out=_stack3(gq[3]))
         del dqkv

@@ -68,7 +68,8 @@ class AttnDesc(C.Structure):
                 ("dO", c_vp), ("do_plane", c_ll), ("do_ld", c_ll),
                 ("out", c_vp), ("ldo", c_ll), ("lse", c_vp), ("delta", c_vp), ("out_planes", c_vp), ("op_plane", c_ll), ("op_ld", c_ll), ("kbar", c_vp), ("ldk", c_ll), ("o", c_vp),
                 ("mask_q", c_vp), ("mask_k", c_vp), ("mask_off", c_vp),
-                ("scale", c_f), ("keep_scale", c_f), ("out_amax", c_vp), ("out_pair", c_vp), ("oq_plane", c_ll), ("oq_ld", c_ll)]
+                ("scale", c_f), ("keep_scale", c_f), ("out_amax", c_vp), ("out_pair", c_vp), ("oq_plane", c_ll), ("oq_ld", c_ll),
+                ("form", c_int), ("do_amax", c_vp)]
 
 
 ATTN_FWD, ATTN_DQ, ATTN_DKV = 0, 1, 2

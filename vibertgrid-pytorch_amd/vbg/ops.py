@@ -1394,9 +1394,31 @@ def attn_mask_layers(meta, p, seed, sid0, sid_stride, nlayers):
     return [(mq[l, :meta.mask_words], mk[l, :meta.mask_words]) for l in range(nlayers)]
 
 
-def attn(meta, mode, qkv: Planes, dO, out, lse, delta, masks, scale, p, kbar=None, out_planes=None, o=None, out_amax=None, out_pair=None):
-    """one fused attention pass (mode: lib.ATTN_FWD / ATTN_DQ / ATTN_DKV) over all (sequence, head) pairs of the packed batch"""
+_ATTN_PAIR = [os.environ.get("VBG_ATTN_PAIR", "1") != "0"]
+
+
+def set_attn_pair(on: bool):
+    """fused attention on two fp16 pieces per operand / three piece products (csrc/attn.hip FORM 1; inside an autocast region the hi pieces
+    alone, FORM 2) wherever the encoder layer runs its fp16-pair path; off: three bf16 pieces / six piece products everywhere"""
+    _ATTN_PAIR[0] = bool(on)
+
+
+def attn_pair_enabled() -> bool:
+    return _ATTN_PAIR[0]
+
+
+def attn(meta, mode, qkv: Planes, dO, out, lse, delta, masks, scale, p, kbar=None, out_planes=None, o=None, out_amax=None, out_pair=None,
+         do_amax=None):
+    """one fused attention pass (mode: lib.ATTN_FWD / ATTN_DQ / ATTN_DKV) over all (sequence, head) pairs of the packed batch.  The
+    arithmetic form follows the operands: three bf16 planes -> six piece products; fp16-pair planes -> three (inside an autocast region:
+    their hi planes alone, one product).  do_amax: the amax slot dO's pair planes were scaled with."""
     d = AttnDesc()
+    pairs = qkv.buf.shape[0] == 2
+    assert dO is None or (dO.buf.shape[0] == 2) == pairs, "q / k / v and dO planes of different forms"
+    d.form = (2 if amp_one_product() else 1) if pairs else 0
+    if do_amax is not None:
+        d.do_amax = do_amax.data_ptr()
+    _seen(("attn:onep" if d.form == 2 else "attn:pair") if pairs else "attn:bf16x3")
     d.mode, d.heads, d.ntasks, d.max_len = int(mode), meta.heads, meta.ntasks, meta.maxlen
     d.tasks, d.seq_len, d.seq_row0, d.pad_off, d.ntok_pad = P(meta.tasks), P(meta.lens), P(meta.seq_row0), P(meta.pad_off), meta.ntok_pad
     d.qkv, d.qkv_plane, d.qkv_ld = qkv.buf.data_ptr(), qkv.plane, qkv.ld
