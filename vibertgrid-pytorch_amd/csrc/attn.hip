@@ -92,7 +92,10 @@ __global__ __launch_bounds__(256, 2) void attn_kernel(const vbg_attn_desc p) {
     constexpr int NS = FWD ? 1 : 2;                                   // stationary operands
     // FORM 0: three bf16 planes, six piece products; FORM 1: two fp16 planes, three; FORM 2: the hi plane alone, one (`amp`)
     constexpr int NP = FORM == 0 ? 3 : (FORM == 1 ? 2 : 1);           // planes of a streamed operand that travel through LDS
-    constexpr int NST = FORM == 2 ? 1 : 3;                            // fragment sets of a stationary operand (FORM 1: hi, lo' 2^-11, hi 2^-11)
+    // FORM 1, DKV (two stationary operands, four accumulator sets: the register file is full): the stationary fragments stay as stored
+    // (hi, lo': two sets instead of three) and the score products keep their cross terms in a 16-register accumulator of their own
+    constexpr bool SXA = FORM == 1 && DKV;
+    constexpr int NST = FORM == 2 ? 1 : (SXA ? 2 : 3);                // fragment sets of a stationary operand (FORM 1: hi c, lo' c 2^-11, hi c 2^-11)
     constexpr int NE = FORM == 0 ? 3 : (FORM == 1 ? 2 : 1);           // pieces of a register operand (FORM 1: hi, lo')
     constexpr int AT_OP = NP * AT_PL, AT_STAGE = 2 * AT_OP;           // (shadow the three-plane sizes of the file scope)
     constexpr float ESC = FORM == 0 ? 1.f : 8192.f, IESC = FORM == 0 ? 1.f : 1.f / 8192.f;     // scale of the probabilities as a register operand
@@ -165,9 +168,9 @@ __global__ __launch_bounds__(256, 2) void attn_kernel(const vbg_attn_desc p) {
         const bool ok = own0 + lr < L;
 #pragma unroll
         for (int s = 0; s < NS; ++s) {
-            if constexpr (FORM == 0) {
+            if constexpr (FORM == 0 || SXA) {
 #pragma unroll
-                for (int q = 0; q < 3; ++q)
+                for (int q = 0; q < NP; ++q)
 #pragma unroll
                     for (int ks = 0; ks < 4; ++ks) {
                         at_u32x4 v = {0u, 0u, 0u, 0u};
@@ -231,10 +234,14 @@ __global__ __launch_bounds__(256, 2) void attn_kernel(const vbg_attn_desc p) {
     constexpr int qa[6] = {2, 0, 1, 1, 0, 0}, qb[6] = {0, 2, 1, 0, 1, 0};       // piece products, smallest first
     // score-type product: D[streamed row][own row] += X_stream[row][:] . X_own[row][:]
     // the piece products of one k-step, smallest first, into ONE accumulator (FORM 1: the stationary side carries the 2^-11)
-    auto sp3 = [&](const at_u32x4 (&fa)[NP], const at_u32x4 (&sb)[NST][4], int ks, f32x16& acc, int first, int last) {
+    auto sp3 = [&](const at_u32x4 (&fa)[NP], const at_u32x4 (&sb)[NST][4], int ks, f32x16& acc, f32x16& sx, int first, int last) {
         if constexpr (FORM == 0) {
 #pragma unroll
             for (int t = 0; t < 6; ++t) if (t >= first && t < last) acc = AT_MFMA(fa[qa[t]], sb[qb[t]][ks], acc);
+        } else if constexpr (SXA) {
+            if (first <= 0 && 0 < last) sx = AT_MFMA_H(fa[1], sb[0][ks], sx);             // lo' x hi
+            if (first <= 1 && 1 < last) sx = AT_MFMA_H(fa[0], sb[1][ks], sx);             // hi x lo'
+            if (first <= 2 && 2 < last) acc = AT_MFMA_H(fa[0], sb[0][ks], acc);           // hi x hi
         } else if constexpr (FORM == 1) {
             if (first <= 0 && 0 < last) acc = AT_MFMA_H(fa[1], sb[2][ks], acc);
             if (first <= 1 && 1 < last) acc = AT_MFMA_H(fa[0], sb[1][ks], acc);
@@ -244,12 +251,21 @@ __global__ __launch_bounds__(256, 2) void attn_kernel(const vbg_attn_desc p) {
         }
     };
     auto sprod = [&](const unsigned char* img, const at_u32x4 (&sb)[NST][4], f32x16& acc) {
+        f32x16 sx;
+        if constexpr (SXA) {
+#pragma unroll
+            for (int r = 0; r < 16; ++r) sx[r] = 0.f;
+        }
 #pragma unroll
         for (int ks = 0; ks < 4; ++ks) {
             at_u32x4 fa[NP];
 #pragma unroll
             for (int q = 0; q < NP; ++q) fa[q] = *reinterpret_cast<const at_u32x4*>(img + q * AT_PL + fra[ks]);
-            sp3(fa, sb, ks, acc, 0, 6);
+            sp3(fa, sb, ks, acc, sx, 0, 6);
+        }
+        if constexpr (SXA) {
+#pragma unroll
+            for (int r = 0; r < 16; ++r) acc[r] = fmaf(sx[r], 0.00048828125f, acc[r]);
         }
     };
     // second product: D[column d of the streamed operand][own row] += sum over streamed rows X_stream[row][d] E[row][own row]
@@ -335,6 +351,11 @@ __global__ __launch_bounds__(256, 2) void attn_kernel(const vbg_attn_desc p) {
     constexpr int NPR = FORM == 0 ? 6 : (FORM == 1 ? 3 : 1), CUT = FORM == 0 ? 3 : (FORM == 1 ? 2 : 1);
     auto sprod_woven = [&](const unsigned char* img, const at_u32x4 (&sb)[NST][4], f32x16& acc, auto&& work) {
         at_u32x4 fa[2][NP];
+        f32x16 sx;
+        if constexpr (SXA) {
+#pragma unroll
+            for (int r = 0; r < 16; ++r) sx[r] = 0.f;
+        }
 #pragma unroll
         for (int q = 0; q < NP; ++q) fa[0][q] = *reinterpret_cast<const at_u32x4*>(img + q * AT_PL + fra[0]);
 #pragma unroll
@@ -343,14 +364,18 @@ __global__ __launch_bounds__(256, 2) void attn_kernel(const vbg_attn_desc p) {
 #pragma unroll
                 for (int q = 0; q < NP; ++q) fa[(ks + 1) & 1][q] = *reinterpret_cast<const at_u32x4*>(img + q * AT_PL + fra[ks + 1]);
             }
-            sp3(fa[ks & 1], sb, ks, acc, 0, CUT);
+            sp3(fa[ks & 1], sb, ks, acc, sx, 0, CUT);
             __builtin_amdgcn_sched_barrier(0);
             work(2 * ks);
             __builtin_amdgcn_sched_barrier(0);
-            sp3(fa[ks & 1], sb, ks, acc, CUT, NPR);
+            sp3(fa[ks & 1], sb, ks, acc, sx, CUT, NPR);
             __builtin_amdgcn_sched_barrier(0);
             work(2 * ks + 1);
             __builtin_amdgcn_sched_barrier(0);
+        }
+        if constexpr (SXA) {
+#pragma unroll
+            for (int r = 0; r < 16; ++r) acc[r] = fmaf(sx[r], 0.00048828125f, acc[r]);
         }
     };
     auto tprod_woven = [&](const unsigned char* img, const at_u32x4 (&bp)[NE][2], f32x16 (&acc)[2], auto&& work) {
