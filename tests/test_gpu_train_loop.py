@@ -207,6 +207,7 @@ def test_stock_loop_on_model_owned_flat_storage(golden, tmp_path):
     dev = torch.device("cuda")
     dbatch = to_dev(_e2e_inputs(golden("e2e.npz")), dev)
     res = {}
+    ops.set_pair(os.environ.get("VBG_PAIR", "1") != "0", force=False)          # (the library's own thresholds, whatever ran before in this process)
     for mode in ("homed", "plain"):
         ops.set_home(mode == "homed")
         try:
@@ -248,7 +249,9 @@ def test_stock_loop_on_model_owned_flat_storage(golden, tmp_path):
     #  step -- second-step gradients of the lowest encoder layers were 8 % off while every loss still agreed)
     wg = max((float((gh[k] - gp[k]).norm() / (gp[k].norm() + 1e-30)), k) for k in gp if "key.bias" not in k)
     print("worst second-step gradient distance homed vs plain:", wg)
-    assert wg[0] < 2e-3, wg
+    # (3e-4 measured alone, the tiny fixture moves its gradients by 1e-3 ... 3e-2 under a 1e-7 change of the parameters -- see
+    #  test_gradscaler_loop_torch_and_fused --; the stale images read 8e-2 on the lowest encoder layers)
+    assert wg[0] < 2e-2, wg
     print("stock loop, homed vs plain losses:", lh, lp)
     assert abs(lh[0] - lp[0]) <= 1e-6 * abs(lp[0])
     worst = max((float((ah[k] - ap[k]).norm() / (ap[k].norm() + 1e-12)), k) for k in ah if "pooler" not in k and "key.bias" not in k)
