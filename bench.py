@@ -314,6 +314,7 @@ def main():
             print(f"[bench] gloo side group unavailable ({type(e).__name__}: {e}); clipping decided per rank", file=sys.stderr, flush=True)
     assert world == args.gpus, f"--gpus {args.gpus} but WORLD_SIZE={world} (launch with torch.distributed.run)"
 
+    from vbg import functions as vbg_functions
     from vbg import ops
     from vbg.lib import OP_DENSE_K
     from vbg.optim import FlatReducer, FusedAdamW, FusedSGD, clip_grad_norm_, split_parameters
@@ -578,7 +579,7 @@ def main():
                        if args.shape == "cfg2" else f"EXPLORATORY {args.shape}: {shape}, T=512, batch {B}/GPU (not the BASELINE metric's configuration)",
                        "global_batch": B * world, "seq_len": 512, "parallelism": f"dp{world}" + ("+syncbn" if sync_bn else ""),
                        **({"step_barrier": not args.no_step_barrier, "syncbn_comm": reducer.sync_bn_mode, "ddp_overlap": reducer.overlap,
-                           "buckets": len(reducer.buckets), "backend": dist.get_backend(), "syncbn_collectives": Fn_seq(),
+                           "buckets": len(reducer.buckets), "backend": dist.get_backend(), "syncbn_collectives": int(vbg_functions.SyncCtx.seq),
                            **({"forced_reducer_on_one_rank": True} if forced else {})} if (world > 1 or forced) else {}),
                        "last_loss": round(float(last), 4), **({"ranks_in_sync": ranks_in_sync} if ranks_in_sync is not None else {}), **({"h2d_in_step": packed_src.nbytes()} if args.h2d else {})},
             # algorithmic (fp32-equivalent, PAD-free) TFLOP/s of the whole step per GPU, SURVEY.md 8d, and as a fraction of the matrix-core
@@ -663,11 +664,6 @@ def main():
         os.write(real_stdout, (json.dumps(out) + "\n").encode())
     if world > 1 or forced:
         dist.destroy_process_group()
-
-
-def Fn_seq():
-    from vbg import functions as Fn
-    return int(Fn.SyncCtx.seq)
 
 
 if __name__ == "__main__":

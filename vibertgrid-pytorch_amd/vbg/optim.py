@@ -555,9 +555,7 @@ class FlatReducer:
         Fn.SyncCtx.direct = None
         if sync_bn_group == "direct":
             # THE DEFAULT on RCCL (round 5): the statistics on a communicator of this library's own, enqueued on the compute stream
-            # (vbg/rccl.py): no event hand-overs to and from ProcessGroupNCCL's stream (measured on one rank: 40.9 vs 41.2 ms per step --
-            # the ~70 us a SyncBatchNorm layer costs is RCCL's own small-message kernel and the route's extra launches, not the
-            # dispatcher), and -- the point at N > 1 -- never queued behind a 32 MB gradient bucket on that stream.  Two communicators
+            # (vbg/rccl.py): no event hand-overs to and from ProcessGroupNCCL's stream (measured on one rank: 34.8 vs 35.8 ms per step), and -- the point at N > 1 -- never queued behind a 32 MB gradient bucket on that stream.  Two communicators
             # then have kernels in flight during backward.  That is deadlock-free when every rank ENQUEUES them in the same relative
             # order (streams beyond the device's hardware queues share one, and a collective's kernel parked at the head of a queue holds
             # up whatever sits behind it): the same program on every rank issues the same sequence, which is what static_graph=True
@@ -568,8 +566,17 @@ class FlatReducer:
                 raise ValueError("sync_bn_group='direct' needs backend 'nccl' (RCCL) and the default process group")
             dev = optimizers[0].group.pflat.device
             Fn.SyncCtx.group = group
-            Fn.SyncCtx.direct = rccl.DirectComm(dev)
-            self.sync_bn_mode = "direct RCCL communicator on the compute stream"
+            try:
+                Fn.SyncCtx.direct = rccl.DirectComm(dev)
+                self.sync_bn_mode = "direct RCCL communicator on the compute stream"
+            except Exception as e:          # (the same on every rank: a library that cannot be driven this way; collectives have not started)
+                import sys
+                print(f"[vbg reducer] no direct RCCL communicator ({type(e).__name__}: {e}); SyncBatchNorm statistics through torch.distributed",
+                      file=sys.stderr, flush=True)
+                Fn.SyncCtx.direct = None
+                sync_bn_group = "default"
+        if sync_bn_group == "direct":
+            pass
         elif sync_bn_group == "new":
             if group is not None:
                 raise ValueError("FlatReducer(group=<sub-group>): pass sync_bn_group=<ProcessGroup> or 'default' -- dist.new_group is a "
