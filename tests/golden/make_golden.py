@@ -788,6 +788,36 @@ def gen_full_chunked(V, tmp, name, check_against=None, extra=None):
     npz(f"full_{name}.npz", **out)
 
 
+def gen_full_amp(V, tmp, name, dtype):
+    """The reference's `amp: True` step at full scale: its autocast region (pipeline/train_val_utils.py:264) around the train forward of a
+    tests/full_scale.py case (frozen BatchNorm, plain losses: the every-gradient setup), on the CPU -- CUDA autocast cannot run here;
+    CPU autocast to `dtype` (fp16 where this torch build's CPU kernels take it, else bfloat16) is the closest thing the reference itself
+    can produce in this container: the same op list in reduced precision (conv / linear / matmul), normalisation and losses in fp32.
+    Stores the loss and the sampled gradients like gen_full."""
+    sys.path.insert(0, os.path.join(ROOT, "tests"))
+    import full_scale as F
+    import time
+    c = F.CASES[name]
+    net = _full_net(V, tmp, name)
+    load_synth(net)
+    batch = F.inputs(name)
+    net.train()
+    for m in net.modules():
+        if isinstance(m, torch.nn.modules.batchnorm._BatchNorm):
+            m.eval()
+    random.seed(7)
+    t0 = time.time()
+    with torch.autocast("cpu", dtype=dtype):
+        loss = net(*batch)
+    loss.backward()
+    print(name, "autocast", dtype, "train step", round(time.time() - t0, 1), "s, loss", float(loss))
+    out = {"checksums": np.array(F.checksums(batch)), "train_loss": loss.float(), "autocast_dtype": np.array(str(dtype))}
+    for k, p in net.named_parameters():
+        if not k.startswith("BERTgrid_generator.") and p.grad is not None:
+            out[f"grad::{k}"] = F.sample(p.grad.float(), 1024)
+    npz(f"full_{name}_amp.npz", **out)
+
+
 def gen_full(V, tmp, name):
     """Full-scale reference runs (12-layer bert-base / roberta-base dims, real vocab sizes, resnet-34, 512x512 / 1024x1024, T=512 ->
     two windows): tests/full_scale.py defines the cases and the seeded inputs; the outputs of model/ViBERTgrid_net.py:501-544 in
@@ -923,6 +953,12 @@ def main():
     for name in ("cfg2", "cfg4", "cfg5", "cfg2p", "cfg2e", "cfg4e", "cfg5e", "cfg3", "cfg3e", "cfg2e8", "cfg4e8", "cfg1"):
         if "full_" + name in which:
             gen_full(V, tmp, name)
+    if "full_cfg2e8_amp" in which:     # the reference under autocast at the benchmark's batch (fp16 if the CPU kernels take it, else bf16)
+        try:
+            gen_full_amp(V, tmp, "cfg2e8", torch.float16)
+        except Exception as e:
+            print("fp16 CPU autocast failed:", type(e).__name__, str(e)[:200], "-> bfloat16")
+            gen_full_amp(V, tmp, "cfg2e8", torch.bfloat16)
     if "chunk_rule" in which:          # (prints only) the mean-of-groups rule against the direct batch-8 step of full_cfg2e8.npz
         gen_full_chunked(V, tmp, "cfg2e8c", check_against="full_cfg2e8.npz")
     if "full_cfg5e16" in which:        # batch 16 x 1024^2 from eight reference steps of two documents; the rule's check rides in the fixture

@@ -258,7 +258,7 @@ def test_full_scale_amp_one_product_forms(golden, tmp_path):
     random.seed(7)
     seen = ops.dispatch_log(True)
     try:
-        with torch.autocast("cuda", dtype=torch.bfloat16):
+        with torch.autocast("cuda", dtype=torch.float16):          # (torch.cuda.amp.autocast of pipeline/train_val_utils.py:264: fp16)
             tl = net(*dbatch)
         assert ops.amp_enabled() and tl.dtype in (torch.float32, torch.float64)
         tl.backward()
@@ -267,6 +267,7 @@ def test_full_scale_amp_one_product_forms(golden, tmp_path):
         ops.set_amp(False)
     print(f"{name} amp: dispatch seen:", {k: seen[k] for k in sorted(seen)})
     assert seen.get("plane_gemm:onep", 0) >= 36 + 48 and seen.get("plane_gemm:pair", 0) == 0, seen
+    assert seen.get("attn:onep", 0) == 36 and seen.get("attn:pair", 0) == 0 and seen.get("attn:bf16x3", 0) == 0, seen      # attention on one product too (round 5)
     assert seen.get("conv3:onep", 0) >= 30 and seen.get("conv3:wgrad_onep", 0) >= 25, seen
     rl = float(np.asarray(g["train_loss"]).reshape(-1)[0])
     print(f"{name} amp: train loss {float(tl.detach()):.6f} reference (fp32) {rl:.6f}")
