@@ -663,6 +663,9 @@ def main():
         sys.stdout.flush()
         os.write(real_stdout, (json.dumps(out) + "\n").encode())
     if world > 1 or forced:
+        if vbg_functions.SyncCtx.direct is not None:          # the library's own RCCL communicator goes first
+            vbg_functions.SyncCtx.direct.destroy()
+            vbg_functions.SyncCtx.direct = None
         dist.destroy_process_group()
 
 

@@ -809,12 +809,16 @@ def gen_full_amp(V, tmp, name, dtype):
     t0 = time.time()
     with torch.autocast("cpu", dtype=dtype):
         loss = net(*batch)
-    loss.backward()
+    # `scaler.scale(train_loss).backward()` of the reference's loop (pipeline/train_val_utils.py:274) with torch.cuda.amp.GradScaler's
+    # initial scale 2^16, gradients unscaled afterwards as `scaler.step` does: without it the fp16 backward underflows (a first version of
+    # this fixture: the reference's autocast gradients at a median cosine of 0.987 to its own fp32 gradients)
+    scale = 65536.0
+    (loss * scale).backward()
     print(name, "autocast", dtype, "train step", round(time.time() - t0, 1), "s, loss", float(loss))
-    out = {"checksums": np.array(F.checksums(batch)), "train_loss": loss.float(), "autocast_dtype": np.array(str(dtype))}
+    out = {"checksums": np.array(F.checksums(batch)), "train_loss": loss.float(), "autocast_dtype": np.array(str(dtype)), "loss_scale": np.array(scale)}
     for k, p in net.named_parameters():
         if not k.startswith("BERTgrid_generator.") and p.grad is not None:
-            out[f"grad::{k}"] = F.sample(p.grad.float(), 1024)
+            out[f"grad::{k}"] = F.sample(p.grad.float() / scale, 1024)
     npz(f"full_{name}_amp.npz", **out)
 
 

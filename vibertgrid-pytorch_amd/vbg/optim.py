@@ -127,7 +127,8 @@ class FlatGroup:
         gradient views come back, over ONE memset of the flat buffer when all of them were dropped (the usual case), slice by slice
         otherwise (a caller that keeps some gradients to accumulate into).  A gradient the caller left in place is accumulated into,
         as torch would."""
-        missing = [i for i, p in enumerate(self.params) if p.grad is None]
+        # (a parameter frozen after it was homed keeps `.grad = None`: torch.optim skips it, as it would without flat storage)
+        missing = [i for i, p in enumerate(self.params) if p.grad is None and p.requires_grad]
         if not missing:
             return
         if len(missing) == len(self.params):
