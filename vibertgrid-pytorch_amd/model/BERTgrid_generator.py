@@ -133,11 +133,38 @@ class BERTgridGenerator(nn.Module):
         self._step_seed = 0x5EED
 
     # ------------------------------------------------------------------------------------------
+    def prefetch_host(self, corpus: torch.Tensor, mask: torch.Tensor, seg_indices):
+        """The integer inputs the index tables are built from on the host (token ids, mask, segment indices), fetched in ONE device->host
+        copy BEFORE anything of this forward is enqueued.  The reference's loop hands over device tensors (`.to(device)` per tensor,
+        pipeline/train_val_utils.py:257-262), and a copy back is a stream drain wherever it stands: behind the CNN's first stage and
+        behind the whole encoder, where `_encode` / `_segment_embeddings` would issue theirs, the host waits ~1.5 ms per step and then
+        enqueues the rest of the forward in front of an idle device.  At the top of the forward the stream holds nothing of this step yet.
+        Tensors uploaded through vbg.batch.PackedBatch carry their host copy along and need nothing.  The arrays are held for this
+        forward only (keyed by tensor identity; `release_host` drops them): nothing is attached to the caller's tensors."""
+        self._host = {}
+        if not corpus.is_cuda:
+            return
+        want = [t for t in (corpus, mask) + tuple(seg_indices) if host_mirror(t) is None and t.numel()]
+        if not want:
+            return
+        host = torch.cat([t.reshape(-1).long() for t in want]).cpu().numpy()
+        o = 0
+        for t in want:
+            self._host[id(t)] = host[o:o + t.numel()].reshape(tuple(t.shape))
+            o += t.numel()
+
+    def release_host(self):
+        self._host = {}
+
+    def _mirror(self, t):
+        m = host_mirror(t)
+        return m if m is not None else self.__dict__.get("_host", {}).get(id(t))
+
     def _encode(self, corpus: torch.Tensor, mask: torch.Tensor):
         """-> (token states [ntok, hidden] on device, packing)"""
         cfg = self.model.config
         dev = corpus.device
-        hc, hm = host_mirror(corpus), host_mirror(mask)
+        hc, hm = self._mirror(corpus), self._mirror(mask)
         if hc is None or hm is None:
             host = torch.cat([corpus.reshape(-1).long(), mask.reshape(-1).long()]).cpu().numpy()      # one D2H sync
             n = corpus.numel()
@@ -214,8 +241,8 @@ class BERTgridGenerator(nn.Module):
         dev = corpus.device
         x, pk = self._encode(corpus, mask)
         B = corpus.shape[0]
-        mirrors = [host_mirror(s) for s in seg_indices]
-        if B and all(m is not None for m in mirrors):          # uploaded through vbg.batch.PackedBatch: no device->host copy
+        mirrors = [self._mirror(s) if s.numel() else np.zeros(0, np.int64) for s in seg_indices]
+        if B and all(m is not None for m in mirrors):          # uploaded through vbg.batch.PackedBatch, or fetched by prefetch_host
             seg_host = np.concatenate([np.asarray(m, dtype=np.int64).reshape(-1) for m in mirrors])
         else:
             seg_host = torch.cat([s.reshape(-1).long() for s in seg_indices]).cpu().numpy() if B else np.zeros(0, np.int64)

@@ -221,16 +221,25 @@ class ViBERTgridNet(nn.Module):
     def inference(self, image: Tuple[torch.Tensor], seg_indices: Tuple[torch.Tensor], coors: torch.Tensor, corpus: torch.Tensor,
                   mask: torch.Tensor):
         ops.set_amp(torch.is_autocast_enabled("cuda"))
-        batch, icoors, packed, B, H, W = self._trunk(image, seg_indices, coors, corpus, mask)
-        emb_cat, p_fuse = self._features(batch, packed, B, H, W, seg_indices, corpus, mask)
+        self.BERTgrid_generator.prefetch_host(corpus, mask, seg_indices)
+        try:
+            batch, icoors, packed, B, H, W = self._trunk(image, seg_indices, coors, corpus, mask)
+            emb_cat, p_fuse = self._features(batch, packed, B, H, W, seg_indices, corpus, mask)
+        finally:
+            self.BERTgrid_generator.release_host()
         roi = self.grid_roi_align_net(p_fuse, icoors, None, packed=packed)
         fuse = self.late_fusion_net(roi, emb_cat)
         return self.field_type_classification_head.inference(fuse)
 
     def forward(self, image: Tuple[torch.Tensor], seg_indices: Tuple[torch.Tensor], segment_classes: Tuple[torch.Tensor],
                 coors: torch.Tensor, corpus: torch.Tensor, mask: torch.Tensor):
-        with bn_tick_scope():          # the BatchNorm step counters of the whole forward advance in one launch
-            return self._forward(image, seg_indices, segment_classes, coors, corpus, mask)
+        # (the host copies of the integer inputs first: one device->host copy while the stream holds nothing of this step)
+        self.BERTgrid_generator.prefetch_host(corpus, mask, seg_indices)
+        try:
+            with bn_tick_scope():          # the BatchNorm step counters of the whole forward advance in one launch
+                return self._forward(image, seg_indices, segment_classes, coors, corpus, mask)
+        finally:
+            self.BERTgrid_generator.release_host()
 
     def _home(self):
         """Flat parameter / gradient storage, owned by the model (vbg.optim.home_parameters): built at the first training forward on
