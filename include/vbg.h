@@ -368,17 +368,18 @@ int vbg_dropout_add_ln_fwd_planes(const float* x, const float* res, int rows, in
                                   unsigned long long stream_id, float* y, float* xhat, float* rstd, unsigned short* y_planes, int ldp,
                                   long long plane, unsigned short* y_pair, int ldq, long long qplane, void* stream);
 /* (y_pair, optional: y also as fp16-pair planes [2][rows][ldq] -- the A operand of the form-1 forward products) */
-/* dx (to the dense output), dres, dgamma/dbeta +=.  `slots_ws` (optional): fp32 [vbg_ln_slots()][2][hidden] workspace that is ZERO
- * on entry and left zero on exit; with it the per-block column sums are spread over the slot rows and folded by a second tiny
- * launch (same-address atomics serialise: ~500 blocks per column at cfg2), without it they go straight into dgamma/dbeta */
-int vbg_ln_slots(void);
+/* dx (to the dense output), dres, dgamma/dbeta +=.  `slots_ws` (optional): fp32 workspace [vbg_ln_bwd_ws_rows(rows)][2][hidden]; it
+ * need not be initialised and holds nothing afterwards.  With it every block of the kernel stores its column sums as one plain row and a
+ * second small launch adds the rows in a fixed order (deterministic; round 5: the 516 x 2304 float atomics of the earlier slot scheme
+ * were a ~9 us tail at the L2's atomic rate); without it (few rows) the sums go straight into dgamma / dbeta as atomics */
+int vbg_ln_bwd_ws_rows(int rows);
 int vbg_dropout_add_ln_bwd(const float* dy, const float* xhat, const float* rstd, int rows, int hidden,
                            const float* gamma, float drop_p, unsigned long long seed, unsigned long long stream_id,
                            float* dx, float* dres, float* dgamma, float* dbeta, float* slots_ws, unsigned* dx_amax, void* stream);
 /* dx_amax (optional): amax slot (zeroed by the caller) that receives max |dx| -- the scale of dx as an fp16-pair operand */
 /* the same with dx delivered as bf16 planes [3][rows][ldp] (not as fp32) and its column sums added into dbias_accum[hidden]: dx is the
  * gradient of the dense output in front of the LayerNorm, which is only ever a plane operand of that layer's gradient products, and
- * its column sums are that layer's bias gradient.  slots3_ws: fp32 [vbg_ln_slots()][3][hidden], zero on entry, left zero. */
+ * its column sums are that layer's bias gradient.  slots3_ws: fp32 [vbg_ln_bwd_ws_rows(rows)][3][hidden], as above (mandatory). */
 int vbg_dropout_add_ln_bwd_planes(const float* dy, const float* xhat, const float* rstd, int rows, int hidden,
                                   const float* gamma, float drop_p, unsigned long long seed, unsigned long long stream_id,
                                   unsigned short* dx_planes, int ldp, long long plane, float* dres, float* dgamma, float* dbeta,

@@ -601,10 +601,11 @@ def test_dropout_add_ln(ops, rows, Hd):
     assert int(slot.max().item()) == int(dx.abs().max().view(torch.int32).item())          # max |dx| rides on the kernel
     assert close(dx, x.grad, 1e-3, 1e-5) and close(dres, r.grad, 1e-3, 1e-5)
     assert close(dg, gam.grad, 1e-3, 1e-3) and close(db, bet.grad, 1e-3, 1e-3)
-    # a second call accumulates into dgamma / dbeta and finds the workspace clean
+    # a second call accumulates into dgamma / dbeta; the partials workspace (rows >= 512) needs no particular content on entry
+    for w in ops._LN_WS.values():
+        w.fill_(float("nan"))
     ops.dropout_add_ln_bwd(gy.to(d), xhat, rstd, gam.detach().to(d), 0.0, 1, 0, dg, db)
     assert close(dg, 2 * gam.grad, 1e-3, 2e-3) and close(db, 2 * bet.grad, 1e-3, 2e-3)
-    assert all(float(w.abs().max()) == 0.0 for w in ops._LN_WS.values())
     # dropout: same mask forward and backward, keep rate ~ 1-p, kept values scaled by 1/(1-p)
     p = 0.1
     one = torch.ones(rows, Hd, device=d)
@@ -624,7 +625,13 @@ def test_dropout_add_ln(ops, rows, Hd):
     pdx, dres2 = ops.dropout_add_ln_bwd_planes(gy2, xhat, rstd, gam1, p, 123, 7, dg2, db2, dbias)
     assert torch.equal(dres2, dres_ref) and torch.equal(pdx.buf, ops.split_planes(dx_ref).buf)
     assert torch.allclose(dbias.double() - 3.0, dx_ref.double().sum(0), rtol=1e-4, atol=1e-4 * rows ** 0.5)
-    assert all(float(w.abs().max()) == 0.0 for w in ops._LN_WS3.values())
+    # the partials workspace needs no initialisation, and its rows are added in a fixed order: a second run over a workspace full of NaN
+    # gives the same bits (the slot scheme of rounds 2-4 used float atomics and a workspace that had to be left zero)
+    for w in ops._LN_WS.values():
+        w.fill_(float("nan"))
+    dg3, db3, dbias3 = torch.zeros(Hd, device=d), torch.zeros(Hd, device=d), torch.full((Hd,), 3.0, device=d)
+    ops.dropout_add_ln_bwd_planes(gy2, xhat, rstd, gam1, p, 123, 7, dg3, db3, dbias3)
+    assert torch.equal(dg3, dg2) and torch.equal(db3, db2) and torch.equal(dbias3, dbias)
 
 
 def test_softmax(ops):

@@ -128,11 +128,19 @@ __global__ __launch_bounds__(LN_THREADS) void embed_ln_bwd_kernel(
 }
 
 // ---- wave-per-row LayerNorm kernels (hidden % 256 == 0, hidden <= 1024): each lane owns float4 chunks lane + 64*j,
-// no block-level barrier; a block of 256 threads handles 4 rows per pass and LN_WROWS passes (backward keeps the
-// dgamma / dbeta partial sums of its columns in registers across all its rows, one atomic per column per wave).
+// no block-level barrier; a block of 256 threads handles 4 rows per pass and `wrows` passes (backward keeps the
+// dgamma / dbeta partial sums of its columns in registers across all its rows; the block's sums leave as ONE plain row of a partials
+// workspace, ln_fold_rows_kernel adds the rows in a fixed order).
 constexpr int LN_V = 4;            // max float4 per lane (hidden <= 1024)
-constexpr int LN_WROWS = 2;        // rows per wave in the backward kernel (8 rows per block -> >= 2 blocks per CU at cfg2)
-constexpr int LN_SLOTS = 32;       // slot rows of the dgamma / dbeta workspace
+
+// rows per wave of the backward kernel: about one block of four waves per CU (258 blocks at cfg2's 4128 rows; the next row's loads are
+// in flight while a row is reduced and stored), never more than 8
+static int ln_bwd_wrows(int rows) {
+    static const int forced = [] { const char* e = getenv("VBG_LN_WROWS"); return e ? atoi(e) : 0; }();
+    if (forced > 0) return forced;
+    int w = rows / 1024;
+    return w < 1 ? 1 : (w > 8 ? 8 : w);
+}
 
 __device__ __forceinline__ float4 drop4(float4 v, uint32_t thr, float ks, uint64_t seed, uint64_t sid, uint64_t idx) {
     if (thr) {
@@ -217,7 +225,7 @@ __global__ __launch_bounds__(256) void dropout_add_ln_fwd_kernel(
 
 // PL: dx (the gradient of the dense output in front of this LayerNorm) leaves as bf16 planes [3][rows][ldp] instead of fp32 -- it is
 // only ever a plane operand of that layer's data- and weight-gradient products -- and its column sums (the dense layer's bias
-// gradient) ride along in a third slot array; slots are then [LN_SLOTS][3][hidden] and mandatory.
+// gradient) ride along in a third array of the partials row; the workspace is then [blocks][3][hidden] and mandatory.
 // PL = 0: dx as fp32 (+ its largest magnitude); 1: dx as three bf16 planes + column sums; 2 (round 4): dx as TWO fp16 planes scaled by the
 // power of two of a rigorous BOUND of |dx| -- no fp32 round trip and no split pass for a gradient that is only ever a plane operand --,
 // + column sums + the true largest magnitude (the next producer's bound needs it).  The bound: dz = rstd (g gamma - mean(g gamma) -
@@ -228,12 +236,12 @@ template <int PL>
 __global__ __launch_bounds__(256) void dropout_add_ln_bwd_kernel(
     const float* __restrict__ dy, const float* __restrict__ xhat, const float* __restrict__ rstd, int rows, int hidden,
     const float* __restrict__ gamma, uint32_t drop_thr, float keep_scale, uint64_t seed, uint64_t sid,
-    float* __restrict__ dx, float* __restrict__ dres, float* dgamma, float* dbeta, float* slots,
+    float* __restrict__ dx, float* __restrict__ dres, float* dgamma, float* dbeta, float* __restrict__ part, int wrows,
     unsigned short* __restrict__ dxp, int ldp, long long plane, unsigned* dx_amax, const unsigned* dy_amax = nullptr,
     unsigned* dx_bound = nullptr) {
     const int lane = threadIdx.x & 63;
     const int nv = hidden >> 8;
-    const int t0 = (blockIdx.x * 4 + (threadIdx.x >> 6)) * LN_WROWS;
+    const int t0 = (blockIdx.x * 4 + (threadIdx.x >> 6)) * wrows;
     float amx = 0.f;                                  // max |dx| of this thread (dx_amax: the scale of dx as a pair-plane operand)
     float4 gam[LN_V], ag[LN_V], ab[LN_V], ac[LN_V];
 #pragma unroll
@@ -241,6 +249,19 @@ __global__ __launch_bounds__(256) void dropout_add_ln_bwd_kernel(
         ac[j] = make_float4(0.f, 0.f, 0.f, 0.f);
         ag[j] = ab[j] = make_float4(0.f, 0.f, 0.f, 0.f);
         gam[j] = (j < nv) ? *reinterpret_cast<const float4*>(gamma + (lane + 64 * j) * 4) : ag[j];
+    }
+    // (the first row's loads are issued in front of the bound's prologue: its L2 round trips and barrier run under their latency)
+    const int tend = min(rows, t0 + wrows);
+    float4 g[LN_V], xh[LN_V], gn[LN_V], xn[LN_V];
+    float rs = 0.f, rsn = 0.f;
+    if (t0 < tend) {
+#pragma unroll
+        for (int j = 0; j < LN_V; ++j)
+            if (j < nv) {
+                gn[j] = *reinterpret_cast<const float4*>(dy + (long long)t0 * hidden + (lane + 64 * j) * 4);
+                xn[j] = *reinterpret_cast<const float4*>(xhat + (long long)t0 * hidden + (lane + 64 * j) * 4);
+            }
+        rsn = rstd[t0];
     }
     float qsc = 1.f;
     if constexpr (PL == 2) {
@@ -267,16 +288,24 @@ __global__ __launch_bounds__(256) void dropout_add_ln_bwd_kernel(
         qsc = vbg_pow2_scale(__float_as_uint(bound)).x;
         if (dx_bound && blockIdx.x == 0 && threadIdx.x == 0) dx_bound[0] = __float_as_uint(bound);
     }
-    for (int t = t0; t < min(rows, t0 + LN_WROWS); ++t) {
+    for (int t = t0; t < tend; ++t) {
         const long long base = (long long)t * hidden;
-        float4 g[LN_V], xh[LN_V];
         float s1 = 0.f, s2 = 0.f;
+#pragma unroll
+        for (int j = 0; j < LN_V; ++j) { g[j] = gn[j]; xh[j] = xn[j]; }
+        rs = rsn;
+        if (t + 1 < tend) {                              // the next row's loads fly while this one is reduced and stored
+#pragma unroll
+            for (int j = 0; j < LN_V; ++j)
+                if (j < nv) {
+                    gn[j] = *reinterpret_cast<const float4*>(dy + base + hidden + (lane + 64 * j) * 4);
+                    xn[j] = *reinterpret_cast<const float4*>(xhat + base + hidden + (lane + 64 * j) * 4);
+                }
+            rsn = rstd[t + 1];
+        }
 #pragma unroll
         for (int j = 0; j < LN_V; ++j)
             if (j < nv) {
-                const int c = (lane + 64 * j) * 4;
-                g[j] = *reinterpret_cast<const float4*>(dy + base + c);
-                xh[j] = *reinterpret_cast<const float4*>(xhat + base + c);
                 ag[j].x += g[j].x * xh[j].x; ag[j].y += g[j].y * xh[j].y; ag[j].z += g[j].z * xh[j].z; ag[j].w += g[j].w * xh[j].w;
                 ab[j].x += g[j].x; ab[j].y += g[j].y; ab[j].z += g[j].z; ab[j].w += g[j].w;
                 const float a = g[j].x * gam[j].x, b = g[j].y * gam[j].y, c2 = g[j].z * gam[j].z, d = g[j].w * gam[j].w;
@@ -284,7 +313,6 @@ __global__ __launch_bounds__(256) void dropout_add_ln_bwd_kernel(
                 s2 += (a * xh[j].x + b * xh[j].y) + (c2 * xh[j].z + d * xh[j].w);
             }
         const float m1 = wave_sum(s1) / (float)hidden, m2 = wave_sum(s2) / (float)hidden;
-        const float rs = rstd[t];
 #pragma unroll
         for (int j = 0; j < LN_V; ++j)
             if (j < nv) {
@@ -328,7 +356,9 @@ __global__ __launch_bounds__(256) void dropout_add_ln_bwd_kernel(
                 }
             }
     }
-    // cross-wave reduction of the column partials through LDS, then ONE atomic per column per block
+    // cross-wave reduction of the column partials through LDS; the block's sums then leave as row blockIdx.x of the partials workspace
+    // (plain stores; 516 blocks x 2304 float atomics used to be a ~9 us tail at the L2's atomic rate), or, without a workspace (few
+    // rows), as one atomic per column straight into dgamma / dbeta
     constexpr int NA = PL != 0 ? 3 : 2;
     __shared__ float red[NA][4][256 * LN_V];
     const int w = threadIdx.x >> 6;
@@ -341,14 +371,18 @@ __global__ __launch_bounds__(256) void dropout_add_ln_bwd_kernel(
             if constexpr (PL != 0) *reinterpret_cast<float4*>(&red[2][w][c]) = ac[j];
         }
     __syncthreads();
-    // same-address atomics serialise (~516 blocks at cfg2): with a slot workspace the block sums land in one of LN_SLOTS slot
-    // rows and ln_fold_kernel adds the slots into dgamma / dbeta (and clears them for the next call)
-    float* dg = slots ? slots + (size_t)(blockIdx.x % LN_SLOTS) * NA * hidden : dgamma;
-    float* db = slots ? dg + hidden : dbeta;
-    for (int c = threadIdx.x; c < hidden; c += 256) {
-        unsafeAtomicAdd(dg + c, (red[0][0][c] + red[0][1][c]) + (red[0][2][c] + red[0][3][c]));
-        unsafeAtomicAdd(db + c, (red[1][0][c] + red[1][1][c]) + (red[1][2][c] + red[1][3][c]));
-        if constexpr (PL != 0) unsafeAtomicAdd(dg + 2 * hidden + c, (red[2][0][c] + red[2][1][c]) + (red[2][2][c] + red[2][3][c]));
+    if (part) {
+        float* pp = part + (size_t)blockIdx.x * NA * hidden;
+        for (int c = threadIdx.x; c < hidden; c += 256) {
+            pp[c] = (red[0][0][c] + red[0][1][c]) + (red[0][2][c] + red[0][3][c]);
+            pp[hidden + c] = (red[1][0][c] + red[1][1][c]) + (red[1][2][c] + red[1][3][c]);
+            if constexpr (PL != 0) pp[2 * hidden + c] = (red[2][0][c] + red[2][1][c]) + (red[2][2][c] + red[2][3][c]);
+        }
+    } else {
+        for (int c = threadIdx.x; c < hidden; c += 256) {
+            unsafeAtomicAdd(dgamma + c, (red[0][0][c] + red[0][1][c]) + (red[0][2][c] + red[0][3][c]));
+            unsafeAtomicAdd(dbeta + c, (red[1][0][c] + red[1][1][c]) + (red[1][2][c] + red[1][3][c]));
+        }
     }
     if constexpr (PL != 1) {
         if (dx_amax) {                                // (uniform)
@@ -358,18 +392,29 @@ __global__ __launch_bounds__(256) void dropout_add_ln_bwd_kernel(
     }
 }
 
-// folds the slot rows ([LN_SLOTS][na][hidden]) into dgamma / dbeta (/ dbias) and clears them
-__global__ void ln_fold_kernel(float* __restrict__ slots, int hidden, int na, float* dgamma, float* dbeta, float* dbias) {
-    const int c = blockIdx.x * blockDim.x + threadIdx.x;
-    if (c >= na * hidden) return;
+// adds the rows of the partials workspace ([nrows][na][hidden], one row per block of the backward kernel) into dgamma / dbeta (/ dbias):
+// a block is 64 columns x 16 row groups (one wave each), every wave has its ~nrows / 16 loads in flight together, the groups meet in LDS
+// and are added in group order -- the sum does not depend on who ran when
+__global__ __launch_bounds__(1024) void ln_fold_rows_kernel(const float* __restrict__ part, int nrows, int hidden, int na, float* dgamma,
+                                                            float* dbeta, float* dbias) {
+    __shared__ float sh[16][64];
+    const int col = blockIdx.x * 64 + (threadIdx.x & 63), grp = threadIdx.x >> 6;
+    const size_t ld = (size_t)na * hidden;
     float v[4] = {0.f, 0.f, 0.f, 0.f};
-#pragma unroll 2
-    for (int s = 0; s < LN_SLOTS; s += 4) {
+    int r = grp;
+    for (; r + 48 < nrows; r += 64) {
 #pragma unroll
-        for (int j = 0; j < 4; ++j) { v[j] += slots[(size_t)(s + j) * na * hidden + c]; slots[(size_t)(s + j) * na * hidden + c] = 0.f; }
+        for (int j = 0; j < 4; ++j) v[j] += part[(size_t)(r + 16 * j) * ld + col];
     }
-    const float t = (v[0] + v[1]) + (v[2] + v[3]);
-    if (c < hidden) dgamma[c] += t; else if (c < 2 * hidden) dbeta[c - hidden] += t; else dbias[c - 2 * hidden] += t;
+    for (; r < nrows; r += 16) v[0] += part[(size_t)r * ld + col];
+    sh[grp][threadIdx.x & 63] = (v[0] + v[1]) + (v[2] + v[3]);
+    __syncthreads();
+    if (grp == 0) {
+        float t = 0.f;
+#pragma unroll
+        for (int j = 0; j < 16; ++j) t += sh[j][threadIdx.x];
+        if (col < hidden) dgamma[col] += t; else if (col < 2 * hidden) dbeta[col - hidden] += t; else dbias[col - 2 * hidden] += t;
+    }
 }
 
 // ------------------------------------------------------------------------------------------
@@ -666,11 +711,12 @@ extern "C" int vbg_dropout_add_ln_bwd(const float* dy, const float* xhat, const 
     VBG_CHECK_ARG(hidden > 0 && hidden % 256 == 0 && hidden <= 256 * LN_V && drop_p >= 0.f && drop_p < 1.f);
     VBG_CHECK_ARG(((uintptr_t)dy | (uintptr_t)xhat | (uintptr_t)gamma | (uintptr_t)dx | (uintptr_t)dres) % 16 == 0);
     if (rows <= 0) return VBG_OK;
-    VBG_LAUNCH(dropout_add_ln_bwd_kernel<0>, dim3(cdiv(rows, 4 * LN_WROWS)), dim3(256), 0, (hipStream_t)stream, dy, xhat, rstd, rows,
-               hidden, gamma, drop_threshold(drop_p), 1.0f / (1.0f - drop_p), seed, sid, dx, dres, dgamma, dbeta, slots_ws,
+    const int wrows = slots_ws ? ln_bwd_wrows(rows) : 2, nblk = cdiv(rows, 4 * wrows);
+    VBG_LAUNCH(dropout_add_ln_bwd_kernel<0>, dim3(nblk), dim3(256), 0, (hipStream_t)stream, dy, xhat, rstd, rows,
+               hidden, gamma, drop_threshold(drop_p), 1.0f / (1.0f - drop_p), seed, sid, dx, dres, dgamma, dbeta, slots_ws, wrows,
                (unsigned short*)nullptr, 0, 0ll, dx_amax);
-    if (slots_ws) VBG_LAUNCH(ln_fold_kernel, dim3(cdiv(2 * hidden, 256)), dim3(256), 0, (hipStream_t)stream, slots_ws, hidden, 2, dgamma, dbeta,
-                             (float*)nullptr);
+    if (slots_ws) VBG_LAUNCH(ln_fold_rows_kernel, dim3(2 * hidden / 64), dim3(1024), 0, (hipStream_t)stream, slots_ws, nblk, hidden, 2, dgamma,
+                             dbeta, (float*)nullptr);
     VBG_LAUNCH_RET();
 }
 
@@ -683,10 +729,11 @@ extern "C" int vbg_dropout_add_ln_bwd_planes(const float* dy, const float* xhat,
     VBG_CHECK_ARG(((uintptr_t)dy | (uintptr_t)xhat | (uintptr_t)gamma | (uintptr_t)dres) % 16 == 0);
     VBG_CHECK_ARG(ldp % 4 == 0 && ldp >= hidden && plane % 4 == 0 && plane >= (long long)rows * ldp && ((uintptr_t)dx_planes & 7) == 0);
     if (rows <= 0) return VBG_OK;
-    VBG_LAUNCH(dropout_add_ln_bwd_kernel<1>, dim3(cdiv(rows, 4 * LN_WROWS)), dim3(256), 0, (hipStream_t)stream, dy, xhat, rstd, rows,
-               hidden, gamma, drop_threshold(drop_p), 1.0f / (1.0f - drop_p), seed, sid, (float*)nullptr, dres, dgamma, dbeta, slots3_ws,
+    const int wrows = ln_bwd_wrows(rows), nblk = cdiv(rows, 4 * wrows);
+    VBG_LAUNCH(dropout_add_ln_bwd_kernel<1>, dim3(nblk), dim3(256), 0, (hipStream_t)stream, dy, xhat, rstd, rows,
+               hidden, gamma, drop_threshold(drop_p), 1.0f / (1.0f - drop_p), seed, sid, (float*)nullptr, dres, dgamma, dbeta, slots3_ws, wrows,
                dx_planes, ldp, plane, (unsigned*)nullptr);
-    VBG_LAUNCH(ln_fold_kernel, dim3(cdiv(3 * hidden, 256)), dim3(256), 0, (hipStream_t)stream, slots3_ws, hidden, 3, dgamma, dbeta, dbias_accum);
+    VBG_LAUNCH(ln_fold_rows_kernel, dim3(3 * hidden / 64), dim3(1024), 0, (hipStream_t)stream, slots3_ws, nblk, hidden, 3, dgamma, dbeta, dbias_accum);
     VBG_LAUNCH_RET();
 }
 
@@ -700,10 +747,11 @@ extern "C" int vbg_dropout_add_ln_bwd_pair(const float* dy, const float* xhat, c
     VBG_CHECK_ARG(((uintptr_t)dy | (uintptr_t)xhat | (uintptr_t)gamma | (uintptr_t)dres) % 16 == 0);
     VBG_CHECK_ARG(ldp % 4 == 0 && ldp >= hidden && plane % 4 == 0 && plane >= (long long)rows * ldp && ((uintptr_t)dx_pair & 7) == 0);
     if (rows <= 0) return VBG_OK;
-    VBG_LAUNCH(dropout_add_ln_bwd_kernel<2>, dim3(cdiv(rows, 4 * LN_WROWS)), dim3(256), 0, (hipStream_t)stream, dy, xhat, rstd, rows,
-               hidden, gamma, drop_threshold(drop_p), 1.0f / (1.0f - drop_p), seed, sid, (float*)nullptr, dres, dgamma, dbeta, slots3_ws,
+    const int wrows = ln_bwd_wrows(rows), nblk = cdiv(rows, 4 * wrows);
+    VBG_LAUNCH(dropout_add_ln_bwd_kernel<2>, dim3(nblk), dim3(256), 0, (hipStream_t)stream, dy, xhat, rstd, rows,
+               hidden, gamma, drop_threshold(drop_p), 1.0f / (1.0f - drop_p), seed, sid, (float*)nullptr, dres, dgamma, dbeta, slots3_ws, wrows,
                dx_pair, ldp, plane, dx_amax, dy_amax, dx_bound);
-    VBG_LAUNCH(ln_fold_kernel, dim3(cdiv(3 * hidden, 256)), dim3(256), 0, (hipStream_t)stream, slots3_ws, hidden, 3, dgamma, dbeta, dbias_accum);
+    VBG_LAUNCH(ln_fold_rows_kernel, dim3(3 * hidden / 64), dim3(1024), 0, (hipStream_t)stream, slots3_ws, nblk, hidden, 3, dgamma, dbeta, dbias_accum);
     VBG_LAUNCH_RET();
 }
 
@@ -810,6 +858,6 @@ extern "C" int vbg_row_softmax(const float* x, int rows, int cols, float* y, voi
     VBG_LAUNCH_RET();
 }
 
-extern "C" int vbg_ln_slots(void) { return LN_SLOTS; }
+extern "C" int vbg_ln_bwd_ws_rows(int rows) { return rows > 0 ? cdiv(rows, 4 * ln_bwd_wrows(rows)) : 0; }
 
 extern "C" int vbg_version(void) { return VBG_VERSION; }

@@ -115,7 +115,7 @@ SIGNATURES = {
     "vbg_embed_ln_bwd": (c_int, [c_vp, c_vp, c_vp, c_vp, c_vp, c_int, c_int, c_vp, c_f, c_ull, c_ull, c_vp, c_vp, c_vp, c_vp, c_vp, c_vp]),
     "vbg_dropout_add_ln_fwd": (c_int, [c_vp, c_vp, c_int, c_int, c_vp, c_vp, c_f, c_f, c_ull, c_ull, c_vp, c_vp, c_vp, c_vp]),
     "vbg_dropout_add_ln_fwd_planes": (c_int, [c_vp, c_vp, c_int, c_int, c_vp, c_vp, c_f, c_f, c_ull, c_ull, c_vp, c_vp, c_vp, c_vp, c_int, c_ll, c_vp, c_int, c_ll, c_vp]),
-    "vbg_ln_slots": (c_int, []),
+    "vbg_ln_bwd_ws_rows": (c_int, [c_int]),
     "vbg_dropout_add_ln_bwd": (c_int, [c_vp, c_vp, c_vp, c_int, c_int, c_vp, c_f, c_ull, c_ull, c_vp, c_vp, c_vp, c_vp, c_vp, c_vp, c_vp]),
     "vbg_dropout_add_ln_bwd_pair": (c_int, [c_vp, c_vp, c_vp, c_int, c_int, c_vp, c_f, c_ull, c_ull, c_vp, c_int, c_ll, c_vp, c_vp, c_vp, c_vp, c_vp, c_vp, c_vp, c_vp, c_vp]),
     "vbg_dropout_add_ln_bwd_planes": (c_int, [c_vp, c_vp, c_vp, c_int, c_int, c_vp, c_f, c_ull, c_ull, c_vp, c_int, c_ll, c_vp, c_vp, c_vp, c_vp, c_vp, c_vp]),

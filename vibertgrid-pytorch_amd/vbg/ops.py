@@ -1289,26 +1289,22 @@ def dropout_add_ln_fwd(x, res, gamma, beta, eps, p, seed, sid, out_planes=None, 
 _LN_WS = {}
 
 
-def _ln_workspace(device, hidden):
-    """persistent zero workspace of the LayerNorm backward (the kernel pair leaves it zero again); one per device and stream"""
-    key = (device, hidden, raw_stream(device))
+def _ln_workspace(device, hidden, rows, na=2):
+    """partials workspace of the LayerNorm backward ([blocks of the kernel][na][hidden] fp32, uninitialised: every block stores its row,
+    the fold launch reads them all); one per device and stream, grown on demand"""
+    key = (device, hidden, na, raw_stream(device))
+    need = int(lib.vbg_ln_bwd_ws_rows(rows)) * na * hidden
     ws = _LN_WS.get(key)
-    if ws is None:
-        ws = _LN_WS[key] = torch.zeros((int(lib.vbg_ln_slots()) * 2 * hidden,), device=device, dtype=f32)
+    if ws is None or ws.numel() < need:
+        ws = _LN_WS[key] = torch.empty((need,), device=device, dtype=f32)
     return ws
-
-
-_LN_WS3 = {}
 
 
 def dropout_add_ln_bwd_planes(dy, xhat, rstd, gamma, p, seed, sid, dgamma, dbeta, dbias):
     """LayerNorm backward with dx as planes (-> Planes, dres) and dbias += column sums of dx in the same pass"""
     rows, hidden = xhat.shape
     dev = xhat.device
-    key = (dev, hidden, raw_stream(dev))
-    ws = _LN_WS3.get(key)
-    if ws is None:
-        ws = _LN_WS3[key] = torch.zeros((int(lib.vbg_ln_slots()) * 3 * hidden,), device=dev, dtype=f32)
+    ws = _ln_workspace(dev, hidden, rows, 3)
     pdx = planes_empty(rows, hidden, dev)
     assert pdx.ld == hidden
     dres = torch.empty_like(xhat)
@@ -1323,10 +1319,7 @@ def dropout_add_ln_bwd_pair(dy, xhat, rstd, gamma, p, seed, sid, dgamma, dbeta, 
     dbias += column sums of dx"""
     rows, hidden = xhat.shape
     dev = xhat.device
-    key = (dev, hidden, raw_stream(dev))
-    ws = _LN_WS3.get(key)
-    if ws is None:
-        ws = _LN_WS3[key] = torch.zeros((int(lib.vbg_ln_slots()) * 3 * hidden,), device=dev, dtype=f32)
+    ws = _ln_workspace(dev, hidden, rows, 3)
     qdx = pair_empty(rows, hidden, dev)
     assert qdx.ld == hidden
     dres = torch.empty_like(xhat)
@@ -1341,7 +1334,7 @@ def dropout_add_ln_bwd(dy, xhat, rstd, gamma, p, seed, sid, dgamma, dbeta, dx_am
     rows, hidden = xhat.shape
     dx = torch.empty_like(xhat)
     dres = torch.empty_like(xhat)
-    ws = _ln_workspace(xhat.device, hidden) if rows >= 512 else None
+    ws = _ln_workspace(xhat.device, hidden, rows) if rows >= 512 else None
     check(lib.vbg_dropout_add_ln_bwd(P(dy), P(xhat), P(rstd), rows, hidden, P(gamma), p, seed, sid, P(dx), P(dres), P(dgamma),
                                      P(dbeta), P(ws), P(dx_amax), _stream()), "vbg_dropout_add_ln_bwd")
     return dx, dres
