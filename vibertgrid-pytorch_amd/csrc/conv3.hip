@@ -981,6 +981,39 @@ __global__ void conv3_wgrad_reduce_kernel(const float4* __restrict__ slab, int n
     dW[i] = s;
 }
 
+// the same for many strips over a small dW (the [64 x 9 x 64] blocks of the first trunk stage: 256 strips, 9216 float4 -- 36 blocks of the
+// kernel above, every thread 256 dependent-in-order loads: 64 us): a block is 64 float4 columns x 16 strip groups (one wave each), every
+// thread has its nsplit / 16 loads in flight together, the groups meet in LDS and are added in group order -- a fixed order as well
+__global__ __launch_bounds__(1024) void conv3_wgrad_reduce_par_kernel(const float4* __restrict__ slab, int nsplit, long long n4,
+                                                                      float4* __restrict__ dW) {
+    __shared__ float4 sh[16][64];
+    const int c = threadIdx.x & 63, g = threadIdx.x >> 6;
+    const long long i = (long long)blockIdx.x * 64 + c;
+    float4 a = make_float4(0.f, 0.f, 0.f, 0.f);
+    if (i < n4) {
+        int k = g;
+        for (; k + 48 < nsplit; k += 64) {
+            float4 v[4];
+#pragma unroll
+            for (int j = 0; j < 4; ++j) v[j] = slab[(long long)(k + 16 * j) * n4 + i];
+#pragma unroll
+            for (int j = 0; j < 4; ++j) { a.x += v[j].x; a.y += v[j].y; a.z += v[j].z; a.w += v[j].w; }
+        }
+        for (; k < nsplit; k += 16) {
+            const float4 v = slab[(long long)k * n4 + i];
+            a.x += v.x; a.y += v.y; a.z += v.z; a.w += v.w;
+        }
+    }
+    sh[g][c] = a;
+    __syncthreads();
+    if (g == 0 && i < n4) {
+        float4 s = dW[i];
+#pragma unroll
+        for (int j = 0; j < 16; ++j) { s.x += sh[j][c].x; s.y += sh[j][c].y; s.z += sh[j][c].z; s.w += sh[j][c].w; }
+        dW[i] = s;
+    }
+}
+
 }  // namespace vbg
 
 extern "C" int vbg_conv3x3_wgrad_strips(int B, int H, int W, int Cs, int Cout) {
@@ -1039,8 +1072,14 @@ extern "C" int vbg_conv3x3_wgrad(const float* dy, const float* x, float* dw, flo
     }
     if (slab) {
         const long long n4 = (long long)Cout * 9 * Cs / 4;
-        hipLaunchKernelGGL(vbg::conv3_wgrad_reduce_kernel, dim3((unsigned)((n4 + 255) / 256)), dim3(256), 0, (hipStream_t)stream,
-                           reinterpret_cast<const float4*>(slab), nsplit, n4, reinterpret_cast<float4*>(dw));
+        // (many strips over a small dW: strips in parallel as well; VBG_CONV3W_REDUCE_PAR=0 keeps the one-thread-per-element kernel)
+        static const int par_from = getenv("VBG_CONV3W_REDUCE_PAR") ? atoi(getenv("VBG_CONV3W_REDUCE_PAR")) : 32;
+        if (par_from > 0 && nsplit >= par_from)
+            hipLaunchKernelGGL(vbg::conv3_wgrad_reduce_par_kernel, dim3((unsigned)((n4 + 63) / 64)), dim3(1024), 0, (hipStream_t)stream,
+                               reinterpret_cast<const float4*>(slab), nsplit, n4, reinterpret_cast<float4*>(dw));
+        else
+            hipLaunchKernelGGL(vbg::conv3_wgrad_reduce_kernel, dim3((unsigned)((n4 + 255) / 256)), dim3(256), 0, (hipStream_t)stream,
+                               reinterpret_cast<const float4*>(slab), nsplit, n4, reinterpret_cast<float4*>(dw));
     }
     VBG_LAUNCH_RET();
 }

@@ -1054,13 +1054,19 @@ def conv3w_ok(B, H, W, Cs, Cout, kh, kw, stride, pad) -> bool:
     """shapes the row-reuse weight-gradient kernel takes (csrc/conv3.hip): default split form, strips of at least 8 k-tiles"""
     roi = H == 7 and W == 7 and _CONV3_ROI[0]              # region maps: four two-row chunks per image
     if not (_CONV3[0] and _SPLIT3[0] and not _amp_generic() and kh == 3 and kw == 3 and stride == 1 and pad == 1 and (W % 16 == 0 or roi)
-            and Cs % 32 == 0 and Cout % 128 == 0 and (3 * W + 18) * Cs < (1 << 28)):       # (64-wide filters: the generic kernel is faster)
+            and Cs % 32 == 0 and (Cout % 128 == 0 or (_CONV3W_N64[0] and Cout % 64 == 0 and Cs % 64 == 0))
+            and (3 * W + 18) * Cs < (1 << 28)):
         return False
     strips = int(lib.vbg_conv3x3_wgrad_strips(B, H, W, Cs, Cout))
     return strips >= 1 and (B * 4 if roi else B * H * W // 16) // strips >= _CONV3W_MIN[0]
 
 
 _CONV3W_MIN = [int(os.environ.get("VBG_CONV3W_MIN", "8"))]
+# odd multiples of 64 filters (the 64 -> 64 convolutions of the first trunk stage) on the row-reuse weight-gradient kernel's [64 x 9 x 64]
+# blocks in the fp16 form instead of the generic fp32-MFMA product: 116 -> 40 us + a 9.5 us strip reduction per layer at cfg2 (round 5;
+# until the strips were reduced in parallel -- conv3_wgrad_reduce_par_kernel -- the 256 slabs of a 9216-float4 dW took 64 us to add and
+# the generic kernel was as fast).  VBG_CONV3W_N64=0: the generic product
+_CONV3W_N64 = [os.environ.get("VBG_CONV3W_N64", "1") != "0"]
 
 
 def conv3x3_wgrad(dy, x, dw_ohwi, slabs=True, f16x2=False, dy_amax=None, x_amax=None):
