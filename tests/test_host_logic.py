@@ -78,7 +78,9 @@ def test_dispatch_predicates():
     # wide 3x3 / stride-1 convolutions of cfg2 (batch 8): row-reuse kernels, fp16 form for forward, input and weight gradient
     assert ops.conv3_ok(8, 128, 128, 256, 256, 3, 3, 1, 1, fwd=True) and ops.conv3_f16_bwd_ok(8, 128, 128, 256, 256, 3, 3, 1, 1)
     assert ops.conv3_f16_wgrad_ok(8, 128, 128, 256, 256, 3, 3, 1, 1) and ops.conv3_f16_wgrad_ok(8, 16, 16, 512, 512, 3, 3, 1, 1)
-    assert not ops.conv3_ok(8, 128, 128, 256, 256, 3, 3, 2, 1) and not ops.conv3_f16_wgrad_ok(8, 128, 128, 64, 64, 3, 3, 1, 1)
+    assert not ops.conv3_ok(8, 128, 128, 256, 256, 3, 3, 2, 1)
+    # 64 -> 64 weight gradients: the row-reuse kernel's [64 x 9 x 64] blocks since the end of round 5 (64 filters need a multiple of 64 channels)
+    assert ops.conv3_f16_wgrad_ok(8, 128, 128, 64, 64, 3, 3, 1, 1) and not ops.conv3_f16_wgrad_ok(8, 128, 128, 32, 64, 3, 3, 1, 1)
     # the late trunk stages (256 channels at 32 x 32: 128 tiles, 512 at 16 x 16: 64): forward and input gradient on the row-reuse
     # kernel with several workgroups per tile; without that form the input gradient falls back to the generic kernel
     assert ops.conv3_ok(8, 32, 32, 256, 256, 3, 3, 1, 1, fwd=True) and ops.conv3_ok(8, 32, 32, 256, 256, 3, 3, 1, 1)
