@@ -448,6 +448,22 @@ def main():
     launches, flops, ms, mfma_flops = prof.summary()
     c3_ms = sum(e0.elapsed_time(e1) for _, _, e0, e1 in c3rec)
     c3_fl, c3_exec = sum(r[0] for r in c3rec), sum(r[0] * r[1] for r in c3rec)
+    # In the step as it runs the encoder's launches share the chip with the CNN's first stage (second stream, VBG_OVERLAP): the step is
+    # shorter, every overlapped launch longer -- the figures above are those of the launches AS RUN (what a kernel trace of this command
+    # shows).  One more pass on ONE stream gives the same launches alone on the chip: `roofline*.single_stream`.
+    single = None
+    if ops.overlap_enabled() and world == 1:
+        ops.set_overlap(False)
+        prof1, c3rec1 = ops.GemmProfiler(OP_DENSE_K, OP_DENSE_K, False), []
+        ops.set_gemm_profiler(prof1)
+        ops.set_conv3_profiler(c3rec1)
+        timed_leg(1)
+        ops.set_gemm_profiler(None)
+        ops.set_conv3_profiler(None)
+        ops.set_overlap(True)
+        l1, f1, ms1, mf1 = prof1.summary()
+        c3_ms1 = sum(e0.elapsed_time(e1) for _, _, e0, e1 in c3rec1)
+        single = {"nt": (l1, ms1, mf1), "c3": (len(c3rec1), c3_ms1, sum(r[0] * r[1] for r in c3rec1))}
 
     h2d_leg = None
     if not args.h2d and not args.no_h2d_leg:      # the same steps with the batch uploaded inside every step (SURVEY §8d step body)
@@ -617,6 +633,16 @@ def main():
                                "piece_products_per_product": round(pp_c3, 3), "traffic": traffic_c3, "traffic_source": traffic_c3_src,
                                "launches": len(c3rec), "avg_us": round(1e3 * c3_ms / len(c3rec), 2), "ms_per_step": round(c3_ms / args.steps, 3),
                                "vs_fp32_mfma_peak": round(c3_fl / c3_ms / 1e9 / PEAK_F32_TF, 4)}
+            if single is not None and single["c3"][1] > 0 and single["nt"][1] > 0:
+                how = "the same launches in a pass with everything on ONE stream (VBG_OVERLAP=0): alone on the chip"
+                n1, m1, x1 = single["nt"]
+                nt["single_stream"] = {"frac": round(x1 / m1 / 1e9 / mfma_peak, 4), "avg_us": round(1e3 * m1 / max(n1, 1), 2),
+                                       "ms_per_step": round(m1 / (args.steps + 1), 3), "how": how}          # (the pass runs one warm-up step)
+                n1, m1, x1 = single["c3"]
+                c3["single_stream"] = {"frac": round(x1 / m1 / 1e9 / mfma_peak, 4), "avg_us": round(1e3 * m1 / max(n1, 1), 2),
+                                       "ms_per_step": round(m1 / (args.steps + 1), 3), "how": how}
+                nt["as_run"] = c3["as_run"] = ("`frac` / `avg_us` are the launches as they run in the step: the encoder on a second stream beside the "
+                                               "CNN's first stage -- a shorter step made of longer launches; `single_stream` is the kernel alone")
             # `roofline` = the family that takes more of the step (ms_per_step); the other one rides beside it under its own name
             if c3["ms_per_step"] >= nt["ms_per_step"]:
                 out["roofline"], out["roofline_nt"] = c3, nt

@@ -197,7 +197,7 @@ class ViBERTgridNet(nn.Module):
         gen = self.BERTgrid_generator
         # the part of the CNN in front of the early fusion does not need the grid: enqueue it first, so the host-side packing of
         # the token windows / index tables of the encoder runs behind ~3 ms of device work instead of an idle device
-        if ops.overlap_enabled() and batch.is_cuda:
+        if ops.overlap_enabled() and batch.is_cuda and self._overlap_safe():
             # ... and the encoder goes on the side stream (vbg/ops.py): its workgroups and the CNN's fill each other's idle CUs.
             # autograd runs every backward node on the stream of its forward, so the encoder's backward overlaps the backward of
             # the CNN in front of the early fusion the same way; JoinSideFn brings the two streams together at the end of backward
@@ -217,6 +217,28 @@ class ViBERTgridNet(nn.Module):
         grid = gen._scatter((H, W), emb_cat, boxes, box_off, box_doc, B, 0)
         p_fuse = self.backbone.stage2(pre, grid)
         return emb_cat, p_fuse
+
+    def _overlap_safe(self) -> bool:
+        """May the encoder run on the side stream in this call?  Only where it pays and where nobody reads gradients behind the library's
+        back.  (i) Training steps: a single-document `inference()` is host-bound and the extra stream traffic costs it 3 % (5.06 -> 5.21
+        ms).  (ii) The encoder's weight gradients are written by kernels on the side stream straight into the flat gradient views
+        (autograd sees `None`): vbg.optim.FlatReducer is told per parameter and its staging stream waits for the side stream, the end of
+        backward() joins the streams for whatever the caller enqueues next -- but torch's DistributedDataParallel copies `.grad` into its
+        buckets from a hook on the AccumulateGrad node, which the engine runs on the caller's stream WITHOUT an event for an undefined
+        gradient: it would read gradients the side stream is still writing (measured: the second step's loss of the stock DDP route off
+        by 2.5e-4 instead of 1e-6, tests/test_gpu_ddp.py).  So: inside a process group, one stream unless every flat group this model
+        is homed in is collected by a live FlatReducer."""
+        if not torch.is_grad_enabled():
+            return False
+        if torch.distributed.is_available() and torch.distributed.is_initialized():
+            home = self.__dict__.get("_vbg_home_state")
+            if home is None or Fn.GRAD_READY[0] is None:
+                return False
+            for g in home.groups:
+                r = getattr(g, "_vbg_reducer", None)
+                if r is None or r() is None or Fn.GRAD_READY[0] != r()._param_ready:
+                    return False
+        return True
 
     def inference(self, image: Tuple[torch.Tensor], seg_indices: Tuple[torch.Tensor], coors: torch.Tensor, corpus: torch.Tensor,
                   mask: torch.Tensor):

@@ -31,7 +31,7 @@ def _stream():
 # backward; enqueued on two HIP streams the workgroups of one fill the CUs the other leaves idle (a 198-tile plane product
 # covers 0.77 of the chip, a grouped weight-gradient launch 0.84).  `VBG_OVERLAP=0` puts everything back on one stream.
 # ----------------------------------------------------------------------------------------------
-_OVERLAP = [os.environ.get("VBG_OVERLAP", "0") != "0"]
+_OVERLAP = [os.environ.get("VBG_OVERLAP", "1") != "0"]
 _SIDE = {}
 
 

@@ -598,6 +598,9 @@ class FlatReducer:
         if self.sync_bn_mode in ("shared communicator", "direct RCCL communicator on the compute stream") and self.overlap and not self.static_graph:
             self.overlap = False       # graphs not known to be rank-invariant: every bucket from finish(), a rank-invariant point
         Fn.GRAD_READY[0] = self._param_ready      # sunk gradients (written by the wgrad kernels) report here
+        import weakref
+        for o in optimizers:                      # (ViBERTgridNet._overlap_safe: these groups' gradients are collected by a reducer that
+            o.group._vbg_reducer = weakref.ref(self)      #  knows about the side streams)
         cap = int(bucket_mb * (1 << 20) / 4)
         for o in optimizers:
             if not self.dry:
