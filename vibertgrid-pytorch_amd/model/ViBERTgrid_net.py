@@ -202,6 +202,7 @@ class ViBERTgridNet(nn.Module):
             # autograd runs every backward node on the stream of its forward, so the encoder's backward overlaps the backward of
             # the CNN in front of the early fusion the same way; JoinSideFn brings the two streams together at the end of backward
             main, side = torch.cuda.current_stream(batch.device), ops.side_stream(batch.device)
+            Fn.SIDE_OK[0] = True                # (until forward() returns: the graph will hold a JoinSideFn node)
             side.wait_stream(main)              # inputs / parameters written on the caller's stream so far
             pre = self.backbone.stage1(batch)
             with torch.cuda.stream(side):
@@ -249,6 +250,7 @@ class ViBERTgridNet(nn.Module):
             emb_cat, p_fuse = self._features(batch, packed, B, H, W, seg_indices, corpus, mask)
         finally:
             self.BERTgrid_generator.release_host()
+            Fn.SIDE_OK[0] = False
         roi = self.grid_roi_align_net(p_fuse, icoors, None, packed=packed)
         fuse = self.late_fusion_net(roi, emb_cat)
         return self.field_type_classification_head.inference(fuse)
@@ -262,6 +264,7 @@ class ViBERTgridNet(nn.Module):
                 return self._forward(image, seg_indices, segment_classes, coors, corpus, mask)
         finally:
             self.BERTgrid_generator.release_host()
+            Fn.SIDE_OK[0] = False
 
     def _home(self):
         """Flat parameter / gradient storage, owned by the model (vbg.optim.home_parameters): built at the first training forward on

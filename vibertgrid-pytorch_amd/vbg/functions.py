@@ -34,6 +34,9 @@ def _c(t):
 # when a sunk gradient is complete so the bucket all-reduce can start, exactly like a post-accumulate hook would.
 # ----------------------------------------------------------------------------------------------
 GRAD_READY = [None]        # callable(param) or None
+# set by ViBERTgridNet for the duration of a forward that put its encoder on the side stream (the graph then holds a JoinSideFn node, whose
+# end-of-backward callback joins every side stream): backward nodes built meanwhile may use side streams of their own
+SIDE_OK = [False]
 
 
 def wgrad_dest(w):
@@ -314,6 +317,7 @@ class ConvFn(torch.autograd.Function):
         w4 = ohwi(w)
         y, col, _ = _conv_any(x, w4, stride, pad, b, w_owner=w, x_amax=ctx.x_amax)
         ctx.stride, ctx.pad, ctx.has_bias = stride, pad, b is not None
+        ctx.side_ok = SIDE_OK[0]
         ctx.w_ref, ctx.b_ref = w, b
         ctx.save_for_backward(x, w4, col)
         return y
@@ -328,8 +332,19 @@ class ConvFn(torch.autograd.Function):
         f16_d = ctx.needs_input_grad[0] and ops.conv3_f16_bwd_ok(B_, H_, W_, Cout_, Cin_, kh, kw, ctx.stride, ctx.pad)
         f16_w = col is None and ops.conv3_f16_wgrad_ok(B_, H_, W_, Cin_, Cout_, kh, kw, ctx.stride, ctx.pad)
         dy_amax = ops.amax(dy) if (f16_d or f16_w) else None
+        if ctx.side_ok and ctx.needs_input_grad[0] and sinks(ctx.w_ref) and ops.conv_wgrad_stream_enabled(2):
+            # (as in ConvBnFn: the weight gradient beside the input gradient, on the conv weight-gradient stream)
+            cur, ws = torch.cuda.current_stream(dy.device), ops.side_stream(dy.device, "cwgrad")
+            ws.wait_stream(cur)
+            with torch.cuda.stream(ws):
+                dw = _conv_wgrad_any(dy, x, col, tuple(w4.shape), ctx.stride, ctx.pad, ctx.w_ref, dy_amax=dy_amax, x_amax=ctx.x_amax)
+                for t in (dy, x, col):
+                    if t is not None:
+                        t.record_stream(ws)
+            assert dw is None
+        else:
+            dw = _conv_wgrad_any(dy, x, col, tuple(w4.shape), ctx.stride, ctx.pad, ctx.w_ref, dy_amax=dy_amax, x_amax=ctx.x_amax)
         dx = ops.conv2d_dgrad(dy, w4, tuple(x.shape), ctx.stride, ctx.pad, dy_amax=dy_amax, w_owner=ctx.w_ref) if ctx.needs_input_grad[0] else None
-        dw = _conv_wgrad_any(dy, x, col, tuple(w4.shape), ctx.stride, ctx.pad, ctx.w_ref, dy_amax=dy_amax, x_amax=ctx.x_amax)
         db = _bias_grad(ctx.b_ref, dy.view(-1, dy.shape[-1])) if ctx.has_bias else None
         return dx, dw, db, None, None
 
@@ -401,6 +416,7 @@ class ConvBnFn(torch.autograd.Function):
         if y_amax is not None:
             y._vbg_amax = (y_amax, y._version)
         ctx.fold = fold
+        ctx.side_ok = SIDE_OK[0]
         ctx.cfg = (stride, pad, relu, training, count, res is not None, sync)
         ctx.w_ref, ctx.affine = w, (gamma, beta)
         ctx.save_for_backward(x, w4, col, z, y if relu else None, mean, invstd, gamma, count_dev)
@@ -443,9 +459,24 @@ class ConvBnFn(torch.autograd.Function):
         x, w4, col, z, y, mean, invstd, gamma, count_dev = ctx.saved_tensors
         stride, pad, relu, training, count, has_res, sync = ctx.cfg
         dz = dz2.view(z.shape)
+        dres = dres2.view(z.shape) if has_res else None
+        if ctx.side_ok and ctx.needs_input_grad[0] and sinks(ctx.w_ref) and ops.conv_wgrad_stream_enabled():
+            # the weight gradient goes straight into the flat gradient view and nothing else in this backward reads it: it runs on a
+            # stream of its own beside the input gradient, which the layer below waits for -- two launches that each leave most of the
+            # chip idle (the one-round launches of the late trunk stages) share it.  The operands stay reserved for that stream when this
+            # node releases them; JoinSideFn's end-of-backward callback / FlatReducer's staging stream wait for it.
+            cur, ws = torch.cuda.current_stream(dz.device), ops.side_stream(dz.device, "cwgrad")
+            ws.wait_stream(cur)
+            with torch.cuda.stream(ws):
+                dw = _conv_wgrad_any(dz, x, col, tuple(w4.shape), stride, pad, ctx.w_ref, dy_amax=dz_amax, x_amax=ctx.x_amax)
+                for t in (dz2, x, col):
+                    if t is not None:
+                        t.record_stream(ws)
+            assert dw is None
+            dx = ops.conv2d_dgrad(dz, w4, tuple(x.shape), stride, pad, dy_amax=dz_amax, w_owner=ctx.w_ref)
+            return dx, None, dgamma, dbeta, None, None, dres, None, None, None, None, None, None, None
         dx = ops.conv2d_dgrad(dz, w4, tuple(x.shape), stride, pad, dy_amax=dz_amax, w_owner=ctx.w_ref) if ctx.needs_input_grad[0] else None
         dw = _conv_wgrad_any(dz, x, col, tuple(w4.shape), stride, pad, ctx.w_ref, dy_amax=dz_amax, x_amax=ctx.x_amax)
-        dres = dres2.view(z.shape) if has_res else None
         return dx, dw, dgamma, dbeta, None, None, dres, None, None, None, None, None, None, None
 
 
@@ -631,6 +662,7 @@ class BertLayerFn(torch.autograd.Function):
         ntok, hid = x.shape
         H, dh = meta.heads, meta.dh
         dev = x.device
+        ctx.side_ok = SIDE_OK[0]            # (this forward runs on the encoder's side stream: the graph holds the node that joins the streams)
         fused_qkv = _back_to_back(wq, wk, wv) and _back_to_back(bq, bk, bv)
         planes = ops.planes_enabled() and hid % 32 == 0 and wi.shape[0] % 32 == 0
         flash = planes and dh == 64 and meta.maxlen <= 512 and ops.flash_enabled()
@@ -994,7 +1026,7 @@ class BertLayerFn(torch.autograd.Function):
             fresh.append(d_ is None)
             dests.append(d_ if d_ is not None else torch.zeros_like(wp))
         jobs = [(pdfo, pg, dests[0]), (pdh, px1, dests[1]), (pdao, pctx, dests[2]), (pdqkv, px, dw_qkv)]
-        if qkv_sunk and not any(fresh) and ops.overlap_enabled() and ops.wgrad_stream_enabled():
+        if qkv_sunk and not any(fresh) and ctx.side_ok and ops.wgrad_stream_enabled():
             # every destination is a flat gradient buffer nothing else in this backward touches: the launch goes on the
             # weight-gradient stream and shares the chip with the backward of the layer below.  The operands stay reserved for
             # that stream when this node releases them; JoinSideFn's callback / FlatReducer's staging stream wait for it.

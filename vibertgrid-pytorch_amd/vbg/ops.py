@@ -56,6 +56,15 @@ def set_wgrad_stream(on: bool):
     _WGRAD_STREAM[0] = bool(on)
 
 
+_CONV_WGRAD_STREAM = [int(os.environ.get("VBG_CONV_WGRAD_STREAM", "2"))]
+
+
+def conv_wgrad_stream_enabled(level: int = 1) -> bool:
+    """weight gradients of the conv + BatchNorm nodes on a stream of their own, beside the input gradient of the same node (level 2:
+    those of the plain convolution nodes -- FPN, heads -- as well)"""
+    return int(_CONV_WGRAD_STREAM[0]) >= level
+
+
 def side_stream(device, name: str = "side") -> "torch.cuda.Stream":
     """the side stream `name` of `device` (created on first use)"""
     idx = torch.device(device).index
@@ -791,8 +800,10 @@ AMAX_WORDS, AMAX_STRIDE = 64, 32          # include/vbg.h VBG_AMAX_WORDS / VBG_A
 def amax_slot(device):
     """a fresh ZERO amax slot (64 int32 words 128 bytes apart whose max is the bit pattern of a tensor's largest magnitude: vbg_amax and
     the amax outputs of bn_apply / bn_bwd_apply max INTO it).  Slots come from a zero-filled pool (one 2 MB fill launch per 256
-    slots); an exhausted pool is replaced, never rewound, so a slot saved for backward stays valid"""
-    key = (device.type, device.index)
+    slots); an exhausted pool is replaced, never rewound, so a slot saved for backward stays valid.  One pool per STREAM: the fill
+    of a fresh pool is ordered in front of every use of its slots by the stream itself (with one pool for all streams, a pool created
+    by the encoder's side stream handed its next slots to the CNN's stream, whose kernels could run before the fill)"""
+    key = (device.type, device.index, raw_stream(device))
     ent = _AMAX_POOL.get(key)
     if ent is None or ent[1] >= ent[0].shape[0]:
         ent = _AMAX_POOL[key] = [torch.zeros((256, AMAX_WORDS * AMAX_STRIDE), device=device, dtype=torch.int32), 0]
