@@ -803,7 +803,7 @@ def amax_slot(device):
     slots); an exhausted pool is replaced, never rewound, so a slot saved for backward stays valid.  One pool per STREAM: the fill
     of a fresh pool is ordered in front of every use of its slots by the stream itself (with one pool for all streams, a pool created
     by the encoder's side stream handed its next slots to the CNN's stream, whose kernels could run before the fill)"""
-    key = (device.type, device.index, raw_stream(device))
+    key = (device.type, device.index, raw_stream(device) if device.type == "cuda" else 0)
     ent = _AMAX_POOL.get(key)
     if ent is None or ent[1] >= ent[0].shape[0]:
         ent = _AMAX_POOL[key] = [torch.zeros((256, AMAX_WORDS * AMAX_STRIDE), device=device, dtype=torch.int32), 0]
