@@ -243,6 +243,8 @@ def main():
     ap.add_argument("--cpu-threads", type=int, default=0, help="threads of the CPU baseline (default: all cores AND 16, both reported)")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-syncbn", action="store_true")
+    ap.add_argument("--no-single-stream-pass", action="store_true",
+                    help="skip the extra pass that times the roofline families' launches with everything on one stream (profiled runs: the kernel trace then holds launches as they run only)")
     ap.add_argument("--syncbn-comm", default="direct", choices=["direct", "shared", "own"],
                     help="N > 1: SyncBatchNorm statistics as ncclAllReduce calls of a communicator of the library's own on the compute stream "
                          "(default, vbg/rccl.py), on the gradient buckets' torch.distributed communicator (shared: one communicator, one order of "
@@ -452,7 +454,7 @@ def main():
     # shorter, every overlapped launch longer -- the figures above are those of the launches AS RUN (what a kernel trace of this command
     # shows).  One more pass on ONE stream gives the same launches alone on the chip: `roofline*.single_stream`.
     single = None
-    if ops.overlap_enabled() and world == 1:
+    if ops.overlap_enabled() and world == 1 and not args.no_single_stream_pass:
         ops.set_overlap(False)
         prof1, c3rec1 = ops.GemmProfiler(OP_DENSE_K, OP_DENSE_K, False), []
         ops.set_gemm_profiler(prof1)

@@ -85,7 +85,8 @@ for src, dst in (("gemm_shapes.txt", "gemm_shapes.txt"), ("bench_line.json", "be
                  ("conv3_pw.txt", "conv3_pw.txt"), ("step_conv3.txt", "step_conv3.txt"), ("conv3_forms.txt", "conv3_forms.txt"),
                  ("attn_shapes.txt", "attn_shapes.txt"), ("step_plane.txt", "step_plane.txt"), ("plane_pair_shapes.txt", "plane_pair_shapes.txt"),
                  ("bench_amp_line.json", "bench_amp_line.json"), ("infer_latency.txt", "infer_latency.txt"),
-                 ("stock_loop_phases.txt", "stock_loop_phases.txt"), ("forced_reducer.txt", "forced_reducer.txt")):
+                 ("stock_loop_phases.txt", "stock_loop_phases.txt"), ("forced_reducer.txt", "forced_reducer.txt"),
+                 ("stream_race.txt", "stream_race.txt")):
     if os.path.exists(G + src):
         shutil.copy(G + src, P + dst)
 if os.path.exists(G + "prof_amp/amp_kernel_stats.csv"):
