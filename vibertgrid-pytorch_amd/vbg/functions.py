@@ -332,7 +332,7 @@ class ConvFn(torch.autograd.Function):
         f16_d = ctx.needs_input_grad[0] and ops.conv3_f16_bwd_ok(B_, H_, W_, Cout_, Cin_, kh, kw, ctx.stride, ctx.pad)
         f16_w = col is None and ops.conv3_f16_wgrad_ok(B_, H_, W_, Cin_, Cout_, kh, kw, ctx.stride, ctx.pad)
         dy_amax = ops.amax(dy) if (f16_d or f16_w) else None
-        if ctx.side_ok and ctx.needs_input_grad[0] and sinks(ctx.w_ref) and ops.conv_wgrad_stream_enabled(2):
+        if ctx.side_ok and ctx.needs_input_grad[0] and sinks(ctx.w_ref) and ops.conv_wgrad_stream_enabled(2, dy.numel() // dy.shape[-1]):
             # (as in ConvBnFn: the weight gradient beside the input gradient, on the conv weight-gradient stream)
             cur, ws = torch.cuda.current_stream(dy.device), ops.side_stream(dy.device, "cwgrad")
             ws.wait_stream(cur)
@@ -460,7 +460,7 @@ class ConvBnFn(torch.autograd.Function):
         stride, pad, relu, training, count, has_res, sync = ctx.cfg
         dz = dz2.view(z.shape)
         dres = dres2.view(z.shape) if has_res else None
-        if ctx.side_ok and ctx.needs_input_grad[0] and sinks(ctx.w_ref) and ops.conv_wgrad_stream_enabled():
+        if ctx.side_ok and ctx.needs_input_grad[0] and sinks(ctx.w_ref) and ops.conv_wgrad_stream_enabled(1, dz2.shape[0]):
             # the weight gradient goes straight into the flat gradient view and nothing else in this backward reads it: it runs on a
             # stream of its own beside the input gradient, which the layer below waits for -- two launches that each leave most of the
             # chip idle (the one-round launches of the late trunk stages) share it.  The operands stay reserved for that stream when this

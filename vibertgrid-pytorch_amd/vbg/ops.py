@@ -59,9 +59,15 @@ def set_wgrad_stream(on: bool):
 _CONV_WGRAD_STREAM = [int(os.environ.get("VBG_CONV_WGRAD_STREAM", "2"))]
 
 
-def conv_wgrad_stream_enabled(level: int = 1) -> bool:
+_CONV_WGRAD_STREAM_MAXPIX = [int(os.environ.get("VBG_CONV_WGRAD_STREAM_MAXPIX", "0"))]
+
+
+def conv_wgrad_stream_enabled(level: int = 1, pixels: int = 0) -> bool:
     """weight gradients of the conv + BatchNorm nodes on a stream of their own, beside the input gradient of the same node (level 2:
-    those of the plain convolution nodes -- FPN, heads -- as well)"""
+    those of the plain convolution nodes -- FPN, heads -- as well); pixels: B * H * W of the node's output (VBG_CONV_WGRAD_STREAM_MAXPIX > 0:
+    only nodes with at most that many)"""
+    if _CONV_WGRAD_STREAM_MAXPIX[0] > 0 and pixels > _CONV_WGRAD_STREAM_MAXPIX[0]:
+        return False
     return int(_CONV_WGRAD_STREAM[0]) >= level
 
 
