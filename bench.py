@@ -233,6 +233,52 @@ def stock_loop_leg(make_net, batch, dev, world, steps, warm, amp=False, resident
     return dt, last
 
 
+def _free_port():
+    import socket
+    sk = socket.socket()
+    sk.bind(("127.0.0.1", 0))
+    port = sk.getsockname()[1]
+    sk.close()
+    return port
+
+
+def self_launch(n, argv):
+    """`python bench.py --gpus N` (N > 1) without a launcher around it -- the form the driver's BENCH command has: re-exec this file under
+    `python -m torch.distributed.run --nnodes 1 --nproc-per-node N` on a free loopback port, the way the reference is started
+    (readme.md:87 `torchrun --nnodes 1 --nproc_per_node N`, pipeline/distributed_utils.py:74-77 reads RANK / WORLD_SIZE / LOCAL_RANK).
+    Rank 0's JSON line is the only thing the ranks write to stdout, and they inherit this process's stdout: nothing to relay.
+    `--syncbn-comm direct` (the opt-in second communicator, vbg/rccl.py) is first PROBED: three dry steps in a run of their own under a
+    20 s stall watchdog; if the probe stalls or fails the timed run falls back to `--syncbn-comm shared` with a warning -- a deadlock
+    between two communicators cannot be undone from inside the process that is stuck in it, a parent can.  Returns the exit code."""
+    import signal
+    import subprocess
+
+    def run(extra, limit, quiet=False):
+        cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", f"--nproc-per-node={n}", "--master-addr", "127.0.0.1",
+               "--master-port", str(_free_port()), os.path.abspath(__file__)] + argv + extra
+        print("[bench] launching: " + " ".join(cmd), file=sys.stderr, flush=True)
+        p = subprocess.Popen(cmd, start_new_session=True, env=dict(os.environ, VBG_SELF_LAUNCHED="1"), stdout=2 if quiet else None)   # (a probe's stdout goes to stderr)
+        try:
+            return p.wait(timeout=limit)
+        except subprocess.TimeoutExpired:
+            try:
+                os.killpg(p.pid, signal.SIGKILL)          # (the session this function started: launcher + ranks, nothing else)
+            except ProcessLookupError:
+                pass
+            p.wait()
+            return -9
+
+    direct = any(a == "direct" for i, a in enumerate(argv) if i and argv[i - 1] == "--syncbn-comm") or "--syncbn-comm=direct" in argv
+    if direct and ("--launch-check" not in argv or os.environ.get("VBG_PROBE_IN_CHECK") == "1"):
+        rc = run(["--comm-probe"], float(os.environ.get("VBG_PROBE_LIMIT", "420")), quiet=True)
+        if rc != 0:
+            print(f"[bench] WARNING: the two-communicator probe (--syncbn-comm direct) did not pass (exit code {rc}); "
+                  "falling back to --syncbn-comm shared (one communicator, one order of collectives)", file=sys.stderr, flush=True)
+            argv = [a for a in argv if a != "--syncbn-comm=direct"]
+            argv = [a for i, a in enumerate(argv) if not (a == "--syncbn-comm" or (i and argv[i - 1] == "--syncbn-comm"))] + ["--syncbn-comm", "shared", "--comm-fallback"]
+    return run([], None)
+
+
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
@@ -245,10 +291,14 @@ def main():
     ap.add_argument("--no-syncbn", action="store_true")
     ap.add_argument("--no-single-stream-pass", action="store_true",
                     help="skip the extra pass that times the roofline families' launches with everything on one stream (profiled runs: the kernel trace then holds launches as they run only)")
-    ap.add_argument("--syncbn-comm", default="direct", choices=["direct", "shared", "own"],
-                    help="N > 1: SyncBatchNorm statistics as ncclAllReduce calls of a communicator of the library's own on the compute stream "
-                         "(default, vbg/rccl.py), on the gradient buckets' torch.distributed communicator (shared: one communicator, one order of "
-                         "collectives), or on a second torch.distributed communicator (own) -- the A/Bs")
+    ap.add_argument("--syncbn-comm", default="shared", choices=["direct", "shared", "own"],
+                    help="N > 1: SyncBatchNorm statistics on the gradient buckets' torch.distributed communicator (shared, the default: one "
+                         "communicator, one order of collectives), as ncclAllReduce calls of a communicator of the library's own on the compute "
+                         "stream (direct, vbg/rccl.py: opt-in, probed by the self-launcher before the timed run), or on a second torch.distributed "
+                         "communicator (own) -- the A/Bs")
+    ap.add_argument("--comm-probe", action="store_true", help=argparse.SUPPRESS)        # child of self_launch: three dry steps under a watchdog
+    ap.add_argument("--comm-fallback", action="store_true", help=argparse.SUPPRESS)     # set by self_launch when the probe failed
+    ap.add_argument("--launch-check", action="store_true", help=argparse.SUPPRESS)      # launcher plumbing only (CPU test): rendezvous + one all-reduce
     ap.add_argument("--no-ddp-overlap", action="store_true", help="N > 1: launch every gradient bucket after backward (A/B of the overlap)")
     ap.add_argument("--dist-timeout", type=int, default=int(os.environ.get("VBG_DIST_TIMEOUT", "240")),
                     help="N > 1: process-group timeout in seconds; a stalled step also prints which bucket / SyncBatchNorm collective every rank is at")
@@ -274,6 +324,31 @@ def main():
     args = ap.parse_args()
     if args.cpu_baseline_only:          # child process of the default run: the CPU oracle at that many threads, one JSON line
         print(json.dumps(cpu_baseline(args.cpu_baseline_only, args.cpu_baseline_shape)), flush=True)
+        return
+    if args.gpus > 1 and "RANK" not in os.environ:
+        # the driver's command form is `python bench.py --gpus N ...`: become the launcher
+        raise SystemExit(self_launch(args.gpus, sys.argv[1:]))
+    if args.launch_check:
+        # what the launcher hands a rank, proven without a GPU (tests/test_bench_launcher.py, gloo): rendezvous on 127.0.0.1, one all-reduce
+        import datetime
+        if args.comm_probe and os.environ.get("VBG_PROBE_FAIL") == "1":          # (test hook: a probe that stalls ends with the watchdog's code)
+            os._exit(17)
+        world, rank = int(os.environ.get("WORLD_SIZE", "1")), int(os.environ.get("RANK", "0"))
+        os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
+        os.environ.setdefault("GLOO_SOCKET_IFNAME", "lo")
+        real_stdout = os.dup(1)          # (as in the real run: gloo's connection notes must not share stdout with the JSON line)
+        sys.stdout.flush()
+        os.dup2(2, 1)
+        dist.init_process_group(os.environ.get("VBG_DIST_BACKEND", "gloo"), rank=rank, world_size=world, timeout=datetime.timedelta(seconds=60))
+        t = torch.tensor([float(rank + 1)])
+        dist.all_reduce(t)
+        seen = dist.get_world_size()
+        dist.barrier()
+        if rank == 0:
+            os.write(real_stdout, (json.dumps({"launch_check": True, "world_size": seen, "gpus_arg": args.gpus, "rank_sum": float(t.item()),
+                                               "self_launched": os.environ.get("VBG_SELF_LAUNCHED") == "1", "syncbn_comm": args.syncbn_comm,
+                                               "comm_fallback": bool(args.comm_fallback)}) + "\n").encode())
+        dist.destroy_process_group()
         return
 
     # stdout carries the ONE JSON line and nothing else: file descriptor 1 is pointed at stderr for the rest of the run (librccl prints a
@@ -402,6 +477,18 @@ def main():
             dist.barrier()          # `if distributed: torch.distributed.barrier()` of the reference loop (pipeline/train_val_utils.py:286-287)
         return val
 
+    if args.comm_probe:
+        # child of self_launch: does the two-communicator configuration make progress on THIS node?  Three dry steps; a step that makes no
+        # progress for 20 s ends the process with code 17 (the watchdog prints which bucket / statistics collective every rank is at)
+        reducer.start_watchdog(20.0, exit_code=17)
+        for _ in range(3):
+            step()
+        if world > 1:
+            dist.barrier()
+        torch.cuda.synchronize()
+        if rank == 0:
+            print(f"[bench] communicator probe passed: 3 steps, {int(vbg_functions.SyncCtx.seq)} SyncBatchNorm collectives on '{reducer.sync_bn_mode}'", file=sys.stderr, flush=True)
+        os._exit(0)                     # (no teardown of two communicators in a probe)
     for _ in range(args.warmup):
         last = step()
 
@@ -598,6 +685,11 @@ def main():
                        "global_batch": B * world, "seq_len": 512, "parallelism": f"dp{world}" + ("+syncbn" if sync_bn else ""),
                        **({"step_barrier": not args.no_step_barrier, "syncbn_comm": reducer.sync_bn_mode, "ddp_overlap": reducer.overlap,
                            "buckets": len(reducer.buckets), "backend": dist.get_backend(), "syncbn_collectives": int(vbg_functions.SyncCtx.seq),
+                           "world_size": dist.get_world_size(),          # as torch.distributed sees it (== --gpus, asserted above)
+                           "comm_nranks": {"buckets": dist.get_world_size(),
+                                           "syncbn": (vbg_functions.SyncCtx.direct.nranks() if vbg_functions.SyncCtx.direct is not None else dist.get_world_size())},
+                           "launcher": "self (bench.py re-executed under torch.distributed.run)" if os.environ.get("VBG_SELF_LAUNCHED") == "1" else "external",
+                           **({"syncbn_comm_fallback": "the --syncbn-comm direct probe failed; shared communicator used"} if args.comm_fallback else {}),
                            **({"forced_reducer_on_one_rank": True} if forced else {})} if (world > 1 or forced) else {}),
                        "last_loss": round(float(last), 4), **({"ranks_in_sync": ranks_in_sync} if ranks_in_sync is not None else {}), **({"h2d_in_step": packed_src.nbytes()} if args.h2d else {})},
             # algorithmic (fp32-equivalent, PAD-free) TFLOP/s of the whole step per GPU, SURVEY.md 8d, and as a fraction of the matrix-core

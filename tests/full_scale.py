@@ -50,6 +50,9 @@ CASES["cfg2e8"] = dict(CASES["cfg2"], plain=True, bn_frozen=True, B=8)
 # BASELINE configs[3] at its stated per-GPU batch: eight char-level documents (S = 512: ~3 900 RoIs through the region-map kernels) in ONE step of
 # the reference, library's own dispatch
 CASES["cfg4e8"] = dict(CASES["cfg4"], plain=True, bn_frozen=True, B=8)
+# BASELINE configs[2] at its stated per-GPU batch (round 6): eight FUNSD-layout documents -- own-layout resnet-34 (early
+# fusion WITH bias, `conv_N_x` names), 4 classes -- in ONE step of the reference, library's own dispatch (cfg3 was held at B = 2 only)
+CASES["cfg3e8"] = dict(CASES["cfg3"], plain=True, bn_frozen=True, B=8)
 # BASELINE configs[4] at its stated per-GPU batch: SIXTEEN 1024 x 1024 documents.  One step of the reference at that batch does not fit this
 # container (the reference's segmentation head keeps [16, 256, 1024, 1024] fp32 activations: 17 GB each, 64 GB of RAM), so the fixture is
 # assembled from EIGHT steps of the reference on consecutive pairs of the sixteen documents (`chunk`): with frozen BatchNorm the documents

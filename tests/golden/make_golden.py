@@ -925,7 +925,7 @@ def main():
     import pipeline.custom_loss as L
     import pipeline.transform as T
 
-    which = sys.argv[1:] or ["transform", "windows", "aggregate", "scatter", "losses", "labels", "bert", "backbone", "backbone_d", "e2e", "e2e_roberta", "losses_bce", "e2e_modes", "e2e_amp", "full_cfg2", "full_cfg4", "full_cfg5", "full_cfg2p", "full_cfg2e", "full_cfg4e", "full_cfg5e", "full_cfg3", "full_cfg3e", "full_cfg2e8", "full_cfg4e8", "full_cfg1", "full_cfg5e16"]
+    which = sys.argv[1:] or ["transform", "windows", "aggregate", "scatter", "losses", "labels", "bert", "backbone", "backbone_d", "e2e", "e2e_roberta", "losses_bce", "e2e_modes", "e2e_amp", "full_cfg2", "full_cfg4", "full_cfg5", "full_cfg2p", "full_cfg2e", "full_cfg4e", "full_cfg5e", "full_cfg3", "full_cfg3e", "full_cfg2e8", "full_cfg4e8", "full_cfg1", "full_cfg5e16", "full_cfg3e8"]
     if "transform" in which:
         gen_transform(T)
     if "windows" in which:
@@ -954,7 +954,7 @@ def main():
         gen_e2e_modes(V, tmp)
     if "e2e_amp" in which:
         gen_e2e_amp(V, tmp)
-    for name in ("cfg2", "cfg4", "cfg5", "cfg2p", "cfg2e", "cfg4e", "cfg5e", "cfg3", "cfg3e", "cfg2e8", "cfg4e8", "cfg1"):
+    for name in ("cfg2", "cfg4", "cfg5", "cfg2p", "cfg2e", "cfg4e", "cfg5e", "cfg3", "cfg3e", "cfg2e8", "cfg4e8", "cfg1", "cfg3e8"):
         if "full_" + name in which:
             gen_full(V, tmp, name)
     if "full_cfg2e8_amp" in which:     # the reference under autocast at the benchmark's batch (fp16 if the CPU kernels take it, else bf16)

@@ -1,0 +1,133 @@
+#!/usr/bin/env python3
+"""Does any kernel read memory nobody wrote, or leave part of an output unwritten?
+
+In a loop of identical steps the caching allocator hands every call site the block it had in the step before, so "uninitialised"
+memory holds exactly the values the same tensor had one step earlier -- a kernel that reads past what was written, or does not write
+all of its output, is invisible until something shifts the allocation pattern (a second stream that holds blocks longer, a different
+batch).  This tool makes it visible deterministically, on ONE stream: torch.empty / empty_like are replaced by versions that fill the
+fresh tensor with NaN (floats) or 0x7f7f7f7f (ints); one cfg2 step (bench.py's model and batch) per allocation SITE with only that site
+poisoned, loss and every flat gradient compared with the unpoisoned step.  A site whose poison reaches a result is reported.
+
+    python tools/poison_check.py [--sites-only]"""
+import argparse, contextlib, os, random, sys, tempfile, traceback
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+sys.path.insert(0, ROOT); sys.path.insert(0, os.path.join(ROOT, "vibertgrid-pytorch_amd"))
+import torch
+import bench
+
+PKG = os.path.join(ROOT, "vibertgrid-pytorch_amd")
+_orig_empty, _orig_empty_like = torch.empty, torch.empty_like
+STATE = {"mode": "off", "site": None, "sites": {}}
+
+
+def _site():
+    for fr in traceback.extract_stack()[:-2][::-1]:
+        if fr.filename.startswith(PKG):
+            return f"{os.path.relpath(fr.filename, PKG)}:{fr.lineno} ({fr.name})"
+    return None
+
+
+def _poison(t):
+    if not t.is_cuda or t.numel() == 0:
+        return t
+    if t.is_floating_point():
+        t.fill_(float("nan"))
+    elif t.dtype in (torch.int32, torch.int64, torch.int16):
+        t.fill_(0x7f7f if t.dtype == torch.int16 else 0x7f7f7f7f)
+    return t
+
+
+def _wrap(orig):
+    def f(*a, **k):
+        t = orig(*a, **k)
+        if STATE["mode"] == "off":
+            return t
+        s = _site()
+        if s is None:
+            return t
+        if STATE["mode"] == "collect":
+            STATE["sites"][s] = STATE["sites"].get(s, 0) + 1
+        elif STATE["mode"] == "all" or (STATE["mode"] == "one" and s == STATE["site"]):
+            _poison(t)
+        return t
+    return f
+
+
+def main():
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--sites-only", action="store_true")
+    args = ap.parse_args()
+    torch.empty, torch.empty_like = _wrap(_orig_empty), _wrap(_orig_empty_like)
+    from vbg import ops
+    from vbg.batch import PackedBatch
+    from vbg.optim import FusedAdamW, FusedSGD, split_parameters
+    dev = torch.device("cuda", 0)
+    with contextlib.redirect_stdout(sys.stderr):
+        torch.manual_seed(42)
+        net = bench.build_model(tempfile.mkdtemp(prefix="vbg_poison_")).to(dev).train()
+    cnn, bert = split_parameters(net)
+    opts = [FusedSGD(cnn, dev, lr=0.0), FusedAdamW(bert, dev, lr=0.0)]
+    groups = [o.group for o in opts]
+    batch = PackedBatch.pack(*bench.synthetic_batch(8, 512, 512, 512, 128, bench.NCLS, bench.VOCAB, 1234)).to(dev)
+    gen = net.BERTgrid_generator
+    ops.set_overlap(False); ops._CONV_WGRAD_STREAM[0] = 0; ops.set_wgrad_stream(False)
+
+    def one():
+        for o in opts:
+            o.zero_grad()
+        gen._step_seed = 0x5EED
+        random.seed(7)
+        loss = net(*batch)
+        loss.backward()
+        out = [o.group.gflat.clone() for o in opts]
+        torch.cuda.synchronize()
+        return float(loss.detach()), out
+
+    one()
+    l0, g0 = one()
+    STATE["mode"] = "collect"
+    one()
+    STATE["mode"] = "off"
+    sites = sorted(STATE["sites"])
+    print(f"{len(sites)} allocation sites of the package in one training step ({sum(STATE['sites'].values())} torch.empty / empty_like calls)", flush=True)
+    if args.sites_only:
+        for s in sites:
+            print(f"  {STATE['sites'][s]:4d} x {s}")
+        return
+
+    def report(tag, l, g):
+        bad = []
+        for grp, a, b in zip(groups, g0, g):
+            for n, p, off in zip(grp.names, grp.params, grp.offsets):
+                x, y = a[off:off + p.numel()], b[off:off + p.numel()]
+                nan = int(torch.isnan(y).sum())
+                nx = float(x.norm())
+                r = float((x - y).norm()) / nx if (nx > 0 and nan == 0) else (float("nan") if nan else 0.0)
+                if "key.bias" in n and not nan:          # (analytically zero -- softmax is shift-invariant --: what is there is rounding noise)
+                    continue
+                if nan or r > 2e-5:
+                    bad.append((n, nan, r))
+        ok = (l == l0 or abs(l - l0) <= 1e-6 * abs(l0)) and not bad
+        if not ok:
+            print(f"POISON REACHES A RESULT  {tag}: loss {l!r} (clean {l0!r}); {len(bad)} parameter gradients differ; first: "
+                  + "; ".join(f"{n} nan={nan} rel={r:.1e}" for n, nan, r in bad[:6]), flush=True)
+        return ok
+
+    clean = 0
+    for s in sites:
+        STATE["mode"], STATE["site"] = "one", s
+        try:
+            l, g = one()
+        finally:
+            STATE["mode"] = "off"
+        if report(s, l, g):
+            clean += 1
+    print(f"{clean} of {len(sites)} sites: poison in the fresh tensor reaches neither the loss nor any gradient", flush=True)
+    STATE["mode"] = "all"
+    l, g = one()
+    STATE["mode"] = "off"
+    print("every site poisoned at once:", "clean" if report("ALL", l, g) else "see above", flush=True)
+
+
+if __name__ == "__main__":
+    main()

@@ -774,9 +774,11 @@ __global__ __launch_bounds__(256, 2) void attn_kernel(const vbg_attn_desc p) {
 __global__ __launch_bounds__(64) void attn_mask_kernel(const int* __restrict__ seq_len, const long long* __restrict__ mask_off, int heads,
                                                        int maxlen, unsigned thr16, unsigned long long seed, unsigned long long sid,
                                                        unsigned* __restrict__ mask_q, unsigned* __restrict__ mask_k, int ngroups,
-                                                       unsigned long long sid_stride, long long layer_words) {
+                                                       unsigned long long sid_stride, long long layer_words, int g0) {
+    // (ngroups = (sequence, head) groups per layer IN THIS LAUNCH, g0 = the first of them: more than 65 535 groups are cut into
+    //  several launches by the callers -- grid z limit)
     const int layer = blockIdx.z / ngroups;
-    const int g = blockIdx.z - layer * ngroups, seq = g / heads, head = g % heads;
+    const int g = g0 + (int)blockIdx.z - layer * ngroups, seq = g / heads, head = g % heads;
     sid += (unsigned long long)layer * sid_stride;
     mask_q += (long long)layer * layer_words;
     mask_k += (long long)layer * layer_words;
@@ -864,9 +866,12 @@ extern "C" int vbg_attn_mask(const int* seq_len, const long long* mask_off, int 
     VBG_CHECK_ARG(nseq >= 0 && heads > 0 && maxlen >= 0 && drop_p > 0.f && drop_p < 1.f);
     if (nseq == 0 || maxlen == 0) return VBG_OK;
     VBG_CHECK_ARG(seq_len && mask_off && mask_q && mask_k);
-    const int nkb = (maxlen + 31) / 32;
-    VBG_LAUNCH(attn_mask_kernel, dim3((nkb + 1) / 2, nkb, nseq * heads), dim3(64), 0, (hipStream_t)stream, seq_len, mask_off, heads, maxlen,
-               vbg_attn_drop_thr16(drop_p), seed, stream_id, mask_q, mask_k, nseq * heads, 0ull, 0ll);
+    const int nkb = (maxlen + 31) / 32, ngroups = nseq * heads;
+    for (int g0 = 0; g0 < ngroups; g0 += 65535) {
+        const int ng = (ngroups - g0 < 65535) ? (ngroups - g0) : 65535;
+        VBG_LAUNCH(attn_mask_kernel, dim3((nkb + 1) / 2, nkb, ng), dim3(64), 0, (hipStream_t)stream, seq_len, mask_off, heads, maxlen,
+                   vbg_attn_drop_thr16(drop_p), seed, stream_id, mask_q, mask_k, ng, 0ull, 0ll, g0);
+    }
     VBG_LAUNCH_RET();
 }
 
@@ -877,13 +882,22 @@ extern "C" int vbg_attn_mask_layers(const int* seq_len, const long long* mask_of
     if (nseq == 0 || maxlen == 0 || nlayers == 0) return VBG_OK;
     VBG_CHECK_ARG(seq_len && mask_off && mask_q && mask_k);
     const int nkb = (maxlen + 31) / 32, ngroups = nseq * heads;
-    VBG_CHECK_ARG(ngroups <= 65535);
+    if (ngroups > 65535) {                                 // a layer alone exceeds the grid z limit: per layer, groups in chunks
+        for (int l = 0; l < nlayers; ++l)
+            for (int g0 = 0; g0 < ngroups; g0 += 65535) {
+                const int ng = (ngroups - g0 < 65535) ? (ngroups - g0) : 65535;
+                VBG_LAUNCH(attn_mask_kernel, dim3((nkb + 1) / 2, nkb, ng), dim3(64), 0, (hipStream_t)stream, seq_len, mask_off, heads, maxlen,
+                           vbg_attn_drop_thr16(drop_p), seed, stream_id0 + (unsigned long long)l * stream_id_stride, mask_q + (long long)l * layer_words,
+                           mask_k + (long long)l * layer_words, ng, 0ull, 0ll, g0);
+            }
+        VBG_LAUNCH_RET();
+    }
     const int per = 65535 / ngroups;                       // layers per launch (grid z limit)
     for (int l0 = 0; l0 < nlayers; l0 += per) {
         const int nl = (nlayers - l0 < per) ? (nlayers - l0) : per;
         VBG_LAUNCH(attn_mask_kernel, dim3((nkb + 1) / 2, nkb, ngroups * nl), dim3(64), 0, (hipStream_t)stream, seq_len, mask_off, heads, maxlen,
                    vbg_attn_drop_thr16(drop_p), seed, stream_id0 + (unsigned long long)l0 * stream_id_stride, mask_q + (long long)l0 * layer_words,
-                   mask_k + (long long)l0 * layer_words, ngroups, stream_id_stride, layer_words);
+                   mask_k + (long long)l0 * layer_words, ngroups, stream_id_stride, layer_words, 0);
     }
     VBG_LAUNCH_RET();
 }

@@ -40,6 +40,7 @@ struct conv3_args {
     unsigned* tickets;     // [tiles] arrival counters of the split form, zero between launches
     int accumulate;
     const unsigned* a_amax; // F16 form: bits of max |X| (a device word written by the producer of X), or null: X is used as it is
+    int dbg_no_ring_guard; // VBG_DEBUG_CONV3_NO_RING_GUARD=1: leave out the round-6 barrier behind the read of k-tile 0 (tests prove they can see the race)
 };
 
 __device__ __forceinline__ __amdgpu_buffer_rsrc_t c3_rsrc(const float* base) {
@@ -521,6 +522,17 @@ __global__ __launch_bounds__(256, 2) void conv3x3_kernel(const conv3_args p) {
             bst = nst;
         };
         read_frags(p0{}, 0, 0, 0);
+        // Round 6 -- the one place where the ring's rule ("a stage is refilled only after a barrier behind its last reader") did not hold:
+        // k-tile 0 is read HERE, behind the prologue's barrier, and the first k-tile of the loop ends with the DMA of k-tile 4 into the
+        // same stage 0 -- with no barrier in between.  A wave that fell one k-tile behind its siblings right after the prologue barrier (a
+        // 64-filter k-tile is six MFMAs: ~300 clocks) read k-tile 4's filter slice as k-tile 0: one wave's 64 x 32 block of ONE tile off by one
+        // k-tile's contribution (1/6 of its magnitude), seen in 5-12 % of cfg2 steps once three streams shared the chip -- the "conv
+        // weight-gradient stream" outlier of profiles/r05_stream_race.txt (tools/stream_race_check.py --trace named the tensor, the wave
+        // and the size).  Every wave now holds k-tile 0's fragments in registers before anybody may refill the stage.
+        if (!p.dbg_no_ring_guard) {                            // (uniform: a kernel argument)
+            asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+            __builtin_amdgcn_s_barrier();
+        }
         using k0 = std::integral_constant<int, 0>;
         using k1 = std::integral_constant<int, 1>;
         using k2 = std::integral_constant<int, 2>;
@@ -1174,6 +1186,8 @@ static int conv3x3_impl(const float* x, const float* w, const unsigned short* wp
     const long long M = (long long)B * H * W;
     VBG_CHECK_ARG(M < (1ll << 31));
     a.M = (int)M; a.accumulate = accumulate; a.a_amax = x_amax; a.roi = roi ? B : 0;
+    static const int no_ring_guard = [] { const char* e = getenv("VBG_DEBUG_CONV3_NO_RING_GUARD"); return (e && e[0] == '1') ? 1 : 0; }();
+    a.dbg_no_ring_guard = no_ring_guard;
     // split form: nsplit blocks per tile meet in split_slab [tiles][nsplit][128 * 128] / split_tickets [tiles] (zero; left zero)
     const bool split = nsplit > 1;
     VBG_CHECK_ARG(nsplit >= 1 && (!split || (split_slab && split_tickets && !roi && N % (bn_req ? bn_req : 128) == 0 && ((long long)H * W) % 128 == 0)));

@@ -218,7 +218,7 @@ class BERTgridGenerator(nn.Module):
         seed = self._step_seed * 0x9E3779B1 + (torch.initial_seed() & 0xFFFFFFFF) + rank * 0x85EBCA6B
         eps = float(cfg.layer_norm_eps)
         # the attention-dropout keeps of all layers in one launch (stream ids as BertLayerFn numbers them: layer * 8)
-        flash_ok = ops.planes_enabled() and ops.flash_enabled() and dh == 64 and hidden % 32 == 0 and 0 < maxlen <= 512      # (BertLayerFn's test)
+        flash_ok = maxlen > 0 and ops.flash_ok(hidden, int(cfg.intermediate_size), dh, maxlen)      # (BertLayerFn's own test)
         meta.mask_pool = (ops.attn_mask_layers(meta, pa, seed, 0, 8, len(m.encoder.layer))
                           if (pa > 0 and flash_ok and ops.mask_pool_enabled() and torch.is_grad_enabled()) else None)
         x = Fn.BertEmbedFn.apply(emb.word_embeddings.weight, emb.position_embeddings.weight, emb.token_type_embeddings.weight,

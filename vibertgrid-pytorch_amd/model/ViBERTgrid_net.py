@@ -274,6 +274,16 @@ class ViBERTgridNet(nn.Module):
         AdamW step the views like any other parameter."""
         home = self.__dict__.get("_vbg_home_state")
         if home is None or not home.valid():
+            if home is not None:
+                # something moved the parameters (`.to()`, `.half()`, a fresh `p.data`) after an optimizer / reducer of vbg.optim was built
+                # over the old flat buffers: it would go on stepping buffers the model no longer reads -- training would silently stop
+                # updating the weights (ADVICE r5).  Rebuild the optimizer after moving the model.
+                for g in home.groups:
+                    for attr in ("_vbg_optimizer", "_vbg_reducer"):
+                        ref = getattr(g, attr, None)
+                        if ref is not None and ref() is not None:
+                            raise RuntimeError("ViBERTgridNet: the parameters left their flat storage (Module.to / .half / a new param.data) while a "
+                                               f"live {type(ref()).__name__} still steps the old buffers; move the model first, then build the optimizers")
             from vbg.optim import ModelHome
             home = ModelHome(self, track_unused=self.classifier_mode == "full")
             self.__dict__["_vbg_home_state"] = home

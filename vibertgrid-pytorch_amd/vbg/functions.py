@@ -338,9 +338,7 @@ class ConvFn(torch.autograd.Function):
             ws.wait_stream(cur)
             with torch.cuda.stream(ws):
                 dw = _conv_wgrad_any(dy, x, col, tuple(w4.shape), ctx.stride, ctx.pad, ctx.w_ref, dy_amax=dy_amax, x_amax=ctx.x_amax)
-                for t in (dy, x, col):
-                    if t is not None:
-                        t.record_stream(ws)
+                ops.reserve_for(ws, dy, x, col, dy_amax, ctx.x_amax)
             assert dw is None
         else:
             dw = _conv_wgrad_any(dy, x, col, tuple(w4.shape), ctx.stride, ctx.pad, ctx.w_ref, dy_amax=dy_amax, x_amax=ctx.x_amax)
@@ -469,9 +467,10 @@ class ConvBnFn(torch.autograd.Function):
             ws.wait_stream(cur)
             with torch.cuda.stream(ws):
                 dw = _conv_wgrad_any(dz, x, col, tuple(w4.shape), stride, pad, ctx.w_ref, dy_amax=dz_amax, x_amax=ctx.x_amax)
-                for t in (dz2, x, col):
-                    if t is not None:
-                        t.record_stream(ws)
+                # (the amax slots too: they are views of the CALLER stream's slot pool, and a pool whose last view dies -- this node's
+                # release of ctx.x_amax / dz_amax can be that moment -- goes back to the caching allocator of the caller's stream, which may
+                # hand the 2 MB block to the next slot pool and zero it while this launch is still queued: the round-5 outlier)
+                ops.reserve_for(ws, dz2, x, col, dz_amax, ctx.x_amax)
             assert dw is None
             dx = ops.conv2d_dgrad(dz, w4, tuple(x.shape), stride, pad, dy_amax=dz_amax, w_owner=ctx.w_ref)
             return dx, None, dgamma, dbeta, None, None, dres, None, None, None, None, None, None, None
@@ -665,7 +664,7 @@ class BertLayerFn(torch.autograd.Function):
         ctx.side_ok = SIDE_OK[0]            # (this forward runs on the encoder's side stream: the graph holds the node that joins the streams)
         fused_qkv = _back_to_back(wq, wk, wv) and _back_to_back(bq, bk, bv)
         planes = ops.planes_enabled() and hid % 32 == 0 and wi.shape[0] % 32 == 0
-        flash = planes and dh == 64 and meta.maxlen <= 512 and ops.flash_enabled()
+        flash = ops.flash_ok(hid, wi.shape[0], dh, meta.maxlen)
         px = pctx = px1 = pg = pqkv = qkv = P = lse = masks = kbar = None
         if not flash:
             qkv = torch.empty((ntok, 3 * hid), device=dev, dtype=f32)

@@ -82,6 +82,19 @@ def side_stream(device, name: str = "side") -> "torch.cuda.Stream":
     return s
 
 
+_RESERVE_AMAX = [os.environ.get("VBG_AMAX_RESERVE", "1") != "0"]
+
+
+def reserve_for(stream, *tensors):
+    """every operand a launch on `stream` reads that was allocated under ANOTHER stream: the caching allocator must not hand the block
+    to anybody else before that launch has run (record_stream marks the whole block, so a slot view reserves its pool).
+    VBG_AMAX_RESERVE=0 leaves the amax slots (int32 views) out -- the round-5 behaviour, kept ONLY as the A/B that names the root
+    cause of the intermittent weight-gradient mismatch (tools/stream_race_check.py --amax-pool 16)"""
+    for t in tensors:
+        if t is not None and (_RESERVE_AMAX[0] or t.dtype != torch.int32):
+            t.record_stream(stream)
+
+
 def side_streams():
     """every side stream created so far: whoever consumes results of the whole backward on another stream (the gradient
     all-reduce, vbg/optim.FlatReducer) waits for these as well"""
@@ -453,6 +466,12 @@ def set_flash(on: bool):
     _FLASH[0] = bool(on)
 
 
+def flash_ok(hidden: int, inter: int, dh: int, maxlen: int) -> bool:
+    """does an encoder layer of these dimensions run the fused attention?  ONE predicate for vbg.functions.BertLayerFn and for the
+    generator's all-layer dropout-mask launch (the two hand-written copies had drifted apart by the `inter % 32` term)"""
+    return planes_enabled() and hidden % 32 == 0 and inter % 32 == 0 and dh == 64 and maxlen <= 512 and flash_enabled()
+
+
 def flash_enabled() -> bool:
     return _FLASH[0]
 
@@ -798,6 +817,7 @@ def set_conv3_f16(on: bool):
 
 
 _AMAX_POOL = {}
+_AMAX_POOL_SLOTS = [int(os.environ.get("VBG_AMAX_POOL_SLOTS", "256"))]      # (tests shrink it to make pools turn over inside one backward)
 
 
 AMAX_WORDS, AMAX_STRIDE = 64, 32          # include/vbg.h VBG_AMAX_WORDS / VBG_AMAX_STRIDE
@@ -812,7 +832,7 @@ def amax_slot(device):
     key = (device.type, device.index, raw_stream(device) if device.type == "cuda" else 0)
     ent = _AMAX_POOL.get(key)
     if ent is None or ent[1] >= ent[0].shape[0]:
-        ent = _AMAX_POOL[key] = [torch.zeros((256, AMAX_WORDS * AMAX_STRIDE), device=device, dtype=torch.int32), 0]
+        ent = _AMAX_POOL[key] = [torch.zeros((_AMAX_POOL_SLOTS[0], AMAX_WORDS * AMAX_STRIDE), device=device, dtype=torch.int32), 0]
     i = ent[1]
     ent[1] = i + 1
     return ent[0][i]

@@ -110,6 +110,7 @@ class FlatGroup:
         self._tq = {"jobs": {}, "buf": None, "tbl": None, "tag": None, "tiles": 0}
         self._ver = {}
         self._owners = {}
+        self._armed = []                     # indices whose gradient view arm() attached in the current backward
 
     def zero_grad(self):
         self.gflat.zero_()
@@ -128,16 +129,41 @@ class FlatGroup:
         otherwise (a caller that keeps some gradients to accumulate into).  A gradient the caller left in place is accumulated into,
         as torch would."""
         # (a parameter frozen after it was homed keeps `.grad = None`: torch.optim skips it, as it would without flat storage)
-        missing = [i for i, p in enumerate(self.params) if p.grad is None and p.requires_grad]
-        if not missing:
-            return
+        missing, foreign = [], []
+        for i, (p, gv) in enumerate(zip(self.params, self.gviews)):
+            g = p.grad
+            if g is None:
+                if p.requires_grad:
+                    missing.append(i)
+            elif g is not gv:
+                foreign.append(i)
+        self._armed = missing                # (ModelHome.drop_untouched only hands None back for gradients attached HERE, in this backward)
         if len(missing) == len(self.params):
             self.gflat.zero_()
         else:
-            for i in missing:
-                self.gviews[i].zero_()
+            # one memset per contiguous RUN of missing parameters (ADVICE r5: one frozen parameter used to turn the single memset into
+            # ~400 per-parameter launches)
+            k = 0
+            while k < len(missing):
+                j = k
+                while j + 1 < len(missing) and missing[j + 1] == missing[j] + 1:
+                    j += 1
+                i0, i1 = missing[k], missing[j]
+                end = self.offsets[i1 + 1] if i1 + 1 < len(self.params) else self.total
+                self.gflat[self.offsets[i0]:end].zero_()
+                k = j + 1
         for i in missing:
             self.params[i].grad = self.gviews[i]
+        # a `.grad` that is somebody else's tensor (DistributedDataParallel's finalize_backward leaves one on a locally-unused parameter):
+        # its contents move into the flat view -- the weight-gradient kernels accumulate into the VIEW's memory (wgrad_dest), and
+        # torch.optim must see what they wrote
+        for i in foreign:
+            g = self.params[i].grad
+            gv = self.gviews[i]
+            if g.shape == gv.shape and g.device == gv.device:
+                with torch.no_grad():
+                    gv.copy_(g)
+                self.params[i].grad = gv
 
     def attach(self, p):
         """gradient view of one parameter whose `.grad` is None outside an armed backward (a Function used on its own): zeroed, attached"""
@@ -326,11 +352,16 @@ class ModelHome:
         return all(g.valid() for g in self.groups)
 
     def drop_untouched(self):
+        """end of a backward (classifier_mode full): a parameter that took no part in it gets `.grad = None` back -- but only where arm()
+        attached the view in THIS backward.  A gradient that already existed when the backward started (gradient accumulation, DDP
+        `no_sync` micro-steps) stays, as torch would have left it."""
         t = self.touched
         for g in self.groups:
-            for p in g.params:
+            for i in g._armed:
+                p = g.params[i]
                 if id(p) not in t:
                     p.grad = None
+            g._armed = []
 
 
 def _torch_defaults(cls, **kw):
@@ -369,6 +400,8 @@ class _FlatOptimizer(torch.optim.Optimizer):
         super().__init__([p for _, p in named], defaults)
         self.grad_scale = 1.0
         self.steps = 0
+        import weakref
+        self.group._vbg_optimizer = weakref.ref(self)          # (ViBERTgridNet._home: a group a live optimizer steps is never silently replaced)
 
     def zero_grad(self, set_to_none: bool = False):
         self.group.zero_grad()
@@ -551,30 +584,47 @@ class FlatReducer:
         if self.dry:
             sync_bn_group = None
         if sync_bn_group == "auto":
-            from . import rccl
-            sync_bn_group = os.environ.get("VBG_SYNCBN_GROUP", "direct" if (group is None and rccl.available()) else "default")
+            # round 6: the shared communicator is the default again.  The direct communicator has only ever run on a
+            # one-rank group, and a second ncclComm_t with collectives in flight beside ProcessGroupNCCL's is the configuration a first
+            # N > 1 run should not meet unasked: VBG_SYNCBN_GROUP=direct / sync_bn_group="direct" / bench.py --syncbn-comm direct opt in.
+            sync_bn_group = os.environ.get("VBG_SYNCBN_GROUP", "default")
+        if Fn.SyncCtx.direct is not None:          # a reducer is being rebuilt: the previous one's communicator goes first
+            try:
+                Fn.SyncCtx.direct.destroy()
+            except Exception:
+                pass
         Fn.SyncCtx.direct = None
         if sync_bn_group == "direct":
-            # THE DEFAULT on RCCL (round 5): the statistics on a communicator of this library's own, enqueued on the compute stream
-            # (vbg/rccl.py): no event hand-overs to and from ProcessGroupNCCL's stream (measured on one rank: 34.8 vs 35.8 ms per step), and -- the point at N > 1 -- never queued behind a 32 MB gradient bucket on that stream.  Two communicators
-            # then have kernels in flight during backward.  That is deadlock-free when every rank ENQUEUES them in the same relative
-            # order (streams beyond the device's hardware queues share one, and a collective's kernel parked at the head of a queue holds
-            # up whatever sits behind it): the same program on every rank issues the same sequence, which is what static_graph=True
-            # asserts -- without it the buckets leave from finish(), behind every statistics collective of the step, as on the shared
-            # communicator.
+            # OPT-IN: the statistics on a communicator of this library's own, enqueued on the compute stream (vbg/rccl.py): no event
+            # hand-overs to and from ProcessGroupNCCL's stream (measured on one rank: 34.8 vs 35.8 ms per step), and -- the point at
+            # N > 1 -- never queued behind a 32 MB gradient bucket on that stream.  Two communicators then have kernels in flight during
+            # backward.  That is deadlock-free when every rank ENQUEUES them in the same relative order (streams beyond the device's
+            # hardware queues share one, and a collective's kernel parked at the head of a queue holds up whatever sits behind it): the
+            # same program on every rank issues the same sequence, which is what static_graph=True asserts -- without it the buckets
+            # leave from finish(), behind every statistics collective of the step, as on the shared communicator.
             from . import rccl
             if group is not None or not rccl.available():
                 raise ValueError("sync_bn_group='direct' needs backend 'nccl' (RCCL) and the default process group")
             dev = optimizers[0].group.pflat.device
             Fn.SyncCtx.group = group
+            comm, err = None, None
             try:
-                Fn.SyncCtx.direct = rccl.DirectComm(dev)
+                comm = rccl.DirectComm(dev)
+            except Exception as e:
+                err = e
+            # every rank must end up on the SAME communicator: the ranks agree on success over the default group (a rank-local
+            # fallback would leave some ranks on the direct communicator and some on torch.distributed's -- mismatched collectives)
+            ok = torch.tensor([0 if comm is None else 1], device=dev, dtype=torch.int32)
+            dist.all_reduce(ok, op=dist.ReduceOp.MIN)
+            if int(ok.item()) == 1:
+                Fn.SyncCtx.direct = comm
                 self.sync_bn_mode = "direct RCCL communicator on the compute stream"
-            except Exception as e:          # (the same on every rank: a library that cannot be driven this way; collectives have not started)
+            else:
                 import sys
-                print(f"[vbg reducer] no direct RCCL communicator ({type(e).__name__}: {e}); SyncBatchNorm statistics through torch.distributed",
-                      file=sys.stderr, flush=True)
-                Fn.SyncCtx.direct = None
+                if comm is not None:
+                    comm.destroy()
+                print(f"[vbg reducer] no direct RCCL communicator on every rank ({'this rank: ' + type(err).__name__ + ': ' + str(err) if err else 'another rank failed'}); "
+                      "SyncBatchNorm statistics through torch.distributed on every rank", file=sys.stderr, flush=True)
                 sync_bn_group = "default"
         if sync_bn_group == "direct":
             pass

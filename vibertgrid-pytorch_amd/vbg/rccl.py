@@ -61,12 +61,16 @@ class DirectComm:
         self.rank, self.world = dist.get_rank(), dist.get_world_size()
         lib = _lib()
         uid = _UniqueId()
+        box = [None]
         if self.rank == 0:
-            _check(lib.ncclGetUniqueId(C.byref(uid)), "ncclGetUniqueId")
-        box = [C.string_at(C.addressof(uid), 128) if self.rank == 0 else None]          # (raw bytes: .value would stop at the first NUL)
+            # (a failure on rank 0 still reaches the broadcast below -- as None -- so that nobody waits for an id that never comes)
+            if lib.ncclGetUniqueId(C.byref(uid)) == 0:
+                box = [C.string_at(C.addressof(uid), 128)]          # (raw bytes: .value would stop at the first NUL)
         dist.broadcast_object_list(box, src=0)
-        C.memmove(C.addressof(uid), box[0], 128)
         self.comm = C.c_void_p()
+        if box[0] is None:
+            raise RuntimeError("ncclGetUniqueId failed on rank 0")
+        C.memmove(C.addressof(uid), box[0], 128)
         with torch.cuda.device(self.device):
             _check(lib.ncclCommInitRank(C.byref(self.comm), self.world, uid, self.rank), "ncclCommInitRank")
         self.calls = 0
@@ -78,6 +82,14 @@ class DirectComm:
         _check(_lib().ncclAllReduce(t.data_ptr(), t.data_ptr(), t.numel(), _DT[t.dtype], _NCCL_SUM, self.comm, C.c_void_p(stream)), "ncclAllReduce")
         self.calls += 1
         return t
+
+    def nranks(self) -> int:
+        """ranks of the communicator as RCCL itself counts them (ncclCommCount)"""
+        n = C.c_int(0)
+        lib = _lib()
+        lib.ncclCommCount.argtypes = [C.c_void_p, C.POINTER(C.c_int)]
+        _check(lib.ncclCommCount(self.comm, C.byref(n)), "ncclCommCount")
+        return int(n.value)
 
     def destroy(self):
         if self.comm:
