@@ -498,6 +498,7 @@ def main():
     t0 = time.perf_counter()
     for _ in range(args.steps):
         last = step()
+    t_enq = time.perf_counter() - t0          # the host has enqueued every timed step (what it could not run ahead of, it waited for inside)
     if world > 1:
         dist.barrier()
     torch.cuda.synchronize()
@@ -698,6 +699,9 @@ def main():
             "step_tflops": round(value / world * f_step / 1e3, 2),
             "step_frac": round(value / world * f_step / 1e3 / (PEAK_F32_TF if args.fp32_mfma else PEAK_BF16_TF / (1 if args.amp else 3)), 4),
             "step_frac_peak": round(PEAK_F32_TF if args.fp32_mfma else PEAK_BF16_TF / (1 if args.amp else 3), 1),
+            # who paces the step: the host had enqueued all timed steps after `host_enqueue_ms_per_step` x steps; `device_tail_ms` = what the
+            # device still had queued at that moment (a few ms: the device paces and the host runs ahead; ~0: the host does)
+            "host": {"enqueue_ms_per_step": round(1e3 * t_enq / args.steps, 3), "device_tail_ms": round(1e3 * (dt - t_enq), 3)},
         }
         # Roofline objects (the step is bound by the matrix cores).  Definition, the same for both: `achieved` = ALGORITHMIC
         # (fp32-equivalent, 2 M N K per product; only real pixels on the 7x7 region maps) TFLOP/s over the launches' own time -- event pairs

@@ -470,7 +470,7 @@ def _rccl_worker(rank, port, tmp):
         red = None
         if with_reducer:
             assert any(isinstance(m, torch.nn.SyncBatchNorm) for m in net.modules())
-            red = FlatReducer(opts, bucket_mb=4.0, force_enable=True, static_graph=True, sync_bn_group="auto" if mode == "direct" else "default")
+            red = FlatReducer(opts, bucket_mb=4.0, force_enable=True, static_graph=True, sync_bn_group="direct" if mode == "direct" else "auto")          # (round 6: "auto" = the shared communicator; "direct" is the opt-in)
             # (the default on RCCL: the statistics as ncclAllReduce calls of a communicator of the library's own on the compute stream,
             #  vbg/rccl.py; "shared": through torch.distributed on the buckets' communicator)
             assert red.sync_bn_mode == ("direct RCCL communicator on the compute stream" if mode == "direct" else "shared communicator")

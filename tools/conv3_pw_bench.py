@@ -14,13 +14,14 @@ from gemm_bench import report, timeit
 from vbg import ops
 
 dev = torch.device("cuda")
+GEN = torch.Generator(device=dev).manual_seed(5)
 SHAPES = [(8, 128, 128, 256, 256), (8, 128, 128, 128, 128), (8, 64, 64, 128, 128), (8, 64, 64, 256, 256), (8, 32, 32, 256, 256),
           (8, 16, 16, 512, 512), (8, 128, 128, 64, 64), (1024, 7, 7, 256, 256)]
 for (B, H, W, Ci, Co) in SHAPES:
-    x = torch.randn(B, H, W, Ci, device=dev)
-    wd = (torch.randn(Co, Ci, 3, 3, device=dev) / (3 * Ci ** 0.5)).contiguous(memory_format=torch.channels_last)
+    x = torch.randn(B, H, W, Ci, device=dev, generator=GEN)
+    wd = (torch.randn(Co, Ci, 3, 3, device=dev, generator=GEN) / (3 * Ci ** 0.5)).contiguous(memory_format=torch.channels_last)
     w4 = wd.permute(0, 2, 3, 1)
-    dy = torch.randn(B, H, W, Co, device=dev) * 1e-6
+    dy = torch.randn(B, H, W, Co, device=dev, generator=GEN) * 1e-6
     am = ops.amax(dy)
     fl = 2.0 * B * H * W * Ci * Co * 9
     tag = f"B{B} {H}x{W} {Ci}->{Co}"
@@ -32,6 +33,15 @@ for (B, H, W, Ci, Co) in SHAPES:
     report(f"dgrad in-kernel split  {tag} nsplit {nzb}", fl, timeit(lambda: ops.conv3x3(dy, wf, f16x2=True, x_amax=am)))
     report(f"dgrad PW               {tag} nsplit {nzb}", fl, timeit(lambda: ops.conv3x3(dy, w4, f16x2=True, x_amax=am, w_planes=wpf, n_out=Ci)))
     assert torch.equal(ops.conv3x3(x, w4, f16x2=True), ops.conv3x3(x, w4, f16x2=True, w_planes=wp))
+    late = ops.conv3_late_choice(B, H, W, Ci, Co)
+    if late is not None:          # the late trunk stages as the library runs them: 64-filter tiles, its split count
+        wp64, wpf64 = ops.conv3_planes(wd, w4, False, bn=late[0]), ops.conv3_planes(wd, w4, True, bn=late[0])
+        report(f"fwd   PW bn64          {tag} nsplit {late[1]}", fl, timeit(lambda: ops.conv3x3(x, w4, f16x2=True, w_planes=wp64, nsplit=late[1], bn=late[0])))
+        report(f"dgrad PW bn64          {tag} nsplit {late[1]}", fl, timeit(lambda: ops.conv3x3(dy, w4, f16x2=True, x_amax=am, w_planes=wpf64, n_out=Ci, nsplit=late[1], bn=late[0])))
+    if os.environ.get("VBG_BENCH_HASH"):          # bit-identity across builds: a checksum of the PW results
+        y = ops.conv3x3(x, w4, f16x2=True, w_planes=wp)
+        d = ops.conv3x3(dy, w4, f16x2=True, x_amax=am, w_planes=wpf, n_out=Ci)
+        print(f"hash {tag}: fwd {float(y.double().sum()):.17g} {float(y.double().abs().sum()):.17g} dgrad {float(d.double().sum()):.17g} {float(d.double().abs().sum()):.17g}", flush=True)
     if H * W % 128 == 0 and H != 7 and W < 128:
         for z in (1, 2, 3, 4, 6, 8):
             cs = z // 3 if z % 3 == 0 else z

@@ -146,13 +146,35 @@ struct c3_pipe2 {
 // ONEP (`amp`, PWM = 2 only): ONE product -- the hi pieces of both operands (x rounded to fp16: the operand of the reference's autocast
 // convolution; gradients scaled into range as in the pair form), fp32 accumulation.  The lo pieces are neither written, loaded (128-filter
 // tiles: the hi plane is the first half of a k-tile's block) nor read.
+#ifndef VBG_C3_NSB64
+#define VBG_C3_NSB64 4          // ring stages of the pipelined pre-split kernel on 64-filter tiles (4 KB each); 8 measured: no change (round 6)
+#endif
+#ifndef VBG_C3_ASMW
+#define VBG_C3_ASMW 0           // 1: the pipelined loop's activation pieces go to LDS through inline-asm ds_write_b64 (c3_lds_store_b64); measured: no change
+#endif
+// (Round 6 experiment, compiled out by default: -DVBG_C3_ASMW=1 / -DVBG_C3_NSB64=8.  Both were built on the reading that the one-round
+//  64-filter launches wait for their filter DMA; four builds, bit-identical results, every cfg2 shape within +-1 % and the step within
+//  0.2 % -- tools/calls/r6_call09.sh, gpurun_out/r6c09_*: the reading was wrong, the switches stay for the record.)
+// An LDS store the compiler does not see as one.  hipcc puts `s_waitcnt vmcnt(0)` in front of every LDS WRITE that follows an LDS-DMA in
+// program order (it cannot prove that the DMA's destination and the store do not overlap), i.e. in front of the activation pieces of
+// every third k-tile -- which waits for the filter DMA issued ONE k-tile earlier to land: the ring's lead is gone exactly where a
+// 64-filter k-tile (six MFMAs) needs it most (ISA of round 5: `s_waitcnt vmcnt(0)` + 4 ds_write_b64 in the kw = 1 tile).  The stores
+// go to the activation buffers, the DMA to the filter ring: disjoint by construction.  Ordering against the readers is what it was: the
+// explicit `s_waitcnt lgkmcnt(0)` + s_barrier that ends every k-tile.
+__device__ __forceinline__ void c3_lds_store_b64(unsigned* dst, const uint2& v) {
+    typedef __attribute__((address_space(3))) unsigned* lds_u32;
+    const unsigned addr = (unsigned)(size_t)(lds_u32)dst;
+    const unsigned long long d = ((unsigned long long)v.y << 32) | v.x;
+    asm volatile("ds_write_b64 %0, %1" ::"v"(addr), "v"(d) : "memory");
+}
+
 template <int BM, int BN, bool F16, int PWM = 0, bool ONEP = false>
 __global__ __launch_bounds__(256, 2) void conv3x3_kernel(const conv3_args p) {
     constexpr bool PW = PWM != 0;
     static_assert(!PW || (F16 && BM == 128), "pre-split weights: the fp16-pair form on 128-pixel tiles");
     static_assert(!ONEP || PWM == 2, "the one-product form exists for the pipelined pre-split kernels");
     constexpr int NT = 256, SKH = 24;
-    constexpr int NSB = 4, DPF = NSB - 1;                      // PW: stages of the filter ring / k-tiles in flight
+    constexpr int NSB = (PWM == 2 && BN == 64) ? VBG_C3_NSB64 : 4, DPF = NSB - 1;      // PW: stages of the filter ring / k-tiles in flight
     constexpr int BTILE = 64 * BN;                             // PW: bytes of one k-tile of the filter (2 planes x BN rows x 32 B)
     constexpr int NDB = BN / 64;                               // PW: 1 KiB DMA units per wave and k-tile
     constexpr int NDBE = (ONEP && NDB == 2) ? 1 : NDB;         // ... that are issued (ONEP at 128 filters: the hi plane = units 0-3 only)
@@ -423,8 +445,9 @@ __global__ __launch_bounds__(256, 2) void conv3x3_kernel(const conv3_args p) {
     set_a(kh0);
     const int nsup = (p.ksplit == 3 ? 1 : 3) * cw / 16;
     if constexpr (PWM == 2) {
-        // Ring of NSB = 4 stages; the DMA of k-tile t + 4 is issued at the END of k-tile t into the stage of k-tile t itself (its
-        // fragments were read during k-tile t - 1), and must have landed by the end of k-tile t + 2: two k-tiles of lead.
+        // Ring of NSB stages (4); the DMA of k-tile t + NSB is issued at the END of k-tile t into the
+        // stage of k-tile t itself (its fragments were read during k-tile t - 1), and must have landed by the end of k-tile t + NSB - 2:
+        // NSB - 2 k-tiles of lead.
         // What hipcc adds on its own (measured in the ISA): nothing in front of an LDS READ that follows an LDS-DMA as long as the
         // kernel has ONE LDS object, but `s_waitcnt vmcnt` for the most recent LDS-DMA in front of every LDS WRITE -- so the
         // activation super-tile is split in registers in the gaps of the MFMAs and WRITTEN at the end of its k-tile, in front of that
@@ -436,7 +459,7 @@ __global__ __launch_bounds__(256, 2) void conv3x3_kernel(const conv3_args p) {
         store_a(0);
 #pragma unroll
         for (int d = 0; d < NSB; ++d) issue_b();
-        asm volatile("s_waitcnt vmcnt(%0) lgkmcnt(0)" ::"n"(2 * NDBE) : "memory");    // k-tiles 0 and 1 have landed
+        asm volatile("s_waitcnt vmcnt(%0) lgkmcnt(0)" ::"n"((NSB - 2) * NDBE) : "memory");    // k-tiles 0 and 1 have landed
         __builtin_amdgcn_s_barrier();
         c3_u32x4 fA[2][NPL][TM], fB[2][NPL][TNF];
         auto read_frags = [&](auto par_tag, int abuf, int stage, int kw) {
@@ -482,13 +505,23 @@ __global__ __launch_bounds__(256, 2) void conv3x3_kernel(const conv3_args p) {
 #pragma unroll
             for (int i = 0; i < NAI; ++i) {
                 const int o = a_lrow[i] * (SKH / 2) + kc / 2;
+#if VBG_C3_ASMW
+                c3_lds_store_b64(&dst[o], sh[i]);
+                if constexpr (!ONEP) c3_lds_store_b64(&dst[o + PA], sl[i]);
+#else
                 *reinterpret_cast<uint2*>(&dst[o]) = sh[i];
                 if constexpr (!ONEP) *reinterpret_cast<uint2*>(&dst[o + PA]) = sl[i];
+#endif
             }
             if (wide && tid < 8) {
                 const int o = h_row * (SKH / 2) + kc / 2;
+#if VBG_C3_ASMW
+                c3_lds_store_b64(&dst[o], sh[NAI]);
+                if constexpr (!ONEP) c3_lds_store_b64(&dst[o + PA], sl[NAI]);
+#else
                 *reinterpret_cast<uint2*>(&dst[o]) = sh[NAI];
                 if constexpr (!ONEP) *reinterpret_cast<uint2*>(&dst[o + PA]) = sl[NAI];
+#endif
             }
         };
         using p0 = std::integral_constant<int, 0>;
@@ -513,10 +546,10 @@ __global__ __launch_bounds__(256, 2) void conv3x3_kernel(const conv3_args p) {
             issue_b();                                      // k-tile t + 4 into this k-tile's stage
             if constexpr (KW == 0) {
                 // k-tile t + 2 has landed: t + 3, t + 4 and the activation loads just issued may stay in flight
-                if (wide) asm volatile("s_waitcnt vmcnt(%0) lgkmcnt(0)" ::"n"(2 * NDBE + NAI + 1) : "memory");
-                else asm volatile("s_waitcnt vmcnt(%0) lgkmcnt(0)" ::"n"(2 * NDBE + NAI) : "memory");
+                if (wide) asm volatile("s_waitcnt vmcnt(%0) lgkmcnt(0)" ::"n"((NSB - 2) * NDBE + NAI + 1) : "memory");
+                else asm volatile("s_waitcnt vmcnt(%0) lgkmcnt(0)" ::"n"((NSB - 2) * NDBE + NAI) : "memory");
             } else {
-                asm volatile("s_waitcnt vmcnt(%0) lgkmcnt(0)" ::"n"(2 * NDBE) : "memory");
+                asm volatile("s_waitcnt vmcnt(%0) lgkmcnt(0)" ::"n"((NSB - 2) * NDBE) : "memory");
             }
             __builtin_amdgcn_s_barrier();
             bst = nst;

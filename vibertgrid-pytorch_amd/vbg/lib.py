@@ -11,7 +11,8 @@ import torch  # noqa: F401  -- MUST be imported before libvbg.so is dlopen'ed: p
 #                              both have to bind to the SAME libamdhip64 instance (torch ships its own copy)
 
 _HERE = os.path.dirname(os.path.abspath(__file__))
-LIB_PATH = os.path.join(os.path.dirname(_HERE), "libvbg.so")
+# VBG_LIB_PATH: another build of the SAME library (A/B measurements of compile-time switches, tools/calls/*.sh); never a different product
+LIB_PATH = os.environ.get("VBG_LIB_PATH") or os.path.join(os.path.dirname(_HERE), "libvbg.so")
 
 c_int, c_ll, c_f, c_d, c_vp, c_ull = C.c_int, C.c_longlong, C.c_float, C.c_double, C.c_void_p, C.c_ulonglong
 
