@@ -653,12 +653,22 @@ def main():
     # HBM-side bytes per launch of the same kernel: rocprofv3 PMC passes of this command (cannot be collected in-process),
     # summarised in profiles/ by the round that produced them; null when the file is absent
     def pmc_traffic(stem):
-        for rnd in ("r05", "r04", "r03", "r02", "r01"):
+        for rnd in ("r06", "r05", "r04", "r03", "r02", "r01"):
             tf = os.path.join(ROOT, "profiles", f"{rnd}_{stem}.json")
             if os.path.exists(tf):
                 with open(tf) as fh:
                     return (round(float(json.load(fh)["bytes_per_launch"]), 0),
                             f"profiles/{rnd}_{stem}.json: rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE passes of this command (counters cannot be read in-process), not this run")
+        return None, None
+    def trace_avg(fam):
+        """average launch duration of a roofline family in the committed rocprofv3 kernel trace of this command (tools/make_profiles.py)"""
+        for rnd in ("r06",):
+            tf = os.path.join(ROOT, "profiles", f"{rnd}_trace_avg.json")
+            if os.path.exists(tf):
+                with open(tf) as fh:
+                    d = json.load(fh)
+                if fam in d:
+                    return float(d[fam]["avg_us"]), f"profiles/{rnd}_trace_avg.json"
         return None, None
     traffic, traffic_src = pmc_traffic("gemm_hbm_traffic")
     traffic_c3, traffic_c3_src = pmc_traffic("conv3_hbm_traffic")
@@ -717,6 +727,11 @@ def main():
               "mfma_executed": round(mfma_rate, 1), "mfma_peak": round(mfma_peak, 1), "piece_products_per_product": round(pp_nt, 3),
               "traffic": traffic, "traffic_source": traffic_src, "launches": launches, "avg_us": round(1e3 * ms / max(launches, 1), 2),
               "ms_per_step": round(ms / args.steps, 3), "vs_fp32_mfma_peak": round(ach / PEAK_F32_TF, 4)}
+        tavg, tsrc = trace_avg("nt")
+        if tavg and launches and not (args.amp or args.fp32_mfma):
+            # `frac` with the committed kernel trace's average launch duration in place of this run's event pairs
+            nt["frac_trace"] = round(mfma_flops / launches / (tavg * 1e-6) / 1e12 / mfma_peak, 4)
+            nt["frac_trace_source"] = f"{tsrc}: {tavg:.2f} us per launch in the rocprofv3 kernel trace of this command (another run, same box class)"
         if getattr(prof, "ingest", None) and prof.ingest[0] and prof.ingest[2] > 0:
             # what the plane products of the family are bound by: bytes their workgroups move from L2 into LDS -- tiles x k-tiles
             # x stage bytes, every operand panel once per tile that uses it -- over the same launch times
@@ -731,6 +746,10 @@ def main():
                                "piece_products_per_product": round(pp_c3, 3), "traffic": traffic_c3, "traffic_source": traffic_c3_src,
                                "launches": len(c3rec), "avg_us": round(1e3 * c3_ms / len(c3rec), 2), "ms_per_step": round(c3_ms / args.steps, 3),
                                "vs_fp32_mfma_peak": round(c3_fl / c3_ms / 1e9 / PEAK_F32_TF, 4)}
+            tavg, tsrc = trace_avg("conv3")
+            if tavg and not (args.amp or args.fp32_mfma):
+                c3["frac_trace"] = round(c3_exec / len(c3rec) / (tavg * 1e-6) / 1e12 / mfma_peak, 4)
+                c3["frac_trace_source"] = f"{tsrc}: {tavg:.2f} us per launch in the rocprofv3 kernel trace of this command (another run, same box class)"
             if single is not None and single["c3"][1] > 0 and single["nt"][1] > 0:
                 how = "the same launches in a pass with everything on ONE stream (VBG_OVERLAP=0): alone on the chip"
                 n1, m1, x1 = single["nt"]

@@ -7,7 +7,7 @@ expects (tools/collect_profiles.sh): gpurun_out/prof_e (kernel-trace + stats of 
 gpurun_out/pmc_f / pmc_w (FETCH_SIZE / WRITE_SIZE passes of `bench.py --steps 3 --warmup 1 --no-h2d-leg`), gpurun_out/pmc_m (SQ / GRBM
 pass of the same command), gpurun_out/gemm_shapes.txt, gpurun_out/bench_line.json"""
 import collections, csv, json, os, re, shutil, subprocess, sys
-TAG = sys.argv[1] if len(sys.argv) > 1 else "r05"
+TAG = sys.argv[1] if len(sys.argv) > 1 else "r06"
 NSTEP = int(sys.argv[2]) if len(sys.argv) > 2 else 23          # bench.py --steps 10 --warmup 3: 3 + 10 (headline) + 10 (roofline leg)
 NPMC = int(sys.argv[3]) if len(sys.argv) > 3 else 7            # bench.py --steps 3 --warmup 1: 1 + 3 + 3
 R = os.path.dirname(os.path.dirname(os.path.abspath(__file__))) + "/"
@@ -191,6 +191,14 @@ for fam, sel, key in (("row-reuse 3x3 convolutions (conv3x3_kernel, forward + in
                    f"(step {prof_line.get('ms_per_step')} ms);  bench.py live ({key}, unprofiled: step {line.get('ms_per_step')} ms): "
                    f"{live.get('launches', 0) / max(line.get('steps', 1), 1):.0f} launches per step, average {live.get('avg_us')} us"
                    + (f", alone on the chip {live['single_stream']['avg_us']} us" if 'single_stream' in live else ""))
+# (bench.py reads this file and emits `roofline*.frac_trace`: the same fraction with the trace's average launch duration in place of the event pairs')
+tr = {}
+for fam, sel in (("conv3", lambda n: "conv3x3_kernel<" in n), ("nt", lambda n: is_roofline_launch(n, None))):
+    tw = sum(float(r["TotalDurationNs"]) for r in rows if sel(r["Name"])); tn = sum(int(r["Calls"]) for r in rows if sel(r["Name"]))
+    if tn:
+        tr[fam] = {"avg_us": tw / tn / 1e3, "launches_per_step": tn / NSTEP}
+json.dump(dict(tr, source="profiles/" + TAG + "_bench_kernel_stats.csv (rocprofv3 --kernel-trace --stats of `bench.py --steps 10 --warmup 3`, streams as run)"),
+          open(P + "trace_avg.json", "w"), indent=1)
 open(P + "agreement.txt", "w").write("\n".join(agr) + "\n")
 print("\n".join(agr))
 print(open(P + "bench_line.json").read()[:1500])
