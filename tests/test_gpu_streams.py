@@ -143,3 +143,66 @@ def test_pipelined_conv3_ring_is_safe_under_contention():
     bit-identical to the first.  (tools/calls/r6_call06.sh runs the same function with VBG_DEBUG_CONV3_NO_RING_GUARD=1 to show that it
     SEES the race when the barrier is left out.)"""
     assert _ring_contention_mismatches(400) == 0
+
+
+def test_no_kernel_reads_memory_nobody_wrote():
+    """In a loop of identical steps the caching allocator hands every call site the block it had one step earlier, so "uninitialised"
+    memory holds exactly what the same tensor held before: a kernel that reads past what was written, or leaves part of its output
+    unwritten, is invisible until the allocation pattern shifts (another batch, another stream holding blocks longer).  Here every
+    fresh `torch.empty` / `empty_like` of the package is filled with NaN (ints: 0x7f7f7f7f) for one cfg2 batch-8 training step on ONE
+    stream: loss and every gradient must equal the unpoisoned step's (tools/poison_check.py does the same site by site)."""
+    if ROOT not in sys.path:
+        sys.path.insert(0, ROOT)
+    sys.path.insert(0, os.path.join(ROOT, "tools"))
+    import bench
+    import poison_check as PC
+    from vbg import ops
+    from vbg.batch import PackedBatch
+    from vbg.optim import FusedAdamW, FusedSGD, split_parameters
+
+    dev = torch.device("cuda", 0)
+    with contextlib.redirect_stdout(sys.stderr):
+        torch.manual_seed(42)
+        net = bench.build_model(tempfile.mkdtemp(prefix="vbg_poison_")).to(dev).train()
+    cnn, bert = split_parameters(net)
+    opts = [FusedSGD(cnn, dev, lr=0.0), FusedAdamW(bert, dev, lr=0.0)]
+    batch = PackedBatch.pack(*bench.synthetic_batch(8, 512, 512, 512, 128, bench.NCLS, bench.VOCAB, 1234)).to(dev)
+    gen = net.BERTgrid_generator
+    was = (ops.overlap_enabled(), ops._CONV_WGRAD_STREAM[0])
+    ops.set_overlap(False)
+    ops._CONV_WGRAD_STREAM[0] = 0
+
+    def one():
+        for o in opts:
+            o.zero_grad()
+        gen._step_seed = 0x5EED
+        random.seed(7)
+        loss = net(*batch)
+        loss.backward()
+        out = [o.group.gflat.clone() for o in opts]
+        torch.cuda.synchronize()
+        return float(loss.detach()), out
+
+    e0, e1 = torch.empty, torch.empty_like
+    try:
+        one()
+        l0, g0 = one()
+        torch.empty, torch.empty_like = PC._wrap(e0), PC._wrap(e1)
+        PC.STATE["mode"] = "all"
+        l1, g1 = one()
+    finally:
+        PC.STATE["mode"] = "off"
+        torch.empty, torch.empty_like = e0, e1
+        ops.set_overlap(was[0])
+        ops._CONV_WGRAD_STREAM[0] = was[1]
+    assert l1 == l0, (l1, l0)
+    for o, a, b in zip(opts, g0, g1):
+        assert int(torch.isnan(b).sum()) == 0
+        grp = o.group
+        for n, p, off in zip(grp.names, grp.params, grp.offsets):
+            if "key.bias" in n:          # analytically zero (softmax is shift-invariant): what is there is rounding noise
+                continue
+            x, y = a[off:off + p.numel()], b[off:off + p.numel()]
+            nx = float(x.norm())
+            if nx > 0:
+                assert float((x - y).norm()) / nx < 2e-5, n

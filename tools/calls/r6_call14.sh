@@ -1,0 +1,9 @@
+# round 6, call 14: the RoI / field-type branch on a stream of its own beside the segmentation head (VBG_HEADS_STREAM): A/B x 3 on one box, race check
+cd /root/repo
+mkdir -p gpurun_out
+R=gpurun_out/r6c14
+run() { env $1 timeout 300 python bench.py --steps 20 --warmup 5 --no-cpu-baseline --no-amp-leg --no-h2d-leg --no-stock-leg --no-single-stream-pass 2>/dev/null < /dev/null | python -c "import sys,json; d=json.loads(sys.stdin.read()); print('$1', d['value'], d['ms_per_step'], d['config']['last_loss'])" | tee -a ${R}_ab.txt; }
+rm -f ${R}_ab.txt
+for i in 1 2 3; do run VBG_HEADS_STREAM=0; run VBG_HEADS_STREAM=1; done
+VBG_HEADS_STREAM=1 timeout 600 python tools/stream_race_check.py --reps 60 --only-default --offenders 2e-5 2>/dev/null | grep -v "noise floor #" | tail -4 | tee ${R}_race.txt
+VBG_HEADS_STREAM=1 timeout 900 python -m pytest tests/test_gpu_streams.py tests/test_gpu_model.py -x -q -m gpu 2>&1 | tail -3

@@ -1,4 +1,4 @@
-# every rocprofv3 collection the committed profiles/ are made from, on one box:  gpurun -- bash tools/collect_profiles.sh ; python tools/make_profiles.py r05
+# every rocprofv3 collection the committed profiles/ are made from, on one box:  gpurun -- bash tools/collect_profiles.sh ; python tools/make_profiles.py r06
 cd /tmp && export TMPDIR=/tmp && cd $GRAFT_REPO_ROOT
 B="python bench.py --steps 3 --warmup 1 --no-cpu-baseline --no-amp-leg --no-h2d-leg --no-stock-leg --no-single-stream-pass"
 timeout 900 python bench.py --steps 20 --warmup 5 2>gpurun_out/bench_line.err | grep "^{" > gpurun_out/bench_line.json
@@ -21,4 +21,4 @@ timeout 300 python tools/infer_latency.py > gpurun_out/infer_latency.txt 2>&1
 ( BB="python bench.py --steps 20 --warmup 5 --no-cpu-baseline --no-amp-leg --no-h2d-leg --no-stock-leg"
   $BB 2>/dev/null | python -c "import sys,json; d=json.loads(sys.stdin.read()); print('one process, no process group:', d['value'], 'docs/s', d['ms_per_step'], 'ms')"
   for extra in "" "--syncbn-comm shared" "--no-syncbn" "--no-ddp-overlap"; do VBG_FORCE_REDUCER=1 $BB $extra 2>/dev/null | python -c "import sys,json; d=json.loads(sys.stdin.read()); c=d['config']; print('one-rank RCCL group, FlatReducer + SyncBatchNorm $extra:', d['value'], 'docs/s', d['ms_per_step'], 'ms;', c.get('syncbn_collectives'), 'statistics collectives;', c.get('syncbn_comm'), '; overlap', c.get('ddp_overlap'), '; buckets', c.get('buckets'))"; done ) > gpurun_out/forced_reducer.txt
-timeout 600 python tools/stream_race_check.py --reps 4 2>/dev/null > gpurun_out/stream_race.txt
+timeout 900 python tools/stream_race_check.py --reps 24 --only-default 2>/dev/null | grep -v "noise floor #" > gpurun_out/stream_race_final.txt

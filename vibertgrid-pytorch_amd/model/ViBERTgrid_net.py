@@ -14,6 +14,8 @@ are never materialised, and activations are NHWC.
 """
 from typing import Any, Dict, List, Tuple
 
+import contextlib
+
 import torch
 import torch.nn as nn
 from transformers import AutoConfig, BertModel, BertTokenizer, RobertaModel, RobertaTokenizer
@@ -315,20 +317,61 @@ class ViBERTgridNet(nn.Module):
                 return total_loss
             return total_loss, pred_mask, pred_ss, gt_label, pred_label
         # label-only work of all four losses first: ONE device->host copy, host RNG draws in the reference's order
-        classes = torch.cat([c.reshape(-1) for c in segment_classes]).int()
-        pos_neg, cls_map = seg_head.make_labels(packed, classes, B, H, W)
-        label_class, label_pn = cls_head.make_labels(segment_classes)
-        plans = seg_head.plans(pos_neg, cls_map) + cls_head.plans(label_class, label_pn)
-        pending = PendingCounts(plans)          # counts travel to the host while the trunk below is being enqueued / running
+        # Round 6: with the heads' stream on (training steps, same conditions as the encoder's stream) this prologue -- owner map, label
+        # raster, nine rocPRIM selections: ~0.5 ms of small launches -- no longer sits in front of the trunk on the caller's stream (where
+        # the encoder's stream waited for it as well) but on the heads' stream, which has nothing else to do until P_fuse exists.
+        dev = batch.device
+        hs_on = (ops.heads_stream_enabled() and ops.overlap_enabled() and batch.is_cuda and self._overlap_safe())
+        main = hs = None
+        if hs_on:
+            main, hs = torch.cuda.current_stream(dev), ops.side_stream(dev, "heads")
+            hs.wait_stream(main)            # boxes / classes written on the caller's stream so far
+        with (torch.cuda.stream(hs) if hs_on else contextlib.nullcontext()):
+            classes = torch.cat([c.reshape(-1) for c in segment_classes]).int()
+            pos_neg, cls_map = seg_head.make_labels(packed, classes, B, H, W)
+            label_class, label_pn = cls_head.make_labels(segment_classes)
+            plans = seg_head.plans(pos_neg, cls_map) + cls_head.plans(label_class, label_pn)
+            pending = PendingCounts(plans)          # counts travel to the host while the trunk below is being enqueued / running
+        if hs_on:
+            ops.reserve_for(hs, *packed, *[t for t in segment_classes if torch.is_tensor(t)])
 
         emb_cat, p_fuse = self._features(batch, packed, B, H, W, seg_indices, corpus, mask)
-        pending.finish()
+        labels_ready = None
+        with (torch.cuda.stream(hs) if hs_on else contextlib.nullcontext()):
+            pending.finish()
+            if hs_on:
+                labels_ready = torch.cuda.Event()
+                labels_ready.record(hs)
         train_only = self.work_mode == "train" and self.training
-        loss_aux, pred_mask, pred_ss = seg_head(p_fuse, segment_classes, icoors, prepared=(pos_neg, cls_map, plans[:2]),
-                                                materialize=not train_only)
-        roi = self.grid_roi_align_net(p_fuse, icoors, None, packed=packed)
-        fuse = self.late_fusion_net(roi, emb_cat)
-        loss_c, gt_label, pred_label = cls_head(fuse, segment_classes, prepared=(label_class, label_pn, plans[2:]))
+        if hs_on and Fn.SIDE_OK[0]:
+            # the two heads are independent between P_fuse and the loss sum, forward and backward: the RoI / field-type branch (small
+            # launches: RoIAlign, region-map convolutions, two linears, the classifier) stays on the heads' stream beside the
+            # segmentation head's chip-wide convolutions.  autograd runs every node's backward on the stream of its forward and
+            # synchronises the gradients that cross; what autograd does NOT know is written here: every tensor allocated under one
+            # stream and read (also from saved-for-backward slots) under the other is reserved for it.
+            hs.wait_stream(main)            # P_fuse, the segment embeddings
+            with torch.cuda.stream(hs):
+                roi = self.grid_roi_align_net(p_fuse, icoors, None, packed=packed)
+                fuse = self.late_fusion_net(roi, emb_cat)
+                loss_c, gt_label, pred_label = cls_head(fuse, segment_classes, prepared=(label_class, label_pn, plans[2:]))
+            ops.reserve_for(hs, p_fuse, emb_cat)
+            main.wait_event(labels_ready)   # (the label work only -- not the RoI branch enqueued behind it)
+            seg_t = [pos_neg, cls_map] + [t for pl in plans[:2] for t in [pl.labels] + [x for c in pl.cats for x in (c.idx, c.cnt_dev, getattr(c, "elem", None))]]
+            ops.reserve_for(main, *[t for t in seg_t if torch.is_tensor(t)])
+            loss_aux, pred_mask, pred_ss = seg_head(p_fuse, segment_classes, icoors, prepared=(pos_neg, cls_map, plans[:2]),
+                                                    materialize=not train_only)
+            main.wait_stream(hs)
+            ops.reserve_for(main, loss_c, gt_label, pred_label)
+        else:
+            if hs_on:                       # (labels on the heads' stream, but no joining node in this graph: everything else on one stream)
+                main.wait_stream(hs)
+                every = [pos_neg, cls_map, label_class, label_pn] + [t for pl in plans for t in [pl.labels] + [x for c in pl.cats for x in (c.idx, c.cnt_dev, getattr(c, "elem", None))]]
+                ops.reserve_for(main, *[t for t in every if torch.is_tensor(t)])
+            loss_aux, pred_mask, pred_ss = seg_head(p_fuse, segment_classes, icoors, prepared=(pos_neg, cls_map, plans[:2]),
+                                                    materialize=not train_only)
+            roi = self.grid_roi_align_net(p_fuse, icoors, None, packed=packed)
+            fuse = self.late_fusion_net(roi, emb_cat)
+            loss_c, gt_label, pred_label = cls_head(fuse, segment_classes, prepared=(label_class, label_pn, plans[2:]))
         total_loss = self._rooted(loss_c + self.loss_control_lambda * loss_aux, home)
         if train_only:
             return total_loss

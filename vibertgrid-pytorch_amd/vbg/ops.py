@@ -71,6 +71,19 @@ def conv_wgrad_stream_enabled(level: int = 1, pixels: int = 0) -> bool:
     return int(_CONV_WGRAD_STREAM[0]) >= level
 
 
+_HEADS_STREAM = [os.environ.get("VBG_HEADS_STREAM", "1") != "0"]          # round 6: +2.3 % at cfg2 (A/B x 3 on one box: 31.26 -> 30.56 ms)
+
+
+def heads_stream_enabled() -> bool:
+    """the RoI / field-type branch (RoIAlign, region-map convolutions, late fusion, classifier, its losses) on a stream of its own beside
+    the segmentation head -- both start from P_fuse and meet again in the loss sum, forward and backward (same conditions as VBG_OVERLAP)"""
+    return _HEADS_STREAM[0]
+
+
+def set_heads_stream(on: bool):
+    _HEADS_STREAM[0] = bool(on)
+
+
 def side_stream(device, name: str = "side") -> "torch.cuda.Stream":
     """the side stream `name` of `device` (created on first use)"""
     idx = torch.device(device).index
