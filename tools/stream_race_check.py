@@ -47,6 +47,8 @@ def main():
                     "filled with NaN and freed): a kernel that reads memory nobody wrote shows without any second stream")
     ap.add_argument("--trace", action="store_true", help="capture the intermediates of the 64-channel conv + BatchNorm backward nodes (incoming gradient, "
                     "BatchNorm slot sums, dz, its amax slot, the input gradient) in every run and name the FIRST one that leaves the one-stream run's")
+    ap.add_argument("--amp", action="store_true", help="the steps inside torch.autocast(float16): the one-product forms")
+    ap.add_argument("--shape", default="cfg2", choices=["cfg2", "cfg3", "cfg4", "cfg5"], help="bench.py's other shapes (cfg4: 512 segments per document -> ~4 000 RoIs on the heads' stream; cfg5: 16 x 1024 x 1024)")
     ap.add_argument("--offenders", type=float, default=0.0, help="for every run whose cnn group differs by more than this: list every parameter above it, in flat-buffer order")
     args = ap.parse_args()
     from vbg import ops
@@ -58,11 +60,16 @@ def main():
     dev = torch.device("cuda", 0)
     with contextlib.redirect_stdout(sys.stderr):
         torch.manual_seed(42)
-        net = bench.build_model(tempfile.mkdtemp(prefix="vbg_race_")).to(dev).train()
+        shp = {"cfg2": dict(img=512, S=128, ncls=bench.NCLS, vocab=bench.VOCAB, backbone="resnet_34_fpn_pretrained", batch=8, roberta=False),
+               "cfg3": dict(img=512, S=128, ncls=4, vocab=bench.VOCAB, backbone="resnet_34_fpn", batch=8, roberta=False),
+               "cfg4": dict(img=512, S=512, ncls=12, vocab=21128, backbone="resnet_34_fpn", batch=8, roberta=False),
+               "cfg5": dict(img=1024, S=128, ncls=bench.NCLS, vocab=50265, backbone="resnet_34_fpn", batch=16, roberta=True)}[args.shape]
+        net = bench.build_model(tempfile.mkdtemp(prefix="vbg_race_"), backbone=shp["backbone"], vocab=shp["vocab"], img=shp["img"], ncls=shp["ncls"],
+                                roberta=shp["roberta"]).to(dev).train()
     cnn, bert = split_parameters(net)
     opts = [FusedSGD(cnn, dev, lr=0.0), FusedAdamW(bert, dev, lr=0.0)]
     groups = [o.group for o in opts]
-    batch = PackedBatch.pack(*bench.synthetic_batch(8, 512, 512, 512, 128, bench.NCLS, bench.VOCAB, 1234)).to(dev)
+    batch = PackedBatch.pack(*bench.synthetic_batch(shp["batch"], shp["img"], shp["img"], 512, shp["S"], shp["ncls"], shp["vocab"], 1234)).to(dev)
     gen = net.BERTgrid_generator
 
     def one(overlap, cw, bw):
@@ -71,7 +78,8 @@ def main():
             o.zero_grad()
         gen._step_seed = 0x5EED
         random.seed(7)
-        loss = net(*batch)
+        with torch.autocast("cuda", dtype=torch.float16, enabled=args.amp):
+            loss = net(*batch)
         loss.backward()
         out = [o.group.gflat.clone() for o in opts]          # (enqueued right behind backward(): the join must cover it)
         torch.cuda.synchronize()

@@ -321,7 +321,10 @@ class ViBERTgridNet(nn.Module):
         # raster, nine rocPRIM selections: ~0.5 ms of small launches -- no longer sits in front of the trunk on the caller's stream (where
         # the encoder's stream waited for it as well) but on the heads' stream, which has nothing else to do until P_fuse exists.
         dev = batch.device
-        hs_on = (ops.heads_stream_enabled() and ops.overlap_enabled() and batch.is_cuda and self._overlap_safe())
+        hs_on = (ops.heads_stream_enabled() and ops.overlap_enabled() and batch.is_cuda and self._overlap_safe()
+                 # (a SyncBatchNorm communicator driven on the COMPUTE stream -- the opt-in direct RCCL one -- must see its collectives
+                 #  from one stream: the RoI branch's BatchNorms would issue theirs from the heads' stream)
+                 and not (Fn.SyncCtx.direct is not None and Fn.SyncCtx.active()))
         main = hs = None
         if hs_on:
             main, hs = torch.cuda.current_stream(dev), ops.side_stream(dev, "heads")
