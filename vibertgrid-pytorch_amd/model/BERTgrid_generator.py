@@ -224,12 +224,14 @@ class BERTgridGenerator(nn.Module):
         x = Fn.BertEmbedFn.apply(emb.word_embeddings.weight, emb.position_embeddings.weight, emb.token_type_embeddings.weight,
                                  emb.LayerNorm.weight, emb.LayerNorm.bias, ids, pos, eps, p, seed, 1000)
         xpl = None                       # bf16 planes of x, handed from each layer's closing LayerNorm to the next layer's first product
+        self._layer_seq = []             # autograd sequence counter behind every layer's node(s): ViBERTgridNet._stage1_backward_priority
         for li, layer in enumerate(m.encoder.layer):
             a, o_, it, ou = layer.attention.self, layer.attention.output, layer.intermediate, layer.output
             x, xpl = Fn.BertLayerFn.apply(x, xpl, a.query.weight, a.query.bias, a.key.weight, a.key.bias, a.value.weight, a.value.bias,
                                      o_.dense.weight, o_.dense.bias, o_.LayerNorm.weight, o_.LayerNorm.bias,
                                      it.dense.weight, it.dense.bias, ou.dense.weight, ou.dense.bias, ou.LayerNorm.weight,
                                      ou.LayerNorm.bias, meta, eps, p, seed, li)
+            self._layer_seq.append(torch.autograd._get_sequence_nr())
         return x, pk
 
     def BERT_embedding(self, corpus: torch.Tensor, mask: torch.Tensor, seg_indices: Tuple[torch.Tensor]):

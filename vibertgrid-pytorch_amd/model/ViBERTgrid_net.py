@@ -206,9 +206,12 @@ class ViBERTgridNet(nn.Module):
             main, side = torch.cuda.current_stream(batch.device), ops.side_stream(batch.device)
             Fn.SIDE_OK[0] = True                # (until forward() returns: the graph will hold a JoinSideFn node)
             side.wait_stream(main)              # inputs / parameters written on the caller's stream so far
+            seq_lo = torch.autograd._get_sequence_nr()
             pre = self.backbone.stage1(batch)
+            seq_hi = torch.autograd._get_sequence_nr()
             with torch.cuda.stream(side):
                 emb_cat, counts = gen._segment_embeddings(corpus, mask, seg_indices)
+            self._stage1_backward_priority(pre, seq_lo, seq_hi, getattr(gen, "_layer_seq", None))
             main.wait_stream(side)
             emb_cat.record_stream(main)
             emb_cat = Fn.JoinSideFn.apply(emb_cat)
@@ -220,6 +223,40 @@ class ViBERTgridNet(nn.Module):
         grid = gen._scatter((H, W), emb_cat, boxes, box_off, box_doc, B, 0)
         p_fuse = self.backbone.stage2(pre, grid)
         return emb_cat, p_fuse
+
+    @staticmethod
+    def _stage1_backward_priority(pre, seq_lo, seq_hi, layer_seq):
+        """WHEN the host enqueues the backward of the CNN's first stage.  The autograd engine runs the ready node with the highest
+        sequence number first; the encoder's nodes are created behind the first stage's (the forward enqueues the CNN first, so that
+        the host-side packing of the token windows hides behind device work), so in backward the engine walks the WHOLE encoder -- twelve
+        layers, ~5 ms of host enqueue time -- before it touches the first stage, whose 2.5 ms of device work then starts when the
+        encoder's backward is nearly over instead of beside it (kernel trace of round 6: the caller's stream idle for 7 ms).  Here the
+        first stage's nodes get the sequence number that sits behind the encoder's top `n` layers: those are enqueued first (they keep
+        the encoder's stream fed while the host is busy elsewhere), then the first stage, then the rest of the encoder."""
+        n = ops.stage1_bwd_after()
+        if n < 0 or not layer_seq or seq_hi <= seq_lo:
+            return
+        L = len(layer_seq)
+        k = max(0, L - n)                          # layers k .. L-1 first, then the first stage, then layers k-1 .. 0
+        target = layer_seq[k - 1] if k > 0 else max(seq_lo - 1, 0)
+        if k == L:
+            return
+        if n == 0:
+            target = layer_seq[-1] + 1024          # ahead of the whole encoder
+        seen, stack = set(), [t.grad_fn for t in pre if t is not None and t.grad_fn is not None]
+        while stack:
+            node = stack.pop()
+            if node is None or id(node) in seen:
+                continue
+            seen.add(id(node))
+            sq = node._sequence_nr()
+            if seq_lo <= sq < seq_hi:
+                if not hasattr(node, "_set_sequence_nr"):
+                    return          # (a scheduling hint only: without the setter the engine's own order stands)
+                node._set_sequence_nr(target)
+            for nxt, _ in node.next_functions:
+                if nxt is not None and id(nxt) not in seen:
+                    stack.append(nxt)
 
     def _overlap_safe(self) -> bool:
         """May the encoder run on the side stream in this call?  Only where it pays and where nobody reads gradients behind the library's

@@ -84,6 +84,15 @@ def set_heads_stream(on: bool):
     _HEADS_STREAM[0] = bool(on)
 
 
+_STAGE1_BWD_AFTER = [int(os.environ.get("VBG_STAGE1_BWD_AFTER", "6"))]          # round 6: +0.5 % at cfg2 (A/B x 2 over n = -1, 0, 2 ... 10: profiles/r06_stage1_bwd_order.txt)
+
+
+def stage1_bwd_after() -> int:
+    """how many of the encoder's TOP layers run their backward before the backward of the CNN's first stage is enqueued (-1: the
+    autograd engine's own order -- every encoder layer first, because the encoder's nodes are younger; see ViBERTgridNet._features)"""
+    return _STAGE1_BWD_AFTER[0]
+
+
 def side_stream(device, name: str = "side") -> "torch.cuda.Stream":
     """the side stream `name` of `device` (created on first use)"""
     idx = torch.device(device).index
