@@ -144,3 +144,68 @@ def test_reducer_refuses_a_subgroup_without_a_syncbn_group():
             dist.get_world_size = real
     finally:
         dist.destroy_process_group()
+
+
+def test_arm_and_drop_untouched_follow_torch_semantics():
+    """ADVICE r5 (vbg/optim.py): FlatGroup.arm() -- the start of a backward, after the loop's `optimizer.zero_grad()` dropped the gradients --
+    (i) zeroes a contiguous RUN of missing parameters with one memset instead of one launch per parameter, (ii) leaves a gradient the
+    caller kept in place (accumulated into, as torch would), (iii) takes a `.grad` that is somebody else's tensor (what DDP's
+    finalize_backward leaves on a locally-unused parameter) into the flat view; ModelHome.drop_untouched() only hands `None` back for
+    gradients that arm() itself attached in this backward -- one that existed when the backward started survives (gradient accumulation,
+    DDP no_sync micro-steps)."""
+    from vbg.optim import FlatGroup, ModelHome
+    net = _Toy()
+    named = [(n, p) for n, p in net.named_parameters() if "bert_model" not in n and "fc" not in n]
+    g = FlatGroup(named, torch.device("cpu"))
+    n = len(g.params)
+    assert n == 4
+    # all dropped -> one memset of the whole buffer, every view back
+    g.gflat.fill_(7.0)
+    for p in g.params:
+        p.grad = None
+    g.arm()
+    assert float(g.gflat.abs().max()) == 0.0 and all(p.grad is gv for p, gv in zip(g.params, g.gviews)) and g._armed == list(range(n))
+    # one gradient kept, the others dropped: the kept one is accumulated into (not zeroed), the run of missing ones is zeroed
+    g.gflat.fill_(3.0)
+    for i, p in enumerate(g.params):
+        p.grad = g.gviews[i] if i == 1 else None
+    g.arm()
+    assert float(g.gviews[1].min()) == 3.0 and g._armed == [0, 2, 3]
+    assert all(float(g.gviews[i].abs().max()) == 0.0 for i in (0, 2, 3))
+    # a foreign .grad tensor: its contents move into the flat view, which becomes .grad again
+    foreign = torch.full_like(g.params[2].data, 5.0)
+    g.params[2].grad = foreign
+    g.arm()
+    assert g.params[2].grad is g.gviews[2] and float(g.gviews[2].min()) == 5.0
+    # drop_untouched: only what arm() attached in THIS backward and nobody touched
+    home = ModelHome.__new__(ModelHome)
+    home.groups, home.touched = [g], set()
+    for i, p in enumerate(g.params):
+        p.grad = g.gviews[i] if i in (0, 1) else None          # 0, 1 existed before this backward; 2, 3 were dropped by zero_grad()
+    g.arm()
+    assert g._armed == [2, 3]
+    home.touched.add(id(g.params[2]))                          # parameter 2 took part in the backward, 3 did not
+    home.drop_untouched()
+    assert g.params[0].grad is g.gviews[0] and g.params[1].grad is g.gviews[1] and g.params[2].grad is g.gviews[2] and g.params[3].grad is None
+
+
+def test_rehoming_under_a_live_optimizer_raises():
+    """`_home()` used to rebuild the flat groups silently when `valid()` failed (a `.to()` / `.half()` / fresh `p.data` after an
+    optimizer existed) -- the optimizer then went on stepping buffers the model no longer read.  A group a live optimizer / reducer owns is
+    never replaced: the model raises."""
+    from model.ViBERTgrid_net import ViBERTgridNet
+    from vbg.optim import FlatGroup, FusedSGD, ModelHome, split_parameters
+    net = _Toy()
+    cnn, _ = split_parameters(net)
+    opt = FusedSGD(cnn, torch.device("cpu"), lr=0.1)
+    home = ModelHome.__new__(ModelHome)
+    home.groups, home.touched = [opt.group], None
+    holder = type("M", (), {})()
+    holder.__dict__["_vbg_home_state"] = home
+    holder.classifier_mode = "simp"
+    assert ViBERTgridNet._home(holder) is home                 # still valid: kept
+    cnn[0][1].data = cnn[0][1].data.clone()                    # the parameter left its flat storage
+    assert not home.valid()
+    with pytest.raises(RuntimeError, match="flat storage"):
+        ViBERTgridNet._home(holder)
+    del opt                                                    # nobody steps the old buffers any more: re-homing is fine (not exercised here)
