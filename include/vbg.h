@@ -407,6 +407,41 @@ int vbg_gelu_bwd(const float* h, float* dg_inout, long long n, void* stream);   
 int vbg_relu_bwd(const float* y, float* dy_inout, long long n, void* stream);      /* dx = dy * (y > 0)  */
 
 /* ------------------------------------------------------------------------------------------
+ * One encoder layer forward in ONE call (round 6; csrc/encoder.hip).  Replaces one transformers BertLayer.forward inside BertModel
+ * (model/BERTgrid_generator.py:134: BertSelfAttention, BertSelfOutput, BertIntermediate, BertOutput) = the seven launches
+ *   vbg_plane_gemm (stacked Q/K/V projection -> planes) -> vbg_attn(FWD) -> vbg_plane_gemm (output projection) ->
+ *   vbg_dropout_add_ln_fwd_planes -> vbg_plane_gemm (FFN1, GELU) -> vbg_plane_gemm (FFN2) -> vbg_dropout_add_ln_fwd_planes
+ * with exactly the descriptors the caller would have passed one by one (bit-identical results); what it saves is host time per launch.
+ * A vbg_planes_ref names a plane tensor (buf NULL = absent): three bf16 planes for a form-0 product, fp16-pair planes for forms 1 / 2.
+ *   form_qkv / form_ao / form_ffn: arithmetic form of the products (vbg_plane_gemm_desc.form); form_attn: of the attention (vbg_attn_desc.form;
+ *   != 0: pqkv receives fp16-pair planes, else three bf16 planes).
+ *   xa = planes of x in the form of form_qkv; wqkv [3 hidden][hidden], wo, wi, wo2 = weight planes in the form of their product.
+ *   form_ao != 0 reads pctxq (the attention writes it), else pctx; form_ffn != 0 reads px1q / pgq, else px1 / pg; every present output
+ *   plane tensor is written (the caller keeps them for backward / hands py / pyq to the next layer).
+ *   Dropout streams: stream_id0 + 1 (first LayerNorm), + 2 (second); attention keeps from mask_q / mask_k (vbg_attn_mask; NULL = none). */
+typedef struct vbg_planes_ref { unsigned short* buf; long long plane, ld; } vbg_planes_ref;
+typedef struct vbg_bert_layer_fwd_desc {
+    int ntok, hidden, inter, heads;
+    float eps, drop_p; unsigned long long seed, stream_id0;
+    int form_qkv, form_attn, form_ao, form_ffn;
+    int tile_qkv, tile_ao, tile_ffn1, tile_ffn2;
+    /* packed sequences: the fields of vbg_attn_desc */
+    int ntasks, max_len; const int* tasks; const int* seq_len; const int* seq_row0; const int* pad_off; long long ntok_pad;
+    const unsigned* mask_q; const unsigned* mask_k; const long long* mask_off; float attn_scale, keep_scale;
+    /* inputs */
+    const float* x; vbg_planes_ref xa;
+    vbg_planes_ref wqkv, wo, wi, wo2;
+    const float* bqkv; const float* bo; const float* bi; const float* bo2; const float* g1; const float* b1; const float* g2; const float* b2;
+    /* outputs (fp32 [ntok][hidden] unless noted) */
+    vbg_planes_ref pqkv;                                     /* [ntok][3 hidden] planes of q, k, v */
+    float* ctx; float* lse; float* kbar; vbg_planes_ref pctx, pctxq;      /* attention output, its row statistics [2][heads][ntok_pad], kbar (optional) */
+    float* ao; float* x1; float* xhat1; float* rstd1; vbg_planes_ref px1, px1q;
+    float* h; vbg_planes_ref pg, pgq;                        /* h [ntok][inter] fp32; gelu(h) as planes only */
+    float* fo; float* y; float* xhat2; float* rstd2; vbg_planes_ref py, pyq;
+} vbg_bert_layer_fwd_desc;
+int vbg_bert_layer_fwd(const vbg_bert_layer_fwd_desc* desc, void* stream);
+
+/* ------------------------------------------------------------------------------------------
  * a4. token -> segment aggregation  (model/BERTgrid_generator.py:148-191)
  * ------------------------------------------------------------------------------------------ */
 /* tok_row[i] = row of the i-th token (mask==1 order) in `tok`; runs: start[s], len[s] in token order.

@@ -10,7 +10,7 @@ import bench
 dev = torch.device("cuda")
 with contextlib.redirect_stdout(sys.stderr):
     net = bench.build_model(tempfile.mkdtemp()).to(dev).eval()
-for B in (1, 8):
+for B in [int(b) for b in os.environ.get("VBG_INFER_BATCHES", "1,8").split(",")]:
     batch = bench.synthetic_batch(B, 512, 512, 512, 128, 5, 30522, 7)
     mv = lambda ts: tuple(t.to(dev) for t in ts)
     args = (mv(batch[0]), mv(batch[1]), mv(batch[3]), batch[4].to(dev), batch[5].to(dev))

@@ -56,6 +56,7 @@ def _wrap(orig):
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--sites-only", action="store_true")
+    ap.add_argument("--amp", action="store_true", help="the step inside torch.autocast (the one-product forms)")
     args = ap.parse_args()
     torch.empty, torch.empty_like = _wrap(_orig_empty), _wrap(_orig_empty_like)
     from vbg import ops
@@ -77,7 +78,8 @@ def main():
             o.zero_grad()
         gen._step_seed = 0x5EED
         random.seed(7)
-        loss = net(*batch)
+        with torch.autocast("cuda", dtype=torch.float16, enabled=args.amp):
+            loss = net(*batch)
         loss.backward()
         out = [o.group.gflat.clone() for o in opts]
         torch.cuda.synchronize()

@@ -686,19 +686,32 @@ class BertLayerFn(torch.autograd.Function):
         # q, k, v leave the projection as planes only (the fused attention kernels' operands): fp16-pair planes when the projection runs
         # the pair form and the backward that follows is the all-pair one (round 5: the attention then runs three fp16 piece products per
         # product, csrc/attn.hip FORM 1), three bf16 planes otherwise
-        attn_pair = (flash and pair and fused_qkv and xq is not None and ops.attn_pair_enabled() and ops.bound_planes_enabled()
+        # parameters NOT stored back to back and nothing to differentiate (inference, validation): the stacked planes of the three
+        # projections are cached on the weights (round 6) -- one Q/K/V product as in training instead of three
+        one_qkv = fused_qkv or (planes and not any(ctx.needs_input_grad))
+        attn_pair = (flash and pair and one_qkv and xq is not None and ops.attn_pair_enabled() and ops.bound_planes_enabled()
                      and (pair_bwd or not any(ctx.needs_input_grad)))
+        # round 6: the layer's seven launches leave from ONE library call (csrc/encoder.hip) -- same descriptors, a third of the host time
+        fast = planes and flash and one_qkv and ops.layer_entry_ok()
         if flash:
             pqkv = ops.pair_empty(ntok, 3 * hid, dev) if attn_pair else ops.planes_empty(ntok, 3 * hid, dev)
         if planes:                 # operands split into bf16 planes once (csrc/gemm_planes.hip), weights once per optimizer step
-            if not pair_bwd:           # (the bf16 planes of x: the QKV product's operand without the pair form, and its weight gradient's)
+            if not pair_bwd and not (one_qkv and xq is not None and not any(ctx.needs_input_grad)):
+                # (the bf16 planes of x: the QKV product's operand without the pair form, and its weight gradient's)
                 px = ops.Planes(xpl, ntok, hid, xpl.shape[2]) if (xpl is not None and not carrier_is_pair) else ops.split_planes(x)
-            if fused_qkv and xq is not None:
-                ops.plane_gemm(xq, ops.weight_planes(wq, view=_stack3(wq), also=(wk, wv), pair=True), qkv, bias=_stack3(bq),
-                               out_planes=None if attn_pair else pqkv, out_pair=pqkv if attn_pair else None, tile=ops.pair_tile(ntok, 3 * hid), form=1)
-            elif fused_qkv:
-                ops.plane_gemm(px, ops.weight_planes(wq, view=_stack3(wq), also=(wk, wv)), qkv, bias=_stack3(bq), out_planes=pqkv,
-                               tile=ops._dense_tile(ntok, 3 * hid))
+            if one_qkv:
+                if fused_qkv:
+                    wqkv_pl, bqkv_t = ops.weight_planes(wq, view=_stack3(wq), also=(wk, wv), pair=xq is not None), _stack3(bq)
+                else:
+                    wqkv_pl, bqkv_t = ops.stacked_qkv(wq, wk, wv, bq, bk, bv, pair=xq is not None)
+                tile_qkv = ops.pair_tile(ntok, 3 * hid) if xq is not None else ops._dense_tile(ntok, 3 * hid)
+            if fast:
+                pass
+            elif one_qkv and xq is not None:
+                ops.plane_gemm(xq, wqkv_pl, qkv, bias=bqkv_t,
+                               out_planes=None if attn_pair else pqkv, out_pair=pqkv if attn_pair else None, tile=tile_qkv, form=1)
+            elif one_qkv:
+                ops.plane_gemm(px, wqkv_pl, qkv, bias=bqkv_t, out_planes=pqkv, tile=tile_qkv)
             else:              # parameters not laid out back to back (no flat buffers): one product per projection, same kernel
                 for j, (w, b) in enumerate(((wq, bq), (wk, bk), (wv, bv))):
                     ops.plane_gemm(px, ops.weight_planes(w), None if flash else qkv[:, j * hid:(j + 1) * hid], bias=b,
@@ -727,7 +740,8 @@ class BertLayerFn(torch.autograd.Function):
             # (autocast region: the output projection multiplies the hi plane of those, no bf16 planes of O are written)
             amp_ao = pctxq is not None and ops.amp_one_product()
             pctx = None if amp_ao else ops.planes_empty(ntok, hid, dev)
-            ops.attn(meta, ATTN_FWD, pqkv, None, ctxv, lse, None, masks, 1.0 / (dh ** 0.5), p, kbar=kbar, out_planes=pctx, out_pair=pctxq)
+            if not fast:
+                ops.attn(meta, ATTN_FWD, pqkv, None, ctxv, lse, None, masks, 1.0 / (dh ** 0.5), p, kbar=kbar, out_planes=pctx, out_pair=pctxq)
         else:
             # scores -> probabilities (in place), grouped over (sequence, head)
             P = torch.empty((meta.s_elems,), device=dev, dtype=f32)
@@ -741,48 +755,68 @@ class BertLayerFn(torch.autograd.Function):
             # (the attention-output projection stays on the six-product form, its operand's bf16 planes come from the attention kernel:
             #  measured at full scale, moving it to the pair form as well raised the gradient error of the ill-conditioned trunk
             #  convolutions from 6.3e-4 to 1.0e-3 of the reference -- the forward feeds everything; the backward products do not)
-            if flash and amp_ao:
-                ao = ops.plane_gemm(pctxq, ops.weight_planes(wo, pair=True),
-                                    torch.empty((ntok, hid), device=dev, dtype=f32), bias=bo, tile=ops.pair_tile(ntok, hid) or 128129, form=1)
+            ao = torch.empty((ntok, hid), device=dev, dtype=f32)
+            ao_pair = bool(flash and amp_ao)
+            if ao_pair:
+                wo_pl, tile_ao = ops.weight_planes(wo, pair=True), ops.pair_tile(ntok, hid) or 128129
             else:
                 if pctx is None:
                     pctx = ops.split_planes(ctxv)
-                ao = ops.plane_gemm(pctx, ops.weight_planes(wo), torch.empty((ntok, hid), device=dev, dtype=f32), bias=bo, tile=ops._dense_tile(ntok, hid))
+                wo_pl, tile_ao = ops.weight_planes(wo), ops._dense_tile(ntok, hid)
             px1 = None if pair_bwd else ops.planes_empty(ntok, hid, dev)
             px1q = ops.pair_empty(ntok, hid, dev) if pair else None
-            x1, xh1, rs1 = ops.dropout_add_ln_fwd(ao, x, g1, b1, eps, p, seed, sid + 1, out_planes=px1, out_pair=px1q)
             inter = wi.shape[0]
             h = torch.empty((ntok, inter), device=dev, dtype=f32)
             # gelu(h) leaves the FFN1 epilogue as planes only (the A operand of FFN2 and, untransposed, of its weight gradient)
             pg = None if pair_bwd else ops.planes_empty(ntok, inter, dev)
-            pgq = None
+            pgq = ops.pair_empty(ntok, inter, dev) if pair else None
+            fo = torch.empty((ntok, hid), device=dev, dtype=f32)
+            wi_pl, wo2_pl = ops.weight_planes(wi, pair=pair), ops.weight_planes(wo2, pair=pair)
             if pair:
-                pgq = ops.pair_empty(ntok, inter, dev)
-                ops.plane_gemm(px1q, ops.weight_planes(wi, pair=True), h, bias=bi, epi=EPI_GELU_DUAL, out_planes=pg, out_pair=pgq,
-                               tile=ops.pair_tile(ntok, inter, True), form=1)
-                fo = ops.plane_gemm(pgq, ops.weight_planes(wo2, pair=True), torch.empty((ntok, hid), device=dev, dtype=f32), bias=bo2,
-                                    tile=ops.pair_tile(ntok, hid), form=1)
-                if not pair_bwd:
-                    pgq = px1q = None
+                tile_f1, tile_f2 = ops.pair_tile(ntok, inter, True), ops.pair_tile(ntok, hid)
             else:
-                ops.plane_gemm(px1, ops.weight_planes(wi), h, bias=bi, epi=EPI_GELU_DUAL, out_planes=pg, tile=ops._dense_tile(ntok, inter, True))
-                fo = ops.plane_gemm(pg, ops.weight_planes(wo2), torch.empty((ntok, hid), device=dev, dtype=f32), bias=bo2, tile=ops._dense_tile(ntok, hid))
+                tile_f1, tile_f2 = ops._dense_tile(ntok, inter, True), ops._dense_tile(ntok, hid)
+            if fast:
+                x1, xh1, y, xh2 = (torch.empty_like(x) for _ in range(4))
+                rs1, rs2 = (torch.empty((ntok,), device=dev, dtype=f32) for _ in range(2))
+                py = None if pair_bwd else ops.planes_empty(ntok, hid, dev)
+                pyq = ops.pair_empty(ntok, hid, dev) if pair else None
+                ops.bert_layer_fwd(meta, eps=eps, p=p, seed=seed, sid=sid, x=x, xa=xq if xq is not None else px, pair_qkv=xq is not None,
+                                   wqkv=wqkv_pl, bqkv=bqkv_t, tile_qkv=tile_qkv, pqkv=pqkv, attn_pair=attn_pair, ctxv=ctxv, lse=lse, kbar=kbar,
+                                   pctx=pctx, pctxq=pctxq, masks=masks, scale=1.0 / (dh ** 0.5), wo=wo_pl, bo=bo, ao_pair=ao_pair, tile_ao=tile_ao,
+                                   ao=ao, g1=g1, b1=b1, x1=x1, xh1=xh1, rs1=rs1, px1=px1, px1q=px1q, wi=wi_pl, bi=bi, wo2=wo2_pl, bo2=bo2,
+                                   pair_ffn=pair, tile_ffn1=tile_f1, tile_ffn2=tile_f2, h=h, pg=pg, pgq=pgq, fo=fo, g2=g2, b2=b2, y=y, xh2=xh2,
+                                   rs2=rs2, py=py, pyq=pyq)
+            else:
+                ops.plane_gemm(pctxq if ao_pair else pctx, wo_pl, ao, bias=bo, tile=tile_ao, form=1 if ao_pair else 0)
+                x1, xh1, rs1 = ops.dropout_add_ln_fwd(ao, x, g1, b1, eps, p, seed, sid + 1, out_planes=px1, out_pair=px1q)
+                if pair:
+                    ops.plane_gemm(px1q, wi_pl, h, bias=bi, epi=EPI_GELU_DUAL, out_planes=pg, out_pair=pgq, tile=tile_f1, form=1)
+                    ops.plane_gemm(pgq, wo2_pl, fo, bias=bo2, tile=tile_f2, form=1)
+                else:
+                    ops.plane_gemm(px1, wi_pl, h, bias=bi, epi=EPI_GELU_DUAL, out_planes=pg, tile=tile_f1)
+                    ops.plane_gemm(pg, wo2_pl, fo, bias=bo2, tile=tile_f2)
+            if pair and not pair_bwd:
+                pgq = px1q = None
             g = None
         else:
             ao = ops.linear_fwd(ctxv, wo, bo)
             x1, xh1, rs1 = ops.dropout_add_ln_fwd(ao, x, g1, b1, eps, p, seed, sid + 1)
             h, g = ops.linear_fwd(x1, wi, bi, EPI_GELU_DUAL)
             fo = ops.linear_fwd(g, wo2, bo2)
-        pyq = None
-        if planes:
-            py = None if pair_bwd else ops.planes_empty(ntok, hid, dev)
-            pyq = ops.pair_empty(ntok, hid, dev) if pair else None
-        y, xh2, rs2 = ops.dropout_add_ln_fwd(fo, x1, g2, b2, eps, p, seed, sid + 2, out_planes=py, out_pair=pyq)
+        if not fast:
+            pyq = None
+            if planes:
+                py = None if pair_bwd else ops.planes_empty(ntok, hid, dev)
+                pyq = ops.pair_empty(ntok, hid, dev) if pair else None
+            y, xh2, rs2 = ops.dropout_add_ln_fwd(fo, x1, g2, b2, eps, p, seed, sid + 2, out_planes=py, out_pair=pyq)
         ctx.meta, ctx.cfg = meta, (eps, p, seed, sid)
         ctx.planes, ctx.flash, ctx.pair_bwd = planes, flash, pair_bwd
         ctx.w_refs = (wq, wk, wv, wo, wi, wo2)
         ctx.b_refs = (bq, bk, bv, bo, bi, bo2, g1, b1, g2, b2)
-        if planes:
+        if not any(ctx.needs_input_grad):
+            pass                                   # (nothing is differentiated -- inference, validation: nothing to keep)
+        elif planes:
             # backward needs the activations only as GEMM operands: their planes stand in for x / ctx / x1 / gelu(h)
             ctx.pl_shape = (ntok, hid, wi.shape[0])
             if pair_bwd:

@@ -73,6 +73,27 @@ class AttnDesc(C.Structure):
                 ("form", c_int), ("do_amax", c_vp)]
 
 
+class PlanesRef(C.Structure):                # include/vbg.h vbg_planes_ref
+    _fields_ = [("buf", c_vp), ("plane", c_ll), ("ld", c_ll)]
+
+
+class BertLayerFwdDesc(C.Structure):         # include/vbg.h vbg_bert_layer_fwd_desc
+    _fields_ = [("ntok", c_int), ("hidden", c_int), ("inter", c_int), ("heads", c_int),
+                ("eps", c_f), ("drop_p", c_f), ("seed", c_ull), ("stream_id0", c_ull),
+                ("form_qkv", c_int), ("form_attn", c_int), ("form_ao", c_int), ("form_ffn", c_int),
+                ("tile_qkv", c_int), ("tile_ao", c_int), ("tile_ffn1", c_int), ("tile_ffn2", c_int),
+                ("ntasks", c_int), ("max_len", c_int), ("tasks", c_vp), ("seq_len", c_vp), ("seq_row0", c_vp), ("pad_off", c_vp), ("ntok_pad", c_ll),
+                ("mask_q", c_vp), ("mask_k", c_vp), ("mask_off", c_vp), ("attn_scale", c_f), ("keep_scale", c_f),
+                ("x", c_vp), ("xa", PlanesRef),
+                ("wqkv", PlanesRef), ("wo", PlanesRef), ("wi", PlanesRef), ("wo2", PlanesRef),
+                ("bqkv", c_vp), ("bo", c_vp), ("bi", c_vp), ("bo2", c_vp), ("g1", c_vp), ("b1", c_vp), ("g2", c_vp), ("b2", c_vp),
+                ("pqkv", PlanesRef),
+                ("ctx", c_vp), ("lse", c_vp), ("kbar", c_vp), ("pctx", PlanesRef), ("pctxq", PlanesRef),
+                ("ao", c_vp), ("x1", c_vp), ("xhat1", c_vp), ("rstd1", c_vp), ("px1", PlanesRef), ("px1q", PlanesRef),
+                ("h", c_vp), ("pg", PlanesRef), ("pgq", PlanesRef),
+                ("fo", c_vp), ("y", c_vp), ("xhat2", c_vp), ("rstd2", c_vp), ("py", PlanesRef), ("pyq", PlanesRef)]
+
+
 ATTN_FWD, ATTN_DQ, ATTN_DKV = 0, 1, 2
 OP_DENSE_K, OP_DENSE_R, OP_CONV_K, OP_CONV_R, OP_WT_R = 0, 1, 2, 3, 4
 EPI_NONE, EPI_RELU, EPI_GELU_DUAL, EPI_MUL_GELU_GRAD = 0, 1, 2, 3
@@ -94,6 +115,7 @@ SIGNATURES = {
     "vbg_split_planes_t_batched": (c_int, [c_vp, c_vp, c_vp, c_int, c_int, c_ll, c_vp]),
     "vbg_split_planes_pair_t_batched": (c_int, [c_vp, c_vp, c_vp, c_int, c_int, c_ll, c_vp]),
     "vbg_attn": (c_int, [C.POINTER(AttnDesc), c_vp]),
+    "vbg_bert_layer_fwd": (c_int, [C.POINTER(BertLayerFwdDesc), c_vp]),
     "vbg_attn_drop_thr16": (C.c_uint, [c_f]),
     "vbg_attn_mask": (c_int, [c_vp, c_vp, c_int, c_int, c_int, c_f, c_ull, c_ull, c_vp, c_vp, c_vp]),
     "vbg_attn_mask_layers": (c_int, [c_vp, c_vp, c_int, c_int, c_int, c_f, c_ull, c_ull, c_ull, c_int, c_ll, c_vp, c_vp, c_vp]),

@@ -8,7 +8,7 @@ import os
 import torch
 
 from .lib import (EPI_GELU_DUAL, EPI_NONE, EPI_RELU, OP_CONV_K, OP_CONV_R, OP_DENSE_K, OP_DENSE_R, OP_WT_R, ConvGeo,
-                  AttnDesc, GemmDesc, PlaneGemmDesc, check, lib)
+                  AttnDesc, BertLayerFwdDesc, GemmDesc, PlaneGemmDesc, check, lib)
 
 f32 = torch.float32
 i32 = torch.int32
@@ -1504,6 +1504,101 @@ def attn(meta, mode, qkv: Planes, dO, out, lse, delta, masks, scale, p, kbar=Non
         d.out_amax = out_amax.data_ptr()
     check(lib.vbg_attn(C.byref(d), _stream()), "vbg_attn")
     return out
+
+
+# ----------------------------------------------------------------------------------------------
+# One encoder layer forward as ONE library call (csrc/encoder.hip, include/vbg.h vbg_bert_layer_fwd): the same seven launches with the
+# same descriptors as plane_gemm / attn / dropout_add_ln_fwd above would build one by one -- bit-identical results -- for about a third of
+# the host time per layer (no per-launch descriptor building in Python, one ctypes call).  `VBG_LAYER_ENTRY=0`: the per-launch path.
+# ----------------------------------------------------------------------------------------------
+_LAYER_ENTRY = [os.environ.get("VBG_LAYER_ENTRY", "1") != "0"]
+
+
+def set_layer_entry(on: bool):
+    _LAYER_ENTRY[0] = bool(on)
+
+
+def layer_entry_ok() -> bool:
+    """the measurement hooks time single launches and the stream-K tail needs its workspace: both stay on the per-launch path"""
+    return _LAYER_ENTRY[0] and _GEMM_PROF is None and not _STREAMK[0]
+
+
+def stacked_qkv(wq, wk, wv, bq, bk, bv, pair):
+    """planes of [wq; wk; wv] and the stacked bias for parameters that are NOT stored back to back (no flat buffers: inference, frozen
+    encoders) -- the Q/K/V projection then runs as one product as it does in training.  Cached on wq; stale when the optimizer kernels
+    ran (epoch), torch updated one of the six tensors in place (`_version`) or one moved (data_ptr).  No-grad callers only."""
+    cache = wq.__dict__.setdefault("_vbg_wplanes", {})
+    key = ("qkv", bool(pair))
+    tag = (_W_EPOCH[0],) + tuple(v for t in (wq, wk, wv, bq, bk, bv) for v in (t._version, t.data_ptr()))
+    hit = cache.get(key)
+    if hit is not None and hit[0] == tag:
+        return hit[1], hit[2]
+    n, k = wq.shape
+    with torch.no_grad():
+        pl = hit[1] if hit is not None else (pair_empty(3 * n, k, wq.device) if pair else planes_empty(3 * n, k, wq.device))
+        for j, w in enumerate((wq, wk, wv)):
+            assert tuple(w.shape) == (n, k) and w.is_contiguous()
+            sub = Planes(pl.buf[:, j * n:(j + 1) * n], n, k, pl.ld)
+            if pair:
+                split_planes_pair(w.detach(), out=sub)
+            else:
+                split_planes(w.detach(), out=sub)
+        bias = torch.cat([bq.detach().reshape(-1), bk.detach().reshape(-1), bv.detach().reshape(-1)]).contiguous()
+    cache[key] = (tag, pl, bias)
+    return pl, bias
+
+
+def _pref(r, pl):
+    if pl is not None:
+        r.buf, r.plane, r.ld = pl.buf.data_ptr(), pl.buf.stride(0), pl.ld
+
+
+def bert_layer_fwd(meta, *, eps, p, seed, sid, x, xa, pair_qkv, wqkv, bqkv, tile_qkv, pqkv, attn_pair, ctxv, lse, kbar, pctx, pctxq, masks, scale,
+                   wo, bo, ao_pair, tile_ao, ao, g1, b1, x1, xh1, rs1, px1, px1q, wi, bi, wo2, bo2, pair_ffn, tile_ffn1, tile_ffn2, h, pg, pgq, fo,
+                   g2, b2, y, xh2, rs2, py, pyq):
+    """Planes arguments may be None where include/vbg.h marks them optional; the flags say which form each product runs (pair: fp16-pair
+    planes, three piece products -- one on the hi planes inside an autocast region -- else three bf16 planes, six)."""
+    d = BertLayerFwdDesc()
+    ntok, hid = x.shape
+    inter = h.shape[1]
+    gform = 2 if _AMP[0] else 1
+    d.ntok, d.hidden, d.inter, d.heads = ntok, hid, inter, meta.heads
+    d.eps, d.drop_p, d.seed, d.stream_id0 = eps, p, seed, sid
+    d.form_qkv = gform if pair_qkv else 0
+    d.form_attn = (2 if amp_one_product() else 1) if attn_pair else 0
+    d.form_ao = gform if ao_pair else 0
+    d.form_ffn = gform if pair_ffn else 0
+    d.tile_qkv, d.tile_ao, d.tile_ffn1, d.tile_ffn2 = tile_qkv, tile_ao, tile_ffn1, tile_ffn2
+    d.ntasks, d.max_len, d.ntok_pad = meta.ntasks, meta.maxlen, meta.ntok_pad
+    d.tasks, d.seq_len, d.seq_row0, d.pad_off = meta.tasks.data_ptr(), meta.lens.data_ptr(), meta.seq_row0.data_ptr(), meta.pad_off.data_ptr()
+    if masks is not None:
+        d.mask_q, d.mask_k, d.mask_off = masks[0].data_ptr(), masks[1].data_ptr(), meta.mask_off.data_ptr()
+        d.keep_scale = attn_keep_scale(p)
+    else:
+        d.keep_scale = 1.0
+    d.attn_scale = scale
+    d.x = x.data_ptr()
+    _pref(d.xa, xa); _pref(d.wqkv, wqkv); _pref(d.wo, wo); _pref(d.wi, wi); _pref(d.wo2, wo2)
+    d.bqkv, d.bo, d.bi, d.bo2 = bqkv.data_ptr(), bo.data_ptr(), bi.data_ptr(), bo2.data_ptr()
+    d.g1, d.b1, d.g2, d.b2 = g1.data_ptr(), b1.data_ptr(), g2.data_ptr(), b2.data_ptr()
+    _pref(d.pqkv, pqkv)
+    d.ctx, d.lse = ctxv.data_ptr(), lse.data_ptr()
+    if kbar is not None:
+        d.kbar = kbar.data_ptr()
+    _pref(d.pctx, pctx); _pref(d.pctxq, pctxq)
+    d.ao, d.x1, d.xhat1, d.rstd1 = ao.data_ptr(), x1.data_ptr(), xh1.data_ptr(), rs1.data_ptr()
+    _pref(d.px1, px1); _pref(d.px1q, px1q)
+    d.h = h.data_ptr()
+    _pref(d.pg, pg); _pref(d.pgq, pgq)
+    d.fo, d.y, d.xhat2, d.rstd2 = fo.data_ptr(), y.data_ptr(), xh2.data_ptr(), rs2.data_ptr()
+    _pref(d.py, py); _pref(d.pyq, pyq)
+    if _DISPATCH[0] is not None:            # (the same tags the per-launch path leaves: tests assert which forms ran)
+        for f, t in ((d.form_qkv, tile_qkv), (d.form_ao, tile_ao), (d.form_ffn, tile_ffn1), (d.form_ffn, tile_ffn2)):
+            _seen(("plane_gemm:onep" if f == 2 else "plane_gemm:pair") if f else "plane_gemm:bf16x3")
+            _seen(f"plane_gemm:tile{int(t)}")
+        _seen(("attn:onep" if d.form_attn == 2 else "attn:pair") if attn_pair else "attn:bf16x3")
+        _seen("bert_layer_fwd:entry")
+    check(lib.vbg_bert_layer_fwd(C.byref(d), _stream()), "vbg_bert_layer_fwd")
 
 
 def row_softmax(x):
