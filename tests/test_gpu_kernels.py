@@ -1469,6 +1469,51 @@ def test_plane_gemm_nt_vs_fp64(tile):
         assert float((old - out).abs().max()) <= 1e-6 * scale
 
 
+def test_plane_gemm_pair_forms_on_the_small_tile():
+    """round 6: FORM 1 / FORM 2 on the 4-wave 64 x 64 NT tile (forward products of single documents).  The same piece products in the same
+    k order as the 8-wave tiles: bit-identical results, incl. bias, the GELU-dual epilogue and both plane outputs."""
+    from vbg import ops
+    from vbg.lib import EPI_GELU_DUAL
+    dev = torch.device("cuda")
+    g = torch.Generator().manual_seed(64064)
+    for (M, N, K) in ((512, 768, 768), (512, 2304, 768), (130, 3072, 768), (512, 768, 3072), (49, 264, 96)):
+        a = torch.randn(M, K, generator=g).to(dev)
+        b = (torch.randn(N, K, generator=g) / K ** 0.5).to(dev)
+        bias = torch.randn(N, generator=g).to(dev)
+        qa, qb = ops.split_planes_pair(a), ops.split_planes_pair(b)
+        for amp in (False, True):
+            with ops.amp_scope(amp):
+                big, small = torch.empty(M, N, device=dev), torch.empty(M, N, device=dev)
+                ops.plane_gemm(qa, qb, big, bias=bias, tile=128129, form=1)
+                log = ops.dispatch_log(True)
+                ops.plane_gemm(qa, qb, small, bias=bias, tile=64064, form=1)
+                ops.dispatch_log(False)
+                assert log.get("plane_gemm:onep" if amp else "plane_gemm:pair", 0) == 1 and log.get("plane_gemm:tile64064", 0) == 1
+                assert torch.equal(big, small), (M, N, K, amp)
+                outs = []
+                for tile in (128129, 64064):
+                    h = torch.empty(M, N, device=dev)
+                    pg, pq = ops.planes_empty(M, N, dev), ops.pair_empty(M, N, dev)
+                    ops.plane_gemm(qa, qb, h, bias=bias, epi=EPI_GELU_DUAL, out_planes=pg, out_pair=pq, tile=tile, form=1)
+                    outs.append((h, pg.buf[:, :, :N].clone(), pq.buf[:, :, :N].clone()))
+                for x, y in zip(*outs):
+                    assert torch.equal(x, y), (M, N, K, amp)
+                # planes only (the Q/K/V projection: no fp32 output at all)
+                pq1, pq2 = ops.pair_empty(M, N, dev), ops.pair_empty(M, N, dev)
+                ops.plane_gemm(qa, qb, None, bias=bias, out_pair=pq1, tile=128129, form=1)
+                ops.plane_gemm(qa, qb, None, bias=bias, out_pair=pq2, tile=64064, form=1)
+                assert torch.equal(pq1.buf[:, :, :N], pq2.buf[:, :, :N])
+        ref = a.double() @ b.double().t() + bias.double()
+        scale = float((a.double().abs() @ b.double().abs().t()).max())
+        with ops.amp_scope(False):
+            out = torch.empty(M, N, device=dev)
+            ops.plane_gemm(qa, qb, out, bias=bias, tile=64064, form=1)
+        assert float((out.double() - ref).abs().max()) <= 2e-6 * scale
+    # what the small tile's epilogue does not have is refused, not ignored
+    with pytest.raises(Exception):
+        ops.plane_gemm(qa, qb, torch.empty(M, N, device=dev), tile=64064, form=1, c_amax=ops.amax_slot(dev))
+
+
 @pytest.mark.parametrize("tile", [128129, 128130, 256128])
 def test_plane_gemm_pair_form_vs_fp64(tile):
     """csrc/gemm_planes.hip FORM 1: operands as two fp16 planes (hi, lo' = (x - hi) 2^11, round to nearest), three piece products, the

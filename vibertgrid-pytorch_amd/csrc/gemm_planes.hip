@@ -64,7 +64,9 @@ __global__ __launch_bounds__(WGM * WGN * 64) void plane_gemm_kernel(const vbg_pl
     constexpr int NW = WGM * WGN, NT = NW * 64;
     constexpr int BK = 32;
     constexpr int NPL = FORM == 2 ? 1 : (FORM ? 2 : 3);        // planes per operand that are loaded
-    static_assert(FORM == 0 || (NW == 8 && (TRANS || PP)), "the fp16-pair form exists for the 8-wave tiles (NT: ping-pong loop)");
+    // (round 6: ... and for the 4-wave 64 x 64 NT tile -- single documents: a 512-token product is 96 such tiles, and the form halves what each computes)
+    static_assert(FORM == 0 || (NW == 8 && (TRANS || PP)) || (NW == 4 && !TRANS && BM == 64 && BN == 64),
+                  "the fp16-pair form exists for the 8-wave tiles (NT: ping-pong loop) and the 64 x 64 NT tile");
     constexpr int WM = BM / WGM, WN = BN / WGN, TM = WM / 32, TN = WN / 32;
     constexpr int PA = BM * 64, PB = BN * 64;                  // bytes of one plane of a stage (64 B per row)
     constexpr int STAGE = NPL * (PA + PB);
@@ -1394,6 +1396,7 @@ static int plane_gemm_dispatch(const vbg_plane_gemm_desc* desc, void* stream, vo
                 else pg_launch_pair<128, 128, 4, 2, 3, true, 2>(d, s, ev0, ev1);
             } else if (tile == 256128) pg_launch_pair<256, 128, 4, 2, 3, false, 2>(d, s, ev0, ev1);
             else if (tile == 128129 || tile == 0) pg_launch_pair<128, 128, 4, 2, 4, false, 2>(d, s, ev0, ev1);
+            else if (tile == 64064 && d.ngroups == 0 && !d.c_amax && !d.cq_ref_in && !d.colsum) pg_launch_pair<64, 64, 2, 2, 3, false, 2>(d, s, ev0, ev1);
             else return VBG_EARG;
             VBG_LAUNCH_RET();
         }
@@ -1411,6 +1414,9 @@ static int plane_gemm_dispatch(const vbg_plane_gemm_desc* desc, void* stream, vo
         else if (tile == 128129 || tile == 0) {
             if (deep) pg_launch_pair<128, 128, 4, 2, 4>(d, s, ev0, ev1);
             else pg_launch_pair<128, 128, 4, 2, 3>(d, s, ev0, ev1);
+        } else if (tile == 64064 && d.ngroups == 0 && !d.c_amax && !d.cq_ref_in && !d.colsum) {
+            // small forward products (single-document inference): no amax / bound / column-sum by-products, those live in the 8-wave epilogue
+            pg_launch_pair<64, 64, 2, 2, 3>(d, s, ev0, ev1);
         } else return VBG_EARG;
         VBG_LAUNCH_RET();
     }

@@ -671,7 +671,11 @@ class BertLayerFn(torch.autograd.Function):
         # forward products whose operands are LayerNorm / GELU outputs and weights run on two fp16 pieces per operand (three piece
         # products, csrc/gemm_planes.hip FORM 1) once the problem fills the 8-wave tiles; the pair planes of x arrive as an attribute of
         # the previous layer's bf16 planes (written by its closing LayerNorm)
-        pair = planes and ops.pair_enabled() and ops.pair_tile(ntok, hid) != 0
+        # (round 6: nothing to differentiate -- inference, validation -- and a problem below the 8-wave tiles: the form runs on the 64 x 64 tile,
+        #  half the matrix-core work of the six-product form that single documents used to take)
+        nograd = not any(ctx.needs_input_grad)
+        pair = planes and ops.pair_enabled() and (ops.pair_tile(ntok, hid) != 0 or (nograd and ops.pair_small_enabled()))
+        ptile = lambda n, wide=False: ops.pair_tile(ntok, n, wide) or 64064
         carrier_is_pair = xpl is not None and xpl.shape[0] == 2          # (the previous layer ran the all-pair path: xpl ARE the pair planes)
         xq = (ops.Planes(xpl, ntok, hid, xpl.shape[2]) if carrier_is_pair else getattr(xpl, "_vbg_pair", None)) if (pair and xpl is not None) else None
         # all-pair path: the backward products run on two fp16 pieces as well (needs every weight / bias gradient of the layer sunk into
@@ -681,14 +685,14 @@ class BertLayerFn(torch.autograd.Function):
                     and any(ctx.needs_input_grad)
                     and all(sinks(t) for t in (wq, wk, wv, bq, bk, bv, wo, bo, wi, bi, wo2, bo2)))
         assert not carrier_is_pair or pair, "pair planes handed to a layer that does not run the pair form"
-        if pair_bwd and xq is None:
+        if (pair_bwd or (pair and nograd)) and xq is None:
             xq = ops.split_planes_pair(x)
         # q, k, v leave the projection as planes only (the fused attention kernels' operands): fp16-pair planes when the projection runs
         # the pair form and the backward that follows is the all-pair one (round 5: the attention then runs three fp16 piece products per
         # product, csrc/attn.hip FORM 1), three bf16 planes otherwise
         # parameters NOT stored back to back and nothing to differentiate (inference, validation): the stacked planes of the three
         # projections are cached on the weights (round 6) -- one Q/K/V product as in training instead of three
-        one_qkv = fused_qkv or (planes and not any(ctx.needs_input_grad))
+        one_qkv = fused_qkv or (planes and nograd)
         attn_pair = (flash and pair and one_qkv and xq is not None and ops.attn_pair_enabled() and ops.bound_planes_enabled()
                      and (pair_bwd or not any(ctx.needs_input_grad)))
         # round 6: the layer's seven launches leave from ONE library call (csrc/encoder.hip) -- same descriptors, a third of the host time
@@ -704,7 +708,7 @@ class BertLayerFn(torch.autograd.Function):
                     wqkv_pl, bqkv_t = ops.weight_planes(wq, view=_stack3(wq), also=(wk, wv), pair=xq is not None), _stack3(bq)
                 else:
                     wqkv_pl, bqkv_t = ops.stacked_qkv(wq, wk, wv, bq, bk, bv, pair=xq is not None)
-                tile_qkv = ops.pair_tile(ntok, 3 * hid) if xq is not None else ops._dense_tile(ntok, 3 * hid)
+                tile_qkv = ptile(3 * hid) if xq is not None else ops._dense_tile(ntok, 3 * hid)
             if fast:
                 pass
             elif one_qkv and xq is not None:
@@ -763,23 +767,26 @@ class BertLayerFn(torch.autograd.Function):
                 if pctx is None:
                     pctx = ops.split_planes(ctxv)
                 wo_pl, tile_ao = ops.weight_planes(wo), ops._dense_tile(ntok, hid)
-            px1 = None if pair_bwd else ops.planes_empty(ntok, hid, dev)
+            # (the bf16 planes of x1 / gelu(h) / y are operands of the BACKWARD's six-product form: not written when that backward runs the
+            #  pair form, nor when there is no backward at all and the forward reads the pair planes)
+            keep3 = not pair_bwd and not (pair and nograd)
+            px1 = ops.planes_empty(ntok, hid, dev) if keep3 else None
             px1q = ops.pair_empty(ntok, hid, dev) if pair else None
             inter = wi.shape[0]
             h = torch.empty((ntok, inter), device=dev, dtype=f32)
             # gelu(h) leaves the FFN1 epilogue as planes only (the A operand of FFN2 and, untransposed, of its weight gradient)
-            pg = None if pair_bwd else ops.planes_empty(ntok, inter, dev)
+            pg = ops.planes_empty(ntok, inter, dev) if keep3 else None
             pgq = ops.pair_empty(ntok, inter, dev) if pair else None
             fo = torch.empty((ntok, hid), device=dev, dtype=f32)
             wi_pl, wo2_pl = ops.weight_planes(wi, pair=pair), ops.weight_planes(wo2, pair=pair)
             if pair:
-                tile_f1, tile_f2 = ops.pair_tile(ntok, inter, True), ops.pair_tile(ntok, hid)
+                tile_f1, tile_f2 = ptile(inter, True), ptile(hid)
             else:
                 tile_f1, tile_f2 = ops._dense_tile(ntok, inter, True), ops._dense_tile(ntok, hid)
             if fast:
                 x1, xh1, y, xh2 = (torch.empty_like(x) for _ in range(4))
                 rs1, rs2 = (torch.empty((ntok,), device=dev, dtype=f32) for _ in range(2))
-                py = None if pair_bwd else ops.planes_empty(ntok, hid, dev)
+                py = ops.planes_empty(ntok, hid, dev) if keep3 else None
                 pyq = ops.pair_empty(ntok, hid, dev) if pair else None
                 ops.bert_layer_fwd(meta, eps=eps, p=p, seed=seed, sid=sid, x=x, xa=xq if xq is not None else px, pair_qkv=xq is not None,
                                    wqkv=wqkv_pl, bqkv=bqkv_t, tile_qkv=tile_qkv, pqkv=pqkv, attn_pair=attn_pair, ctxv=ctxv, lse=lse, kbar=kbar,
@@ -807,7 +814,7 @@ class BertLayerFn(torch.autograd.Function):
         if not fast:
             pyq = None
             if planes:
-                py = None if pair_bwd else ops.planes_empty(ntok, hid, dev)
+                py = ops.planes_empty(ntok, hid, dev) if keep3 else None
                 pyq = ops.pair_empty(ntok, hid, dev) if pair else None
             y, xh2, rs2 = ops.dropout_add_ln_fwd(fo, x1, g2, b2, eps, p, seed, sid + 2, out_planes=py, out_pair=pyq)
         ctx.meta, ctx.cfg = meta, (eps, p, seed, sid)

@@ -321,6 +321,19 @@ def pair_bwd_enabled() -> bool:
     return pair_enabled() and _PAIR_BWD[0]
 
 
+_PAIR_SMALL = [os.environ.get("VBG_PAIR_SMALL", "1") != "0"]
+
+
+def set_pair_small(on: bool):
+    """forward-only encoder layers (inference, validation) below the 8-wave tiles on the fp16-pair form's 64 x 64 tile instead of the
+    six-product bf16 form (`VBG_PAIR_SMALL=0`: the A/B)"""
+    _PAIR_SMALL[0] = bool(on)
+
+
+def pair_small_enabled() -> bool:
+    return _PAIR_SMALL[0]
+
+
 def pair_tile(M, N, wide=False):
     """tile of a form-1 product [M, N], or 0 when the problem is too small for the form (it then runs the bf16 form)"""
     t = _dense_tile(M, N, wide)
