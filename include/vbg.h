@@ -86,6 +86,12 @@ typedef struct vbg_gemm_desc {
        form 0 there), and products whose geometry forces 16-deep k-tiles run as form 0.  Results of all forms agree to fp32
        rounding for 0 / 3 and to bf16 operand rounding for 1. */
     int bf16;
+    /* round 6, optional: DETERMINISTIC split of the reduction.  splitk > 1 with slab_stride > 0 (elements): split s of the k range STORES its
+       partial product at C + s * slab_stride (plain stores, no atomics; no bias / epilogue / accumulate / groups / statistics), and
+       vbg_slab_reduce adds the slabs in split order, with the bias and an optional ReLU.  For products with a handful of output tiles and a
+       very long reduction: the first layer of the field-type classifier on ONE document is 128 x 1024 outputs over k = 13 312
+       (model/field_type_classification_head.py:78-110) -- 32 tiles of 416 k-tiles otherwise. */
+    long long slab_stride;
 } vbg_gemm_desc;
 
 int vbg_gemm(const vbg_gemm_desc* desc, void* stream);
@@ -93,6 +99,9 @@ int vbg_gemm(const vbg_gemm_desc* desc, void* stream);
  * timestamps delivered to two events (hipExtLaunchKernel start / stop events: no barrier packets around the kernel, the figure
  * rocprofv3's kernel trace reports), plus create / destroy / elapsed for those events (hipEvent_t passed as void*). */
 int vbg_gemm_timed(const vbg_gemm_desc* desc, void* stream, void* start_event, void* stop_event);
+/* out[m][n] = (relu ? max(., 0) : .)(sum_{s < nslabs, in order} slabs[s * slab_stride + m * lds + n] + bias[n])  (bias may be NULL; N % 4 == 0) */
+int vbg_slab_reduce(const float* slabs, int nslabs, long long slab_stride, int M, int N, long long lds, const float* bias, int relu,
+                    float* out, long long ldc, void* stream);
 int vbg_timer_create(void** event);
 int vbg_timer_destroy(void* event);
 int vbg_timer_elapsed_ms(void* start_event, void* stop_event, float* ms);
@@ -123,7 +132,8 @@ typedef struct vbg_plane_gemm_desc {
     unsigned short* Cp; long long c_plane; long long ldp;
     int epi; float alpha; int accumulate;                         /* C += result (atomics only if splitk > 1) */
     int splitk;                                                   /* >1 requires accumulate */
-    int tile;                                                     /* 0 auto; 256256 / 256128 / 128128 / 128129 / 128130 / 128064 / 64064 */
+    int tile;                                                     /* 0 auto; 256256 / 256128 / 128128 / 128129 / 128130 / 128064 / 64064;
+                                                                     64004: 64 x 64 with four LDS stages (forms 1, 2: cold weights, few tiles) */
     /* trans != 0 ("TN"): C[M,N] (+)= alpha * sum_k A[k,M] * B[k,N] -- the reduction index is the operands' ROW index: A planes
        [3][K][lda], B planes [3][K][ldb], lda / ldb multiples of 32 (zero padded), K any length.  The weight gradient dW = dY^T X
        straight from the planes of dY and X that the data-gradient / forward products already use (LDS transpose reads). */

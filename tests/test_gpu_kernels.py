@@ -56,6 +56,39 @@ def test_gemm_nt(ops, M, N, K):
         assert close(y, eye @ w.t(), 0, 1e-6)
 
 
+@pytest.mark.parametrize("M,N,K,relu", [(128, 1024, 13312, True), (15, 1024, 13312, False), (128, 256, 4100, True), (200, 512, 8192, False)])
+def test_linear_slab_split_is_deterministic(ops, M, N, K, relu):
+    """round 6: a forward linear layer with a handful of output tiles over a very long reduction (the field-type head's first layer on one
+    document) cuts the reduction into slabs that a second launch adds in split order (include/vbg.h vbg_gemm_desc.slab_stride,
+    vbg_slab_reduce): against fp64, bit-identical run to run, with and without autograd (no atomics anywhere), and actually taken"""
+    from vbg.lib import EPI_NONE, EPI_RELU
+    assert ops.slab_split(M, N, K) >= 2 and ops.slab_split(1024, 1024, 13312) == 1 and ops.slab_split(128, 1024, 1024) == 1
+    x, w, b = rnd(M, K, seed=11).to(dev()), (rnd(N, K, seed=12) / math.sqrt(K)).to(dev()), rnd(N, seed=13).to(dev())
+    ref = x.double() @ w.double().t() + b.double()
+    if relu:
+        ref = ref.clamp_min(0)
+    scale = float((x.double().abs() @ w.double().abs().t()).max())
+    log = ops.dispatch_log(True)
+    y = ops.linear_fwd(x, w, b, EPI_RELU if relu else EPI_NONE)
+    ops.dispatch_log(False)
+    assert log.get("gemm:slab_split", 0) == 1
+    assert float((y.double() - ref).abs().max()) <= 2e-6 * scale
+    with torch.no_grad():
+        y2 = ops.linear_fwd(x, w, b, EPI_RELU if relu else EPI_NONE)
+    assert torch.equal(y, y2) and torch.equal(y, ops.linear_fwd(x, w, b, EPI_RELU if relu else EPI_NONE))
+    was = ops._SLAB_SPLIT[0]
+    ops._SLAB_SPLIT[0] = False
+    try:
+        with torch.no_grad():
+            y1 = ops.linear_fwd(x, w, b, EPI_RELU if relu else EPI_NONE)
+    finally:
+        ops._SLAB_SPLIT[0] = was
+    assert float((y1 - y).abs().max()) <= 2e-6 * scale
+    # a split without k-tiles of its own is refused (its slab would stay unwritten)
+    with pytest.raises(Exception):
+        ops.gemm_raw(64, 64, 256, x, K, 0, w, K, 0, torch.empty(8, 64, 64, device=dev()), 64, splitk=8, slab_stride=64 * 64)
+
+
 @pytest.mark.parametrize("tile", [64, 128])
 def test_gemm_tiles_epilogues(ops, tile):
     from vbg.lib import EPI_GELU_DUAL, EPI_RELU, OP_DENSE_K
@@ -259,7 +292,7 @@ def test_conv3x3_row_reuse(ops, B, H, W, Cs, N):
 
 
 @pytest.mark.parametrize("B,H,W,Cs,N,nz", [(8, 32, 32, 64, 256, 3), (8, 32, 32, 64, 256, 4), (2, 16, 16, 96, 128, 6), (2, 16, 16, 96, 128, 2),
-                                           (4, 16, 16, 192, 384, 12), (1, 8, 16, 32, 128, 3)])
+                                           (4, 16, 16, 192, 384, 12), (1, 8, 16, 32, 128, 3), (1, 16, 16, 512, 512, 12)])
 def test_conv3x3_split(ops, B, H, W, Cs, N, nz):
     """split form of csrc/conv3.hip (nz workgroups per tile, one filter row and / or channel group each, slabs + arrival ticket, the
     last arriver adds them in block order): against fp64 conv2d with bias and fused BatchNorm statistics, both arithmetic forms, the
@@ -292,6 +325,8 @@ def test_conv3x3_split(ops, B, H, W, Cs, N, nz):
     # the library's own choice for the late trunk stages puts at least 256 workgroups on the chip
     assert ops.conv3_split(8, 32, 32, 256, 256) * 128 >= 256 and ops.conv3_split(8, 16, 16, 512, 512) * 64 >= 256
     assert ops.conv3_ok(8, 32, 32, 256, 256, 3, 3, 1, 1) and ops.conv3_ok(8, 16, 16, 512, 512, 3, 3, 1, 1)
+    # ... and a single document's last stage (8 tiles) is split twelve ways instead of running 32 workgroups of the generic kernel
+    assert ops.conv3_split(1, 16, 16, 512, 512) == 12 and ops.conv3_ok(1, 16, 16, 512, 512, 3, 3, 1, 1)
 
 
 @pytest.mark.parametrize("B,H,W,Cs,N,nz", [(2, 8, 128, 32, 128, 1), (1, 128, 128, 64, 64, 1), (2, 5, 256, 32, 128, 1), (1, 3, 512, 16, 132, 1),
@@ -1490,14 +1525,18 @@ def test_plane_gemm_pair_forms_on_the_small_tile():
                 ops.dispatch_log(False)
                 assert log.get("plane_gemm:onep" if amp else "plane_gemm:pair", 0) == 1 and log.get("plane_gemm:tile64064", 0) == 1
                 assert torch.equal(big, small), (M, N, K, amp)
+                deep = torch.empty(M, N, device=dev)
+                ops.plane_gemm(qa, qb, deep, bias=bias, tile=64004, form=1)          # (four LDS stages: the same products in the same order)
+                assert torch.equal(big, deep), (M, N, K, amp)
                 outs = []
-                for tile in (128129, 64064):
+                for tile in (128129, 64064, 64004):
                     h = torch.empty(M, N, device=dev)
                     pg, pq = ops.planes_empty(M, N, dev), ops.pair_empty(M, N, dev)
                     ops.plane_gemm(qa, qb, h, bias=bias, epi=EPI_GELU_DUAL, out_planes=pg, out_pair=pq, tile=tile, form=1)
                     outs.append((h, pg.buf[:, :, :N].clone(), pq.buf[:, :, :N].clone()))
-                for x, y in zip(*outs):
-                    assert torch.equal(x, y), (M, N, K, amp)
+                for other in outs[1:]:
+                    for x, y in zip(outs[0], other):
+                        assert torch.equal(x, y), (M, N, K, amp)
                 # planes only (the Q/K/V projection: no fp32 output at all)
                 pq1, pq2 = ops.pair_empty(M, N, dev), ops.pair_empty(M, N, dev)
                 ops.plane_gemm(qa, qb, None, bias=bias, out_pair=pq1, tile=128129, form=1)

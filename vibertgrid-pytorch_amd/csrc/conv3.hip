@@ -1137,7 +1137,8 @@ extern "C" int vbg_conv3x3_split(int B, int H, int W, int Cs, int N) {
     static const int forced = getenv("VBG_CONV3_SPLIT_Z") ? atoi(getenv("VBG_CONV3_SPLIT_Z")) : 0;
     if (W < 16 || (W & (W - 1)) != 0 || ((long long)H * W) % 128 != 0 || N % 128 != 0 || Cs % 16 != 0 || W >= 128) return 1;
     const long long tiles = ((long long)B * H * W / 128) * (N / 128);
-    if (tiles >= 240 || tiles < 16) return 1;
+    // (round 6: down to 4 tiles -- a single document's last stage is 8 tiles of 4608-long reductions: 92 us on the generic 64 x 64 tiles, 32 workgroups)
+    if (tiles >= 240 || tiles < 4) return 1;
     int nz = tiles * 3 >= 256 ? 3 : tiles * 4 >= 256 ? 4 : tiles * 6 >= 256 ? 6 : 12;      // (measured: 512 channels at 16 x 16 pixels, 4: 63 us, 6: 66, 3: 71, 1: 137)
     if (forced > 0) nz = forced;
     const int cs = nz % 3 == 0 ? nz / 3 : nz;

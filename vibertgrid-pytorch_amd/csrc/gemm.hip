@@ -167,7 +167,7 @@ __global__ __launch_bounds__(NT) void gemm_kernel(const vbg_gemm_desc p) {
     int M = p.M, N = p.N, K = p.K;
     const float* A = p.A;
     const float* B = p.B;
-    float* C = p.C;
+    float* C = p.C + (long long)split * p.slab_stride;          // (slab_stride > 0: every split stores its own partial product)
     float* C2 = p.C2;
     const float* bias = p.bias;
     if (p.grp) {
@@ -1091,7 +1091,11 @@ static int gemm_dispatch(const vbg_gemm_desc* desc, void* stream, const vbg::lau
     VBG_CHECK_ARG(d.A && d.B && d.C);
     VBG_CHECK_ARG(d.M >= 0 && d.N >= 0 && d.K >= 0);
     VBG_CHECK_ARG(d.splitk >= 0);
-    if (d.splitk > 1) VBG_CHECK_ARG(d.accumulate == 1);
+    VBG_CHECK_ARG(d.slab_stride >= 0);
+    if (d.slab_stride > 0)          // deterministic split: plain partial products, combined by vbg_slab_reduce
+        VBG_CHECK_ARG(d.splitk > 1 && !d.accumulate && d.epi == VBG_EPI_NONE && !d.bias && !d.C2 && !d.grp && !d.stats && d.slab_stride >= (long long)d.M * d.ldc &&
+                      d.K >= 64ll * d.splitk * d.splitk);          // (every split owns k-tiles: a split without any would leave its slab unwritten)
+    else if (d.splitk > 1) VBG_CHECK_ARG(d.accumulate == 1);
     if (d.epi == VBG_EPI_GELU_DUAL) VBG_CHECK_ARG(d.C2 != nullptr);
     if (d.accumulate) VBG_CHECK_ARG(d.epi == VBG_EPI_NONE);
     VBG_CHECK_ARG(d.a_nseg >= 0 && d.a_nseg <= 4);
@@ -1191,4 +1195,33 @@ extern "C" int vbg_timer_elapsed_ms(void* start_event, void* stop_event, float* 
     VBG_CHECK_ARG(start_event && stop_event && ms);
     const hipError_t err = hipEventElapsedTime(ms, (hipEvent_t)start_event, (hipEvent_t)stop_event);
     return err == hipSuccess ? VBG_OK : (int)err;
+}
+
+// ---- deterministic split-K, second pass: the slabs added in split order, bias, optional ReLU (include/vbg.h vbg_gemm_desc.slab_stride) ----
+namespace vbg {
+__global__ __launch_bounds__(256) void slab_reduce_kernel(const float* __restrict__ slabs, int nslabs, long long slab_stride, int M, int N4, long long lds,
+                                                          const float* __restrict__ bias, int relu, float* __restrict__ out, long long ldc) {
+    const long long i = (long long)blockIdx.x * 256 + threadIdx.x;
+    if (i >= (long long)M * N4) return;
+    const int m = (int)(i / N4), c = (int)(i - (long long)m * N4) * 4;
+    float4 v = *reinterpret_cast<const float4*>(slabs + (long long)m * lds + c);
+    for (int s = 1; s < nslabs; ++s) {
+        const float4 w = *reinterpret_cast<const float4*>(slabs + s * slab_stride + (long long)m * lds + c);
+        v.x += w.x; v.y += w.y; v.z += w.z; v.w += w.w;
+    }
+    if (bias) { const float4 b = *reinterpret_cast<const float4*>(bias + c); v.x += b.x; v.y += b.y; v.z += b.z; v.w += b.w; }
+    if (relu) { v.x = fmaxf(v.x, 0.f); v.y = fmaxf(v.y, 0.f); v.z = fmaxf(v.z, 0.f); v.w = fmaxf(v.w, 0.f); }
+    *reinterpret_cast<float4*>(out + (long long)m * ldc + c) = v;
+}
+}  // namespace vbg
+
+extern "C" int vbg_slab_reduce(const float* slabs, int nslabs, long long slab_stride, int M, int N, long long lds, const float* bias, int relu,
+                               float* out, long long ldc, void* stream) {
+    VBG_CHECK_ARG(slabs && out && nslabs >= 1 && M >= 0 && N >= 0 && N % 4 == 0 && lds % 4 == 0 && ldc % 4 == 0 && slab_stride % 4 == 0 && lds >= N && ldc >= N);
+    VBG_CHECK_ARG(((uintptr_t)slabs | (uintptr_t)out | (uintptr_t)bias) % 16 == 0);
+    if (M == 0 || N == 0) return VBG_OK;
+    const long long n = (long long)M * (N / 4);
+    VBG_LAUNCH(vbg::slab_reduce_kernel, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, (hipStream_t)stream, slabs, nslabs, slab_stride, M, N / 4, lds,
+               bias, relu, out, ldc);
+    VBG_LAUNCH_RET();
 }

@@ -72,7 +72,9 @@ __global__ __launch_bounds__(WGM * WGN * 64) void plane_gemm_kernel(const vbg_pl
     constexpr int STAGE = NPL * (PA + PB);
     constexpr int NIA = NPL * BM / 16 / NW, NIB = NPL * BN / 16 / NW;      // DMA instructions per wave and stage
     static_assert((NPL * BM / 16) % NW == 0 && (NPL * BN / 16) % NW == 0, "DMA units must divide over the waves");
-    static_assert(NST == 2 || NST == 3 || (NST == 4 && !TRANS && WGM * WGN == 8 && PP), "two or three LDS stages (four: ping-pong loop only)");
+    // (round 6: the 4-wave 64 x 64 NT tile takes more stages -- a single document's products are a few hundred tiles that wait for COLD weights)
+    static_assert(NST == 2 || NST == 3 || (NST == 4 && !TRANS && WGM * WGN == 8 && PP) || (NST >= 4 && NST <= 8 && !TRANS && WGM * WGN == 4 && BM == 64 && BN == 64),
+                  "two or three LDS stages (four: ping-pong loop; four to eight: the 64 x 64 NT tile)");
     constexpr int CTS = BN + 4;
     constexpr int SMEM = (NST * STAGE > BM * CTS * 4) ? NST * STAGE : BM * CTS * 4;
     __shared__ __attribute__((aligned(1024))) unsigned char smem[SMEM];          // (the ONE LDS object of the kernel)
@@ -384,9 +386,10 @@ __global__ __launch_bounds__(WGM * WGN * 64) void plane_gemm_kernel(const vbg_pl
         if (!grp) __builtin_amdgcn_s_barrier();             // group 0 waits for group 1's last interval
     } else {
     issue(0, 0u);
-    if constexpr (NST == 3) {
-        issue(1, ntiles > 1 ? 0u : PG_INVALID);
-        asm volatile("s_waitcnt vmcnt(%0)" ::"n"(NIW) : "memory");
+    if constexpr (NST >= 3) {
+#pragma unroll
+        for (int s_ = 1; s_ < NST - 1; ++s_) issue(s_, ntiles > s_ ? 0u : PG_INVALID);
+        asm volatile("s_waitcnt vmcnt(%0)" ::"n"((NST - 2) * NIW) : "memory");
     } else {
         asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
     }
@@ -405,10 +408,10 @@ __global__ __launch_bounds__(WGM * WGN * 64) void plane_gemm_kernel(const vbg_pl
     int cur = 0;                                   // stage of tile t
     for (int t = 0; t < ntiles; ++t) {
         const int nxt = (cur + 1 == NST) ? 0 : cur + 1;
-        const int nn = (nxt + 1 == NST) ? 0 : nxt + 1;
+        const int far = (cur == 0) ? NST - 1 : cur - 1;          // stage of tile t + NST - 1 = the one tile t - 1 left (NST = 3: cur + 2)
         // ---- first half: products of set 0; set 1 of this tile is read and the DMA of tile t+NST-1 is issued in their gaps ----
         __builtin_amdgcn_sched_barrier(0);
-        issue(NST == 3 ? nn : nxt, t + NST - 1 < ntiles ? 0u : PG_INVALID);
+        issue(NST >= 3 ? far : nxt, t + NST - 1 < ntiles ? 0u : PG_INVALID);
         read_frags(cur, fo1, fa1, fb1);
         mma(fa0, fb0);
         // (a 32x32x16 bf16 MFMA holds the matrix pipe for 32 cycles = ~8 issue slots: one LDS read and one DMA per gap ride free)
@@ -419,10 +422,10 @@ __global__ __launch_bounds__(WGM * WGN * 64) void plane_gemm_kernel(const vbg_pl
             if (g < NIW) { __builtin_amdgcn_sched_group_barrier(0x004, 2, 0); __builtin_amdgcn_sched_group_barrier(0x020, 1, 0); }
         }
         __builtin_amdgcn_sched_barrier(0);
-        if constexpr (NST == 3) {
-            // tile t+1 must have landed (this wave's share; the DMA just issued stays in flight), and this wave's reads of the stage
-            // the NEXT iteration's DMA overwrites must be done, before anybody passes the barrier
-            asm volatile("s_waitcnt vmcnt(%0) lgkmcnt(0)" ::"n"(NIW) : "memory");
+        if constexpr (NST >= 3) {
+            // tile t+1 must have landed (this wave's share; the DMAs of tiles t+2 .. t+NST-1 stay in flight), and this wave's reads of the
+            // stage the NEXT iteration's DMA overwrites must be done, before anybody passes the barrier
+            asm volatile("s_waitcnt vmcnt(%0) lgkmcnt(0)" ::"n"((NST - 2) * NIW) : "memory");
             __builtin_amdgcn_s_barrier();
             __builtin_amdgcn_sched_barrier(0);
             read_frags(nxt, fo0, fa0, fb0);          // (unconditional: past the last tile it reads stale LDS that nobody uses)
@@ -1396,7 +1399,10 @@ static int plane_gemm_dispatch(const vbg_plane_gemm_desc* desc, void* stream, vo
                 else pg_launch_pair<128, 128, 4, 2, 3, true, 2>(d, s, ev0, ev1);
             } else if (tile == 256128) pg_launch_pair<256, 128, 4, 2, 3, false, 2>(d, s, ev0, ev1);
             else if (tile == 128129 || tile == 0) pg_launch_pair<128, 128, 4, 2, 4, false, 2>(d, s, ev0, ev1);
-            else if (tile == 64064 && d.ngroups == 0 && !d.c_amax && !d.cq_ref_in && !d.colsum) pg_launch_pair<64, 64, 2, 2, 3, false, 2>(d, s, ev0, ev1);
+            else if ((tile == 64064 || tile == 64004) && d.ngroups == 0 && !d.c_amax && !d.cq_ref_in && !d.colsum) {
+                if (tile == 64004) pg_launch_pair<64, 64, 2, 2, 4, false, 2>(d, s, ev0, ev1);
+                else pg_launch_pair<64, 64, 2, 2, 3, false, 2>(d, s, ev0, ev1);
+            }
             else return VBG_EARG;
             VBG_LAUNCH_RET();
         }
@@ -1414,9 +1420,12 @@ static int plane_gemm_dispatch(const vbg_plane_gemm_desc* desc, void* stream, vo
         else if (tile == 128129 || tile == 0) {
             if (deep) pg_launch_pair<128, 128, 4, 2, 4>(d, s, ev0, ev1);
             else pg_launch_pair<128, 128, 4, 2, 3>(d, s, ev0, ev1);
-        } else if (tile == 64064 && d.ngroups == 0 && !d.c_amax && !d.cq_ref_in && !d.colsum) {
-            // small forward products (single-document inference): no amax / bound / column-sum by-products, those live in the 8-wave epilogue
-            pg_launch_pair<64, 64, 2, 2, 3>(d, s, ev0, ev1);
+        } else if ((tile == 64064 || tile == 64004) && d.ngroups == 0 && !d.c_amax && !d.cq_ref_in && !d.colsum) {
+            // small forward products (single-document inference): no amax / bound / column-sum by-products, those live in the 8-wave epilogue.
+            // 64004: four LDS stages (64 KB, two workgroups per CU): three k-tiles in flight for weights that come from HBM -- FFN2 of one document
+            // 42 -> 32 us (tools/small_gemm_cold.py; eight stages and a split-K over atomics were measured too: no better / slower)
+            if (tile == 64004) pg_launch_pair<64, 64, 2, 2, 4>(d, s, ev0, ev1);
+            else pg_launch_pair<64, 64, 2, 2, 3>(d, s, ev0, ev1);
         } else return VBG_EARG;
         VBG_LAUNCH_RET();
     }

@@ -675,7 +675,7 @@ class BertLayerFn(torch.autograd.Function):
         #  half the matrix-core work of the six-product form that single documents used to take)
         nograd = not any(ctx.needs_input_grad)
         pair = planes and ops.pair_enabled() and (ops.pair_tile(ntok, hid) != 0 or (nograd and ops.pair_small_enabled()))
-        ptile = lambda n, wide=False: ops.pair_tile(ntok, n, wide) or 64064
+        ptile = lambda n, wide=False: ops.pair_tile(ntok, n, wide) or 64004          # (four LDS stages: the weights of a lone document come from HBM)
         carrier_is_pair = xpl is not None and xpl.shape[0] == 2          # (the previous layer ran the all-pair path: xpl ARE the pair planes)
         xq = (ops.Planes(xpl, ntok, hid, xpl.shape[2]) if carrier_is_pair else getattr(xpl, "_vbg_pair", None)) if (pair and xpl is not None) else None
         # all-pair path: the backward products run on two fp16 pieces as well (needs every weight / bias gradient of the layer sunk into

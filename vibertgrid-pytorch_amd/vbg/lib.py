@@ -33,7 +33,7 @@ class GemmDesc(C.Structure):
                 ("C", c_vp), ("ldc", c_ll), ("C2", c_vp), ("bias", c_vp),
                 ("epi", c_int), ("alpha", c_f), ("accumulate", c_int), ("splitk", c_int), ("tile", c_int),
                 ("grp", c_vp), ("ngroups", c_int), ("grp_maxM", c_int), ("grp_maxN", c_int), ("bk", c_int),
-                ("stats", c_vp), ("stats_slots", c_int), ("bf16", c_int)]
+                ("stats", c_vp), ("stats_slots", c_int), ("bf16", c_int), ("slab_stride", c_ll)]
 
 
 class Conv3WprepEntry(C.Structure):          # include/vbg.h vbg_conv3_wprep_entry
@@ -106,6 +106,7 @@ SIGNATURES = {
     "vbg_timer_create": (c_int, [c_vp]),
     "vbg_timer_destroy": (c_int, [c_vp]),
     "vbg_timer_elapsed_ms": (c_int, [c_vp, c_vp, c_vp]),
+    "vbg_slab_reduce": (c_int, [c_vp, c_int, c_ll, c_int, c_int, c_ll, c_vp, c_int, c_vp, c_ll, c_vp]),
     "vbg_plane_gemm": (c_int, [C.POINTER(PlaneGemmDesc), c_vp]),
     "vbg_plane_gemm_timed": (c_int, [C.POINTER(PlaneGemmDesc), c_vp, c_vp, c_vp]),
     "vbg_split_planes": (c_int, [c_vp, c_ll, c_int, c_int, c_vp, c_int, c_ll, c_int, c_vp, c_vp]),

@@ -167,7 +167,7 @@ def _chk_f32(*ts):
 # ----------------------------------------------------------------------------------------------
 def gemm_raw(M, N, K, A, lda, a_kind, B, ldb, b_kind, Cout, ldc, *, bias=None, epi=EPI_NONE, C2=None, accumulate=False,
              splitk=1, geo=None, segs=None, a_hw=(0, 0), a_relu_scale=None, grp=None, ngroups=0, grp_max=(0, 0), tile=0,
-             alpha=1.0, a_ptr_off=0, b_ptr_off=0, c_ptr_off=0, bk=0, stats=None):
+             alpha=1.0, a_ptr_off=0, b_ptr_off=0, c_ptr_off=0, bk=0, stats=None, slab_stride=0):
     """A, B, Cout: tensors (their data_ptr + element offsets are used).  stats: BatchNorm slot workspace [slots*2N] fp64 that receives the
     per-column sum / sum of squares of the output (fused into the epilogue; the launch is then never split)."""
     d = GemmDesc()
@@ -206,6 +206,7 @@ def gemm_raw(M, N, K, A, lda, a_kind, B, ldb, b_kind, Cout, ldc, *, bias=None, e
         _untag(Cout)
     d.epi, d.alpha, d.accumulate, d.splitk, d.tile = epi, float(alpha), int(bool(accumulate)), int(splitk), int(tile)
     d.bk = int(bk)
+    d.slab_stride = int(slab_stride)          # (> 0: split s stores its partial product at Cout + s * slab_stride; slab_reduce adds them)
     if _AMP[0] or _SPLIT3[0]:
         d.bf16 = 1 if _AMP[0] else 3
         if bk == 16:
@@ -721,8 +722,30 @@ def linear_fwd(x, w, bias=None, epi=EPI_NONE, out=None, out2=None):
         out = torch.empty((M, N), device=x.device, dtype=f32)
     if epi == EPI_GELU_DUAL and out2 is None:
         out2 = torch.empty_like(out)
+    sk = slab_split(M, N, K) if (epi in (EPI_NONE, EPI_RELU) and N % 4 == 0 and out.stride(0) % 4 == 0 and _GEMM_PROF is None) else 1
+    if sk > 1:
+        # a handful of output tiles over a very long reduction (the field-type head's first layer on one document: 32 tiles of 416
+        # k-tiles, 253 us): the reduction is cut into `sk` slabs that a second small launch adds in order -- deterministic
+        slabs = torch.empty((sk, M, N), device=x.device, dtype=f32)
+        gemm_raw(M, N, K, x, x.stride(0), OP_DENSE_K, w, w.stride(0), OP_DENSE_K, slabs, N, splitk=sk, slab_stride=M * N)
+        check(lib.vbg_slab_reduce(P(slabs), sk, M * N, M, N, N, P(bias), int(epi == EPI_RELU), P(out), out.stride(0), _stream()), "vbg_slab_reduce")
+        _seen("gemm:slab_split")
+        return out
     gemm_raw(M, N, K, x, x.stride(0), OP_DENSE_K, w, w.stride(0), OP_DENSE_K, out, out.stride(0), bias=bias, epi=epi, C2=out2)
     return (out, out2) if epi == EPI_GELU_DUAL else out
+
+
+_SLAB_SPLIT = [os.environ.get("VBG_SLAB_SPLIT", "1") != "0"]
+
+
+def slab_split(M, N, K) -> int:
+    """slabs a forward linear layer's reduction is cut into (1: none): at most 64 output tiles of 64 x 64 and k >= 4096, enough slabs to
+    put ~256 workgroups on the chip, each at least 1024 deep, at most 8"""
+    tiles = ((M + 63) // 64) * ((N + 63) // 64)
+    if not _SLAB_SPLIT[0] or tiles > 64 or K < 4096 or M == 0:
+        return 1
+    sk = min(8, 256 // tiles, K // 1024)
+    return sk if sk >= 2 else 1
 
 
 def linear_dgrad(dy, w, out=None, accumulate=False):
@@ -1224,7 +1247,7 @@ def conv3_late_choice(B, H, W, Cs, N):
     if not (_CONV3_BN64[0] and _CONV3_PW[0] and _CONV3_SPLITK[0]) or (H == 7 and W == 7) or N % 128 or (H * W) % 128 or W >= 128 or Cs % 16:
         return None
     t128 = (B * H * W // 128) * (N // 128)
-    if t128 >= 240 or t128 < 16:
+    if t128 >= 240 or t128 < 4:          # (round 6: from 4 tiles on -- a single document's last stage)
         return None
     t64 = 2 * t128
     nz = 1 if t64 >= 240 else min(4, -(-480 // t64))
