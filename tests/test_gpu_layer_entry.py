@@ -120,6 +120,26 @@ def test_inference_is_bit_identical_and_runs_one_qkv_product(tmp_path, pair):
         ops.set_layer_entry(was); ops.set_pair(True, force=False)
 
 
+def test_inference_inside_autocast_takes_the_one_product_forms_on_the_small_tile(tmp_path):
+    """`amp: True` validation / inference of a document or two: the encoder's products run form 2 on the 64 x 64 tile (round 6), through
+    the layer entry; probabilities stay within the fp16 operand rounding of the fp32-grade call"""
+    from vbg import ops
+    dev = torch.device("cuda")
+    net = _net(tmp_path, 0.0).to(dev).eval()
+    imgs, segs, classes, coors, corpus, mask = _batch(dev)
+    with torch.no_grad():
+        ref = net.inference(imgs, segs, coors, corpus, mask).clone()
+        log = ops.dispatch_log(True)
+        with torch.autocast("cuda", dtype=torch.float16):
+            got = net.inference(imgs, segs, coors, corpus, mask).clone()
+        ops.dispatch_log(False)
+    ops.set_amp(False)
+    assert log.get("bert_layer_fwd:entry", 0) == LAYERS and log.get("plane_gemm:onep", 0) >= 3 * LAYERS and log.get("attn:onep", 0) == LAYERS, log
+    assert log.get("plane_gemm:tile64004", 0) >= 3 * LAYERS, log
+    assert bool(torch.isfinite(got).all()) and torch.allclose(got.sum(1), torch.ones(got.shape[0], device=dev), atol=1e-5)
+    assert float((got - ref).abs().max()) < 2e-2 and float((got - ref).abs().max()) > 0.0
+
+
 def test_layer_entry_rejects_a_descriptor_without_its_operands():
     import ctypes as C
     from vbg.lib import BertLayerFwdDesc, lib
