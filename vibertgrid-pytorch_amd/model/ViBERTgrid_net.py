@@ -260,8 +260,8 @@ class ViBERTgridNet(nn.Module):
 
     def _overlap_safe(self) -> bool:
         """May the encoder run on the side stream in this call?  Only where it pays and where nobody reads gradients behind the library's
-        back.  (i) Training steps: a single-document `inference()` is host-bound and the extra stream traffic costs it 3 % (5.06 -> 5.21
-        ms).  (ii) The encoder's weight gradients are written by kernels on the side stream straight into the flat gradient views
+        back.  (i) Training steps: forward-only calls lose on the second stream (round 5: 5.06 -> 5.21 ms for one document; round 6, with
+        the call no longer host-bound: 3.9 -> 4.1 ms, eight documents 8.95 -> 9.18 ms, profiles/r06_infer_overlap_ab.txt).  (ii) The encoder's weight gradients are written by kernels on the side stream straight into the flat gradient views
         (autograd sees `None`): vbg.optim.FlatReducer is told per parameter and its staging stream waits for the side stream, the end of
         backward() joins the streams for whatever the caller enqueues next -- but torch's DistributedDataParallel copies `.grad` into its
         buckets from a hook on the AccumulateGrad node, which the engine runs on the caller's stream WITHOUT an event for an undefined
