@@ -1140,6 +1140,7 @@ extern "C" int vbg_conv3x3_split(int B, int H, int W, int Cs, int N) {
     // (round 6: down to 4 tiles -- a single document's last stage is 8 tiles of 4608-long reductions: 92 us on the generic 64 x 64 tiles, 32 workgroups)
     if (tiles >= 240 || tiles < 4) return 1;
     int nz = tiles * 3 >= 256 ? 3 : tiles * 4 >= 256 ? 4 : tiles * 6 >= 256 ? 6 : 12;      // (measured: 512 channels at 16 x 16 pixels, 4: 63 us, 6: 66, 3: 71, 1: 137)
+    if (tiles < 16) nz = 4;          // (one document: 8 tiles -- 4: 45 us, 6: 46, 12: 63, 1: 86; tools/conv3_small_sweep.py)
     if (forced > 0) nz = forced;
     const int cs = nz % 3 == 0 ? nz / 3 : nz;
     if (Cs % cs != 0 || (Cs / cs) % 16 != 0) return 1;

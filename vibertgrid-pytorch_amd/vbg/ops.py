@@ -1571,7 +1571,7 @@ def stacked_qkv(wq, wk, wv, bq, bk, bv, pair):
         return hit[1], hit[2]
     n, k = wq.shape
     with torch.no_grad():
-        pl = hit[1] if hit is not None else (pair_empty(3 * n, k, wq.device) if pair else planes_empty(3 * n, k, wq.device))
+        pl = hit[1] if (hit is not None and hit[1].buf.device == wq.device) else (pair_empty(3 * n, k, wq.device) if pair else planes_empty(3 * n, k, wq.device))
         for j, w in enumerate((wq, wk, wv)):
             assert tuple(w.shape) == (n, k) and w.is_contiguous()
             sub = Planes(pl.buf[:, j * n:(j + 1) * n], n, k, pl.ld)
