@@ -76,13 +76,14 @@ def test_gemm_desc_offsets_against_the_c_compiler(tmp_path):
     import ctypes as C
     import shutil
     import subprocess
-    from vbg.lib import AttnDesc, Conv3WprepEntry, GemmDesc, ConvGeo, PlaneGemmDesc, PlaneGroup
+    from vbg.lib import AttnDesc, BertLayerFwdDesc, Conv3WprepEntry, GemmDesc, ConvGeo, PlaneGemmDesc, PlaneGroup, PlanesRef
     if shutil.which("gcc") is None:
         pytest.skip("no C compiler")
     root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
     src = ['#include <stdio.h>', '#include <stddef.h>', '#include "vbg.h"', 'int main(void) {']
     for st, cls in (("vbg_gemm_desc", GemmDesc), ("vbg_conv_geo", ConvGeo), ("vbg_plane_gemm_desc", PlaneGemmDesc), ("vbg_plane_group", PlaneGroup),
-                    ("vbg_attn_desc", AttnDesc), ("vbg_conv3_wprep_entry", Conv3WprepEntry)):
+                    ("vbg_attn_desc", AttnDesc), ("vbg_conv3_wprep_entry", Conv3WprepEntry), ("vbg_planes_ref", PlanesRef),
+                    ("vbg_bert_layer_fwd_desc", BertLayerFwdDesc)):
         src.append(f'printf("{st} sizeof %zu\\n", sizeof({st}));')
         for name, _ in cls._fields_:
             src.append(f'printf("{st} {name} %zu\\n", offsetof({st}, {name}));')
@@ -94,7 +95,8 @@ def test_gemm_desc_offsets_against_the_c_compiler(tmp_path):
     out = subprocess.run([exe], check=True, capture_output=True, text=True).stdout.split("\n")
     got = {(a, b): int(c) for a, b, c in (ln.split() for ln in out if ln)}
     for st, cls in (("vbg_gemm_desc", GemmDesc), ("vbg_conv_geo", ConvGeo), ("vbg_plane_gemm_desc", PlaneGemmDesc), ("vbg_plane_group", PlaneGroup),
-                    ("vbg_attn_desc", AttnDesc), ("vbg_conv3_wprep_entry", Conv3WprepEntry)):
+                    ("vbg_attn_desc", AttnDesc), ("vbg_conv3_wprep_entry", Conv3WprepEntry), ("vbg_planes_ref", PlanesRef),
+                    ("vbg_bert_layer_fwd_desc", BertLayerFwdDesc)):
         assert got[(st, "sizeof")] == C.sizeof(cls)
         for name, _ in cls._fields_:
             assert got[(st, name)] == getattr(cls, name).offset, (st, name)
