@@ -625,11 +625,13 @@ def main():
             # ... and the strict six-product form everywhere: no fp16-pair products (forward BERT linears, wide 3x3 convolutions)
             ops.set_pair(False)          # (also takes the BERT backward off the pair form)
             ops.set_conv3_f16(False)
+            ops.set_gemm_f16(False)
             sdt, _ = timed_leg()
             ops.set_pair(True)
             ops.set_conv3_f16(True)
+            ops.set_gemm_f16(True)
             strict_leg = {"value": round(B * world * args.steps / sdt, 3), "unit": "docs/sec", "ms_per_step": round(1e3 * sdt / args.steps, 3),
-                          "dtype": "three bf16 pieces per operand / six piece products for EVERY fp32-grade product (VBG_PAIR=0 VBG_CONV3_F16=0)"}
+                          "dtype": "three bf16 pieces per operand / six piece products for EVERY fp32-grade product (VBG_PAIR=0 VBG_CONV3_F16=0 VBG_GEMM_F16=0)"}
         amp_leg = {"value": round(B * world * args.steps / adt, 3), "unit": "docs/sec", "ms_per_step": round(1e3 * adt / args.steps, 3),
                    "dtype": "one reduced-precision MFMA product per product (fp16 hi pieces on the plane / row-reuse kernels, bf16 on the generic ones), "
                             "f32 accumulate / storage / everything else", "last_loss": round(float(amp_last), 4)}
@@ -689,7 +691,7 @@ def main():
                            "fp16-pair planes / pre-split filters; gradients scaled into range by their amax slots) on the BERT linears and the wide 3x3 "
                            "convolutions and the attention-output projection, to bf16 on the generic kernels (1x1, heads, stem); the fused attention itself stays on six bf16 piece products" if args.amp else
                            "f32 MFMA for every product" if args.fp32_mfma else
-                           "fp32-grade on the bf16 / fp16 matrix cores, f32 accumulate: (a) exact 3-way bf16 split of every operand, 6 piece products per product -- fused attention, the attention-output projection, the generic convolutions, 1x1 / heads; (b) 2 fp16 pieces per operand (round to nearest, hi + lo 2^-11: 2^-23 relative), 3 piece products, same measured error against fp64 -- the BERT linears QKV / FFN1 / FFN2 forward, all BERT data and weight gradients, and the wide 3x3 convolutions forward, input gradient and weight gradient (gradient operands scaled by the power of two that centres their largest magnitude in fp16's range: exact); an operand outside fp16's range becomes inf, never a clipped value; the strided conv weight gradients and the unaligned stem on the f32 MFMA; the strict form (a) everywhere is the `bf16x3_strict` leg"),
+                           "fp32-grade on the bf16 / fp16 matrix cores, f32 accumulate: (a) exact 3-way bf16 split of every operand, 6 piece products per product -- fused attention, the attention-output projection, the generic convolutions, 1x1 / heads; (b) 2 fp16 pieces per operand (round to nearest, hi + lo 2^-11: 2^-23 relative), 3 piece products, same measured error against fp64 -- the BERT linears QKV / FFN1 / FFN2 forward, all BERT data and weight gradients, the wide 3x3 convolutions forward, input gradient and weight gradient, and (round 6) the forward of the generic kernels' products on 64 x 64 tiles: strided / 1x1 convolutions, early fusion, heads (gradient operands scaled by the power of two that centres their largest magnitude in fp16's range: exact); an operand outside fp16's range becomes inf, never a clipped value; the strided conv weight gradients and the unaligned stem on the f32 MFMA; the strict form (a) everywhere is the `bf16x3_strict` leg"),
             "config": {"workload": ("SROIE line-level cfg2: resnet_34_fpn_pretrained + bert-base-uncased (12L, vocab 30522, random init), "
                                     f"512x512, T=512 tokens, S=128 segments, batch {B}/GPU, fwd+bwd+SGD/AdamW, dropout 0.1, simp classifier")
                        if args.shape == "cfg2" else f"EXPLORATORY {args.shape}: {shape}, T=512, batch {B}/GPU (not the BASELINE metric's configuration)",

@@ -82,6 +82,10 @@ typedef struct vbg_gemm_desc {
           these ops.
        3: fp32-grade on the bf16 matrix cores -- every operand element is split exactly into three bf16 pieces inside the kernel and
           each product is the fp32 sum of the six piece products of order <= 2^-16 (error <= 2^-23 of the product).
+       2 (round 6): fp32-grade on the fp16 matrix cores for operands INSIDE fp16's range -- two pieces per element (hi = fp16(x), lo' =
+          fp16((x - hi) 2^11), round to nearest), three piece products: half the matrix-core work of form 3, the same measured error
+          against fp64; |x| >= 65520 becomes inf, never a clipped value.  The FORWARD kinds only (A DENSE_K / CONV_K, B DENSE_K: activations
+          and weights) where they run 64 x 64 tiles; any other kind or tile given form 2 runs form 3 (on the 128 x 128 tiles it measured slower).
        Forms 1 and 3 need 16-byte aligned operands (a_vec, b_vec); form 3 is not available for row-contiguous A (the library uses
        form 0 there), and products whose geometry forces 16-deep k-tiles run as form 0.  Results of all forms agree to fp32
        rounding for 0 / 3 and to bf16 operand rounding for 1. */

@@ -89,6 +89,80 @@ def test_linear_slab_split_is_deterministic(ops, M, N, K, relu):
         ops.gemm_raw(64, 64, 256, x, K, 0, w, K, 0, torch.empty(8, 64, 64, device=dev()), 64, splitk=8, slab_stride=64 * 64)
 
 
+def test_gemm_fp16_pair_form_of_the_forward_kinds(ops):
+    """round 6, include/vbg.h vbg_gemm_desc.bf16 = 2: the generic kernels' FORWARD products (dense NT, K-segmented NT with on-the-fly
+    upsampling, strided / 1x1 / 3x3 implicit-GEMM convolutions) on two fp16 pieces per operand, three piece products, the split done in
+    registers: the bound of the six-product form against fp64, every tile the dispatcher picks, bias / ReLU / GELU epilogues, fused
+    BatchNorm statistics; out-of-range operands visible; the backward kinds given the form fall back to six products"""
+    from vbg.lib import EPI_GELU_DUAL, EPI_NONE, EPI_RELU, OP_DENSE_K
+    d = dev()
+    g = torch.Generator().manual_seed(22)
+    torch.set_grad_enabled(False)          # (with autograd on, vbg.ops.gemm_raw lets the library split long reductions over atomics: not bit-reproducible)
+    request_grad = lambda: torch.set_grad_enabled(True)
+    try:
+        _fp16_form_body(ops, d, g, EPI_GELU_DUAL, EPI_NONE, EPI_RELU, OP_DENSE_K)
+    finally:
+        request_grad()
+
+
+def _fp16_form_body(ops, d, g, EPI_GELU_DUAL, EPI_NONE, EPI_RELU, OP_DENSE_K):
+    for (M, N, K) in ((333, 260, 160), (4128, 768, 768), (1024, 1024, 12544), (131072, 256, 64), (40000, 512, 96)):
+        x = (torch.randn(M, K, generator=g) * torch.exp2(torch.randint(-6, 6, (M, 1), generator=g).float())).to(d)
+        w = (torch.randn(N, K, generator=g) / K ** 0.5).to(d)
+        b = torch.randn(N, generator=g).to(d)
+        ref = x.double() @ w.double().t() + b.double()
+        scale = float((x.double().abs() @ w.double().abs().t()).max())
+        for tile in (0, 64, 128):
+            log = ops.dispatch_log(True)
+            out = torch.empty(M, N, device=d)
+            ops.gemm_raw(M, N, K, x, K, OP_DENSE_K, w, K, OP_DENSE_K, out, N, bias=b, tile=tile, f16=True)
+            ops.dispatch_log(False)
+            assert log.get("gemm:f16x2", 0) == 1, log
+            assert float((out.double() - ref).abs().max()) <= 2e-6 * scale, (M, N, K, tile)
+            six = torch.empty(M, N, device=d)
+            ops.gemm_raw(M, N, K, x, K, OP_DENSE_K, w, K, OP_DENSE_K, six, N, bias=b, tile=tile)
+            assert float((six - out).abs().max()) <= 2e-6 * scale
+            # a different arithmetic where the form is really taken: the shapes the six-product form runs on 64 x 64 tiles (on 128 x 128
+            # tiles the fp16 form measured slower -- tools/gemm_f16_bench.py -- and the library keeps six products there)
+            small = tile == 64 or (tile == 0 and not (-(-M // 128) * -(-N // 128) >= 192 and N >= 128))
+            assert torch.equal(six, out) != small, (M, N, K, tile)
+        out = torch.empty(M, N, device=d)
+        ops.gemm_raw(M, N, K, x, K, OP_DENSE_K, w, K, OP_DENSE_K, out, N, bias=b, epi=EPI_RELU, f16=True)
+        assert float((out.double() - ref.clamp_min(0)).abs().max()) <= 2e-6 * scale
+        if M <= 4128:
+            out2 = torch.empty(M, N, device=d)
+            ops.gemm_raw(M, N, K, x, K, OP_DENSE_K, w, K, OP_DENSE_K, out, N, bias=b, epi=EPI_GELU_DUAL, C2=out2, f16=True)
+            assert float((out2.double() - F.gelu(ref)).abs().max()) <= 3e-6 * scale
+    # out of range: visible, never clipped
+    big = torch.full((128, 64), 70000.0, device=d)
+    o = torch.empty(128, 64, device=d)
+    ops.gemm_raw(128, 64, 64, big, 64, OP_DENSE_K, torch.ones(64, 64, device=d), 64, OP_DENSE_K, o, 64, f16=True)
+    assert not bool(torch.isfinite(o).any())
+    # convolutions through the implicit-GEMM loader (3x3 stride 2, 1x1 stride 2, 3x3 stride 1 on a shape the row-reuse kernel does not take)
+    for (B, H, W, Ci, Co, k, s_, p_) in ((2, 64, 64, 64, 128, 3, 2, 1), (2, 64, 64, 64, 128, 1, 2, 0), (1, 24, 40, 32, 96, 3, 1, 1)):
+        xi = torch.randn(B, Ci, H, W, generator=g)
+        wi = torch.randn(Co, Ci, k, k, generator=g) / (Ci * k * k) ** 0.5
+        ref = F.conv2d(xi.double(), wi.double(), None, s_, p_).permute(0, 2, 3, 1)
+        xh, wh = xi.permute(0, 2, 3, 1).contiguous().to(d), wi.permute(0, 2, 3, 1).contiguous().to(d)
+        was = ops._CONV3[0]
+        ops._CONV3[0] = False
+        try:
+            log = ops.dispatch_log(True)
+            y = ops.conv2d_fwd(xh, wh, s_, p_)
+            ops.dispatch_log(False)
+        finally:
+            ops._CONV3[0] = was
+        assert log.get("gemm:f16x2", 0) == 1, log
+        assert float((y.double().cpu() - ref).abs().max()) <= 3e-6 * float(ref.abs().max()) * (Ci * k * k) ** 0.5
+    # the backward kinds do not take the form (their gradient operands are not scaled into fp16's range here)
+    dy, wt = torch.randn(512, 256, generator=g).to(d) * 1e-7, torch.randn(256, 128, generator=g).to(d)
+    from vbg.lib import OP_DENSE_R
+    a, c = torch.empty(512, 128, device=d), torch.empty(512, 128, device=d)
+    ops.gemm_raw(512, 128, 256, dy, 256, OP_DENSE_K, wt, 128, OP_DENSE_R, a, 128, f16=True)
+    ops.gemm_raw(512, 128, 256, dy, 256, OP_DENSE_K, wt, 128, OP_DENSE_R, c, 128)
+    assert torch.equal(a, c)
+
+
 @pytest.mark.parametrize("tile", [64, 128])
 def test_gemm_tiles_epilogues(ops, tile):
     from vbg.lib import EPI_GELU_DUAL, EPI_RELU, OP_DENSE_K

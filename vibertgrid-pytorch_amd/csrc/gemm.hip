@@ -84,6 +84,7 @@ __device__ __forceinline__ unsigned cvt_pk_bf16(float lo, float hi) {
     return r;
 }
 typedef __bf16 bf16x8 __attribute__((ext_vector_type(8)));
+typedef _Float16 f16x8 __attribute__((ext_vector_type(8)));
 // scheduling pipeline of a bf16 k-tile body: after every MFMA its share of the NV VALU and ND LDS-write instructions of the region
 template <int M, int NM, int NV, int ND>
 struct sched_pipe {
@@ -108,7 +109,11 @@ template <int BM, int BN, int BK, int NT, int AK, int BKD, bool VEC, int PREC = 
 __global__ __launch_bounds__(NT) void gemm_kernel(const vbg_gemm_desc p) {
     constexpr bool HB = PREC != 0;
     constexpr bool PIPE2_X16 = VBG_PIPE2_X16;      // 16-deep bf16 k-tiles on the two-tiles-in-flight loop as well (measured, see below)
-    constexpr int NP = PREC == 3 ? 3 : 1;      // bf16 planes per operand tile
+    // PREC 2 (round 6): fp32-grade products on the fp16 matrix cores for operands inside fp16's range (FORWARD products: activations and
+    // weights) -- two pieces per operand, hi = fp16(x), lo' = fp16((x - hi) 2^11), both rounded to nearest, three piece products (hi hi into
+    // the main accumulators, lo' hi + hi lo' into a second set that is scaled by 2^-11 once, behind the loop): the arithmetic of
+    // csrc/gemm_planes.hip FORM 1 and of the row-reuse convolutions, with the split done here, in registers.  Half the matrix-core work of PREC 3.
+    constexpr int NP = PREC == 3 ? 3 : (PREC == 2 ? 2 : 1);      // 16-bit planes per operand tile
     constexpr int WGM = 2, WGN = 2;
     constexpr int NBUF = 2;
     constexpr int NE = VEC ? 1 : 4;            // separately addressed pieces per float4
@@ -500,6 +505,15 @@ __global__ __launch_bounds__(NT) void gemm_kernel(const vbg_gemm_desc p) {
         mid = __builtin_amdgcn_perm(__float_as_uint(rb), __float_as_uint(ra), 0x07060302u);
         lo = __builtin_amdgcn_perm(__float_as_uint(sb), __float_as_uint(sa), 0x07060302u);
     };
+    auto split2 = [&](float a, float b, unsigned& hi, unsigned& lo) {
+        typedef float f32x2_t __attribute__((ext_vector_type(2)));
+        typedef _Float16 f16x2_t __attribute__((ext_vector_type(2)));
+        const f32x2_t v = {a, b};
+        const f16x2_t h = __builtin_convertvector(v, f16x2_t);                        // v_cvt_pk_f16_f32: round to nearest even
+        const f16x2_t l = __builtin_convertvector((v - __builtin_convertvector(h, f32x2_t)) * 2048.f, f16x2_t);
+        hi = __builtin_bit_cast(unsigned, h);
+        lo = __builtin_bit_cast(unsigned, l);
+    };
     auto store_half = [&](unsigned* dst, const auto& r, auto kc_tag, auto br4_tag, auto plane_tag) {
         constexpr int n = std::extent<std::remove_reference_t<decltype(r)>>::value;
         constexpr int BR4 = decltype(br4_tag)::value;
@@ -517,6 +531,12 @@ __global__ __launch_bounds__(NT) void gemm_kernel(const vbg_gemm_desc p) {
                     *reinterpret_cast<uint2*>(&dst[o]) = h;
                     *reinterpret_cast<uint2*>(&dst[o + PL]) = m;
                     *reinterpret_cast<uint2*>(&dst[o + 2 * PL]) = l;
+                } else if constexpr (PREC == 2) {
+                    uint2 h, l;
+                    split2(r[i].x, r[i].y, h.x, l.x);
+                    split2(r[i].z, r[i].w, h.y, l.y);
+                    *reinterpret_cast<uint2*>(&dst[o]) = h;
+                    *reinterpret_cast<uint2*>(&dst[o + PL]) = l;
                 } else {
                     uint2 w;
                     w.x = cvt_pk_bf16(r[i].x, r[i].y); w.y = cvt_pk_bf16(r[i].z, r[i].w);
@@ -535,6 +555,10 @@ __global__ __launch_bounds__(NT) void gemm_kernel(const vbg_gemm_desc p) {
                         unsigned h, m, l;
                         split3(e0[e], e1[e], h, m, l);
                         dst[o] = h; dst[o + PL] = m; dst[o + 2 * PL] = l;
+                    } else if constexpr (PREC == 2) {
+                        unsigned h, l;
+                        split2(e0[e], e1[e], h, l);
+                        dst[o] = h; dst[o + PL] = l;
                     } else {
                         dst[o] = cvt_pk_bf16(e0[e], e1[e]);
                     }
@@ -594,13 +618,16 @@ __global__ __launch_bounds__(NT) void gemm_kernel(const vbg_gemm_desc p) {
     const int lane = tid & 63, wave = tid >> 6;
     const int wm = wave >> 1, wn = wave & 1;
     const int lr = lane & 31, lk = lane >> 5;
-    f32x16 acc[TM][TN];
+    f32x16 acc[TM][TN], acx[PREC == 2 ? TM : 1][PREC == 2 ? TN : 1];          // (PREC 2: the cross products, scaled by 2^11)
 #pragma unroll
     for (int i = 0; i < TM; ++i)
 #pragma unroll
         for (int j = 0; j < TN; ++j)
 #pragma unroll
-            for (int r = 0; r < 16; ++r) acc[i][j][r] = 0.f;
+            for (int r = 0; r < 16; ++r) {
+                acc[i][j][r] = 0.f;
+                if constexpr (PREC == 2) acx[i][j][r] = 0.f;
+            }
 
     // MFMA step j of k-group g uses k = 8g + 4*lk + j (same permutation for A and B)
     const int a_off = A_KC ? (wm * WM + lr) * SKR + 4 * lk : 4 * lk * SA + wm * WM + lr;
@@ -679,7 +706,7 @@ __global__ __launch_bounds__(NT) void gemm_kernel(const vbg_gemm_desc p) {
             store_half(reinterpret_cast<unsigned*>(Bs + buf * BSZ), RB, std::integral_constant<bool, B_KC>{}, std::integral_constant<int, BN / 4>{}, std::integral_constant<int, PB>{});
         };
         constexpr int KS = BK / 16;
-        constexpr int NPP = PREC == 3 ? 6 : 1;
+        constexpr int NPP = PREC == 3 ? 6 : (PREC == 2 ? 3 : 1);
         const int arow = A_KC ? wm * WM + lr : (lr & 3) * PSA + (wm * WM + lr) / 4;
         const int brow = B_KC ? wn * WN + lr : (lr & 3) * PSB + (wn * WN + lr) / 4;
         constexpr int AI = A_KC ? 32 : 8, BI = B_KC ? 32 : 8;              // LDS rows between a wave's 32-row fragments
@@ -709,6 +736,11 @@ __global__ __launch_bounds__(NT) void gemm_kernel(const vbg_gemm_desc p) {
                     for (int i = 0; i < TM; ++i)
 #pragma unroll
                         for (int n = 0; n < TN; ++n)
+                            if constexpr (PREC == 2) {          // (lo', hi) (hi, lo') -> cross sums, (hi, hi) -> main
+                                f32x16& d_ = t < 2 ? acx[i][n] : acc[i][n];
+                                d_ = __builtin_amdgcn_mfma_f32_32x32x16_f16(__builtin_bit_cast(f16x8, fa[s][t == 0 ? 1 : 0][i]),
+                                                                            __builtin_bit_cast(f16x8, fb[s][t == 1 ? 1 : 0][n]), d_, 0, 0, 0);
+                            } else
                             acc[i][n] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(__builtin_bit_cast(bf16x8, fa[s][qa[t]][i]),
                                                                                 __builtin_bit_cast(bf16x8, fb[s][qb[t]][n]), acc[i][n], 0, 0, 0);
         };
@@ -731,7 +763,7 @@ __global__ __launch_bounds__(NT) void gemm_kernel(const vbg_gemm_desc p) {
             __builtin_amdgcn_sched_barrier(0);
             fix(SA, SB, srem_a, srem_b);
             __builtin_amdgcn_sched_barrier(0);
-            if constexpr (PREC == 3) {
+            if constexpr (PREC == 3 || PREC == 2) {
                 mma_range(i0{}, ih{});
                 __builtin_amdgcn_sched_barrier(0);
                 mma_range(ih{}, i1{});
@@ -794,7 +826,7 @@ __global__ __launch_bounds__(NT) void gemm_kernel(const vbg_gemm_desc p) {
                 if constexpr (MORE) load_tiles(tail_tag);
                 __builtin_amdgcn_sched_barrier(0);
                 // piece products, smallest first: (lo,hi) (hi,lo) (mid,mid) (mid,hi) (hi,mid) (hi,hi)
-                constexpr int NPP = PREC == 3 ? 6 : 1;
+                constexpr int NPP = PREC == 3 ? 6 : (PREC == 2 ? 3 : 1);
                 constexpr int qa[6] = {PREC == 3 ? 2 : 0, 0, 1, 1, 0, 0}, qb[6] = {0, 2, 1, 0, 1, 0};
                 auto mma_range = [&](auto t0_tag, auto t1_tag) {
 #pragma unroll
@@ -805,13 +837,18 @@ __global__ __launch_bounds__(NT) void gemm_kernel(const vbg_gemm_desc p) {
                             for (int i = 0; i < TM; ++i)
 #pragma unroll
                                 for (int n = 0; n < TN; ++n)
+                                    if constexpr (PREC == 2) {
+                                        f32x16& d_ = t < 2 ? acx[i][n] : acc[i][n];
+                                        d_ = __builtin_amdgcn_mfma_f32_32x32x16_f16(__builtin_bit_cast(f16x8, fa[s][t == 0 ? 1 : 0][i]),
+                                                                                    __builtin_bit_cast(f16x8, fb[s][t == 1 ? 1 : 0][n]), d_, 0, 0, 0);
+                                    } else
                                     acc[i][n] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(__builtin_bit_cast(bf16x8, fa[s][qa[t]][i]),
                                                                                         __builtin_bit_cast(bf16x8, fb[s][qb[t]][n]), acc[i][n], 0, 0, 0);
                 };
                 using i0 = std::integral_constant<int, 0>;
                 using ih = std::integral_constant<int, NPP / 3>;
                 using i1 = std::integral_constant<int, NPP>;
-                if constexpr (PREC == 3 && MORE) {
+                if constexpr ((PREC == 3 || PREC == 2) && MORE) {
                     // first half of the piece products covers the latency of the loads just issued; the split of the loaded tile and its
                     // LDS writes are then issued into the gaps of the second half (a 32x32x16 bf16 MFMA holds the matrix pipe for 32
                     // cycles = ~8 issue slots)
@@ -872,6 +909,15 @@ __global__ __launch_bounds__(NT) void gemm_kernel(const vbg_gemm_desc p) {
             if (tail_in_range && ntiles >= 2) { k_tile(yes_t{}, yes_t{}, it & 1); ++it; }
         }
         k_tile(no_t{}, no_t{}, it & 1);
+    }
+
+    if constexpr (PREC == 2) {
+#pragma unroll
+        for (int i = 0; i < TM; ++i)
+#pragma unroll
+            for (int j = 0; j < TN; ++j)
+#pragma unroll
+                for (int r = 0; r < 16; ++r) acc[i][j][r] += acx[i][j][r] * (1.f / 2048.f);
     }
 
     // ---------------- epilogue ----------------------------------------------------------
@@ -1036,7 +1082,14 @@ static int launch_pair(const vbg_gemm_desc& d, int groups, int maxM, int maxN, h
     pick_tile(d, groups, maxM, maxN, tile, bk);
     if (!(d.a_vec && d.b_vec)) {                         // unaligned operands: general scalar-load path
         launch_one<64, 64, 16, 256, AK, BKD, false>(d, groups, maxM, maxN, s, t);
-    } else if (d.bf16 == 3 && d.bk != 16 &&
+    } else if (d.bf16 == 2 && d.bk != 16 && (AK == VBG_OP_DENSE_K || AK == VBG_OP_CONV_K) && BKD == VBG_OP_DENSE_K &&
+               (d.tile == 0 ? !((long)cdiv(maxM, 128) * cdiv(maxN, 128) * groups * d.splitk >= 192 && maxN >= 128) : tile == 64064)) {
+        // the fp16-pair form of the forward kinds (PREC 2), where the six-product form would run 64 x 64 tiles: 1024 x 1024 x 12544 163 -> 120 us,
+        // the strided 3x3 convolutions 36 -> 29 / 41 -> 30 us.  On the 128 x 128 tiles it measured SLOWER than six products (131072 x 256 x 1024:
+        // 391 -> 423 us; a second accumulator set on 304 registers, a VALU-heavier split): those keep PREC 3 (tools/gemm_f16_bench.py)
+        if constexpr ((AK == VBG_OP_DENSE_K || AK == VBG_OP_CONV_K) && BKD == VBG_OP_DENSE_K)
+            launch_one<64, 64, 32, 256, AK, BKD, true, 2>(d, groups, maxM, maxN, s, t);
+    } else if ((d.bf16 == 3 || d.bf16 == 2) && d.bk != 16 &&
                (AK != VBG_OP_DENSE_R || d.tile != 0 || BKD == VBG_OP_DENSE_R ||
                 (BKD == VBG_OP_CONV_R && d.K / d.splitk >= 2048 && maxM >= 128 && maxN >= 128))) {
         // fp32-grade split form (tools/gemm_bench.py; --fp32 for the other form).  Forward and dgrad kinds: 128x128x16 tiles (73 KB

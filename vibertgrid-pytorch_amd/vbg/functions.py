@@ -212,7 +212,7 @@ class SegLinearFn(torch.autograd.Function):
             kend += c
             segs.append((x, kend, c, s))
         ops.gemm_raw(M, N, K, xs[0], chans[0], OP_DENSE_K, w2d, K, OP_DENSE_K, out, N, bias=b, segs=segs,
-                     a_hw=hw if any(shifts) else (0, 0))
+                     a_hw=hw if any(shifts) else (0, 0), f16=True)
         ctx.shifts, ctx.hw, ctx.chans, ctx.has_bias = shifts, hw, chans, b is not None
         ctx.full_shape = full.shape
         ctx.save_for_backward(w2d, *xs)

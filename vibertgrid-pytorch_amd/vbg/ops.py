@@ -165,9 +165,16 @@ def _chk_f32(*ts):
 # ----------------------------------------------------------------------------------------------
 # GEMM family
 # ----------------------------------------------------------------------------------------------
+_GEMM_F16 = [os.environ.get("VBG_GEMM_F16", "1") != "0"]          # round 6: the generic kernels' forward products on two fp16 pieces (0: three bf16 pieces)
+
+
+def set_gemm_f16(on: bool):
+    _GEMM_F16[0] = bool(on)
+
+
 def gemm_raw(M, N, K, A, lda, a_kind, B, ldb, b_kind, Cout, ldc, *, bias=None, epi=EPI_NONE, C2=None, accumulate=False,
              splitk=1, geo=None, segs=None, a_hw=(0, 0), a_relu_scale=None, grp=None, ngroups=0, grp_max=(0, 0), tile=0,
-             alpha=1.0, a_ptr_off=0, b_ptr_off=0, c_ptr_off=0, bk=0, stats=None, slab_stride=0):
+             alpha=1.0, a_ptr_off=0, b_ptr_off=0, c_ptr_off=0, bk=0, stats=None, slab_stride=0, f16=False):
     """A, B, Cout: tensors (their data_ptr + element offsets are used).  stats: BatchNorm slot workspace [slots*2N] fp64 that receives the
     per-column sum / sum of squares of the output (fused into the epilogue; the launch is then never split)."""
     d = GemmDesc()
@@ -208,7 +215,11 @@ def gemm_raw(M, N, K, A, lda, a_kind, B, ldb, b_kind, Cout, ldc, *, bias=None, e
     d.bk = int(bk)
     d.slab_stride = int(slab_stride)          # (> 0: split s stores its partial product at Cout + s * slab_stride; slab_reduce adds them)
     if _AMP[0] or _SPLIT3[0]:
-        d.bf16 = 1 if _AMP[0] else 3
+        # f16: a FORWARD product (activations x weights, inside fp16's range): two fp16 pieces per operand, three piece products (include/vbg.h
+        # vbg_gemm_desc.bf16 = 2, round 6) -- half the matrix-core work of the six-product form; the library runs it for the forward kinds only
+        d.bf16 = 1 if _AMP[0] else (2 if (f16 and _GEMM_F16[0] and grp is None) else 3)
+        if _DISPATCH[0] is not None and not _AMP[0] and grp is None:
+            _seen("gemm:f16x2" if d.bf16 == 2 else "gemm:bf16x3")
         if bk == 16:
             d.bk = 0        # (the 16-deep k-tiles are an fp32-form tuning)
         if grp is not None and not _AMP[0]:
@@ -727,11 +738,11 @@ def linear_fwd(x, w, bias=None, epi=EPI_NONE, out=None, out2=None):
         # a handful of output tiles over a very long reduction (the field-type head's first layer on one document: 32 tiles of 416
         # k-tiles, 253 us): the reduction is cut into `sk` slabs that a second small launch adds in order -- deterministic
         slabs = torch.empty((sk, M, N), device=x.device, dtype=f32)
-        gemm_raw(M, N, K, x, x.stride(0), OP_DENSE_K, w, w.stride(0), OP_DENSE_K, slabs, N, splitk=sk, slab_stride=M * N)
+        gemm_raw(M, N, K, x, x.stride(0), OP_DENSE_K, w, w.stride(0), OP_DENSE_K, slabs, N, splitk=sk, slab_stride=M * N, f16=True)
         check(lib.vbg_slab_reduce(P(slabs), sk, M * N, M, N, N, P(bias), int(epi == EPI_RELU), P(out), out.stride(0), _stream()), "vbg_slab_reduce")
         _seen("gemm:slab_split")
         return out
-    gemm_raw(M, N, K, x, x.stride(0), OP_DENSE_K, w, w.stride(0), OP_DENSE_K, out, out.stride(0), bias=bias, epi=epi, C2=out2)
+    gemm_raw(M, N, K, x, x.stride(0), OP_DENSE_K, w, w.stride(0), OP_DENSE_K, out, out.stride(0), bias=bias, epi=epi, C2=out2, f16=True)
     return (out, out2) if epi == EPI_GELU_DUAL else out
 
 
@@ -1208,10 +1219,10 @@ def conv2d_fwd(x, w_ohwi, stride, pad, bias=None, out=None, stats=None, w_owner=
         # 65520 or more no longer becomes inf, and small activations keep more bits -- exact either way
         return conv3x3(x, w_ohwi, bias, out, stats, f16x2=_CONV3_F16[0], w_planes=wp, x_amax=x_amax if _CONV3_F16[0] else None)
     if kh == 1 and kw == 1 and stride == 1 and pad == 0:
-        gemm_raw(M, Cout, K, x, Cin, OP_DENSE_K, w_ohwi, K, OP_DENSE_K, out, Cout, bias=bias, stats=stats)
+        gemm_raw(M, Cout, K, x, Cin, OP_DENSE_K, w_ohwi, K, OP_DENSE_K, out, Cout, bias=bias, stats=stats, f16=True)
     else:
         gemm_raw(M, Cout, K, x, Cin, OP_CONV_K, w_ohwi, K, OP_DENSE_K, out, Cout, bias=bias,
-                 geo=conv_geo(H, W, Cin, Ho, Wo, kh, kw, stride, pad, 0), stats=stats)
+                 geo=conv_geo(H, W, Cin, Ho, Wo, kh, kw, stride, pad, 0), stats=stats, f16=True)
     return out
 
 
