@@ -84,6 +84,11 @@ def test_linear_slab_split_is_deterministic(ops, M, N, K, relu):
     finally:
         ops._SLAB_SPLIT[0] = was
     assert float((y1 - y).abs().max()) <= 2e-6 * scale
+    # inside an autocast region (one bf16 product per product) the slabs work the same way
+    with ops.amp_scope(True), torch.no_grad():
+        ya = ops.linear_fwd(x, w, b, EPI_RELU if relu else EPI_NONE)
+        assert torch.equal(ya, ops.linear_fwd(x, w, b, EPI_RELU if relu else EPI_NONE))
+    assert float((ya.double() - ref).abs().max()) <= 2e-2 * scale and float((ya - y).abs().max()) > 0
     # a split without k-tiles of its own is refused (its slab would stay unwritten)
     with pytest.raises(Exception):
         ops.gemm_raw(64, 64, 256, x, K, 0, w, K, 0, torch.empty(8, 64, 64, device=dev()), 64, splitk=8, slab_stride=64 * 64)
